@@ -1,0 +1,250 @@
+"""Tensor-level wrappers over the C ABI: torch provides device memory and the stream, nothing else.
+
+Every function enqueues hand-written HIP kernels from libams_hip.so on torch's current stream.
+All tensors must be contiguous fp32 CUDA(HIP) tensors unless stated.  There is no CPU path.
+"""
+import ctypes
+
+import torch
+
+from ._lib import load, check, AmsError
+
+_vp = ctypes.c_void_p
+
+
+def _p(t):
+    return _vp(t.data_ptr()) if t is not None else _vp(0)
+
+
+def _s():
+    return _vp(torch.cuda.current_stream().cuda_stream)
+
+
+def _chk(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise AmsError('ams_hip ops need device tensors (there is no CPU fallback)')
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise AmsError('ams_hip ops need contiguous fp32 tensors, got %s %s' % (t.dtype, tuple(t.stride())))
+
+
+def _ws(nbytes, like):
+    n = max(int(nbytes), 16)
+    return torch.empty((n + 3) // 4, dtype=torch.float32, device=like.device)
+
+
+# ------------------------------------------------------------------ front
+def front_filter(w, bases):
+    _chk(w, bases)
+    W, N = bases.shape
+    f = torch.empty_like(bases)
+    check(load().ams_front_filter_fwd(_p(w), _p(bases), _p(f), W, N, _s()), 'ams_front_filter_fwd')
+    return f
+
+
+def front_filter_bwd(w, bases, df):
+    _chk(w, bases, df)
+    W, N = bases.shape
+    dw, db = torch.empty_like(w), torch.empty_like(bases)
+    check(load().ams_front_filter_bwd(_p(w), _p(bases), _p(df), _p(dw), _p(db), W, N, _s()), 'ams_front_filter_bwd')
+    return dw, db
+
+
+def front_conv(x, f, hop):
+    _chk(x, f)
+    Bt, L = x.shape
+    W, N = f.shape
+    T = -(-L // hop)
+    y = torch.empty((Bt, T, N), dtype=torch.float32, device=x.device)
+    check(load().ams_front_conv_fwd(_p(x), _p(f), _p(y), Bt, L, W, N, hop, _s()), 'ams_front_conv_fwd')
+    return y
+
+
+def front_conv_bwd_filter(x, dy, W, hop):
+    _chk(x, dy)
+    Bt, L = x.shape
+    N = dy.shape[2]
+    lib = load()
+    nb = lib.ams_front_conv_bwd_filter_workspace_bytes(Bt, L, W, N, hop)
+    ws = _ws(nb, x)
+    df = torch.empty((W, N), dtype=torch.float32, device=x.device)
+    check(lib.ams_front_conv_bwd_filter(_p(x), _p(dy), _p(df), Bt, L, W, N, hop, _p(ws), nb, _s()), 'ams_front_conv_bwd_filter')
+    return df
+
+
+# ------------------------------------------------------------------ GEMM
+def gemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False, M=None, N=None, K=None,
+         lda=None, ldb=None, ldc=None, mask=(0, 0)):
+    """out[M,N] (+)= op(A) op(B) (+ bias).  A/B may be 2-D tensors (dims inferred) or raw views with explicit
+    M,N,K and leading dimensions (for column slices of wider buffers)."""
+    lib = load()
+    if M is None:
+        _chk(A, B, bias)
+        if transA:
+            K_, M = A.shape
+        else:
+            M, K_ = A.shape
+        if transB:
+            N, K2 = B.shape
+        else:
+            K2, N = B.shape
+        if K_ != K2:
+            raise AmsError('gemm: inner dimensions differ (%d vs %d)' % (K_, K2))
+        K = K_
+        lda, ldb = A.stride(0), B.stride(0)
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.device)
+        ldc = N
+    elif ldc is None:
+        ldc = out.stride(0) if out.dim() == 2 else N
+    nb = lib.ams_gemm_workspace_bytes(M, N, K)
+    ws = _ws(nb, A) if nb else None
+    check(lib.ams_gemm_f32(int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc, _p(bias), int(accumulate),
+                           mask[0], mask[1], _p(ws), nb, _s()), 'ams_gemm_f32')
+    return out
+
+
+# ------------------------------------------------------------------ masks
+def make_masks(rep_non_mix, B, S, a, b, take_abs, want_argmax=False):
+    """rep_non_mix: [B*S, ...] rows (b,s) row-major.  Returns Y [B, TF, S] (and int32 argmax [B, TF])."""
+    _chk(rep_non_mix)
+    TF = rep_non_mix.numel() // (B * S)
+    Y = torch.empty((B, TF, S), dtype=torch.float32, device=rep_non_mix.device)
+    am = torch.empty((B, TF), dtype=torch.int32, device=rep_non_mix.device) if want_argmax else None
+    check(load().ams_make_masks(_p(rep_non_mix), _p(Y), _p(am), B, S, TF, float(a), float(b), int(take_abs), _s()), 'ams_make_masks')
+    return (Y, am) if want_argmax else Y
+
+
+# ------------------------------------------------------------------ BLSTM
+def blstm_fwd(x, Kf, bf, Kb, bb):
+    """One BLSTM layer (utils/ops.py:358-383).  x [B,T,D]; K* [D+H,4H]; b* [4H].
+    Returns out [B,T,2H] and the tensors the backward needs (G = activated gates, cst = cell states)."""
+    _chk(x, Kf, bf, Kb, bb)
+    lib = load()
+    B, T, D = x.shape
+    H = Kf.shape[1] // 4
+    G = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=x.device)
+    x2 = x.view(B * T, D)
+    # hoisted input projections (one MFMA GEMM per direction, written into the strided gate buffer)
+    gemm(x2, Kf, bias=bf, out=G, M=B * T, N=4 * H, K=D, lda=D, ldb=4 * H, ldc=8 * H)
+    gemm(x2, Kb, bias=bb, out=G.view(-1)[4 * H:], M=B * T, N=4 * H, K=D, lda=D, ldb=4 * H, ldc=8 * H)
+    out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
+    cst = torch.empty((B, T, 2, H), dtype=torch.float32, device=x.device)
+    pack = torch.empty(lib.ams_blstm_pack_floats(H, 0), dtype=torch.float32, device=x.device)
+    check(lib.ams_blstm_recurrent_fwd(_p(G), _p(out), _p(cst), _p(Kf[D:]), _p(Kb[D:]), 4 * H, _p(pack), B, T, H, _s()),
+          'ams_blstm_recurrent_fwd')
+    return out, G, cst
+
+
+def blstm_bwd(x, Kf, Kb, out, G, cst, dout, need_dx=True):
+    """BPTT for one BLSTM layer.  DESTROYS G (it becomes d pre-activation).  Returns dx, dKf, dbf, dKb, dbb."""
+    _chk(x, Kf, Kb, out, G, cst, dout)
+    lib = load()
+    B, T, D = x.shape
+    H = Kf.shape[1] // 4
+    dev = x.device
+    dc = torch.empty((B, 2, H), dtype=torch.float32, device=dev)
+    pack = torch.empty(lib.ams_blstm_pack_floats(H, 1), dtype=torch.float32, device=dev)
+    check(lib.ams_blstm_recurrent_bwd(_p(G), _p(cst), _p(dout), _p(dc), _p(Kf[D:]), _p(Kb[D:]), 4 * H, _p(pack), B, T, H, _s()),
+          'ams_blstm_recurrent_bwd')
+    M = B * T
+    x2 = x.view(M, D)
+    dZf = G.view(-1)                       # direction 0 columns start at 0, ld = 8H
+    dZb = G.view(-1)[4 * H:]
+    dKf = torch.empty_like(Kf)
+    dKb = torch.empty_like(Kb)
+    # dWx = x^T dZ   (reduction over B*T)
+    gemm(x2, dZf, transA=True, out=dKf, M=D, N=4 * H, K=M, lda=D, ldb=8 * H, ldc=4 * H)
+    gemm(x2, dZb, transA=True, out=dKb, M=D, N=4 * H, K=M, lda=D, ldb=8 * H, ldc=4 * H)
+    # dU = h_prev^T dZ : forward dir pairs out[b,t-1] with dZ[b,t]; backward dir pairs out[b,t+1] with dZ[b,t]
+    of = out.view(-1)
+    gemm(of, dZf[8 * H:], transA=True, out=dKf[D:], M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H, ldc=4 * H, mask=(T, T - 1))
+    gemm(of[2 * H + H:], dZb, transA=True, out=dKb[D:], M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H, ldc=4 * H, mask=(T, T - 1))
+    nb = lib.ams_colsum_workspace_bytes(M, 8 * H)
+    ws = _ws(nb, x)
+    db = torch.empty(8 * H, dtype=torch.float32, device=dev)
+    check(lib.ams_colsum(_p(G), _p(db), M, 8 * H, 8 * H, 0, _p(ws), nb, _s()), 'ams_colsum')
+    dx = None
+    if need_dx:
+        dx = torch.empty((B, T, D), dtype=torch.float32, device=dev)
+        gemm(dZf, Kf, transB=True, out=dx, M=M, N=D, K=4 * H, lda=8 * H, ldb=4 * H, ldc=D)
+        gemm(dZb, Kb, transB=True, out=dx, accumulate=True, M=M, N=D, K=4 * H, lda=8 * H, ldb=4 * H, ldc=D)
+    return dx, dKf, db[:4 * H], dKb, db[4 * H:]
+
+
+# ------------------------------------------------------------------ l2norm / dense
+def l2norm_fwd(u, E):
+    _chk(u)
+    rows = u.numel() // E
+    v = torch.empty_like(u)
+    inv = torch.empty(rows, dtype=torch.float32, device=u.device)
+    check(load().ams_l2norm_fwd(_p(u), _p(v), _p(inv), rows, E, _s()), 'ams_l2norm_fwd')
+    return v, inv
+
+
+def l2norm_bwd(v, inv, dv, E):
+    _chk(v, inv, dv)
+    du = torch.empty_like(v)
+    check(load().ams_l2norm_bwd(_p(v), _p(inv), _p(dv), _p(du), inv.numel(), E, _s()), 'ams_l2norm_bwd')
+    return du
+
+
+def colsum(x2):
+    _chk(x2)
+    lib = load()
+    rows, cols = x2.shape
+    nb = lib.ams_colsum_workspace_bytes(rows, cols)
+    ws = _ws(nb, x2)
+    out = torch.empty(cols, dtype=torch.float32, device=x2.device)
+    check(lib.ams_colsum(_p(x2), _p(out), rows, cols, cols, 0, _p(ws), nb, _s()), 'ams_colsum')
+    return out
+
+
+# ------------------------------------------------------------------ DPCL loss
+def dpcl_loss_fwd(V, Y):
+    """V [B,TF,E], Y [B,TF,S] -> out[4] = (cost, term1, term2, term3), workspace for the backward."""
+    _chk(V, Y)
+    lib = load()
+    B, TF, E = V.shape
+    S = Y.shape[2]
+    nb = lib.ams_dpcl_workspace_bytes(B, TF, E, S)
+    ws = _ws(nb, V)
+    out = torch.empty(4, dtype=torch.float32, device=V.device)
+    check(lib.ams_dpcl_loss_fwd(_p(V), _p(Y), _p(out), B, TF, E, S, _p(ws), nb, _s()), 'ams_dpcl_loss_fwd')
+    return out, ws
+
+
+def dpcl_loss_bwd(V, Y, ws, inv=None):
+    _chk(V, Y, inv)
+    B, TF, E = V.shape
+    S = Y.shape[2]
+    d = torch.empty_like(V)
+    check(load().ams_dpcl_loss_bwd(_p(V), _p(Y), _p(inv), _p(d), B, TF, E, S, _p(ws), _s()), 'ams_dpcl_loss_bwd')
+    return d
+
+
+# ------------------------------------------------------------------ optimizers
+def opt_amsgrad(p, g, m, v, vhat, lr_t, beta1, beta2, eps, grad_scale=1.0):
+    _chk(p, g, m, v, vhat)
+    check(load().ams_opt_amsgrad(_p(p), _p(g), _p(m), _p(v), _p(vhat), p.numel(), lr_t, beta1, beta2, eps, grad_scale, _s()),
+          'ams_opt_amsgrad')
+
+
+def opt_rmsprop(p, g, ms, lr, decay=0.9, eps=1e-10, grad_scale=1.0):
+    _chk(p, g, ms)
+    check(load().ams_opt_rmsprop(_p(p), _p(g), _p(ms), p.numel(), lr, decay, eps, grad_scale, _s()), 'ams_opt_rmsprop')
+
+
+def opt_momentum(p, g, acc, lr, momentum=0.9, grad_scale=1.0):
+    _chk(p, g, acc)
+    check(load().ams_opt_momentum(_p(p), _p(g), _p(acc), p.numel(), lr, momentum, grad_scale, _s()), 'ams_opt_momentum')
+
+
+def sumsq(x):
+    _chk(x)
+    ws = _ws(4096, x)
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    check(load().ams_sumsq(_p(x), _p(out), x.numel(), _p(ws), 4096, _s()), 'ams_sumsq')
+    return out

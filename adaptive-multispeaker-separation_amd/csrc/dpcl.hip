@@ -1,0 +1,277 @@
+// Deep-clustering affinity loss (reference models/dpcl.py:41-87), forward and backward.
+//
+//   cost = mean_b( ||V^T D V||_F - 2 ||V^T D Y||_F + ||Y^T D Y||_F ),  D_i = 1/sqrt((Y (Y^T 1))_i)
+//
+// The reference materialises DV, DY and runs three batched matmuls with K = T*F.  Here V ([B,TF,E], 210 MB
+// at the benchmark shape) is streamed ONCE: each point is the augmented vector z_i = [v_i | y_i] (E+S <= 64
+// entries) and a single Gram  Z^T D Z  accumulated with v_mfma_f32_16x16x4_f32 contains all three blocks
+// (V^T D V, V^T D Y, Y^T D Y).  HBM-bound: algorithmic bytes = TF*(E+S)*4 per utterance.
+//
+// Backward streams V again: dV_i = D_i (Gn v_i - An y_i) with Gn = 2G/(|G| B), An = 2A/(|A| B), fused with the
+// l2-normalise backward so dU is written directly (one read of V, Y; one write of dU).  Thread-per-point
+// VALU matvec with the small matrices fetched through the scalar cache; points are transposed through LDS so
+// global traffic stays float4-coalesced.
+#include "common.h"
+
+namespace {
+
+constexpr int CHUNK = 2048;            // points per workgroup in the Gram pass
+
+__global__ void dpcl_count_kernel(const float* __restrict__ Y, float* __restrict__ cnt, long TF, int S) {
+    __shared__ float sm[4][8];
+    const int b = blockIdx.x;
+    float acc[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc[s] = 0.f;
+    const float* y = Y + (long)b * TF * S;
+    for (long i = threadIdx.x; i < TF; i += blockDim.x)
+        for (int s = 0; s < S; ++s) acc[s] += y[i * S + s];
+    for (int s = 0; s < S; ++s) {
+        const float v = wave_sum(acc[s]);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][s] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < S) cnt[(long)b * S + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void dpcl_gram_kernel(const float* __restrict__ V, const float* __restrict__ Y,
+                                                        const float* __restrict__ cnt, float* __restrict__ part, long TF,
+                                                        int E, int S, int nchunk) {
+    constexpr int Z = NT * 16;
+    __shared__ float red[Z * Z];
+    const int b = blockIdx.y, c = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e_lo = lane & 15, slot = lane >> 4;
+    for (int i = tid; i < Z * Z; i += 256) red[i] = 0.f;
+
+    float cn[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) cn[s] = (s < S) ? cnt[(long)b * S + s] : 0.f;
+
+    f32x4 acc[NT][NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const long p_begin = (long)c * CHUNK, p_end = min(TF, p_begin + CHUNK);
+    const float* Vb = V + (long)b * TF * E;
+    const float* Yb = Y + (long)b * TF * S;
+    for (long p0 = p_begin + wave * 4; p0 < p_end; p0 += 16) {
+        const long p = p0 + slot;
+        const bool ok = p < p_end;
+        float d = 0.f;
+        if (ok) {
+            float diag = 0.f;
+            for (int s = 0; s < S; ++s) diag += Yb[p * S + s] * cn[s];
+            d = 1.0f / sqrtf(diag);
+        }
+        float a[NT], bb[NT];
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti) {
+            const int e = ti * 16 + e_lo;
+            float z = 0.f;
+            if (ok) {
+                if (e < E) z = Vb[p * E + e];
+                else if (e < E + S) z = Yb[p * S + (e - E)];
+            }
+            a[ti] = z;
+            bb[ti] = (z != 0.f) ? z * d : 0.f;       // 0 * inf guard: rows of Y that are all zero give D = inf
+        }
+#pragma unroll
+        for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+            for (int tj = 0; tj < NT; ++tj)
+                acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], bb[tj], acc[ti][tj], 0, 0, 0);
+    }
+    __syncthreads();
+    // C/D layout: row = (lane>>4)*4 + r, col = lane&15.  4 waves add into LDS one after another (fixed order).
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < NT; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        red[(ti * 16 + slot * 4 + r) * Z + tj * 16 + e_lo] += acc[ti][tj][r];
+        }
+        __syncthreads();
+    }
+    float* out = part + ((long)b * nchunk + c) * (Z * Z);
+    for (int i = tid; i < Z * Z; i += 256) out[i] = red[i];
+}
+
+// Per utterance: reduce chunk partials (fixed order), Frobenius norms, cost_b, normalised matrices for bwd.
+__global__ void dpcl_finish_kernel(const float* __restrict__ part, float* __restrict__ per_utt, float* __restrict__ mats,
+                                   int E, int S, int Z, int nchunk, int B) {
+    extern __shared__ float gram[];
+    __shared__ float sm[3][4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < Z * Z; i += blockDim.x) {
+        float s = 0.f;
+        for (int c = 0; c < nchunk; ++c) s += part[((long)b * nchunk + c) * (Z * Z) + i];
+        gram[i] = s;
+    }
+    __syncthreads();
+    float sg = 0.f, sa = 0.f, sc = 0.f;
+    for (int i = tid; i < Z * Z; i += blockDim.x) {
+        const int r = i / Z, c = i - r * Z;
+        const float v = gram[i];
+        if (r < E && c < E) sg += v * v;
+        else if (r < E && c >= E && c < E + S) sa += v * v;
+        else if (r >= E && r < E + S && c >= E && c < E + S) sc += v * v;
+    }
+    sg = wave_sum(sg); sa = wave_sum(sa); sc = wave_sum(sc);
+    if ((tid & 63) == 0) { sm[0][tid >> 6] = sg; sm[1][tid >> 6] = sa; sm[2][tid >> 6] = sc; }
+    __syncthreads();
+    const float nG = sqrtf(sm[0][0] + sm[0][1] + sm[0][2] + sm[0][3]);
+    const float nA = sqrtf(sm[1][0] + sm[1][1] + sm[1][2] + sm[1][3]);
+    const float nC = sqrtf(sm[2][0] + sm[2][1] + sm[2][2] + sm[2][3]);
+    if (tid == 0) {
+        per_utt[b * 4 + 0] = nG - 2.0f * nA + nC;
+        per_utt[b * 4 + 1] = nG;
+        per_utt[b * 4 + 2] = -2.0f * nA;
+        per_utt[b * 4 + 3] = nC;
+    }
+    // mats[b]: Gn [E,E] then An [E,S]
+    float* m = mats + (long)b * (E * E + E * S);
+    const float kg = 2.0f / (nG * B), ka = 2.0f / (nA * B);
+    for (int i = tid; i < E * E; i += blockDim.x) m[i] = gram[(i / E) * Z + (i % E)] * kg;
+    for (int i = tid; i < E * S; i += blockDim.x) m[E * E + i] = gram[(i / S) * Z + E + (i % S)] * ka;
+}
+
+__global__ void dpcl_mean_kernel(const float* __restrict__ per_utt, float* __restrict__ out, int B) {
+    // out[0] = cost, out[1..3] = the three summary terms (dpcl.py:82-85)
+    const int k = threadIdx.x;
+    if (k < 4) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += per_utt[b * 4 + k];
+        out[k] = s / B;
+    }
+}
+
+// Backward, fused with l2norm backward.  One thread per point.
+template <int E_>
+__global__ __launch_bounds__(256) void dpcl_bwd_kernel(const float* __restrict__ V, const float* __restrict__ Y,
+                                                       const float* __restrict__ cnt, const float* __restrict__ mats,
+                                                       const float* __restrict__ inv, float* __restrict__ dU, long TF, int S,
+                                                       int fuse_l2norm) {
+    constexpr int LDS_STRIDE = E_ + 1;
+    __shared__ float tile[256 * LDS_STRIDE];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const long p0 = (long)blockIdx.x * 256;
+    const int npts = (int)min((long)256, TF - p0);
+    const float* Vb = V + ((long)b * TF + p0) * E_;
+    // coalesced load of npts*E floats -> LDS [point][E+1]
+    for (int i = tid; i < npts * E_; i += 256) tile[(i / E_) * LDS_STRIDE + (i % E_)] = Vb[i];
+    __syncthreads();
+    const float* G = mats + (long)b * (E_ * E_ + E_ * S);
+    const float* A = G + E_ * E_;
+    float v[E_], dv[E_];
+    if (tid < npts) {
+#pragma unroll
+        for (int e = 0; e < E_; ++e) { v[e] = tile[tid * LDS_STRIDE + e]; dv[e] = 0.f; }
+        const long p = p0 + tid;
+        const float* y = Y + ((long)b * TF + p) * S;
+        float diag = 0.f;
+        for (int s = 0; s < S; ++s) diag += y[s] * cnt[(long)b * S + s];
+        const float d = 1.0f / sqrtf(diag);
+        // dv = Gn^T-free: G is symmetric; dv[f] = sum_e v[e] G[e][f]
+        for (int e = 0; e < E_; ++e) {
+            const float ve = v[e];
+#pragma unroll
+            for (int f = 0; f < E_; ++f) dv[f] += ve * G[e * E_ + f];
+        }
+        for (int s = 0; s < S; ++s) {
+            const float ys = y[s];
+            if (ys != 0.f) {
+#pragma unroll
+                for (int f = 0; f < E_; ++f) dv[f] -= ys * A[f * S + s];
+            }
+        }
+        const bool dz = !(diag > 0.f);           // all-zero Y row: D = inf in the reference; contributes 0 * inf
+#pragma unroll
+        for (int f = 0; f < E_; ++f) dv[f] = dz ? 0.f : dv[f] * d;
+        if (fuse_l2norm) {
+            float dot = 0.f;
+#pragma unroll
+            for (int f = 0; f < E_; ++f) dot += v[f] * dv[f];
+            const float iv = inv[(long)b * TF + p];
+            const bool active = iv < 0.999999e6f;
+#pragma unroll
+            for (int f = 0; f < E_; ++f) dv[f] = active ? (dv[f] - v[f] * dot) * iv : dv[f] * iv;
+        }
+    }
+    __syncthreads();
+    if (tid < npts) {
+#pragma unroll
+        for (int f = 0; f < E_; ++f) tile[tid * LDS_STRIDE + f] = dv[f];
+    }
+    __syncthreads();
+    float* Ub = dU + ((long)b * TF + p0) * E_;
+    for (int i = tid; i < npts * E_; i += 256) Ub[i] = tile[(i / E_) * LDS_STRIDE + (i % E_)];
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ams_dpcl_workspace_bytes(int B, long TF, int E, int S) {
+    const int NT = ceil_div(E + S, 16), Z = NT * 16;
+    const int nchunk = ceil_div(TF, CHUNK);
+    // cnt [B,S] | per_utt [B,4] | mats [B, E*E+E*S] | partials [B, nchunk, Z*Z]
+    return sizeof(float) * ((size_t)B * S + (size_t)B * 4 + (size_t)B * (E * E + E * S) + (size_t)B * nchunk * Z * Z);
+}
+
+// out[0] = cost, out[1..3] = mean of the three terms.  ws keeps cnt/mats for ams_dpcl_loss_bwd.
+ams_status ams_dpcl_loss_fwd(const float* V, const float* Y, float* out, int B, long TF, int E, int S, void* ws, size_t ws_bytes,
+                             void* stream) {
+    AMS_REQUIRE(V && Y && out && ws && B > 0 && TF > 0 && E > 0 && S > 0 && S <= 8 && E + S <= 64);
+    if (ws_bytes < ams_dpcl_workspace_bytes(B, TF, E, S)) return AMS_E_WORKSPACE_TOO_SMALL;
+    hipStream_t st = (hipStream_t)stream;
+    const int NT = ceil_div(E + S, 16), Z = NT * 16, nchunk = ceil_div(TF, CHUNK);
+    float* cnt = (float*)ws;
+    float* per_utt = cnt + (size_t)B * S;
+    float* mats = per_utt + (size_t)B * 4;
+    float* part = mats + (size_t)B * (E * E + E * S);
+    hipLaunchKernelGGL(dpcl_count_kernel, dim3(B), dim3(256), 0, st, Y, cnt, TF, S);
+    dim3 grid(nchunk, B);
+    switch (NT) {
+        case 1: hipLaunchKernelGGL((dpcl_gram_kernel<1>), grid, dim3(256), 0, st, V, Y, cnt, part, TF, E, S, nchunk); break;
+        case 2: hipLaunchKernelGGL((dpcl_gram_kernel<2>), grid, dim3(256), 0, st, V, Y, cnt, part, TF, E, S, nchunk); break;
+        case 3: hipLaunchKernelGGL((dpcl_gram_kernel<3>), grid, dim3(256), 0, st, V, Y, cnt, part, TF, E, S, nchunk); break;
+        default: hipLaunchKernelGGL((dpcl_gram_kernel<4>), grid, dim3(256), 0, st, V, Y, cnt, part, TF, E, S, nchunk); break;
+    }
+    hipLaunchKernelGGL(dpcl_finish_kernel, dim3(B), dim3(256), Z * Z * sizeof(float), st, part, per_utt, mats, E, S, Z, nchunk, B);
+    hipLaunchKernelGGL(dpcl_mean_kernel, dim3(1), dim3(64), 0, st, per_utt, out, B);
+    return ams_check_launch();
+}
+
+// dU (or dV when inv == NULL) from the state a preceding ams_dpcl_loss_fwd left in ws.
+ams_status ams_dpcl_loss_bwd(const float* V, const float* Y, const float* inv, float* dU, int B, long TF, int E, int S,
+                             const void* ws, void* stream) {
+    AMS_REQUIRE(V && Y && dU && ws && B > 0 && TF > 0 && S > 0 && S <= 8);
+    hipStream_t st = (hipStream_t)stream;
+    const float* cnt = (const float*)ws;
+    const float* mats = cnt + (size_t)B * S + (size_t)B * 4;
+    dim3 grid(ceil_div(TF, 256), B);
+    const int fuse = inv ? 1 : 0;
+#define AMS_DPCL_BWD(EE) \
+    hipLaunchKernelGGL((dpcl_bwd_kernel<EE>), grid, dim3(256), 0, st, V, Y, cnt, mats, inv, dU, TF, S, fuse)
+    switch (E) {
+        case 40: AMS_DPCL_BWD(40); break;
+        case 32: AMS_DPCL_BWD(32); break;
+        case 20: AMS_DPCL_BWD(20); break;
+        case 16: AMS_DPCL_BWD(16); break;
+        case 8: AMS_DPCL_BWD(8); break;
+        case 4: AMS_DPCL_BWD(4); break;
+        case 3: AMS_DPCL_BWD(3); break;
+        default: return AMS_E_INVALID_ARG;
+    }
+#undef AMS_DPCL_BWD
+    return ams_check_launch();
+}
+
+}  // extern "C"

@@ -1,0 +1,260 @@
+// HBM-bound streaming kernels: filter construction, mask creation, l2-normalise, column sums,
+// optimizers, global norm.  All are single-pass, float4 where the layout allows, grid-stride with
+// <= 2048 workgroups (8 per CU) as the CDNA4 guide recommends for memory-bound work.
+#include "common.h"
+
+thread_local int g_ams_last_hip_error = 0;
+
+namespace {
+
+inline int stream_blocks(long n, int per_block = 256) {
+    long b = (n + per_block - 1) / per_block;
+    if (b > 2048) b = 2048;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+// f[k,n] = |w[k]| * bases[k,n]   (reference models/adapt.py:106, :234)
+__global__ void front_filter_fwd_kernel(const float* __restrict__ w, const float* __restrict__ bases, float* __restrict__ f,
+                                        int W, int N) {
+    const long total = (long)W * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x)
+        f[i] = fabsf(w[i / N]) * bases[i];
+}
+
+// dbases = |w| * df ; dw[k] = sign(w[k]) * sum_n bases[k,n]*df[k,n]   (one wave per tap k)
+__global__ void front_filter_bwd_kernel(const float* __restrict__ w, const float* __restrict__ bases,
+                                        const float* __restrict__ df, float* __restrict__ dw, float* __restrict__ dbases,
+                                        int W, int N) {
+    const int lane = threadIdx.x & 63;
+    const int k = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (k >= W) return;
+    const float wk = w[k], aw = fabsf(wk);
+    float s = 0.f;
+    for (int n = lane; n < N; n += 64) {
+        const float d = df[(long)k * N + n];
+        s += bases[(long)k * N + n] * d;
+        dbases[(long)k * N + n] = aw * d;
+    }
+    s = wave_sum(s);
+    if (lane == 0) dw[k] = (wk > 0.f ? 1.f : (wk < 0.f ? -1.f : 0.f)) * s;
+}
+
+// Plugged-separator mask creation (reference models/network.py:369-378; STFT variant :499-502).
+// rep_nm rows are (b,s) row-major, each [TF]; Y[b,i,s] = a if s == argmax_s' |rep[b,s',i]| else b_.
+__global__ void make_masks_kernel(const float* __restrict__ rep_nm, float* __restrict__ Y, int32_t* __restrict__ am,
+                                  int B, int S, long TF, float a, float b_, int take_abs) {
+    const long total = (long)B * TF;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long b = i / TF, p = i - b * TF;
+        float best = 0.f;
+        int bi = 0;
+        for (int s = 0; s < S; ++s) {
+            float v = rep_nm[((long)b * S + s) * TF + p];
+            if (take_abs) v = fabsf(v);
+            if (s == 0 || v > best) { best = v; bi = s; }       // first index wins ties (tf.argmax)
+        }
+        for (int s = 0; s < S; ++s) Y[i * S + s] = (s == bi) ? a : b_;
+        if (am) am[i] = bi;
+    }
+}
+
+// tf.nn.l2_normalize over groups of E contiguous floats: v = u * rsqrt(max(sum u^2, 1e-12)).
+// Quarter-wave (16 lanes) per group keeps 64 B..256 B contiguous per request for E = 40.
+__global__ void l2norm_fwd_kernel(const float* __restrict__ u, float* __restrict__ v, float* __restrict__ inv, long rows, int E) {
+    const int sub = threadIdx.x & 15;
+    const long gid0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const long gstride = ((long)gridDim.x * blockDim.x) >> 4;
+    for (long r = gid0; r < rows; r += gstride) {
+        const float* p = u + r * E;
+        float ss = 0.f;
+        for (int e = sub; e < E; e += 16) { const float x = p[e]; ss += x * x; }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 16);
+        const float iv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+        for (int e = sub; e < E; e += 16) v[r * E + e] = p[e] * iv;
+        if (inv && sub == 0) inv[r] = iv;
+    }
+}
+
+// du = (dv - v <v,dv>) * inv   (clamp active -> du = dv * inv)
+__global__ void l2norm_bwd_kernel(const float* __restrict__ v, const float* __restrict__ inv, const float* __restrict__ dv,
+                                  float* __restrict__ du, long rows, int E) {
+    const int sub = threadIdx.x & 15;
+    const long gid0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const long gstride = ((long)gridDim.x * blockDim.x) >> 4;
+    for (long r = gid0; r < rows; r += gstride) {
+        float dot = 0.f;
+        for (int e = sub; e < E; e += 16) dot += v[r * E + e] * dv[r * E + e];
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 16);
+        const float iv = inv[r];
+        const bool active = iv < 0.999999e6f;
+        for (int e = sub; e < E; e += 16) {
+            const float d = dv[r * E + e];
+            du[r * E + e] = active ? (d - v[r * E + e] * dot) * iv : d * iv;
+        }
+    }
+}
+
+// Column sums of a [rows, cols] matrix (bias gradients).  Two-stage, deterministic.
+__global__ void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ part, long rows, int cols, long ld,
+                                      int rows_per_block) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min(rows, r0 + rows_per_block);
+    float s = 0.f;
+    for (long r = r0; r < r1; ++r) s += x[r * ld + c];
+    part[(long)blockIdx.y * cols + c] = s;
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int cols, int nparts, int accumulate) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int p = 0; p < nparts; ++p) s += part[(long)p * cols + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
+// ---- optimizers (reference utils/ops.py:686-703; TF RMSProp/Momentum) ----
+__global__ void amsgrad_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
+                               float* __restrict__ vh, long n, float lr_t, float b1, float b2, float eps, float gscale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float mi = b1 * m[i] + (1.0f - b1) * gi;
+        const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
+        const float vhi = fmaxf(vi, vh[i]);
+        m[i] = mi; v[i] = vi; vh[i] = vhi;
+        p[i] -= lr_t * mi / (sqrtf(vhi) + eps);
+    }
+}
+__global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ ms, long n, float lr,
+                               float decay, float eps, float gscale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gi = g[i] * gscale;
+        const float s = decay * ms[i] + (1.0f - decay) * gi * gi;
+        ms[i] = s;
+        p[i] -= lr * gi / sqrtf(s + eps);
+    }
+}
+__global__ void momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ acc, long n, float lr,
+                                float mom, float gscale) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float a = mom * acc[i] + g[i] * gscale;
+        acc[i] = a;
+        p[i] -= lr * a;
+    }
+}
+
+// sum of squares -> per-block partials -> single value (deterministic two-stage)
+__global__ void sumsq_partial_kernel(const float* __restrict__ x, float* __restrict__ part, long n) {
+    __shared__ float sm[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += x[i] * x[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+__global__ void sum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int n) {
+    __shared__ float sm[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) s += part[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+}  // namespace
+
+extern "C" {
+
+int ams_last_error(void) { return g_ams_last_hip_error; }
+int ams_abi_version(void) { return AMS_ABI_VERSION; }
+
+ams_status ams_front_filter_fwd(const float* w, const float* bases, float* f, int W, int N, void* stream) {
+    AMS_REQUIRE(w && bases && f && W > 0 && N > 0);
+    hipLaunchKernelGGL(front_filter_fwd_kernel, dim3(stream_blocks((long)W * N)), dim3(256), 0, (hipStream_t)stream, w, bases, f, W, N);
+    return ams_check_launch();
+}
+
+ams_status ams_front_filter_bwd(const float* w, const float* bases, const float* df, float* dw, float* dbases, int W, int N,
+                                void* stream) {
+    AMS_REQUIRE(w && bases && df && dw && dbases && W > 0 && N > 0);
+    hipLaunchKernelGGL(front_filter_bwd_kernel, dim3(ceil_div(W, 4)), dim3(256), 0, (hipStream_t)stream, w, bases, df, dw, dbases, W, N);
+    return ams_check_launch();
+}
+
+ams_status ams_make_masks(const float* rep_non_mix, float* Y, int32_t* argmax, int B, int S, long TF, float a, float b,
+                          int take_abs, void* stream) {
+    AMS_REQUIRE(rep_non_mix && Y && B > 0 && S > 0 && TF > 0);
+    hipLaunchKernelGGL(make_masks_kernel, dim3(stream_blocks((long)B * TF)), dim3(256), 0, (hipStream_t)stream, rep_non_mix, Y,
+                       argmax, B, S, TF, a, b, take_abs);
+    return ams_check_launch();
+}
+
+ams_status ams_l2norm_fwd(const float* u, float* v, float* inv, long rows, int E, void* stream) {
+    AMS_REQUIRE(u && v && rows > 0 && E > 0);
+    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(stream_blocks(rows * 16)), dim3(256), 0, (hipStream_t)stream, u, v, inv, rows, E);
+    return ams_check_launch();
+}
+
+ams_status ams_l2norm_bwd(const float* v, const float* inv, const float* dv, float* du, long rows, int E, void* stream) {
+    AMS_REQUIRE(v && inv && dv && du && rows > 0 && E > 0);
+    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(stream_blocks(rows * 16)), dim3(256), 0, (hipStream_t)stream, v, inv, dv, du, rows, E);
+    return ams_check_launch();
+}
+
+size_t ams_colsum_workspace_bytes(long rows, int cols) {
+    const int nparts = ceil_div(rows, 256);
+    return (size_t)nparts * cols * sizeof(float);
+}
+
+ams_status ams_colsum(const float* x, float* out, long rows, int cols, long ld, int accumulate, void* ws, size_t ws_bytes,
+                      void* stream) {
+    AMS_REQUIRE(x && out && rows > 0 && cols > 0 && ws);
+    const int rpb = 256;
+    const int nparts = ceil_div(rows, rpb);
+    if ((size_t)nparts * cols * sizeof(float) > ws_bytes) return AMS_E_WORKSPACE_TOO_SMALL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(cols, 256), nparts), dim3(256), 0, st, x, (float*)ws, rows, cols, ld, rpb);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, st, (const float*)ws, out, cols, nparts, accumulate);
+    return ams_check_launch();
+}
+
+ams_status ams_opt_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, long n, float lr_t, float beta1,
+                           float beta2, float eps, float grad_scale, void* stream) {
+    AMS_REQUIRE(p && g && m && v && vhat && n > 0);
+    hipLaunchKernelGGL(amsgrad_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vhat, n, lr_t, beta1,
+                       beta2, eps, grad_scale);
+    return ams_check_launch();
+}
+
+ams_status ams_opt_rmsprop(float* p, const float* g, float* ms, long n, float lr, float decay, float eps, float grad_scale,
+                           void* stream) {
+    AMS_REQUIRE(p && g && ms && n > 0);
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, ms, n, lr, decay, eps, grad_scale);
+    return ams_check_launch();
+}
+
+ams_status ams_opt_momentum(float* p, const float* g, float* accum, long n, float lr, float momentum, float grad_scale,
+                            void* stream) {
+    AMS_REQUIRE(p && g && accum && n > 0);
+    hipLaunchKernelGGL(momentum_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, accum, n, lr, momentum, grad_scale);
+    return ams_check_launch();
+}
+
+// out[0] = sum x^2  (ws: >= 1024 floats)
+ams_status ams_sumsq(const float* x, float* out, long n, void* ws, size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(x && out && n > 0 && ws);
+    int blocks = stream_blocks(n);
+    if (blocks > 1024) blocks = 1024;
+    if ((size_t)blocks * sizeof(float) > ws_bytes) return AMS_E_WORKSPACE_TOO_SMALL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(sumsq_partial_kernel, dim3(blocks), dim3(256), 0, st, x, (float*)ws, n);
+    hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, out, blocks);
+    return ams_check_launch();
+}
+
+}  // extern "C"

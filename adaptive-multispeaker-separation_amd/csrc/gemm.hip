@@ -1,0 +1,369 @@
+// fp32 MFMA GEMM family for gfx950 (v_mfma_f32_32x32x2_f32: exact f32, 157 TF peak).
+//
+// One templated kernel, C[M,N] (+)= op(A)[M,K] . op(B)[K,N] (+ bias[N]), with A-operand loaders:
+//   A_ROW    A[m,k] = A[m*lda + k]                      (activations x weights: in-proj, dense fwd)
+//   A_COL    A[m,k] = A[k*lda + m]                      (X^T . dY weight gradients), optional row mask
+//   A_FRAMES A[m,k] = x[b*L + t*hop + k - pl], m = b*T+t (adaptive analysis filterbank = strided conv;
+//                                                         reference models/adapt.py:122)
+//   A_FRAMES_T  A[m=k_w, k=(b,t)] = frame element        (filter gradient of the same conv)
+// and B-operand loaders B_ROW (B[k*ldb+n]) / B_COL (B[n*ldb+k]).
+//
+// Tiling: 128x128x16 block tile, 256 threads = 4 waves in 2x2, each wave 64x64 = 2x2 MFMA 32x32 tiles
+// (64 accumulator VGPRs).  LDS holds k-major operand panels As[16][128+pad], Bs[16][128+pad] so the
+// MFMA operand fetch (lane l: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]) is a conflict-free ds_read_b32.
+// Register-staged double buffering: tile t+1 is fetched into VGPRs before the MFMAs of tile t and
+// written to the other LDS buffer after them (one barrier per k-tile).
+// Split-K (gridDim.z) writes fp32 partial slabs to a caller workspace; a second kernel reduces them in
+// fixed order (deterministic) and applies bias / accumulate.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16;
+constexpr int PAD_T = 2;   // k-contiguous source, transposed scalar LDS writes: stride 130 -> conflict-free
+constexpr int PAD_V = 4;   // m/n-contiguous source, float4 LDS writes: stride 132 keeps 16B alignment
+
+enum { A_ROW = 0, A_COL = 1, A_FRAMES = 2, A_FRAMES_T = 3 };
+enum { B_ROW = 0, B_COL = 1 };
+
+struct GemmArgs {
+    const float* A; const float* B; float* C; const float* bias;
+    int M, N, K;
+    long lda, ldb, ldc;
+    int accumulate;            // C += result
+    // frames loader
+    int fr_L, fr_T, fr_hop, fr_pl, fr_W;
+    // A_COL row mask: element (m, k) is zero when (k % mask_period) == mask_skip  (period 0 = off)
+    int mask_period, mask_skip;
+    // split-K
+    int splits, k_per_split;
+    float* partial;            // [splits, M, N] when splits > 1
+    int a_vec, b_vec;          // 16-byte vector loads legal
+};
+
+template <int AMODE>
+__device__ __forceinline__ float loadA1(const GemmArgs& g, int m, int k) {
+    if (m >= g.M || k >= g.K) return 0.f;
+    if (AMODE == A_ROW) return g.A[(long)m * g.lda + k];
+    if (AMODE == A_COL) {
+        if (g.mask_period && (k % g.mask_period) == g.mask_skip) return 0.f;
+        return g.A[(long)k * g.lda + m];
+    }
+    if (AMODE == A_FRAMES) {
+        int b = m / g.fr_T, t = m - b * g.fr_T;
+        int p = t * g.fr_hop + k - g.fr_pl;
+        return (p >= 0 && p < g.fr_L) ? g.A[(long)b * g.fr_L + p] : 0.f;
+    }
+    // A_FRAMES_T: m = filter tap, k = frame index (b,t)
+    int b = k / g.fr_T, t = k - b * g.fr_T;
+    int p = t * g.fr_hop + m - g.fr_pl;
+    return (p >= 0 && p < g.fr_L) ? g.A[(long)b * g.fr_L + p] : 0.f;
+}
+
+template <int BMODE>
+__device__ __forceinline__ float loadB1(const GemmArgs& g, int k, int n) {
+    if (n >= g.N || k >= g.K) return 0.f;
+    if (BMODE == B_ROW) return g.B[(long)k * g.ldb + n];
+    return g.B[(long)n * g.ldb + k];
+}
+
+// Is operand A contiguous along k (-> transposed LDS writes) ?
+template <int AMODE> struct AKContig { static constexpr bool v = (AMODE == A_ROW || AMODE == A_FRAMES); };
+
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+    constexpr bool AK = AKContig<AMODE>::v;
+    constexpr bool BKc = (BMODE == B_COL);
+    constexpr int LDA_S = BM + (AK ? PAD_T : PAD_V);
+    constexpr int LDB_S = BN + (BKc ? PAD_T : PAD_V);
+    __shared__ __attribute__((aligned(16))) float smem[2 * BK * LDA_S + 2 * BK * LDB_S];
+    float* As = smem;
+    float* Bs = smem + 2 * BK * LDA_S;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware tile order: consecutive block ids land on different XCDs (b % 8); give each XCD a
+    // contiguous run of tiles that share A row-panels so its private L2 sees the reuse.
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int ntiles = tiles_m * tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+
+    const int split = blockIdx.y;
+    const int k_begin = split * g.k_per_split;
+    const int k_end = min(g.K, k_begin + g.k_per_split);
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[2], rb[2];
+
+    auto fetch = [&](int kt) {
+        const int k0 = k_begin + kt * BK;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = tid + h * 256;
+            if (AK) {
+                const int m = m0 + (q >> 2), k = k0 + (q & 3) * 4;
+                bool fast = g.a_vec && m < g.M && k + 3 < k_end;
+                if (AMODE == A_FRAMES && fast) {
+                    int b = m / g.fr_T, t = m - b * g.fr_T;
+                    int p = t * g.fr_hop + k - g.fr_pl;
+                    if (p >= 0 && p + 3 < g.fr_L) ra[h] = *reinterpret_cast<const float4*>(g.A + (long)b * g.fr_L + p);
+                    else fast = false;
+                } else if (fast) {
+                    ra[h] = *reinterpret_cast<const float4*>(g.A + (long)m * g.lda + k);
+                }
+                if (!fast) {
+                    ra[h].x = (k + 0 < k_end) ? loadA1<AMODE>(g, m, k + 0) : 0.f;
+                    ra[h].y = (k + 1 < k_end) ? loadA1<AMODE>(g, m, k + 1) : 0.f;
+                    ra[h].z = (k + 2 < k_end) ? loadA1<AMODE>(g, m, k + 2) : 0.f;
+                    ra[h].w = (k + 3 < k_end) ? loadA1<AMODE>(g, m, k + 3) : 0.f;
+                }
+            } else {
+                const int k = k0 + (q >> 5), m = m0 + (q & 31) * 4;
+                bool fast = g.a_vec && k < k_end && m + 3 < g.M && AMODE == A_COL &&
+                            !(g.mask_period && (k % g.mask_period) == g.mask_skip);
+                if (fast) ra[h] = *reinterpret_cast<const float4*>(g.A + (long)k * g.lda + m);
+                else {
+                    const bool kv = k < k_end;
+                    ra[h].x = kv ? loadA1<AMODE>(g, m + 0, k) : 0.f;
+                    ra[h].y = kv ? loadA1<AMODE>(g, m + 1, k) : 0.f;
+                    ra[h].z = kv ? loadA1<AMODE>(g, m + 2, k) : 0.f;
+                    ra[h].w = kv ? loadA1<AMODE>(g, m + 3, k) : 0.f;
+                }
+            }
+            if (BKc) {
+                const int n = n0 + (q >> 2), k = k0 + (q & 3) * 4;
+                if (g.b_vec && n < g.N && k + 3 < k_end) rb[h] = *reinterpret_cast<const float4*>(g.B + (long)n * g.ldb + k);
+                else {
+                    rb[h].x = (k + 0 < k_end) ? loadB1<BMODE>(g, k + 0, n) : 0.f;
+                    rb[h].y = (k + 1 < k_end) ? loadB1<BMODE>(g, k + 1, n) : 0.f;
+                    rb[h].z = (k + 2 < k_end) ? loadB1<BMODE>(g, k + 2, n) : 0.f;
+                    rb[h].w = (k + 3 < k_end) ? loadB1<BMODE>(g, k + 3, n) : 0.f;
+                }
+            } else {
+                const int k = k0 + (q >> 5), n = n0 + (q & 31) * 4;
+                if (g.b_vec && k < k_end && n + 3 < g.N) rb[h] = *reinterpret_cast<const float4*>(g.B + (long)k * g.ldb + n);
+                else {
+                    const bool kv = k < k_end;
+                    rb[h].x = kv ? loadB1<BMODE>(g, k, n + 0) : 0.f;
+                    rb[h].y = kv ? loadB1<BMODE>(g, k, n + 1) : 0.f;
+                    rb[h].z = kv ? loadB1<BMODE>(g, k, n + 2) : 0.f;
+                    rb[h].w = kv ? loadB1<BMODE>(g, k, n + 3) : 0.f;
+                }
+            }
+        }
+    };
+
+    auto stash = [&](int buf) {
+        float* as = As + buf * BK * LDA_S;
+        float* bs = Bs + buf * BK * LDB_S;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int q = tid + h * 256;
+            if (AK) {
+                const int mi = q >> 2, kq = (q & 3) * 4;
+                as[(kq + 0) * LDA_S + mi] = ra[h].x;
+                as[(kq + 1) * LDA_S + mi] = ra[h].y;
+                as[(kq + 2) * LDA_S + mi] = ra[h].z;
+                as[(kq + 3) * LDA_S + mi] = ra[h].w;
+            } else {
+                const int ki = q >> 5, mi = (q & 31) * 4;
+                *reinterpret_cast<float4*>(as + ki * LDA_S + mi) = ra[h];
+            }
+            if (BKc) {
+                const int ni = q >> 2, kq = (q & 3) * 4;
+                bs[(kq + 0) * LDB_S + ni] = rb[h].x;
+                bs[(kq + 1) * LDB_S + ni] = rb[h].y;
+                bs[(kq + 2) * LDB_S + ni] = rb[h].z;
+                bs[(kq + 3) * LDB_S + ni] = rb[h].w;
+            } else {
+                const int ki = q >> 5, ni = (q & 31) * 4;
+                *reinterpret_cast<float4*>(bs + ki * LDB_S + ni) = rb[h];
+            }
+        }
+    };
+
+    if (nk > 0) {
+        fetch(0);
+        stash(0);
+    }
+    __syncthreads();
+
+    const int l31 = lane & 31, lk = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) fetch(kt + 1);
+        const float* as = As + buf * BK * LDA_S + wm * 64 + l31;
+        const float* bs = Bs + buf * BK * LDB_S + wn * 64 + l31;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a0 = as[(kk + lk) * LDA_S];
+            const float a1 = as[(kk + lk) * LDA_S + 32];
+            const float b0 = bs[(kk + lk) * LDB_S];
+            const float b1 = bs[(kk + lk) * LDB_S + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nk) stash(buf ^ 1);
+        __syncthreads();
+    }
+
+    // Epilogue.  C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+    float* out = g.splits > 1 ? g.partial + (long)split * g.M * g.N : g.C;
+    const long ldo = g.splits > 1 ? g.N : g.ldc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + l31;
+            if (col >= g.N) continue;
+            const float bv = (g.splits == 1 && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (row < g.M) {
+                    float v = acc[i][j][r] + bv;
+                    float* p = out + (long)row * ldo + col;
+                    if (g.splits == 1 && g.accumulate) v += *p;
+                    *p = v;
+                }
+            }
+        }
+}
+
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, const float* __restrict__ bias,
+                                     int M, int N, long ldc, int splits, int accumulate) {
+    const long total = (long)M * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / N), n = (int)(i - (long)m * N);
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += partial[(long)k * total + i];
+        if (bias) s += bias[n];
+        float* p = C + (long)m * ldc + n;
+        if (accumulate) s += *p;
+        *p = s;
+    }
+}
+
+template <int AMODE, int BMODE>
+ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
+    // split K when the tile count alone cannot fill 256 CUs and K is long
+    int splits = 1;
+    if (ws && tiles < 192 && g.K >= 512) {
+        splits = (512 + tiles - 1) / tiles;
+        const int max_by_k = g.K / 256;
+        if (splits > max_by_k) splits = max_by_k;
+        if (splits > 32) splits = 32;
+        while (splits > 1 && (size_t)splits * g.M * g.N * sizeof(float) > ws_bytes) --splits;
+        if (splits < 1) splits = 1;
+    }
+    int kps = ceil_div(g.K, splits);
+    kps = ceil_div(kps, BK) * BK;
+    splits = ceil_div(g.K, kps);
+    g.splits = splits;
+    g.k_per_split = kps;
+    g.partial = (float*)ws;
+    dim3 grid(tiles, splits);
+    hipLaunchKernelGGL((gemm_f32_kernel<AMODE, BMODE>), grid, dim3(256), 0, st, g);
+    ams_status s = ams_check_launch();
+    if (s != AMS_OK) return s;
+    if (splits > 1) {
+        const long total = (long)g.M * g.N;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g.partial, g.C, g.bias, g.M, g.N, g.ldc,
+                           splits, g.accumulate);
+        s = ams_check_launch();
+    }
+    return s;
+}
+
+inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+size_t ams_gemm_workspace_bytes(int M, int N, int K) {
+    const int tiles = ceil_div(M, BM) * ceil_div(N, BN);
+    if (tiles >= 192 || K < 512) return 0;
+    int splits = (512 + tiles - 1) / tiles;
+    if (splits > K / 256) splits = K / 256;
+    if (splits > 32) splits = 32;
+    if (splits <= 1) return 0;
+    return (size_t)splits * M * N * sizeof(float);
+}
+
+ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                        float* C, long ldc, const float* bias, int accumulate, int mask_period, int mask_skip, void* ws,
+                        size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C);
+    GemmArgs g{};
+    g.A = A; g.B = B; g.C = C; g.bias = bias;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.accumulate = accumulate;
+    g.mask_period = mask_period; g.mask_skip = mask_skip;
+    g.a_vec = aligned16(A) && (lda % 4 == 0);
+    g.b_vec = aligned16(B) && (ldb % 4 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (!transA && !transB) return launch<A_ROW, B_ROW>(g, ws, ws_bytes, st);
+    if (!transA && transB) return launch<A_ROW, B_COL>(g, ws, ws_bytes, st);
+    if (transA && !transB) return launch<A_COL, B_ROW>(g, ws, ws_bytes, st);
+    return launch<A_COL, B_COL>(g, ws, ws_bytes, st);
+}
+
+// Adaptive analysis filterbank, path A (reference models/adapt.py:122): y[b,t,n] = sum_k xpad[b,t*hop+k-pl] f[k,n]
+ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, void* stream) {
+    AMS_REQUIRE(x && f && y && Bt > 0 && L > 0 && W > 0 && N > 0 && hop > 0);
+    const int T = (L + hop - 1) / hop;
+    int pad_total = (T - 1) * hop + W - L;
+    if (pad_total < 0) pad_total = 0;
+    GemmArgs g{};
+    g.A = x; g.B = f; g.C = y; g.bias = nullptr;
+    g.M = Bt * T; g.N = N; g.K = W; g.lda = 0; g.ldb = N; g.ldc = N;
+    g.fr_L = L; g.fr_T = T; g.fr_hop = hop; g.fr_pl = pad_total / 2; g.fr_W = W;
+    g.a_vec = aligned16(x) && (L % 4 == 0) && (hop % 4 == 0) && (g.fr_pl % 4 == 0);
+    g.b_vec = aligned16(f) && (N % 4 == 0);
+    return launch<A_FRAMES, B_ROW>(g, nullptr, 0, (hipStream_t)stream);
+}
+
+size_t ams_front_conv_bwd_filter_workspace_bytes(int Bt, int L, int W, int N, int hop) {
+    const int T = (L + hop - 1) / hop;
+    return ams_gemm_workspace_bytes(W, N, Bt * T);
+}
+
+// df[k,n] = sum_{b,t} xpad[b,t*hop+k-pl] * dy[b,t,n]   
+ams_status ams_front_conv_bwd_filter(const float* x, const float* dy, float* df, int Bt, int L, int W, int N, int hop,
+                                     void* ws, size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(x && dy && df && Bt > 0 && L > 0 && W > 0 && N > 0 && hop > 0);
+    const int T = (L + hop - 1) / hop;
+    int pad_total = (T - 1) * hop + W - L;
+    if (pad_total < 0) pad_total = 0;
+    GemmArgs g{};
+    g.A = x; g.B = dy; g.C = df; g.bias = nullptr;
+    g.M = W; g.N = N; g.K = Bt * T; g.lda = 0; g.ldb = N; g.ldc = N;
+    g.fr_L = L; g.fr_T = T; g.fr_hop = hop; g.fr_pl = pad_total / 2; g.fr_W = W;
+    g.a_vec = 0;
+    g.b_vec = aligned16(dy) && (N % 4 == 0);
+    return launch<A_FRAMES_T, B_ROW>(g, ws, ws_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,101 @@
+/* libams_hip.so -- C ABI of the MI355X (gfx950) separation hot path.
+ *
+ * Drop-in boundary for Totoketchup/Adaptive-MultiSpeaker-Separation.  The reference has no FFI: its
+ * "operators" are TF-1.x graph ops called from Python.  Each entry point below replaces the
+ * TF op call sites named in its comment (paths relative to the reference root); the Python host mirror
+ * (adaptive-multispeaker-separation_amd/{models,utils}) binds them through ctypes.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to fp32 row-major data unless the type says otherwise;
+ *   - `stream` is a hipStream_t; work is only enqueued, never synchronised; nothing is allocated;
+ *   - the caller owns inputs, outputs and workspaces (sizes from the *_workspace_bytes / *_floats helpers);
+ *   - return value: AMS_OK or a negative ams_status; on AMS_E_LAUNCH_FAILED the hipError_t is in ams_last_error();
+ *   - re-entrant across streams/threads (no global mutable state besides the thread-local last error).
+ */
+#ifndef AMS_H
+#define AMS_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AMS_ABI_VERSION 1
+
+typedef int32_t ams_status;
+#define AMS_OK 0
+#define AMS_E_INVALID_ARG (-1)
+#define AMS_E_WORKSPACE_TOO_SMALL (-2)
+#define AMS_E_LAUNCH_FAILED (-3)
+
+int ams_last_error(void);
+int ams_abi_version(void);
+
+/* ---- K1  effective filter  f[k,n] = |w[k]| * bases[k,n]      models/adapt.py:104-106, :232-234 ---- */
+ams_status ams_front_filter_fwd(const float* w, const float* bases, float* f, int W, int N, void* stream);
+ams_status ams_front_filter_bwd(const float* w, const float* bases, const float* df, float* dw, float* dbases, int W, int N,
+                                void* stream);
+
+/* ---- K2  analysis filterbank, path A: tf.nn.conv2d stride=hop SAME        models/adapt.py:122 ----
+ * x [Bt,L], f [W,N] -> y [Bt,T',N], T' = ceil(L/hop), pad_left = ((T'-1)hop+W-L)/2. */
+ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, void* stream);
+size_t ams_front_conv_bwd_filter_workspace_bytes(int Bt, int L, int W, int N, int hop);
+ams_status ams_front_conv_bwd_filter(const float* x, const float* dy, float* df, int Bt, int L, int W, int N, int hop, void* ws,
+                                     size_t ws_bytes, void* stream);
+
+/* ---- dense contractions (tf.matmul / tf.nn.conv1d k=1 / dynamic_rnn input projection) ----
+ * C[M,N] (+)= op(A) . op(B) (+ bias[N]);  transX = 0: row-major [rows,cols] as written, 1: stored transposed.
+ * mask_period/mask_skip (transA only): reduction rows k with k % period == skip are treated as zero
+ * (used for the time-shifted h_{t-1}^T . da product).  utils/ops.py:366-383, :501-503. */
+size_t ams_gemm_workspace_bytes(int M, int N, int K);
+ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C,
+                        long ldc, const float* bias, int accumulate, int mask_period, int mask_skip, void* ws, size_t ws_bytes,
+                        void* stream);
+
+/* ---- K7  dominant-speaker masks: one_hot(argmax_s |rep|, S, a, b)   models/network.py:377-378, :501-502 ----
+ * rep_non_mix rows are (b,s) row-major, each TF long; Y [B,TF,S]; argmax [B,TF] int32 (may be NULL). */
+ams_status ams_make_masks(const float* rep_non_mix, float* Y, int32_t* argmax, int B, int S, long TF, float a, float b,
+                          int take_abs, void* stream);
+
+/* ---- K10  BLSTM recurrence (tf.nn.dynamic_rnn(BasicLSTMCell) x 2 directions)   utils/ops.py:358-383 ----
+ * G [B,T,2,4H]: in = x.Wx + b (both directions), out = activated gates (fwd) / d pre-activation (bwd).
+ * out [B,T,2H], cst [B,T,2,H].  Uf/Ub = rows D.. of each direction's [D+H,4H] kernel, ldu = 4H.
+ * pack: scratch of ams_blstm_pack_floats(H, backward) floats. */
+size_t ams_blstm_pack_floats(int H, int backward);
+ams_status ams_blstm_recurrent_fwd(float* G, float* out, float* cst, const float* Uf, const float* Ub, long ldu, float* pack,
+                                   int B, int T, int H, void* stream);
+ams_status ams_blstm_recurrent_bwd(float* G, const float* cst, const float* dout, float* dc, const float* Uf, const float* Ub,
+                                   long ldu, float* pack, int B, int T, int H, void* stream);
+
+/* ---- K13  tf.nn.l2_normalize over groups of E       utils/ops.py:323-324 ---- */
+ams_status ams_l2norm_fwd(const float* u, float* v, float* inv, long rows, int E, void* stream);
+ams_status ams_l2norm_bwd(const float* v, const float* inv, const float* dv, float* du, long rows, int E, void* stream);
+
+/* column sums (bias gradients) */
+size_t ams_colsum_workspace_bytes(long rows, int cols);
+ams_status ams_colsum(const float* x, float* out, long rows, int cols, long ld, int accumulate, void* ws, size_t ws_bytes,
+                      void* stream);
+
+/* ---- K14  deep-clustering loss      models/dpcl.py:41-87 ----
+ * V [B,TF,E], Y [B,TF,S]; out[0] = cost, out[1..3] = the reference's summaries '1','2','3'.
+ * bwd: inv != NULL fuses the l2-normalise backward (writes dU), else writes dV. */
+size_t ams_dpcl_workspace_bytes(int B, long TF, int E, int S);
+ams_status ams_dpcl_loss_fwd(const float* V, const float* Y, float* out, int B, long TF, int E, int S, void* ws, size_t ws_bytes,
+                             void* stream);
+ams_status ams_dpcl_loss_bwd(const float* V, const float* Y, const float* inv, float* dU, int B, long TF, int E, int S,
+                             const void* ws, void* stream);
+
+/* ---- K24  optimizers     models/network.py:181-194, utils/ops.py:686-703 ---- */
+ams_status ams_opt_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, long n, float lr_t, float beta1,
+                           float beta2, float eps, float grad_scale, void* stream);
+ams_status ams_opt_rmsprop(float* p, const float* g, float* ms, long n, float lr, float decay, float eps, float grad_scale,
+                           void* stream);
+ams_status ams_opt_momentum(float* p, const float* g, float* accum, long n, float lr, float momentum, float grad_scale,
+                            void* stream);
+ams_status ams_sumsq(const float* x, float* out, long n, void* ws, size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AMS_H */

@@ -1,0 +1,180 @@
+"""GPU parity: every HIP kernel, called through the C ABI (ctypes), against the float64 numpy oracle on
+the same seeded inputs.  Spec tolerance (BASELINE.json north_star): 1e-3 relative fp32; the asserts below
+use the much tighter bound an exact-f32 MFMA path should meet (`TOL`), so a layout bug cannot hide."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import front as ofront, blstm as oblstm, dense as odense, dpcl as odpcl, separate as osep, optim as ooptim
+
+TOL = 2e-5          # observed fp32 round-off class; spec is 1e-3
+
+
+def dev(x):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def rel(a, b):
+    b = np.asarray(b, np.float64)
+    return np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from ams_hip import ops as o
+    return o
+
+
+@pytest.mark.parametrize('M,N,K,tA,tB', [
+    (130, 70, 45, 0, 0), (130, 70, 45, 0, 1), (130, 70, 45, 1, 0), (130, 70, 45, 1, 1),
+    (257, 1200, 600, 0, 0), (300, 1200, 2049, 1, 0), (512, 256, 1024, 0, 1), (64, 10240, 600, 0, 0),
+    (33, 17, 5, 0, 0), (128, 128, 16, 0, 0), (600, 520, 5120, 1, 0),
+])
+def test_gemm(ops, M, N, K, tA, tB):
+    rng = np.random.RandomState(M + N + K)
+    A = rng.randn(*((K, M) if tA else (M, K)))
+    B = rng.randn(*((N, K) if tB else (K, N)))
+    bias = rng.randn(N)
+    ref = (A.T if tA else A) @ (B.T if tB else B) + bias
+    out = ops.gemm(dev(A), dev(B), transA=bool(tA), transB=bool(tB), bias=dev(bias))
+    assert rel(host(out), ref) < TOL
+    # accumulate on top
+    C0 = rng.randn(M, N)
+    c = dev(C0)
+    ops.gemm(dev(A), dev(B), transA=bool(tA), transB=bool(tB), out=c, accumulate=True)
+    assert rel(host(c), ref - bias + C0) < TOL
+
+
+def test_gemm_strided_and_masked(ops):
+    rng = np.random.RandomState(1)
+    T, Bq, H = 7, 5, 12
+    M = Bq * T
+    out = rng.randn(M, 2 * H)
+    dZ = rng.randn(M, 8 * H)
+    # forward direction dU: sum_{t>=1} out[b,t-1,:H]^T dZ[b,t,:4H]
+    ref = np.zeros((H, 4 * H))
+    for b in range(Bq):
+        for t in range(1, T):
+            ref += np.outer(out[b * T + t - 1, :H], dZ[b * T + t, :4 * H])
+    o, z = dev(out), dev(dZ)
+    res = torch.empty((H, 4 * H), device='cuda')
+    ops.gemm(o.view(-1), z.view(-1)[8 * H:], transA=True, out=res, M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H, ldc=4 * H,
+             mask=(T, T - 1))
+    assert rel(host(res), ref) < TOL
+
+
+@pytest.mark.parametrize('Bt,L,W,N,hop', [(3, 1000, 128, 8, 48), (6, 4096, 1024, 256, 256), (2, 2048, 256, 40, 64)])
+def test_front_conv_and_filter(ops, Bt, L, W, N, hop):
+    rng = np.random.RandomState(L)
+    x, w, bases = rng.randn(Bt, L), rng.randn(W), rng.randn(W, N)
+    f = ops.front_filter(dev(w), dev(bases))
+    f_ref = ofront.front_filter(w, bases)
+    assert rel(host(f), f_ref) < 1e-6
+    y = ops.front_conv(dev(x), f, hop)
+    y_ref = ofront.conv_strided(x, f_ref, hop)
+    assert y.shape == y_ref.shape and rel(host(y), y_ref) < TOL
+    dy = rng.randn(*y_ref.shape)
+    df = ops.front_conv_bwd_filter(dev(x), dev(dy), W, hop)
+    df_ref = ofront.conv_strided_bwd_filter(x, dy, W, hop)
+    assert rel(host(df), df_ref) < TOL
+    dw, db = ops.front_filter_bwd(dev(w), dev(bases), df)
+    dw_ref, db_ref = ofront.front_filter_bwd(w, bases, df_ref)
+    assert rel(host(dw), dw_ref) < TOL and rel(host(db), db_ref) < TOL
+
+
+def test_make_masks(ops):
+    rng = np.random.RandomState(2)
+    B, S, T, F = 3, 3, 5, 7
+    rep = rng.randn(B * S, T, F)
+    rep[0, 0, 0] = rep[1, 0, 0] = 5.0                       # tie -> lowest index
+    X_nm = rep.reshape(B, S, T, F).transpose(0, 2, 3, 1)
+    for a, b, ab in ((1.0, 0.0, True), (1.0, -1.0, True), (1.0, 0.0, False)):
+        Y_ref, am_ref = osep.make_masks(np.abs(X_nm) if ab else X_nm, a, b)
+        Y, am = ops.make_masks(dev(rep), B, S, a, b, ab, want_argmax=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(am.cpu().numpy().reshape(B, T, F), am_ref)
+        assert np.array_equal(host(Y).reshape(B, T, F, S), Y_ref)
+
+
+@pytest.mark.parametrize('B,T,D,H', [(5, 7, 12, 8), (20, 9, 24, 20), (3, 4, 16, 300), (17, 6, 10, 6)])
+def test_blstm_layer(ops, B, T, D, H):
+    rng = np.random.RandomState(B * T + H)
+    lim = np.sqrt(6.0 / (D + 5 * H))
+    x = rng.randn(B, T, D)
+    Kf, Kb = rng.uniform(-lim, lim, (D + H, 4 * H)) * 3, rng.uniform(-lim, lim, (D + H, 4 * H)) * 3
+    bf, bb = rng.randn(4 * H) * 0.1, rng.randn(4 * H) * 0.1
+    out_ref, cache = oblstm.blstm_fwd(x, Kf, bf, Kb, bb)
+    xd, Kfd, Kbd = dev(x), dev(Kf), dev(Kb)
+    out, G, cst = ops.blstm_fwd(xd, Kfd, dev(bf), Kbd, dev(bb))
+    assert rel(host(out), out_ref) < TOL
+    dout = rng.randn(B, T, 2 * H)
+    dx_ref, (dKf_r, dbf_r, dKb_r, dbb_r) = oblstm.blstm_bwd(dout, cache)
+    dx, dKf, dbf, dKb, dbb = ops.blstm_bwd(xd, Kfd, Kbd, out, G, cst, dev(dout))
+    assert rel(host(dx), dx_ref) < 5 * TOL
+    assert rel(host(dKf), dKf_r) < 5 * TOL and rel(host(dKb), dKb_r) < 5 * TOL
+    assert rel(host(dbf), dbf_r) < 5 * TOL and rel(host(dbb), dbb_r) < 5 * TOL
+
+
+@pytest.mark.parametrize('B,TF,E,S', [(2, 300, 8, 2), (3, 5000, 40, 2), (2, 2049, 40, 3), (2, 77, 3, 2)])
+def test_l2norm_dpcl(ops, B, TF, E, S):
+    rng = np.random.RandomState(TF)
+    u = rng.randn(B, TF * E)
+    u[0, :E] = 0.0                                           # exercises the eps clamp
+    V_ref, inv_ref = odense.l2norm_fwd(u, E)
+    V, inv = ops.l2norm_fwd(dev(u), E)
+    assert rel(host(V).reshape(V_ref.shape), V_ref) < 1e-6
+    lab = rng.randint(0, S, (B, TF))
+    Y = np.eye(S)[lab]
+    c_ref, terms = odpcl.dpcl_cost(V_ref.reshape(B, TF, E), Y)
+    Vd, Yd = V.view(B, TF, E), dev(Y)
+    out, ws = ops.dpcl_loss_fwd(Vd, Yd)
+    o = host(out)
+    assert abs(o[0] - c_ref) < TOL * max(1.0, abs(c_ref))
+    for k in range(3):
+        assert abs(o[1 + k] - terms[k]) < TOL * max(1.0, abs(terms[k]))
+    dV_ref = odpcl.dpcl_cost_bwd(V_ref.reshape(B, TF, E), Y)
+    dV = ops.dpcl_loss_bwd(Vd, Yd, ws)
+    assert rel(host(dV), dV_ref) < 5 * TOL
+    du_ref = odense.l2norm_bwd(V_ref, inv_ref, dV_ref.reshape(V_ref.shape))
+    du = ops.dpcl_loss_bwd(Vd, Yd, ws, inv=inv)
+    assert rel(host(du).reshape(du_ref.shape), du_ref) < 5 * TOL
+    du2 = ops.l2norm_bwd(V, inv, dV.view(B, -1), E)
+    assert rel(host(du2).reshape(du_ref.shape), du_ref) < 5 * TOL
+
+
+def test_optimizers(ops):
+    rng = np.random.RandomState(5)
+    n = 100003
+    p0, g = rng.randn(n), rng.randn(3, n)
+    p = dev(p0)
+    m, v, vh = torch.zeros_like(p), torch.zeros_like(p), torch.zeros_like(p)
+    ref = ooptim.AMSGrad(0.01)
+    pr = p0.copy()
+    b1p, b2p = 0.9, 0.99
+    for k in range(3):
+        ref.apply([pr], [g[k]])
+        lr_t = 0.01 * np.sqrt(1 - b2p) / (1 - b1p)
+        ops.opt_amsgrad(p, dev(g[k]), m, v, vh, lr_t, 0.9, 0.99, 1e-3)
+        b1p *= 0.9
+        b2p *= 0.99
+    assert rel(host(p), pr) < 1e-5
+    p, ms = dev(p0), torch.ones(n, device='cuda')
+    r, pr = ooptim.RMSProp(0.01), p0.copy()
+    for k in range(3):
+        r.apply([pr], [g[k]])
+        ops.opt_rmsprop(p, dev(g[k]), ms, 0.01)
+    assert rel(host(p), pr) < 1e-5
+    p, acc = dev(p0), torch.zeros(n, device='cuda')
+    r, pr = ooptim.Momentum(0.01), p0.copy()
+    for k in range(3):
+        r.apply([pr], [g[k]])
+        ops.opt_momentum(p, dev(g[k]), acc, 0.01)
+    assert rel(host(p), pr) < 1e-5
+    assert abs(host(ops.sumsq(dev(g[0])))[0] - np.sum(g[0].astype(np.float32).astype(np.float64) ** 2)) < 1e-4 * n
