@@ -1,0 +1,50 @@
+"""One process per GPU; gradient exchange over RCCL (torch.distributed backend 'nccl' on ROCm) / gloo on CPU.
+
+The reference is single-process single-GPU (utils/trainer.py:273-278); utterance-level data parallelism is the
+build's addition: rank r trains on its own minibatch shard, weights are broadcast from rank 0 at
+start, and one all-reduce of the flat gradient buffer per step keeps replicas identical.
+"""
+import os
+
+import torch
+import torch.distributed as td
+
+
+class Dist(object):
+    def __init__(self, backend=None):
+        self.world_size = int(os.environ.get('WORLD_SIZE', '1'))
+        self.rank = int(os.environ.get('RANK', '0'))
+        self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+        self.enabled = self.world_size > 1
+        if self.enabled and not td.is_initialized():
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29500')
+            if backend is None:
+                backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+            if backend == 'nccl':
+                torch.cuda.set_device(self.local_rank)
+            td.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
+
+    def all_reduce_sum(self, t):
+        if self.enabled:
+            td.all_reduce(t, op=td.ReduceOp.SUM)
+        return t
+
+    def all_reduce_max(self, t):
+        if self.enabled:
+            td.all_reduce(t, op=td.ReduceOp.MAX)
+        return t
+
+    def broadcast(self, t, src=0):
+        if self.enabled:
+            td.broadcast(t, src)
+        return t
+
+    def barrier(self):
+        if self.enabled:
+            td.barrier()
+
+    def shard(self, n):
+        """Contiguous utterance shard [lo, hi) of a global batch of n for this rank."""
+        per = n // self.world_size
+        return self.rank * per, (self.rank + 1) * per

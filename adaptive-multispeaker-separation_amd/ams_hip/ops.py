@@ -99,6 +99,9 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False
         ldc = N
     elif ldc is None:
         ldc = out.stride(0) if out.dim() == 2 else N
+    for t_ in (A, B, out, bias):
+        if t_ is not None and (t_.dtype != torch.float32 or not t_.is_cuda):
+            raise AmsError('gemm: operands must be fp32 device tensors')
     nb = lib.ams_gemm_workspace_bytes(M, N, K)
     ws = _ws(nb, A) if nb else None
     check(lib.ams_gemm_f32(int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc, _p(bias), int(accumulate),
@@ -216,12 +219,12 @@ def dpcl_loss_fwd(V, Y):
     return out, ws
 
 
-def dpcl_loss_bwd(V, Y, ws, inv=None):
-    _chk(V, Y, inv)
+def dpcl_loss_bwd(V, Y, ws, inv=None, upstream=None):
+    _chk(V, Y, inv, upstream)
     B, TF, E = V.shape
     S = Y.shape[2]
     d = torch.empty_like(V)
-    check(load().ams_dpcl_loss_bwd(_p(V), _p(Y), _p(inv), _p(d), B, TF, E, S, _p(ws), _s()), 'ams_dpcl_loss_bwd')
+    check(load().ams_dpcl_loss_bwd(_p(V), _p(Y), _p(inv), _p(upstream), _p(d), B, TF, E, S, _p(ws), _s()), 'ams_dpcl_loss_bwd')
     return d
 
 

@@ -1,0 +1,78 @@
+"""Flat-buffer optimizers and gradient exchange (reference models/network.py:167-194, utils/ops.py:639-792).
+
+All trainable variables are re-pointed into ONE contiguous fp32 buffer; their gradients live in a second
+buffer of the same layout.  That buffer is what RCCL all-reduces (one collective per step over xGMI) and
+what the fused optimizer kernel walks -- one launch instead of one tiny kernel per variable per moment.
+"""
+import math
+
+import torch
+
+from . import ops
+
+
+class FlatOptimizer(object):
+    def __init__(self, variables, kind, learning_rate, decay_epoch, gradient_clip, dist=None):
+        self.vars = list(variables)
+        self.kind = kind
+        self.base_lr = float(learning_rate)
+        self.decay_epoch = int(decay_epoch)
+        self.clip = float(gradient_clip)
+        self.dist = dist
+        self.global_epoch = 0
+        self.t = 0
+        n = sum(v.numel() for v in self.vars)
+        dev = self.vars[0].device if self.vars else torch.device('cpu')
+        self.flat = torch.empty(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        off = 0
+        for v in self.vars:
+            k = v.numel()
+            self.flat[off:off + k].copy_(v.detach().reshape(-1))
+            v.data = self.flat[off:off + k].view(v.shape)
+            v.requires_grad_(True)
+            v.grad = self.flat_grad[off:off + k].view(v.shape)
+            off += k
+        z = lambda: torch.zeros(n, dtype=torch.float32, device=dev)  # noqa: E731
+        if kind == 'Adam':                      # the reference's 'Adam' is AMSGrad(eps=1e-3, beta2=.99), undecayed lr
+            self.m, self.v, self.vhat = z(), z(), z()
+            self.beta1, self.beta2, self.eps = 0.9, 0.99, 1e-3
+            self.b1p, self.b2p = self.beta1, self.beta2
+        elif kind == 'RMSProp':
+            self.ms = torch.ones(n, dtype=torch.float32, device=dev)
+        elif kind == 'SGD':
+            self.acc = z()
+        else:
+            raise ValueError('unknown optimizer %r' % kind)
+
+    # tf.train.exponential_decay(lr, global_epoch, decay_epoch, 0.5, staircase=True)  (network.py:175-177)
+    def learning_rate(self):
+        return self.base_lr * 0.5 ** (self.global_epoch // self.decay_epoch)
+
+    def increment_epoch(self):
+        self.global_epoch += 1
+
+    def zero_grad(self):
+        self.flat_grad.zero_()
+
+    def step(self):
+        """Gradient exchange + clip + fused update.  Gradients must already be in flat_grad."""
+        if self.flat.numel() == 0:
+            return
+        scale = 1.0
+        if self.dist is not None and self.dist.world_size > 1:
+            self.dist.all_reduce_sum(self.flat_grad)
+            scale = 1.0 / self.dist.world_size            # every loss is a batch mean
+        if self.clip != 0.0:
+            gn = math.sqrt(float(ops.sumsq(self.flat_grad).item())) * scale
+            scale *= self.clip / max(gn, self.clip)       # tf.clip_by_global_norm
+        if self.kind == 'Adam':
+            lr_t = self.base_lr * math.sqrt(1.0 - self.b2p) / (1.0 - self.b1p)
+            ops.opt_amsgrad(self.flat, self.flat_grad, self.m, self.v, self.vhat, lr_t, self.beta1, self.beta2, self.eps, scale)
+            self.b1p *= self.beta1
+            self.b2p *= self.beta2
+        elif self.kind == 'RMSProp':
+            ops.opt_rmsprop(self.flat, self.flat_grad, self.ms, self.learning_rate(), 0.9, 1e-10, scale)
+        else:
+            ops.opt_momentum(self.flat, self.flat_grad, self.acc, self.learning_rate(), 0.9, scale)
+        self.t += 1

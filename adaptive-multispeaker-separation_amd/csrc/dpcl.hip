@@ -156,8 +156,8 @@ __global__ void dpcl_mean_kernel(const float* __restrict__ per_utt, float* __res
 template <int E_>
 __global__ __launch_bounds__(256) void dpcl_bwd_kernel(const float* __restrict__ V, const float* __restrict__ Y,
                                                        const float* __restrict__ cnt, const float* __restrict__ mats,
-                                                       const float* __restrict__ inv, float* __restrict__ dU, long TF, int S,
-                                                       int fuse_l2norm) {
+                                                       const float* __restrict__ inv, const float* __restrict__ upstream,
+                                                       float* __restrict__ dU, long TF, int S, int fuse_l2norm) {
     constexpr int LDS_STRIDE = E_ + 1;
     __shared__ float tile[256 * LDS_STRIDE];
     const int b = blockIdx.y, tid = threadIdx.x;
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256) void dpcl_bwd_kernel(const float* __restrict__
         const float* y = Y + ((long)b * TF + p) * S;
         float diag = 0.f;
         for (int s = 0; s < S; ++s) diag += y[s] * cnt[(long)b * S + s];
-        const float d = 1.0f / sqrtf(diag);
+        const float d = (1.0f / sqrtf(diag)) * (upstream ? upstream[0] : 1.0f);
         // dv = Gn^T-free: G is symmetric; dv[f] = sum_e v[e] G[e][f]
         for (int e = 0; e < E_; ++e) {
             const float ve = v[e];
@@ -249,9 +249,10 @@ ams_status ams_dpcl_loss_fwd(const float* V, const float* Y, float* out, int B, 
     return ams_check_launch();
 }
 
-// dU (or dV when inv == NULL) from the state a preceding ams_dpcl_loss_fwd left in ws.
-ams_status ams_dpcl_loss_bwd(const float* V, const float* Y, const float* inv, float* dU, int B, long TF, int E, int S,
-                             const void* ws, void* stream) {
+// dU (or dV when inv == NULL) from the state a preceding ams_dpcl_loss_fwd left in ws; upstream (device scalar,
+// may be NULL) multiplies the result (chain rule for d loss / d cost).
+ams_status ams_dpcl_loss_bwd(const float* V, const float* Y, const float* inv, const float* upstream, float* dU, int B, long TF,
+                             int E, int S, const void* ws, void* stream) {
     AMS_REQUIRE(V && Y && dU && ws && B > 0 && TF > 0 && S > 0 && S <= 8);
     hipStream_t st = (hipStream_t)stream;
     const float* cnt = (const float*)ws;
@@ -259,7 +260,7 @@ ams_status ams_dpcl_loss_bwd(const float* V, const float* Y, const float* inv, f
     dim3 grid(ceil_div(TF, 256), B);
     const int fuse = inv ? 1 : 0;
 #define AMS_DPCL_BWD(EE) \
-    hipLaunchKernelGGL((dpcl_bwd_kernel<EE>), grid, dim3(256), 0, st, V, Y, cnt, mats, inv, dU, TF, S, fuse)
+    hipLaunchKernelGGL((dpcl_bwd_kernel<EE>), grid, dim3(256), 0, st, V, Y, cnt, mats, inv, upstream, dU, TF, S, fuse)
     switch (E) {
         case 40: AMS_DPCL_BWD(40); break;
         case 32: AMS_DPCL_BWD(32); break;

@@ -1,0 +1,155 @@
+# -*- coding: utf-8 -*-
+"""Adaptive front / back end (reference models/adapt.py), host mirror over the HIP kernels.
+
+Learned analysis filterbank (1-D conv, optional max-pool with argmax / average pool), pretraining
+separator (ideal mask / perfect subtraction), synthesis (unpool + transposed conv), costs, and the
+connect_* wiring used by the front_* recipes.
+"""
+import os
+
+import torch
+
+import config
+from ams_hip import functional as F
+from ams_hip.graph import Node, get_default_graph, scope, get_scope_variable
+from models.network import Network
+from utils.ops import xavier_uniform
+
+
+class Adapt(Network):
+    def __init__(self, *args, **kwargs):
+        super(Adapt, self).__init__(*args, **kwargs)
+
+        if kwargs is not None:
+            self.N = kwargs['filters']
+            self.max_pool_value = kwargs['max_pool']
+            self.l = kwargs['regularization']
+            self.beta = kwargs['beta']
+            self.p = kwargs['sparsity']
+            self.window = kwargs['window_size']
+            self.pretraining = kwargs['pretraining']
+            self.overlap_coef = kwargs['overlap_coef']
+            self.overlap_value = kwargs['overlap_value']
+            self.loss = kwargs['loss']
+            self.separation = kwargs['separation']
+            self.with_max_pool = kwargs['with_max_pool']
+            self.with_average_pool = kwargs['with_average_pool']
+            self.hop_size = kwargs['hop_size']
+            self.non_negativity = kwargs['non_negativity']
+
+        g = get_default_graph()
+        with g.variable_scope('preprocessing'):
+            x_mix, x_non_mix = self.x_mix, self.x_non_mix
+
+            def _x(run):
+                # rows 0..B-1 mixtures, then (b,s) row-major (adapt.py:43,47)
+                xm, xn = x_mix.value(run), x_non_mix.value(run)
+                return torch.cat([xm, xn.reshape(-1, xn.shape[-1])], dim=0)
+            self.x = Node('x', _x)
+
+        if self.pretraining:
+            self.front
+            self.separator
+            self.back
+            self.cost_model = self.cost
+            self.finish_construction()
+            self.optimize
+        else:
+            self.front
+
+    ##
+    # Front End creating STFT like data (adapt.py:95-134)
+    ##
+    @scope
+    def front(self):
+        self.window_filter = get_scope_variable('window', 'w', shape=(self.window,), initializer=xavier_uniform)
+        self.bases = get_scope_variable('bases', 'bases', shape=(self.window, self.N), initializer=xavier_uniform)
+        w, bases, x = self.window_filter, self.bases, self.x
+        self.conv_filter = Node('conv_filter', lambda run: F.front_filter(w, bases))
+        filt = self.conv_filter
+        hop, P = self.hop_size, self.max_pool_value
+
+        if self.with_max_pool:
+            def _pool(run):
+                return F.front_maxpool(x.value(run), filt.value(run), P, hop)      # (y, argmax int64)
+            pooled = Node('maxpool', _pool)
+            self.argmax = Node('argmax', lambda run: pooled.value(run)[1])
+            y = Node('output', lambda run: pooled.value(run)[0])
+        elif self.with_average_pool:
+            y = Node('output', lambda run: F.front_avgpool(x.value(run), filt.value(run), P))
+        else:
+            y = Node('output', lambda run: F.front_conv(x.value(run), filt.value(run), hop))
+        self.y = y
+
+        # sparsity statistics (adapt.py:130-132); only evaluated when beta != 0
+        def _sparse(run):
+            from ams_hip import losses_host
+            return losses_host.sparse_constraint(y.value(run), self.p, self.dist)
+        self.sparse_constraint = Node('sparse_constraint', _sparse)
+        return y
+
+    @scope
+    def separator(self):
+        from ams_hip import losses_host
+        return losses_host.build_adapt_separator(self)
+
+    @scope
+    def back(self):
+        from ams_hip import losses_host
+        return losses_host.build_adapt_back(self)
+
+    @scope
+    def cost(self):
+        from ams_hip import losses_host
+        return losses_host.build_adapt_cost(self)
+
+    @scope
+    def cost_finetuning(self):
+        from ams_hip import separate_host
+        return separate_host.build_cost_finetuning(self, self.back)
+
+    def connect_front(self, separator_class):
+        self.sepNet = separator_class(True, **self.args)
+
+    def connect_only_front_to_separator(self, separator, freeze_front=True):
+        self.connect_front(separator)
+        self.sepNet.output = self.sepNet.prediction
+        self.cost_model = self.sepNet.cost
+        self.back  # To save the back values !
+        g = get_default_graph()
+        var_list = [v for v in g.global_variables() if ('back/' in v.ams_name or 'front/' in v.ams_name)]
+        self.create_saver(subset=var_list)
+        self.restore_model(self.args['model_folder'])
+        self.finish_construction()
+        self.freeze_all_with('front/')
+        self.freeze_all_with('back/')
+        self.optimize
+        self.tensorboard_init()
+
+    def connect_enhance_to_separator(self, separator):
+        self.connect_front(separator)
+        self.sepNet.output = self.sepNet.enhance
+        self.cost_model = self.sepNet.enhance_cost
+        self.back  # To save the back values !
+        g = get_default_graph()
+        var_list = [v for v in g.global_variables()
+                    if ('back/' in v.ams_name or 'front/' in v.ams_name or 'prediction/' in v.ams_name
+                        or 'speaker_centroids' in v.ams_name)]
+        self.create_saver(subset=var_list)
+        self.restore_model(self.args['model_folder'])
+        self.finish_construction()
+        self.freeze_all_except('enhance/')
+        self.optimize
+        self.tensorboard_init()
+
+    def restore_front_separator(self, path, separator):
+        self.connect_front(separator)
+        self.sepNet.output = self.sepNet.prediction
+        self.back
+        self.restore_model(path)
+
+    def create_centroids_saver(self):
+        self.centroids_saver = [self.sepNet.speaker_vectors.ams_name]
+
+    def savedModel(self):
+        raise NotImplementedError('TF SavedModel export (adapt.py:64-90) has no equivalent; use save()/restore_model()')

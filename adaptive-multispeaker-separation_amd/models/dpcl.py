@@ -1,0 +1,51 @@
+# -*- coding: utf-8 -*-
+"""Deep Clustering separator (reference models/dpcl.py), host mirror over the HIP kernels."""
+from ams_hip import functional as F
+from ams_hip.graph import Node, get_default_graph, scope
+from models.network import Separator
+from utils.ops import BLSTM, Conv1D, Reshape, Normalize, f_props
+
+
+class DPCL(Separator):
+
+    def __init__(self, graph=None, **kwargs):
+        kwargs['mask_a'] = 1.0
+        kwargs['mask_b'] = 0.0
+
+        super(DPCL, self).__init__(graph, **kwargs)
+        self.init_separator()
+
+    @scope
+    def prediction(self):
+        # DPCL network (dpcl.py:19-39): BLSTM x nb_layers -> Conv1D -> Reshape [B,T,F,E] -> Normalize(3)
+        self.true_masks = self.y
+        E, Fq = self.embedding_size, self.F
+        layers = [BLSTM(self.layer_size, name='BLSTM_' + str(i), drop_val=self.rdropout,
+                        in_dim=(Fq if i == 0 else self.layer_size)) for i in range(self.nb_layers)]
+        conv = Conv1D([1, self.layer_size, E * Fq])
+        x_node = self.X
+
+        def _pred(run):
+            x = x_node.value(run)
+            h = f_props(layers, x)
+            u = conv.f_prop(h)                                 # [B, T, F*E]  (column = f*E + e)
+            return F.l2norm(u, E)                              # Reshape + Normalize(3)
+        return Node('prediction', _pred, register=False)
+
+    @scope
+    def cost(self):
+        # dpcl.py:41-87
+        pred, y = self.prediction, self.y
+        g = get_default_graph()
+
+        def _terms(run):
+            V = pred.value(run)
+            Y = y.value(run)
+            B = V.shape[0]
+            return F.dpcl_loss(V.reshape(B, -1, self.embedding_size), Y.reshape(B, -1, Y.shape[-1]))
+        terms = Node('terms', _terms)
+        cost = Node('cost_value', lambda run: terms.value(run)[0:1])
+        g.summaries['cost/cost'] = cost
+        for k, name in ((1, '1'), (2, '2'), (3, '3')):           # dpcl.py:83-85
+            g.summaries['cost/' + name] = Node(name, lambda run, k=k: terms.value(run)[k])
+        return cost

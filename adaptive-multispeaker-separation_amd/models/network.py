@@ -1,0 +1,518 @@
+# -*- coding: utf-8 -*-
+"""Host mirror of the reference's model-construction API (reference models/network.py).
+
+Same classes, constructor kwargs, lazily-built attribute names and session-facing methods -- ``Network`` and
+``Separator`` -- so ``utils/trainer.py`` recipes read like the reference's.  Attributes that were TF tensors are
+``ams_hip.graph.Node`` objects evaluated once per ``train/valid_batch/...`` call; their bodies launch the HIP
+kernels of libams_hip.so (no TF, no CPU fallback).
+"""
+import json
+import os
+import random
+
+import numpy as np
+import torch
+
+import config
+from ams_hip import functional as F
+from ams_hip import ops as K
+from ams_hip.graph import Node, Placeholder, Run, get_default_graph, scope
+from ams_hip.optim import FlatOptimizer
+from utils.ops import BLSTM, Conv1D, f_props, log10
+
+_ADJ = ['autumn', 'hidden', 'bitter', 'misty', 'silent', 'empty', 'dry', 'dark', 'summer', 'icy', 'quiet', 'white', 'cool',
+        'spring', 'winter', 'patient', 'twilight', 'dawn', 'crimson', 'wispy', 'weathered', 'blue', 'billowing', 'broken']
+_NOUN = ['waterfall', 'river', 'breeze', 'moon', 'rain', 'wind', 'sea', 'morning', 'snow', 'lake', 'sunset', 'pine', 'shadow',
+         'leaf', 'dawn', 'glitter', 'forest', 'hill', 'cloud', 'meadow', 'sun', 'glade', 'bird', 'brook']
+
+
+def haikunate():
+    """Stand-in for haikunator.Haikunator().haikunate() (network.py:35): adjective-noun-4digits."""
+    r = random.SystemRandom()
+    return '%s-%s-%04d' % (r.choice(_ADJ), r.choice(_NOUN), r.randint(0, 9999))
+
+
+class SummaryWriter(object):
+    """JSON-lines stand-in for tf.summary.FileWriter (network.py:120-122); off the timed path."""
+
+    def __init__(self, path):
+        self.path = path
+        self._f = None
+
+    def add(self, step, values):
+        if self._f is None:
+            os.makedirs(self.path, exist_ok=True)
+            self._f = open(os.path.join(self.path, 'events.jsonl'), 'a')
+        self._f.write(json.dumps({'step': int(step), 'values': values}) + '\n')
+        self._f.flush()
+
+
+class Network(object):
+    """docstring for Network"""
+
+    def __init__(self, graph=None, *args, **kwargs):
+        # Constant seed for uniform results (network.py:17-18)
+        np.random.seed(42)
+
+        if kwargs is not None and len(kwargs):
+            self.folder = kwargs['type']
+            self.S = kwargs['nb_speakers']
+            self.args = kwargs
+            self.learning_rate = kwargs['learning_rate']
+            self.my_opt = kwargs['optimizer']
+            self.decay_epoch = kwargs['decay_epoch']
+            self.gradient_clip = kwargs['gradient_norm_clip']
+        else:
+            raise Exception('Keyword Arguments missing ! Please add the right arguments in input | check doc')
+
+        self.dist = kwargs.get('dist', None)
+        self.summaries_enabled = kwargs.get('summaries', True)
+
+        if graph is None:
+            # Run ID
+            self.runID = kwargs.get('run_id') or haikunate()
+            print('ID : {}'.format(self.runID))
+            g = get_default_graph()
+            with g.variable_scope('inputs'):
+                self.training = Placeholder('is_training')
+                if not kwargs['pipeline']:
+                    # fed through feed_dict (network.py:44-63)
+                    self.x_non_mix = Placeholder('non_mix_input')      # [B, S, L]
+                    self.x_mix = Placeholder('mix_input')              # [B, L]
+                    self.I = Placeholder('indicies')                   # [B, S]
+                else:
+                    # tensors produced by the input pipeline (network.py:65-85)
+                    nm, mx, ind = kwargs['non_mix'], kwargs['mix'], kwargs['ind']
+                    self.x_non_mix = Node('non_mix_input', lambda run: nm.value(run))
+                    self.x_mix = Node('mix_input', lambda run: mx.value(run))
+                    self.I = Node('indicies', lambda run: ind.value(run))
+
+    # --------------------------------------------------------------- bookkeeping
+    def _dir(self):
+        return os.path.join(config.log_dir, self.folder, self.runID)
+
+    def tensorboard_init(self):
+        self.create_saver()
+        g = get_default_graph()
+        train_keys, valid_keys, test_keys = [], [], []
+        for name in g.summaries:                                        # network.py:98-107
+            if not ('input' in name or 'output' in name):
+                train_keys.append(name)
+            else:
+                valid_keys.append(name)
+            if 'SDR_improvement' in name:
+                valid_keys.append(name)
+                test_keys.append(name)
+            if 'audio' in name or 'stft' in name or 'mask' in name:
+                test_keys.append(name)
+        self.merged_train = train_keys
+        self.merged_valid = valid_keys if len(valid_keys) else None
+        self.merged_test = test_keys if len(test_keys) else None
+        self.train_writer = SummaryWriter(os.path.join(self._dir(), 'train'))
+        self.valid_writer = SummaryWriter(os.path.join(self._dir(), 'valid'))
+        self.test_writer = SummaryWriter(os.path.join(self._dir(), 'test'))
+        # Save arguments (network.py:124-129)
+        if self.dist is None or self.dist.rank == 0:
+            os.makedirs(self._dir(), exist_ok=True)
+            with open(os.path.join(self._dir(), 'params'), 'w') as f:
+                for k in ('mix', 'non_mix', 'ind'):
+                    self.args.pop(k, None)
+                json.dump({k: v for k, v in self.args.items() if _jsonable(v)}, f)
+
+    def create_saver(self, subset=None):
+        g = get_default_graph()
+        self.saver = list(g.variables.keys()) if subset is None else [v.ams_name for v in subset]
+
+    def _latest_checkpoint(self, path):
+        marker = os.path.join(path, 'checkpoint')
+        if os.path.exists(marker):
+            with open(marker) as f:
+                name = json.load(f)['model_checkpoint_path']
+            return os.path.join(path, name)
+        cands = sorted([p for p in os.listdir(path) if p.startswith('model-') and p.endswith('.npz')],
+                       key=lambda p: int(p[6:-4]))
+        if not cands:
+            raise IOError('no checkpoint in %s' % path)
+        return os.path.join(path, cands[-1])
+
+    # Restore last checkpoint of the current graph using the total path (network.py:139-140)
+    def restore_model(self, path):
+        g = get_default_graph()
+        data = np.load(self._latest_checkpoint(path))
+        for name in self.saver:
+            key = name.replace('/', '.')
+            if key not in data.files:
+                raise KeyError('variable %s not found in checkpoint %s' % (name, path))
+            v = g.variables[name]
+            v.data.copy_(torch.from_numpy(data[key]).to(v.device))
+            g.initialized.add(name)
+
+    def restore_last_checkpoint(self):
+        self.restore_model(self._dir())
+
+    def init_all(self):
+        g = get_default_graph()
+        g.initialized.update(g.variables.keys())      # variables are materialised with their initial value
+
+    def non_initialized_variables(self):
+        g = get_default_graph()
+        return [n for n in g.variables if n not in g.initialized]
+
+    def initialize_non_init(self):
+        names = self.non_initialized_variables()
+        print('not init: ', names)
+        get_default_graph().initialized.update(names)
+
+    @scope
+    def optimize(self):
+        print('Train the following variables :', [v.ams_name for v in self.trainable_variables])
+        g = get_default_graph()
+        for v in g.global_variables():
+            v.requires_grad_(False)
+        opt = FlatOptimizer(self.trainable_variables, self.my_opt, self.learning_rate, self.decay_epoch,
+                            self.gradient_clip, self.dist)
+        self.optimizer = opt
+        self.increment_epoch = opt.increment_epoch
+        g.summaries['optimize/learning_rate'] = Node('learning_rate', lambda run: opt.learning_rate())
+        return opt
+
+    def sdr_improvement(self, s_target, s_approx, with_perm=False):
+        """network.py:196-221 -- built by models that own a waveform output (Adapt.back, postprocessing)."""
+        from ams_hip import losses_host
+        return losses_host.sdr_improvement(self, s_target, s_approx, with_perm)
+
+    # --------------------------------------------------------------- checkpoints
+    def save(self, step):
+        path = os.path.join(self._dir(), 'model')
+        if self.dist is None or self.dist.rank == 0:
+            g = get_default_graph()
+            os.makedirs(self._dir(), exist_ok=True)
+            arrays = {n.replace('/', '.'): g.variables[n].detach().cpu().numpy() for n in self.saver}
+            fname = 'model-%d.npz' % step
+            np.savez(os.path.join(self._dir(), fname), **arrays)
+            with open(os.path.join(self._dir(), 'checkpoint'), 'w') as f:
+                json.dump({'model_checkpoint_path': fname}, f)
+        return path
+
+    # --------------------------------------------------------------- session-facing methods
+    def _feeds(self, feed_dict, training):
+        feeds = dict(feed_dict)
+        feeds[self.training] = training
+        return Run(feeds, training)
+
+    def _summaries(self, run, keys):
+        g = get_default_graph()
+        out = {}
+        for k in keys or []:
+            v = g.summaries[k].value(run)
+            out[k] = float(v) if not torch.is_tensor(v) else float(v.detach().reshape(-1)[0].item())
+        return out
+
+    def train(self, feed_dict, step):
+        run = self._feeds(feed_dict, True)
+        opt = self.optimize
+        opt.zero_grad()
+        cost = self.cost_model.value(run)
+        cost.reshape(-1)[0].backward()
+        opt.step()
+        if self.summaries_enabled and getattr(self, 'merged_train', None):
+            with torch.no_grad():
+                self.train_writer.add(step, self._summaries(run, self.merged_train))
+        self.last_run = run
+        return cost.detach().reshape(-1)[0]
+
+    def infer(self, feed_dict, step):
+        run = self._feeds(feed_dict, False)
+        with torch.no_grad():
+            return [self.x_mix.value(run), self.x_non_mix.value(run), self.output.value(run)]
+
+    def improvement(self, feed_dict, step):
+        run = self._feeds(feed_dict, False)
+        with torch.no_grad():
+            return [self.x_mix.value(run), self.x_non_mix.value(run), self.sdr_imp.value(run)]
+
+    def valid_batch(self, feed_dict, step):
+        run = self._feeds(feed_dict, False)
+        with torch.no_grad():
+            cost = self.cost_model.value(run)
+            if getattr(self, 'merged_valid', None) and self.summaries_enabled:
+                self.valid_writer.add(step, self._summaries(run, self.merged_valid))
+        return float(cost.reshape(-1)[0].item())
+
+    def get_embeddings(self, feed_dict):
+        run = self._feeds(feed_dict, False)
+        with torch.no_grad():
+            return self.prediction.value(run)
+
+    def test_batch(self, feed_dict):
+        run = self._feeds(feed_dict, False)
+        with torch.no_grad():
+            return float(self.cost_model.value(run).reshape(-1)[0].item())
+
+    def test(self, feed_dict):
+        run = self._feeds(feed_dict, True)
+        with torch.no_grad():
+            return self.y.value(run)
+
+    def add_valid_summary(self, val, step):
+        self.valid_writer.add(step, {'Valid Cost': float(val)})
+
+    def freeze_all_with(self, prefix):
+        self.trainable_variables = [v for v in self.trainable_variables if prefix not in v.ams_name]
+
+    def freeze_all_except(self, *prefix):
+        to_train = []
+        for var in self.trainable_variables:
+            for p in prefix:
+                if p in var.ams_name:
+                    to_train.append(var)
+                    break
+        self.trainable_variables = to_train
+
+    @classmethod
+    def load(cls, path, modified_args):
+        # Load parameters used for the desired model to load (network.py:291-306)
+        params_path = os.path.join(path, 'params')
+        with open(params_path) as f:
+            args = json.load(f)
+            keys_to_update = ['learning_rate', 'epochs', 'batch_size', 'chunk_size', 'nb_speakers',
+                              'regularization', 'overlap_coef', 'loss', 'beta', 'model_folder', 'type', 'pretraining',
+                              'with_silence', 'end_assign', 'beta_kmeans', 'nb_tries', 'nb_steps', 'threshold', 'optimizer',
+                              'men', 'women', 'recurrent_dropout', 'recurrent_dropout_enhance']
+            to_modify = {key: modified_args[key] for key in keys_to_update if key in modified_args.keys()}
+            to_modify.update({key: val for key, val in modified_args.items() if key not in args.keys()})
+        args.update(to_modify)
+        print("LOADED = ", {k: v for k, v in args.items() if _jsonable(v)})
+        return cls(**args)
+
+    def finish_construction(self):
+        self.trainable_variables = get_default_graph().global_variables()
+
+
+def _jsonable(v):
+    try:
+        json.dumps(v)
+        return True
+    except (TypeError, ValueError):
+        return False
+
+
+from models.Kmeans_2 import KMeans  # noqa: E402  (reference import order, network.py:311)
+
+
+class Separator(Network):
+
+    def __init__(self, plugged=False, *args, **kwargs):
+        super(Separator, self).__init__(plugged, *args, **kwargs)
+
+        self.num_speakers = kwargs['tot_speakers']
+        self.layer_size = kwargs['layer_size']
+        self.embedding_size = kwargs['embedding_size']
+        self.normalize = kwargs['no_normalize']
+        self.nb_layers = kwargs['nb_layers']
+        self.a = kwargs['mask_a']
+        self.b = kwargs['mask_b']
+        self.rdropout = kwargs['recurrent_dropout']
+
+        # Preproc
+        self.normalize_input = kwargs['normalize_separator']
+        self.abs_input = kwargs['abs_input']
+        self.pre_func = kwargs['pre_func']
+        self.silent_threshold = kwargs['silence_mask_db']
+
+        # Loss Parameters
+        self.loss_with_silence = kwargs['silence_loss']
+        self.threshold_silence_loss = kwargs['threshold_silence_loss']
+        self.function_mask = kwargs['function_mask']
+
+        # Kmeans Parameters
+        self.beta = kwargs['beta_kmeans']
+        self.threshold = kwargs['threshold']
+        self.with_silence = kwargs['with_silence']
+        self.nb_tries = kwargs['nb_tries']
+        self.nb_steps = kwargs['nb_steps']
+
+        # Negative Sampling for L41
+        self.sampling = kwargs['sampling']
+        self.ns_rate = kwargs['ns_rate']
+        self.ns_method = kwargs['ns_method']
+
+        self.add_dilated = kwargs['add_dilated']
+        if self.add_dilated:
+            raise NotImplementedError('--add_dilated (experimental dilated front, network.py:527-551) is out of scope')
+
+        self.graph = get_default_graph()
+        self.plugged = plugged
+        # If the Separator is not independant but using a front layer (network.py:357-400)
+        if self.plugged:
+            self.F = kwargs['filters']
+            g = self.graph
+            self.training = g.get_tensor_by_name('inputs/is_training:0')
+            front = g.get_tensor_by_name('front/output:0')
+            non_mix_in = g.get_tensor_by_name('inputs/non_mix_input:0')
+            self.x_non_mix = non_mix_in
+            self.x_mix = g.get_tensor_by_name('inputs/mix_input:0')
+            S, Fq = self.S, self.F
+
+            with g.variable_scope('split_front'):
+                def _x(run):
+                    B = non_mix_in.value(run).shape[0]
+                    return front.value(run)[:B]                          # [B, T, N] signed mixture representation
+                self.X = Node('X', _x)
+                x_split = self.X
+                self.X_input = Node('X_input', lambda run: x_split.value(run))     # tf.identity(self.X), network.py:371
+
+                def _xnm(run):
+                    B = non_mix_in.value(run).shape[0]
+                    return front.value(run)[B:]                          # rows (b,s): [B*S, T, N]
+                self.X_non_mix_rows = Node('X_non_mix_rows', _xnm)
+                self.X_non_mix = Node('X_non_mix', lambda run: self.X_non_mix_rows.value(run).reshape(
+                    -1, S, self.X_non_mix_rows.value(run).shape[1], Fq).permute(0, 2, 3, 1))
+
+            with g.variable_scope('create_masks'):
+                def _y(run):
+                    rows = self.X_non_mix_rows.value(run)
+                    B = rows.shape[0] // S
+                    y = K.make_masks(rows, B, S, self.a, self.b, True)  # [B, TF, S]
+                    return self._weight_masks(y, run).reshape(B, rows.shape[1], Fq, S)
+                self.y = Node('y', _y)
+
+            self.I = g.get_tensor_by_name('inputs/indicies:0')
+        else:
+            # STFT hyperparams
+            self.window_size = kwargs['window_size']
+            self.hop_size = kwargs['hop_size']
+            self.F = kwargs['window_size'] // 2 + 1
+
+    def _weight_masks(self, y, run):
+        """network.py:381-396: magnitude-weighted masks / silence loss mask (torch glue, off the headline path)."""
+        if self.function_mask in ('linear', 'sqrt', 'square') or self.loss_with_silence:
+            X = self.X.value(run)
+            B = X.shape[0]
+            ax = X.abs().reshape(B, -1)
+            mx = ax.max(dim=1, keepdim=True)[0]
+            if self.function_mask == 'linear':
+                y = y * (ax / mx).unsqueeze(2)
+            elif self.function_mask == 'sqrt':
+                y = y * torch.sqrt(ax / mx).unsqueeze(2)
+            elif self.function_mask == 'square':
+                y = y * torch.square(ax / mx).unsqueeze(2)
+            if self.loss_with_silence:
+                y = y * (log10(mx / ax) < self.threshold_silence_loss).float().unsqueeze(2)
+        return y
+
+    def init_separator(self):
+        if self.plugged:
+            if self.abs_input:
+                src = self.X
+                self.X = Node('abs_input', lambda run: src.value(run).abs(), register=False)
+            if self.normalize_input == '01':
+                self.normalization01
+            elif self.normalize_input == 'meanstd':
+                self.normalization_mean_std
+            self.prediction
+        else:
+            # STFT
+            self.preprocessing
+            if self.pre_func in ('sqrt', 'log'):
+                src, fn = self.X, self.pre_func
+                self.X = Node('pre_func', lambda run: torch.sqrt(src.value(run)) if fn == 'sqrt'
+                              else log10(src.value(run) + 1e-12), register=False)
+            if self.normalize_input == '01':
+                self.normalization01
+            elif self.normalize_input == 'meanstd':
+                self.normalization_mean_std
+            if self.silent_threshold > 0:
+                src, thr = self.X, self.silent_threshold
+
+                def _sil(run):
+                    X = src.value(run)
+                    mx = X.amax(dim=(1, 2), keepdim=True)
+                    return (mx - X < thr / 20.).float() * X
+                self.X = Node('silent_mask', _sil, register=False)
+            self.prediction
+            if self.args['model_folder'] is None:
+                self.cost_model = self.cost
+                self.finish_construction()
+                self.optimize
+
+    def add_enhance_layer(self):
+        self.separate
+        self.enhance
+        self.cost_model = self.enhance_cost
+        self.finish_construction()
+        self.freeze_all_except('enhance')
+        self.optimize
+
+    def add_finetuning(self):
+        self.separate
+        self.enhance
+        self.postprocessing
+        self.cost_finetuning
+        self.cost_model = self.cost_finetuning
+        self.finish_construction()
+        to_train = []
+        for var in self.trainable_variables:
+            for p in self.args['train']:
+                if p in var.ams_name:
+                    to_train.append(var)
+        self.trainable_variables = to_train
+        self.optimize
+
+    @scope
+    def preprocessing(self):
+        from ams_hip import stft_host
+        return stft_host.build_preprocessing(self)
+
+    @scope
+    def normalization01(self):
+        src = self.X
+
+        def _n(run):
+            X = src.value(run)
+            mn = X.amin(dim=(1, 2), keepdim=True)
+            mx = X.amax(dim=(1, 2), keepdim=True)
+            return (X - mn) / (mx - mn)
+        self.X = Node('X01', _n)
+        return self.X
+
+    @scope
+    def normalization_mean_std(self):
+        src = self.X
+
+        def _n(run):
+            X = src.value(run)
+            m = X.mean(dim=(1, 2), keepdim=True)
+            v = ((X - m) ** 2).mean(dim=(1, 2), keepdim=True)
+            return (X - m) / torch.sqrt(v)
+        self.X = Node('Xms', _n)
+        return self.X
+
+    @scope
+    def prediction(self):
+        pass
+
+    @scope
+    def separate(self):
+        from ams_hip import separate_host
+        return separate_host.build_separate(self, KMeans)
+
+    @scope
+    def postprocessing(self):
+        from ams_hip import stft_host
+        return stft_host.build_postprocessing(self)
+
+    @scope
+    def enhance(self):
+        from ams_hip import separate_host
+        return separate_host.build_enhance(self, BLSTM, Conv1D, f_props)
+
+    @scope
+    def enhance_cost(self):
+        from ams_hip import separate_host
+        return separate_host.build_enhance_cost(self)
+
+    @scope
+    def cost_finetuning(self):
+        from ams_hip import separate_host
+        return separate_host.build_cost_finetuning(self, self.postprocessing)

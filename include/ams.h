@@ -79,12 +79,13 @@ ams_status ams_colsum(const float* x, float* out, long rows, int cols, long ld, 
 
 /* ---- K14  deep-clustering loss      models/dpcl.py:41-87 ----
  * V [B,TF,E], Y [B,TF,S]; out[0] = cost, out[1..3] = the reference's summaries '1','2','3'.
- * bwd: inv != NULL fuses the l2-normalise backward (writes dU), else writes dV. */
+ * bwd: inv != NULL fuses the l2-normalise backward (writes dU), else writes dV; upstream = optional device scalar
+ * d loss / d cost. */
 size_t ams_dpcl_workspace_bytes(int B, long TF, int E, int S);
 ams_status ams_dpcl_loss_fwd(const float* V, const float* Y, float* out, int B, long TF, int E, int S, void* ws, size_t ws_bytes,
                              void* stream);
-ams_status ams_dpcl_loss_bwd(const float* V, const float* Y, const float* inv, float* dU, int B, long TF, int E, int S,
-                             const void* ws, void* stream);
+ams_status ams_dpcl_loss_bwd(const float* V, const float* Y, const float* inv, const float* upstream, float* dU, int B, long TF,
+                             int E, int S, const void* ws, void* stream);
 
 /* ---- K24  optimizers     models/network.py:181-194, utils/ops.py:686-703 ---- */
 ams_status ams_opt_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, long n, float lr_t, float beta1,

@@ -64,7 +64,7 @@ def test_gemm_strided_and_masked(ops):
         for t in range(1, T):
             ref += np.outer(out[b * T + t - 1, :H], dZ[b * T + t, :4 * H])
     o, z = dev(out), dev(dZ)
-    res = torch.empty((H, 4 * H), device='cuda')
+    res = torch.empty((H, 4 * H), device='cuda', dtype=torch.float32)
     ops.gemm(o.view(-1), z.view(-1)[8 * H:], transA=True, out=res, M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H, ldc=4 * H,
              mask=(T, T - 1))
     assert rel(host(res), ref) < TOL
@@ -165,13 +165,13 @@ def test_optimizers(ops):
         b1p *= 0.9
         b2p *= 0.99
     assert rel(host(p), pr) < 1e-5
-    p, ms = dev(p0), torch.ones(n, device='cuda')
+    p, ms = dev(p0), torch.ones(n, device='cuda', dtype=torch.float32)
     r, pr = ooptim.RMSProp(0.01), p0.copy()
     for k in range(3):
         r.apply([pr], [g[k]])
         ops.opt_rmsprop(p, dev(g[k]), ms, 0.01)
     assert rel(host(p), pr) < 1e-5
-    p, acc = dev(p0), torch.zeros(n, device='cuda')
+    p, acc = dev(p0), torch.zeros(n, device='cuda', dtype=torch.float32)
     r, pr = ooptim.Momentum(0.01), p0.copy()
     for k in range(3):
         r.apply([pr], [g[k]])

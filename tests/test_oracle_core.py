@@ -7,12 +7,11 @@ import torch.nn.functional as F
 
 from oracle import front, stft, blstm, dense, dpcl, l41, separate, losses, optim, step
 
-torch.set_default_dtype(torch.float64)
 RNG = np.random.RandomState(0)
 
 
 def t(x):
-    return torch.from_numpy(np.ascontiguousarray(x))
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.float64 if np.asarray(x).dtype.kind == 'f' else None))
 
 
 def rel(a, b):
@@ -133,7 +132,7 @@ def test_stft_vs_torch_and_istft():
     R, L, W, hop = 2, 2048, 256, 128
     x = RNG.randn(R, L)
     s = stft.stft(x, W, hop)
-    ref = torch.stft(t(x), W, hop, W, window=torch.hann_window(W, periodic=True), center=False, return_complex=True)
+    ref = torch.stft(t(x), W, hop, W, window=torch.hann_window(W, periodic=True, dtype=torch.float64), center=False, return_complex=True)
     assert rel(s.real, ref.permute(0, 2, 1).real.numpy()) < 1e-12
     assert rel(s.imag, ref.permute(0, 2, 1).imag.numpy()) < 1e-10
     rec = stft.istft(np.abs(s), np.angle(s), W, hop)
@@ -153,7 +152,7 @@ def test_stft_vs_torch_and_istft():
 # ---------------------------------------------------------------- BLSTM
 def _torch_lstm_from_tf(K, b, D, H):
     """TF kernel [D+H,4H] gates (i,j,f,o) -> torch nn.LSTM weights gates (i,f,g,o); +1 forget bias."""
-    lstm = torch.nn.LSTM(D, H, batch_first=True)
+    lstm = torch.nn.LSTM(D, H, batch_first=True).double()
     perm = np.concatenate([np.arange(0, H), np.arange(2 * H, 3 * H), np.arange(H, 2 * H), np.arange(3 * H, 4 * H)])
     Kp, bp = K[:, perm], b[perm].copy()
     bp[H:2 * H] += 1.0
@@ -198,7 +197,7 @@ def test_dense_l2norm_dpcl_grads():
     u = xt @ Wt + bt
     v = F.normalize(u.reshape(B, T, Fq, E), dim=3, eps=1e-6)       # eps on the norm == 1e-12 on the sum of squares
     Vt, Yt = v.reshape(B, T * Fq, E), t(Y)
-    cnt = Yt.transpose(1, 2) @ torch.ones(B, T * Fq, 1)
+    cnt = Yt.transpose(1, 2) @ torch.ones(B, T * Fq, 1, dtype=torch.float64)
     D = 1 / torch.sqrt(Yt @ cnt)
     DV, DY = D * Vt, D * Yt
     cost = (torch.linalg.matrix_norm(Vt.transpose(1, 2) @ DV) - 2 * torch.linalg.matrix_norm(Vt.transpose(1, 2) @ DY)
@@ -277,8 +276,8 @@ def test_amsgrad_matches_formula():
     assert rel(p, q) < 1e-14
     tp = torch.nn.Parameter(t(p0.copy()))
     o = torch.optim.RMSprop([tp], lr=0.01, alpha=0.9, eps=0.0)
-    o.state[tp]['step'] = torch.tensor(0.)
-    o.state[tp]['square_avg'] = torch.ones(5)
+    o.state[tp]['step'] = torch.tensor(0., dtype=torch.float64)
+    o.state[tp]['square_avg'] = torch.ones(5, dtype=torch.float64)
     pr = p0.copy()
     r = optim.RMSProp(0.01, eps=0.0)
     for k in range(3):
