@@ -30,6 +30,44 @@ def _chk(*ts):
             raise AmsError('ams_hip ops need contiguous fp32 tensors, got %s %s' % (t.dtype, tuple(t.stride())))
 
 
+class _Profile(object):
+    """HIP-event timing of individual launches on the launching stream (bench.py `roofline`).  Events are
+    recorded around a launch only when enabled; elapsed times are read after the timed region."""
+
+    def __init__(self):
+        self.reset(False)
+
+    def reset(self, enabled=False):
+        self.enabled = enabled
+        self.records = []            # (start_event, stop_event, flops, bytes, tag)
+
+    def begin(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        return e
+
+    def end(self, start, flops=0.0, nbytes=0.0, tag=''):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record(torch.cuda.current_stream())
+        self.records.append((start, e, flops, nbytes, tag))
+
+    def summary(self, tag=None):
+        torch.cuda.synchronize()
+        ms = fl = by = 0.0
+        n = 0
+        for s, e, f, b, t in self.records:
+            if tag is not None and t != tag:
+                continue
+            ms += s.elapsed_time(e)
+            fl += f
+            by += b
+            n += 1
+        return {'launches': n, 'ms': ms, 'flops': fl, 'bytes': by}
+
+
+PROFILE = _Profile()
+
+
 def _ws(nbytes, like):
     n = max(int(nbytes), 16)
     return torch.empty((n + 3) // 4, dtype=torch.float32, device=like.device)
@@ -104,8 +142,11 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False
             raise AmsError('gemm: operands must be fp32 device tensors')
     nb = lib.ams_gemm_workspace_bytes(M, N, K)
     ws = _ws(nb, A) if nb else None
+    ev = PROFILE.begin() if PROFILE.enabled else None
     check(lib.ams_gemm_f32(int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc, _p(bias), int(accumulate),
                            mask[0], mask[1], _p(ws), nb, _s()), 'ams_gemm_f32')
+    if ev is not None:
+        PROFILE.end(ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N), 'gemm')
     return out
 
 

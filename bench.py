@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""Headline benchmark: mixtures/sec of the front_DPCL training step (2 speakers, 256-filter adaptive front
++ 3xBLSTM(600) deep clustering, batch 64 per GPU) -- BASELINE.json `metric`, SURVEY.md 8(d) cfg3(i).
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = forward + backward + gradient all-reduce (N>1) + AMSGrad update on one synthetic batch that is
+already resident in HBM.  Rank 0 prints ONE JSON line.  The `roofline` object is measured with HIP events
+around every launch of the dominant kernel inside the timed region; `cpu_baseline` times the numpy oracle
+(float32) on the host cores for a bounded sample of the same workload (rank 0, N=1 only).
+"""
+from __future__ import print_function
+
+import argparse
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, 'adaptive-multispeaker-separation_amd')
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+HBM_PEAK_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=64, help='mixtures per GPU (weak scaling)')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=4)
+    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--graph', type=int, default=int(os.environ.get('AMS_BENCH_GRAPH', '0')),
+                    help='replay fwd+bwd from a captured hipGraph')
+    ap.add_argument('--chunk', type=int, default=20480)
+    ap.add_argument('--filters', type=int, default=256)
+    ap.add_argument('--quiet', action='store_true')
+    return ap.parse_args()
+
+
+def build(args, tmp):
+    os.environ.setdefault('AMS_LOG_DIR', os.path.join(tmp, 'log'))
+    from ams_hip import testing
+    from models.dpcl import DPCL
+    from utils.trainer import Front_Separator_Trainer
+    folder, params = testing.make_pretrained_adapt(os.path.join(tmp, 'pre_rank%s' % os.environ.get('RANK', '0')),
+                                                   window_size=1024, filters=args.filters, hop_size=256,
+                                                   chunk_size=args.chunk, batch_size=args.batch, nb_speakers=2)
+    a = dict(params)
+    a.update(testing.SEPARATOR_DEFAULTS)
+    a.update(model_folder=folder, model_previous=None, batch_size=args.batch, learning_rate=1e-3, optimizer='Adam',
+             pretraining=False, layer_size=600, nb_layers=3, embedding_size=40, synthetic_batches=2, synthetic_pool=2,
+             no_summaries=True)
+    trainer = Front_Separator_Trainer(DPCL, 'front_DPCL', **a)
+    dist, tfds = trainer.prepare()
+    # benches use the SURVEY 8(d) dense init U(+-0.05) (the reference's +-12 range is kept for parity fixtures)
+    import torch
+    g = trainer.graph
+    gen = torch.Generator(device='cpu').manual_seed(9)
+    W = g.variables['prediction/W']
+    W.data.copy_((torch.rand(W.shape, generator=gen) * 0.1 - 0.05).to(W.device))
+    trainer._sync_replicas(dist)
+    return trainer, tfds, dist
+
+
+def cpu_baseline(args):
+    """float32 numpy oracle of the same step on the host cores (kind 'port')."""
+    import numpy as np
+    from oracle import step as ostep, optim as ooptim
+    from data.dataset import synthetic_mixtures
+    B = args.cpu_batch
+    rng = np.random.RandomState(1)
+    P = ostep.init_params(rng, np.float32, front_W=1024, N=args.filters, D_in=args.filters, layer_size=600, nb_layers=3,
+                          E=40, F=args.filters, conv1d_scale=0.05)
+    mix, nm, _ = synthetic_mixtures(np.arange(B), 2, args.chunk)
+    names = sorted(n for n in P if n.startswith('prediction/'))
+    opt = ooptim.AMSGrad(1e-3)
+    times = []
+    for _ in range(args.cpu_steps + 1):
+        t0 = time.time()
+        cost, grads, _, _ = ostep.front_dpcl_loss(mix, nm, P, 256, 3, 40)
+        opt.apply([P[n] for n in names], [grads[n].astype(np.float32) for n in names])
+        times.append(time.time() - t0)
+    t = float(np.median(times[1:]))
+    try:
+        import threadpoolctl
+        cores = max([p.get('num_threads', 1) for p in threadpoolctl.threadpool_info()] + [1])
+    except Exception:
+        cores = os.cpu_count()
+    return {'value': B / t, 'unit': 'mixtures/s', 'cores': int(cores), 'kind': 'port',
+            'sample': 'numpy float32 oracle (not TensorFlow), same front_DPCL step, batch %d, median of %d steps, %.1f s/step'
+                      % (B, args.cpu_steps, t)}
+
+
+def main():
+    args = parse()
+    import torch
+    from ams_hip import ops
+    tmp = tempfile.mkdtemp(prefix='ams_bench_')
+    trainer, tfds, dist = build(args, tmp)
+    model, g = trainer.model, trainer.graph
+    rank, world = dist.rank, dist.world_size
+    if args.gpus != world and rank == 0 and not args.quiet:
+        print('note: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)' % (args.gpus, world), file=sys.stderr)
+
+    with g.as_default():
+        feed = {tfds.handle: tfds.get_handle(tfds.TRAIN), tfds.chunk_size: args.chunk}
+
+        def one_step(i):
+            return model.train(feed, i)
+
+        for i in range(args.warmup):
+            c = one_step(i)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        ops.PROFILE.reset(enabled=True)
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            c = one_step(args.warmup + i)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0
+        ops.PROFILE.enabled = False
+        last_cost = float(c)
+
+    el = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
+    dist.all_reduce_max(el)
+    elapsed = float(el.item())
+    B, L, N, T, H, E, S = args.batch, args.chunk, args.filters, -(-args.chunk // 256), 300, 40, 2
+    value = world * B * args.steps / elapsed
+
+    # ---- roofline of the dominant kernel: the fp32 MFMA GEMM family (dense 600->F*E, its two gradients, LSTM projections)
+    prof = ops.PROFILE.summary()
+    roof = None
+    if prof['launches']:
+        avg_ms = prof['ms'] / prof['launches']
+        flops_per_launch = prof['flops'] / prof['launches']
+        achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+        roof = {'bound': 'mfma', 'kernel': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32)', 'achieved': round(achieved, 2),
+                'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+                'traffic': None, 'launches_per_step': prof['launches'] / args.steps,
+                'avg_launch_ms': round(avg_ms, 4), 'share_of_step': round(prof['ms'] / args.steps / (elapsed / args.steps * 1e3), 3)}
+
+    out = {
+        'metric': 'mixtures/sec training throughput (2-spk, 256-filter adapt+BLSTM-DPCL)',
+        'value': round(value, 2), 'unit': 'mixtures/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'front_DPCL training step (SURVEY 8d cfg3(i)): frozen adaptive front W=1024 hop=256 N=%d -> '
+                               '3xBLSTM(600) -> dense 600->%d -> l2norm -> DPCL loss, fwd+bwd+AMSGrad' % (N, N * E),
+                   'batch_per_gpu': B, 'global_batch': B * world, 'nb_speakers': S, 'chunk_size': L, 'frames': T,
+                   'parallelism': 'dp%d' % world, 'hip_graph': bool(args.graph)},
+        'roofline': roof, 'final_cost': last_cost,
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(args)
+        print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

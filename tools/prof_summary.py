@@ -1,0 +1,23 @@
+#!/usr/bin/env python
+"""Summarise a rocprofv3 --kernel-trace --stats run (rocpd sqlite .db) as a text table for profiles/."""
+import sqlite3
+import sys
+
+
+def main(db, out, note=''):
+    c = sqlite3.connect(db)
+    rows = list(c.execute("select name, count(*), sum(duration), avg(duration), min(duration), max(duration) from kernels "
+                          "group by name order by sum(duration) desc"))
+    tot = float(sum(r[2] for r in rows))
+    with open(out, 'w') as f:
+        f.write('# rocprofv3 --kernel-trace --stats summary (durations in microseconds; source: %s)\n' % db.split('/')[-1])
+        if note:
+            f.write('# %s\n' % note)
+        f.write('# total kernel time: %.3f ms\n' % (tot / 1e6))
+        f.write('%-100s %8s %12s %10s %10s %10s %6s\n' % ('kernel', 'calls', 'total_us', 'avg_us', 'min_us', 'max_us', 'pct'))
+        for n, k, s, a, mn, mx in rows:
+            f.write('%-100s %8d %12.1f %10.2f %10.2f %10.2f %6.2f\n' % (n[:100], k, s / 1e3, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / tot))
+
+
+if __name__ == '__main__':
+    main(sys.argv[1], sys.argv[2], ' '.join(sys.argv[3:]))
