@@ -112,6 +112,52 @@ class DPCLLoss(Function):
         return ops.dpcl_loss_bwd(V, Y, ws, upstream=_c(dout)), None
 
 
+class L2NormKeep(Function):
+    """L2Norm that also hands back the inverse norms, so a loss can differentiate w.r.t. the PRE-normalised
+    tensor in one fused kernel (see DPCLLossFromU).  Returns (v [..., F, E], inv [rows])."""
+
+    @staticmethod
+    def forward(ctx, u, E):
+        v, inv = ops.l2norm_fwd(u, E)
+        ctx.save_for_backward(v, inv)
+        ctx.E = E
+        ctx.mark_non_differentiable(inv)
+        return v.view(u.shape[:-1] + (u.shape[-1] // E, E)), inv
+
+    @staticmethod
+    def backward(ctx, dv, _dinv):
+        v, inv = ctx.saved_tensors
+        return ops.l2norm_bwd(v, inv, _c(dv).view(v.shape), ctx.E), None
+
+
+class DPCLLossFromU(Function):
+    """DPCL loss whose autograd input is u (dense output BEFORE l2-normalise): the backward kernel applies
+    d loss/dV and the l2norm Jacobian in one pass over V (models/dpcl.py:41-87 + utils/ops.py:323-324)."""
+
+    @staticmethod
+    def forward(ctx, u, V, inv, Y):
+        out, ws = ops.dpcl_loss_fwd(V, Y)
+        ctx.save_for_backward(V, inv, Y, ws)
+        ctx.ushape = u.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        V, inv, Y, ws = ctx.saved_tensors
+        du = ops.dpcl_loss_bwd(V, Y, ws, inv=inv, upstream=_c(dout))
+        return du.view(ctx.ushape), None, None, None
+
+
+def l2norm_keep(u, E):
+    return L2NormKeep.apply(_c(u), E)
+
+
+def dpcl_loss_from_u(u, V, inv, Y):
+    B = V.shape[0]
+    E = V.shape[-1]
+    return DPCLLossFromU.apply(u, _c(V.detach()).reshape(B, -1, E), inv, _c(Y))
+
+
 def front_filter(w, bases):
     return FrontFilter.apply(w, bases)
 

@@ -207,14 +207,14 @@ ams_status ams_l2norm_bwd(const float* v, const float* inv, const float* dv, flo
 }
 
 size_t ams_colsum_workspace_bytes(long rows, int cols) {
-    const int nparts = ceil_div(rows, 256);
+    const int nparts = ceil_div(rows, 32);
     return (size_t)nparts * cols * sizeof(float);
 }
 
 ams_status ams_colsum(const float* x, float* out, long rows, int cols, long ld, int accumulate, void* ws, size_t ws_bytes,
                       void* stream) {
     AMS_REQUIRE(x && out && rows > 0 && cols > 0 && ws);
-    const int rpb = 256;
+    const int rpb = 32;
     const int nparts = ceil_div(rows, rpb);
     if ((size_t)nparts * cols * sizeof(float) > ws_bytes) return AMS_E_WORKSPACE_TOO_SMALL;
     hipStream_t st = (hipStream_t)stream;

@@ -16,6 +16,7 @@
 // Split-K (gridDim.z) writes fp32 partial slabs to a caller workspace; a second kernel reduces them in
 // fixed order (deterministic) and applies bias / accumulate.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -262,18 +263,36 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* _
     }
 }
 
+// Split-K factor from a small cost model calibrated on MI355X (scratch sweep, round 1):
+//   t(s) = n * (k_iters * 1.02us + 5us) / occ(n)  +  (s+1)*M*N*4 B / 2.5 TB/s        [s > 1]
+// n = ceil(tiles*s/256) workgroups end up on the busiest CU (equal-work workgroups time-share a CU's four
+// SIMDs, so the launch ends when that CU drains); occ(n) discounts CUs holding only 1-3 workgroups, whose
+// barrier stalls are not covered by a neighbour's MFMAs; the last term is the fp32 partial-slab round trip.
+inline int choose_splits(int M, int N, int K) {
+    const int tiles = ceil_div(M, BM) * ceil_div(N, BN);
+    int best = 1;
+    double best_t = 1e30;
+    for (int s = 1; s <= 32; ++s) {
+        if (s > 1 && K / s < 128) break;
+        const int kps = ceil_div(ceil_div(K, s), BK) * BK;
+        const int s2 = ceil_div(K, kps);
+        const int n = ceil_div((long)tiles * s2, 256);
+        const double occ = n <= 1 ? 0.62 : (n == 2 ? 0.80 : (n == 3 ? 0.92 : 1.0));
+        double t = n * ((kps / BK) * 1.024 + 5.0) / occ;
+        if (s2 > 1) t += (double)(s2 + 1) * M * N * 4.0 / 2.5e6;
+        if (t < best_t - 1e-9) { best_t = t; best = s2; }
+    }
+    return best;
+}
+
 template <int AMODE, int BMODE>
 ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st) {
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
-    // split K when the tile count alone cannot fill 256 CUs and K is long
     int splits = 1;
-    if (ws && tiles < 192 && g.K >= 512) {
-        splits = (512 + tiles - 1) / tiles;
-        const int max_by_k = g.K / 256;
-        if (splits > max_by_k) splits = max_by_k;
-        if (splits > 32) splits = 32;
+    if (ws) {
+        splits = choose_splits(g.M, g.N, g.K);
+        if (const char* f = getenv("AMS_GEMM_SPLITS")) { const int v = atoi(f); if (v > 0) splits = v; }   // tuning aid
         while (splits > 1 && (size_t)splits * g.M * g.N * sizeof(float) > ws_bytes) --splits;
-        if (splits < 1) splits = 1;
     }
     int kps = ceil_div(g.K, splits);
     kps = ceil_div(kps, BK) * BK;
@@ -303,11 +322,8 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 extern "C" {
 
 size_t ams_gemm_workspace_bytes(int M, int N, int K) {
-    const int tiles = ceil_div(M, BM) * ceil_div(N, BN);
-    if (tiles >= 192 || K < 512) return 0;
-    int splits = (512 + tiles - 1) / tiles;
-    if (splits > K / 256) splits = K / 256;
-    if (splits > 32) splits = 32;
+    int splits = choose_splits(M, N, K);
+    if (const char* f = getenv("AMS_GEMM_SPLITS")) { const int v = atoi(f); if (v > 0) splits = v; }
     if (splits <= 1) return 0;
     return (size_t)splits * M * N * sizeof(float);
 }

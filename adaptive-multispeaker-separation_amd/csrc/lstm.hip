@@ -97,20 +97,50 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgs a) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // Epilogue operands (this thread's (batch,unit) element) are fetched FIRST so their latency hides under
+    // the recurrent product.  thread -> (batch row, unit); C/D layout: row = (lane>>4)*4 + reg, col = lane&15
+    const int bl = tid >> 4, ul = tid & 15;
+    const int b = bt * TB + bl, u = ut * TU + ul;
+    const bool live = (b < a.B && u < H);
+    float* grow = a.G + (((long)(live ? b : 0) * T + t) * 2 + dir) * (4 * H);
+    float zq[4] = {0.f, 0.f, 0.f, 0.f};
+    float c_prev = 0.f;
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) zq[q] = grow[q * H + u];
+        if (has_prev) c_prev = a.cst[(((long)b * T + tp) * 2 + dir) * H + u];
+    }
+
     if (has_prev) {
         const float* hrow = a.out + ((long)b_row * T + tp) * (2 * H) + dir * H;
         const float* pk = a.pk + (((long)dir * a.n_ut + ut) * a.n_g) * (4 * 64 * 4) + lane * 4;
-        for (int g = wave; g < a.n_g; g += 4) {
-            const float4 av = ld4_guard(hrow, g * 16 + (lane >> 4) * 4, H, b_row < a.B, vec);
-            float4 bv[4];
+        // Issue EVERY operand load of a chunk before the first MFMA: the h/U fetches are L2 round trips
+        // (~1 us) and a load->MFMA->load loop would pay that latency once per k-group.
+        constexpr int CH = 5;                          // k-groups per wave per chunk (H = 300: 19 groups / 4 waves)
+        for (int g0 = wave; g0 < a.n_g; g0 += 4 * CH) {
+            float4 av[CH], bv[CH][4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bv[q] = *reinterpret_cast<const float4*>(pk + ((long)g * 4 + q) * 256);
+            for (int i = 0; i < CH; ++i) {
+                const int g = g0 + 4 * i;
+                if (g < a.n_g) {
+                    av[i] = ld4_guard(hrow, g * 16 + (lane >> 4) * 4, H, b_row < a.B, vec);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[q].x, acc[q], 0, 0, 0);
-                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[q].y, acc[q], 0, 0, 0);
-                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv[q].z, acc[q], 0, 0, 0);
-                acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv[q].w, acc[q], 0, 0, 0);
+                    for (int q = 0; q < 4; ++q) bv[i][q] = *reinterpret_cast<const float4*>(pk + ((long)g * 4 + q) * 256);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int g = g0 + 4 * i;
+                if (g < a.n_g) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[i][q].x, acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv[i][q].y, acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bv[i][q].z, acc[q], 0, 0, 0);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv[i][q].w, acc[q], 0, 0, 0);
+                }
             }
         }
     }
@@ -118,16 +148,12 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgs a) {
     for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(&red[wave][q][lane][0]) = acc[q];
     __syncthreads();
 
-    // thread -> (batch row, unit); C/D layout: row = (lane>>4)*4 + reg, col = lane&15
-    const int bl = tid >> 4, ul = tid & 15;
-    const int b = bt * TB + bl, u = ut * TU + ul;
-    if (b >= a.B || u >= H) return;
+    if (!live) return;
     const int src_lane = (bl >> 2) * 16 + ul, src_reg = bl & 3;
-    float* grow = a.G + (((long)b * T + t) * 2 + dir) * (4 * H);
     float pre[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        float s = grow[q * H + u];
+        float s = zq[q];
 #pragma unroll
         for (int w = 0; w < 4; ++w) s += red[w][q][src_lane][src_reg];
         pre[q] = s;
@@ -136,7 +162,6 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgs a) {
     const float gg = tanhf(pre[1]);
     const float fg = 1.0f / (1.0f + expf(-(pre[2] + 1.0f)));     // forget_bias = 1.0
     const float og = 1.0f / (1.0f + expf(-pre[3]));
-    const float c_prev = has_prev ? a.cst[(((long)b * T + tp) * 2 + dir) * H + u] : 0.f;
     const float c = c_prev * fg + ig * gg;
     const float h = tanhf(c) * og;
     grow[0 * H + u] = ig;
@@ -161,52 +186,58 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgs a) {
     const int b_row = bt * TB + (lane & 15);
     const bool vec = (H % 4 == 0);
 
+    const int bl = tid >> 4, ul = tid & 15;
+    const int b = bt * TB + bl, u = ut * TU + ul;
+    const bool live = (b < a.B && u < H);
+    float* grow = a.G + (((long)(live ? b : 0) * T + t) * 2 + dir) * (4 * H);
+    float* dcp = a.dc + ((long)(live ? b : 0) * 2 + dir) * H + (live ? u : 0);
+    float dh = 0.f, ig = 0.f, gg = 0.f, fg = 0.f, og = 0.f, c = 0.f, c_prev = 0.f, dc_next = 0.f;
+    if (live) {
+        dh = a.dout[((long)b * T + t) * (2 * H) + dir * H + u];
+        ig = grow[0 * H + u]; gg = grow[1 * H + u]; fg = grow[2 * H + u]; og = grow[3 * H + u];
+        c = a.cst[(((long)b * T + t) * 2 + dir) * H + u];
+        if (has_prev) c_prev = a.cst[(((long)b * T + tp) * 2 + dir) * H + u];
+        if (has_next) dc_next = *dcp;
+    }
+
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if (has_next) {
         const float* darow = a.G + (((long)b_row * T + tn) * 2 + dir) * (4 * H);
         const float* pk = a.pk + (((long)dir * a.n_ut + ut) * a.n_g) * (64 * 4) + lane * 4;
-        int g = wave;
-        for (; g + 4 < a.n_g; g += 8) {
-            const float4 a0 = ld4_guard(darow, g * 16 + (lane >> 4) * 4, 4 * H, b_row < a.B, vec);
-            const float4 a1 = ld4_guard(darow, (g + 4) * 16 + (lane >> 4) * 4, 4 * H, b_row < a.B, vec);
-            const float4 b0 = *reinterpret_cast<const float4*>(pk + (long)g * 256);
-            const float4 b1 = *reinterpret_cast<const float4*>(pk + (long)(g + 4) * 256);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.x, b1.x, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.y, b1.y, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.z, b1.z, acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1.w, b1.w, acc1, 0, 0, 0);
-        }
-        for (; g < a.n_g; g += 4) {
-            const float4 a0 = ld4_guard(darow, g * 16 + (lane >> 4) * 4, 4 * H, b_row < a.B, vec);
-            const float4 b0 = *reinterpret_cast<const float4*>(pk + (long)g * 256);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.x, b0.x, acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.y, b0.y, acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.z, b0.z, acc0, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0.w, b0.w, acc0, 0, 0, 0);
+        constexpr int CH = 10;                         // k-groups per wave per chunk (4H = 1200: 75 groups / 4 waves = 19)
+        for (int g0 = wave; g0 < a.n_g; g0 += 4 * CH) {
+            float4 av[CH], bv[CH];
+#pragma unroll
+            for (int i = 0; i < CH; ++i) {
+                const int g = g0 + 4 * i;
+                if (g < a.n_g) {
+                    av[i] = ld4_guard(darow, g * 16 + (lane >> 4) * 4, 4 * H, b_row < a.B, vec);
+                    bv[i] = *reinterpret_cast<const float4*>(pk + (long)g * 256);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < CH; i += 2) {
+                const int g = g0 + 4 * i;
+                const bool ok0 = g < a.n_g, ok1 = (i + 1 < CH) && (g + 4 < a.n_g);
+                if (ok0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[i].x, acc0, 0, 0, 0);
+                if (ok1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i + 1].x, bv[i + 1].x, acc1, 0, 0, 0);
+                if (ok0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv[i].y, acc0, 0, 0, 0);
+                if (ok1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i + 1].y, bv[i + 1].y, acc1, 0, 0, 0);
+                if (ok0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].z, bv[i].z, acc0, 0, 0, 0);
+                if (ok1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i + 1].z, bv[i + 1].z, acc1, 0, 0, 0);
+                if (ok0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].w, bv[i].w, acc0, 0, 0, 0);
+                if (ok1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i + 1].w, bv[i + 1].w, acc1, 0, 0, 0);
+            }
         }
     }
     acc0 += acc1;
     *reinterpret_cast<f32x4*>(&red[wave][lane][0]) = acc0;
     __syncthreads();
 
-    const int bl = tid >> 4, ul = tid & 15;
-    const int b = bt * TB + bl, u = ut * TU + ul;
-    if (b >= a.B || u >= H) return;
+    if (!live) return;
     const int src_lane = (bl >> 2) * 16 + ul, src_reg = bl & 3;
-    float dh = a.dout[((long)b * T + t) * (2 * H) + dir * H + u];
 #pragma unroll
     for (int w = 0; w < 4; ++w) dh += red[w][src_lane][src_reg];
-
-    float* grow = a.G + (((long)b * T + t) * 2 + dir) * (4 * H);
-    const float ig = grow[0 * H + u], gg = grow[1 * H + u], fg = grow[2 * H + u], og = grow[3 * H + u];
-    const float c = a.cst[(((long)b * T + t) * 2 + dir) * H + u];
-    const float c_prev = has_prev ? a.cst[(((long)b * T + tp) * 2 + dir) * H + u] : 0.f;
-    float* dcp = a.dc + ((long)b * 2 + dir) * H + u;
-    const float dc_next = has_next ? *dcp : 0.f;
     const float tc = tanhf(c);
     const float d_o = dh * tc;
     const float dcv = dc_next + dh * og * (1.0f - tc * tc);

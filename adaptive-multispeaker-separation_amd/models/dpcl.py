@@ -3,7 +3,7 @@
 from ams_hip import functional as F
 from ams_hip.graph import Node, get_default_graph, scope
 from models.network import Separator
-from utils.ops import BLSTM, Conv1D, Reshape, Normalize, f_props
+from utils.ops import BLSTM, Conv1D, f_props
 
 
 class DPCL(Separator):
@@ -25,24 +25,25 @@ class DPCL(Separator):
         conv = Conv1D([1, self.layer_size, E * Fq])
         x_node = self.X
 
-        def _pred(run):
+        def _embed(run):
             x = x_node.value(run)
-            h = f_props(layers, x)
-            u = conv.f_prop(h)                                 # [B, T, F*E]  (column = f*E + e)
-            return F.l2norm(u, E)                              # Reshape + Normalize(3)
-        return Node('prediction', _pred, register=False)
+            u = conv.f_prop(f_props(layers, x))                # [B, T, F*E]  (column = f*E + e)
+            V, inv = F.l2norm_keep(u, E)                       # Reshape + Normalize(3)
+            return u, V, inv
+        self._embed = Node('embed', _embed, register=False)
+        return Node('prediction', lambda run: self._embed.value(run)[1], register=False)
 
     @scope
     def cost(self):
         # dpcl.py:41-87
-        pred, y = self.prediction, self.y
+        self.prediction
+        embed, y = self._embed, self.y
         g = get_default_graph()
 
         def _terms(run):
-            V = pred.value(run)
+            u, V, inv = embed.value(run)
             Y = y.value(run)
-            B = V.shape[0]
-            return F.dpcl_loss(V.reshape(B, -1, self.embedding_size), Y.reshape(B, -1, Y.shape[-1]))
+            return F.dpcl_loss_from_u(u, V, inv, Y.reshape(V.shape[0], -1, Y.shape[-1]))
         terms = Node('terms', _terms)
         cost = Node('cost_value', lambda run: terms.value(run)[0:1])
         g.summaries['cost/cost'] = cost

@@ -208,7 +208,54 @@ class Network(object):
             out[k] = float(v) if not torch.is_tensor(v) else float(v.detach().reshape(-1)[0].item())
         return out
 
+    # ---- hipGraph replay of forward+backward (the launch-bound inner loops: 80 recurrent steps x 6 cells x 2) ----
+    def _train_graphed(self, feed_dict, step):
+        """Capture zero_grad + forward + backward once (after 2 eager steps) and replay it; inputs are copied into
+        static buffers, the optimizer (per-step lr_t, all-reduce) stays outside the graph."""
+        st = self.__dict__.setdefault('_cg_state', {'n': 0, 'graph': None, 'stream': torch.cuda.Stream()})
+        probe = self._feeds(feed_dict, True)
+        ins = [n.value(probe) for n in (self.x_mix, self.x_non_mix, self.I)]
+        opt = self.optimize
+        side = st['stream']
+        if st['graph'] is None:
+            st['n'] += 1
+            if st['n'] <= 2:
+                # eager warm-up ON THE CAPTURE STREAM, so autograd's AccumulateGrad nodes are bound to it
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    run = self._feeds(feed_dict, True)
+                    for node, t in zip((self.x_mix, self.x_non_mix, self.I), ins):
+                        run.cache[id(node)] = t
+                    opt.zero_grad()
+                    cost = self.cost_model.value(run)
+                    cost.reshape(-1)[0].backward()
+                torch.cuda.current_stream().wait_stream(side)
+                opt.step()
+                self.last_run = run
+                return cost.detach().reshape(-1)[0]
+            st['static'] = [t.clone() for t in ins]
+            run = self._feeds(feed_dict, True)
+            for node, t in zip((self.x_mix, self.x_non_mix, self.I), st['static']):
+                run.cache[id(node)] = t
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=side):
+                opt.zero_grad()
+                cost = self.cost_model.value(run)
+                cost.reshape(-1)[0].backward()
+            st['graph'], st['cost'], st['run'] = g, cost, run
+        for dst, src in zip(st['static'], ins):
+            dst.copy_(src)
+        st['graph'].replay()
+        opt.step()
+        self.last_run = st['run']
+        return st['cost'].detach().reshape(-1)[0]
+
     def train(self, feed_dict, step):
+        if self.args.get('hip_graph'):
+            c = self._train_graphed(feed_dict, step)
+            if c is not None:
+                return c
         run = self._feeds(feed_dict, True)
         opt = self.optimize
         opt.zero_grad()
