@@ -180,3 +180,367 @@ def l2norm(u, E):
 
 def dpcl_loss(V, Y):
     return DPCLLoss.apply(_c(V), _c(Y))
+
+
+# =====================================================================================================
+# Synthesis, waveform costs, masks, STFT, L41, k-means
+# =====================================================================================================
+class SynthStrided(Function):
+    """tf.nn.conv2d_transpose stride=hop SAME (models/adapt.py:236-243): z [R,T,N], f2 [W,N] -> [R,L].
+    MFMA GEMM (z . f2^T) + gather-form overlap-add; backward = analysis conv of dout (+ its filter gradient)."""
+
+    @staticmethod
+    def forward(ctx, z, f2, hop, L):
+        R, T, N = z.shape
+        W = f2.shape[0]
+        Tn = -(-L // hop)
+        pl = max((Tn - 1) * hop + W - L, 0) // 2
+        frames = ops.gemm(z.view(R * T, N), f2, transB=True)              # [R*T, W]
+        out = ops.overlap_add(frames, R, T, W, L, hop, pl)
+        ctx.save_for_backward(z, f2)
+        ctx.hop, ctx.L = hop, L
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        z, f2 = ctx.saved_tensors
+        dout = _c(dout)
+        dz = ops.front_conv(dout, f2, ctx.hop)[:, :z.shape[1]] if ctx.needs_input_grad[0] else None
+        df2 = ops.front_conv_bwd_filter(dout, _c(z), f2.shape[0], ctx.hop) if ctx.needs_input_grad[1] else None
+        if dz is not None and not dz.is_contiguous():
+            dz = dz.contiguous()
+        return dz, df2, None, None
+
+
+def synth_strided(z, f2, hop, L):
+    return SynthStrided.apply(_c(z), f2, hop, L)
+
+
+def upsample_nearest(z, P):
+    """avg-pool back path: tf.keras UpSampling2D((1,P)) (adapt.py:226-228) -- index glue."""
+    return z.repeat_interleave(P, dim=1)
+
+
+class PairStats(Function):
+    """One pass over the waveforms -> [B, 2S^2+3S+1] table (D | Q | Na | Nt | Tm | Nm), see csrc/synth.hip."""
+
+    @staticmethod
+    def forward(ctx, target, est, mix):
+        ctx.save_for_backward(target, est)
+        return ops.pair_stats_fwd(target, est, mix)
+
+    @staticmethod
+    def backward(ctx, g):
+        target, est = ctx.saved_tensors
+        return None, ops.pair_stats_bwd(target, est, _c(g)), None
+
+
+def pair_stats(target, est, mix):
+    """Returns dict of views D,Q [B,S,S], Na,Nt,Tm [B,S], Nm [B]."""
+    B, S, L = est.shape
+    st = PairStats.apply(_c(target), _c(est), _c(mix) if mix is not None else None)
+    SS = S * S
+    return {'D': st[:, :SS].reshape(B, S, S), 'Q': st[:, SS:2 * SS].reshape(B, S, S), 'Na': st[:, 2 * SS:2 * SS + S],
+            'Nt': st[:, 2 * SS + S:2 * SS + 2 * S], 'Tm': st[:, 2 * SS + 2 * S:2 * SS + 3 * S], 'Nm': st[:, 2 * SS + 3 * S]}
+
+
+def _log10(x):
+    return torch.log(x) / 2.302585092994046
+
+
+def _diag(t):
+    return torch.diagonal(t, dim1=1, dim2=2)
+
+
+def _perm_table(S, device):
+    from itertools import permutations
+    return torch.tensor(list(permutations(range(S))), dtype=torch.long, device=device)      # lexicographic (App. A-14)
+
+
+def sdr_improvement(x_mix, s_target, s_approx, with_perm=False):
+    """Network.sdr_improvement (network.py:196-221) for [B,S,L] operands (identity pairing)."""
+    st = pair_stats(s_target, s_approx, x_mix)
+    D, Na, Nt, Tm, Nm = _diag(st['D']), st['Na'], st['Nt'], st['Tm'], st['Nm'].unsqueeze(1)
+    sep = 10.0 * _log10(1.0 / ((Nt * Na) / (D * D) - 1.0))
+    non = 10.0 * _log10(1.0 / ((Nt * Nm) / (Tm * Tm) - 1.0))
+    val = (sep - non).mean(dim=-1)
+    val = val.mean(dim=-1) if not with_perm else val.mean(dim=0)
+    return val, (Nt * Na) / (D * D + 1e-12)
+
+
+def pretrain_cost(x_mix, x_non_mix, back):
+    """Adapt.cost pretraining branch (adapt.py:321-330) -> tensor [3] = (l2, sdr, sdr_improvement)."""
+    st = pair_stats(x_non_mix, back, x_mix)
+    D, Q, Na, Nt, Tm, Nm = _diag(st['D']), _diag(st['Q']), st['Na'], st['Nt'], st['Tm'], st['Nm'].unsqueeze(1)
+    l2 = Q.sum(dim=1).mean()
+    sdr = ((Nt * Na) / (D * D + 1e-12)).mean()
+    with torch.no_grad():
+        sep = 10.0 * _log10(1.0 / ((Nt * Na) / (D * D) - 1.0))
+        non = 10.0 * _log10(1.0 / ((Nt * Nm) / (Tm * Tm) - 1.0))
+        imp = (sep - non).mean()
+    return torch.stack([l2, sdr, imp])
+
+
+class CrossDots(Function):
+    """D2[i,j,s] = <t[i,s,:], a[j,s,:]>: the cross-batch table the reference's fine-tune SDR term builds by
+    broadcasting [B,1,S,L] against [B,S,L] (quirk C-3, adapt.py:361-365).  One MFMA GEMM per speaker."""
+
+    @staticmethod
+    def forward(ctx, t, a):
+        B, S, L = a.shape
+        out = torch.empty((S, B, B), dtype=torch.float32, device=a.device)
+        for s in range(S):
+            ops.gemm(t.view(-1)[s * L:], a.view(-1)[s * L:], transB=True, out=out[s], M=B, N=B, K=L, lda=S * L, ldb=S * L, ldc=B)
+        ctx.save_for_backward(t)
+        ctx.shape = (B, S, L)
+        return out.permute(1, 2, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        (t,) = ctx.saved_tensors
+        B, S, L = ctx.shape
+        gs = _c(g.permute(2, 0, 1))                                        # [S, i, j]
+        da = torch.empty((B, S, L), dtype=torch.float32, device=t.device)
+        for s in range(S):
+            # da[j, s, :] = sum_i g[i,j,s] t[i,s,:]
+            ops.gemm(gs[s], t.view(-1)[s * L:], transA=True, out=da.view(-1)[s * L:], M=B, N=L, K=B, lda=B, ldb=S * L, ldc=S * L)
+        return None, da
+
+
+def pit_cost_adapt(x_mix, x_non_mix, back):
+    """Adapt.cost non-pretraining branch (adapt.py:339-365) -> tensor [3] = (l2, sdr, sdr_improvement)."""
+    B, S, L = back.shape
+    st = pair_stats(x_non_mix, back, x_mix)
+    P = _perm_table(S, back.device)
+    Qp = st['Q'][:, torch.arange(S, device=back.device).unsqueeze(0), P]          # [B, P, S]: Q[b, s, perm[p][s]]
+    l2 = (Qp / L).sum(dim=-1).min(dim=-1)[0].mean()
+    D2 = CrossDots.apply(_c(x_non_mix), _c(back))                                   # [i, j, s]
+    sdr_t = (st['Nt'].unsqueeze(1) * st['Na'].unsqueeze(0)) / (D2 * D2 + 1e-12)     # [B,B,S]
+    sdr = sdr_t.min(dim=1)[0].sum(dim=-1).mean()
+    with torch.no_grad():
+        Nm, Tm = st['Nm'], st['Tm']
+        sep = 10.0 * _log10(1.0 / ((st['Nt'].unsqueeze(1) * st['Na'].unsqueeze(0)) / (D2 * D2) - 1.0))
+        # mix term broadcasts the same way: target i against mix j
+        Tm2 = CrossDots.apply(_c(x_non_mix), _c(x_mix.unsqueeze(1).expand(B, S, L).contiguous()))
+        non = 10.0 * _log10(1.0 / ((st['Nt'].unsqueeze(1) * Nm.view(1, B, 1)) / (Tm2 * Tm2) - 1.0))
+        imp = (sep - non).mean(dim=-1).mean(dim=0).max()
+    return torch.stack([l2, sdr, imp])
+
+
+def pit_l2(x_non_mix, est, reduce_l, reduce_s, scale=1.0):
+    """Generic PIT squared error from the pair table (cost_finetuning / enhance_cost)."""
+    B, S, L = est.shape
+    st = pair_stats(x_non_mix, est, None)
+    P = _perm_table(S, est.device)
+    Qp = st['Q'][:, torch.arange(S, device=est.device).unsqueeze(0), P]
+    if reduce_l == 'mean':
+        Qp = Qp / L
+    Qp = Qp * scale
+    c = Qp.sum(dim=-1) if reduce_s == 'sum' else Qp.mean(dim=-1)
+    return c.min(dim=-1)[0].mean().reshape(1)
+
+
+class OverlapMetric(Function):
+    @staticmethod
+    def forward(ctx, y, B, S):
+        ctx.save_for_backward(y)
+        ctx.B, ctx.S = B, S
+        return ops.overlap_metric_fwd(y, B, S)
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return ops.overlap_metric_bwd(y, _c(g), ctx.B, ctx.S), None, None
+
+
+def overlap_metric(y, B, S):
+    return OverlapMetric.apply(_c(y), B, S)
+
+
+def pretrain_separator(y, B, S, separation):
+    """Adapt.separator pretraining branch (adapt.py:173-196); elementwise glue on the front output."""
+    T, N = y.shape[1:]
+    mix = y[:B].unsqueeze(1)
+    nm = y[B:].reshape(B, S, T, N)
+    if separation == 'mask':
+        out = mix * (nm / mix)
+    else:
+        out = mix - (nm.sum(dim=1, keepdim=True) - nm)
+    return out.reshape(B * S, T, N)
+
+
+def sumsq(x):
+    return ops.sumsq(_c(x)) if not x.requires_grad else (x * x).sum().reshape(1)
+
+
+def negative_energy(y):
+    neg = torch.where(y < 0, y, torch.zeros_like(y)) ** 2
+    return neg.reshape(neg.shape[0], -1).sum(dim=1).mean()
+
+
+def abs_colsum(y2):
+    return y2.abs().sum(dim=0)
+
+
+def kl_sparsity(p_hat, p):
+    def logfunc(a, b):
+        return a * torch.log(torch.clamp(a, 1e-10, 1.0) / torch.clamp(b, 1e-10, 1.0))
+    pt = torch.as_tensor(p, dtype=p_hat.dtype, device=p_hat.device)
+    return (logfunc(pt, p_hat) + logfunc(1 - pt, 1 - p_hat)).sum()
+
+
+def all_reduce_sum_autograd(t, dist):
+    class _AR(Function):
+        @staticmethod
+        def forward(ctx, x):
+            y = x.clone()
+            dist.all_reduce_sum(y)
+            return y
+
+        @staticmethod
+        def backward(ctx, g):
+            return g
+    return _AR.apply(t)
+
+
+class ApplyMasks(Function):
+    """separated = X_input * masks, rows (b,s)  (models/network.py:577-581)."""
+
+    @staticmethod
+    def forward(ctx, X, masks):
+        ctx.save_for_backward(X)
+        ctx.S = masks.shape[2]
+        return ops.apply_masks_fwd(X, masks)
+
+    @staticmethod
+    def backward(ctx, dsep):
+        (X,) = ctx.saved_tensors
+        return None, ops.apply_masks_bwd(X, _c(dsep), ctx.S)
+
+
+def apply_masks(X_input, masks):
+    """X_input [B,T,F], masks [B,TF,S] -> [B*S, T, F]."""
+    B, T, Fq = X_input.shape
+    sep = ApplyMasks.apply(_c(X_input).view(B, T * Fq), _c(masks))
+    return sep.view(-1, T, Fq)
+
+
+class L41Loss(Function):
+    """models/L41.py:150-178 on already gathered speaker vectors."""
+
+    @staticmethod
+    def forward(ctx, emb, y, vspk):
+        ctx.save_for_backward(emb, y, vspk)
+        return ops.l41_loss_fwd(emb, y, vspk)
+
+    @staticmethod
+    def backward(ctx, g):
+        emb, y, vspk = ctx.saved_tensors
+        demb, dvs = ops.l41_loss_bwd(emb, y, vspk, _c(g))
+        return demb, None, dvs
+
+
+def l41_loss(emb, y, speaker_vectors, I, normalize):
+    """emb [B,T,F,E], y [B,T,F,S]; the [251,E] normalise + gather (L41.py:60-68) is tiny-tensor torch glue."""
+    B, E = emb.shape[0], emb.shape[-1]
+    S = y.shape[-1]
+    sv = speaker_vectors
+    if normalize:
+        sv = sv * torch.rsqrt(torch.clamp((sv * sv).sum(dim=1, keepdim=True), min=1e-12))
+    vs = sv[I.long()]                                                                # [B,S,E]
+    return L41Loss.apply(_c(emb).reshape(B, -1, E), _c(y).reshape(B, -1, S), _c(vs))
+
+
+def one_hot_masks(labels, S):
+    """tf.one_hot(labels, S, 1.0, 0.0) (network.py:569) -- integer glue, no gradient."""
+    return (labels.long().unsqueeze(-1) == torch.arange(S, device=labels.device)).float().contiguous()
+
+
+class KMeansSoft(Function):
+    """Soft k-means (beta set) with gradient to the embeddings (needed by the front_*_finetuning recipes)."""
+
+    @staticmethod
+    def forward(ctx, X, init_idx, C, tries, iterations, beta, w, assign_at_end, normalize_input, faithful_tile):
+        xn = ops.kmeans_normalize(X) if normalize_input else X
+        sel, out, best, trace = ops.kmeans_run(xn, init_idx, C, tries, iterations, beta, w, assign_at_end, faithful_tile)
+        ctx.save_for_backward(X, xn, init_idx, best, sel, *([w] if w is not None else []), *trace)
+        ctx.cfg = (C, tries, iterations, beta, w is not None, assign_at_end, normalize_input, faithful_tile)
+        ctx.mark_non_differentiable(best)
+        return sel, out, best
+
+    @staticmethod
+    def backward(ctx, dsel, dout, _dbest):
+        C, tries, iterations, beta, has_w, assign_at_end, normalize_input, faithful_tile = ctx.cfg
+        saved = ctx.saved_tensors
+        X, xn, init_idx, best, sel = saved[:5]
+        w = saved[5] if has_w else None
+        trace = saved[6 if has_w else 5:]
+        dX = ops.kmeans_soft_bwd(X, xn, init_idx, best, sel, w, trace, dsel, dout, C, tries, iterations, beta, assign_at_end,
+                                 normalize_input, faithful_tile)
+        return (dX,) + (None,) * 9
+
+
+def kmeans(X, init_idx, C, tries, iterations, beta, w, assign_at_end, normalize_input=True, faithful_tile=True):
+    """KMeans.network (Kmeans_2.py:86-111).  Returns (centroids [b,C,E], labels, best_try)."""
+    X = _c(X)
+    if beta is None or not (X.requires_grad and torch.is_grad_enabled()):
+        with torch.no_grad():
+            xn = ops.kmeans_normalize(X) if normalize_input else X
+            sel, out, best, _ = ops.kmeans_run(xn, init_idx, C, tries, iterations, beta, w, assign_at_end, faithful_tile)
+        return sel, out, best
+    return KMeansSoft.apply(X, init_idx, C, tries, iterations, beta, w, assign_at_end, normalize_input, faithful_tile)
+
+
+def stft_mag_phase(x, W, hop, want_phase=True):
+    """tf.contrib.signal.stft(frame_length=W, frame_step=hop, fft_length=W) -> (|.| [R,T,F], unit phasor [R*T,2F]).
+    No gradient: the waveforms carry none on any reference path."""
+    from .stft_host import dft_matrices
+    x = _c(x)
+    R, L = x.shape
+    T = 1 + (L - W) // hop
+    F_ = W // 2 + 1
+    D, _ = dft_matrices(W, hop, x.device)
+    with torch.no_grad():
+        ri = ops.frames_matmul(x, D, hop, T, 0)                          # [R*T, 2F] = [Re | Im]
+        mag, ph = ops.cplx_mag_phase(ri, F_, want_phase)
+    return mag.view(R, T, F_), ph
+
+
+class ISTFT(Function):
+    """inverse_stft with the mixture phase re-attached (network.py:589-603): cplx_apply -> DFT^-1 GEMM -> overlap-add."""
+
+    @staticmethod
+    def forward(ctx, sep, phasor, Dinv, W, hop, S):
+        BS, T, F_ = sep.shape
+        z = ops.cplx_apply_fwd(sep.view(BS * T, F_), phasor, S, T)       # [BS*T, 2F]
+        frames = ops.gemm(z, Dinv)                                       # [BS*T, W]
+        L = (T - 1) * hop + W
+        out = ops.overlap_add(frames, BS, T, W, L, hop, 0)
+        ctx.save_for_backward(phasor, Dinv)
+        ctx.cfg = (BS, T, F_, W, hop, S, L)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        phasor, Dinv = ctx.saved_tensors
+        BS, T, F_, W, hop, S, L = ctx.cfg
+        # d frames[r,t,n] = dout[r, t*hop + n]  ->  a framed product with Dinv^T gives dz directly
+        dz = ops.frames_matmul(_c(dout), _dinv_t(Dinv), hop, T, 0)       # [BS*T, 2F]
+        dsep = ops.cplx_apply_bwd(dz, phasor, S, T)
+        return dsep.view(BS, T, F_), None, None, None, None, None
+
+
+_DINV_T = {}
+
+
+def _dinv_t(Dinv):
+    k = Dinv.data_ptr()
+    if k not in _DINV_T:
+        _DINV_T[k] = Dinv.t().contiguous()
+    return _DINV_T[k]
+
+
+def istft(sep, phasor, W, hop, S):
+    from .stft_host import dft_matrices
+    _, Dinv = dft_matrices(W, hop, sep.device)
+    return ISTFT.apply(_c(sep), phasor, Dinv, W, hop, S)

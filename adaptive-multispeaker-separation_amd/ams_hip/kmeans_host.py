@@ -1,6 +1,60 @@
-"""Host side of the batched k-means (reference models/Kmeans_2.py) -- filled in with the HIP kernels."""
+"""Host side of the batched k-means (reference models/Kmeans_2.py:12-195): same constructor and `.network` /
+`.fit` surface; the Lloyd iterations, restarts, inertia selection and final assignment run in csrc/kmeans.hip."""
+import numpy as np
+import torch
+
+from . import functional as F
+from .graph import Node, Placeholder, get_default_graph
 
 
 class KMeans(object):
-    def __init__(self, *args, **kwargs):
-        raise NotImplementedError('KMeans HIP path not built yet')
+
+    def __init__(self, nb_clusters, centroids_init=None, nb_tries=10, nb_iterations=10, input_tensor=None,
+                 normalize_input=True, latent_space_tensor=None, beta=None, threshold=2.5, assign_at_end=True,
+                 init_indices=None):
+        if centroids_init is not None:
+            raise NotImplementedError('explicit centroids_init (Kmeans_2.py:72-74) is unused by the reference recipes')
+        self.nb_clusters = nb_clusters
+        self.nb_iterations = nb_iterations
+        self.nb_tries = nb_tries
+        self.latent_space_tensor = latent_space_tensor
+        self.beta = beta
+        self.assign_at_end = assign_at_end
+        self.threshold = threshold
+        self.normalize_input = normalize_input
+        self.init_indices = init_indices          # Node / callable giving int32 [b*tries, C]; None -> host RNG as the reference
+        self.faithful_tile = True
+        g = get_default_graph()
+        with g.variable_scope('kmeans'):
+            self.X_in = input_tensor if input_tensor is not None else Placeholder('Kmeans_input')
+            self._result = Node('network', self._run)
+        self.network = (Node('centroids', lambda run: self._result.value(run)[0], register=False),
+                        Node('labels', lambda run: self._result.value(run)[1], register=False))
+
+    def _init_idx(self, run, R, L, device):
+        if self.init_indices is not None:
+            v = self.init_indices.value(run) if hasattr(self.init_indices, 'value') else self.init_indices
+            return torch.as_tensor(np.asarray(v), dtype=torch.int32, device=device).contiguous()
+        # Kmeans_2.py:61-65: np.random.choice(range(l), size=C, replace=False) per row, global numpy RNG
+        a = np.array([np.random.choice(range(L), size=self.nb_clusters, replace=False) for _ in range(R)])
+        return torch.from_numpy(a.astype(np.int32)).to(device)
+
+    def _run(self, run):
+        X = self.X_in.value(run)
+        b, L, E = X.shape
+        w = None
+        if self.latent_space_tensor is not None:
+            lat = self.latent_space_tensor.value(run).reshape(b, L)
+            mx = lat.max(dim=1, keepdim=True)[0]
+            w = ((torch.log(mx / lat) / np.log(10.0)) < self.threshold).float().contiguous()      # Kmeans_2.py:76-80
+        idx = self._init_idx(run, b * self.nb_tries, L, X.device)
+        return F.kmeans(X, idx, self.nb_clusters, self.nb_tries, self.nb_iterations, self.beta, w, self.assign_at_end,
+                        self.normalize_input, self.faithful_tile)
+
+    def fit(self, X_train):
+        from .graph import Run
+        x = torch.as_tensor(X_train, dtype=torch.float32, device=get_default_graph().device)
+        run = Run({self.X_in: x}, training=False)
+        with torch.no_grad():
+            c, l = self._result.value(run)[:2]
+        return c.cpu().numpy(), l.cpu().numpy()

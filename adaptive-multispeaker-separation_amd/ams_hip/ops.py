@@ -292,3 +292,182 @@ def sumsq(x):
     out = torch.empty(1, dtype=torch.float32, device=x.device)
     check(load().ams_sumsq(_p(x), _p(out), x.numel(), _p(ws), 4096, _s()), 'ams_sumsq')
     return out
+
+
+# ------------------------------------------------------------------ framed products / overlap-add (STFT, synthesis)
+def frames_matmul(x, Bm, hop, T, pad_left):
+    """out[(r,t), n] = sum_k xpad[r, t*hop + k - pad_left] * Bm[k, n];  x [R,L], Bm [W,N] -> [R*T, N]."""
+    _chk(x, Bm)
+    R, L = x.shape
+    W, N = Bm.shape
+    out = torch.empty((R * T, N), dtype=torch.float32, device=x.device)
+    ev = PROFILE.begin() if PROFILE.enabled else None
+    check(load().ams_frames_matmul(_p(x), _p(Bm), _p(out), R, L, W, N, hop, T, pad_left, _s()), 'ams_frames_matmul')
+    if ev is not None:
+        PROFILE.end(ev, 2.0 * R * T * N * W, 4.0 * (R * L + W * N + R * T * N), 'gemm')
+    return out
+
+
+def overlap_add(frames, R, T, W, L, hop, pad_left):
+    _chk(frames)
+    out = torch.empty((R, L), dtype=torch.float32, device=frames.device)
+    check(load().ams_overlap_add(_p(frames), _p(out), R, T, W, L, hop, pad_left, _s()), 'ams_overlap_add')
+    return out
+
+
+# ------------------------------------------------------------------ waveform statistics
+def pair_stats_fwd(target, est, mix):
+    _chk(target, est, mix)
+    lib = load()
+    B, S, L = est.shape
+    NS = 2 * S * S + 3 * S + 1
+    nb = lib.ams_pair_stats_workspace_bytes(B, S, L)
+    ws = _ws(nb, est)
+    stats = torch.empty((B, NS), dtype=torch.float32, device=est.device)
+    check(lib.ams_pair_stats_fwd(_p(target), _p(est), _p(mix), _p(stats), B, S, L, _p(ws), nb, _s()), 'ams_pair_stats_fwd')
+    return stats
+
+
+def pair_stats_bwd(target, est, gstats):
+    _chk(target, est, gstats)
+    B, S, L = est.shape
+    dest = torch.empty_like(est)
+    check(load().ams_pair_stats_bwd(_p(target), _p(est), _p(gstats), _p(dest), B, S, L, _s()), 'ams_pair_stats_bwd')
+    return dest
+
+
+def apply_masks_fwd(X, masks):
+    """X [B,TF], masks [B,TF,S] -> [B*S, TF]."""
+    _chk(X, masks)
+    B, TF, S = masks.shape
+    sep = torch.empty((B * S, TF), dtype=torch.float32, device=X.device)
+    check(load().ams_apply_masks_fwd(_p(X), _p(masks), _p(sep), B, S, TF, _s()), 'ams_apply_masks_fwd')
+    return sep
+
+
+def apply_masks_bwd(X, dsep, S):
+    _chk(X, dsep)
+    B, TF = X.shape
+    dm = torch.empty((B, TF, S), dtype=torch.float32, device=X.device)
+    check(load().ams_apply_masks_bwd(_p(X), _p(dsep), _p(dm), B, S, TF, _s()), 'ams_apply_masks_bwd')
+    return dm
+
+
+def overlap_metric_fwd(y, B, S):
+    _chk(y)
+    TN = y.numel() // (B * (S + 1))
+    ws = _ws(4096, y)
+    out = torch.empty(1, dtype=torch.float32, device=y.device)
+    check(load().ams_overlap_metric_fwd(_p(y), _p(out), B, S, TN, _p(ws), 4096, _s()), 'ams_overlap_metric_fwd')
+    return out
+
+
+def overlap_metric_bwd(y, upstream, B, S):
+    _chk(y, upstream)
+    TN = y.numel() // (B * (S + 1))
+    dy = torch.empty_like(y)
+    check(load().ams_overlap_metric_bwd(_p(y), _p(upstream), _p(dy), B, S, TN, _s()), 'ams_overlap_metric_bwd')
+    return dy
+
+
+# ------------------------------------------------------------------ complex glue
+def cplx_mag_phase(ri, F, want_phase=True):
+    _chk(ri)
+    rows = ri.shape[0]
+    mag = torch.empty((rows, F), dtype=torch.float32, device=ri.device)
+    ph = torch.empty((rows, 2 * F), dtype=torch.float32, device=ri.device) if want_phase else None
+    check(load().ams_cplx_mag_phase(_p(ri), _p(mag), _p(ph), rows, F, _s()), 'ams_cplx_mag_phase')
+    return mag, ph
+
+
+def cplx_apply_fwd(sep, phasor, S, T):
+    _chk(sep, phasor)
+    rows, F = sep.shape
+    z = torch.empty((rows, 2 * F), dtype=torch.float32, device=sep.device)
+    check(load().ams_cplx_apply_fwd(_p(sep), _p(phasor), _p(z), rows, F, S, T, _s()), 'ams_cplx_apply_fwd')
+    return z
+
+
+def cplx_apply_bwd(dz, phasor, S, T):
+    _chk(dz, phasor)
+    rows, F2 = dz.shape
+    d = torch.empty((rows, F2 // 2), dtype=torch.float32, device=dz.device)
+    check(load().ams_cplx_apply_bwd(_p(dz), _p(phasor), _p(d), rows, F2 // 2, S, T, _s()), 'ams_cplx_apply_bwd')
+    return d
+
+
+# ------------------------------------------------------------------ L41 loss
+def l41_loss_fwd(emb, y, vspk):
+    _chk(emb, y, vspk)
+    lib = load()
+    B, TF, E = emb.shape
+    S = y.shape[2]
+    nb = lib.ams_l41_workspace_bytes(B, TF, E, S)
+    ws = _ws(nb, emb)
+    cost = torch.empty(1, dtype=torch.float32, device=emb.device)
+    check(lib.ams_l41_loss_fwd(_p(emb), _p(y), _p(vspk), _p(cost), B, TF, E, S, _p(ws), nb, _s()), 'ams_l41_loss_fwd')
+    return cost
+
+
+def l41_loss_bwd(emb, y, vspk, upstream):
+    _chk(emb, y, vspk, upstream)
+    lib = load()
+    B, TF, E = emb.shape
+    S = y.shape[2]
+    nb = lib.ams_l41_workspace_bytes(B, TF, E, S)
+    ws = _ws(nb, emb)
+    demb = torch.empty_like(emb)
+    dvs = torch.empty_like(vspk)
+    check(lib.ams_l41_loss_bwd(_p(emb), _p(y), _p(vspk), _p(upstream), _p(demb), _p(dvs), B, TF, E, S, _p(ws), nb, _s()), 'ams_l41_loss_bwd')
+    return demb, dvs
+
+
+# ------------------------------------------------------------------ k-means
+def kmeans_normalize(x):
+    _chk(x)
+    E = x.shape[-1]
+    xn = torch.empty_like(x)
+    check(load().ams_kmeans_normalize(_p(x), _p(xn), x.numel() // E, E, _s()), 'ams_kmeans_normalize')
+    return xn
+
+
+def kmeans_run(xn, init_idx, C, tries, iterations, beta=None, w=None, assign_at_end=True, faithful_tile=True):
+    """Whole KMeans.network (Kmeans_2.py:86-111) on normalised input xn [b,L,E].
+    init_idx int32 [b*tries, C].  Returns (centroids [b,C,E], labels int32 [b,L] | soft [b,L,C], best [b], cent_trace)
+    where cent_trace is the list of per-iteration centroid tensors [R,C,E] (needed by the soft backward)."""
+    _chk(xn, w)
+    lib = load()
+    b, L, E = xn.shape
+    R = b * tries
+    dev = xn.device
+    hard = beta is None
+    bval = -1.0 if hard else float(beta)
+    nb = lib.ams_kmeans_workspace_bytes(R, L, E, C)
+    ws = _ws(nb, xn)
+    cent = torch.empty((R, C, E), dtype=torch.float32, device=dev)
+    check(lib.ams_kmeans_init(_p(xn), _p(init_idx), _p(cent), b, tries, L, E, C, _s()), 'ams_kmeans_init')
+    trace = [cent]
+    wm = 1 if faithful_tile else 0
+    for _ in range(iterations):
+        nxt = torch.empty_like(cent)
+        check(lib.ams_kmeans_iterate(_p(xn), _p(w), _p(cent), _p(nxt), b, tries, L, E, C, bval, wm, _p(ws), nb, _s()), 'ams_kmeans_iterate')
+        cent = nxt
+        trace.append(cent)
+    inertia = torch.empty(R, dtype=torch.float32, device=dev)
+    labels = torch.empty((R, L), dtype=torch.int32, device=dev) if (hard and not assign_at_end) else None
+    soft = torch.empty((R, L, C), dtype=torch.float32, device=dev) if (not hard and not assign_at_end) else None
+    check(lib.ams_kmeans_assign(_p(xn), _p(w), _p(cent), _p(labels), _p(soft), _p(inertia), b, tries, L, E, C, bval, wm, _p(ws), nb,
+                                _s()), 'ams_kmeans_assign')
+    best = torch.empty(b, dtype=torch.int32, device=dev)
+    sel = torch.empty((b, C, E), dtype=torch.float32, device=dev)
+    check(lib.ams_kmeans_select(_p(inertia), _p(cent), _p(best), _p(sel), b, tries, E, C, _s()), 'ams_kmeans_select')
+    if assign_at_end:
+        out_l = torch.empty((b, L), dtype=torch.int32, device=dev) if hard else None
+        out_s = torch.empty((b, L, C), dtype=torch.float32, device=dev) if not hard else None
+        check(lib.ams_kmeans_assign(_p(xn), _p(None), _p(sel), _p(out_l), _p(out_s), _p(None), b, 1, L, E, C, bval, 0, _p(ws), nb, _s()),
+              'ams_kmeans_assign(end)')
+        out = out_l if hard else out_s
+    else:
+        idx = (best.long() + torch.arange(b, device=dev) * tries)
+        out = (labels if hard else soft)[idx]
+    return sel, out, best, trace

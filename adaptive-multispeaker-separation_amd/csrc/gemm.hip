@@ -361,6 +361,19 @@ ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, 
     return launch<A_FRAMES, B_ROW>(g, nullptr, 0, (hipStream_t)stream);
 }
 
+// Generic framed product: out[(r,t), n] = sum_k xpad[r, t*hop + k - pad_left] * Bm[k, n]   (STFT as a DFT product)
+ams_status ams_frames_matmul(const float* x, const float* Bm, float* out, int R, int L, int W, int N, int hop, int T, int pad_left,
+                             void* stream) {
+    AMS_REQUIRE(x && Bm && out && R > 0 && L > 0 && W > 0 && N > 0 && hop > 0 && T > 0 && pad_left >= 0);
+    GemmArgs g{};
+    g.A = x; g.B = Bm; g.C = out; g.bias = nullptr;
+    g.M = R * T; g.N = N; g.K = W; g.lda = 0; g.ldb = N; g.ldc = N;
+    g.fr_L = L; g.fr_T = T; g.fr_hop = hop; g.fr_pl = pad_left; g.fr_W = W;
+    g.a_vec = aligned16(x) && (L % 4 == 0) && (hop % 4 == 0) && (pad_left % 4 == 0);
+    g.b_vec = aligned16(Bm) && (N % 4 == 0);
+    return launch<A_FRAMES, B_ROW>(g, nullptr, 0, (hipStream_t)stream);
+}
+
 size_t ams_front_conv_bwd_filter_workspace_bytes(int Bt, int L, int W, int N, int hop) {
     const int T = (L + hop - 1) / hop;
     return ams_gemm_workspace_bytes(W, N, Bt * T);

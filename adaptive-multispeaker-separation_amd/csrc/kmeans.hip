@@ -1,0 +1,338 @@
+// Batched k-means mask assignment (reference models/Kmeans_2.py:86-188), HBM-bound streaming kernels.
+//
+// The reference tiles X nb_tries times (2.1 GB at the benchmark shape) and broadcasts a [R,L,C,E] temporary per
+// label pass (4.2 GB).  Here the un-tiled, normalised embeddings are streamed: row r = b*tries + try reads x[b]
+// (tries index the centroid set only), one pass computes the assignment AND the centroid numerators/denominators
+// for the next iteration, and nothing larger than [R, chunks, C*(E+1)] partial sums is written.
+//
+// Bit-exact hard labels.  tf.unsorted_segment_sum is order-nondeterministic; oracle/kmeans.py and these kernels
+// share ONE summation order: 2048-point chunks; lane j (0..255) adds its 8 points j, j+256, .. sequentially; a
+// halving tree v[j] += v[j+s], s = 128..1, combines the lanes; chunk totals are added in chunk order.  Distances
+// accumulate left-to-right over e with separate multiply and add (__fmul_rn/__fadd_rn: no FMA contraction), sqrt
+// is IEEE, ties pick the lowest cluster (tf.argmin).
+//
+// Algorithmic bytes per pass: L*E*4 per row (+ L*4 weights); x[b] is shared by the `tries` rows of an utterance
+// through L2.
+#include "common.h"
+// Bit-exact parity with oracle/kmeans.py needs IEEE mul/add (no FMA contraction), sqrt and divide: contraction is
+// switched off for this translation unit (see Makefile) and sqrtf / operator/ are the correctly rounded forms
+// (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).  NB: without OCML_BASIC_ROUNDED_OPERATIONS the
+// __fsqrt_rn / __fmul_rn intrinsics are NOT rounding-safe (native sqrt, contractable multiply).
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int CHUNK = 2048, LANES = 256, PPL = CHUNK / LANES;
+
+enum { HARD_ACC = 0, SOFT_ACC = 1, HARD_FINAL = 2, SOFT_FINAL = 3 };
+
+// x [nrows, E] -> xn: x * (1/sqrt(max(sum_e x^2, 1e-12))), sequential over e (tf.nn.l2_normalize, Kmeans_2.py:40-41)
+__global__ void kmeans_normalize_kernel(const float* __restrict__ x, float* __restrict__ xn, long nrows, int E) {
+    for (long r = (long)blockIdx.x * blockDim.x + threadIdx.x; r < nrows; r += (long)gridDim.x * blockDim.x) {
+        const float* p = x + r * E;
+        float ss = 0.f;
+        for (int e = 0; e < E; ++e) ss = __fadd_rn(ss, __fmul_rn(p[e], p[e]));
+        const float inv = ((1.0f) / (sqrtf(fmaxf(ss, 1e-12f))));
+        for (int e = 0; e < E; ++e) xn[r * E + e] = __fmul_rn(p[e], inv);
+    }
+}
+
+struct KmArgs {
+    const float* xn;       // [b, L, E]
+    const float* w;        // [b, L] or null (all ones)
+    const float* cent;     // [R, C, E]
+    float* part;           // [R, G, NV]
+    int32_t* labels;       // [R, L] (hard final) or null
+    float* soft;           // [R, L, C] (soft final) or null
+    long L;
+    int b, tries, G;
+    int w_mod_b;           // 1: weight row = r % b (reference tile quirk), 0: r / tries
+    float beta;
+};
+
+template <int E_, int C_, int MODE>
+__global__ __launch_bounds__(256) void kmeans_pass_kernel(KmArgs a) {
+    constexpr bool ACC = (MODE == HARD_ACC || MODE == SOFT_ACC);
+    constexpr bool SOFT = (MODE == SOFT_ACC || MODE == SOFT_FINAL);
+    constexpr int NV = ACC ? C_ * (E_ + 1) : 2 * C_;
+    constexpr int LD = E_ + 1;
+    constexpr int BUF = (256 * LD > 128 * 64) ? 256 * LD : 128 * 64;
+    __shared__ float buf[BUF];
+    __shared__ float scent[C_ * E_];
+    const int r = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int bi = r / a.tries;
+    const float* xb = a.xn + (long)bi * a.L * E_;
+    const float* wb = a.w ? a.w + (long)(a.w_mod_b ? (r % a.b) : bi) * a.L : nullptr;
+    for (int i = tid; i < C_ * E_; i += 256) scent[i] = a.cent[(long)r * C_ * E_ + i];
+
+    float acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+
+    for (int j = 0; j < PPL; ++j) {
+        const long p0 = (long)g * CHUNK + (long)j * LANES;
+        const int npts = (int)max((long)0, min((long)LANES, a.L - p0));
+        __syncthreads();
+        for (int i = tid; i < npts * E_; i += 256) buf[(i / E_) * LD + (i % E_)] = xb[p0 * E_ + i];
+        __syncthreads();
+        if (tid < npts) {
+            float x[E_];
+#pragma unroll
+            for (int e = 0; e < E_; ++e) x[e] = buf[tid * LD + e];
+            const float wv = wb ? wb[p0 + tid] : 1.0f;
+            float d2[C_];
+#pragma unroll
+            for (int c = 0; c < C_; ++c) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < E_; ++e) {
+                    const float diff = __fsub_rn(x[e], scent[c * E_ + e]);
+                    d = __fadd_rn(d, __fmul_rn(__fmul_rn(diff, diff), wv));
+                }
+                d2[c] = d;
+            }
+            if (!SOFT) {
+                int lab = 0;
+                float best = sqrtf(d2[0]);
+#pragma unroll
+                for (int c = 1; c < C_; ++c) {
+                    const float dc = sqrtf(d2[c]);
+                    if (dc < best) { best = dc; lab = c; }
+                }
+                if (MODE == HARD_ACC) {
+#pragma unroll
+                    for (int c = 0; c < C_; ++c) {
+                        const float m = (lab == c) ? 1.0f : 0.0f;
+#pragma unroll
+                        for (int e = 0; e < E_; ++e) acc[c * E_ + e] = __fadd_rn(acc[c * E_ + e], __fmul_rn(__fmul_rn(x[e], wv), m));
+                        acc[C_ * E_ + c] = __fadd_rn(acc[C_ * E_ + c], m);
+                    }
+                } else {
+                    // inertia terms: unweighted distance to the assigned centroid (Kmeans_2.py:131-136)
+                    float dist = 0.f;
+#pragma unroll
+                    for (int c = 0; c < C_; ++c) {
+                        if (lab == c) {
+                            float d = 0.f;
+#pragma unroll
+                            for (int e = 0; e < E_; ++e) {
+                                const float diff = __fsub_rn(x[e], scent[c * E_ + e]);
+                                d = __fadd_rn(d, __fmul_rn(diff, diff));
+                            }
+                            dist = d;
+                        }
+                    }
+#pragma unroll
+                    for (int c = 0; c < C_; ++c) {
+                        const float m = (lab == c) ? 1.0f : 0.0f;
+                        acc[c] = __fadd_rn(acc[c], __fmul_rn(dist, m));
+                        acc[C_ + c] = __fadd_rn(acc[C_ + c], m);
+                    }
+                    if (a.labels) a.labels[(long)r * a.L + p0 + tid] = lab;
+                }
+            } else {
+                float ex[C_], sum = 0.f;
+#pragma unroll
+                for (int c = 0; c < C_; ++c) { ex[c] = expf(-a.beta * d2[c]); sum += ex[c]; }
+                const float inv = 1.0f / sum;
+                if (MODE == SOFT_ACC) {
+#pragma unroll
+                    for (int c = 0; c < C_; ++c) {
+                        const float lb = ex[c] * inv;
+#pragma unroll
+                        for (int e = 0; e < E_; ++e) acc[c * E_ + e] += x[e] * wv * lb;
+                        acc[C_ * E_ + c] += lb;
+                    }
+                } else {
+#pragma unroll
+                    for (int c = 0; c < C_; ++c) {
+                        const float lb = ex[c] * inv;
+                        float d = 0.f;
+#pragma unroll
+                        for (int e = 0; e < E_; ++e) { const float diff = x[e] - scent[c * E_ + e]; d += diff * diff; }
+                        acc[c] += d * lb;
+                        acc[C_ + c] += lb;
+                        if (a.soft) a.soft[((long)r * a.L + p0 + tid) * C_ + c] = lb;
+                    }
+                }
+            }
+        }
+    }
+    // halving tree over the 256 lanes: s = 128, 64 through LDS (in batches of <= 64 values), s = 32..1 by shuffles.
+    // NV is a compile-time constant, so both loops unroll fully and `acc` stays in registers.
+#pragma unroll
+    for (int v0 = 0; v0 < NV; v0 += 64) {
+        __syncthreads();
+        if (wave >= 2) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i)
+                if (v0 + i < NV) buf[((wave - 2) * 64 + lane) * 64 + i] = acc[v0 + i];
+        }
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i)
+                if (v0 + i < NV) acc[v0 + i] = __fadd_rn(acc[v0 + i], buf[(wave * 64 + lane) * 64 + i]);
+        }
+        __syncthreads();
+        if (wave == 1) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i)
+                if (v0 + i < NV) buf[lane * 64 + i] = acc[v0 + i];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i)
+                if (v0 + i < NV) acc[v0 + i] = __fadd_rn(acc[v0 + i], buf[lane * 64 + i]);
+        }
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float v = acc[i];
+#pragma unroll
+            for (int s = 32; s >= 1; s >>= 1) v = __fadd_rn(v, __shfl_down(v, s, 64));
+            if (lane == 0) a.part[((long)r * a.G + g) * NV + i] = v;
+        }
+    }
+}
+
+// Sum chunk partials in chunk order; ACC passes: centroid = num / den.  FINAL passes: inertia[r] = sum_c tot_c/cnt_c.
+__global__ void kmeans_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int R, int G, int C, int E, int final_) {
+    const int NV = final_ ? 2 * C : C * (E + 1);
+    const int per = final_ ? 1 : C * E;
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)R * per) return;
+    const int r = (int)(i / per), k = (int)(i - (long)r * per);
+    const float* pr = part + (long)r * G * NV;
+    if (final_) {
+        float inertia = 0.f;
+        for (int c = 0; c < C; ++c) {
+            float tot = 0.f, cnt = 0.f;
+            for (int g = 0; g < G; ++g) { tot = __fadd_rn(tot, pr[(long)g * NV + c]); cnt = __fadd_rn(cnt, pr[(long)g * NV + C + c]); }
+            inertia = __fadd_rn(inertia, ((tot) / (cnt)));
+        }
+        out[r] = inertia;
+    } else {
+        const int c = k / E;
+        float num = 0.f, den = 0.f;
+        for (int g = 0; g < G; ++g) { num = __fadd_rn(num, pr[(long)g * NV + k]); den = __fadd_rn(den, pr[(long)g * NV + C * E + c]); }
+        out[(long)r * C * E + k] = ((num) / (den));
+    }
+}
+
+// centroids[r,c,:] = xn[r/tries, idx[r,c], :]                 (Kmeans_2.py:61-71)
+__global__ void kmeans_init_kernel(const float* __restrict__ xn, const int32_t* __restrict__ idx, float* __restrict__ cent, int R,
+                                   int C, int E, long L, int tries) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)R * C * E) return;
+    const int e = (int)(i % E);
+    const long rc = i / E;
+    const int r = (int)(rc / C);
+    cent[i] = xn[((long)(r / tries) * L + idx[rc]) * E + e];
+}
+
+// best[b] = argmin_try inertia[b*tries + try] (first minimum); sel[b] = centroids[b*tries + best]
+__global__ void kmeans_select_kernel(const float* __restrict__ inertia, const float* __restrict__ cent, int32_t* __restrict__ best,
+                                     float* __restrict__ sel, int b, int tries, int CE) {
+    const int bi = blockIdx.x;
+    if (bi >= b) return;
+    int bt = 0;
+    float bv = inertia[(long)bi * tries];
+    for (int t = 1; t < tries; ++t) {
+        const float v = inertia[(long)bi * tries + t];
+        if (v < bv) { bv = v; bt = t; }
+    }
+    if (threadIdx.x == 0) best[bi] = bt;
+    for (int i = threadIdx.x; i < CE; i += blockDim.x) sel[(long)bi * CE + i] = cent[((long)bi * tries + bt) * CE + i];
+}
+
+template <int MODE>
+ams_status launch_pass(const KmArgs& a, int R, int E, int C, hipStream_t st) {
+    dim3 grid(a.G, R);
+#define AMS_KM(EE, CC) hipLaunchKernelGGL((kmeans_pass_kernel<EE, CC, MODE>), grid, dim3(256), 0, st, a)
+    if (E == 40 && C == 2) AMS_KM(40, 2);
+    else if (E == 40 && C == 3) AMS_KM(40, 3);
+    else if (E == 40 && C == 4) AMS_KM(40, 4);
+    else if (E == 8 && C == 2) AMS_KM(8, 2);
+    else if (E == 8 && C == 3) AMS_KM(8, 3);
+    else if (E == 8 && C == 4) AMS_KM(8, 4);
+    else if (E == 20 && C == 2) AMS_KM(20, 2);
+    else if (E == 20 && C == 3) AMS_KM(20, 3);
+    else return AMS_E_INVALID_ARG;
+#undef AMS_KM
+    return ams_check_launch();
+}
+
+}  // namespace
+
+extern "C" {
+
+ams_status ams_kmeans_normalize(const float* x, float* xn, long nrows, int E, void* stream) {
+    AMS_REQUIRE(x && xn && nrows > 0 && E > 0);
+    long blocks = (nrows + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(kmeans_normalize_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, x, xn, nrows, E);
+    return ams_check_launch();
+}
+
+size_t ams_kmeans_workspace_bytes(int R, long L, int E, int C) {
+    const int G = ceil_div(L, CHUNK);
+    return sizeof(float) * (size_t)R * G * C * (E + 1);
+}
+
+ams_status ams_kmeans_init(const float* xn, const int32_t* init_idx, float* centroids, int b, int tries, long L, int E, int C,
+                           void* stream) {
+    AMS_REQUIRE(xn && init_idx && centroids && b > 0 && tries > 0 && L > 0);
+    const long n = (long)b * tries * C * E;
+    hipLaunchKernelGGL(kmeans_init_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, xn, init_idx, centroids,
+                       b * tries, C, E, L, tries);
+    return ams_check_launch();
+}
+
+// One Lloyd iteration for all R = b*tries rows: labels from `cent_in`, new centroids to `cent_out`.
+// beta < 0: hard assignment (argmin), else soft assignment softmax(-beta d^2).
+ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent_in, float* cent_out, int b, int tries, long L, int E,
+                              int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(xn && cent_in && cent_out && ws && b > 0 && tries > 0 && L > 0 && C >= 2 && C <= 4);
+    const int R = b * tries;
+    if (ws_bytes < ams_kmeans_workspace_bytes(R, L, E, C)) return AMS_E_WORKSPACE_TOO_SMALL;
+    hipStream_t st = (hipStream_t)stream;
+    KmArgs a{};
+    a.xn = xn; a.w = w; a.cent = cent_in; a.part = (float*)ws; a.L = L; a.b = b; a.tries = tries; a.G = ceil_div(L, CHUNK);
+    a.w_mod_b = w_mod_b; a.beta = beta;
+    ams_status s = beta < 0.f ? launch_pass<HARD_ACC>(a, R, E, C, st) : launch_pass<SOFT_ACC>(a, R, E, C, st);
+    if (s != AMS_OK) return s;
+    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(ceil_div((long)R * C * E, 256)), dim3(256), 0, st, (const float*)ws, cent_out, R, a.G,
+                       C, E, 0);
+    return ams_check_launch();
+}
+
+// Labels for `cent` (+ per-row inertia).  hard: labels int32 [R,L]; soft: soft [R,L,C].  Either output may be NULL.
+ams_status ams_kmeans_assign(const float* xn, const float* w, const float* cent, int32_t* labels, float* soft, float* inertia, int b,
+                             int tries, long L, int E, int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(xn && cent && ws && b > 0 && tries > 0 && L > 0 && C >= 2 && C <= 4);
+    const int R = b * tries;
+    if (ws_bytes < ams_kmeans_workspace_bytes(R, L, E, C)) return AMS_E_WORKSPACE_TOO_SMALL;
+    hipStream_t st = (hipStream_t)stream;
+    KmArgs a{};
+    a.xn = xn; a.w = w; a.cent = cent; a.part = (float*)ws; a.labels = labels; a.soft = soft; a.L = L; a.b = b; a.tries = tries;
+    a.G = ceil_div(L, CHUNK); a.w_mod_b = w_mod_b; a.beta = beta;
+    ams_status s = beta < 0.f ? launch_pass<HARD_FINAL>(a, R, E, C, st) : launch_pass<SOFT_FINAL>(a, R, E, C, st);
+    if (s != AMS_OK) return s;
+    if (inertia) {
+        hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, st, (const float*)ws, inertia, R, a.G, C, E, 1);
+        s = ams_check_launch();
+    }
+    return s;
+}
+
+ams_status ams_kmeans_select(const float* inertia, const float* centroids, int32_t* best, float* selected, int b, int tries, int E,
+                             int C, void* stream) {
+    AMS_REQUIRE(inertia && centroids && best && selected && b > 0 && tries > 0);
+    hipLaunchKernelGGL(kmeans_select_kernel, dim3(b), dim3(64), 0, (hipStream_t)stream, inertia, centroids, best, selected, b, tries, C * E);
+    return ams_check_launch();
+}
+
+}  // extern "C"

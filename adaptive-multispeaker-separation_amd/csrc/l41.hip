@@ -1,0 +1,148 @@
+// Lab41 source-contrastive loss (reference models/L41.py:150-178, sampling=None):
+//   cost = mean_{t,f} mean_b mean_s  -log(sigmoid(y[b,t,f,s] * <Vspk[b,s,:], emb[b,t,f,:]>))
+// The reference broadcasts a [B,T,F,S,E] temporary (420 MB at the benchmark shape); here emb is streamed once per
+// pass, thread-per-point with the S speaker vectors in LDS, points transposed through LDS for coalesced traffic.
+// HBM-bound: algorithmic bytes = TF*(E+S)*4 per utterance forward, + TF*E*4 written backward.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXS = 4;
+
+__device__ __forceinline__ float softplus_neg(float z) {      // -log(sigmoid(z)) = log(1 + exp(-z)), stable
+    return z > 0.f ? log1pf(expf(-z)) : -z + log1pf(expf(z));
+}
+
+template <int E_, bool BWD>
+__global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb, const float* __restrict__ y,
+                                                  const float* __restrict__ vs, const float* __restrict__ upstream,
+                                                  float* __restrict__ part, float* __restrict__ demb, float* __restrict__ dvs_part,
+                                                  long TF, int S, int nblk, float scale) {
+    constexpr int LD = E_ + 1;
+    __shared__ float tile[256 * LD];
+    __shared__ float svs[MAXS * E_];
+    __shared__ float red[4][MAXS * E_ + 1];
+    const int b = blockIdx.y, tid = threadIdx.x;
+    const long p0 = (long)blockIdx.x * 256;
+    const int npts = (int)min((long)256, TF - p0);
+    const float* eb = emb + ((long)b * TF + p0) * E_;
+    for (int i = tid; i < npts * E_; i += 256) tile[(i / E_) * LD + (i % E_)] = eb[i];
+    for (int i = tid; i < S * E_; i += 256) svs[i] = vs[(long)b * S * E_ + i];
+    __syncthreads();
+    float cost = 0.f;
+    float dz[MAXS] = {0.f, 0.f, 0.f, 0.f};
+    float v[E_];
+    if (tid < npts) {
+#pragma unroll
+        for (int e = 0; e < E_; ++e) v[e] = tile[tid * LD + e];
+        const float* yp = y + ((long)b * TF + p0 + tid) * S;
+        const float up = BWD ? upstream[0] * scale : 0.f;
+        for (int s = 0; s < S; ++s) {
+            float dot = 0.f;
+#pragma unroll
+            for (int e = 0; e < E_; ++e) dot += v[e] * svs[s * E_ + e];
+            const float ys = yp[s], z = ys * dot;
+            cost += softplus_neg(z);
+            if (BWD) dz[s] = -ys * up / (1.0f + expf(z));          // d/d dot of -log sigmoid(y dot) = -y sigmoid(-z)
+        }
+    }
+    if (!BWD) {
+        cost = wave_sum(cost);
+        if ((tid & 63) == 0) red[tid >> 6][0] = cost;
+        __syncthreads();
+        if (tid == 0) part[(long)b * nblk + blockIdx.x] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        return;
+    }
+    // backward: demb = sum_s dz_s * Vs_s ; dVs_s += dz_s * emb (block partial)
+    __syncthreads();
+    if (tid < npts) {
+#pragma unroll
+        for (int e = 0; e < E_; ++e) {
+            float d = 0.f;
+            for (int s = 0; s < S; ++s) d += dz[s] * svs[s * E_ + e];
+            tile[tid * LD + e] = d;
+        }
+    }
+    for (int s = 0; s < S; ++s) {
+#pragma unroll
+        for (int e = 0; e < E_; ++e) {
+            const float c = wave_sum((tid < npts) ? dz[s] * v[e] : 0.f);
+            if ((tid & 63) == 0) red[tid >> 6][s * E_ + e] = c;
+        }
+    }
+    __syncthreads();
+    float* db = demb + ((long)b * TF + p0) * E_;
+    for (int i = tid; i < npts * E_; i += 256) db[i] = tile[(i / E_) * LD + (i % E_)];
+    for (int i = tid; i < S * E_; i += 256)
+        dvs_part[((long)b * nblk + blockIdx.x) * (S * E_) + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+
+__global__ void l41_cost_final_kernel(const float* __restrict__ part, float* __restrict__ out, long n, float scale) {
+    __shared__ float sm[4];
+    float s = 0.f;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) s += part[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (sm[0] + sm[1] + sm[2] + sm[3]) * scale;
+}
+
+__global__ void l41_dvs_final_kernel(const float* __restrict__ part, float* __restrict__ dvs, int nblk, int SE, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * SE) return;
+    const int b = i / SE, k = i - b * SE;
+    float s = 0.f;
+    for (int c = 0; c < nblk; ++c) s += part[((long)b * nblk + c) * SE + k];
+    dvs[i] = s;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ams_l41_workspace_bytes(int B, long TF, int E, int S) {
+    const int nblk = ceil_div(TF, 256);
+    return sizeof(float) * (size_t)B * nblk * (S * E > 1 ? S * E : 1);
+}
+
+#define AMS_L41_DISPATCH(BWD, ...)                                                                       \
+    switch (E) {                                                                                         \
+        case 40: hipLaunchKernelGGL((l41_kernel<40, BWD>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 32: hipLaunchKernelGGL((l41_kernel<32, BWD>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 20: hipLaunchKernelGGL((l41_kernel<20, BWD>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 16: hipLaunchKernelGGL((l41_kernel<16, BWD>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 8: hipLaunchKernelGGL((l41_kernel<8, BWD>), grid, dim3(256), 0, st, __VA_ARGS__); break;     \
+        case 4: hipLaunchKernelGGL((l41_kernel<4, BWD>), grid, dim3(256), 0, st, __VA_ARGS__); break;     \
+        case 3: hipLaunchKernelGGL((l41_kernel<3, BWD>), grid, dim3(256), 0, st, __VA_ARGS__); break;     \
+        default: return AMS_E_INVALID_ARG;                                                               \
+    }
+
+// emb [B,TF,E], y [B,TF,S] (+1/-1), vspk [B,S,E] (already gathered / normalised) -> cost[0]
+ams_status ams_l41_loss_fwd(const float* emb, const float* y, const float* vspk, float* cost, int B, long TF, int E, int S, void* ws,
+                            size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(emb && y && vspk && cost && ws && B > 0 && TF > 0 && S > 0 && S <= MAXS);
+    if (ws_bytes < ams_l41_workspace_bytes(B, TF, E, S)) return AMS_E_WORKSPACE_TOO_SMALL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = ceil_div(TF, 256);
+    dim3 grid(nblk, B);
+    const float scale = 1.0f / ((float)B * (float)TF * S);
+    AMS_L41_DISPATCH(false, emb, y, vspk, (const float*)nullptr, (float*)ws, (float*)nullptr, (float*)nullptr, TF, S, nblk, scale)
+    hipLaunchKernelGGL(l41_cost_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, cost, (long)B * nblk, scale);
+    return ams_check_launch();
+}
+
+// demb [B,TF,E], dvspk [B,S,E]; upstream = device scalar d loss / d cost
+ams_status ams_l41_loss_bwd(const float* emb, const float* y, const float* vspk, const float* upstream, float* demb, float* dvspk,
+                            int B, long TF, int E, int S, void* ws, size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(emb && y && vspk && upstream && demb && dvspk && ws && B > 0 && TF > 0 && S > 0 && S <= MAXS);
+    if (ws_bytes < ams_l41_workspace_bytes(B, TF, E, S)) return AMS_E_WORKSPACE_TOO_SMALL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = ceil_div(TF, 256);
+    dim3 grid(nblk, B);
+    const float scale = 1.0f / ((float)B * (float)TF * S);
+    AMS_L41_DISPATCH(true, emb, y, vspk, upstream, (float*)nullptr, demb, (float*)ws, TF, S, nblk, scale)
+    hipLaunchKernelGGL(l41_dvs_final_kernel, dim3(ceil_div(B * S * E, 256)), dim3(256), 0, st, (const float*)ws, dvspk, nblk, S * E, B);
+    return ams_check_launch();
+}
+
+}  // extern "C"

@@ -96,6 +96,57 @@ ams_status ams_opt_momentum(float* p, const float* g, float* accum, long n, floa
                             void* stream);
 ams_status ams_sumsq(const float* x, float* out, long n, void* ws, size_t ws_bytes, void* stream);
 
+/* ---- framed products: out[(r,t), n] = sum_k xpad[r, t*hop + k - pad_left] * Bm[k, n]   (K6 STFT as a DFT product,
+ * tf.contrib.signal.stft models/network.py:482-492; also the generic form of K2) ---- */
+ams_status ams_frames_matmul(const float* x, const float* Bm, float* out, int R, int L, int W, int N, int hop, int T, int pad_left,
+                             void* stream);
+
+/* ---- K5/K21 overlap-and-add: out[r,l] = sum_t frames[r,t,l+pad_left-t*hop]
+ * second half of tf.nn.conv2d_transpose (models/adapt.py:241-243) and of inverse_stft (models/network.py:598-602) ---- */
+ams_status ams_overlap_add(const float* frames, float* out, int R, int T, int W, int L, int hop, int pad_left, void* stream);
+
+/* ---- K22/K23 waveform statistics for SDR / L2 / PIT costs   models/adapt.py:321-372,404-431; network.py:196-221,662-724
+ * stats per utterance: D[S*S] (<t_s,a_s'>) | Na[S] | Nt[S] | Tm[S] (<t_s,mix>) | Nm[1];  mix may be NULL ---- */
+size_t ams_pair_stats_workspace_bytes(int B, int S, long L);
+ams_status ams_pair_stats_fwd(const float* target, const float* est, const float* mix, float* stats, int B, int S, long L, void* ws,
+                              size_t ws_bytes, void* stream);
+ams_status ams_pair_stats_bwd(const float* target, const float* est, const float* gstats, float* dest, int B, int S, long L,
+                              void* stream);
+
+/* ---- K20 mask application   models/network.py:577-581 ---- */
+ams_status ams_apply_masks_fwd(const float* X, const float* masks, float* sep, int B, int S, long TF, void* stream);
+ams_status ams_apply_masks_bwd(const float* X, const float* dsep, float* dmasks, int B, int S, long TF, void* stream);
+
+/* ---- overlap metric of the pretraining separator   models/adapt.py:141-160 ---- */
+ams_status ams_overlap_metric_fwd(const float* y, float* out, int B, int S, long TN, void* ws, size_t ws_bytes, void* stream);
+ams_status ams_overlap_metric_bwd(const float* y, const float* upstream, float* dy, int B, int S, long TN, void* stream);
+
+/* ---- K6/K7/K21 complex glue around the DFT products   models/network.py:497-499, 589-596 ---- */
+ams_status ams_cplx_mag_phase(const float* ri, float* mag, float* phasor, long rows, int F, void* stream);
+ams_status ams_cplx_apply_fwd(const float* sep, const float* phasor, float* z, long rows, int F, int S, int T, void* stream);
+ams_status ams_cplx_apply_bwd(const float* dz, const float* phasor, float* dsep, long rows, int F, int S, int T, void* stream);
+
+/* ---- K15 L41 loss   models/L41.py:150-178 (sampling=None) ---- */
+size_t ams_l41_workspace_bytes(int B, long TF, int E, int S);
+ams_status ams_l41_loss_fwd(const float* emb, const float* y, const float* vspk, float* cost, int B, long TF, int E, int S, void* ws,
+                            size_t ws_bytes, void* stream);
+ams_status ams_l41_loss_bwd(const float* emb, const float* y, const float* vspk, const float* upstream, float* demb, float* dvspk,
+                            int B, long TF, int E, int S, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- K16-K19 batched k-means   models/Kmeans_2.py:40-188 ----
+ * xn [b,L,E] normalised input (ams_kmeans_normalize); rows r = b_idx*tries + try; centroids [b*tries, C, E];
+ * w [b,L] silence weights or NULL; beta < 0 => hard assignment; w_mod_b reproduces the reference's tile order. */
+ams_status ams_kmeans_normalize(const float* x, float* xn, long nrows, int E, void* stream);
+size_t ams_kmeans_workspace_bytes(int R, long L, int E, int C);
+ams_status ams_kmeans_init(const float* xn, const int32_t* init_idx, float* centroids, int b, int tries, long L, int E, int C,
+                           void* stream);
+ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent_in, float* cent_out, int b, int tries, long L, int E,
+                              int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* stream);
+ams_status ams_kmeans_assign(const float* xn, const float* w, const float* cent, int32_t* labels, float* soft, float* inertia, int b,
+                             int tries, long L, int E, int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* stream);
+ams_status ams_kmeans_select(const float* inertia, const float* centroids, int32_t* best, float* selected, int b, int tries, int E,
+                             int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -254,3 +254,25 @@ def pretrain_separator_bwd(y, B, S, separation, dout):
         tot = d.sum(axis=1, keepdims=True)
         dy[B:] = (-(tot - d)).reshape(B * S, T, N)
     return dy
+
+
+def overlap_metric_bwd(y, B, S):
+    """d overlap / d y (all rows; mixture rows get 0).  m = 1 - |a-c|/(max(a,c)+1e-8) with a=|y_s|, c=|y_s'|."""
+    from itertools import combinations
+    T, N = y.shape[1:]
+    nm = y[B:].reshape(B, S, T * N)
+    a_abs = np.abs(nm)
+    g = np.zeros_like(nm)
+    npairs = S * (S - 1) // 2
+    for (i, j) in combinations(range(S), 2):
+        a, c = a_abs[:, i], a_abs[:, j]
+        mx = np.maximum(a, c) + 1e-8
+        diff = a - c
+        sg = np.sign(diff)
+        da = -sg / mx + np.where(a >= c, np.abs(diff) / mx ** 2, 0.0)
+        dc = sg / mx + np.where(c > a, np.abs(diff) / mx ** 2, 0.0)
+        g[:, i] += da * np.sign(nm[:, i])
+        g[:, j] += dc * np.sign(nm[:, j])
+    dy = np.zeros_like(y)
+    dy[B:] = (g / (B * npairs * T * N)).reshape(B * S, T, N)
+    return dy

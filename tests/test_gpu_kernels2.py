@@ -1,0 +1,188 @@
+"""GPU parity (second batch): synthesis, waveform statistics / costs, masks, STFT / iSTFT, L41 loss, k-means --
+each through the C ABI against the float64 (or, for bit-exact k-means labels, float32) numpy oracle."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import front as ofront, stft as ostft, l41 as ol41, losses as olosses, separate as osep, kmeans as okm
+
+TOL = 2e-5
+
+
+def dev(x, dtype=np.float32):
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=dtype)).cuda()
+
+
+def host(t):
+    torch.cuda.synchronize()
+    return t.detach().cpu().numpy().astype(np.float64)
+
+
+def rel(a, b):
+    b = np.asarray(b, np.float64)
+    return np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.fixture(scope='module')
+def F():
+    from ams_hip import functional as f
+    return f
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from ams_hip import ops as o
+    return o
+
+
+@pytest.mark.parametrize('R,L,W,N,hop', [(3, 640, 64, 6, 16), (4, 4096, 1024, 256, 256), (2, 1000, 128, 8, 48)])
+def test_synth_strided(F, R, L, W, N, hop):
+    rng = np.random.RandomState(L)
+    T = -(-L // hop)
+    z, f2, dout = rng.randn(R, T, N), rng.randn(W, N), rng.randn(R, L)
+    zt, ft = dev(z).requires_grad_(), dev(f2).requires_grad_()
+    out = F.synth_strided(zt, ft, hop, L)
+    assert rel(host(out), ofront.synth_strided(z, f2, hop, L)) < TOL
+    out.backward(dev(dout))
+    dz, df2 = ofront.synth_strided_bwd(z, f2, hop, dout)
+    assert rel(host(zt.grad), dz) < TOL and rel(host(ft.grad), df2) < TOL
+
+
+@pytest.mark.parametrize('S', [2, 3])
+def test_pair_stats_and_costs(F, S):
+    rng = np.random.RandomState(S)
+    B, L = 5, 3000
+    xn, bk = rng.randn(B, S, L) * 0.1, rng.randn(B, S, L) * 0.1
+    xm = xn.sum(1)
+    for kind in ('l2', 'sdr', 'l2+sdr'):
+        bt = dev(bk).requires_grad_()
+        p = F.pretrain_cost(dev(xm), dev(xn), bt)
+        loss = p[0] if kind == 'l2' else p[1] if kind == 'sdr' else p[0] + p[1]
+        lo, l2, sdr = olosses.pretrain_cost(xm, xn, bk, kind)
+        assert abs(float(loss) - lo) < TOL * max(1.0, abs(lo))
+        imp, _ = olosses.sdr_improvement(xm, xn, bk)
+        assert abs(float(p[2]) - imp) < 1e-4 * max(1.0, abs(imp))
+        loss.backward()
+        assert rel(host(bt.grad), olosses.pretrain_cost_bwd(xn, bk, kind)) < 5 * TOL
+    # PIT cost of the fine-tune recipes (0.5 sum_l, mean_s, min_perm, mean_b) + sub-gradient
+    bt = dev(bk).requires_grad_()
+    c = F.pit_l2(dev(xn), bt, 'sum', 'mean', 0.5)
+    c_ref, best = olosses.cost_finetuning(xn, bk)
+    assert abs(float(c) - c_ref) < TOL * max(1.0, abs(c_ref))
+    c.backward()
+    assert rel(host(bt.grad), olosses.pit_l2_bwd(xn, bk, best, 'sum', 'mean', 0.5)) < 5 * TOL
+    # Adapt.cost non-pretraining branch, including the cross-batch SDR broadcast (quirk C-3)
+    bt = dev(bk).requires_grad_()
+    p = F.pit_cost_adapt(dev(xm), dev(xn), bt)
+    lo, l2, sdr = olosses.pit_cost_adapt(xm, xn, bk, 'sdr+l2')
+    assert abs(float(p[0]) - l2) < TOL * max(1.0, abs(l2)) and abs(float(p[1]) - sdr) < 1e-4 * max(1.0, abs(sdr))
+    imp_ref, _ = olosses.sdr_improvement(xm, xn[:, None], bk, True)
+    assert abs(float(p[2]) - imp_ref) < 1e-3 * max(1.0, abs(imp_ref))
+    # gradient of the quirky sdr term vs torch autograd on the CPU restatement
+    bt2 = torch.from_numpy(bk).requires_grad_()
+    t_ = torch.from_numpy(xn)
+    tn, an = (t_ ** 2).sum(-1), (bt2 ** 2).sum(-1)
+    ts2 = ((t_[:, None] * bt2[None]).sum(-1)) ** 2
+    sdr_t = (tn[:, None] * an[None]) / (ts2 + 1e-12)
+    sdr_t.min(1)[0].sum(-1).mean().backward()
+    p[1].backward()
+    assert rel(host(bt.grad), bt2.grad.numpy()) < 1e-3
+
+
+def test_overlap_metric(F):
+    rng = np.random.RandomState(3)
+    B, S, T, N = 3, 3, 5, 7
+    y = rng.randn(B * (S + 1), T, N)
+    yt = dev(y).requires_grad_()
+    ov = F.overlap_metric(yt, B, S)
+    assert abs(float(ov) - ofront.overlap_metric(y, B, S)) < 1e-6
+    (ov * 3.0).backward()
+    assert rel(host(yt.grad), 3.0 * ofront.overlap_metric_bwd(y, B, S)) < 1e-5
+
+
+def test_apply_masks(F):
+    rng = np.random.RandomState(4)
+    B, T, Fq, S = 2, 5, 6, 3
+    X, m = rng.randn(B, T, Fq), rng.rand(B, T * Fq, S)
+    mt = dev(m).requires_grad_()
+    sep = F.apply_masks(dev(X), mt)
+    assert rel(host(sep), osep.apply_masks(X, m)) < 1e-6
+    d = rng.randn(B * S, T, Fq)
+    sep.backward(dev(d))
+    assert rel(host(mt.grad), osep.apply_masks_bwd(X, d, S)) < 1e-6
+
+
+@pytest.mark.parametrize('R,L,W,hop,S', [(4, 2048, 256, 128, 2), (6, 20480, 512, 256, 3), (2, 1500, 128, 32, 1)])
+def test_stft_istft(F, R, L, W, hop, S):
+    rng = np.random.RandomState(W)
+    x = rng.randn(R, L)
+    mag, ph = F.stft_mag_phase(dev(x), W, hop)
+    s = ostft.stft(x, W, hop)
+    assert rel(host(mag), np.abs(s)) < TOL
+    T, Fq = mag.shape[1:]
+    big = np.abs(s) > 1e-3 * np.abs(s).max()
+    phn = host(ph).reshape(R, T, 2 * Fq)
+    assert np.abs(phn[..., :Fq] - np.cos(np.angle(s)))[big].max() < 1e-3
+    assert np.abs(phn[..., Fq:] - np.sin(np.angle(s)))[big].max() < 1e-3
+    # inverse with the (mixture) phase tiled over S speakers: rows (b,s)
+    B = R
+    sep = rng.rand(B * S, T, Fq)
+    ang = np.repeat(np.angle(s), S, axis=0)
+    st = dev(sep).requires_grad_()
+    out = F.istft(st, ph, W, hop, S)
+    ref = ostft.istft(sep, ang, W, hop)
+    assert out.shape[1] == (T - 1) * hop + W and rel(host(out), ref) < 5 * TOL
+    dout = rng.randn(*ref.shape)
+    out.backward(dev(dout))
+    assert rel(host(st.grad), ostft.istft_bwd(ang, W, hop, dout)) < 5 * TOL
+
+
+@pytest.mark.parametrize('normalize', [True, False])
+def test_l41_loss(F, normalize):
+    rng = np.random.RandomState(6)
+    B, T, Fq, E, S, NS = 3, 4, 70, 40, 2, 11
+    emb, spk = rng.randn(B, T, Fq, E) * 0.3, rng.randn(NS, E)
+    I = np.array([[0, 3], [3, 5], [10, 1]], dtype=np.int32)
+    y = np.where(rng.rand(B, T, Fq, S) > 0.5, 1.0, -1.0)
+    et, st = dev(emb).requires_grad_(), dev(spk).requires_grad_()
+    c = F.l41_loss(et, dev(y), st, dev(I, np.int32), normalize)
+    c_ref = ol41.l41_cost(emb, y, spk, I, normalize)
+    assert abs(float(c) - c_ref) < TOL * max(1.0, abs(c_ref))
+    c.backward()
+    de, ds = ol41.l41_cost_bwd(emb, y, spk, I, normalize)
+    assert rel(host(et.grad), de) < 5 * TOL and rel(host(st.grad), ds) < 5 * TOL
+
+
+@pytest.mark.parametrize('b,L,E,C,tries,with_w,end', [(3, 5000, 40, 2, 2, False, True), (2, 4100, 40, 3, 3, True, False),
+                                                       (2, 2500, 8, 2, 1, True, True), (1, 20480, 40, 2, 2, False, True)])
+def test_kmeans_hard_bit_exact(F, ops, b, L, E, C, tries, with_w, end):
+    """Labels must be IDENTICAL to the float32 oracle (same summation order, no FMA, IEEE sqrt/div)."""
+    rng = np.random.RandomState(L + C)
+    centers = rng.randn(C, E).astype(np.float32) * 2.0
+    lab_true = rng.randint(0, C, (b, L))
+    X = (centers[lab_true] + rng.randn(b, L, E).astype(np.float32) * 0.7).astype(np.float32)
+    w = (rng.rand(b, L) > 0.2).astype(np.float32) if with_w else None
+    idx = np.stack([rng.choice(L, C, replace=False) for _ in range(b * tries)]).astype(np.int32)
+    cent_ref, lab_ref, best_ref = okm.kmeans(X, idx, C, tries, 4, beta=None, notsilent=w, assign_at_end=end)
+    xn = ops.kmeans_normalize(dev(X))
+    assert np.array_equal(host(xn).astype(np.float32), okm.l2_normalize_rows(X))
+    cent, lab, best = F.kmeans(dev(X), dev(idx, np.int32), C, tries, 4, None, dev(w) if with_w else None, end)
+    torch.cuda.synchronize()
+    assert np.array_equal(best.cpu().numpy(), best_ref)
+    assert np.array_equal(cent.cpu().numpy(), cent_ref)
+    assert np.array_equal(lab.cpu().numpy(), lab_ref)
+
+
+def test_kmeans_soft_forward(F):
+    rng = np.random.RandomState(9)
+    b, L, E, C, tries = 2, 3000, 40, 2, 2
+    centers = rng.randn(C, E) * 2.0
+    X = centers[rng.randint(0, C, (b, L))] + rng.randn(b, L, E) * 0.7
+    w = (rng.rand(b, L) > 0.2).astype(np.float64)
+    idx = np.stack([rng.choice(L, C, replace=False) for _ in range(b * tries)]).astype(np.int32)
+    cent_ref, lab_ref, best_ref = okm.kmeans(X, idx, C, tries, 5, beta=10.0, notsilent=w, assign_at_end=True)
+    cent, lab, best = F.kmeans(dev(X), dev(idx, np.int32), C, tries, 5, 10.0, dev(w), True)
+    assert np.array_equal(best.cpu().numpy(), best_ref)
+    assert rel(host(cent), cent_ref) < 1e-4 and np.abs(host(lab) - lab_ref).max() < 1e-3

@@ -306,3 +306,16 @@ def test_front_dpcl_step_grads_finite_difference():
         P[name][idx] += h
         fd = (cp - cm) / (2 * h)
         assert abs(fd - grads[name][idx]) < 1e-6 * max(1.0, abs(fd)), name
+
+
+def test_overlap_metric_grad():
+    B, S, T, N = 2, 3, 4, 5
+    y = RNG.randn(B * (S + 1), T, N)
+    yt = t(y).requires_grad_()
+    nm = yt[B:].reshape(B, S, -1).abs()
+    from itertools import combinations
+    vals = [(1.0 - (nm[:, i] - nm[:, j]).abs() / (torch.maximum(nm[:, i], nm[:, j]) + 1e-8)).mean(-1) for i, j in combinations(range(S), 2)]
+    ov = torch.stack(vals, 1).mean(1).mean()
+    ov.backward()
+    assert abs(front.overlap_metric(y, B, S) - ov.item()) < 1e-12
+    assert rel(front.overlap_metric_bwd(y, B, S), yt.grad.numpy()) < 1e-11
