@@ -440,6 +440,9 @@ def kmeans_run(xn, init_idx, C, tries, iterations, beta=None, w=None, assign_at_
     b, L, E = xn.shape
     R = b * tries
     dev = xn.device
+    if tuple(init_idx.shape) != (R, C) or init_idx.dtype != torch.int32 or not init_idx.is_cuda:
+        raise AmsError('kmeans: init_idx must be an int32 device tensor of shape [b*tries, C] = %s, got %s %s'
+                       % ((R, C), tuple(init_idx.shape), init_idx.dtype))
     hard = beta is None
     bval = -1.0 if hard else float(beta)
     nb = lib.ams_kmeans_workspace_bytes(R, L, E, C)

@@ -24,4 +24,4 @@ not by TensorFlow.
 All functions take/return numpy arrays and are dtype-generic: float64 for the
 parity oracle, float32 for the timed CPU baseline.
 """
-from . import front, stft, blstm, dense, dpcl, l41, kmeans, separate, losses, optim, step  # noqa: F401
+from . import front, stft, blstm, dense, dpcl, l41, kmeans, separate, losses, optim, step, recipes  # noqa: F401

@@ -1,0 +1,63 @@
+"""Oracle: remaining whole-recipe restatements (pretraining step, inference pipelines).
+
+Test infrastructure only -- see oracle/__init__.py.
+"""
+import numpy as np
+from . import front, stft, separate, losses, kmeans, step
+
+
+def pretrain_loss(x_mix, x_non_mix, P, hop, loss_kind, separation, overlap_coef=0.0, want_grads=True):
+    """experiments.training.pretraining step, path A (adapt.py:16-56, 95-252, 307-402) with beta=0, regularization=0."""
+    B, S, L = x_non_mix.shape
+    x = np.concatenate([x_mix, x_non_mix.reshape(B * S, L)], axis=0)
+    w1, b1, w2, b2 = P['front/window/w'], P['front/bases/bases'], P['back/window/value'], P['back/bases/value']
+    f, f2 = front.front_filter(w1, b1), front.front_filter(w2, b2)
+    y = front.conv_strided(x, f, hop)
+    z = front.pretrain_separator(y, B, S, separation)
+    back = front.synth_strided(z, f2, hop, L).reshape(B, S, L)
+    loss, l2, sdr = losses.pretrain_cost(x_mix, x_non_mix, back, loss_kind)
+    ov = front.overlap_metric(y, B, S)
+    cost = loss + (overlap_coef * ov if overlap_coef != 0.0 else 0.0)
+    if not want_grads:
+        return cost, back
+    dback = losses.pretrain_cost_bwd(x_non_mix, back, loss_kind).reshape(B * S, L)
+    dz, df2 = front.synth_strided_bwd(z, f2, hop, dback)
+    dy = front.pretrain_separator_bwd(y, B, S, separation, dz)
+    if overlap_coef != 0.0:
+        dy = dy + overlap_coef * front.overlap_metric_bwd(y, B, S)
+    df = front.conv_strided_bwd_filter(x, dy, f.shape[0], hop)
+    dw1, db1 = front.front_filter_bwd(w1, b1, df)
+    dw2, db2 = front.front_filter_bwd(w2, b2, df2)
+    grads = {'front/window/w': dw1, 'front/bases/bases': db1, 'back/window/value': dw2, 'back/bases/value': db2}
+    return cost, grads, back
+
+
+def front_separate_infer(x_mix, x_non_mix, P, hop, nb_layers, E, init_idx, nb_tries, nb_steps, beta=None, with_silence=False,
+                         threshold=2.0, end_assign=True):
+    """Front_Separator_Inference (trainer.py:420-434): front -> DPCL embeddings -> k-means masks -> back."""
+    B, S, L = x_non_mix.shape
+    y = step.front_rep(x_mix, x_non_mix, P, hop)
+    X, _ = separate.split_front(y, B, S)
+    V, _ = step.prediction_fwd(X, P, nb_layers, E)
+    T, Fq = X.shape[1:]
+    emb = V.reshape(B, T * Fq, E)
+    w = separate.kmeans_silence_weights(np.abs(X), threshold) if with_silence else None
+    cent, labels, best = kmeans.kmeans(emb, init_idx, S, nb_tries, nb_steps, beta=beta, notsilent=w, assign_at_end=end_assign)
+    masks = kmeans.masks_from_labels(labels, S, beta).astype(X.dtype)
+    sep = separate.apply_masks(X, masks)
+    f2 = front.front_filter(P['back/window/value'], P['back/bases/value'])
+    out = front.synth_strided(sep, f2, hop, L).reshape(B, S, L)
+    return out, labels, V
+
+
+def stft_separate_infer(x_mix, x_non_mix, P, W, hop, nb_layers, E, init_idx, nb_tries, nb_steps, end_assign=True):
+    """STFT_Separator_Inference (trainer.py:406-417): STFT -> DPCL -> hard k-means masks -> iSTFT with the mixture phase."""
+    B, S, L = x_non_mix.shape
+    X, _, ang = stft.stft_preprocessing(x_mix, x_non_mix, W, hop)
+    V, _ = step.prediction_fwd(X, P, nb_layers, E)
+    T, Fq = X.shape[1:]
+    cent, labels, best = kmeans.kmeans(V.reshape(B, T * Fq, E), init_idx, S, nb_tries, nb_steps, assign_at_end=end_assign)
+    masks = kmeans.masks_from_labels(labels, S, None).astype(X.dtype)
+    sep = separate.apply_masks(X, masks)
+    out = stft.istft(sep, np.repeat(ang, S, axis=0), W, hop).reshape(B, S, -1)
+    return out, labels, V

@@ -1,0 +1,187 @@
+"""GPU: whole recipes driven through the reference-API mirror (utils/trainer.py classes) vs the oracle."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from oracle import step as ostep, recipes as orec, optim as ooptim
+
+os.environ.setdefault('AMS_LOG_DIR', tempfile.mkdtemp(prefix='ams_log_'))
+
+
+def rel(a, b):
+    b = np.asarray(b, np.float64)
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def snapshot(g):
+    return {n: v.detach().cpu().numpy().astype(np.float64) for n, v in g.variables.items()}
+
+
+def one_train_step(trainer, tfds, L):
+    g, model = trainer.graph, trainer.model
+    with g.as_default():
+        feed = {tfds.handle: tfds.get_handle(tfds.TRAIN), tfds.chunk_size: L}
+        P = snapshot(g)
+        cost = float(model.train(feed, 0))
+        run = model.last_run
+        xm = model.x_mix.value(run).cpu().numpy().astype(np.float64)
+        xn = model.x_non_mix.value(run).cpu().numpy().astype(np.float64)
+        I = model.I.value(run).cpu().numpy()
+        grads = {v.ams_name: v.grad.detach().cpu().numpy() for v in model.trainable_variables}
+        P_new = {v.ams_name: v.detach().cpu().numpy() for v in model.trainable_variables}
+    return P, cost, xm, xn, I, grads, P_new
+
+
+def check_step(cost, c_ref, grads, g_ref, P, P_new, opt, tol=2e-4):
+    errs = {'cost': abs(cost - c_ref) / max(abs(c_ref), 1e-30)}
+    names = sorted(g_ref)
+    assert sorted(grads) == names
+    for n in names:
+        errs['grad ' + n] = rel(grads[n], g_ref[n])
+    plist = [P[n].copy() for n in names]
+    opt.apply(plist, [g_ref[n] for n in names])
+    for n, p in zip(names, plist):
+        errs['update ' + n] = rel(P_new[n], p)
+    assert max(errs.values()) < tol, errs
+
+
+def base_args(**kw):
+    from ams_hip import testing
+    a = dict(testing.ADAPT_DEFAULTS)
+    a.update(testing.SEPARATOR_DEFAULTS)
+    a.update(testing.ENHANCE_DEFAULTS)
+    a.update(kw)
+    return a
+
+
+@pytest.mark.parametrize('loss,separation,overlap,optimizer', [('sdr+l2', 'mask', 1.0, 'Adam'), ('l2', 'perfect', 0.0, 'RMSProp'),
+                                                                ('sdr', 'perfect', 0.5, 'SGD')])
+def test_pretraining_step(loss, separation, overlap, optimizer):
+    """experiments.training.pretraining (cfg2, default strided front): README.md:23 flags at reduced size."""
+    from utils.trainer import Adapt_Pretrainer
+    B, S, L, W, N, hop = 3, 2, 1024, 64, 16, 16
+    a = base_args(batch_size=B, nb_speakers=S, chunk_size=L, window_size=W, filters=N, hop_size=hop, loss=loss, separation=separation,
+                  overlap_coef=overlap, optimizer=optimizer, learning_rate=1e-3, pretraining=True)
+    a.pop('type')
+    tr = Adapt_Pretrainer(**a)
+    dist, tfds = tr.prepare()
+    P, cost, xm, xn, I, grads, P_new = one_train_step(tr, tfds, L)
+    c_ref, g_ref, back = orec.pretrain_loss(xm, xn, P, hop, loss, separation, overlap)
+    opt = {'Adam': ooptim.AMSGrad(1e-3), 'RMSProp': ooptim.RMSProp(1e-3), 'SGD': ooptim.Momentum(1e-3)}[optimizer]
+    check_step(cost, c_ref, grads, g_ref, P, P_new, opt)
+
+
+def test_stft_dpcl_step():
+    """experiments.training.STFT_DPCL (cfg1) at reduced size."""
+    from models.dpcl import DPCL
+    from utils.trainer import STFT_Separator_Trainer
+    B, S, L, W, hop, LS, NL, E = 4, 2, 2048, 64, 32, 12, 2, 8
+    a = base_args(batch_size=B, nb_speakers=S, chunk_size=L, window_size=W, hop_size=hop, layer_size=LS, nb_layers=NL,
+                  embedding_size=E, model_folder=None, learning_rate=1e-3)
+    a.pop('type')
+    tr = STFT_Separator_Trainer(DPCL, 'STFT_DPCL', **a)
+    dist, tfds = tr.prepare()
+    P, cost, xm, xn, I, grads, P_new = one_train_step(tr, tfds, L)
+    c_ref, g_ref, V, Y = ostep.stft_dpcl_loss(xm, xn, P, W, hop, NL, E)
+    check_step(cost, c_ref, grads, g_ref, P, P_new, ooptim.AMSGrad(1e-3))
+
+
+@pytest.mark.parametrize('normalize', [True, False])
+def test_front_l41_step(normalize):
+    """experiments.training.front_L41 (cfg5 family) at reduced size, S = 3."""
+    from tests.smoke_step import build_front_dpcl  # noqa: F401  (same folder helper)
+    from ams_hip import testing
+    from models.L41 import L41Model
+    from utils.trainer import Front_Separator_Trainer
+    tmp = tempfile.mkdtemp(prefix='ams_l41_')
+    B, S, L, W, N, hop, LS, NL, E = 3, 3, 1024, 64, 16, 16, 12, 2, 8
+    folder, params = testing.make_pretrained_adapt(os.path.join(tmp, 'pre'), window_size=W, filters=N, hop_size=hop, chunk_size=L,
+                                                   batch_size=B, nb_speakers=S)
+    a = base_args(**params)
+    a.update(layer_size=LS, nb_layers=NL, embedding_size=E, model_folder=folder, model_previous=None, pretraining=False,
+             no_normalize=normalize, learning_rate=1e-3)
+    a.pop('type')
+    tr = Front_Separator_Trainer(L41Model, 'front_L41', **a)
+    dist, tfds = tr.prepare()
+    P, cost, xm, xn, I, grads, P_new = one_train_step(tr, tfds, L)
+    c_ref, g_ref, V, Y = ostep.front_l41_loss(xm, xn, I, P, hop, NL, E, normalize)
+    check_step(cost, c_ref, grads, g_ref, P, P_new, ooptim.AMSGrad(1e-3))
+
+
+def _full_checkpoint(tmp, rng, W, N, hop, L, B, S, LS, NL, E, Fq, D_in, front=True):
+    from ams_hip import testing
+    P = ostep.init_params(rng, np.float32, front_W=W if front else None, N=N, D_in=D_in, layer_size=LS, nb_layers=NL, E=E, F=Fq,
+                          conv1d_scale=0.5)
+    params = dict(testing.ADAPT_DEFAULTS)
+    if not front:
+        for k in ('filters', 'max_pool'):
+            params.pop(k)
+    params.update(testing.SEPARATOR_DEFAULTS)
+    params.update(window_size=W, hop_size=hop, chunk_size=L, batch_size=B, nb_speakers=S, layer_size=LS, nb_layers=NL,
+                  embedding_size=E, type='front_DPCL' if front else 'STFT_DPCL', pretraining=False)
+    if front:
+        params.update(filters=N)
+    return testing.write_checkpoint(os.path.join(tmp, 'ckpt'), P, params), params, P
+
+
+@pytest.mark.parametrize('beta,with_silence', [(None, False), (None, True), (5.0, True)])
+def test_front_separator_inference(beta, with_silence):
+    """Front_Separator_Inference: front -> DPCL -> k-means masks -> back (trainer.py:420-434)."""
+    from models.dpcl import DPCL
+    from utils.trainer import Front_Separator_Inference
+    tmp = tempfile.mkdtemp(prefix='ams_inf_')
+    rng = np.random.RandomState(11)
+    B, S, L, W, N, hop, LS, NL, E, tries, steps = 2, 2, 2048, 64, 16, 16, 12, 2, 8, 2, 3
+    folder, params, P = _full_checkpoint(tmp, rng, W, N, hop, L, B, S, LS, NL, E, N, N)
+    T = -(-L // hop)
+    idx = np.stack([rng.choice(T * N, S, replace=False) for _ in range(B * tries)]).astype(np.int32)
+    a = base_args(**params)
+    a.update(model_folder=folder, nb_tries=tries, nb_steps=steps, beta_kmeans=beta, with_silence=with_silence, end_assign=True,
+             kmeans_init_indices=idx, out=False)
+    a.pop('type')
+    tr = Front_Separator_Inference(DPCL, 'front_DPCL_inference', **a)
+    dist, tfds = tr.prepare()
+    g, model = tr.graph, tr.model
+    with g.as_default():
+        feed = {tfds.handle: tfds.get_handle(tfds.TEST), tfds.chunk_size: L}
+        xm, xn, out = model.infer(feed, 0)
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    out_ref, lab_ref, V_ref = orec.front_separate_infer(xm.cpu().numpy().astype(np.float64), xn.cpu().numpy().astype(np.float64), P64, hop,
+                                                        NL, E, idx, tries, steps, beta=beta, with_silence=with_silence, end_assign=True)
+    assert out.shape == (B, S, L)
+    # embeddings agree to round-off; a label may flip only at a numerical tie, so compare the waveforms in norm
+    err = np.linalg.norm(out.cpu().numpy() - out_ref) / np.linalg.norm(out_ref)
+    assert err < 2e-2, err
+
+
+def test_stft_separator_inference():
+    """STFT_Separator_Inference: STFT -> DPCL -> hard k-means -> iSTFT (trainer.py:406-417)."""
+    from models.dpcl import DPCL
+    from utils.trainer import STFT_Separator_Inference
+    tmp = tempfile.mkdtemp(prefix='ams_sinf_')
+    rng = np.random.RandomState(12)
+    B, S, L, W, hop, LS, NL, E, tries, steps = 2, 2, 2048, 64, 32, 12, 2, 8, 2, 3
+    Fq = W // 2 + 1
+    folder, params, P = _full_checkpoint(tmp, rng, W, None, hop, L, B, S, LS, NL, E, Fq, Fq, front=False)
+    T = 1 + (L - W) // hop
+    idx = np.stack([rng.choice(T * Fq, S, replace=False) for _ in range(B * tries)]).astype(np.int32)
+    a = base_args(**params)
+    a.update(model_folder=folder, nb_tries=tries, nb_steps=steps, end_assign=True, kmeans_init_indices=idx, out=False)
+    a.pop('type')
+    tr = STFT_Separator_Inference(DPCL, 'STFT_DPCL_inference', **a)
+    dist, tfds = tr.prepare()
+    g, model = tr.graph, tr.model
+    with g.as_default():
+        feed = {tfds.handle: tfds.get_handle(tfds.TEST), tfds.chunk_size: L}
+        xm, xn, out = model.infer(feed, 0)
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    out_ref, lab_ref, V_ref = orec.stft_separate_infer(xm.cpu().numpy().astype(np.float64), xn.cpu().numpy().astype(np.float64), P64, W, hop,
+                                                       NL, E, idx, tries, steps, end_assign=True)
+    assert out.shape == (B, S, (T - 1) * hop + W)
+    err = np.linalg.norm(out.cpu().numpy() - out_ref) / np.linalg.norm(out_ref)
+    assert err < 2e-2, err
