@@ -461,22 +461,31 @@ class KMeansSoft(Function):
 
     @staticmethod
     def forward(ctx, X, init_idx, C, tries, iterations, beta, w, assign_at_end, normalize_input, faithful_tile):
-        xn = ops.kmeans_normalize(X) if normalize_input else X
+        b, L, E = X.shape
+        if normalize_input:
+            xn, inv = ops.l2norm_fwd(X.view(b, L * E), E)
+            xn = xn.view(b, L, E)
+        else:
+            xn, inv = X, None
         sel, out, best, trace = ops.kmeans_run(xn, init_idx, C, tries, iterations, beta, w, assign_at_end, faithful_tile)
-        ctx.save_for_backward(X, xn, init_idx, best, sel, *([w] if w is not None else []), *trace)
-        ctx.cfg = (C, tries, iterations, beta, w is not None, assign_at_end, normalize_input, faithful_tile)
+        extra = [t for t in (inv, w) if t is not None]
+        ctx.save_for_backward(xn, init_idx, best, *extra, *trace)
+        ctx.cfg = (C, tries, iterations, beta, inv is not None, w is not None, assign_at_end, faithful_tile)
         ctx.mark_non_differentiable(best)
         return sel, out, best
 
     @staticmethod
     def backward(ctx, dsel, dout, _dbest):
-        C, tries, iterations, beta, has_w, assign_at_end, normalize_input, faithful_tile = ctx.cfg
-        saved = ctx.saved_tensors
-        X, xn, init_idx, best, sel = saved[:5]
-        w = saved[5] if has_w else None
-        trace = saved[6 if has_w else 5:]
-        dX = ops.kmeans_soft_bwd(X, xn, init_idx, best, sel, w, trace, dsel, dout, C, tries, iterations, beta, assign_at_end,
-                                 normalize_input, faithful_tile)
+        from .kmeans_bwd import soft_bwd
+        C, tries, iterations, beta, has_inv, has_w, assign_at_end, faithful_tile = ctx.cfg
+        saved = list(ctx.saved_tensors)
+        xn, init_idx, best = saved[:3]
+        k = 3
+        inv = saved[k] if has_inv else None
+        k += int(has_inv)
+        w = saved[k] if has_w else None
+        k += int(has_w)
+        dX = soft_bwd(xn, inv, init_idx, best, w, saved[k:], dsel, dout, C, tries, iterations, beta, assign_at_end, faithful_tile)
         return (dX,) + (None,) * 9
 
 

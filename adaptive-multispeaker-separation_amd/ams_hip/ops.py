@@ -453,9 +453,13 @@ def kmeans_run(xn, init_idx, C, tries, iterations, beta=None, w=None, assign_at_
     wm = 1 if faithful_tile else 0
     for _ in range(iterations):
         nxt = torch.empty_like(cent)
-        check(lib.ams_kmeans_iterate(_p(xn), _p(w), _p(cent), _p(nxt), b, tries, L, E, C, bval, wm, _p(ws), nb, _s()), 'ams_kmeans_iterate')
+        den = torch.empty((R, C), dtype=torch.float32, device=dev) if not hard else None
+        check(lib.ams_kmeans_iterate(_p(xn), _p(w), _p(cent), _p(nxt), _p(den), b, tries, L, E, C, bval, wm, _p(ws), nb, _s()),
+              'ams_kmeans_iterate')
         cent = nxt
         trace.append(cent)
+        if den is not None:
+            trace.append(den)           # soft: trace = [c_0, c_1, den_0, c_2, den_1, ...]
     inertia = torch.empty(R, dtype=torch.float32, device=dev)
     labels = torch.empty((R, L), dtype=torch.int32, device=dev) if (hard and not assign_at_end) else None
     soft = torch.empty((R, L, C), dtype=torch.float32, device=dev) if (not hard and not assign_at_end) else None

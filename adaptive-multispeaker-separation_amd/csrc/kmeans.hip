@@ -199,7 +199,8 @@ __global__ __launch_bounds__(256) void kmeans_pass_kernel(KmArgs a) {
 }
 
 // Sum chunk partials in chunk order; ACC passes: centroid = num / den.  FINAL passes: inertia[r] = sum_c tot_c/cnt_c.
-__global__ void kmeans_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, int R, int G, int C, int E, int final_) {
+__global__ void kmeans_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, float* __restrict__ den_out, int R,
+                                     int G, int C, int E, int final_) {
     const int NV = final_ ? 2 * C : C * (E + 1);
     const int per = final_ ? 1 : C * E;
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -219,6 +220,7 @@ __global__ void kmeans_reduce_kernel(const float* __restrict__ part, float* __re
         float num = 0.f, den = 0.f;
         for (int g = 0; g < G; ++g) { num = __fadd_rn(num, pr[(long)g * NV + k]); den = __fadd_rn(den, pr[(long)g * NV + C * E + c]); }
         out[(long)r * C * E + k] = ((num) / (den));
+        if (den_out && (k % E) == 0) den_out[(long)r * C + c] = den;
     }
 }
 
@@ -246,6 +248,145 @@ __global__ void kmeans_select_kernel(const float* __restrict__ inertia, const fl
     }
     if (threadIdx.x == 0) best[bi] = bt;
     for (int i = threadIdx.x; i < CE; i += blockDim.x) sel[(long)bi * CE + i] = cent[((long)bi * tries + bt) * CE + i];
+}
+
+
+// ---- soft k-means backward, one streaming pass per unrolled iteration, selected try only ----
+// ITER pass (g = d/d c_{i+1}):   dnum_c = g_c/den_c, dden_c = -<g_c, c_{i+1,c}>/den_c,
+//   dlab[l,c] = w_l <x_l, dnum_c> + dden_c,  dx_l += w_l sum_c lab[l,c] dnum_c
+// FINAL pass (labels returned to the caller): dlab[l,c] = dout[l,c]
+// both: dlogit = lab (dlab - sum_c lab dlab), dd2 = -beta w_l dlogit, dx_l += sum_c 2 (x_l - c_c) dd2[l,c],
+//       g_out[c] = - sum_l 2 (x_l - c_c) dd2[l,c]      (gradient w.r.t. the centroids that produced lab)
+struct KmBwdArgs {
+    const float* xn; const float* w; const float* cent; const float* cent_next; const float* den; const float* g_in;
+    const float* dout; float* dx; float* part; long L; int G; int iter_mode; float beta;
+};
+
+template <int E_, int C_>
+__global__ __launch_bounds__(256) void kmeans_soft_bwd_kernel(KmBwdArgs a) {
+    constexpr int NV = C_ * E_;
+    constexpr int LD = E_ + 1;
+    constexpr int BUF = (256 * LD > 128 * 64) ? 256 * LD : 128 * 64;
+    __shared__ float buf[BUF];
+    __shared__ float scent[C_ * E_], sdnum[C_ * E_], sdden[C_];
+    const int r = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const float* xb = a.xn + (long)r * a.L * E_;
+    float* dxb = a.dx + (long)r * a.L * E_;
+    const float* wb = a.w ? a.w + (long)r * a.L : nullptr;
+    for (int i = tid; i < C_ * E_; i += 256) scent[i] = a.cent[(long)r * C_ * E_ + i];
+    if (a.iter_mode) {
+        for (int i = tid; i < C_ * E_; i += 256) sdnum[i] = a.g_in[(long)r * C_ * E_ + i] / a.den[(long)r * C_ + i / E_];
+        if (tid < C_) {
+            float d = 0.f;
+            for (int e = 0; e < E_; ++e) d += a.g_in[((long)r * C_ + tid) * E_ + e] * a.cent_next[((long)r * C_ + tid) * E_ + e];
+            sdden[tid] = -d / a.den[(long)r * C_ + tid];
+        }
+    }
+    float acc[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
+
+    for (int j = 0; j < PPL; ++j) {
+        const long p0 = (long)g * CHUNK + (long)j * LANES;
+        const int npts = (int)max((long)0, min((long)LANES, a.L - p0));
+        __syncthreads();
+        for (int i = tid; i < npts * E_; i += 256) buf[(i / E_) * LD + (i % E_)] = xb[p0 * E_ + i];
+        __syncthreads();
+        float dxl[E_];
+        if (tid < npts) {
+            float x[E_];
+#pragma unroll
+            for (int e = 0; e < E_; ++e) { x[e] = buf[tid * LD + e]; dxl[e] = 0.f; }
+            const float wv = wb ? wb[p0 + tid] : 1.0f;
+            float lab[C_], dlab[C_], sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < C_; ++c) {
+                float d = 0.f;
+#pragma unroll
+                for (int e = 0; e < E_; ++e) { const float diff = x[e] - scent[c * E_ + e]; d += diff * diff * wv; }
+                lab[c] = expf(-a.beta * d);
+                sum += lab[c];
+            }
+            const float inv = 1.0f / sum;
+            float mean = 0.f;
+#pragma unroll
+            for (int c = 0; c < C_; ++c) {
+                lab[c] *= inv;
+                if (a.iter_mode) {
+                    float dot = 0.f;
+#pragma unroll
+                    for (int e = 0; e < E_; ++e) dot += x[e] * sdnum[c * E_ + e];
+                    dlab[c] = wv * dot + sdden[c];
+#pragma unroll
+                    for (int e = 0; e < E_; ++e) dxl[e] += wv * lab[c] * sdnum[c * E_ + e];
+                } else {
+                    dlab[c] = a.dout[((long)r * a.L + p0 + tid) * C_ + c];
+                }
+                mean += lab[c] * dlab[c];
+            }
+#pragma unroll
+            for (int c = 0; c < C_; ++c) {
+                const float dd2 = -a.beta * wv * lab[c] * (dlab[c] - mean);
+#pragma unroll
+                for (int e = 0; e < E_; ++e) {
+                    const float t2 = 2.0f * (x[e] - scent[c * E_ + e]) * dd2;
+                    dxl[e] += t2;
+                    acc[c * E_ + e] -= t2;
+                }
+            }
+        }
+        // dx += dxl, transposed through LDS for coalesced read-modify-write
+        __syncthreads();
+        if (tid < npts) {
+#pragma unroll
+            for (int e = 0; e < E_; ++e) buf[tid * LD + e] = dxl[e];
+        }
+        __syncthreads();
+        for (int i = tid; i < npts * E_; i += 256) dxb[p0 * E_ + i] += buf[(i / E_) * LD + (i % E_)];
+    }
+#pragma unroll
+    for (int v0 = 0; v0 < NV; v0 += 64) {
+        __syncthreads();
+        if (wave >= 2) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i)
+                if (v0 + i < NV) buf[((wave - 2) * 64 + lane) * 64 + i] = acc[v0 + i];
+        }
+        __syncthreads();
+        if (wave < 2) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i)
+                if (v0 + i < NV) acc[v0 + i] += buf[(wave * 64 + lane) * 64 + i];
+        }
+        __syncthreads();
+        if (wave == 1) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i)
+                if (v0 + i < NV) buf[lane * 64 + i] = acc[v0 + i];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int i = 0; i < 64; ++i)
+                if (v0 + i < NV) acc[v0 + i] += buf[lane * 64 + i];
+        }
+    }
+    if (wave == 0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float v = wave_sum(acc[i]);
+            if (lane == 0) a.part[((long)r * a.G + g) * NV + i] = v;
+        }
+    }
+}
+
+__global__ void kmeans_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ g_out, int R, int G, int NV, int accumulate) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)R * NV) return;
+    const int r = (int)(i / NV), k = (int)(i - (long)r * NV);
+    float s = 0.f;
+    for (int g = 0; g < G; ++g) s += part[((long)r * G + g) * NV + k];
+    g_out[i] = accumulate ? g_out[i] + s : s;
 }
 
 template <int MODE>
@@ -293,8 +434,8 @@ ams_status ams_kmeans_init(const float* xn, const int32_t* init_idx, float* cent
 
 // One Lloyd iteration for all R = b*tries rows: labels from `cent_in`, new centroids to `cent_out`.
 // beta < 0: hard assignment (argmin), else soft assignment softmax(-beta d^2).
-ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent_in, float* cent_out, int b, int tries, long L, int E,
-                              int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* stream) {
+ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent_in, float* cent_out, float* den_out, int b, int tries,
+                              long L, int E, int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* stream) {
     AMS_REQUIRE(xn && cent_in && cent_out && ws && b > 0 && tries > 0 && L > 0 && C >= 2 && C <= 4);
     const int R = b * tries;
     if (ws_bytes < ams_kmeans_workspace_bytes(R, L, E, C)) return AMS_E_WORKSPACE_TOO_SMALL;
@@ -304,8 +445,8 @@ ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent
     a.w_mod_b = w_mod_b; a.beta = beta;
     ams_status s = beta < 0.f ? launch_pass<HARD_ACC>(a, R, E, C, st) : launch_pass<SOFT_ACC>(a, R, E, C, st);
     if (s != AMS_OK) return s;
-    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(ceil_div((long)R * C * E, 256)), dim3(256), 0, st, (const float*)ws, cent_out, R, a.G,
-                       C, E, 0);
+    hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(ceil_div((long)R * C * E, 256)), dim3(256), 0, st, (const float*)ws, cent_out, den_out, R,
+                       a.G, C, E, 0);
     return ams_check_launch();
 }
 
@@ -322,10 +463,39 @@ ams_status ams_kmeans_assign(const float* xn, const float* w, const float* cent,
     ams_status s = beta < 0.f ? launch_pass<HARD_FINAL>(a, R, E, C, st) : launch_pass<SOFT_FINAL>(a, R, E, C, st);
     if (s != AMS_OK) return s;
     if (inertia) {
-        hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, st, (const float*)ws, inertia, R, a.G, C, E, 1);
+        hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, st, (const float*)ws, inertia, (float*)nullptr, R, a.G, C, E, 1);
         s = ams_check_launch();
     }
     return s;
+}
+
+// One backward pass of the unrolled soft k-means for b rows (the selected tries, already gathered by the caller):
+// iter_mode 1: cent = c_i, cent_next = c_{i+1}, den = sum_l lab_i, g_in = d/d c_{i+1};  g_out = d/d c_i (overwritten)
+// iter_mode 0: cent = final centroids, dout = d/d labels [b,L,C];                        g_out += d/d cent
+// dx [b,L,E] is accumulated into.
+ams_status ams_kmeans_soft_bwd_pass(const float* xn, const float* w, const float* cent, const float* cent_next, const float* den,
+                                    const float* g_in, const float* dout, float* dx, float* g_out, int b, long L, int E, int C,
+                                    float beta, int iter_mode, void* ws, size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(xn && cent && dx && g_out && ws && b > 0 && L > 0 && C >= 2 && C <= 4 && beta >= 0.f);
+    AMS_REQUIRE(iter_mode ? (cent_next && den && g_in) : (dout != nullptr));
+    if (ws_bytes < ams_kmeans_workspace_bytes(b, L, E, C)) return AMS_E_WORKSPACE_TOO_SMALL;
+    hipStream_t st = (hipStream_t)stream;
+    KmBwdArgs a{};
+    a.xn = xn; a.w = w; a.cent = cent; a.cent_next = cent_next; a.den = den; a.g_in = g_in; a.dout = dout; a.dx = dx;
+    a.part = (float*)ws; a.L = L; a.G = ceil_div(L, CHUNK); a.iter_mode = iter_mode; a.beta = beta;
+    dim3 grid(a.G, b);
+#define AMS_KB(EE, CC) hipLaunchKernelGGL((kmeans_soft_bwd_kernel<EE, CC>), grid, dim3(256), 0, st, a)
+    if (E == 40 && C == 2) AMS_KB(40, 2);
+    else if (E == 40 && C == 3) AMS_KB(40, 3);
+    else if (E == 40 && C == 4) AMS_KB(40, 4);
+    else if (E == 8 && C == 2) AMS_KB(8, 2);
+    else if (E == 8 && C == 3) AMS_KB(8, 3);
+    else if (E == 20 && C == 2) AMS_KB(20, 2);
+    else return AMS_E_INVALID_ARG;
+#undef AMS_KB
+    hipLaunchKernelGGL(kmeans_bwd_reduce_kernel, dim3(ceil_div((long)b * C * E, 256)), dim3(256), 0, st, (const float*)ws, g_out, b, a.G,
+                       C * E, iter_mode ? 0 : 1);
+    return ams_check_launch();
 }
 
 ams_status ams_kmeans_select(const float* inertia, const float* centroids, int32_t* best, float* selected, int b, int tries, int E,

@@ -140,8 +140,12 @@ ams_status ams_kmeans_normalize(const float* x, float* xn, long nrows, int E, vo
 size_t ams_kmeans_workspace_bytes(int R, long L, int E, int C);
 ams_status ams_kmeans_init(const float* xn, const int32_t* init_idx, float* centroids, int b, int tries, long L, int E, int C,
                            void* stream);
-ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent_in, float* cent_out, int b, int tries, long L, int E,
-                              int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* stream);
+ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent_in, float* cent_out, float* den_out, int b, int tries,
+                              long L, int E, int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* stream);
+/* backward of one unrolled soft iteration / of the final soft assignment, for b already-selected rows */
+ams_status ams_kmeans_soft_bwd_pass(const float* xn, const float* w, const float* cent, const float* cent_next, const float* den,
+                                    const float* g_in, const float* dout, float* dx, float* g_out, int b, long L, int E, int C,
+                                    float beta, int iter_mode, void* ws, size_t ws_bytes, void* stream);
 ams_status ams_kmeans_assign(const float* xn, const float* w, const float* cent, int32_t* labels, float* soft, float* inertia, int b,
                              int tries, long L, int E, int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* stream);
 ams_status ams_kmeans_select(const float* inertia, const float* centroids, int32_t* best, float* selected, int b, int tries, int E,

@@ -61,3 +61,13 @@ def stft_separate_infer(x_mix, x_non_mix, P, W, hop, nb_layers, E, init_idx, nb_
     sep = separate.apply_masks(X, masks)
     out = stft.istft(sep, np.repeat(ang, S, axis=0), W, hop).reshape(B, S, -1)
     return out, labels, V
+
+
+def front_finetune_cost(x_mix, x_non_mix, P, hop, nb_layers, E, init_idx, nb_tries, nb_steps, beta, with_silence, threshold, end_assign,
+                        loss_kind):
+    """Front_Separator_Finetuning_Trainer objective (trainer.py:600-619 -> adapt.py:339-372), forward only: frozen front ->
+    DPCL embeddings -> SOFT k-means masks -> back -> PIT l2 + (cross-batch, quirk C-3) sdr."""
+    out, labels, V = front_separate_infer(x_mix, x_non_mix, P, hop, nb_layers, E, init_idx, nb_tries, nb_steps, beta=beta,
+                                          with_silence=with_silence, threshold=threshold, end_assign=end_assign)
+    loss, l2, sdr = losses.pit_cost_adapt(x_mix, x_non_mix, out, loss_kind)
+    return loss, out

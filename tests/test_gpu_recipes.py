@@ -185,3 +185,38 @@ def test_stft_separator_inference():
     assert out.shape == (B, S, (T - 1) * hop + W)
     err = np.linalg.norm(out.cpu().numpy() - out_ref) / np.linalg.norm(out_ref)
     assert err < 2e-2, err
+
+
+def test_front_dpcl_finetuning_step():
+    """experiments.training.front_DPCL_finetuning (cfg3(ii)): gradient reaches prediction/* only through the soft k-means
+    masks, the back end and the PIT cost.  Cost vs the oracle; gradients vs central differences of the float64 oracle."""
+    from models.dpcl import DPCL
+    from utils.trainer import Front_Separator_Finetuning_Trainer
+    tmp = tempfile.mkdtemp(prefix='ams_ft_')
+    rng = np.random.RandomState(21)
+    B, S, L, W, N, hop, LS, NL, E, tries, steps, beta = 2, 2, 1024, 64, 16, 16, 12, 2, 8, 1, 3, 4.0
+    folder, params, P = _full_checkpoint(tmp, rng, W, N, hop, L, B, S, LS, NL, E, N, N)
+    T = -(-L // hop)
+    idx = np.stack([rng.choice(T * N, S, replace=False) for _ in range(B * tries)]).astype(np.int32)
+    a = base_args(**params)
+    a.update(model_folder=folder, nb_tries=tries, nb_steps=steps, beta_kmeans=beta, with_silence=True, threshold=2.0, end_assign=True,
+             kmeans_init_indices=idx, loss='sdr+l2', optimizer='RMSProp', learning_rate=1e-4, pretraining=False)
+    a.pop('type')
+    tr = Front_Separator_Finetuning_Trainer(DPCL, 'front_L41_finetuning', **a)
+    dist, tfds = tr.prepare()
+    assert all(v.ams_name.startswith('prediction/') for v in tr.model.trainable_variables)
+    Pg, cost, xm, xn, I, grads, P_new = one_train_step(tr, tfds, L)
+    args = (hop, NL, E, idx, tries, steps, beta, True, 2.0, True, 'sdr+l2')
+    c_ref, _ = orec.front_finetune_cost(xm, xn, Pg, *args)
+    assert abs(cost - c_ref) < 1e-3 * abs(c_ref), (cost, c_ref)
+    for name in ('prediction/W', 'prediction/forward_BLSTM_1/rnn/basic_lstm_cell/kernel', 'prediction/b'):
+        g = grads[name]
+        k = np.unravel_index(np.argmax(np.abs(g)), g.shape)          # probe the largest entry
+        h = 1e-5 * max(1.0, abs(Pg[name][k]))
+        Pp = {n: v.copy() for n, v in Pg.items()}
+        Pp[name][k] += h
+        cp, _ = orec.front_finetune_cost(xm, xn, Pp, *args)
+        Pp[name][k] -= 2 * h
+        cm, _ = orec.front_finetune_cost(xm, xn, Pp, *args)
+        fd = (cp - cm) / (2 * h)
+        assert abs(g[k] - fd) < 2e-2 * max(abs(fd), 1e-6), (name, g[k], fd)
