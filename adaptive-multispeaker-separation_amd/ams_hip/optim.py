@@ -55,17 +55,26 @@ class FlatOptimizer(object):
     def zero_grad(self):
         self.flat_grad.zero_()
 
+    def exchange(self):
+        """Data-parallel gradient exchange: ONE all-reduce (sum) of the flat gradient buffer; returns the scale that
+        turns it into the mean (every loss on the hot path is a batch mean) and applies the clip."""
+        scale = 1.0
+        if self.dist is not None and self.dist.world_size > 1:
+            self.dist.all_reduce_sum(self.flat_grad)
+            scale = 1.0 / self.dist.world_size
+        if self.clip != 0.0:
+            gn = math.sqrt(float(self._sumsq(self.flat_grad))) * scale        # norm of the AVERAGED gradient
+            scale *= self.clip / max(gn, self.clip)                           # tf.clip_by_global_norm
+        return scale
+
+    def _sumsq(self, t):
+        return ops.sumsq(t).item() if t.is_cuda else float((t.double() ** 2).sum())
+
     def step(self):
         """Gradient exchange + clip + fused update.  Gradients must already be in flat_grad."""
         if self.flat.numel() == 0:
             return
-        scale = 1.0
-        if self.dist is not None and self.dist.world_size > 1:
-            self.dist.all_reduce_sum(self.flat_grad)
-            scale = 1.0 / self.dist.world_size            # every loss is a batch mean (SURVEY 8e)
-        if self.clip != 0.0:
-            gn = math.sqrt(float(ops.sumsq(self.flat_grad).item())) * scale
-            scale *= self.clip / max(gn, self.clip)       # tf.clip_by_global_norm
+        scale = self.exchange()
         if self.kind == 'Adam':
             lr_t = self.base_lr * math.sqrt(1.0 - self.b2p) / (1.0 - self.b1p)
             ops.opt_amsgrad(self.flat, self.flat_grad, self.m, self.v, self.vhat, lr_t, self.beta1, self.beta2, self.eps, scale)

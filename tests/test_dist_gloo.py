@@ -1,0 +1,75 @@
+"""CPU, world_size 2 over gloo: the data-parallel plumbing of the N>1 path -- identical replicas after the rank-0
+broadcast, disjoint utterance shards, and the single all-reduce of the flat gradient buffer giving the full-batch mean
+(SURVEY 8e).  No kernel is launched; RCCL replaces gloo on the GPU box."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, tmp, q):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                      AMS_LOG_DIR=os.path.join(tmp, 'log%d' % rank))
+    for p in (ROOT, os.path.join(ROOT, 'adaptive-multispeaker-separation_amd')):
+        sys.path.insert(0, p)
+    from tests.smoke_step import build_front_dpcl
+    trainer, tfds = build_front_dpcl(os.path.join(tmp, 'r%d' % rank), B=2, L=256, W=32, N=8, hop=8, layer_size=8, nb_layers=1, E=4)
+    g, model, dist = trainer.graph, trainer.model, trainer.args['dist']
+    assert dist.world_size == world and dist.rank == rank
+    # 1. replicas identical after the broadcast from rank 0 (each rank initialised with its own RNG stream on purpose)
+    if rank == 1:
+        for v in g.global_variables():
+            v.data.add_(1.0)
+    trainer._sync_replicas(dist)
+    w = torch.cat([v.detach().reshape(-1) for v in g.global_variables()])
+    gathered = [torch.zeros_like(w) for _ in range(world)]
+    torch.distributed.all_gather(gathered, w)
+    same = all(torch.equal(gathered[0], t) for t in gathered)
+    # 2. shards: disjoint, contiguous, covering the global batch
+    idx = tfds._batch_indices(tfds.TRAIN, 3)
+    # 3. gradient exchange: flat_grad = rank-dependent "per-rank mean gradient" -> averaged full-batch gradient
+    opt = model.optimize
+    opt.flat_grad.copy_(torch.arange(opt.flat_grad.numel(), dtype=torch.float32) * (rank + 1))
+    scale = opt.exchange()
+    avg = (opt.flat_grad * scale)
+    expect = torch.arange(opt.flat_grad.numel(), dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+    # 4. clip uses the norm of the averaged gradient
+    opt.clip = 0.5
+    opt.flat_grad.copy_(torch.ones_like(opt.flat_grad) * (rank + 1))
+    s2 = opt.exchange()
+    gn = float(torch.linalg.vector_norm(torch.ones_like(opt.flat_grad) * 1.5))
+    q.put((rank, same, idx.tolist(), bool(torch.allclose(avg, expect)), abs(s2 - (1.0 / world) * 0.5 / max(gn, 0.5)) < 1e-6))
+    dist.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_gloo_data_parallel(tmp_path):
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, str(tmp_path), q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), 'replicas differ after broadcast'
+    assert res[0][2] == [12, 13] and res[1][2] == [14, 15]            # batch 3, world 2, B=2: (3*2+rank)*2 ...
+    assert all(r[3] for r in res), 'all-reduced mean gradient wrong'
+    assert all(r[4] for r in res), 'global-norm clip must use the averaged gradient'

@@ -1,0 +1,88 @@
+"""Golden vectors (tests/golden/*.npz, produced by tests/golden/make_golden.py from the float64 oracle):
+CPU: the oracle still reproduces them; GPU: the HIP path matches them."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import step as ostep, recipes as orec, kmeans as okm, stft as ostft
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+
+
+def load(name):
+    d = np.load(os.path.join(G, name))
+    return {k: d[k] for k in d.files}
+
+
+def rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def test_oracle_reproduces_front_dpcl_and_pretraining_goldens():
+    d = load('front_dpcl_step.npz')
+    B, S, L, W, N, hop, LS, NL, E = [int(v) for v in d['cfg']]
+    P = {k[2:]: v for k, v in d.items() if k.startswith('P/')}
+    cost, grads, V, Y = ostep.front_dpcl_loss(d['x_mix'], d['x_non_mix'], P, hop, NL, E)
+    assert abs(cost - d['cost']) < 1e-12 and rel(V, d['V']) < 1e-12 and np.array_equal(Y, d['Y'])
+    for k, v in grads.items():
+        assert rel(v, d['G/' + k]) < 1e-10, k
+    p = load('pretraining_step.npz')
+    c, g, back = orec.pretrain_loss(d['x_mix'], d['x_non_mix'], P, hop, 'sdr+l2', 'mask', 1.0)
+    assert abs(c - p['cost']) < 1e-12 and rel(back, p['back']) < 1e-12
+
+
+def test_oracle_reproduces_kmeans_and_stft_goldens():
+    k = load('kmeans_hard.npz')
+    C, tries, iters = [int(v) for v in k['cfg']]
+    cent, lab, best = okm.kmeans(k['X'], k['idx'], C, tries, iters, beta=None, notsilent=k['w'], assign_at_end=True)
+    assert np.array_equal(lab, k['labels']) and np.array_equal(cent, k['centroids']) and np.array_equal(best, k['best'])
+    s = load('stft.npz')
+    st = ostft.stft(s['x'], 256, 128)
+    assert rel(np.abs(st), s['mag']) < 1e-12 and rel(ostft.istft(np.abs(st), np.angle(st), 256, 128), s['rec']) < 1e-12
+
+
+@pytest.mark.gpu
+def test_hip_matches_front_dpcl_golden():
+    import torch
+    from ams_hip import functional as F, ops
+    d = load('front_dpcl_step.npz')
+    B, S, L, W, N, hop, LS, NL, E = [int(v) for v in d['cfg']]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    P = {k[2:]: dev(v).requires_grad_(k[2:].startswith('prediction/')) for k, v in d.items() if k.startswith('P/')}
+    x = dev(np.concatenate([d['x_mix'], d['x_non_mix'].reshape(B * S, L)], 0))
+    y = F.front_conv(x, F.front_filter(P['front/window/w'], P['front/bases/bases']), hop)
+    Y = ops.make_masks(y[B:].contiguous(), B, S, 1.0, 0.0, True)
+    h = y[:B].contiguous()
+    for i in range(NL):
+        kf, bf, kb, bb = ostep.lstm_names('prediction', i)
+        h = F.blstm(h, P[kf], P[bf], P[kb], P[bb])
+    u = F.dense(h, P['prediction/W'], P['prediction/b'])
+    V, inv = F.l2norm_keep(u, E)
+    out = F.dpcl_loss_from_u(u, V, inv, Y)
+    out[0].backward()
+    torch.cuda.synchronize()
+    assert abs(float(out[0]) - float(d['cost'])) < 1e-4 * abs(float(d['cost']))
+    assert rel(V.detach().cpu().numpy(), d['V']) < 1e-3                 # north_star: embeddings within 1e-3 rel fp32
+    assert np.array_equal(Y.cpu().numpy().reshape(d['Y'].shape), d['Y'])
+    for k, v in P.items():
+        if k.startswith('prediction/'):
+            assert rel(v.grad.cpu().numpy(), d['G/' + k]) < 1e-3, k
+
+
+@pytest.mark.gpu
+def test_hip_matches_kmeans_and_stft_goldens():
+    import torch
+    from ams_hip import functional as F
+    k = load('kmeans_hard.npz')
+    C, tries, iters = [int(v) for v in k['cfg']]
+    cent, lab, best = F.kmeans(torch.from_numpy(k['X']).cuda(), torch.from_numpy(k['idx']).cuda(), C, tries, iters, None,
+                               torch.from_numpy(k['w']).cuda(), True)
+    torch.cuda.synchronize()
+    assert np.array_equal(lab.cpu().numpy(), k['labels'])               # north_star: cluster assignment bit-exact
+    assert np.array_equal(cent.cpu().numpy(), k['centroids']) and np.array_equal(best.cpu().numpy(), k['best'])
+    s = load('stft.npz')
+    mag, ph = F.stft_mag_phase(torch.from_numpy(s['x'].astype(np.float32)).cuda(), 256, 128)
+    assert rel(mag.cpu().numpy(), s['mag']) < 1e-4
+    rec = F.istft(mag, ph, 256, 128, 1)
+    assert rel(rec.cpu().numpy(), s['rec']) < 1e-4
