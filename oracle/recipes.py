@@ -71,3 +71,50 @@ def front_finetune_cost(x_mix, x_non_mix, P, hop, nb_layers, E, init_idx, nb_tri
                                           with_silence=with_silence, threshold=threshold, end_assign=end_assign)
     loss, l2, sdr = losses.pit_cost_adapt(x_mix, x_non_mix, out, loss_kind)
     return loss, out
+
+
+def front_enhance_loss(x_mix, x_non_mix, P, hop, nb_layers, E, nb_layers_enh, init_idx, nb_tries, nb_steps, nonlinearity='softmax',
+                       end_assign=True, want_grads=True):
+    """Front_Separator_Enhance_Trainer objective (trainer.py:621-630, adapt.py:457-469): frozen front + DPCL + hard k-means masks ->
+    enhance BLSTM stack (network.py:610-660) -> PIT squared error against the signed non-mix representation (network.py:662-693).
+    Gradients for the 'enhance/*' variables only."""
+    from . import blstm, dense
+    B, S, L = x_non_mix.shape
+    y = step.front_rep(x_mix, x_non_mix, P, hop)
+    X, X_nm = separate.split_front(y, B, S)
+    V, _ = step.prediction_fwd(X, P, nb_layers, E)
+    T, Fq = X.shape[1:]
+    cent, labels, best = kmeans.kmeans(V.reshape(B, T * Fq, E), init_idx, S, nb_tries, nb_steps, assign_at_end=end_assign)
+    masks = kmeans.masks_from_labels(labels, S, None).astype(X.dtype)
+    sep = separate.apply_masks(X, masks)                                    # [B*S, T, F]
+    z = separate.enhance_input(sep, X, S, False)                            # [B*S, T, 2F]
+    h, caches = blstm.blstm_stack_fwd(z, step.stack_params(P, 'enhance', nb_layers_enh))
+    u = dense.dense_fwd(h, P['enhance/W'], P['enhance/b'])                  # [B*S, T, F]
+    cost_in, out = separate.enhance_output(u, X, S, nonlinearity)           # [B,TF,S]
+    cost, best_perm = losses.enhance_cost(X_nm, cost_in)
+    if not want_grads:
+        return cost
+    est = cost_in.transpose(0, 2, 1)                                        # [B,S,TF]
+    tgt = X_nm.reshape(B, -1, S).transpose(0, 2, 1)
+    d_est = losses.pit_l2_bwd(tgt, est, best_perm, 'sum', 'sum', 1.0)       # [B,S,TF]
+    d_cost_in = d_est.transpose(0, 2, 1)                                    # [B,TF,S]
+    dy = d_cost_in * X.reshape(B, T * Fq, 1)
+    if nonlinearity == 'softmax':
+        yv = cost_in / np.where(X.reshape(B, T * Fq, 1) == 0, 1.0, X.reshape(B, T * Fq, 1))
+        ylog = u.reshape(B, S, T * Fq).transpose(0, 2, 1)
+        e = np.exp(ylog - ylog.max(axis=2, keepdims=True))
+        sm = e / e.sum(axis=2, keepdims=True)
+        dlog = sm * (dy - (dy * sm).sum(axis=2, keepdims=True))
+    elif nonlinearity == 'tanh':
+        ylog = u.reshape(B, S, T * Fq).transpose(0, 2, 1)
+        dlog = dy * (1.0 - np.tanh(ylog) ** 2)
+    else:
+        dlog = dy
+    du = dlog.transpose(0, 2, 1).reshape(B * S, T, Fq)
+    dh, dW, db = dense.dense_bwd(h, P['enhance/W'], du)
+    _, lg = blstm.blstm_stack_bwd(dh, caches, need_dx=False)
+    grads = {'enhance/W': dW, 'enhance/b': db}
+    for i, g in enumerate(lg):
+        for n, v in zip(step.lstm_names('enhance', i), g):
+            grads[n] = v
+    return cost, grads

@@ -10,6 +10,8 @@ def build_front_dpcl(tmp, B=3, L=1024, W=64, N=16, hop=16, layer_size=16, nb_lay
     from ams_hip import testing
     from models.dpcl import DPCL
     from utils.trainer import Front_Separator_Trainer
+    import utils.ops
+    utils.ops.rng.seed(42)          # the reference's module-level Conv1D RNG (utils/ops.py:5): make the init order-independent here
     folder, params = testing.make_pretrained_adapt(os.path.join(tmp, 'pre'), window_size=W, filters=N, hop_size=hop,
                                                    chunk_size=L, batch_size=B, nb_speakers=S)
     args = dict(params)
