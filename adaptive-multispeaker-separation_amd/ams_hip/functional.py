@@ -553,3 +553,23 @@ def istft(sep, phasor, W, hop, S):
     from .stft_host import dft_matrices
     _, Dinv = dft_matrices(W, hop, sep.device)
     return ISTFT.apply(_c(sep), phasor, Dinv, W, hop, S)
+
+
+def front_maxpool(x, f, P, hop):
+    from .pooling import front_maxpool as _f
+    return _f(x, f, P, hop)
+
+
+def synth_unpool(vals, argmax_mix, f2, L, S, P=None, hop=None):
+    from .pooling import synth_unpool as _f
+    return _f(vals, argmax_mix, f2, L, P, hop, S)
+
+
+def front_avgpool(x, f, P):
+    from .pooling import front_avgpool as _f
+    return _f(x, f, P)
+
+
+def synth_avgpool(z, f2, P, L):
+    from .pooling import synth_avgpool as _f
+    return _f(z, f2, P, L)

@@ -67,9 +67,9 @@ def build_adapt_back(m):
         z = z.reshape(B * S, -1, N)
         if m.with_max_pool:
             am = m.argmax.value(run)[:B]                                   # mixture argmax, tiled S times (adapt.py:212-218)
-            out = F.synth_unpool(z, am, f2.value(run), L, S)
+            out = F.synth_unpool(z, am, f2.value(run), L, S, P, hop)
         elif m.with_average_pool:
-            out = F.synth_strided(F.upsample_nearest(z, P), f2.value(run), 1, L)
+            out = F.synth_avgpool(z, f2.value(run), P, L)
         else:
             out = F.synth_strided(z, f2.value(run), hop, L)
         return out.reshape(B, S, L)

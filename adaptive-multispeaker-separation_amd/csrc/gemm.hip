@@ -40,6 +40,7 @@ struct GemmArgs {
     int splits, k_per_split;
     float* partial;            // [splits, M, N] when splits > 1
     int a_vec, b_vec;          // 16-byte vector loads legal
+    int32_t* pidx;             // EPI_MAXPOOL: per (row-tile, column) arg-max row
 };
 
 template <int AMODE>
@@ -71,7 +72,9 @@ __device__ __forceinline__ float loadB1(const GemmArgs& g, int k, int n) {
 // Is operand A contiguous along k (-> transposed LDS writes) ?
 template <int AMODE> struct AKContig { static constexpr bool v = (AMODE == A_ROW || AMODE == A_FRAMES); };
 
-template <int AMODE, int BMODE>
+enum { EPI_STORE = 0, EPI_MAXPOOL = 1 };
+
+template <int AMODE, int BMODE, int EPI = EPI_STORE>
 __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
     constexpr bool AK = AKContig<AMODE>::v;
     constexpr bool BKc = (BMODE == B_COL);
@@ -226,6 +229,40 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         __syncthreads();
     }
 
+    if (EPI == EPI_MAXPOOL) {
+        // Fused max-pool partial (reference models/adapt.py:115-117: stride-1 conv + max_pool_with_argmax): the [Bt,L,N]
+        // conv output is never written; each 128-row tile emits, per column, its maximum and the row that holds it
+        // (first maximum wins ties).  A second small kernel combines tiles into pooling windows.
+        float* sred = smem;                                     // [2 wn][2 j][32] values then rows
+        int* srow = reinterpret_cast<int*>(smem + 128);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float best = -3.4e38f;
+            int brow = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    const float v = acc[i][j][r];
+                    if (row < g.M && (v > best || (v == best && row < brow))) { best = v; brow = row; }
+                }
+            const float ob = __shfl_xor(best, 32, 64);
+            const int orow = __shfl_xor(brow, 32, 64);
+            if (ob > best || (ob == best && orow < brow)) { best = ob; brow = orow; }
+            if (wm == 1 && lk == 0) { sred[(wn * 2 + j) * 32 + l31] = best; srow[(wn * 2 + j) * 32 + l31] = brow; }
+            __syncthreads();
+            if (wm == 0 && lk == 0) {
+                const float ob2 = sred[(wn * 2 + j) * 32 + l31];
+                const int or2 = srow[(wn * 2 + j) * 32 + l31];
+                if (ob2 > best || (ob2 == best && or2 < brow)) { best = ob2; brow = or2; }
+                const int col = n0 + wn * 64 + j * 32 + l31;
+                if (col < g.N) { g.C[(long)tile_m * g.N + col] = best; g.pidx[(long)tile_m * g.N + col] = brow; }
+            }
+            __syncthreads();
+        }
+        return;
+    }
     // Epilogue.  C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
     float* out = g.splits > 1 ? g.partial + (long)split * g.M * g.N : g.C;
     const long ldo = g.splits > 1 ? g.N : g.ldc;
@@ -374,6 +411,21 @@ ams_status ams_frames_matmul(const float* x, const float* Bm, float* out, int R,
     return launch<A_FRAMES, B_ROW>(g, nullptr, 0, (hipStream_t)stream);
 }
 
+// Filter gradient of a framed product with explicit geometry: dB[k,n] = sum_{r,t} xpad[r, t*hop + k - pad_left] * dy[(r,t), n]
+size_t ams_frames_matmul_bwd_filter_workspace_bytes(int R, int W, int N, int T) { return ams_gemm_workspace_bytes(W, N, R * T); }
+
+ams_status ams_frames_matmul_bwd_filter(const float* x, const float* dy, float* dB, int R, int L, int W, int N, int hop, int T,
+                                        int pad_left, void* ws, size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(x && dy && dB && R > 0 && L > 0 && W > 0 && N > 0 && hop > 0 && T > 0 && pad_left >= 0);
+    GemmArgs g{};
+    g.A = x; g.B = dy; g.C = dB; g.bias = nullptr;
+    g.M = W; g.N = N; g.K = R * T; g.lda = 0; g.ldb = N; g.ldc = N;
+    g.fr_L = L; g.fr_T = T; g.fr_hop = hop; g.fr_pl = pad_left; g.fr_W = W;
+    g.a_vec = 0;
+    g.b_vec = aligned16(dy) && (N % 4 == 0);
+    return launch<A_FRAMES_T, B_ROW>(g, ws, ws_bytes, (hipStream_t)stream);
+}
+
 size_t ams_front_conv_bwd_filter_workspace_bytes(int Bt, int L, int W, int N, int hop) {
     const int T = (L + hop - 1) / hop;
     return ams_gemm_workspace_bytes(W, N, Bt * T);
@@ -393,6 +445,192 @@ ams_status ams_front_conv_bwd_filter(const float* x, const float* dy, float* df,
     g.a_vec = 0;
     g.b_vec = aligned16(dy) && (N % 4 == 0);
     return launch<A_FRAMES_T, B_ROW>(g, ws, ws_bytes, (hipStream_t)stream);
+}
+
+}  // extern "C"
+
+// ---- max-pool front (path B) --------------------------------------------------------------------------------------
+namespace {
+
+// Combine per-tile partial maxima into pooling windows: window t covers positions [t*hop, t*hop+P) of row b.
+// argmax = l*N + n (TF-1.x GPU convention: no batch term; reference utils/ops.py:111-116 relies on it).
+__global__ void maxpool_window_kernel(const float* __restrict__ pmax, const int32_t* __restrict__ pidx, float* __restrict__ y,
+                                      long long* __restrict__ argmax, int Bt, int L, int N, int P, int hop, int T) {
+    const long total = (long)Bt * T * N;
+    const int tiles_per_row = L / BM;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N);
+        const long bt = i / N;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        const int j0 = (t * hop) / BM, j1 = (t * hop + P) / BM;
+        float best = -3.4e38f;
+        int brow = 0;
+        for (int j = j0; j < j1; ++j) {
+            const long k = ((long)b * tiles_per_row + j) * N + n;
+            const float v = pmax[k];
+            if (v > best) { best = v; brow = pidx[k]; }          // tiles scanned in increasing position: first max wins
+        }
+        y[i] = best;
+        argmax[i] = (long long)(brow - b * L) * N + n;
+    }
+}
+
+// Generic (any P / hop / L) fallback: one thread per (b,t,n); O(P*W) each -- used for small or unaligned shapes.
+__global__ void maxpool_naive_kernel(const float* __restrict__ x, const float* __restrict__ f, float* __restrict__ y,
+                                     long long* __restrict__ argmax, int Bt, int L, int W, int N, int P, int hop, int T, int pl) {
+    const long total = (long)Bt * T * N;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int n = (int)(i % N);
+        const long bt = i / N;
+        const int t = (int)(bt % T), b = (int)(bt / T);
+        float best = -3.4e38f;
+        int bl = 0;
+        for (int l = t * hop; l < t * hop + P; ++l) {
+            float s = 0.f;
+            for (int k = 0; k < W; ++k) {
+                const int p = l + k - pl;
+                if (p >= 0 && p < L) s += x[(long)b * L + p] * f[(long)k * N + n];
+            }
+            if (s > best) { best = s; bl = l; }
+        }
+        y[i] = best;
+        argmax[i] = (long long)bl * N + n;
+    }
+}
+
+// Gather-form filter gradient shared by the max-pool front and the sparse (unpool) synthesis:
+//   df[k,n] = sum_{r,t} xpad[r, pos(r/rdiv,t,n) + k] * v[r,t,n],   pos = argmax / N.   Thread per tap k; sequential over (r,t).
+__global__ __launch_bounds__(256) void gather_filter_grad_kernel(const float* __restrict__ x, const float* __restrict__ v,
+                                                                 const long long* __restrict__ argmax, float* __restrict__ df, int R,
+                                                                 int L, int W, int N, int T, int pl, int rdiv) {
+    const int n = blockIdx.y;
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= W) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) {
+        const float* xr = x + (long)r * L;
+        for (int t = 0; t < T; ++t) {
+            const int pos = (int)(argmax[((long)(r / rdiv) * T + t) * N + n] / N);
+            const int p = pos + k - pl;
+            const float val = v[((long)r * T + t) * N + n];
+            if (p >= 0 && p < L) s += xr[p] * val;
+        }
+    }
+    df[(long)k * N + n] = s;
+}
+
+// Sparse synthesis, gather form (never builds the unpooled [R,L,N] tensor; reference adapt.py:210-243, ops.py:94-120):
+//   out[r,l] = sum_n sum_{t in cand(l)} vals[r,t,n] * f2[l - pos + pl, n],  pos = argmax[r/S,t,n] / N
+__global__ __launch_bounds__(256) void synth_unpool_kernel(const float* __restrict__ vals, const long long* __restrict__ argmax,
+                                                           const float* __restrict__ f2, float* __restrict__ out, int R, int L, int W,
+                                                           int N, int T, int P, int hop, int pl, int S) {
+    const int r = blockIdx.y;
+    const int l = blockIdx.x * blockDim.x + threadIdx.x;
+    const int l_lo = blockIdx.x * blockDim.x, l_hi = min(L, l_lo + (int)blockDim.x) - 1;
+    // windows whose positions [t*hop, t*hop+P) can reach any sample of this block: pos in (l+pl-W, l+pl]
+    int t0 = (l_lo + pl - W + 1 - (P - 1));
+    t0 = t0 <= 0 ? 0 : t0 / hop;
+    int t1 = (l_hi + pl) / hop;
+    if (t1 > T - 1) t1 = T - 1;
+    float s = 0.f;
+    const long long* am = argmax + (long)(r / S) * T * N;
+    for (int n = 0; n < N; ++n)
+        for (int t = t0; t <= t1; ++t) {
+            const int pos = (int)(am[(long)t * N + n] / N);
+            const int k = l - pos + pl;
+            if (l < L && k >= 0 && k < W) s += vals[((long)r * T + t) * N + n] * f2[(long)k * N + n];
+        }
+    if (l < L) out[(long)r * L + l] = s;
+}
+
+// dvals[r,t,n] = sum_k dout_pad[r, pos + k] * f2[k,n]     (one wave per (r,t,n))
+__global__ __launch_bounds__(256) void synth_unpool_bwd_vals_kernel(const float* __restrict__ dout, const long long* __restrict__ argmax,
+                                                                    const float* __restrict__ f2, float* __restrict__ dvals, long total,
+                                                                    int L, int W, int N, int T, int pl, int S) {
+    const int lane = threadIdx.x & 63;
+    const long wid0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, wstride = ((long)gridDim.x * blockDim.x) >> 6;
+    for (long i = wid0; i < total; i += wstride) {
+        const int n = (int)(i % N);
+        const long rt = i / N;
+        const int t = (int)(rt % T), r = (int)(rt / T);
+        const int pos = (int)(argmax[((long)(r / S) * T + t) * N + n] / N);
+        float s = 0.f;
+        for (int k = lane; k < W; k += 64) {
+            const int p = pos + k - pl;
+            if (p >= 0 && p < L) s += dout[(long)r * L + p] * f2[(long)k * N + n];
+        }
+        s = wave_sum(s);
+        if (lane == 0) dvals[i] = s;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t ams_front_maxpool_workspace_bytes(int Bt, int L, int N) {
+    return (size_t)Bt * (L / BM + 1) * N * (sizeof(float) + sizeof(int32_t));
+}
+
+// Path B front: y [Bt,T,N], argmax int64 [Bt,T,N], T = (L-P)/hop + 1   (reference models/adapt.py:115-117)
+ams_status ams_front_maxpool_fwd(const float* x, const float* f, float* y, long long* argmax, int Bt, int L, int W, int N, int P, int hop,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(x && f && y && argmax && Bt > 0 && L >= P && W > 0 && N > 0 && P > 0 && hop > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int T = (L - P) / hop + 1;
+    const int pl = (W - 1) / 2;                                  // stride-1 SAME: pad_total = W-1, left = floor
+    const long total = (long)Bt * T * N;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 8192) blocks = 8192;
+    if (L % BM == 0 && P % BM == 0 && hop % BM == 0 && ws && ws_bytes >= ams_front_maxpool_workspace_bytes(Bt, L, N)) {
+        GemmArgs g{};
+        g.A = x; g.B = f; g.bias = nullptr;
+        g.M = Bt * L; g.N = N; g.K = W; g.ldb = N; g.ldc = N;
+        g.fr_L = L; g.fr_T = L; g.fr_hop = 1; g.fr_pl = pl; g.fr_W = W;
+        g.a_vec = 0;                                             // hop 1: frame starts are not 16-byte aligned
+        g.b_vec = aligned16(f) && (N % 4 == 0);
+        g.splits = 1; g.k_per_split = ceil_div(W, BK) * BK;
+        const int tiles_m = g.M / BM;
+        g.C = (float*)ws;
+        g.pidx = (int32_t*)((float*)ws + (size_t)tiles_m * N);
+        dim3 grid(tiles_m * ceil_div(N, BN), 1);
+        hipLaunchKernelGGL((gemm_f32_kernel<A_FRAMES, B_ROW, EPI_MAXPOOL>), grid, dim3(256), 0, st, g);
+        hipLaunchKernelGGL(maxpool_window_kernel, dim3(blocks), dim3(256), 0, st, (const float*)g.C, (const int32_t*)g.pidx, y, argmax, Bt,
+                           L, N, P, hop, T);
+    } else {
+        hipLaunchKernelGGL(maxpool_naive_kernel, dim3(blocks), dim3(256), 0, st, x, f, y, argmax, Bt, L, W, N, P, hop, T, pl);
+    }
+    return ams_check_launch();
+}
+
+// df[k,n] = sum_{r,t} xpad[r, argmax[r/rdiv,t,n]/N + k] * v[r,t,n]   (max-pool front: x = waveforms, v = dy, rdiv = 1;
+// sparse synthesis: x = d out, v = pooled values, rdiv = S because the mixture's argmax is tiled over speakers)
+ams_status ams_gather_filter_grad(const float* x, const float* v, const long long* argmax, float* df, int R, int L, int W, int N, int T,
+                                  int rdiv, void* stream) {
+    AMS_REQUIRE(x && v && argmax && df && R > 0 && L > 0 && W > 0 && N > 0 && T > 0 && rdiv > 0);
+    hipLaunchKernelGGL(gather_filter_grad_kernel, dim3(ceil_div(W, 256), N), dim3(256), 0, (hipStream_t)stream, x, v, argmax, df, R, L, W,
+                       N, T, (W - 1) / 2, rdiv);
+    return ams_check_launch();
+}
+
+// Path B back: unpool with the mixture's argmax (tiled S times) + stride-1 conv2d_transpose SAME, sparse form.
+ams_status ams_synth_unpool_fwd(const float* vals, const long long* argmax, const float* f2, float* out, int R, int L, int W, int N, int T,
+                                int P, int hop, int S, void* stream) {
+    AMS_REQUIRE(vals && argmax && f2 && out && R > 0 && L > 0 && W > 0 && N > 0 && T > 0 && P > 0 && hop > 0 && S > 0);
+    hipLaunchKernelGGL(synth_unpool_kernel, dim3(ceil_div(L, 256), R), dim3(256), 0, (hipStream_t)stream, vals, argmax, f2, out, R, L, W,
+                       N, T, P, hop, (W - 1) / 2, S);
+    return ams_check_launch();
+}
+
+ams_status ams_synth_unpool_bwd_vals(const float* dout, const long long* argmax, const float* f2, float* dvals, int R, int L, int W, int N,
+                                     int T, int S, void* stream) {
+    AMS_REQUIRE(dout && argmax && f2 && dvals && R > 0 && L > 0 && W > 0 && N > 0 && T > 0 && S > 0);
+    const long total = (long)R * T * N;
+    long blocks = (total + 3) / 4;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(synth_unpool_bwd_vals_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dout, argmax, f2, dvals, total,
+                       L, W, N, T, (W - 1) / 2, S);
+    return ams_check_launch();
 }
 
 }  // extern "C"

@@ -44,6 +44,19 @@ size_t ams_front_conv_bwd_filter_workspace_bytes(int Bt, int L, int W, int N, in
 ams_status ams_front_conv_bwd_filter(const float* x, const float* dy, float* df, int Bt, int L, int W, int N, int hop, void* ws,
                                      size_t ws_bytes, void* stream);
 
+/* ---- K3/K4/K5 path B (--with_max_pool): stride-1 conv + tf.nn.max_pool_with_argmax fused (models/adapt.py:115-117);
+ * argmax int64 = l*N + n (no batch term).  Sparse (unpool-free) synthesis and gather-form filter
+ * gradients (models/adapt.py:210-243, utils/ops.py:94-120). ---- */
+size_t ams_front_maxpool_workspace_bytes(int Bt, int L, int N);
+ams_status ams_front_maxpool_fwd(const float* x, const float* f, float* y, long long* argmax, int Bt, int L, int W, int N, int P, int hop,
+                                 void* ws, size_t ws_bytes, void* stream);
+ams_status ams_gather_filter_grad(const float* x, const float* v, const long long* argmax, float* df, int R, int L, int W, int N, int T,
+                                  int rdiv, void* stream);
+ams_status ams_synth_unpool_fwd(const float* vals, const long long* argmax, const float* f2, float* out, int R, int L, int W, int N, int T,
+                                int P, int hop, int S, void* stream);
+ams_status ams_synth_unpool_bwd_vals(const float* dout, const long long* argmax, const float* f2, float* dvals, int R, int L, int W, int N,
+                                     int T, int S, void* stream);
+
 /* ---- dense contractions (tf.matmul / tf.nn.conv1d k=1 / dynamic_rnn input projection) ----
  * C[M,N] (+)= op(A) . op(B) (+ bias[N]);  transX = 0: row-major [rows,cols] as written, 1: stored transposed.
  * mask_period/mask_skip (transA only): reduction rows k with k % period == skip are treated as zero
@@ -100,6 +113,10 @@ ams_status ams_sumsq(const float* x, float* out, long n, void* ws, size_t ws_byt
  * tf.contrib.signal.stft models/network.py:482-492; also the generic form of K2) ---- */
 ams_status ams_frames_matmul(const float* x, const float* Bm, float* out, int R, int L, int W, int N, int hop, int T, int pad_left,
                              void* stream);
+
+size_t ams_frames_matmul_bwd_filter_workspace_bytes(int R, int W, int N, int T);
+ams_status ams_frames_matmul_bwd_filter(const float* x, const float* dy, float* dB, int R, int L, int W, int N, int hop, int T,
+                                        int pad_left, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- K5/K21 overlap-and-add: out[r,l] = sum_t frames[r,t,l+pad_left-t*hop]
  * second half of tf.nn.conv2d_transpose (models/adapt.py:241-243) and of inverse_stft (models/network.py:598-602) ---- */

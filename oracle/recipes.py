@@ -118,3 +118,38 @@ def front_enhance_loss(x_mix, x_non_mix, P, hop, nb_layers, E, nb_layers_enh, in
         for n, v in zip(step.lstm_names('enhance', i), g):
             grads[n] = v
     return cost, grads
+
+
+def pretrain_loss_maxpool(x_mix, x_non_mix, P, Pool, hop, loss_kind, separation, want_grads=True):
+    """experiments.training.pretraining --with_max_pool (path B; adapt.py:114-117, 210-223) with beta = reg = overlap_coef = 0."""
+    B, S, L = x_non_mix.shape
+    x = np.concatenate([x_mix, x_non_mix.reshape(B * S, L)], axis=0)
+    w1, b1, w2, b2 = P['front/window/w'], P['front/bases/bases'], P['back/window/value'], P['back/bases/value']
+    f, f2 = front.front_filter(w1, b1), front.front_filter(w2, b2)
+    W = f.shape[0]
+    y, am = front.front_maxpool(x, f, Pool, hop)
+    z = front.pretrain_separator(y, B, S, separation)
+    am_t = np.repeat(am[:B], S, axis=0)                              # mixture argmax tiled S times (adapt.py:212-218)
+    back = front.synth_unpool(z, am_t, f2, L).reshape(B, S, L)
+    loss, l2, sdr = losses.pretrain_cost(x_mix, x_non_mix, back, loss_kind)
+    if not want_grads:
+        return loss, back
+    dback = losses.pretrain_cost_bwd(x_non_mix, back, loss_kind).reshape(B * S, L)
+    dz, df2 = front.synth_unpool_bwd(z, am_t, f2, dback)
+    dy = front.pretrain_separator_bwd(y, B, S, separation, dz)
+    df = front.front_maxpool_bwd_filter(x, dy, am, W)
+    dw1, db1 = front.front_filter_bwd(w1, b1, df)
+    dw2, db2 = front.front_filter_bwd(w2, b2, df2)
+    return loss, {'front/window/w': dw1, 'front/bases/bases': db1, 'back/window/value': dw2, 'back/bases/value': db2}, back, am
+
+
+def pretrain_forward_avgpool(x_mix, x_non_mix, P, Pool, separation):
+    """Forward of the --with_average_pool pretraining path (path C; adapt.py:118-120, 225-228): returns back [B,S,L]."""
+    B, S, L = x_non_mix.shape
+    x = np.concatenate([x_mix, x_non_mix.reshape(B * S, L)], axis=0)
+    f = front.front_filter(P['front/window/w'], P['front/bases/bases'])
+    f2 = front.front_filter(P['back/window/value'], P['back/bases/value'])
+    y = front.front_avgpool(x, f, Pool)
+    z = front.pretrain_separator(y, B, S, separation)
+    up = front.upsample_nearest(z, Pool)
+    return front.synth_strided(up, f2, 1, L).reshape(B, S, L), y

