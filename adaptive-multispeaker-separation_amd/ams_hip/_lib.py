@@ -23,7 +23,7 @@ def parse_header(path=HEADER_PATH):
     src = open(path).read()
     src = re.sub(r'/\*.*?\*/', ' ', src, flags=re.S)
     protos = {}
-    for m in re.finditer(r'\b(ams_status|size_t|int|void)\s+(ams_\w+)\s*\(([^)]*)\)\s*;', src):
+    for m in re.finditer(r'\b(ams_status|size_t|int|void)\s+(ams_\w+)\s*\(([^)]*)\)\s*;', src):  # noqa: E501
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         argtypes = []
         if args and args != 'void':

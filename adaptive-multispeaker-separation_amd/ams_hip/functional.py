@@ -13,6 +13,45 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+class _Overlap(object):
+    """Weight-gradient products are off the backward critical path (only dx feeds the next layer's BPTT), while the
+    recurrent step kernels are latency-bound and leave most CUs idle.  When enabled, dW / dU / db products are launched on
+    a SIDE HIP stream and accumulate straight into the parameters' pre-assigned gradient views (the flat all-reduce buffer),
+    so they overlap the next layer's recurrence; `join()` is called before the optimizer / all-reduce."""
+
+    def __init__(self):
+        self.enabled = False
+        self.stream = None
+
+    def side(self):
+        if self.stream is None:
+            import os
+            self.stream = torch.cuda.Stream(priority=int(os.environ.get('AMS_SIDE_PRIORITY', '0')))
+        return self.stream
+
+    def usable(self, *params):
+        return self.enabled and all(p.grad is not None and p.grad.is_contiguous() for p in params)
+
+    def fork(self, *tensors):
+        s = self.side()
+        s.wait_stream(torch.cuda.current_stream())
+        for t in tensors:
+            t.record_stream(s)
+        return s
+
+    def cap(self, on):
+        import os
+        from ._lib import load
+        load().ams_gemm_set_lds_pad(int(os.environ.get('AMS_SIDE_LDS_PAD', '0')) if on else 0)
+
+    def join(self):
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
+
+
+OVERLAP = _Overlap()
+
+
 class FrontFilter(Function):
     """f = |w| * bases   (models/adapt.py:106, :234)."""
 
@@ -50,12 +89,25 @@ class BLSTMLayer(Function):
     def forward(ctx, x, Kf, bf, Kb, bb):
         out, G, cst = ops.blstm_fwd(x, Kf, bf, Kb, bb)
         ctx.save_for_backward(x, Kf, Kb, out, G, cst)
+        ctx.biases = (bf, bb)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, Kf, Kb, out, G, cst = ctx.saved_tensors
-        dx, dKf, dbf, dKb, dbb = ops.blstm_bwd(x, Kf, Kb, out, G, cst, _c(dout), need_dx=ctx.needs_input_grad[0])
+        bf, bb = ctx.biases
+        need_dx = ctx.needs_input_grad[0]
+        if OVERLAP.usable(Kf, Kb, bf, bb) and all(ctx.needs_input_grad[1:]):
+            B, T, D = x.shape
+            ops.blstm_bwd_recurrent(x, Kf, Kb, G, cst, _c(dout))
+            s = OVERLAP.fork(x, out, G)
+            with torch.cuda.stream(s):
+                OVERLAP.cap(True)
+                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True)
+                OVERLAP.cap(False)
+            dx = ops.blstm_bwd_dx(G, Kf, Kb, B, T, D) if need_dx else None
+            return dx, None, None, None, None
+        dx, dKf, dbf, dKb, dbb = ops.blstm_bwd(x, Kf, Kb, out, G, cst, _c(dout), need_dx=need_dx)
         return dx, dKf, dbf, dKb, dbb
 
 
@@ -65,6 +117,7 @@ class Dense(Function):
     @staticmethod
     def forward(ctx, x, W, b):
         ctx.save_for_backward(x, W)
+        ctx.bias = b
         x2 = x.reshape(-1, x.shape[-1])
         u = ops.gemm(x2, W, bias=b)
         return u.view(x.shape[:-1] + (W.shape[1],))
@@ -74,6 +127,16 @@ class Dense(Function):
         x, W = ctx.saved_tensors
         du2 = _c(du).view(-1, W.shape[1])
         x2 = x.reshape(-1, x.shape[-1])
+        b = ctx.bias
+        if OVERLAP.usable(W, b) and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            s = OVERLAP.fork(x2, du2)
+            with torch.cuda.stream(s):
+                OVERLAP.cap(True)
+                ops.gemm(x2, du2, transA=True, out=W.grad, accumulate=True)
+                OVERLAP.cap(False)
+                ops.colsum_into(du2, b.grad, True)
+            dx = ops.gemm(du2, W, transB=True).view(x.shape) if ctx.needs_input_grad[0] else None
+            return dx, None, None
         dx = ops.gemm(du2, W, transB=True).view(x.shape) if ctx.needs_input_grad[0] else None
         dW = ops.gemm(x2, du2, transA=True) if ctx.needs_input_grad[1] else None
         db = ops.colsum(du2) if ctx.needs_input_grad[2] else None

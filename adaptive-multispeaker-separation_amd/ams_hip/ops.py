@@ -182,40 +182,68 @@ def blstm_fwd(x, Kf, bf, Kb, bb):
     return out, G, cst
 
 
-def blstm_bwd(x, Kf, Kb, out, G, cst, dout, need_dx=True):
-    """BPTT for one BLSTM layer.  DESTROYS G (it becomes d pre-activation).  Returns dx, dKf, dbf, dKb, dbb."""
-    _chk(x, Kf, Kb, out, G, cst, dout)
+def blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout):
+    """BPTT recurrence of one BLSTM layer: overwrites G (activated gates) with d pre-activation."""
+    _chk(x, Kf, Kb, G, cst, dout)
     lib = load()
     B, T, D = x.shape
     H = Kf.shape[1] // 4
-    dev = x.device
-    dc = torch.empty((B, 2, H), dtype=torch.float32, device=dev)
-    pack = torch.empty(lib.ams_blstm_pack_floats(H, 1), dtype=torch.float32, device=dev)
+    dc = torch.empty((B, 2, H), dtype=torch.float32, device=x.device)
+    pack = torch.empty(lib.ams_blstm_pack_floats(H, 1), dtype=torch.float32, device=x.device)
     check(lib.ams_blstm_recurrent_bwd(_p(G), _p(cst), _p(dout), _p(dc), _p(Kf[D:]), _p(Kb[D:]), 4 * H, _p(pack), B, T, H, _s()),
           'ams_blstm_recurrent_bwd')
+
+
+def blstm_bwd_dx(G, Kf, Kb, B, T, D):
+    """dx = dZ_f . Wx_f^T + dZ_b . Wx_b^T  (the only hoisted product on the backward critical path)."""
+    H = Kf.shape[1] // 4
+    M = B * T
+    dZf = G.view(-1)
+    dZb = G.view(-1)[4 * H:]
+    dx = torch.empty((B, T, D), dtype=torch.float32, device=G.device)
+    gemm(dZf, Kf, transB=True, out=dx, M=M, N=D, K=4 * H, lda=8 * H, ldb=4 * H, ldc=D)
+    gemm(dZb, Kb, transB=True, out=dx, accumulate=True, M=M, N=D, K=4 * H, lda=8 * H, ldb=4 * H, ldc=D)
+    return dx
+
+
+def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate):
+    """Weight gradients of one BLSTM layer from dZ (= G after blstm_bwd_recurrent), written (or accumulated) into the given
+    buffers: dWx = x^T dZ, dU = h_prev^T dZ (time-shifted, masked at sequence boundaries), db = column sums."""
+    lib = load()
+    B, T, D = x.shape
+    H = dKf.shape[1] // 4
     M = B * T
     x2 = x.view(M, D)
     dZf = G.view(-1)                       # direction 0 columns start at 0, ld = 8H
     dZb = G.view(-1)[4 * H:]
-    dKf = torch.empty_like(Kf)
-    dKb = torch.empty_like(Kb)
-    # dWx = x^T dZ   (reduction over B*T)
-    gemm(x2, dZf, transA=True, out=dKf, M=D, N=4 * H, K=M, lda=D, ldb=8 * H, ldc=4 * H)
-    gemm(x2, dZb, transA=True, out=dKb, M=D, N=4 * H, K=M, lda=D, ldb=8 * H, ldc=4 * H)
-    # dU = h_prev^T dZ : forward dir pairs out[b,t-1] with dZ[b,t]; backward dir pairs out[b,t+1] with dZ[b,t]
+    acc = bool(accumulate)
+    gemm(x2, dZf, transA=True, out=dKf, accumulate=acc, M=D, N=4 * H, K=M, lda=D, ldb=8 * H, ldc=4 * H)
+    gemm(x2, dZb, transA=True, out=dKb, accumulate=acc, M=D, N=4 * H, K=M, lda=D, ldb=8 * H, ldc=4 * H)
+    # forward dir pairs out[b,t-1] with dZ[b,t]; backward dir pairs out[b,t+1] with dZ[b,t]
     of = out.view(-1)
-    gemm(of, dZf[8 * H:], transA=True, out=dKf[D:], M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H, ldc=4 * H, mask=(T, T - 1))
-    gemm(of[2 * H + H:], dZb, transA=True, out=dKb[D:], M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H, ldc=4 * H, mask=(T, T - 1))
-    nb = lib.ams_colsum_workspace_bytes(M, 8 * H)
+    gemm(of, dZf[8 * H:], transA=True, out=dKf[D:], accumulate=acc, M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H, ldc=4 * H,
+         mask=(T, T - 1))
+    gemm(of[2 * H + H:], dZb, transA=True, out=dKb[D:], accumulate=acc, M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H, ldc=4 * H,
+         mask=(T, T - 1))
+    nb = lib.ams_colsum_workspace_bytes(M, 4 * H)
     ws = _ws(nb, x)
-    db = torch.empty(8 * H, dtype=torch.float32, device=dev)
-    check(lib.ams_colsum(_p(G), _p(db), M, 8 * H, 8 * H, 0, _p(ws), nb, _s()), 'ams_colsum')
-    dx = None
-    if need_dx:
-        dx = torch.empty((B, T, D), dtype=torch.float32, device=dev)
-        gemm(dZf, Kf, transB=True, out=dx, M=M, N=D, K=4 * H, lda=8 * H, ldb=4 * H, ldc=D)
-        gemm(dZb, Kb, transB=True, out=dx, accumulate=True, M=M, N=D, K=4 * H, lda=8 * H, ldb=4 * H, ldc=D)
-    return dx, dKf, db[:4 * H], dKb, db[4 * H:]
+    check(lib.ams_colsum(_p(dZf), _p(dbf), M, 4 * H, 8 * H, int(acc), _p(ws), nb, _s()), 'ams_colsum')
+    ws2 = _ws(nb, x)
+    check(lib.ams_colsum(_p(dZb), _p(dbb), M, 4 * H, 8 * H, int(acc), _p(ws2), nb, _s()), 'ams_colsum')
+
+
+def blstm_bwd(x, Kf, Kb, out, G, cst, dout, need_dx=True):
+    """BPTT for one BLSTM layer.  DESTROYS G (it becomes d pre-activation).  Returns dx, dKf, dbf, dKb, dbb."""
+    _chk(x, Kf, Kb, out, G, cst, dout)
+    B, T, D = x.shape
+    H = Kf.shape[1] // 4
+    blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout)
+    dKf, dKb = torch.empty_like(Kf), torch.empty_like(Kb)
+    dbf = torch.empty(4 * H, dtype=torch.float32, device=x.device)
+    dbb = torch.empty(4 * H, dtype=torch.float32, device=x.device)
+    blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, False)
+    dx = blstm_bwd_dx(G, Kf, Kb, B, T, D) if need_dx else None
+    return dx, dKf, dbf, dKb, dbb
 
 
 # ------------------------------------------------------------------ l2norm / dense
@@ -233,6 +261,15 @@ def l2norm_bwd(v, inv, dv, E):
     du = torch.empty_like(v)
     check(load().ams_l2norm_bwd(_p(v), _p(inv), _p(dv), _p(du), inv.numel(), E, _s()), 'ams_l2norm_bwd')
     return du
+
+
+def colsum_into(x2, out, accumulate):
+    _chk(x2, out)
+    lib = load()
+    rows, cols = x2.shape
+    nb = lib.ams_colsum_workspace_bytes(rows, cols)
+    ws = _ws(nb, x2)
+    check(lib.ams_colsum(_p(x2), _p(out), rows, cols, cols, int(bool(accumulate)), _p(ws), nb, _s()), 'ams_colsum')
 
 
 def colsum(x2):

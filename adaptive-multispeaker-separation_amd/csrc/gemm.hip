@@ -20,6 +20,8 @@
 
 namespace {
 
+thread_local int t_gemm_lds_pad = 0;
+
 constexpr int BM = 128, BN = 128, BK = 16;
 constexpr int PAD_T = 2;   // k-contiguous source, transposed scalar LDS writes: stride 130 -> conflict-free
 constexpr int PAD_V = 4;   // m/n-contiguous source, float4 LDS writes: stride 132 keeps 16B alignment
@@ -338,7 +340,10 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st) {
     g.k_per_split = kps;
     g.partial = (float*)ws;
     dim3 grid(tiles, splits);
-    hipLaunchKernelGGL((gemm_f32_kernel<AMODE, BMODE>), grid, dim3(256), 0, st, g);
+    // Occupancy cap for launches that are meant to run BESIDE latency-critical kernels (weight-gradient products on
+    // the side stream): unused dynamic LDS limits how many of these workgroups a CU admits, leaving registers/slots
+    // for the recurrent step kernels.  Thread-local, set through ams_gemm_set_lds_pad().
+    hipLaunchKernelGGL((gemm_f32_kernel<AMODE, BMODE>), grid, dim3(256), (size_t)t_gemm_lds_pad, st, g);
     ams_status s = ams_check_launch();
     if (s != AMS_OK) return s;
     if (splits > 1) {
@@ -357,6 +362,8 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 }  // namespace
 
 extern "C" {
+
+void ams_gemm_set_lds_pad(int bytes) { t_gemm_lds_pad = bytes < 0 ? 0 : bytes; }
 
 size_t ams_gemm_workspace_bytes(int M, int N, int K) {
     int splits = choose_splits(M, N, K);

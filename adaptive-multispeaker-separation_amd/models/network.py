@@ -171,6 +171,8 @@ class Network(object):
             v.requires_grad_(False)
         opt = FlatOptimizer(self.trainable_variables, self.my_opt, self.learning_rate, self.decay_epoch,
                             self.gradient_clip, self.dist)
+        F.OVERLAP.enabled = (bool(self.args.get('overlap_weight_grads', True)) and torch.cuda.is_available()
+                             and os.environ.get('AMS_OVERLAP', '1') != '0')
         self.optimizer = opt
         self.increment_epoch = opt.increment_epoch
         g.summaries['optimize/learning_rate'] = Node('learning_rate', lambda run: opt.learning_rate())
@@ -212,7 +214,8 @@ class Network(object):
     def _train_graphed(self, feed_dict, step):
         """Capture zero_grad + forward + backward once (after 2 eager steps) and replay it; inputs are copied into
         static buffers, the optimizer (per-step lr_t, all-reduce) stays outside the graph."""
-        st = self.__dict__.setdefault('_cg_state', {'n': 0, 'graph': None, 'stream': torch.cuda.Stream()})
+        st = self.__dict__.setdefault('_cg_state', {'n': 0, 'graph': None,
+                                                    'stream': torch.cuda.Stream(priority=int(os.environ.get('AMS_MAIN_PRIORITY', '0')))})
         probe = self._feeds(feed_dict, True)
         ins = [n.value(probe) for n in (self.x_mix, self.x_non_mix, self.I)]
         opt = self.optimize
@@ -229,6 +232,7 @@ class Network(object):
                     opt.zero_grad()
                     cost = self.cost_model.value(run)
                     cost.reshape(-1)[0].backward()
+                    F.OVERLAP.join()
                 torch.cuda.current_stream().wait_stream(side)
                 opt.step()
                 self.last_run = run
@@ -243,6 +247,7 @@ class Network(object):
                 opt.zero_grad()
                 cost = self.cost_model.value(run)
                 cost.reshape(-1)[0].backward()
+                F.OVERLAP.join()
             st['graph'], st['cost'], st['run'] = g, cost, run
         for dst, src in zip(st['static'], ins):
             dst.copy_(src)
@@ -261,6 +266,7 @@ class Network(object):
         opt.zero_grad()
         cost = self.cost_model.value(run)
         cost.reshape(-1)[0].backward()
+        F.OVERLAP.join()
         opt.step()
         if self.summaries_enabled and getattr(self, 'merged_train', None):
             with torch.no_grad():

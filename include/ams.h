@@ -62,6 +62,9 @@ ams_status ams_synth_unpool_bwd_vals(const float* dout, const long long* argmax,
  * mask_period/mask_skip (transA only): reduction rows k with k % period == skip are treated as zero
  * (used for the time-shifted h_{t-1}^T . da product).  utils/ops.py:366-383, :501-503. */
 size_t ams_gemm_workspace_bytes(int M, int N, int K);
+/* thread-local launch hint: extra (unused) dynamic LDS bytes per GEMM workgroup, to cap its CU occupancy when it is
+ * launched beside latency-critical kernels on another stream; 0 = off */
+void ams_gemm_set_lds_pad(int bytes);
 ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C,
                         long ldc, const float* bias, int accumulate, int mask_period, int mask_skip, void* ws, size_t ws_bytes,
                         void* stream);
