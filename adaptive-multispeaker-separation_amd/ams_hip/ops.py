@@ -162,6 +162,16 @@ def make_masks(rep_non_mix, B, S, a, b, take_abs, want_argmax=False):
 
 
 # ------------------------------------------------------------------ BLSTM
+import os as _os
+LSTM_PERSIST = _os.environ.get('AMS_LSTM_PERSIST', '0') != '0'     # persistent in-launch recurrence (csrc/lstm_persist.hip)
+LAST_SYNC = []                                                      # most recent sync buffers (word 0 = timeout flag)
+
+
+def persist_errors():
+    """Number of recent persistent-recurrence launches whose bounded in-launch wait timed out (host sync)."""
+    return sum(int(t[:1].view(torch.int32).item() != 0) for t in LAST_SYNC)
+
+
 def blstm_fwd(x, Kf, bf, Kb, bb):
     """One BLSTM layer (utils/ops.py:358-383).  x [B,T,D]; K* [D+H,4H]; b* [4H].
     Returns out [B,T,2H] and the tensors the backward needs (G = activated gates, cst = cell states)."""
@@ -177,8 +187,16 @@ def blstm_fwd(x, Kf, bf, Kb, bb):
     out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
     cst = torch.empty((B, T, 2, H), dtype=torch.float32, device=x.device)
     pack = torch.empty(lib.ams_blstm_pack_floats(H, 0), dtype=torch.float32, device=x.device)
-    check(lib.ams_blstm_recurrent_fwd(_p(G), _p(out), _p(cst), _p(Kf[D:]), _p(Kb[D:]), 4 * H, _p(pack), B, T, H, _s()),
-          'ams_blstm_recurrent_fwd')
+    nsync = lib.ams_blstm_persist_sync_bytes(B, H, 0) if LSTM_PERSIST else 0
+    if nsync:
+        sync = _ws(nsync, x)
+        check(lib.ams_blstm_persist_fwd(_p(G), _p(out), _p(cst), _p(Kf[D:]), _p(Kb[D:]), 4 * H, _p(pack), _p(sync), nsync, B, T, H, _s()),
+              'ams_blstm_persist_fwd')
+        LAST_SYNC.append(sync)
+        del LAST_SYNC[:-8]
+    else:
+        check(lib.ams_blstm_recurrent_fwd(_p(G), _p(out), _p(cst), _p(Kf[D:]), _p(Kb[D:]), 4 * H, _p(pack), B, T, H, _s()),
+              'ams_blstm_recurrent_fwd')
     return out, G, cst
 
 
@@ -188,10 +206,18 @@ def blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout):
     lib = load()
     B, T, D = x.shape
     H = Kf.shape[1] // 4
-    dc = torch.empty((B, 2, H), dtype=torch.float32, device=x.device)
     pack = torch.empty(lib.ams_blstm_pack_floats(H, 1), dtype=torch.float32, device=x.device)
-    check(lib.ams_blstm_recurrent_bwd(_p(G), _p(cst), _p(dout), _p(dc), _p(Kf[D:]), _p(Kb[D:]), 4 * H, _p(pack), B, T, H, _s()),
-          'ams_blstm_recurrent_bwd')
+    nsync = lib.ams_blstm_persist_sync_bytes(B, H, 1) if LSTM_PERSIST else 0
+    if nsync:
+        sync = _ws(nsync, x)
+        check(lib.ams_blstm_persist_bwd(_p(G), _p(cst), _p(dout), _p(Kf[D:]), _p(Kb[D:]), 4 * H, _p(pack), _p(sync), nsync, B, T, H, _s()),
+              'ams_blstm_persist_bwd')
+        LAST_SYNC.append(sync)
+        del LAST_SYNC[:-8]
+    else:
+        dc = torch.empty((B, 2, H), dtype=torch.float32, device=x.device)
+        check(lib.ams_blstm_recurrent_bwd(_p(G), _p(cst), _p(dout), _p(dc), _p(Kf[D:]), _p(Kb[D:]), 4 * H, _p(pack), B, T, H, _s()),
+              'ams_blstm_recurrent_bwd')
 
 
 def blstm_bwd_dx(G, Kf, Kb, B, T, D):

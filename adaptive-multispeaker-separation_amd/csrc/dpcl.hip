@@ -39,16 +39,22 @@ __global__ __launch_bounds__(256) void dpcl_gram_kernel(const float* __restrict_
                                                         const float* __restrict__ cnt, float* __restrict__ part, long TF,
                                                         int E, int S, int nchunk) {
     constexpr int Z = NT * 16;
+    constexpr int ZP = Z + 1;                       // LDS row pitch (odd: the 4 point-slots of a wave land on distinct banks)
+    constexpr int PTS = 64;                         // points staged per iteration (16 per wave)
+    __shared__ float zt[PTS * ZP];                  // augmented points [v | y | 0]
+    __shared__ float dsh[PTS];                      // D_i
     __shared__ float red[Z * Z];
     const int b = blockIdx.y, c = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int e_lo = lane & 15, slot = lane >> 4;
     for (int i = tid; i < Z * Z; i += 256) red[i] = 0.f;
+    for (int i = tid; i < PTS * ZP; i += 256) zt[i] = 0.f;       // padding columns stay zero
 
     float cn[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) cn[s] = (s < S) ? cnt[(long)b * S + s] : 0.f;
 
+    // upper-triangular tile pairs only: the Gram is symmetric
     f32x4 acc[NT][NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
@@ -58,44 +64,59 @@ __global__ __launch_bounds__(256) void dpcl_gram_kernel(const float* __restrict_
     const long p_begin = (long)c * CHUNK, p_end = min(TF, p_begin + CHUNK);
     const float* Vb = V + (long)b * TF * E;
     const float* Yb = Y + (long)b * TF * S;
-    for (long p0 = p_begin + wave * 4; p0 < p_end; p0 += 16) {
-        const long p = p0 + slot;
-        const bool ok = p < p_end;
-        float d = 0.f;
-        if (ok) {
+    for (long p0 = p_begin; p0 < p_end; p0 += PTS) {
+        const int npts = (int)min((long)PTS, p_end - p0);
+        __syncthreads();
+        // coalesced staging: the PTS*E floats of this slab are contiguous in memory
+        for (int i = tid; i < PTS * E; i += 256) {
+            const int p = i / E, e = i - p * E;
+            zt[p * ZP + e] = (p < npts) ? Vb[p0 * E + i] : 0.f;
+        }
+        if (tid < PTS) {
             float diag = 0.f;
-            for (int s = 0; s < S; ++s) diag += Yb[p * S + s] * cn[s];
-            d = 1.0f / sqrtf(diag);
+            if (tid < npts)
+                for (int s = 0; s < S; ++s) {
+                    const float yv = Yb[(p0 + tid) * S + s];
+                    zt[tid * ZP + E + s] = yv;
+                    diag += yv * cn[s];
+                }
+            else
+                for (int s = 0; s < S; ++s) zt[tid * ZP + E + s] = 0.f;
+            dsh[tid] = (tid < npts && diag > 0.f) ? 1.0f / sqrtf(diag) : 0.f;    // all-zero Y row: reference has D = inf
         }
-        float a[NT], bb[NT];
+        __syncthreads();
 #pragma unroll
-        for (int ti = 0; ti < NT; ++ti) {
-            const int e = ti * 16 + e_lo;
-            float z = 0.f;
-            if (ok) {
-                if (e < E) z = Vb[p * E + e];
-                else if (e < E + S) z = Yb[p * S + (e - E)];
+        for (int g = 0; g < 4; ++g) {
+            const int p = wave * 16 + g * 4 + slot;
+            const float d = dsh[p];
+            float a[NT], bb[NT];
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) {
+                a[ti] = zt[p * ZP + ti * 16 + e_lo];
+                bb[ti] = a[ti] * d;
             }
-            a[ti] = z;
-            bb[ti] = (z != 0.f) ? z * d : 0.f;       // 0 * inf guard: rows of Y that are all zero give D = inf
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = ti; tj < NT; ++tj)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], bb[tj], acc[ti][tj], 0, 0, 0);
         }
-#pragma unroll
-        for (int ti = 0; ti < NT; ++ti)
-#pragma unroll
-            for (int tj = 0; tj < NT; ++tj)
-                acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], bb[tj], acc[ti][tj], 0, 0, 0);
     }
     __syncthreads();
-    // C/D layout: row = (lane>>4)*4 + r, col = lane&15.  4 waves add into LDS one after another (fixed order).
+    // C/D layout: row = (lane>>4)*4 + r, col = lane&15.  4 waves add into LDS one after another (fixed order);
+    // off-diagonal tiles are mirrored.
     for (int w = 0; w < 4; ++w) {
         if (wave == w) {
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-                for (int tj = 0; tj < NT; ++tj)
+                for (int tj = ti; tj < NT; ++tj)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        red[(ti * 16 + slot * 4 + r) * Z + tj * 16 + e_lo] += acc[ti][tj][r];
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = ti * 16 + slot * 4 + r, col = tj * 16 + e_lo;
+                        red[row * Z + col] += acc[ti][tj][r];
+                        if (tj != ti) red[col * Z + row] += acc[ti][tj][r];
+                    }
         }
         __syncthreads();
     }

@@ -98,15 +98,21 @@ __global__ void l2norm_bwd_kernel(const float* __restrict__ v, const float* __re
 }
 
 // Column sums of a [rows, cols] matrix (bias gradients).  Two-stage, deterministic.
-__global__ void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ part, long rows, int cols, long ld,
-                                      int rows_per_block) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
+// Stage 1: a block owns 64 columns x `rows_per_block` rows; its 4 waves take interleaved rows (256-byte coalesced
+// segments), then meet in LDS.  Stage 2 adds the few per-block partials in fixed order.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, float* __restrict__ part, long rows, int cols,
+                                                             long ld, int rows_per_block) {
+    __shared__ float sm[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     const long r0 = (long)blockIdx.y * rows_per_block;
     const long r1 = min(rows, r0 + rows_per_block);
     float s = 0.f;
-    for (long r = r0; r < r1; ++r) s += x[r * ld + c];
-    part[(long)blockIdx.y * cols + c] = s;
+    if (c < cols)
+        for (long r = r0 + rl; r < r1; r += 4) s += x[r * ld + c];
+    sm[rl][cl] = s;
+    __syncthreads();
+    if (rl == 0 && c < cols) part[(long)blockIdx.y * cols + c] = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
 }
 __global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int cols, int nparts, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
@@ -207,18 +213,18 @@ ams_status ams_l2norm_bwd(const float* v, const float* inv, const float* dv, flo
 }
 
 size_t ams_colsum_workspace_bytes(long rows, int cols) {
-    const int nparts = ceil_div(rows, 32);
+    const int nparts = ceil_div(rows, 256);
     return (size_t)nparts * cols * sizeof(float);
 }
 
 ams_status ams_colsum(const float* x, float* out, long rows, int cols, long ld, int accumulate, void* ws, size_t ws_bytes,
                       void* stream) {
     AMS_REQUIRE(x && out && rows > 0 && cols > 0 && ws);
-    const int rpb = 32;
+    const int rpb = 256;
     const int nparts = ceil_div(rows, rpb);
     if ((size_t)nparts * cols * sizeof(float) > ws_bytes) return AMS_E_WORKSPACE_TOO_SMALL;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(cols, 256), nparts), dim3(256), 0, st, x, (float*)ws, rows, cols, ld, rpb);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(cols, 64), nparts), dim3(256), 0, st, x, (float*)ws, rows, cols, ld, rpb);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, st, (const float*)ws, out, cols, nparts, accumulate);
     return ams_check_launch();
 }

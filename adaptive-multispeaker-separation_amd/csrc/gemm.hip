@@ -77,7 +77,10 @@ template <int AMODE> struct AKContig { static constexpr bool v = (AMODE == A_ROW
 enum { EPI_STORE = 0, EPI_MAXPOOL = 1 };
 
 template <int AMODE, int BMODE, int EPI = EPI_STORE>
-__global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
+#ifndef AMS_GEMM_WPE
+#define AMS_GEMM_WPE 2
+#endif
+__global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g) {
     constexpr bool AK = AKContig<AMODE>::v;
     constexpr bool BKc = (BMODE == B_COL);
     constexpr int LDA_S = BM + (AK ? PAD_T : PAD_V);
@@ -216,6 +219,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
         if (kt + 1 < nk) fetch(kt + 1);
         const float* as = As + buf * BK * LDA_S + wm * 64 + l31;
         const float* bs = Bs + buf * BK * LDB_S + wn * 64 + l31;
+#ifdef AMS_GEMM_SETPRIO
+        __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const float a0 = as[(kk + lk) * LDA_S];
@@ -227,6 +233,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_kernel(GemmArgs g) {
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+#ifdef AMS_GEMM_SETPRIO
+        __builtin_amdgcn_s_setprio(0);
+#endif
         if (kt + 1 < nk) stash(buf ^ 1);
         __syncthreads();
     }

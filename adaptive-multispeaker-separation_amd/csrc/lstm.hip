@@ -258,6 +258,27 @@ size_t ams_blstm_pack_floats(int H, int backward) {
     return (size_t)2 * n_ut * ceil_div(4 * H, 16) * 64 * 4;
 }
 
+// Re-pack both directions' recurrent matrices into MFMA fragment order (forward: U, backward: U^T).
+ams_status ams_blstm_pack(const float* Uf, const float* Ub, long ldu, float* pack, int H, int backward, void* stream) {
+    AMS_REQUIRE(Uf && Ub && pack && H > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int n_ut = ceil_div(H, TU);
+    if (!backward) {
+        const int n_g = ceil_div(H, 16);
+        const long total = (long)2 * n_ut * n_g * 4 * 64 * 4;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(pack_u_fwd_kernel, dim3(blocks), dim3(256), 0, st, Uf, Ub, ldu, pack, H, n_ut, n_g);
+    } else {
+        const int n_g = ceil_div(4 * H, 16);
+        const long total = (long)2 * n_ut * n_g * 64 * 4;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(pack_u_bwd_kernel, dim3(blocks), dim3(256), 0, st, Uf, Ub, ldu, pack, H, n_ut, n_g);
+    }
+    return ams_check_launch();
+}
+
 // Recurrence, forward.  Uf/Ub: recurrent part of each direction's TF kernel (rows D.. of [D+H,4H]), ldu = 4H.
 ams_status ams_blstm_recurrent_fwd(float* G, float* out, float* cst, const float* Uf, const float* Ub, long ldu, float* pack,
                                    int B, int T, int H, void* stream) {

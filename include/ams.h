@@ -84,6 +84,17 @@ ams_status ams_blstm_recurrent_fwd(float* G, float* out, float* cst, const float
 ams_status ams_blstm_recurrent_bwd(float* G, const float* cst, const float* dout, float* dc, const float* Uf, const float* Ub,
                                    long ldu, float* pack, int B, int T, int H, void* stream);
 
+/* Persistent form of the same recurrence: one launch per layer and pass; workgroup rings exchange h_t / da_t in-launch
+ * through epoch-tagged 8-byte granules (csrc/lstm_persist.hip).  ams_blstm_persist_sync_bytes returns 0 when the shape
+ * cannot use it (not all workgroups resident, or H > 320): callers then use ams_blstm_recurrent_fwd/bwd.
+ * sync word 0 (uint32) is non-zero after the launch if a bounded in-launch wait timed out. */
+ams_status ams_blstm_pack(const float* Uf, const float* Ub, long ldu, float* pack, int H, int backward, void* stream);
+size_t ams_blstm_persist_sync_bytes(int B, int H, int backward);
+ams_status ams_blstm_persist_fwd(float* G, float* out, float* cst, const float* Uf, const float* Ub, long ldu, float* pack, void* sync,
+                                 size_t sync_bytes, int B, int T, int H, void* stream);
+ams_status ams_blstm_persist_bwd(float* G, const float* cst, const float* dout, const float* Uf, const float* Ub, long ldu, float* pack,
+                                 void* sync, size_t sync_bytes, int B, int T, int H, void* stream);
+
 /* ---- K13  tf.nn.l2_normalize over groups of E       utils/ops.py:323-324 ---- */
 ams_status ams_l2norm_fwd(const float* u, float* v, float* inv, long rows, int E, void* stream);
 ams_status ams_l2norm_bwd(const float* v, const float* inv, const float* dv, float* du, long rows, int E, void* stream);
