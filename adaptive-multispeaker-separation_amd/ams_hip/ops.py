@@ -51,6 +51,9 @@ class _Profile(object):
         e.record(torch.cuda.current_stream())
         self.records.append((start, e, flops, nbytes, tag))
 
+    def tags(self):
+        return sorted(set(r[4] for r in self.records))
+
     def summary(self, tag=None):
         torch.cuda.synchronize()
         ms = fl = by = 0.0
@@ -146,7 +149,7 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False
     check(lib.ams_gemm_f32(int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc, _p(bias), int(accumulate),
                            mask[0], mask[1], _p(ws), nb, _s()), 'ams_gemm_f32')
     if ev is not None:
-        PROFILE.end(ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N), 'gemm')
+        PROFILE.end(ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N), 'gemm<%d,%d>' % (int(bool(transA)), int(bool(transB))))
     return out
 
 
@@ -181,9 +184,11 @@ def blstm_fwd(x, Kf, bf, Kb, bb):
     H = Kf.shape[1] // 4
     G = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=x.device)
     x2 = x.view(B * T, D)
-    # hoisted input projections (one MFMA GEMM per direction, written into the strided gate buffer)
-    gemm(x2, Kf, bias=bf, out=G, M=B * T, N=4 * H, K=D, lda=D, ldb=4 * H, ldc=8 * H)
-    gemm(x2, Kb, bias=bb, out=G.view(-1)[4 * H:], M=B * T, N=4 * H, K=D, lda=D, ldb=4 * H, ldc=8 * H)
+    # hoisted input projection of BOTH directions as ONE MFMA GEMM [B*T, D] x [D, 8H]: the two [D,4H] halves of the TF
+    # kernels are gathered side by side (a 2 x D x 4H copy) so N = 8H gives 19 x 40 = 760 tiles = 2.97 per CU instead of
+    # two launches of 400 (1.56 per CU, i.e. 22 % of the CU-time idle).
+    Wcat = blstm_wcat(Kf, Kb, D)
+    gemm(x2, Wcat, bias=torch.cat([bf, bb]), out=G, M=B * T, N=8 * H, K=D, lda=D, ldb=8 * H, ldc=8 * H)
     out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
     cst = torch.empty((B, T, 2, H), dtype=torch.float32, device=x.device)
     pack = torch.empty(lib.ams_blstm_pack_floats(H, 0), dtype=torch.float32, device=x.device)
@@ -198,6 +203,15 @@ def blstm_fwd(x, Kf, bf, Kb, bb):
         check(lib.ams_blstm_recurrent_fwd(_p(G), _p(out), _p(cst), _p(Kf[D:]), _p(Kb[D:]), 4 * H, _p(pack), B, T, H, _s()),
               'ams_blstm_recurrent_fwd')
     return out, G, cst
+
+
+def blstm_wcat(Kf, Kb, D):
+    """[D, 8H] = input parts of the forward | backward kernels side by side (memcpy-class glue, 2 x D x 4H floats)."""
+    H4 = Kf.shape[1]
+    Wcat = torch.empty((D, 2 * H4), dtype=torch.float32, device=Kf.device)
+    Wcat[:, :H4].copy_(Kf[:D])
+    Wcat[:, H4:].copy_(Kb[:D])
+    return Wcat
 
 
 def blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout):
@@ -221,14 +235,12 @@ def blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout):
 
 
 def blstm_bwd_dx(G, Kf, Kb, B, T, D):
-    """dx = dZ_f . Wx_f^T + dZ_b . Wx_b^T  (the only hoisted product on the backward critical path)."""
+    """dx = dZ . [Wx_f | Wx_b]^T  (the only hoisted product on the backward critical path), one GEMM with K = 8H."""
     H = Kf.shape[1] // 4
     M = B * T
-    dZf = G.view(-1)
-    dZb = G.view(-1)[4 * H:]
+    Wcat = blstm_wcat(Kf, Kb, D)
     dx = torch.empty((B, T, D), dtype=torch.float32, device=G.device)
-    gemm(dZf, Kf, transB=True, out=dx, M=M, N=D, K=4 * H, lda=8 * H, ldb=4 * H, ldc=D)
-    gemm(dZb, Kb, transB=True, out=dx, accumulate=True, M=M, N=D, K=4 * H, lda=8 * H, ldb=4 * H, ldc=D)
+    gemm(G.view(-1), Wcat, transB=True, out=dx, M=M, N=D, K=8 * H, lda=8 * H, ldb=8 * H, ldc=D)
     return dx
 
 
@@ -243,8 +255,15 @@ def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate):
     dZf = G.view(-1)                       # direction 0 columns start at 0, ld = 8H
     dZb = G.view(-1)[4 * H:]
     acc = bool(accumulate)
-    gemm(x2, dZf, transA=True, out=dKf, accumulate=acc, M=D, N=4 * H, K=M, lda=D, ldb=8 * H, ldc=4 * H)
-    gemm(x2, dZb, transA=True, out=dKb, accumulate=acc, M=D, N=4 * H, K=M, lda=D, ldb=8 * H, ldc=4 * H)
+    # dWx of both directions in one product x^T . dZ -> [D, 8H], then scattered into the two TF-layout kernels
+    dWcat = gemm(x2, dZf, transA=True, M=D, N=8 * H, K=M, lda=D, ldb=8 * H, ldc=8 * H,
+                 out=torch.empty((D, 8 * H), dtype=torch.float32, device=x.device))
+    if acc:
+        dKf[:D].add_(dWcat[:, :4 * H])
+        dKb[:D].add_(dWcat[:, 4 * H:])
+    else:
+        dKf[:D].copy_(dWcat[:, :4 * H])
+        dKb[:D].copy_(dWcat[:, 4 * H:])
     # forward dir pairs out[b,t-1] with dZ[b,t]; backward dir pairs out[b,t+1] with dZ[b,t]
     of = out.view(-1)
     gemm(of, dZf[8 * H:], transA=True, out=dKf[D:], accumulate=acc, M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H, ldc=4 * H,
@@ -367,7 +386,7 @@ def frames_matmul(x, Bm, hop, T, pad_left):
     ev = PROFILE.begin() if PROFILE.enabled else None
     check(load().ams_frames_matmul(_p(x), _p(Bm), _p(out), R, L, W, N, hop, T, pad_left, _s()), 'ams_frames_matmul')
     if ev is not None:
-        PROFILE.end(ev, 2.0 * R * T * N * W, 4.0 * (R * L + W * N + R * T * N), 'gemm')
+        PROFILE.end(ev, 2.0 * R * T * N * W, 4.0 * (R * L + W * N + R * T * N), 'gemm<2,0>')
     return out
 
 

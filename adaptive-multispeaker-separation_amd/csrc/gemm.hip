@@ -8,7 +8,7 @@
 //   A_FRAMES_T  A[m=k_w, k=(b,t)] = frame element        (filter gradient of the same conv)
 // and B-operand loaders B_ROW (B[k*ldb+n]) / B_COL (B[n*ldb+k]).
 //
-// Tiling: 128x128x16 block tile, 256 threads = 4 waves in 2x2, each wave 64x64 = 2x2 MFMA 32x32 tiles
+// Tiling: 128x128x8 block tile (BK = 8 measured best: 16.8 KB LDS and 95 VGPRs give 5 waves/SIMD, +4..10 % over BK = 16), 256 threads = 4 waves in 2x2, each wave 64x64 = 2x2 MFMA 32x32 tiles
 // (64 accumulator VGPRs).  LDS holds k-major operand panels As[16][128+pad], Bs[16][128+pad] so the
 // MFMA operand fetch (lane l: A[i=l&31][k=l>>5], B[k=l>>5][j=l&31]) is a conflict-free ds_read_b32.
 // Register-staged double buffering: tile t+1 is fetched into VGPRs before the MFMAs of tile t and
@@ -22,7 +22,12 @@ namespace {
 
 thread_local int t_gemm_lds_pad = 0;
 
-constexpr int BM = 128, BN = 128, BK = 16;
+#ifndef AMS_GEMM_BK
+#define AMS_GEMM_BK 8
+#endif
+constexpr int BM = 128, BN = 128, BK = AMS_GEMM_BK;
+constexpr int NLD = BK / 8;       // float4 loads per thread per operand per k-tile
+constexpr int KQ = BK / 4;        // float4 per row of a k-contiguous operand tile
 constexpr int PAD_T = 2;   // k-contiguous source, transposed scalar LDS writes: stride 130 -> conflict-free
 constexpr int PAD_V = 4;   // m/n-contiguous source, float4 LDS writes: stride 132 keeps 16B alignment
 
@@ -118,15 +123,15 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[2], rb[2];
+    float4 ra[NLD], rb[NLD];
 
     auto fetch = [&](int kt) {
         const int k0 = k_begin + kt * BK;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NLD; ++h) {
             const int q = tid + h * 256;
             if (AK) {
-                const int m = m0 + (q >> 2), k = k0 + (q & 3) * 4;
+                const int m = m0 + (q / KQ), k = k0 + (q % KQ) * 4;
                 bool fast = g.a_vec && m < g.M && k + 3 < k_end;
                 if (AMODE == A_FRAMES && fast) {
                     int b = m / g.fr_T, t = m - b * g.fr_T;
@@ -156,7 +161,7 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
                 }
             }
             if (BKc) {
-                const int n = n0 + (q >> 2), k = k0 + (q & 3) * 4;
+                const int n = n0 + (q / KQ), k = k0 + (q % KQ) * 4;
                 if (g.b_vec && n < g.N && k + 3 < k_end) rb[h] = *reinterpret_cast<const float4*>(g.B + (long)n * g.ldb + k);
                 else {
                     rb[h].x = (k + 0 < k_end) ? loadB1<BMODE>(g, k + 0, n) : 0.f;
@@ -182,10 +187,10 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
         float* as = As + buf * BK * LDA_S;
         float* bs = Bs + buf * BK * LDB_S;
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < NLD; ++h) {
             const int q = tid + h * 256;
             if (AK) {
-                const int mi = q >> 2, kq = (q & 3) * 4;
+                const int mi = q / KQ, kq = (q % KQ) * 4;
                 as[(kq + 0) * LDA_S + mi] = ra[h].x;
                 as[(kq + 1) * LDA_S + mi] = ra[h].y;
                 as[(kq + 2) * LDA_S + mi] = ra[h].z;
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
                 *reinterpret_cast<float4*>(as + ki * LDA_S + mi) = ra[h];
             }
             if (BKc) {
-                const int ni = q >> 2, kq = (q & 3) * 4;
+                const int ni = q / KQ, kq = (q % KQ) * 4;
                 bs[(kq + 0) * LDB_S + ni] = rb[h].x;
                 bs[(kq + 1) * LDB_S + ni] = rb[h].y;
                 bs[(kq + 2) * LDB_S + ni] = rb[h].z;
@@ -326,7 +331,7 @@ inline int choose_splits(int M, int N, int K) {
         const int s2 = ceil_div(K, kps);
         const int n = ceil_div((long)tiles * s2, 256);
         const double occ = n <= 1 ? 0.62 : (n == 2 ? 0.80 : (n == 3 ? 0.92 : 1.0));
-        double t = n * ((kps / BK) * 1.024 + 5.0) / occ;
+        double t = n * ((kps / 16.0) * 1.024 + 5.0) / occ;
         if (s2 > 1) t += (double)(s2 + 1) * M * N * 4.0 / 2.5e6;
         if (t < best_t - 1e-9) { best_t = t; best = s2; }
     }

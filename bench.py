@@ -169,7 +169,14 @@ def main():
                 'traffic': None, 'launches_per_step': prof['launches'] / prof_steps,
                 'avg_launch_ms': round(avg_ms, 4), 'share_of_step': round(prof['ms'] / prof_steps / (elapsed / args.steps * 1e3), 3),
                 'measured': ('HIP events around each launch, %d eager steps after the graph-replayed timed region' % prof_steps)
-                if args.graph else 'HIP events around each launch inside the timed region'}
+                if args.graph else 'HIP events around each launch inside the timed region',
+                'by_variant': {}}
+        for tag in ops.PROFILE.tags():
+            pv = ops.PROFILE.summary(tag)
+            if pv['launches']:
+                roof['by_variant']['gemm_f32_kernel' + tag[4:]] = {
+                    'launches_per_step': pv['launches'] / prof_steps, 'avg_launch_us': round(pv['ms'] / pv['launches'] * 1e3, 2),
+                    'TFLOP/s': round(pv['flops'] / (pv['ms'] * 1e-3) / 1e12, 2)}
 
     out = {
         'metric': 'mixtures/sec training throughput (2-spk, 256-filter adapt+BLSTM-DPCL)',

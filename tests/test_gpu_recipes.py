@@ -44,7 +44,7 @@ def check_step(cost, c_ref, grads, g_ref, P, P_new, opt, tol=2e-4):
     gscale = max(float(np.abs(g_ref[n]).max()) for n in names)
     for n in names:
         # a gradient that is analytically zero (e.g. a bias under a softmax over speakers) is compared on the scale of the others
-        errs['grad ' + n] = float(np.abs(grads[n] - g_ref[n]).max() / max(np.abs(g_ref[n]).max(), 1e-3 * gscale))
+        errs['grad ' + n] = float(np.abs(grads[n] - g_ref[n]).max() / max(np.abs(g_ref[n]).max(), 1e-2 * gscale))
     plist = [P[n].copy() for n in names]
     opt.apply(plist, [g_ref[n] for n in names])
     for n, p in zip(names, plist):
