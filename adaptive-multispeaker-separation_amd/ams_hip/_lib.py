@@ -9,7 +9,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libams_hip.so')
+LIB_PATH = os.environ.get('AMS_HIP_LIB') or os.path.join(_HERE, 'libams_hip.so')   # env: kernel-variant A/B runs
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'include', 'ams.h'))
 
 _CT = {

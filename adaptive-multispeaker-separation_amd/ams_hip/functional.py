@@ -211,6 +211,28 @@ class DPCLLossFromU(Function):
         return du.view(ctx.ushape), None, None, None
 
 
+class DPCLLossU(Function):
+    """l2-normalise + DPCL loss in ONE pass over u (dense output before Normalize): V is never materialised in a
+    training step; backward recomputes v = u/|u| (models/dpcl.py:41-87 + utils/ops.py:323-324)."""
+
+    @staticmethod
+    def forward(ctx, u, Y):
+        out, inv, _, ws = ops.dpcl_loss_fwd_u(u, Y)
+        ctx.save_for_backward(u, inv, Y, ws)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        u, inv, Y, ws = ctx.saved_tensors
+        return ops.dpcl_loss_bwd_u(u, Y, inv, ws, upstream=_c(dout)), None
+
+
+def dpcl_loss_u(u, Y, E):
+    """u [B, ..., F*E] (column = f*E + e) -> the 4 loss terms; Y [B, TF, S]."""
+    B = u.shape[0]
+    return DPCLLossU.apply(_c(u).reshape(B, -1, E), _c(Y))
+
+
 def l2norm_keep(u, E):
     return L2NormKeep.apply(_c(u), E)
 

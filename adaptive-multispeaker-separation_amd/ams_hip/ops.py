@@ -99,7 +99,10 @@ def front_conv(x, f, hop):
     W, N = f.shape
     T = -(-L // hop)
     y = torch.empty((Bt, T, N), dtype=torch.float32, device=x.device)
-    check(load().ams_front_conv_fwd(_p(x), _p(f), _p(y), Bt, L, W, N, hop, _s()), 'ams_front_conv_fwd')
+    lib = load()
+    nb = lib.ams_front_conv_fwd_workspace_bytes(Bt, L, W, N, hop)
+    ws = _ws(nb, x) if nb else None
+    check(lib.ams_front_conv_fwd(_p(x), _p(f), _p(y), Bt, L, W, N, hop, _p(ws), nb, _s()), 'ams_front_conv_fwd')
     return y
 
 
@@ -340,6 +343,31 @@ def dpcl_loss_fwd(V, Y):
     out = torch.empty(4, dtype=torch.float32, device=V.device)
     check(lib.ams_dpcl_loss_fwd(_p(V), _p(Y), _p(out), B, TF, E, S, _p(ws), nb, _s()), 'ams_dpcl_loss_fwd')
     return out, ws
+
+
+def dpcl_loss_fwd_u(U, Y, want_V=False):
+    """Fused l2-normalise + DPCL loss on the dense output U [B,TF,E] -> (out[4], inv [B,TF], V or None, ws)."""
+    _chk(U, Y)
+    lib = load()
+    B, TF, E = U.shape
+    S = Y.shape[2]
+    nb = lib.ams_dpcl_u_workspace_bytes(B, TF, E, S)
+    ws = _ws(nb, U)
+    out = torch.empty(4, dtype=torch.float32, device=U.device)
+    inv = torch.empty(B, TF, dtype=torch.float32, device=U.device)
+    V = torch.empty_like(U) if want_V else None
+    check(lib.ams_dpcl_loss_fwd_u(_p(U), _p(Y), _p(inv), _p(V), _p(out), B, TF, E, S, _p(ws), nb, _s()), 'ams_dpcl_loss_fwd_u')
+    return out, inv, V, ws
+
+
+def dpcl_loss_bwd_u(U, Y, inv, ws, upstream=None):
+    _chk(U, Y, inv, upstream)
+    B, TF, E = U.shape
+    S = Y.shape[2]
+    d = torch.empty_like(U)
+    check(load().ams_dpcl_loss_bwd_u(_p(U), _p(Y), _p(inv), _p(upstream), _p(d), B, TF, E, S, _p(ws), _s()),
+          'ams_dpcl_loss_bwd_u')
+    return d
 
 
 def dpcl_loss_bwd(V, Y, ws, inv=None, upstream=None):

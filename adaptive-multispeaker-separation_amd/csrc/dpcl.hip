@@ -124,6 +124,200 @@ __global__ __launch_bounds__(256) void dpcl_gram_kernel(const float* __restrict_
     for (int i = tid; i < Z * Z; i += 256) out[i] = red[i];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Fused pass for training: reads the dense layer's output U (BEFORE l2-normalise) once and produces the per-point
+// 1/|u| and the augmented Gram of the NORMALISED points in the same sweep -- V is never written unless the caller
+// asks for it (V_out).  Algorithmic HBM bytes per utterance: TF*(E+S)*4 read + TF*4 written.
+//   * label counts come from CP fixed-order partial sums per utterance (dpcl_count_part_kernel);
+//   * a workgroup owns UCHUNK points and stages PTS of them per iteration with 16-byte loads that are issued one
+//     iteration ahead (registers), so the MFMA phase of slab i covers the HBM latency of slab i+1;
+//   * normalisation is applied on the MFMA operand fetch (per-lane factor: 1/|u| for embedding columns, 1 for
+//     label columns), the rows in LDS stay raw.
+constexpr int CP = 8;                  // label-count partials per utterance
+constexpr int UCHUNK = 2560;           // points per workgroup in the fused pass
+
+__global__ __launch_bounds__(256) void dpcl_count_part_kernel(const float* __restrict__ Y, float* __restrict__ cntp, long TF, int S) {
+    __shared__ float sm[4][8];
+    const int b = blockIdx.y, c = blockIdx.x;
+    const long per = (TF + CP - 1) / CP;
+    const long lo = (long)c * per, hi = min(TF, lo + per);
+    float acc[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) acc[s] = 0.f;
+    const float* y = Y + (long)b * TF * S;
+    for (long i = lo + threadIdx.x; i < hi; i += 256)
+        for (int s = 0; s < S; ++s) acc[s] += y[i * S + s];
+    for (int s = 0; s < S; ++s) {
+        const float v = wave_sum(acc[s]);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][s] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < S)
+        cntp[((long)b * CP + c) * S + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
+__device__ __forceinline__ void load_counts(const float* __restrict__ cntp, int b, int S, float (&cn)[8]) {
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+        float t = 0.f;
+        if (s < S)
+            for (int c = 0; c < CP; ++c) t += cntp[((long)b * CP + c) * S + s];
+        cn[s] = t;
+    }
+}
+
+template <int NT>
+__global__ __launch_bounds__(256) void dpcl_gram_u_kernel(const float* __restrict__ U, const float* __restrict__ Y,
+                                                          const float* __restrict__ cntp, float* __restrict__ inv_out,
+                                                          float* __restrict__ V_out, float* __restrict__ part, long TF, int E,
+                                                          int S, int nchunk) {
+    constexpr int Z = NT * 16;
+    constexpr int ZP = Z + 4;                       // row pitch: 16-byte aligned rows, 16 lanes x 16 B cover all banks
+    constexpr int PTS = NT <= 3 ? 256 : 128;        // points staged per iteration
+    constexpr int NV = PTS * Z / 4 / 256;           // 16-byte loads per thread and slab (upper bound, E <= Z)
+    __shared__ __attribute__((aligned(16))) float zt[PTS * ZP];   // raw points [u | y | 0]; reused for the final reduce
+    __shared__ float dsh[PTS], ivs[PTS];
+    const int b = blockIdx.y, c = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e_lo = lane & 15, slot = lane >> 4;
+    for (int i = tid; i < PTS * ZP; i += 256) zt[i] = 0.f;       // padding columns stay zero
+
+    float cn[8];
+    load_counts(cntp, b, S, cn);
+
+    f32x4 acc[NT][NT];                              // upper-triangular tile pairs only: the Gram is symmetric
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const long p_begin = (long)c * UCHUNK, p_end = min(TF, p_begin + UCHUNK);
+    const float* Ub = U + (long)b * TF * E;
+    const float* Yb = Y + (long)b * TF * S;
+    const bool vec = (E % 4 == 0) && (((uintptr_t)U & 15) == 0);
+    const int nvec = PTS * E / 4;                   // 16-byte groups per full slab (vec path)
+
+    float4 pre[NV];
+    float yv[8];
+    auto fetch = [&](long p0) {
+        const int npts = (int)min((long)PTS, p_end - p0);
+        if (vec) {
+            const float4* src = reinterpret_cast<const float4*>(Ub + p0 * E);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i4 = tid + 256 * j;
+                pre[j] = (i4 < nvec && i4 * 4 < npts * E) ? src[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            const float* src = Ub + p0 * E;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                float t[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = tid + 256 * (4 * j + q);
+                    t[q] = (i < npts * E) ? src[i] : 0.f;
+                }
+                pre[j] = make_float4(t[0], t[1], t[2], t[3]);
+            }
+        }
+        if (tid < PTS) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) yv[s] = (s < S && tid < npts) ? Yb[(p0 + tid) * S + s] : 0.f;
+        }
+    };
+
+    if (p_begin < p_end) fetch(p_begin);
+    for (long p0 = p_begin; p0 < p_end; p0 += PTS) {
+        const int npts = (int)min((long)PTS, p_end - p0);
+        __syncthreads();                            // MFMA phase of the previous slab is done with zt
+        if (vec) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i4 = tid + 256 * j;
+                if (i4 < nvec) {
+                    const int pnt = (i4 * 4) / E, e = i4 * 4 - pnt * E;
+                    *reinterpret_cast<float4*>(&zt[pnt * ZP + e]) = pre[j];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const float t[4] = {pre[j].x, pre[j].y, pre[j].z, pre[j].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = tid + 256 * (4 * j + q);
+                    if (i < PTS * E) zt[(i / E) * ZP + (i % E)] = t[q];
+                }
+            }
+        }
+        if (tid < PTS) {
+            float diag = 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (s < S) { zt[tid * ZP + E + s] = yv[s]; diag += yv[s] * cn[s]; }
+            dsh[tid] = (tid < npts && diag > 0.f) ? 1.0f / sqrtf(diag) : 0.f;    // all-zero Y row: reference has D = inf
+        }
+        __syncthreads();
+        if (p0 + PTS < p_end) fetch(p0 + PTS);      // in flight during everything below
+        if (tid < PTS) {
+            float ss = 0.f;
+            const float* row = &zt[tid * ZP];
+            for (int e = 0; e < E; ++e) ss += row[e] * row[e];
+            const float iv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));   // tf.nn.l2_normalize epsilon (utils/ops.py:323)
+            ivs[tid] = iv;
+            if (inv_out && tid < npts) inv_out[(long)b * TF + p0 + tid] = iv;
+        }
+        __syncthreads();
+        if (V_out) {
+            float* dst = V_out + ((long)b * TF + p0) * E;
+            for (int i = tid; i < npts * E; i += 256) {
+                const int pnt = i / E, e = i - pnt * E;
+                dst[i] = zt[pnt * ZP + e] * ivs[pnt];
+            }
+        }
+#pragma unroll 4
+        for (int g = 0; g < PTS / 16; ++g) {
+            const int pnt = wave * (PTS / 4) + g * 4 + slot;
+            const float d = dsh[pnt], iv = ivs[pnt];
+            float a[NT], bb[NT];
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti) {
+                const float raw = zt[pnt * ZP + ti * 16 + e_lo];
+                a[ti] = (ti * 16 + e_lo < E) ? raw * iv : raw;
+                bb[ti] = a[ti] * d;
+            }
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = ti; tj < NT; ++tj)
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], bb[tj], acc[ti][tj], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    float* red = zt;                                // Z*Z <= PTS*ZP
+    for (int i = tid; i < Z * Z; i += 256) red[i] = 0.f;
+    __syncthreads();
+    for (int w = 0; w < 4; ++w) {                   // fixed order: waves add one after another, mirrored tiles
+        if (wave == w) {
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = ti; tj < NT; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = ti * 16 + slot * 4 + r, col = tj * 16 + e_lo;
+                        red[row * Z + col] += acc[ti][tj][r];
+                        if (tj != ti) red[col * Z + row] += acc[ti][tj][r];
+                    }
+        }
+        __syncthreads();
+    }
+    float* out = part + ((long)b * nchunk + c) * (Z * Z);
+    for (int i = tid; i < Z * Z; i += 256) out[i] = red[i];
+}
+
 // Per utterance: reduce chunk partials (fixed order), Frobenius norms, cost_b, normalised matrices for bwd.
 __global__ void dpcl_finish_kernel(const float* __restrict__ part, float* __restrict__ per_utt, float* __restrict__ mats,
                                    int E, int S, int Z, int nchunk, int B) {
@@ -174,7 +368,8 @@ __global__ void dpcl_mean_kernel(const float* __restrict__ per_utt, float* __res
 }
 
 // Backward, fused with l2norm backward.  One thread per point.
-template <int E_>
+// FROM_U: V points at U (pre-normalisation), cnt at the CP count partials, inv is mandatory; v = u * inv on the fly.
+template <int E_, bool FROM_U>
 __global__ __launch_bounds__(256) void dpcl_bwd_kernel(const float* __restrict__ V, const float* __restrict__ Y,
                                                        const float* __restrict__ cnt, const float* __restrict__ mats,
                                                        const float* __restrict__ inv, const float* __restrict__ upstream,
@@ -191,13 +386,22 @@ __global__ __launch_bounds__(256) void dpcl_bwd_kernel(const float* __restrict__
     const float* G = mats + (long)b * (E_ * E_ + E_ * S);
     const float* A = G + E_ * E_;
     float v[E_], dv[E_];
-    if (tid < npts) {
+    float cn[8];
+    if (FROM_U) load_counts(cnt, b, S, cn);
+    else {
 #pragma unroll
-        for (int e = 0; e < E_; ++e) { v[e] = tile[tid * LDS_STRIDE + e]; dv[e] = 0.f; }
+        for (int s = 0; s < 8; ++s) cn[s] = (s < S) ? cnt[(long)b * S + s] : 0.f;
+    }
+    if (tid < npts) {
         const long p = p0 + tid;
+        const float iv_u = FROM_U ? inv[(long)b * TF + p] : 1.0f;
+#pragma unroll
+        for (int e = 0; e < E_; ++e) { v[e] = tile[tid * LDS_STRIDE + e] * iv_u; dv[e] = 0.f; }
         const float* y = Y + ((long)b * TF + p) * S;
         float diag = 0.f;
-        for (int s = 0; s < S; ++s) diag += y[s] * cnt[(long)b * S + s];
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            if (s < S) diag += y[s] * cn[s];
         const float d = (1.0f / sqrtf(diag)) * (upstream ? upstream[0] : 1.0f);
         // dv = Gn^T-free: G is symmetric; dv[f] = sum_e v[e] G[e][f]
         for (int e = 0; e < E_; ++e) {
@@ -219,7 +423,7 @@ __global__ __launch_bounds__(256) void dpcl_bwd_kernel(const float* __restrict__
             float dot = 0.f;
 #pragma unroll
             for (int f = 0; f < E_; ++f) dot += v[f] * dv[f];
-            const float iv = inv[(long)b * TF + p];
+            const float iv = FROM_U ? iv_u : inv[(long)b * TF + p];
             const bool active = iv < 0.999999e6f;
 #pragma unroll
             for (int f = 0; f < E_; ++f) dv[f] = active ? (dv[f] - v[f] * dot) * iv : dv[f] * iv;
@@ -281,7 +485,7 @@ ams_status ams_dpcl_loss_bwd(const float* V, const float* Y, const float* inv, c
     dim3 grid(ceil_div(TF, 256), B);
     const int fuse = inv ? 1 : 0;
 #define AMS_DPCL_BWD(EE) \
-    hipLaunchKernelGGL((dpcl_bwd_kernel<EE>), grid, dim3(256), 0, st, V, Y, cnt, mats, inv, upstream, dU, TF, S, fuse)
+    hipLaunchKernelGGL((dpcl_bwd_kernel<EE, false>), grid, dim3(256), 0, st, V, Y, cnt, mats, inv, upstream, dU, TF, S, fuse)
     switch (E) {
         case 40: AMS_DPCL_BWD(40); break;
         case 32: AMS_DPCL_BWD(32); break;
@@ -293,6 +497,62 @@ ams_status ams_dpcl_loss_bwd(const float* V, const float* Y, const float* inv, c
         default: return AMS_E_INVALID_ARG;
     }
 #undef AMS_DPCL_BWD
+    return ams_check_launch();
+}
+
+size_t ams_dpcl_u_workspace_bytes(int B, long TF, int E, int S) {
+    const int NT = ceil_div(E + S, 16), Z = NT * 16;
+    const int nchunk = ceil_div(TF, UCHUNK);
+    // cntp [B,CP,S] | per_utt [B,4] | mats [B, E*E+E*S] | partials [B, nchunk, Z*Z]
+    return sizeof(float) * ((size_t)B * CP * S + (size_t)B * 4 + (size_t)B * (E * E + E * S) + (size_t)B * nchunk * Z * Z);
+}
+
+// Fused l2-normalise + loss forward on the dense output U [B,TF,E].  inv [B,TF] receives 1/|u| (needed by the
+// backward); V_out (may be NULL) receives the normalised embeddings.  ws keeps counts/mats for ams_dpcl_loss_bwd_u.
+ams_status ams_dpcl_loss_fwd_u(const float* U, const float* Y, float* inv, float* V_out, float* out, int B, long TF, int E, int S,
+                               void* ws, size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(U && Y && inv && out && ws && B > 0 && TF > 0 && E > 0 && S > 0 && S <= 8 && E + S <= 64);
+    if (ws_bytes < ams_dpcl_u_workspace_bytes(B, TF, E, S)) return AMS_E_WORKSPACE_TOO_SMALL;
+    hipStream_t st = (hipStream_t)stream;
+    const int NT = ceil_div(E + S, 16), Z = NT * 16, nchunk = ceil_div(TF, UCHUNK);
+    float* cntp = (float*)ws;
+    float* per_utt = cntp + (size_t)B * CP * S;
+    float* mats = per_utt + (size_t)B * 4;
+    float* part = mats + (size_t)B * (E * E + E * S);
+    hipLaunchKernelGGL(dpcl_count_part_kernel, dim3(CP, B), dim3(256), 0, st, Y, cntp, TF, S);
+    dim3 grid(nchunk, B);
+    switch (NT) {
+        case 1: hipLaunchKernelGGL((dpcl_gram_u_kernel<1>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
+        case 2: hipLaunchKernelGGL((dpcl_gram_u_kernel<2>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
+        case 3: hipLaunchKernelGGL((dpcl_gram_u_kernel<3>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
+        default: hipLaunchKernelGGL((dpcl_gram_u_kernel<4>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
+    }
+    hipLaunchKernelGGL(dpcl_finish_kernel, dim3(B), dim3(256), Z * Z * sizeof(float), st, part, per_utt, mats, E, S, Z, nchunk, B);
+    hipLaunchKernelGGL(dpcl_mean_kernel, dim3(1), dim3(64), 0, st, per_utt, out, B);
+    return ams_check_launch();
+}
+
+// dU from U, 1/|u| and the state ams_dpcl_loss_fwd_u left in ws.
+ams_status ams_dpcl_loss_bwd_u(const float* U, const float* Y, const float* inv, const float* upstream, float* dU, int B, long TF,
+                               int E, int S, const void* ws, void* stream) {
+    AMS_REQUIRE(U && Y && inv && dU && ws && B > 0 && TF > 0 && S > 0 && S <= 8);
+    hipStream_t st = (hipStream_t)stream;
+    const float* cntp = (const float*)ws;
+    const float* mats = cntp + (size_t)B * CP * S + (size_t)B * 4;
+    dim3 grid(ceil_div(TF, 256), B);
+#define AMS_DPCL_BWD_U(EE) \
+    hipLaunchKernelGGL((dpcl_bwd_kernel<EE, true>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, S, 1)
+    switch (E) {
+        case 40: AMS_DPCL_BWD_U(40); break;
+        case 32: AMS_DPCL_BWD_U(32); break;
+        case 20: AMS_DPCL_BWD_U(20); break;
+        case 16: AMS_DPCL_BWD_U(16); break;
+        case 8: AMS_DPCL_BWD_U(8); break;
+        case 4: AMS_DPCL_BWD_U(4); break;
+        case 3: AMS_DPCL_BWD_U(3); break;
+        default: return AMS_E_INVALID_ARG;
+    }
+#undef AMS_DPCL_BWD_U
     return ams_check_launch();
 }
 

@@ -405,7 +405,14 @@ ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float
 }
 
 // Adaptive analysis filterbank, path A (reference models/adapt.py:122): y[b,t,n] = sum_k xpad[b,t*hop+k-pl] f[k,n]
-ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, void* stream) {
+size_t ams_front_conv_fwd_workspace_bytes(int Bt, int L, int W, int N, int hop) {
+    if (Bt <= 0 || L <= 0 || W <= 0 || N <= 0 || hop <= 0) return 0;
+    return ams_gemm_workspace_bytes(Bt * ((L + hop - 1) / hop), N, W);
+}
+
+// ws (may be NULL: no split-K) lets the few-tile benchmark shape (5120 x 256 output = 80 tiles) fill 256 CUs.
+ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, void* ws,
+                              size_t ws_bytes, void* stream) {
     AMS_REQUIRE(x && f && y && Bt > 0 && L > 0 && W > 0 && N > 0 && hop > 0);
     const int T = (L + hop - 1) / hop;
     int pad_total = (T - 1) * hop + W - L;
@@ -416,7 +423,7 @@ ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, 
     g.fr_L = L; g.fr_T = T; g.fr_hop = hop; g.fr_pl = pad_total / 2; g.fr_W = W;
     g.a_vec = aligned16(x) && (L % 4 == 0) && (hop % 4 == 0) && (g.fr_pl % 4 == 0);
     g.b_vec = aligned16(f) && (N % 4 == 0);
-    return launch<A_FRAMES, B_ROW>(g, nullptr, 0, (hipStream_t)stream);
+    return launch<A_FRAMES, B_ROW>(g, ws, ws_bytes, (hipStream_t)stream);
 }
 
 // Generic framed product: out[(r,t), n] = sum_k xpad[r, t*hop + k - pad_left] * Bm[k, n]   (STFT as a DFT product)

@@ -6,7 +6,7 @@
 // model offers is used, and each workgroup owns a 16(batch) x 16(hidden unit) output tile for which it
 // needs all four gate columns -- the gate non-linearity and the state update are then workgroup-local.
 //
-// Work split inside a workgroup: 4 waves split K (=H for forward, =4H for backward) and each runs
+// Work split inside a workgroup: NWF (forward) / NWB (backward) waves split K (=H for forward, =4H for backward) and each runs
 // v_mfma_f32_16x16x4_f32 chains on fragments fetched as one float4 per lane:
 //   * the recurrent matrix is re-packed once per layer call into MFMA fragment order (pack kernels
 //     below) so a lane reads 16 contiguous bytes per 4 k-steps (L2-resident: 2 x 1.46 MB per layer);
@@ -24,6 +24,16 @@ namespace {
 
 constexpr int TU = 16;   // hidden units per workgroup
 constexpr int TB = 16;   // batch rows per workgroup
+// Waves per workgroup splitting K (the first 4 also run the epilogue).  Measured on MI355X, B=64 T=80 H=300,
+// per layer: forward 4/8/16 waves = 0.648/0.627/0.662 ms; backward 4 (2 chunks)/4 (1 chunk)/8/16 waves =
+// 0.589/0.559/0.603/0.533 ms -- every wave issues ALL its operand loads before its first MFMA.
+#ifndef AMS_LSTM_FWD_WAVES
+#define AMS_LSTM_FWD_WAVES 8
+#endif
+#ifndef AMS_LSTM_BWD_WAVES
+#define AMS_LSTM_BWD_WAVES 16
+#endif
+constexpr int NWF = AMS_LSTM_FWD_WAVES, NWB = AMS_LSTM_BWD_WAVES;
 
 // Upk[dir][ut][g][q][lane][4]: lane l, j -> U[k = g*16 + (l>>4)*4 + j][q*H + ut*16 + (l&15)]
 __global__ void pack_u_fwd_kernel(const float* __restrict__ Uf, const float* __restrict__ Ub, long ldu, float* __restrict__ pk,
@@ -82,8 +92,8 @@ __device__ __forceinline__ float4 ld4_guard(const float* p, int k, int kmax, boo
     return v;
 }
 
-__global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[4][4][64][4];   // [wave][gate][lane][reg]
+__global__ __launch_bounds__(NWF * 64) void lstm_step_fwd_kernel(StepArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[NWF][4][64][4];   // [wave][gate][lane][reg]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ut = blockIdx.x, bt = blockIdx.y, dir = blockIdx.z;
     const int H = a.H, T = a.T;
@@ -101,7 +111,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgs a) {
     // the recurrent product.  thread -> (batch row, unit); C/D layout: row = (lane>>4)*4 + reg, col = lane&15
     const int bl = tid >> 4, ul = tid & 15;
     const int b = bt * TB + bl, u = ut * TU + ul;
-    const bool live = (b < a.B && u < H);
+    const bool live = (tid < 256 && b < a.B && u < H);
     float* grow = a.G + (((long)(live ? b : 0) * T + t) * 2 + dir) * (4 * H);
     float zq[4] = {0.f, 0.f, 0.f, 0.f};
     float c_prev = 0.f;
@@ -116,12 +126,12 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgs a) {
         const float* pk = a.pk + (((long)dir * a.n_ut + ut) * a.n_g) * (4 * 64 * 4) + lane * 4;
         // Issue EVERY operand load of a chunk before the first MFMA: the h/U fetches are L2 round trips
         // (~1 us) and a load->MFMA->load loop would pay that latency once per k-group.
-        constexpr int CH = 5;                          // k-groups per wave per chunk (H = 300: 19 groups / 4 waves)
-        for (int g0 = wave; g0 < a.n_g; g0 += 4 * CH) {
+        constexpr int CH = (19 + NWF - 1) / NWF;         // k-groups per wave per chunk (H = 300: 19 groups / NWF waves)
+        for (int g0 = wave; g0 < a.n_g; g0 += NWF * CH) {
             float4 av[CH], bv[CH][4];
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
-                const int g = g0 + 4 * i;
+                const int g = g0 + NWF * i;
                 if (g < a.n_g) {
                     av[i] = ld4_guard(hrow, g * 16 + (lane >> 4) * 4, H, b_row < a.B, vec);
 #pragma unroll
@@ -130,7 +140,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
-                const int g = g0 + 4 * i;
+                const int g = g0 + NWF * i;
                 if (g < a.n_g) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[i][q].x, acc[q], 0, 0, 0);
@@ -155,7 +165,7 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgs a) {
     for (int q = 0; q < 4; ++q) {
         float s = zq[q];
 #pragma unroll
-        for (int w = 0; w < 4; ++w) s += red[w][q][src_lane][src_reg];
+        for (int w = 0; w < NWF; ++w) s += red[w][q][src_lane][src_reg];
         pre[q] = s;
     }
     const float ig = 1.0f / (1.0f + expf(-pre[0]));
@@ -173,8 +183,8 @@ __global__ __launch_bounds__(256) void lstm_step_fwd_kernel(StepArgs a) {
 }
 
 // Backward step s: forward direction handles t = T-1-s, backward direction t = s.
-__global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[4][64][4];
+__global__ __launch_bounds__(NWB * 64) void lstm_step_bwd_kernel(StepArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[NWB][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ut = blockIdx.x, bt = blockIdx.y, dir = blockIdx.z;
     const int H = a.H, T = a.T;
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgs a) {
 
     const int bl = tid >> 4, ul = tid & 15;
     const int b = bt * TB + bl, u = ut * TU + ul;
-    const bool live = (b < a.B && u < H);
+    const bool live = (tid < 256 && b < a.B && u < H);
     float* grow = a.G + (((long)(live ? b : 0) * T + t) * 2 + dir) * (4 * H);
     float* dcp = a.dc + ((long)(live ? b : 0) * 2 + dir) * H + (live ? u : 0);
     float dh = 0.f, ig = 0.f, gg = 0.f, fg = 0.f, og = 0.f, c = 0.f, c_prev = 0.f, dc_next = 0.f;
@@ -204,12 +214,12 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgs a) {
     if (has_next) {
         const float* darow = a.G + (((long)b_row * T + tn) * 2 + dir) * (4 * H);
         const float* pk = a.pk + (((long)dir * a.n_ut + ut) * a.n_g) * (64 * 4) + lane * 4;
-        constexpr int CH = 10;                         // k-groups per wave per chunk (4H = 1200: 75 groups / 4 waves = 19)
-        for (int g0 = wave; g0 < a.n_g; g0 += 4 * CH) {
+        constexpr int CH = (75 + NWB - 1) / NWB;            // k-groups per wave per chunk (4H = 1200: 75 groups / NWB waves)
+        for (int g0 = wave; g0 < a.n_g; g0 += NWB * CH) {
             float4 av[CH], bv[CH];
 #pragma unroll
             for (int i = 0; i < CH; ++i) {
-                const int g = g0 + 4 * i;
+                const int g = g0 + NWB * i;
                 if (g < a.n_g) {
                     av[i] = ld4_guard(darow, g * 16 + (lane >> 4) * 4, 4 * H, b_row < a.B, vec);
                     bv[i] = *reinterpret_cast<const float4*>(pk + (long)g * 256);
@@ -217,8 +227,8 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgs a) {
             }
 #pragma unroll
             for (int i = 0; i < CH; i += 2) {
-                const int g = g0 + 4 * i;
-                const bool ok0 = g < a.n_g, ok1 = (i + 1 < CH) && (g + 4 < a.n_g);
+                const int g = g0 + NWB * i;
+                const bool ok0 = g < a.n_g, ok1 = (i + 1 < CH) && (g + NWB < a.n_g);
                 if (ok0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].x, bv[i].x, acc0, 0, 0, 0);
                 if (ok1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i + 1].x, bv[i + 1].x, acc1, 0, 0, 0);
                 if (ok0) acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i].y, bv[i].y, acc0, 0, 0, 0);
@@ -237,7 +247,7 @@ __global__ __launch_bounds__(256) void lstm_step_bwd_kernel(StepArgs a) {
     if (!live) return;
     const int src_lane = (bl >> 2) * 16 + ul, src_reg = bl & 3;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) dh += red[w][src_lane][src_reg];
+    for (int w = 0; w < NWB; ++w) dh += red[w][src_lane][src_reg];
     const float tc = tanhf(c);
     const float d_o = dh * tc;
     const float dcv = dc_next + dh * og * (1.0f - tc * tc);
@@ -297,7 +307,7 @@ ams_status ams_blstm_recurrent_fwd(float* G, float* out, float* cst, const float
     dim3 grid(n_ut, ceil_div(B, TB), 2);
     for (int s = 0; s < T; ++s) {
         a.s = s;
-        hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(NWF * 64), 0, st, a);
     }
     return ams_check_launch();
 }
@@ -320,7 +330,7 @@ ams_status ams_blstm_recurrent_bwd(float* G, const float* cst, const float* dout
     dim3 grid(n_ut, ceil_div(B, TB), 2);
     for (int s = 0; s < T; ++s) {
         a.s = s;
-        hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, dim3(256), 0, st, a);
+        hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, dim3(NWB * 64), 0, st, a);
     }
     return ams_check_launch();
 }

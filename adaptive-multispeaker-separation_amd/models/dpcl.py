@@ -27,23 +27,23 @@ class DPCL(Separator):
 
         def _embed(run):
             x = x_node.value(run)
-            u = conv.f_prop(f_props(layers, x))                # [B, T, F*E]  (column = f*E + e)
-            V, inv = F.l2norm_keep(u, E)                       # Reshape + Normalize(3)
-            return u, V, inv
+            return conv.f_prop(f_props(layers, x))             # [B, T, F*E]  (column = f*E + e)
         self._embed = Node('embed', _embed, register=False)
-        return Node('prediction', lambda run: self._embed.value(run)[1], register=False)
+        # Reshape + Normalize(3); only evaluated when the embeddings themselves are fetched (inference / k-means):
+        # a training step goes u -> fused normalise+loss kernel and never writes V.
+        return Node('prediction', lambda run: F.l2norm_keep(self._embed.value(run), E)[0], register=False)
 
     @scope
     def cost(self):
         # dpcl.py:41-87
         self.prediction
-        embed, y = self._embed, self.y
+        embed, y, E = self._embed, self.y, self.embedding_size
         g = get_default_graph()
 
         def _terms(run):
-            u, V, inv = embed.value(run)
+            u = embed.value(run)
             Y = y.value(run)
-            return F.dpcl_loss_from_u(u, V, inv, Y.reshape(V.shape[0], -1, Y.shape[-1]))
+            return F.dpcl_loss_u(u, Y.reshape(u.shape[0], -1, Y.shape[-1]), E)
         terms = Node('terms', _terms)
         cost = Node('cost_value', lambda run: terms.value(run)[0:1])
         g.summaries['cost/cost'] = cost

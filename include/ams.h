@@ -39,7 +39,9 @@ ams_status ams_front_filter_bwd(const float* w, const float* bases, const float*
 
 /* ---- K2  analysis filterbank, path A: tf.nn.conv2d stride=hop SAME        models/adapt.py:122 ----
  * x [Bt,L], f [W,N] -> y [Bt,T',N], T' = ceil(L/hop), pad_left = ((T'-1)hop+W-L)/2. */
-ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, void* stream);
+size_t ams_front_conv_fwd_workspace_bytes(int Bt, int L, int W, int N, int hop);
+ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, void* ws,
+                              size_t ws_bytes, void* stream);
 size_t ams_front_conv_bwd_filter_workspace_bytes(int Bt, int L, int W, int N, int hop);
 ams_status ams_front_conv_bwd_filter(const float* x, const float* dy, float* df, int Bt, int L, int W, int N, int hop, void* ws,
                                      size_t ws_bytes, void* stream);
@@ -113,6 +115,15 @@ ams_status ams_dpcl_loss_fwd(const float* V, const float* Y, float* out, int B, 
                              void* stream);
 ams_status ams_dpcl_loss_bwd(const float* V, const float* Y, const float* inv, const float* upstream, float* dU, int B, long TF,
                              int E, int S, const void* ws, void* stream);
+
+/* Fused training form of K13+K14: U [B,TF,E] is the dense output BEFORE tf.nn.l2_normalize (utils/ops.py:323-324);
+ * one pass computes inv[B,TF] = 1/max(|u|,1e-6), the loss terms and (V_out != NULL) the normalised embeddings.
+ * The backward recomputes v = u*inv and applies d loss/dV and the l2-normalise Jacobian in one pass. */
+size_t ams_dpcl_u_workspace_bytes(int B, long TF, int E, int S);
+ams_status ams_dpcl_loss_fwd_u(const float* U, const float* Y, float* inv, float* V_out, float* out, int B, long TF, int E, int S,
+                               void* ws, size_t ws_bytes, void* stream);
+ams_status ams_dpcl_loss_bwd_u(const float* U, const float* Y, const float* inv, const float* upstream, float* dU, int B, long TF,
+                               int E, int S, const void* ws, void* stream);
 
 /* ---- K24  optimizers     models/network.py:181-194, utils/ops.py:686-703 ---- */
 ams_status ams_opt_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, long n, float lr_t, float beta1,

@@ -122,7 +122,8 @@ def test_blstm_layer(ops, B, T, D, H):
     assert rel(host(dbf), dbf_r) < 5 * TOL and rel(host(dbb), dbb_r) < 5 * TOL
 
 
-@pytest.mark.parametrize('B,TF,E,S', [(2, 300, 8, 2), (3, 5000, 40, 2), (2, 2049, 40, 3), (2, 77, 3, 2)])
+@pytest.mark.parametrize('B,TF,E,S', [(2, 300, 8, 2), (3, 5000, 40, 2), (2, 2049, 40, 3), (2, 77, 3, 2), (1, 700, 20, 4),
+                                        (2, 2561, 40, 8)])
 def test_l2norm_dpcl(ops, B, TF, E, S):
     rng = np.random.RandomState(TF)
     u = rng.randn(B, TF * E)
@@ -147,6 +148,22 @@ def test_l2norm_dpcl(ops, B, TF, E, S):
     assert rel(host(du).reshape(du_ref.shape), du_ref) < 5 * TOL
     du2 = ops.l2norm_bwd(V, inv, dV.view(B, -1), E)
     assert rel(host(du2).reshape(du_ref.shape), du_ref) < 5 * TOL
+    # fused training form: one pass over u gives 1/|u|, the loss terms and (optionally) V; backward from u
+    Ud = dev(u).view(B, TF, E)
+    out_u, inv_u, V_u, ws_u = ops.dpcl_loss_fwd_u(Ud, Yd, want_V=True)
+    ou = host(out_u)
+    assert abs(ou[0] - c_ref) < TOL * max(1.0, abs(c_ref))
+    for k in range(3):
+        assert abs(ou[1 + k] - terms[k]) < TOL * max(1.0, abs(terms[k]))
+    assert rel(host(inv_u).reshape(-1), inv_ref.reshape(-1)) < 1e-6
+    assert rel(host(V_u).reshape(V_ref.shape), V_ref) < 1e-6
+    out_n, inv_n, V_n, _ = ops.dpcl_loss_fwd_u(Ud, Yd)
+    assert V_n is None and np.array_equal(host(out_n), ou) and np.array_equal(host(inv_n), host(inv_u))
+    du_u = ops.dpcl_loss_bwd_u(Ud, Yd, inv_u, ws_u)
+    assert rel(host(du_u).reshape(du_ref.shape), du_ref) < 5 * TOL
+    up = dev(np.array([0.5]))
+    du_h = ops.dpcl_loss_bwd_u(Ud, Yd, inv_u, ws_u, upstream=up)
+    assert rel(host(du_h).reshape(du_ref.shape), 0.5 * du_ref) < 5 * TOL
 
 
 def test_optimizers(ops):
