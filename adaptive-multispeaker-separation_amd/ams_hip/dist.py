@@ -37,7 +37,12 @@ class Dist(object):
 
     def broadcast(self, t, src=0):
         if self.enabled:
-            td.broadcast(t, src)
+            if t.is_contiguous():
+                td.broadcast(t, src)
+            else:                                   # twin-interleaved BLSTM variables are strided views
+                tmp = t.contiguous()
+                td.broadcast(tmp, src)
+                t.copy_(tmp)
         return t
 
     def barrier(self):

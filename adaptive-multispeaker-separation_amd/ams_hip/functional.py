@@ -30,7 +30,7 @@ class _Overlap(object):
         return self.stream
 
     def usable(self, *params):
-        return self.enabled and all(p.grad is not None and p.grad.is_contiguous() for p in params)
+        return self.enabled and all(p.grad is not None and p.grad.stride(-1) == 1 for p in params)
 
     def fork(self, *tensors):
         s = self.side()

@@ -30,6 +30,27 @@ def _chk(*ts):
             raise AmsError('ams_hip ops need contiguous fp32 tensors, got %s %s' % (t.dtype, tuple(t.stride())))
 
 
+def _chk_rows(*ts):
+    """Like _chk but rows may be strided (twin-interleaved BLSTM kernels): only the last dim must be dense."""
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise AmsError('ams_hip ops need device tensors (there is no CPU fallback)')
+        if t.dtype != torch.float32 or t.stride(-1) != 1:
+            raise AmsError('ams_hip ops need fp32 tensors with dense rows, got %s %s' % (t.dtype, tuple(t.stride())))
+
+
+def _twin(a, b):
+    """True when a and b are the two halves of one row-interleaved block [R, 2, C] (optim.FlatOptimizer twin layout)."""
+    if a is None or b is None or a.shape != b.shape or a.dtype != torch.float32 or b.dtype != torch.float32:
+        return False
+    C = a.shape[-1]
+    if b.data_ptr() != a.data_ptr() + 4 * C or a.stride(-1) != 1 or b.stride(-1) != 1:
+        return False
+    return a.dim() == 1 or (a.stride(0) == 2 * C and b.stride(0) == 2 * C)
+
+
 class _Profile(object):
     """HIP-event timing of individual launches on the launching stream (bench.py `roofline`).  Events are
     recorded around a launch only when enabled; elapsed times are read after the timed region."""
@@ -181,36 +202,44 @@ def persist_errors():
 def blstm_fwd(x, Kf, bf, Kb, bb):
     """One BLSTM layer (utils/ops.py:358-383).  x [B,T,D]; K* [D+H,4H]; b* [4H].
     Returns out [B,T,2H] and the tensors the backward needs (G = activated gates, cst = cell states)."""
-    _chk(x, Kf, bf, Kb, bb)
+    _chk(x, bf, bb)
+    _chk_rows(Kf, Kb)
     lib = load()
     B, T, D = x.shape
     H = Kf.shape[1] // 4
+    ldu = Kf.stride(0)
+    if Kb.stride(0) != ldu:
+        raise AmsError('blstm: the two direction kernels must share one row stride')
     G = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=x.device)
     x2 = x.view(B * T, D)
     # hoisted input projection of BOTH directions as ONE MFMA GEMM [B*T, D] x [D, 8H]: the two [D,4H] halves of the TF
     # kernels are gathered side by side (a 2 x D x 4H copy) so N = 8H gives 19 x 40 = 760 tiles = 2.97 per CU instead of
     # two launches of 400 (1.56 per CU, i.e. 22 % of the CU-time idle).
     Wcat = blstm_wcat(Kf, Kb, D)
-    gemm(x2, Wcat, bias=torch.cat([bf, bb]), out=G, M=B * T, N=8 * H, K=D, lda=D, ldb=8 * H, ldc=8 * H)
+    bias = torch.as_strided(bf, (8 * H,), (1,)) if _twin(bf, bb) else torch.cat([bf, bb])
+    gemm(x2, Wcat, bias=bias, out=G, M=B * T, N=8 * H, K=D, lda=D, ldb=8 * H, ldc=8 * H)
     out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
     cst = torch.empty((B, T, 2, H), dtype=torch.float32, device=x.device)
     pack = torch.empty(lib.ams_blstm_pack_floats(H, 0), dtype=torch.float32, device=x.device)
     nsync = lib.ams_blstm_persist_sync_bytes(B, H, 0) if LSTM_PERSIST else 0
     if nsync:
         sync = _ws(nsync, x)
-        check(lib.ams_blstm_persist_fwd(_p(G), _p(out), _p(cst), _p(Kf[D:]), _p(Kb[D:]), 4 * H, _p(pack), _p(sync), nsync, B, T, H, _s()),
+        check(lib.ams_blstm_persist_fwd(_p(G), _p(out), _p(cst), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(pack), _p(sync), nsync, B, T, H, _s()),
               'ams_blstm_persist_fwd')
         LAST_SYNC.append(sync)
         del LAST_SYNC[:-8]
     else:
-        check(lib.ams_blstm_recurrent_fwd(_p(G), _p(out), _p(cst), _p(Kf[D:]), _p(Kb[D:]), 4 * H, _p(pack), B, T, H, _s()),
+        check(lib.ams_blstm_recurrent_fwd(_p(G), _p(out), _p(cst), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(pack), B, T, H, _s()),
               'ams_blstm_recurrent_fwd')
     return out, G, cst
 
 
 def blstm_wcat(Kf, Kb, D):
-    """[D, 8H] = input parts of the forward | backward kernels side by side (memcpy-class glue, 2 x D x 4H floats)."""
+    """[D, 8H] = input parts of the forward | backward kernels side by side: a zero-copy view when the two kernels are
+    stored twin-interleaved (training through FlatOptimizer), else memcpy-class glue (2 x D x 4H floats)."""
     H4 = Kf.shape[1]
+    if _twin(Kf, Kb):
+        return torch.as_strided(Kf, (D, 2 * H4), (2 * H4, 1))
     Wcat = torch.empty((D, 2 * H4), dtype=torch.float32, device=Kf.device)
     Wcat[:, :H4].copy_(Kf[:D])
     Wcat[:, H4:].copy_(Kb[:D])
@@ -219,21 +248,23 @@ def blstm_wcat(Kf, Kb, D):
 
 def blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout):
     """BPTT recurrence of one BLSTM layer: overwrites G (activated gates) with d pre-activation."""
-    _chk(x, Kf, Kb, G, cst, dout)
+    _chk(x, G, cst, dout)
+    _chk_rows(Kf, Kb)
     lib = load()
     B, T, D = x.shape
     H = Kf.shape[1] // 4
+    ldu = Kf.stride(0)
     pack = torch.empty(lib.ams_blstm_pack_floats(H, 1), dtype=torch.float32, device=x.device)
     nsync = lib.ams_blstm_persist_sync_bytes(B, H, 1) if LSTM_PERSIST else 0
     if nsync:
         sync = _ws(nsync, x)
-        check(lib.ams_blstm_persist_bwd(_p(G), _p(cst), _p(dout), _p(Kf[D:]), _p(Kb[D:]), 4 * H, _p(pack), _p(sync), nsync, B, T, H, _s()),
+        check(lib.ams_blstm_persist_bwd(_p(G), _p(cst), _p(dout), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(pack), _p(sync), nsync, B, T, H, _s()),
               'ams_blstm_persist_bwd')
         LAST_SYNC.append(sync)
         del LAST_SYNC[:-8]
     else:
         dc = torch.empty((B, 2, H), dtype=torch.float32, device=x.device)
-        check(lib.ams_blstm_recurrent_bwd(_p(G), _p(cst), _p(dout), _p(dc), _p(Kf[D:]), _p(Kb[D:]), 4 * H, _p(pack), B, T, H, _s()),
+        check(lib.ams_blstm_recurrent_bwd(_p(G), _p(cst), _p(dout), _p(dc), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(pack), B, T, H, _s()),
               'ams_blstm_recurrent_bwd')
 
 
@@ -259,34 +290,47 @@ def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate):
     dZb = G.view(-1)[4 * H:]
     acc = bool(accumulate)
     # dWx of both directions in one product x^T . dZ -> [D, 8H], then scattered into the two TF-layout kernels
-    dWcat = gemm(x2, dZf, transA=True, M=D, N=8 * H, K=M, lda=D, ldb=8 * H, ldc=8 * H,
-                 out=torch.empty((D, 8 * H), dtype=torch.float32, device=x.device))
-    if acc:
-        dKf[:D].add_(dWcat[:, :4 * H])
-        dKb[:D].add_(dWcat[:, 4 * H:])
+    _chk_rows(dKf, dKb)
+    ldk = dKf.stride(0)
+    if _twin(dKf, dKb):
+        # twin-interleaved gradient block: [dWx_f | dWx_b] IS a row-major [D, 8H] matrix -> written in place
+        gemm(x2, dZf, transA=True, M=D, N=8 * H, K=M, lda=D, ldb=8 * H, ldc=8 * H, accumulate=acc,
+             out=torch.as_strided(dKf, (D, 8 * H), (8 * H, 1)))
     else:
-        dKf[:D].copy_(dWcat[:, :4 * H])
-        dKb[:D].copy_(dWcat[:, 4 * H:])
+        dWcat = gemm(x2, dZf, transA=True, M=D, N=8 * H, K=M, lda=D, ldb=8 * H, ldc=8 * H,
+                     out=torch.empty((D, 8 * H), dtype=torch.float32, device=x.device))
+        if acc:
+            dKf[:D].add_(dWcat[:, :4 * H])
+            dKb[:D].add_(dWcat[:, 4 * H:])
+        else:
+            dKf[:D].copy_(dWcat[:, :4 * H])
+            dKb[:D].copy_(dWcat[:, 4 * H:])
     # forward dir pairs out[b,t-1] with dZ[b,t]; backward dir pairs out[b,t+1] with dZ[b,t]
     of = out.view(-1)
-    gemm(of, dZf[8 * H:], transA=True, out=dKf[D:], accumulate=acc, M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H, ldc=4 * H,
+    gemm(of, dZf[8 * H:], transA=True, out=dKf[D:], accumulate=acc, M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H, ldc=ldk,
          mask=(T, T - 1))
-    gemm(of[2 * H + H:], dZb, transA=True, out=dKb[D:], accumulate=acc, M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H, ldc=4 * H,
-         mask=(T, T - 1))
-    nb = lib.ams_colsum_workspace_bytes(M, 4 * H)
-    ws = _ws(nb, x)
-    check(lib.ams_colsum(_p(dZf), _p(dbf), M, 4 * H, 8 * H, int(acc), _p(ws), nb, _s()), 'ams_colsum')
-    ws2 = _ws(nb, x)
-    check(lib.ams_colsum(_p(dZb), _p(dbb), M, 4 * H, 8 * H, int(acc), _p(ws2), nb, _s()), 'ams_colsum')
+    gemm(of[2 * H + H:], dZb, transA=True, out=dKb[D:], accumulate=acc, M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H,
+         ldc=dKb.stride(0), mask=(T, T - 1))
+    if _twin(dbf, dbb):                    # adjacent bias gradients: one column-sum over all 8H columns of dZ
+        nb = lib.ams_colsum_workspace_bytes(M, 8 * H)
+        ws = _ws(nb, x)
+        check(lib.ams_colsum(_p(dZf), _p(dbf), M, 8 * H, 8 * H, int(acc), _p(ws), nb, _s()), 'ams_colsum')
+    else:
+        nb = lib.ams_colsum_workspace_bytes(M, 4 * H)
+        ws = _ws(nb, x)
+        check(lib.ams_colsum(_p(dZf), _p(dbf), M, 4 * H, 8 * H, int(acc), _p(ws), nb, _s()), 'ams_colsum')
+        ws2 = _ws(nb, x)
+        check(lib.ams_colsum(_p(dZb), _p(dbb), M, 4 * H, 8 * H, int(acc), _p(ws2), nb, _s()), 'ams_colsum')
 
 
 def blstm_bwd(x, Kf, Kb, out, G, cst, dout, need_dx=True):
     """BPTT for one BLSTM layer.  DESTROYS G (it becomes d pre-activation).  Returns dx, dKf, dbf, dKb, dbb."""
-    _chk(x, Kf, Kb, out, G, cst, dout)
+    _chk(x, out, G, cst, dout)
     B, T, D = x.shape
     H = Kf.shape[1] // 4
     blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout)
-    dKf, dKb = torch.empty_like(Kf), torch.empty_like(Kb)
+    dKf = torch.empty(Kf.shape, dtype=torch.float32, device=x.device)
+    dKb = torch.empty(Kb.shape, dtype=torch.float32, device=x.device)
     dbf = torch.empty(4 * H, dtype=torch.float32, device=x.device)
     dbb = torch.empty(4 * H, dtype=torch.float32, device=x.device)
     blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, False)

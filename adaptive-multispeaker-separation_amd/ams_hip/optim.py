@@ -26,12 +26,37 @@ class FlatOptimizer(object):
         self.flat = torch.empty(n, dtype=torch.float32, device=dev)
         self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
+        ids = set(id(v) for v in self.vars)
+        placed = set()
         for v in self.vars:
+            if id(v) in placed:
+                continue
             k = v.numel()
+            w = getattr(v, '_ams_twin', None)
+            if w is not None and id(w) in ids and id(w) not in placed and w.shape == v.shape:
+                # Twin variables (the two directions of a BLSTM layer) are stored ROW-INTERLEAVED: block [R, 2, C] with
+                # v = block[:, 0, :], w = block[:, 1, :].  [Wx_f | Wx_b] is then a plain [D, 8H] row-major matrix, so
+                # the merged-direction GEMMs read weights and write weight gradients in place (no gather/scatter copies).
+                R = v.shape[0] if v.dim() == 2 else 1
+                C = v.shape[-1]
+                for buf, init in ((self.flat, True), (self.flat_grad, False)):
+                    blk = buf[off:off + 2 * k].view(R, 2, C)
+                    for j, t in enumerate((v, w)):
+                        view = blk[:, j, :] if t.dim() == 2 else blk[0, j, :]
+                        if init:
+                            view.copy_(t.detach())
+                            t.data = view
+                            t.requires_grad_(True)
+                        else:
+                            t.grad = view
+                placed.update((id(v), id(w)))
+                off += 2 * k
+                continue
             self.flat[off:off + k].copy_(v.detach().reshape(-1))
             v.data = self.flat[off:off + k].view(v.shape)
             v.requires_grad_(True)
             v.grad = self.flat_grad[off:off + k].view(v.shape)
+            placed.add(id(v))
             off += k
         z = lambda: torch.zeros(n, dtype=torch.float32, device=dev)  # noqa: E731
         if kind == 'Adam':                      # the reference's 'Adam' is AMSGrad(eps=1e-3, beta2=.99), undecayed lr

@@ -114,6 +114,39 @@ __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __rest
     __syncthreads();
     if (rl == 0 && c < cols) part[(long)blockIdx.y * cols + c] = (sm[0][cl] + sm[1][cl]) + (sm[2][cl] + sm[3][cl]);
 }
+// 16-byte variant (cols % 4 == 0, ld % 4 == 0, 16-byte aligned base): a block owns 256 columns, each wave reads whole
+// 1-KB row segments, 8 independent loads per thread in flight.
+__global__ __launch_bounds__(256) void colsum_partial_vec_kernel(const float* __restrict__ x, float* __restrict__ part, long rows,
+                                                                 int cols, long ld, int rows_per_block) {
+    __shared__ float4 sm[4][64];
+    const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int c = blockIdx.x * 256 + cl * 4;
+    const long r0 = (long)blockIdx.y * rows_per_block;
+    const long r1 = min(rows, r0 + rows_per_block);
+    float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+    if (c < cols) {
+        const float* base = x + c;
+        long r = r0 + rl;
+#pragma unroll 4
+        for (; r + 4 < r1; r += 8) {
+            const float4 a = *reinterpret_cast<const float4*>(base + r * ld);
+            const float4 b = *reinterpret_cast<const float4*>(base + (r + 4) * ld);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+            s1.x += b.x; s1.y += b.y; s1.z += b.z; s1.w += b.w;
+        }
+        if (r < r1) {
+            const float4 a = *reinterpret_cast<const float4*>(base + r * ld);
+            s0.x += a.x; s0.y += a.y; s0.z += a.z; s0.w += a.w;
+        }
+    }
+    sm[rl][cl] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+    __syncthreads();
+    if (rl == 0 && c < cols) {
+        const float4 a = sm[0][cl], b = sm[1][cl], d = sm[2][cl], e = sm[3][cl];
+        *reinterpret_cast<float4*>(part + (long)blockIdx.y * cols + c) =
+            make_float4((a.x + b.x) + (d.x + e.x), (a.y + b.y) + (d.y + e.y), (a.z + b.z) + (d.z + e.z), (a.w + b.w) + (d.w + e.w));
+    }
+}
 __global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int cols, int nparts, int accumulate) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= cols) return;
@@ -212,19 +245,23 @@ ams_status ams_l2norm_bwd(const float* v, const float* inv, const float* dv, flo
     return ams_check_launch();
 }
 
+constexpr int COLSUM_RPB = 128;
 size_t ams_colsum_workspace_bytes(long rows, int cols) {
-    const int nparts = ceil_div(rows, 256);
+    const int nparts = ceil_div(rows, COLSUM_RPB);
     return (size_t)nparts * cols * sizeof(float);
 }
 
 ams_status ams_colsum(const float* x, float* out, long rows, int cols, long ld, int accumulate, void* ws, size_t ws_bytes,
                       void* stream) {
     AMS_REQUIRE(x && out && rows > 0 && cols > 0 && ws);
-    const int rpb = 256;
+    const int rpb = COLSUM_RPB;
     const int nparts = ceil_div(rows, rpb);
     if ((size_t)nparts * cols * sizeof(float) > ws_bytes) return AMS_E_WORKSPACE_TOO_SMALL;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(cols, 64), nparts), dim3(256), 0, st, x, (float*)ws, rows, cols, ld, rpb);
+    if (cols % 4 == 0 && ld % 4 == 0 && ((uintptr_t)x & 15) == 0 && ((uintptr_t)ws & 15) == 0)
+        hipLaunchKernelGGL(colsum_partial_vec_kernel, dim3(ceil_div(cols, 256), nparts), dim3(256), 0, st, x, (float*)ws, rows, cols, ld, rpb);
+    else
+        hipLaunchKernelGGL(colsum_partial_kernel, dim3(ceil_div(cols, 64), nparts), dim3(256), 0, st, x, (float*)ws, rows, cols, ld, rpb);
     hipLaunchKernelGGL(colsum_final_kernel, dim3(ceil_div(cols, 256)), dim3(256), 0, st, (const float*)ws, out, cols, nparts, accumulate);
     return ams_check_launch();
 }

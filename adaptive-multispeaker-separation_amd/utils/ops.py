@@ -94,6 +94,7 @@ class BLSTM:
 
         self.Kf, self.bf = mk('forward')
         self.Kb, self.bb = mk('backward')
+        self.Kf._ams_twin, self.bf._ams_twin = self.Kb, self.bb      # storage hint for FlatOptimizer (interleaved rows)
 
     def f_prop(self, x):
         return F.blstm(x, self.Kf, self.bf, self.Kb, self.bb)
