@@ -42,7 +42,7 @@ class _Overlap(object):
     def cap(self, on):
         import os
         from ._lib import load
-        load().ams_gemm_set_lds_pad(int(os.environ.get('AMS_SIDE_LDS_PAD', '0')) if on else 0)
+        load().ams_gemm_set_lds_pad(int(os.environ.get('AMS_SIDE_LDS_PAD', '70000')) if on else 0)
 
     def join(self):
         if self.stream is not None:
@@ -82,6 +82,10 @@ class FrontConv(Function):
         return None, df, None
 
 
+import os as _os
+_ORDER = int(_os.environ.get('AMS_OVERLAP_ORDER', '2'))
+
+
 class BLSTMLayer(Function):
     """utils/ops.py:358-383 (BasicLSTMCell x 2 directions, concat)."""
 
@@ -100,12 +104,16 @@ class BLSTMLayer(Function):
         if OVERLAP.usable(Kf, Kb, bf, bb) and all(ctx.needs_input_grad[1:]):
             B, T, D = x.shape
             ops.blstm_bwd_recurrent(x, Kf, Kb, G, cst, _c(dout))
+            dx = None
+            if _ORDER >= 2 and need_dx:
+                dx = ops.blstm_bwd_dx(G, Kf, Kb, B, T, D)
             s = OVERLAP.fork(x, out, G)
             with torch.cuda.stream(s):
-                OVERLAP.cap(True)
+                OVERLAP.cap(need_dx)               # first layer: no recurrence follows, let the products fill the chip
                 ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True)
                 OVERLAP.cap(False)
-            dx = ops.blstm_bwd_dx(G, Kf, Kb, B, T, D) if need_dx else None
+            if dx is None and need_dx:
+                dx = ops.blstm_bwd_dx(G, Kf, Kb, B, T, D)
             return dx, None, None, None, None
         dx, dKf, dbf, dKb, dbb = ops.blstm_bwd(x, Kf, Kb, out, G, cst, _c(dout), need_dx=need_dx)
         return dx, dKf, dbf, dKb, dbb
@@ -129,13 +137,17 @@ class Dense(Function):
         x2 = x.reshape(-1, x.shape[-1])
         b = ctx.bias
         if OVERLAP.usable(W, b) and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
+            dx = None
+            if _ORDER >= 1 and ctx.needs_input_grad[0]:
+                dx = ops.gemm(du2, W, transB=True).view(x.shape)
             s = OVERLAP.fork(x2, du2)
             with torch.cuda.stream(s):
                 OVERLAP.cap(True)
                 ops.gemm(x2, du2, transA=True, out=W.grad, accumulate=True)
                 OVERLAP.cap(False)
                 ops.colsum_into(du2, b.grad, True)
-            dx = ops.gemm(du2, W, transB=True).view(x.shape) if ctx.needs_input_grad[0] else None
+            if dx is None and ctx.needs_input_grad[0]:
+                dx = ops.gemm(du2, W, transB=True).view(x.shape)
             return dx, None, None
         dx = ops.gemm(du2, W, transB=True).view(x.shape) if ctx.needs_input_grad[0] else None
         dW = ops.gemm(x2, du2, transA=True) if ctx.needs_input_grad[1] else None

@@ -167,11 +167,12 @@ __device__ __forceinline__ void load_counts(const float* __restrict__ cntp, int 
     }
 }
 
-template <int NT>
+template <int NT, int EC>                          // EC: compile-time E (0 = use the run-time value)
 __global__ __launch_bounds__(256) void dpcl_gram_u_kernel(const float* __restrict__ U, const float* __restrict__ Y,
                                                           const float* __restrict__ cntp, float* __restrict__ inv_out,
-                                                          float* __restrict__ V_out, float* __restrict__ part, long TF, int E,
+                                                          float* __restrict__ V_out, float* __restrict__ part, long TF, int E_rt,
                                                           int S, int nchunk) {
+    const int E = EC ? EC : E_rt;
     constexpr int Z = NT * 16;
     constexpr int ZP = Z + 4;                       // row pitch: 16-byte aligned rows, 16 lanes x 16 B cover all banks
     constexpr int PTS = NT <= 3 ? 256 : 128;        // points staged per iteration
@@ -439,6 +440,183 @@ __global__ __launch_bounds__(256) void dpcl_bwd_kernel(const float* __restrict__
     for (int i = tid; i < npts * E_; i += 256) Ub[i] = tile[(i / E_) * LDS_STRIDE + (i % E_)];
 }
 
+
+// Backward from U on the matrix cores.  dV_p = D_p * ([v_p | y_p] . M) with M = [Gn ; -An^T] (Z x E, zero padded), i.e.
+// a [points x Z] . [Z x E] product per utterance: 16-point groups run v_mfma_f32_16x16x4_f32 chains against M held in
+// registers as B fragments (one load per workgroup), the A fragments come from the staged rows in LDS scaled by 1/|u|
+// on the fly.  The l2-normalise Jacobian (a 16-lane dot per point) is applied on the accumulators and dU goes back
+// through LDS so global traffic is 16-byte coalesced both ways; slab i+1 is fetched while slab i is in the MFMA phase.
+// Algorithmic HBM bytes per utterance: TF*(2E+S+1)*4.
+template <int NT, int EC>                          // EC: compile-time E (0 = use the run-time value)
+__global__ __launch_bounds__(256, 2) void dpcl_bwd_u_kernel(const float* __restrict__ U, const float* __restrict__ Y,
+                                                         const float* __restrict__ cntp, const float* __restrict__ mats,
+                                                         const float* __restrict__ inv, const float* __restrict__ upstream,
+                                                         float* __restrict__ dU, long TF, int E_rt, int S) {
+    const int E = EC ? EC : E_rt;
+    constexpr int Z = NT * 16, ZP = Z + 4, KT = Z / 4;
+    constexpr int PTS = NT <= 3 ? 256 : 128;
+    constexpr int NV = PTS * Z / 4 / 256;
+    __shared__ __attribute__((aligned(16))) float zt[PTS * ZP];
+    __shared__ float dsh[PTS], ivs[PTS];
+    const int b = blockIdx.y, c = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e_lo = lane & 15, slot = lane >> 4;
+    for (int i = tid; i < PTS * ZP; i += 256) zt[i] = 0.f;
+
+    float cn[8];
+    load_counts(cntp, b, S, cn);
+    const float up = upstream ? upstream[0] : 1.0f;
+
+    // B fragments: lane (slot, e_lo) holds M[kt*4 + slot][ft*16 + e_lo]
+    float bm[KT][NT];
+    {
+        const float* G = mats + (long)b * (E * E + E * S);
+        const float* A = G + E * E;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int ft = 0; ft < NT; ++ft) {
+                const int k = kt * 4 + slot, f = ft * 16 + e_lo;
+                float v = 0.f;
+                if (f < E) {
+                    if (k < E) v = G[k * E + f];
+                    else if (k < E + S) v = -A[f * S + (k - E)];
+                }
+                bm[kt][ft] = v;
+            }
+    }
+
+    const long p_begin = (long)c * UCHUNK, p_end = min(TF, p_begin + UCHUNK);
+    const float* Ub = U + (long)b * TF * E;
+    const float* Yb = Y + (long)b * TF * S;
+    const float* ib = inv + (long)b * TF;
+    float* dUb = dU + (long)b * TF * E;
+    const bool vec = (E % 4 == 0) && (((uintptr_t)U & 15) == 0) && (((uintptr_t)dU & 15) == 0);
+    const int nvec = PTS * E / 4;
+
+    float4 pre[NV];
+    float yv[8];
+    float ivp = 0.f;
+    auto fetch = [&](long p0) {
+        const int npts = (int)min((long)PTS, p_end - p0);
+        if (vec) {
+            const float4* src = reinterpret_cast<const float4*>(Ub + p0 * E);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i4 = tid + 256 * j;
+                pre[j] = (i4 < nvec && i4 * 4 < npts * E) ? src[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        } else {
+            const float* src = Ub + p0 * E;
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                float t[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = tid + 256 * (4 * j + q);
+                    t[q] = (i < npts * E) ? src[i] : 0.f;
+                }
+                pre[j] = make_float4(t[0], t[1], t[2], t[3]);
+            }
+        }
+        if (tid < PTS) {
+#pragma unroll
+            for (int s = 0; s < 8; ++s) yv[s] = (s < S && tid < npts) ? Yb[(p0 + tid) * S + s] : 0.f;
+            ivp = (tid < npts) ? ib[p0 + tid] : 0.f;
+        }
+    };
+
+    if (p_begin < p_end) fetch(p_begin);
+    for (long p0 = p_begin; p0 < p_end; p0 += PTS) {
+        const int npts = (int)min((long)PTS, p_end - p0);
+        __syncthreads();                            // write-out of the previous slab is done with zt
+        if (vec) {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i4 = tid + 256 * j;
+                if (i4 < nvec) {
+                    const int pnt = (i4 * 4) / E, e = i4 * 4 - pnt * E;
+                    *reinterpret_cast<float4*>(&zt[pnt * ZP + e]) = pre[j];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const float t[4] = {pre[j].x, pre[j].y, pre[j].z, pre[j].w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int i = tid + 256 * (4 * j + q);
+                    if (i < PTS * E) zt[(i / E) * ZP + (i % E)] = t[q];
+                }
+            }
+        }
+        if (tid < PTS) {
+            float diag = 0.f;
+#pragma unroll
+            for (int s = 0; s < 8; ++s)
+                if (s < S) { zt[tid * ZP + E + s] = yv[s]; diag += yv[s] * cn[s]; }
+            dsh[tid] = (tid < npts && diag > 0.f) ? up / sqrtf(diag) : 0.f;     // all-zero Y row contributes nothing
+            ivs[tid] = ivp;
+        }
+        __syncthreads();
+        if (p0 + PTS < p_end) fetch(p0 + PTS);
+
+#pragma unroll 1
+        for (int gi = 0; gi < PTS / 64; ++gi) {
+            const int pb = wave * (PTS / 4) + gi * 16;
+            const float iv_a = ivs[pb + e_lo];
+            f32x4 acc[NT];
+#pragma unroll
+            for (int ft = 0; ft < NT; ++ft) acc[ft] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            const float* arow = &zt[(pb + e_lo) * ZP + slot];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) {
+                float a = arow[kt * 4];
+                a = (kt * 4 + slot < E) ? a * iv_a : a;
+#pragma unroll
+                for (int ft = 0; ft < NT; ++ft) acc[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bm[kt][ft], acc[ft], 0, 0, 0);
+            }
+            // accumulator layout: point = pb + slot*4 + r, column f = ft*16 + e_lo
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int pnt = pb + slot * 4 + r;
+                const float d = dsh[pnt], iv = ivs[pnt];
+                float vv[NT], dd[NT], dot = 0.f;
+#pragma unroll
+                for (int ft = 0; ft < NT; ++ft) {
+                    const int f = ft * 16 + e_lo;
+                    vv[ft] = (f < E) ? zt[pnt * ZP + f] * iv : 0.f;
+                    dd[ft] = acc[ft][r] * d;
+                    dot += vv[ft] * dd[ft];
+                }
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) dot += __shfl_xor(dot, o, 16);
+                const bool active = iv < 0.999999e6f;
+#pragma unroll
+                for (int ft = 0; ft < NT; ++ft) {
+                    const int f = ft * 16 + e_lo;
+                    if (f < E) zt[pnt * ZP + f] = active ? (dd[ft] - vv[ft] * dot) * iv : dd[ft] * iv;
+                }
+            }
+        }
+        __syncthreads();
+        if (vec) {
+            float4* dst = reinterpret_cast<float4*>(dUb + p0 * E);
+#pragma unroll
+            for (int j = 0; j < NV; ++j) {
+                const int i4 = tid + 256 * j;
+                if (i4 < nvec && i4 * 4 < npts * E) {
+                    const int pnt = (i4 * 4) / E, e = i4 * 4 - pnt * E;
+                    dst[i4] = *reinterpret_cast<const float4*>(&zt[pnt * ZP + e]);
+                }
+            }
+        } else {
+            float* dst = dUb + p0 * E;
+            for (int i = tid; i < npts * E; i += 256) dst[i] = zt[(i / E) * ZP + (i % E)];
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -522,10 +700,13 @@ ams_status ams_dpcl_loss_fwd_u(const float* U, const float* Y, float* inv, float
     hipLaunchKernelGGL(dpcl_count_part_kernel, dim3(CP, B), dim3(256), 0, st, Y, cntp, TF, S);
     dim3 grid(nchunk, B);
     switch (NT) {
-        case 1: hipLaunchKernelGGL((dpcl_gram_u_kernel<1>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
-        case 2: hipLaunchKernelGGL((dpcl_gram_u_kernel<2>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
-        case 3: hipLaunchKernelGGL((dpcl_gram_u_kernel<3>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
-        default: hipLaunchKernelGGL((dpcl_gram_u_kernel<4>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
+        case 1: hipLaunchKernelGGL((dpcl_gram_u_kernel<1, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
+        case 2: hipLaunchKernelGGL((dpcl_gram_u_kernel<2, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
+        case 3:
+            if (E == 40) hipLaunchKernelGGL((dpcl_gram_u_kernel<3, 40>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk);
+            else hipLaunchKernelGGL((dpcl_gram_u_kernel<3, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk);
+            break;
+        default: hipLaunchKernelGGL((dpcl_gram_u_kernel<4, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
     }
     hipLaunchKernelGGL(dpcl_finish_kernel, dim3(B), dim3(256), Z * Z * sizeof(float), st, part, per_utt, mats, E, S, Z, nchunk, B);
     hipLaunchKernelGGL(dpcl_mean_kernel, dim3(1), dim3(64), 0, st, per_utt, out, B);
@@ -539,20 +720,18 @@ ams_status ams_dpcl_loss_bwd_u(const float* U, const float* Y, const float* inv,
     hipStream_t st = (hipStream_t)stream;
     const float* cntp = (const float*)ws;
     const float* mats = cntp + (size_t)B * CP * S + (size_t)B * 4;
-    dim3 grid(ceil_div(TF, 256), B);
-#define AMS_DPCL_BWD_U(EE) \
-    hipLaunchKernelGGL((dpcl_bwd_kernel<EE, true>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, S, 1)
-    switch (E) {
-        case 40: AMS_DPCL_BWD_U(40); break;
-        case 32: AMS_DPCL_BWD_U(32); break;
-        case 20: AMS_DPCL_BWD_U(20); break;
-        case 16: AMS_DPCL_BWD_U(16); break;
-        case 8: AMS_DPCL_BWD_U(8); break;
-        case 4: AMS_DPCL_BWD_U(4); break;
-        case 3: AMS_DPCL_BWD_U(3); break;
-        default: return AMS_E_INVALID_ARG;
+    const int NT = ceil_div(E + S, 16);
+    if (E + S > 64) return AMS_E_INVALID_ARG;
+    dim3 grid(ceil_div(TF, UCHUNK), B);
+    switch (NT) {
+        case 1: hipLaunchKernelGGL((dpcl_bwd_u_kernel<1, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S); break;
+        case 2: hipLaunchKernelGGL((dpcl_bwd_u_kernel<2, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S); break;
+        case 3:
+            if (E == 40) hipLaunchKernelGGL((dpcl_bwd_u_kernel<3, 40>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S);
+            else hipLaunchKernelGGL((dpcl_bwd_u_kernel<3, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S);
+            break;
+        default: hipLaunchKernelGGL((dpcl_bwd_u_kernel<4, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S); break;
     }
-#undef AMS_DPCL_BWD_U
     return ams_check_launch();
 }
 

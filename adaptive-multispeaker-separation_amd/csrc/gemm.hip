@@ -357,6 +357,14 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st) {
     // Occupancy cap for launches that are meant to run BESIDE latency-critical kernels (weight-gradient products on
     // the side stream): unused dynamic LDS limits how many of these workgroups a CU admits, leaving registers/slots
     // for the recurrent step kernels.  Thread-local, set through ams_gemm_set_lds_pad().
+    if (t_gemm_lds_pad > 40 * 1024) {               // beyond the default 64 KB static+dynamic limit
+        static thread_local int raised = 0;
+        if (raised < t_gemm_lds_pad) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<AMODE, BMODE, 0>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, t_gemm_lds_pad);
+            raised = t_gemm_lds_pad;
+        }
+    }
     hipLaunchKernelGGL((gemm_f32_kernel<AMODE, BMODE>), grid, dim3(256), (size_t)t_gemm_lds_pad, st, g);
     ams_status s = ams_check_launch();
     if (s != AMS_OK) return s;
