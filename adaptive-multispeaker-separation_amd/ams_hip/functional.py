@@ -108,8 +108,14 @@ class BLSTMLayer(Function):
             if _ORDER >= 2 and need_dx:
                 dx = ops.blstm_bwd_dx(G, Kf, Kb, B, T, D)
             s = OVERLAP.fork(x, out, G)
+            if not need_dx:
+                # first layer: no recurrence follows -- both streams work on the weight gradients, uncapped
+                with torch.cuda.stream(s):
+                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u')
+                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx')
+                return None, None, None, None, None
             with torch.cuda.stream(s):
-                OVERLAP.cap(need_dx)               # first layer: no recurrence follows, let the products fill the chip
+                OVERLAP.cap(True)
                 ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True)
                 OVERLAP.cap(False)
             if dx is None and need_dx:

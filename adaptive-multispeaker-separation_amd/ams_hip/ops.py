@@ -278,9 +278,11 @@ def blstm_bwd_dx(G, Kf, Kb, B, T, D):
     return dx
 
 
-def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate):
+def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate, part='all'):
     """Weight gradients of one BLSTM layer from dZ (= G after blstm_bwd_recurrent), written (or accumulated) into the given
-    buffers: dWx = x^T dZ, dU = h_prev^T dZ (time-shifted, masked at sequence boundaries), db = column sums."""
+    buffers: dWx = x^T dZ, dU = h_prev^T dZ (time-shifted, masked at sequence boundaries), db = column sums.
+    part: 'all' | 'wx' (input kernels + biases) | 'u' (recurrent kernels) -- the two halves are independent and may be
+    issued on different streams."""
     lib = load()
     B, T, D = x.shape
     H = dKf.shape[1] // 4
@@ -289,38 +291,38 @@ def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate):
     dZf = G.view(-1)                       # direction 0 columns start at 0, ld = 8H
     dZb = G.view(-1)[4 * H:]
     acc = bool(accumulate)
-    # dWx of both directions in one product x^T . dZ -> [D, 8H], then scattered into the two TF-layout kernels
     _chk_rows(dKf, dKb)
-    ldk = dKf.stride(0)
-    if _twin(dKf, dKb):
-        # twin-interleaved gradient block: [dWx_f | dWx_b] IS a row-major [D, 8H] matrix -> written in place
-        gemm(x2, dZf, transA=True, M=D, N=8 * H, K=M, lda=D, ldb=8 * H, ldc=8 * H, accumulate=acc,
-             out=torch.as_strided(dKf, (D, 8 * H), (8 * H, 1)))
-    else:
-        dWcat = gemm(x2, dZf, transA=True, M=D, N=8 * H, K=M, lda=D, ldb=8 * H, ldc=8 * H,
-                     out=torch.empty((D, 8 * H), dtype=torch.float32, device=x.device))
-        if acc:
-            dKf[:D].add_(dWcat[:, :4 * H])
-            dKb[:D].add_(dWcat[:, 4 * H:])
+    if part in ('all', 'wx'):
+        if _twin(dKf, dKb):
+            # twin-interleaved gradient block: [dWx_f | dWx_b] IS a row-major [D, 8H] matrix -> written in place
+            gemm(x2, dZf, transA=True, M=D, N=8 * H, K=M, lda=D, ldb=8 * H, ldc=8 * H, accumulate=acc,
+                 out=torch.as_strided(dKf, (D, 8 * H), (8 * H, 1)))
         else:
-            dKf[:D].copy_(dWcat[:, :4 * H])
-            dKb[:D].copy_(dWcat[:, 4 * H:])
-    # forward dir pairs out[b,t-1] with dZ[b,t]; backward dir pairs out[b,t+1] with dZ[b,t]
-    of = out.view(-1)
-    gemm(of, dZf[8 * H:], transA=True, out=dKf[D:], accumulate=acc, M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H, ldc=ldk,
-         mask=(T, T - 1))
-    gemm(of[2 * H + H:], dZb, transA=True, out=dKb[D:], accumulate=acc, M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H,
-         ldc=dKb.stride(0), mask=(T, T - 1))
-    if _twin(dbf, dbb):                    # adjacent bias gradients: one column-sum over all 8H columns of dZ
-        nb = lib.ams_colsum_workspace_bytes(M, 8 * H)
-        ws = _ws(nb, x)
-        check(lib.ams_colsum(_p(dZf), _p(dbf), M, 8 * H, 8 * H, int(acc), _p(ws), nb, _s()), 'ams_colsum')
-    else:
-        nb = lib.ams_colsum_workspace_bytes(M, 4 * H)
-        ws = _ws(nb, x)
-        check(lib.ams_colsum(_p(dZf), _p(dbf), M, 4 * H, 8 * H, int(acc), _p(ws), nb, _s()), 'ams_colsum')
-        ws2 = _ws(nb, x)
-        check(lib.ams_colsum(_p(dZb), _p(dbb), M, 4 * H, 8 * H, int(acc), _p(ws2), nb, _s()), 'ams_colsum')
+            dWcat = gemm(x2, dZf, transA=True, M=D, N=8 * H, K=M, lda=D, ldb=8 * H, ldc=8 * H,
+                         out=torch.empty((D, 8 * H), dtype=torch.float32, device=x.device))
+            if acc:
+                dKf[:D].add_(dWcat[:, :4 * H])
+                dKb[:D].add_(dWcat[:, 4 * H:])
+            else:
+                dKf[:D].copy_(dWcat[:, :4 * H])
+                dKb[:D].copy_(dWcat[:, 4 * H:])
+        if _twin(dbf, dbb):                    # adjacent bias gradients: one column-sum over all 8H columns of dZ
+            nb = lib.ams_colsum_workspace_bytes(M, 8 * H)
+            ws = _ws(nb, x)
+            check(lib.ams_colsum(_p(dZf), _p(dbf), M, 8 * H, 8 * H, int(acc), _p(ws), nb, _s()), 'ams_colsum')
+        else:
+            nb = lib.ams_colsum_workspace_bytes(M, 4 * H)
+            ws = _ws(nb, x)
+            check(lib.ams_colsum(_p(dZf), _p(dbf), M, 4 * H, 8 * H, int(acc), _p(ws), nb, _s()), 'ams_colsum')
+            ws2 = _ws(nb, x)
+            check(lib.ams_colsum(_p(dZb), _p(dbb), M, 4 * H, 8 * H, int(acc), _p(ws2), nb, _s()), 'ams_colsum')
+    if part in ('all', 'u'):
+        # forward dir pairs out[b,t-1] with dZ[b,t]; backward dir pairs out[b,t+1] with dZ[b,t]
+        of = out.view(-1)
+        gemm(of, dZf[8 * H:], transA=True, out=dKf[D:], accumulate=acc, M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H,
+             ldc=dKf.stride(0), mask=(T, T - 1))
+        gemm(of[2 * H + H:], dZb, transA=True, out=dKb[D:], accumulate=acc, M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H,
+             ldc=dKb.stride(0), mask=(T, T - 1))
 
 
 def blstm_bwd(x, Kf, Kb, out, G, cst, dout, need_dx=True):
