@@ -41,6 +41,7 @@ struct GemmArgs {
     int accumulate;            // C += result
     // frames loader
     int fr_L, fr_T, fr_hop, fr_pl, fr_W;
+    int group_m;                  // tile rows per band of the XCD-aware tile order
     // A_COL row mask: element (m, k) is zero when (k % mask_period) == mask_skip  (period 0 = off)
     int mask_period, mask_skip;
     // split-K
@@ -98,8 +99,11 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // XCD-aware tile order: consecutive block ids land on different XCDs (b % 8); give each XCD a
-    // contiguous run of tiles that share A row-panels so its private L2 sees the reuse.
+    // XCD-aware tile order: consecutive block ids land on different XCDs (b % 8); give each XCD a contiguous run of a
+    // BANDED order (bands of group_m tile rows, walked column by column) so the ~32-64 tiles an XCD has in flight
+    // form a near-square patch: they share group_m A row-panels and a few B column-panels in that XCD's private 4 MB L2.
+    // Row-major runs re-fetched every B panel once per tile row: 971 MB of fabric reads for the 5120x10240x600 dense
+    // product whose operands are 37 MB (rocprofv3 FETCH_SIZE, profiles/r01_c_hbm_traffic.txt).
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     const int ntiles = tiles_m * tiles_n;
     int bid = blockIdx.x;
@@ -107,7 +111,11 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
         const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_m = bid / tiles_n, tile_n = bid % tiles_n;
+    const int GROUP_M = g.group_m > 0 ? g.group_m : 1;        // chosen per launch (choose_group_m)
+    const int band = bid / (GROUP_M * tiles_n), within = bid - band * (GROUP_M * tiles_n);
+    const int band_rows = min(GROUP_M, tiles_m - band * GROUP_M);
+    const int tile_n = within / band_rows;
+    const int tile_m = band * GROUP_M + (within - tile_n * band_rows);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int split = blockIdx.y;
@@ -338,9 +346,24 @@ inline int choose_splits(int M, int N, int K) {
     return best;
 }
 
+// Band height of the tile order: the patch of tiles one XCD works on at a time (its share of the grid, at most ~64 in
+// flight) should be as square as the tile grid allows, so every operand panel is fetched by as few XCDs as possible.
+inline int choose_group_m(int tiles_m, int tiles_n) {
+    int c = ceil_div((long)tiles_m * tiles_n, 8);
+    if (c > 64) c = 64;
+    int gm = (int)(sqrt((double)c) + 0.5);
+    if (gm < 1) gm = 1;
+    if (gm > tiles_m) gm = tiles_m;
+    if (ceil_div(c, gm) > tiles_n) gm = ceil_div(c, tiles_n);
+    if (gm > tiles_m) gm = tiles_m;
+    if (const char* f = getenv("AMS_GEMM_GROUP_M")) { const int v = atoi(f); if (v > 0) gm = v; }   // tuning aid
+    return gm;
+}
+
 template <int AMODE, int BMODE>
 ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st) {
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
+    g.group_m = choose_group_m(ceil_div(g.M, BM), ceil_div(g.N, BN));
     int splits = 1;
     if (ws) {
         splits = choose_splits(g.M, g.N, g.K);

@@ -171,6 +171,19 @@ def main():
                 'measured': ('HIP events around each launch, %d eager steps after the graph-replayed timed region' % prof_steps)
                 if args.graph else 'HIP events around each launch inside the timed region',
                 'by_variant': {}}
+        # HBM traffic of the same kernels: rocprofv3 PMC passes cannot run inside this process, so the per-launch figure
+        # comes from the committed summary of `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this very workload
+        # (tools/pmc_summary.py; gfx950 x2 read correction applied there).  null for any other shape.
+        tpath = os.path.join(ROOT, 'profiles', 'r01_c_hbm_traffic.json')
+        if os.path.exists(tpath) and (B, L, N) == (64, 20480, 256):
+            tj = json.load(open(tpath))
+            gk = [v for k, v in tj.items() if k.startswith('gemm_f32_kernel')]
+            calls = sum(v['calls'] for v in gk)
+            if calls:
+                mb = sum(v['calls'] * (v['read_MB_per_launch'] + v['write_MB_per_launch']) for v in gk) / calls
+                roof['traffic'] = round(mb * 1e6)
+                roof['traffic_unit'] = 'bytes per launch (memory-side L2 requests, profiles/r01_c_hbm_traffic.txt)'
+                roof['algorithmic_bytes_per_launch'] = round(prof['bytes'] / prof['launches'])
         for tag in ops.PROFILE.tags():
             pv = ops.PROFILE.summary(tag)
             if pv['launches']:

@@ -1,0 +1,52 @@
+"""Per-kernel HBM traffic from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE; separate runs of the same command).
+
+usage: python tools/pmc_summary.py <fetch_results.db> <write_results.db> <out.txt> [<out.json>] ["command description"]
+
+Units/corrections (MI355X_MICROARCH.md, HBM section): both counters are KILOBYTES per dispatch; on gfx950 FETCH_SIZE tallies
+the 128-byte fabric requests of wide coalesced reads at 64 B, so it is DOUBLED here; WRITE_SIZE is taken as reported
+(uncalibrated).  Infinity-Cache hits are counted, so 'traffic' is memory-side L2 traffic, an upper bound on DRAM bytes.
+"""
+import json
+import sqlite3
+import sys
+
+
+def per_kernel(path, counter):
+    db = sqlite3.connect(path)
+    rows = db.execute("select kernel_name, grid_size_x, grid_size_y, value from counters_collection where counter_name=?",
+                      (counter,)).fetchall()
+    out = {}
+    for name, gx, gy, v in rows:
+        out.setdefault(name, []).append(float(v))
+    return out
+
+
+def short(n):
+    n = n.replace('(anonymous namespace)::', '').replace('void ', '')
+    return n.split('(')[0][:70]
+
+
+def main():
+    f = per_kernel(sys.argv[1], 'FETCH_SIZE')
+    w = per_kernel(sys.argv[2], 'WRITE_SIZE')
+    desc = sys.argv[5] if len(sys.argv) > 5 else ''
+    names = sorted(set(f) | set(w), key=lambda n: -(2 * sum(f.get(n, [0])) + sum(w.get(n, [0]))))
+    lines = ['# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only); MB per launch',
+             '# read = 2 x FETCH_SIZE (gfx950 correction), write = WRITE_SIZE as reported; ' + desc,
+             '%-72s %7s %12s %12s %12s' % ('kernel', 'calls', 'read_MB', 'write_MB', 'total_MB')]
+    js = {}
+    for n in names:
+        fv, wv = f.get(n, []), w.get(n, [])
+        calls = max(len(fv), len(wv))
+        rd = 2.0 * sum(fv) / max(1, len(fv)) * 1024 / 1e6
+        wr = sum(wv) / max(1, len(wv)) * 1024 / 1e6
+        lines.append('%-72s %7d %12.3f %12.3f %12.3f' % (short(n), calls, rd, wr, rd + wr))
+        js[short(n)] = {'calls': calls, 'read_MB_per_launch': round(rd, 4), 'write_MB_per_launch': round(wr, 4)}
+    open(sys.argv[3], 'w').write('\n'.join(lines) + '\n')
+    if len(sys.argv) > 4 and sys.argv[4]:
+        json.dump(js, open(sys.argv[4], 'w'), indent=1, sort_keys=True)
+    print('\n'.join(lines[:24]))
+
+
+if __name__ == '__main__':
+    main()
