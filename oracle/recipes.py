@@ -73,17 +73,13 @@ def front_finetune_cost(x_mix, x_non_mix, P, hop, nb_layers, E, init_idx, nb_tri
     return loss, out
 
 
-def front_enhance_loss(x_mix, x_non_mix, P, hop, nb_layers, E, nb_layers_enh, init_idx, nb_tries, nb_steps, nonlinearity='softmax',
-                       end_assign=True, want_grads=True):
-    """Front_Separator_Enhance_Trainer objective (trainer.py:621-630, adapt.py:457-469): frozen front + DPCL + hard k-means masks ->
-    enhance BLSTM stack (network.py:610-660) -> PIT squared error against the signed non-mix representation (network.py:662-693).
-    Gradients for the 'enhance/*' variables only."""
+def _enhance_loss_core(X, X_nm, P, nb_layers, E, nb_layers_enh, init_idx, nb_tries, nb_steps, nonlinearity, end_assign, want_grads):
+    """Shared tail of the *_enhance trainers: DPCL embeddings -> hard k-means masks -> enhance BLSTM stack (network.py:610-660) ->
+    PIT squared error against the non-mix representation (network.py:662-693).  Gradients for the 'enhance/*' variables only."""
     from . import blstm, dense
-    B, S, L = x_non_mix.shape
-    y = step.front_rep(x_mix, x_non_mix, P, hop)
-    X, X_nm = separate.split_front(y, B, S)
+    B, T, Fq = X.shape
+    S = X_nm.shape[-1]
     V, _ = step.prediction_fwd(X, P, nb_layers, E)
-    T, Fq = X.shape[1:]
     cent, labels, best = kmeans.kmeans(V.reshape(B, T * Fq, E), init_idx, S, nb_tries, nb_steps, assign_at_end=end_assign)
     masks = kmeans.masks_from_labels(labels, S, None).astype(X.dtype)
     sep = separate.apply_masks(X, masks)                                    # [B*S, T, F]
@@ -100,7 +96,6 @@ def front_enhance_loss(x_mix, x_non_mix, P, hop, nb_layers, E, nb_layers_enh, in
     d_cost_in = d_est.transpose(0, 2, 1)                                    # [B,TF,S]
     dy = d_cost_in * X.reshape(B, T * Fq, 1)
     if nonlinearity == 'softmax':
-        yv = cost_in / np.where(X.reshape(B, T * Fq, 1) == 0, 1.0, X.reshape(B, T * Fq, 1))
         ylog = u.reshape(B, S, T * Fq).transpose(0, 2, 1)
         e = np.exp(ylog - ylog.max(axis=2, keepdims=True))
         sm = e / e.sum(axis=2, keepdims=True)
@@ -118,6 +113,111 @@ def front_enhance_loss(x_mix, x_non_mix, P, hop, nb_layers, E, nb_layers_enh, in
         for n, v in zip(step.lstm_names('enhance', i), g):
             grads[n] = v
     return cost, grads
+
+
+def front_enhance_loss(x_mix, x_non_mix, P, hop, nb_layers, E, nb_layers_enh, init_idx, nb_tries, nb_steps, nonlinearity='softmax',
+                       end_assign=True, want_grads=True):
+    """Front_Separator_Enhance_Trainer objective (trainer.py:621-630, adapt.py:457-469): frozen front + DPCL + hard k-means masks ->
+    enhance stack -> PIT squared error against the signed non-mix representation."""
+    B, S, L = x_non_mix.shape
+    y = step.front_rep(x_mix, x_non_mix, P, hop)
+    X, X_nm = separate.split_front(y, B, S)
+    return _enhance_loss_core(X, X_nm, P, nb_layers, E, nb_layers_enh, init_idx, nb_tries, nb_steps, nonlinearity, end_assign, want_grads)
+
+
+def stft_enhance_loss(x_mix, x_non_mix, P, W, hop, nb_layers, E, nb_layers_enh, init_idx, nb_tries, nb_steps, nonlinearity='softmax',
+                      end_assign=True, want_grads=True):
+    """STFT_Separator_enhance_Trainer objective (trainer.py:497-509 -> network.py:505-693): |STFT| -> DPCL -> hard k-means
+    masks -> enhance stack -> PIT squared error against the non-mix magnitudes."""
+    X, X_nm, _ = stft.stft_preprocessing(x_mix, x_non_mix, W, hop)
+    return _enhance_loss_core(X, X_nm, P, nb_layers, E, nb_layers_enh, init_idx, nb_tries, nb_steps, nonlinearity, end_assign, want_grads)
+
+
+def _enhance_forward(X, sep, P, S, nb_layers_enh, nonlinearity):
+    from . import blstm, dense
+    z = separate.enhance_input(sep, X, S, False)
+    h, _ = blstm.blstm_stack_fwd(z, step.stack_params(P, 'enhance', nb_layers_enh))
+    u = dense.dense_fwd(h, P['enhance/W'], P['enhance/b'])
+    return separate.enhance_output(u, X, S, nonlinearity)                   # cost_in [B,TF,S], out [B*S,T,F]
+
+
+def stft_finetune_cost(x_mix, x_non_mix, P, W, hop, nb_layers, E, nb_layers_enh, init_idx, nb_tries, nb_steps, beta,
+                       nonlinearity='softmax', end_assign=True):
+    """STFT_Separator_FineTune_Trainer objective (trainer.py:511-536 -> network.py:505-607,697-725), forward only: |STFT| -> DPCL
+    -> SOFT k-means masks -> enhance stack -> iSTFT with the mixture phase -> PIT 0.5*L2^2 on waveforms."""
+    B, S, L = x_non_mix.shape
+    X, _, ang = stft.stft_preprocessing(x_mix, x_non_mix, W, hop)
+    V, _ = step.prediction_fwd(X, P, nb_layers, E)
+    T, Fq = X.shape[1:]
+    cent, labels, best = kmeans.kmeans(V.reshape(B, T * Fq, E), init_idx, S, nb_tries, nb_steps, beta=beta, assign_at_end=end_assign)
+    masks = kmeans.masks_from_labels(labels, S, beta).astype(X.dtype)
+    sep = separate.apply_masks(X, masks)
+    _, out = _enhance_forward(X, sep, P, S, nb_layers_enh, nonlinearity)
+    wav = stft.istft(out, np.repeat(ang, S, axis=0), W, hop).reshape(B, S, -1)
+    return losses.cost_finetuning(x_non_mix, wav)[0], wav
+
+
+def front_enhance_finetune_cost(x_mix, x_non_mix, P, hop, nb_layers, E, nb_layers_enh, init_idx, nb_tries, nb_steps, beta, with_silence,
+                                threshold, end_assign, nonlinearity='softmax'):
+    """Front_Separator_Enhance_Finetuning_Trainer objective (trainer.py:632-658 -> adapt.py:206-246,404-431), forward only: frozen
+    front -> DPCL -> SOFT k-means masks -> enhance stack -> back end -> PIT 0.5*L2^2 on waveforms (Adapt.cost_finetuning, NOT the
+    sdr+l2 Adapt.cost the plain finetuning trainer uses)."""
+    B, S, L = x_non_mix.shape
+    y = step.front_rep(x_mix, x_non_mix, P, hop)
+    X, _ = separate.split_front(y, B, S)
+    V, _ = step.prediction_fwd(X, P, nb_layers, E)
+    T, Fq = X.shape[1:]
+    w = separate.kmeans_silence_weights(np.abs(X), threshold) if with_silence else None
+    cent, labels, best = kmeans.kmeans(V.reshape(B, T * Fq, E), init_idx, S, nb_tries, nb_steps, beta=beta, notsilent=w,
+                                       assign_at_end=end_assign)
+    masks = kmeans.masks_from_labels(labels, S, beta).astype(X.dtype)
+    sep = separate.apply_masks(X, masks)
+    _, out = _enhance_forward(X, sep, P, S, nb_layers_enh, nonlinearity)
+    f2 = front.front_filter(P['back/window/value'], P['back/bases/value'])
+    back = front.synth_strided(out, f2, hop, L).reshape(B, S, L)
+    return losses.cost_finetuning(x_non_mix, back)[0], back
+
+
+def front_separate_enhanced_infer(x_mix, x_non_mix, P, hop, nb_layers, E, nb_layers_enh, init_idx, nb_tries, nb_steps, beta=None,
+                                  with_silence=False, threshold=2.0, end_assign=True, nonlinearity='softmax'):
+    """Front_Separator_Enhanced_Inference (trainer.py:436-449): front -> DPCL -> k-means masks -> enhance stack -> back."""
+    B, S, L = x_non_mix.shape
+    y = step.front_rep(x_mix, x_non_mix, P, hop)
+    X, _ = separate.split_front(y, B, S)
+    V, _ = step.prediction_fwd(X, P, nb_layers, E)
+    T, Fq = X.shape[1:]
+    w = separate.kmeans_silence_weights(np.abs(X), threshold) if with_silence else None
+    cent, labels, best = kmeans.kmeans(V.reshape(B, T * Fq, E), init_idx, S, nb_tries, nb_steps, beta=beta, notsilent=w,
+                                       assign_at_end=end_assign)
+    masks = kmeans.masks_from_labels(labels, S, beta).astype(X.dtype)
+    sep = separate.apply_masks(X, masks)
+    _, out = _enhance_forward(X, sep, P, S, nb_layers_enh, nonlinearity)
+    f2 = front.front_filter(P['back/window/value'], P['back/bases/value'])
+    return front.synth_strided(out, f2, hop, L).reshape(B, S, L)
+
+
+def stft_separate_enhanced_infer(x_mix, x_non_mix, P, W, hop, nb_layers, E, nb_layers_enh, init_idx, nb_tries, nb_steps,
+                                 end_assign=True, nonlinearity='softmax'):
+    """STFT_Separator_Enhanced_Inference (trainer.py:390-404): |STFT| -> DPCL -> hard k-means -> enhance stack -> iSTFT."""
+    B, S, L = x_non_mix.shape
+    X, _, ang = stft.stft_preprocessing(x_mix, x_non_mix, W, hop)
+    V, _ = step.prediction_fwd(X, P, nb_layers, E)
+    T, Fq = X.shape[1:]
+    cent, labels, best = kmeans.kmeans(V.reshape(B, T * Fq, E), init_idx, S, nb_tries, nb_steps, assign_at_end=end_assign)
+    masks = kmeans.masks_from_labels(labels, S, None).astype(X.dtype)
+    sep = separate.apply_masks(X, masks)
+    _, out = _enhance_forward(X, sep, P, S, nb_layers_enh, nonlinearity)
+    return stft.istft(out, np.repeat(ang, S, axis=0), W, hop).reshape(B, S, -1)
+
+
+def pretrained_infer(x_mix, x_non_mix, P, hop, separation='mask'):
+    """Pretrained_Inference (trainer.py:451-462): the pre-trained filterbank alone -- front -> oracle 'mask'/'perfect'
+    separator (adapt.py:162-196) -> back."""
+    B, S, L = x_non_mix.shape
+    y = step.front_rep(x_mix, x_non_mix, P, hop)
+    sep = front.pretrain_separator(y, B, S, separation)
+    f2 = front.front_filter(P['back/window/value'], P['back/bases/value'])
+    return front.synth_strided(sep, f2, hop, L).reshape(B, S, L)
 
 
 def pretrain_loss_maxpool(x_mix, x_non_mix, P, Pool, hop, loss_kind, separation, want_grads=True):

@@ -130,3 +130,22 @@ def init_params(rng, dtype, front_W=None, N=None, D_in=None, layer_size=600, nb_
         v = rng.standard_normal((tot_speakers, E)) * sd
         P['speaker_centroids'] = np.clip(v, -2 * sd, 2 * sd).astype(dtype)
     return P
+
+
+def init_enhance_params(rng, dtype, F, layer_size_enh, nb_layers_enh, scale=0.5):
+    """Random 'enhance/*' variables with the shapes network.py:629-636 builds: BLSTM stack on [sep | X] (2F inputs) and a
+    width-1 Conv1D back to F."""
+    P = {}
+    H = layer_size_enh // 2
+    d = 2 * F
+    for i in range(nb_layers_enh):
+        lim = np.sqrt(6.0 / (d + H + 4 * H))
+        kf, bf, kb, bb = lstm_names('enhance', i)
+        P[kf] = rng.uniform(-lim, lim, (d + H, 4 * H)).astype(dtype)
+        P[bf] = np.zeros(4 * H, dtype)
+        P[kb] = rng.uniform(-lim, lim, (d + H, 4 * H)).astype(dtype)
+        P[bb] = np.zeros(4 * H, dtype)
+        d = layer_size_enh
+    P['enhance/W'] = rng.uniform(-scale, scale, (layer_size_enh, F)).astype(dtype)
+    P['enhance/b'] = np.zeros(F, dtype)
+    return P

@@ -47,9 +47,12 @@ def check_step(cost, c_ref, grads, g_ref, P, P_new, opt, tol=2e-4):
         errs['grad ' + n] = float(np.abs(grads[n] - g_ref[n]).max() / max(np.abs(g_ref[n]).max(), 1e-2 * gscale))
     plist = [P[n].copy() for n in names]
     opt.apply(plist, [g_ref[n] for n in names])
+    pscale = max(float(np.abs(p).max()) for p in plist)
     for n, p in zip(names, plist):
-        errs['update ' + n] = float(np.abs(P_new[n] - p).max() / max(np.abs(p).max(), 1e-4))
-    assert max(errs.values()) < tol, errs
+        # zero-initialised biases with an analytically-zero gradient (AMSGrad normalises rounding noise): same floor idea
+        errs['update ' + n] = float(np.abs(P_new[n] - p).max() / max(np.abs(p).max(), 1e-2 * pscale))
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    assert worst[0][1] < tol, worst
 
 
 def base_args(**kw):
@@ -115,10 +118,12 @@ def test_front_l41_step(normalize):
     check_step(cost, c_ref, grads, g_ref, P, P_new, ooptim.AMSGrad(1e-3))
 
 
-def _full_checkpoint(tmp, rng, W, N, hop, L, B, S, LS, NL, E, Fq, D_in, front=True):
+def _full_checkpoint(tmp, rng, W, N, hop, L, B, S, LS, NL, E, Fq, D_in, front=True, enhance=None, tot_speakers=None):
     from ams_hip import testing
     P = ostep.init_params(rng, np.float32, front_W=W if front else None, N=N, D_in=D_in, layer_size=LS, nb_layers=NL, E=E, F=Fq,
-                          conv1d_scale=0.5)
+                          conv1d_scale=0.5, tot_speakers=tot_speakers)
+    if enhance is not None:                       # (layer_size_enhance, nb_layers_enhance): a checkpoint left by an *_enhance run
+        P.update(ostep.init_enhance_params(rng, np.float32, Fq, enhance[0], enhance[1]))
     params = dict(testing.ADAPT_DEFAULTS)
     if not front:
         for k in ('filters', 'max_pool'):
@@ -293,3 +298,205 @@ def test_pretraining_forward_with_average_pool():
     (oc * torch.from_numpy(dout)).sum().backward()
     assert rel(ft.grad.cpu().numpy(), fc.grad.numpy()) < 1e-4
     assert rel(f2t.grad.cpu().numpy(), f2c.grad.numpy()) < 1e-4 and rel(zt.grad.cpu().numpy(), zc.grad.numpy()) < 1e-4
+
+
+def _fd_check(cost_fn, Pg, grads, names, tol=2e-2):
+    """Central differences of the float64 oracle cost on the largest gradient entry of each named variable."""
+    for name in names:
+        g = grads[name]
+        k = np.unravel_index(np.argmax(np.abs(g)), g.shape)
+        h = 1e-5 * max(1.0, abs(Pg[name][k]))
+        Pp = {n: v.copy() for n, v in Pg.items()}
+        Pp[name][k] += h
+        cp = cost_fn(Pp)
+        Pp[name][k] -= 2 * h
+        cm = cost_fn(Pp)
+        fd = (cp - cm) / (2 * h)
+        assert abs(g[k] - fd) < tol * max(abs(fd), 1e-6), (name, g[k], fd)
+
+
+def test_stft_dpcl_enhance_step():
+    """experiments.training.STFT_DPCL_enhance: enhance stack on top of a restored STFT + DPCL + hard k-means separator."""
+    from models.dpcl import DPCL
+    from utils.trainer import STFT_Separator_enhance_Trainer
+    tmp = tempfile.mkdtemp(prefix='ams_senh_')
+    rng = np.random.RandomState(41)
+    B, S, L, W, hop, LS, NL, E, tries, steps, LSE, NLE = 2, 2, 1024, 64, 16, 12, 2, 8, 2, 3, 8, 2
+    Fq = W // 2 + 1
+    folder, params, P = _full_checkpoint(tmp, rng, W, None, hop, L, B, S, LS, NL, E, Fq, Fq, front=False)
+    T = 1 + (L - W) // hop
+    idx = np.stack([rng.choice(T * Fq, S, replace=False) for _ in range(B * tries)]).astype(np.int32)
+    a = base_args(**params)
+    a.update(model_folder=folder, nb_tries=tries, nb_steps=steps, end_assign=True, kmeans_init_indices=idx, layer_size_enhance=LSE,
+             nb_layers_enhance=NLE, nonlinearity='softmax', learning_rate=1e-3, pretraining=False)
+    a.pop('type')
+    tr = STFT_Separator_enhance_Trainer(DPCL, 'STFT_DPCL_enhance', **a)
+    dist, tfds = tr.prepare()
+    names = sorted(v.ams_name for v in tr.model.trainable_variables)
+    assert names and all(n.startswith('enhance/') for n in names)
+    Pg, cost, xm, xn, I, grads, P_new = one_train_step(tr, tfds, L)
+    c_ref, g_ref = orec.stft_enhance_loss(xm, xn, Pg, W, hop, NL, E, NLE, idx, tries, steps)
+    check_step(cost, c_ref, grads, g_ref, Pg, P_new, ooptim.AMSGrad(1e-3), tol=5e-4)
+
+
+def test_stft_dpcl_finetuning_step():
+    """experiments.training.STFT_DPCL_finetuning: |STFT| -> DPCL -> soft k-means -> enhance -> iSTFT -> PIT waveform L2; the
+    gradient reaches prediction/* through the soft masks and enhance/* directly."""
+    from models.dpcl import DPCL
+    from utils.trainer import STFT_Separator_FineTune_Trainer
+    tmp = tempfile.mkdtemp(prefix='ams_sft_')
+    rng = np.random.RandomState(43)
+    B, S, L, W, hop, LS, NL, E, tries, steps, LSE, NLE, beta = 2, 2, 1024, 64, 16, 12, 2, 8, 1, 3, 8, 1, 4.0
+    Fq = W // 2 + 1
+    folder, params, P = _full_checkpoint(tmp, rng, W, None, hop, L, B, S, LS, NL, E, Fq, Fq, front=False, enhance=(LSE, NLE))
+    T = 1 + (L - W) // hop
+    idx = np.stack([rng.choice(T * Fq, S, replace=False) for _ in range(B * tries)]).astype(np.int32)
+    a = base_args(**params)
+    a.update(model_folder=folder, nb_tries=tries, nb_steps=steps, beta_kmeans=beta, end_assign=True, kmeans_init_indices=idx,
+             layer_size_enhance=LSE, nb_layers_enhance=NLE, nonlinearity='softmax', learning_rate=1e-4, optimizer='RMSProp',
+             train=['enhance', 'prediction'], pretraining=False)
+    a.pop('type')
+    tr = STFT_Separator_FineTune_Trainer(DPCL, 'STFT_DPCL_finetuning', **a)
+    dist, tfds = tr.prepare()
+    tnames = sorted(v.ams_name for v in tr.model.trainable_variables)
+    assert any(n.startswith('enhance/') for n in tnames) and any(n.startswith('prediction/') for n in tnames)
+    Pg, cost, xm, xn, I, grads, P_new = one_train_step(tr, tfds, L)
+    cost_fn = lambda Pp: orec.stft_finetune_cost(xm, xn, Pp, W, hop, NL, E, NLE, idx, tries, steps, beta)[0]   # noqa: E731
+    c_ref = cost_fn(Pg)
+    assert abs(cost - c_ref) < 1e-3 * abs(c_ref), (cost, c_ref)
+    _fd_check(cost_fn, Pg, grads, ('enhance/W', 'prediction/W', 'prediction/forward_BLSTM_1/rnn/basic_lstm_cell/kernel'))
+
+
+def test_front_dpcl_enhance_finetuning_step():
+    """experiments.training.front_DPCL_enhance_finetuning: frozen front -> DPCL -> soft k-means -> enhance -> back -> PIT cost."""
+    from models.dpcl import DPCL
+    from utils.trainer import Front_Separator_Enhance_Finetuning_Trainer
+    tmp = tempfile.mkdtemp(prefix='ams_eft_')
+    rng = np.random.RandomState(47)
+    B, S, L, W, N, hop, LS, NL, E, tries, steps, LSE, NLE, beta = 2, 2, 1024, 64, 16, 16, 12, 2, 8, 1, 3, 8, 1, 4.0
+    folder, params, P = _full_checkpoint(tmp, rng, W, N, hop, L, B, S, LS, NL, E, N, N, enhance=(LSE, NLE))
+    T = -(-L // hop)
+    idx = np.stack([rng.choice(T * N, S, replace=False) for _ in range(B * tries)]).astype(np.int32)
+    a = base_args(**params)
+    a.update(model_folder=folder, nb_tries=tries, nb_steps=steps, beta_kmeans=beta, with_silence=True, threshold=2.0, end_assign=True,
+             kmeans_init_indices=idx, layer_size_enhance=LSE, nb_layers_enhance=NLE, nonlinearity='softmax', loss='sdr+l2',
+             optimizer='RMSProp', learning_rate=1e-4, train=['enhance', 'prediction'], pretraining=False)
+    a.pop('type')
+    tr = Front_Separator_Enhance_Finetuning_Trainer(DPCL, 'front_DPCL_enhance_finetuning', **a)
+    dist, tfds = tr.prepare()
+    tnames = sorted(v.ams_name for v in tr.model.trainable_variables)
+    assert any(n.startswith('enhance/') for n in tnames) and any(n.startswith('prediction/') for n in tnames)
+    Pg, cost, xm, xn, I, grads, P_new = one_train_step(tr, tfds, L)
+    args = (hop, NL, E, NLE, idx, tries, steps, beta, True, 2.0, True)
+    cost_fn = lambda Pp: orec.front_enhance_finetune_cost(xm, xn, Pp, *args)[0]   # noqa: E731
+    c_ref = cost_fn(Pg)
+    assert abs(cost - c_ref) < 1e-3 * abs(c_ref), (cost, c_ref)
+    _fd_check(cost_fn, Pg, grads, ('enhance/W', 'prediction/W', 'prediction/forward_BLSTM_1/rnn/basic_lstm_cell/kernel'))
+
+
+def _infer(tr, L):
+    dist, tfds = tr.prepare()
+    g, model = tr.graph, tr.model
+    with g.as_default():
+        feed = {tfds.handle: tfds.get_handle(tfds.TEST), tfds.chunk_size: L}
+        xm, xn, out = model.infer(feed, 0)
+    return xm.cpu().numpy().astype(np.float64), xn.cpu().numpy().astype(np.float64), out.cpu().numpy()
+
+
+def test_front_separator_enhanced_inference():
+    """Front_Separator_Enhanced_Inference: front -> DPCL -> k-means -> enhance stack -> back (trainer.py:436-449)."""
+    from models.dpcl import DPCL
+    from utils.trainer import Front_Separator_Enhanced_Inference
+    tmp = tempfile.mkdtemp(prefix='ams_einf_')
+    rng = np.random.RandomState(51)
+    B, S, L, W, N, hop, LS, NL, E, tries, steps, LSE, NLE = 2, 2, 2048, 64, 16, 16, 12, 2, 8, 2, 3, 8, 2
+    folder, params, P = _full_checkpoint(tmp, rng, W, N, hop, L, B, S, LS, NL, E, N, N, enhance=(LSE, NLE))
+    T = -(-L // hop)
+    idx = np.stack([rng.choice(T * N, S, replace=False) for _ in range(B * tries)]).astype(np.int32)
+    a = base_args(**params)
+    a.update(model_folder=folder, nb_tries=tries, nb_steps=steps, end_assign=True, kmeans_init_indices=idx, layer_size_enhance=LSE,
+             nb_layers_enhance=NLE, nonlinearity='softmax', out=False)
+    a.pop('type')
+    tr = Front_Separator_Enhanced_Inference(DPCL, 'front_DPCL_enhance_inference', **a)
+    xm, xn, out = _infer(tr, L)
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    out_ref = orec.front_separate_enhanced_infer(xm, xn, P64, hop, NL, E, NLE, idx, tries, steps)
+    assert out.shape == (B, S, L)
+    err = np.linalg.norm(out - out_ref) / np.linalg.norm(out_ref)
+    assert err < 2e-2, err
+
+
+def test_stft_separator_enhanced_inference():
+    """STFT_Separator_Enhanced_Inference: |STFT| -> DPCL -> hard k-means -> enhance stack -> iSTFT (trainer.py:390-404)."""
+    from models.dpcl import DPCL
+    from utils.trainer import STFT_Separator_Enhanced_Inference
+    tmp = tempfile.mkdtemp(prefix='ams_seinf_')
+    rng = np.random.RandomState(53)
+    B, S, L, W, hop, LS, NL, E, tries, steps, LSE, NLE = 2, 2, 2048, 64, 32, 12, 2, 8, 2, 3, 8, 1
+    Fq = W // 2 + 1
+    folder, params, P = _full_checkpoint(tmp, rng, W, None, hop, L, B, S, LS, NL, E, Fq, Fq, front=False, enhance=(LSE, NLE))
+    T = 1 + (L - W) // hop
+    idx = np.stack([rng.choice(T * Fq, S, replace=False) for _ in range(B * tries)]).astype(np.int32)
+    a = base_args(**params)
+    a.update(model_folder=folder, nb_tries=tries, nb_steps=steps, end_assign=True, kmeans_init_indices=idx, layer_size_enhance=LSE,
+             nb_layers_enhance=NLE, nonlinearity='softmax', out=False)
+    a.pop('type')
+    tr = STFT_Separator_Enhanced_Inference(DPCL, 'STFT_DPCL_enhance_inference', **a)
+    xm, xn, out = _infer(tr, L)
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    out_ref = orec.stft_separate_enhanced_infer(xm, xn, P64, W, hop, NL, E, NLE, idx, tries, steps)
+    assert out.shape == out_ref.shape == (B, S, (T - 1) * hop + W)
+    err = np.linalg.norm(out - out_ref) / np.linalg.norm(out_ref)
+    assert err < 2e-2, err
+
+
+@pytest.mark.parametrize('separation', ['mask', 'perfect'])
+def test_pretrained_inference(separation):
+    """Pretrained_Inference: the pre-trained filterbank with the oracle separator (trainer.py:451-462)."""
+    from ams_hip import testing
+    from utils.trainer import Pretrained_Inference
+    tmp = tempfile.mkdtemp(prefix='ams_pinf_')
+    B, S, L, W, N, hop = 3, 2, 2048, 64, 16, 16
+    folder, params = testing.make_pretrained_adapt(os.path.join(tmp, 'pre'), window_size=W, filters=N, hop_size=hop, chunk_size=L,
+                                                   batch_size=B, nb_speakers=S, separation=separation)
+    a = base_args(**params)
+    a.update(model_folder=folder, out=False, separation=separation)
+    a.pop('type')
+    tr = Pretrained_Inference(None, 'pretrained_inference', **a)
+    xm, xn, out = _infer(tr, L)
+    P = {n: v.detach().cpu().numpy().astype(np.float64) for n, v in tr.graph.variables.items()}
+    out_ref = orec.pretrained_infer(xm, xn, P, hop, separation)
+    assert out.shape == (B, S, L)
+    assert rel(out, out_ref) < 2e-4
+
+
+def test_front_l41_inference_and_finetuning():
+    """The same inference / fine-tuning trainers with the L41 separator (experiments.training.front_L41_finetuning): the
+    checkpoint carries 'speaker_centroids', prediction/* is what k-means clusters."""
+    from models.L41 import L41Model
+    from utils.trainer import Front_Separator_Inference, Front_Separator_Finetuning_Trainer
+    tmp = tempfile.mkdtemp(prefix='ams_l41ft_')
+    rng = np.random.RandomState(61)
+    B, S, L, W, N, hop, LS, NL, E, tries, steps, beta, NSPK = 2, 2, 1024, 64, 16, 16, 12, 2, 8, 1, 3, 4.0, 251
+    folder, params, P = _full_checkpoint(tmp, rng, W, N, hop, L, B, S, LS, NL, E, N, N, tot_speakers=NSPK)
+    T = -(-L // hop)
+    idx = np.stack([rng.choice(T * N, S, replace=False) for _ in range(B * tries)]).astype(np.int32)
+    a = base_args(**params)
+    a.update(model_folder=folder, nb_tries=tries, nb_steps=steps, beta_kmeans=beta, with_silence=True, threshold=2.0, end_assign=True,
+             kmeans_init_indices=idx, tot_speakers=NSPK, out=False, pretraining=False)
+    a.pop('type')
+    tr = Front_Separator_Inference(L41Model, 'front_L41_inference', **dict(a))
+    xm, xn, out = _infer(tr, L)
+    P64 = {k: v.astype(np.float64) for k, v in P.items()}
+    out_ref, _, _ = orec.front_separate_infer(xm, xn, P64, hop, NL, E, idx, tries, steps, beta=beta, with_silence=True, end_assign=True)
+    assert np.linalg.norm(out - out_ref) / np.linalg.norm(out_ref) < 2e-2
+
+    a.update(loss='sdr+l2', optimizer='RMSProp', learning_rate=1e-4)
+    tr = Front_Separator_Finetuning_Trainer(L41Model, 'front_L41_finetuning', **dict(a))
+    dist, tfds = tr.prepare()
+    Pg, cost, xm, xn, I, grads, P_new = one_train_step(tr, tfds, L)
+    args = (hop, NL, E, idx, tries, steps, beta, True, 2.0, True, 'sdr+l2')
+    cost_fn = lambda Pp: orec.front_finetune_cost(xm, xn, Pp, *args)[0]   # noqa: E731
+    c_ref = cost_fn(Pg)
+    assert abs(cost - c_ref) < 1e-3 * abs(c_ref), (cost, c_ref)
+    _fd_check(cost_fn, Pg, grads, ('prediction/W',))
