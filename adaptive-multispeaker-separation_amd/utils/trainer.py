@@ -5,7 +5,7 @@
 loop (train -> every validation_step validate -> save-if-best -> epoch-end lr decay -> final validation,
 restore best, test), and each subclass' ``build`` is the reference's wiring recipe line for line -- only the
 objects underneath launch HIP kernels instead of TF ops.  Additions (all optional): ``--synthetic_batches``,
-``--synthetic_pool`` (synthetic data source size), ``--no_summaries``; data parallelism is picked up from
+``--synthetic_pool`` (synthetic data source size), ``--no_summaries``, ``--hip_graph``; data parallelism is picked up from
 torchrun's environment (WORLD_SIZE/RANK/LOCAL_RANK), one process per GPU, RCCL all-reduce of gradients.
 """
 from __future__ import print_function
@@ -57,6 +57,9 @@ class MyArgs(object):
         parser.add_argument('--synthetic_pool', type=int, help='[ams] distinct synthetic batches kept on device',
                             required=False, default=8)
         parser.add_argument('--no_summaries', help='[ams] do not write per-step summaries', action="store_true")
+        parser.add_argument('--hip_graph', help='[ams] capture forward+backward of the training step into a hipGraph after two '
+                            'eager steps and replay it (fixed batch shape; the 480 recurrent launches of a 3xBLSTM step become '
+                            'one graph launch)', action="store_true")
         self.parser = parser
 
     def add_stft_args(self):
