@@ -319,3 +319,22 @@ def test_overlap_metric_grad():
     ov.backward()
     assert abs(front.overlap_metric(y, B, S) - ov.item()) < 1e-12
     assert rel(front.overlap_metric_bwd(y, B, S), yt.grad.numpy()) < 1e-11
+
+
+def test_kmeans_oracle_matches_sklearn_lloyd():
+    """Independent cross-check of the hard k-means restatement (Kmeans_2.py:86-188): without silence weights and with one try it
+    is plain Lloyd's algorithm for a fixed number of iterations from given seeds -- compare labels/centroids with scikit-learn."""
+    sk = pytest.importorskip('sklearn.cluster')
+    from oracle import kmeans as okm
+    rng = np.random.RandomState(3)
+    b, L, E, C, iters = 2, 400, 6, 3, 4
+    means = rng.randn(b, C, E) * 3.0
+    lab_true = rng.randint(0, C, (b, L))
+    X = means[np.arange(b)[:, None], lab_true] + 0.3 * rng.randn(b, L, E)
+    Xn = X / np.linalg.norm(X, axis=-1, keepdims=True)                      # the reference l2-normalises its input (Kmeans_2.py:61)
+    init = np.stack([np.array([np.flatnonzero(lab_true[i] == c)[0] for c in range(C)]) for i in range(b)]).astype(np.int32)
+    cent, labels, best = okm.kmeans(X, init, C, 1, iters, assign_at_end=True)
+    for i in range(b):
+        km = sk.KMeans(n_clusters=C, init=Xn[i][init[i]], n_init=1, max_iter=iters, tol=0.0, algorithm='lloyd').fit(Xn[i])
+        assert np.allclose(km.cluster_centers_, cent[i], atol=1e-10)
+        assert np.array_equal(km.labels_, labels[i])
