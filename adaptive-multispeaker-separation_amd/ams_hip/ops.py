@@ -60,27 +60,31 @@ class _Profile(object):
 
     def reset(self, enabled=False):
         self.enabled = enabled
-        self.records = []            # (start_event, stop_event, flops, bytes, tag)
+        self.records = []            # (start_event, stop_event, flops, bytes, tag, label)
 
     def begin(self):
         e = torch.cuda.Event(enable_timing=True)
         e.record(torch.cuda.current_stream())
         return e
 
-    def end(self, start, flops=0.0, nbytes=0.0, tag=''):
+    def end(self, start, flops=0.0, nbytes=0.0, tag='', label=''):
         e = torch.cuda.Event(enable_timing=True)
         e.record(torch.cuda.current_stream())
-        self.records.append((start, e, flops, nbytes, tag))
+        self.records.append((start, e, flops, nbytes, tag, label))
 
     def tags(self):
         return sorted(set(r[4] for r in self.records))
 
-    def summary(self, tag=None):
+    def summary(self, tag=None, label=None, prefix=None):
         torch.cuda.synchronize()
         ms = fl = by = 0.0
         n = 0
-        for s, e, f, b, t in self.records:
+        for s, e, f, b, t, lab in self.records:
             if tag is not None and t != tag:
+                continue
+            if label is not None and lab != label:
+                continue
+            if prefix is not None and not t.startswith(prefix):
                 continue
             ms += s.elapsed_time(e)
             fl += f
@@ -123,7 +127,10 @@ def front_conv(x, f, hop):
     lib = load()
     nb = lib.ams_front_conv_fwd_workspace_bytes(Bt, L, W, N, hop)
     ws = _ws(nb, x) if nb else None
+    ev = PROFILE.begin() if PROFILE.enabled else None
     check(lib.ams_front_conv_fwd(_p(x), _p(f), _p(y), Bt, L, W, N, hop, _p(ws), nb, _s()), 'ams_front_conv_fwd')
+    if ev is not None:      # algorithmic bytes: waveform in, frames out, filter once
+        PROFILE.end(ev, 2.0 * Bt * T * N * W, 4.0 * (Bt * L + Bt * T * N + W * N), 'gemm<2,0>', 'front_conv')
     return y
 
 
@@ -141,7 +148,7 @@ def front_conv_bwd_filter(x, dy, W, hop):
 
 # ------------------------------------------------------------------ GEMM
 def gemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False, M=None, N=None, K=None,
-         lda=None, ldb=None, ldc=None, mask=(0, 0)):
+         lda=None, ldb=None, ldc=None, mask=(0, 0), label=''):
     """out[M,N] (+)= op(A) op(B) (+ bias).  A/B may be 2-D tensors (dims inferred) or raw views with explicit
     M,N,K and leading dimensions (for column slices of wider buffers)."""
     lib = load()
@@ -173,7 +180,7 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False
     check(lib.ams_gemm_f32(int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc, _p(bias), int(accumulate),
                            mask[0], mask[1], _p(ws), nb, _s()), 'ams_gemm_f32')
     if ev is not None:
-        PROFILE.end(ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N), 'gemm<%d,%d>' % (int(bool(transA)), int(bool(transB))))
+        PROFILE.end(ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N), 'gemm<%d,%d>' % (int(bool(transA)), int(bool(transB))), label)
     return out
 
 
@@ -217,7 +224,7 @@ def blstm_fwd(x, Kf, bf, Kb, bb):
     # two launches of 400 (1.56 per CU, i.e. 22 % of the CU-time idle).
     Wcat = blstm_wcat(Kf, Kb, D)
     bias = torch.as_strided(bf, (8 * H,), (1,)) if _twin(bf, bb) else torch.cat([bf, bb])
-    gemm(x2, Wcat, bias=bias, out=G, M=B * T, N=8 * H, K=D, lda=D, ldb=8 * H, ldc=8 * H)
+    gemm(x2, Wcat, bias=bias, out=G, M=B * T, N=8 * H, K=D, lda=D, ldb=8 * H, ldc=8 * H, label='blstm_input_gemm')
     out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
     cst = torch.empty((B, T, 2, H), dtype=torch.float32, device=x.device)
     pack = torch.empty(lib.ams_blstm_pack_floats(H, 0), dtype=torch.float32, device=x.device)

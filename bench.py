@@ -158,7 +158,7 @@ def main():
     value = world * B * args.steps / elapsed
 
     # ---- roofline of the dominant kernel: the fp32 MFMA GEMM family (dense 600->F*E, its two gradients, LSTM projections)
-    prof = ops.PROFILE.summary()
+    prof = ops.PROFILE.summary(prefix='gemm')
     roof = None
     if prof['launches']:
         avg_ms = prof['ms'] / prof['launches']
@@ -191,6 +191,24 @@ def main():
                     'launches_per_step': pv['launches'] / prof_steps, 'avg_launch_us': round(pv['ms'] / pv['launches'] * 1e3, 2),
                     'TFLOP/s': round(pv['flops'] / (pv['ms'] * 1e-3) / 1e12, 2)}
 
+    # ---- the two kernels north_star names a target for (same HIP-event records)
+    targets = {}
+    pf = ops.PROFILE.summary(label='front_conv')
+    if pf['launches']:
+        t = pf['ms'] * 1e-3
+        targets['front_conv'] = {
+            'kernel': 'gemm_f32_kernel<A_FRAMES> (+ split-K reduce)', 'avg_launch_us': round(pf['ms'] / pf['launches'] * 1e3, 2),
+            'TFLOP/s': round(pf['flops'] / t / 1e12, 2), 'mfma_frac': round(pf['flops'] / t / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+            'algorithmic_GB/s': round(pf['bytes'] / t / 1e9, 1), 'hbm_frac': round(pf['bytes'] / t / 8e12, 4),
+            'note': 'strided analysis conv = dense contraction, AI ~ 250 flop/B: MFMA-bound, not HBM-bound (DESIGN.md 4)'}
+    pi = ops.PROFILE.summary(label='blstm_input_gemm')
+    if pi['launches']:
+        t = pi['ms'] * 1e-3
+        targets['blstm_input_gemm'] = {
+            'kernel': 'gemm_f32_kernel<A_ROW,B_ROW>, both directions in one [B*T, D] x [D, 8H] product',
+            'avg_launch_us': round(pi['ms'] / pi['launches'] * 1e3, 2), 'TFLOP/s': round(pi['flops'] / t / 1e12, 2),
+            'mfma_frac': round(pi['flops'] / t / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+
     out = {
         'metric': 'mixtures/sec training throughput (2-spk, 256-filter adapt+BLSTM-DPCL)',
         'value': round(value, 2), 'unit': 'mixtures/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -200,7 +218,7 @@ def main():
                                '3xBLSTM(600) -> dense 600->%d -> l2norm -> DPCL loss, fwd+bwd+AMSGrad' % (N, N * E),
                    'batch_per_gpu': B, 'global_batch': B * world, 'nb_speakers': S, 'chunk_size': L, 'frames': T,
                    'parallelism': 'dp%d' % world, 'hip_graph': bool(args.graph)},
-        'roofline': roof, 'final_cost': last_cost,
+        'roofline': roof, 'north_star_targets': targets, 'final_cost': last_cost,
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
