@@ -543,15 +543,52 @@ class L41Loss(Function):
         return demb, None, dvs
 
 
+class L41Speakers(Function):
+    """tf.nn.l2_normalize(speaker_centroids, 1) + gather_nd by I (models/L41.py:60-68); backward scatters through the
+    normalise Jacobian in a fixed order."""
+
+    @staticmethod
+    def forward(ctx, table, I, normalize):
+        I32 = I.to(torch.int32).contiguous()
+        ctx.save_for_backward(table, I32)
+        ctx.normalize = normalize
+        return ops.l41_speaker_fwd(table, I32, normalize)
+
+    @staticmethod
+    def backward(ctx, d_vs):
+        table, I32 = ctx.saved_tensors
+        return ops.l41_speaker_bwd(table, I32, _c(d_vs), ctx.normalize), None, None
+
+
 def l41_loss(emb, y, speaker_vectors, I, normalize):
-    """emb [B,T,F,E], y [B,T,F,S]; the [251,E] normalise + gather (L41.py:60-68) is tiny-tensor torch glue."""
+    """emb [B,T,F,E], y [B,T,F,S]; speaker_vectors [251,E], I [B,S]."""
     B, E = emb.shape[0], emb.shape[-1]
     S = y.shape[-1]
-    sv = speaker_vectors
-    if normalize:
-        sv = sv * torch.rsqrt(torch.clamp((sv * sv).sum(dim=1, keepdim=True), min=1e-12))
-    vs = sv[I.long()]                                                                # [B,S,E]
-    return L41Loss.apply(_c(emb).reshape(B, -1, E), _c(y).reshape(B, -1, S), _c(vs))
+    vs = L41Speakers.apply(_c(speaker_vectors), I, bool(normalize))                  # [B,S,E]
+    return L41Loss.apply(_c(emb).reshape(B, -1, E), _c(y).reshape(B, -1, S), vs)
+
+
+class EnhanceOutput(Function):
+    """Separator.enhance output stage (network.py:640-660): act over the speaker axis, times X; two layouts out."""
+
+    @staticmethod
+    def forward(ctx, u, X, S, nonlinearity):
+        cost_in, sep = ops.enhance_output_fwd(u, X, S, nonlinearity)
+        ctx.save_for_backward(u, X)
+        ctx.S, ctx.nl = S, nonlinearity
+        return cost_in, sep
+
+    @staticmethod
+    def backward(ctx, d_cost_in, d_sep):
+        u, X = ctx.saved_tensors
+        dc = _c(d_cost_in) if d_cost_in is not None else None
+        ds = _c(d_sep) if d_sep is not None else None
+        return ops.enhance_output_bwd(u, X, ctx.S, ctx.nl, dc, ds), None, None, None
+
+
+def enhance_output(u, X, S, nonlinearity):
+    """u [B*S,T,F], X [B,T,F] -> (cost_in [B,TF,S], separated [B,S,TF])."""
+    return EnhanceOutput.apply(_c(u), _c(X), S, nonlinearity)
 
 
 def one_hot_masks(labels, S):

@@ -432,6 +432,53 @@ def dpcl_loss_bwd(V, Y, ws, inv=None, upstream=None):
     return d
 
 
+# ------------------------------------------------------------------ enhance output stage / L41 speaker vectors
+_NONLIN = {None: 0, 'None': 0, 'none': 0, 'softmax': 1, 'tanh': 2}
+
+
+def enhance_output_fwd(u, X, S, nonlinearity, want_separated=True):
+    """u [B*S, T, F] (rows (b,s)), X [B, T, F] -> cost_in [B, TF, S], separated [B, S, TF] (network.py:640-660)."""
+    _chk(u, X)
+    B = X.shape[0]
+    TF = X.numel() // B
+    cost_in = torch.empty((B, TF, S), dtype=torch.float32, device=u.device)
+    sep = torch.empty((B, S, TF), dtype=torch.float32, device=u.device) if want_separated else None
+    check(load().ams_enhance_output_fwd(_p(u), _p(X), _p(cost_in), _p(sep), B, S, TF, _NONLIN[nonlinearity], _s()),
+          'ams_enhance_output_fwd')
+    return cost_in, sep
+
+
+def enhance_output_bwd(u, X, S, nonlinearity, d_cost_in, d_sep):
+    _chk(u, X, d_cost_in, d_sep)
+    B = X.shape[0]
+    TF = X.numel() // B
+    du = torch.empty_like(u)
+    check(load().ams_enhance_output_bwd(_p(u), _p(X), _p(d_cost_in), _p(d_sep), _p(du), B, S, TF, _NONLIN[nonlinearity], _s()),
+          'ams_enhance_output_bwd')
+    return du
+
+
+def l41_speaker_fwd(table, I, normalize):
+    """table [nspk,E], I int32 [B,S] -> vs [B,S,E] (L41.py:60-68)."""
+    _chk(table)
+    if I.dtype != torch.int32 or not I.is_cuda or not I.is_contiguous():
+        raise AmsError('l41_speaker: I must be a contiguous int32 device tensor')
+    nspk, E = table.shape
+    R = I.numel()
+    vs = torch.empty(tuple(I.shape) + (E,), dtype=torch.float32, device=table.device)
+    check(load().ams_l41_speaker_fwd(_p(table), _p(I), _p(vs), R, E, nspk, int(bool(normalize)), _s()), 'ams_l41_speaker_fwd')
+    return vs
+
+
+def l41_speaker_bwd(table, I, d_vs, normalize):
+    _chk(table, d_vs)
+    nspk, E = table.shape
+    d = torch.empty_like(table)
+    check(load().ams_l41_speaker_bwd(_p(table), _p(I), _p(d_vs), _p(d), I.numel(), E, nspk, int(bool(normalize)), _s()),
+          'ams_l41_speaker_bwd')
+    return d
+
+
 # ------------------------------------------------------------------ optimizers
 def opt_amsgrad(p, g, m, v, vhat, lr_t, beta1, beta2, eps, grad_scale=1.0):
     _chk(p, g, m, v, vhat)

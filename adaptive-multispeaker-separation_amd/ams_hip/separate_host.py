@@ -53,20 +53,16 @@ def build_enhance(sep, BLSTM, Conv1D, f_props):
             v = ((z - m) ** 2).mean(dim=(1, 2), keepdim=True)
             z = (z - m) / torch.sqrt(v)
         y = conv.f_prop(f_props(layers, z.contiguous()))              # [B*S, T, F]
-        y = y.reshape(B, S, T * Fq).transpose(1, 2)                   # [B, TF, S]
-        if a['nonlinearity'] == 'softmax':
-            y = torch.softmax(y, dim=2)
-        elif a['nonlinearity'] == 'tanh':
-            y = torch.tanh(y)
-        return y * Xin.reshape(B, T * Fq, 1)                          # cost_in [B, TF, S]
-    sep.cost_in = Node('cost_in', _net)
+        return F.enhance_output(y, Xin, S, a['nonlinearity'])          # (cost_in [B, TF, S], separated [B, S, TF])
+    both = Node('enhance_out', _net)
+    sep.cost_in = Node('cost_in', lambda run: both.value(run)[0])
     sep.enhanced_masks = sep.cost_in
 
     def _out(run):
-        c = sep.cost_in.value(run)
-        B = c.shape[0]
+        sp = both.value(run)[1]
+        B = sp.shape[0]
         T = X_input.value(run).shape[1]
-        return c.transpose(1, 2).reshape(B * S, T, Fq, 1)
+        return sp.reshape(B * S, T, Fq, 1)
     out = Node('enhanced', _out)
     sep.separated = out
     return out

@@ -125,6 +125,21 @@ ams_status ams_dpcl_loss_fwd_u(const float* U, const float* Y, float* inv, float
 ams_status ams_dpcl_loss_bwd_u(const float* U, const float* Y, const float* inv, const float* upstream, float* dU, int B, long TF,
                                int E, int S, const void* ws, void* stream);
 
+/* ---- enhance-layer output stage   models/network.py:640-660 ----
+ * u [B,S,TF] = Conv1D output of the enhance stack (rows (b,s)); X [B,TF] mixture representation.
+ * cost_in[b,p,s] = act_s(u[b,:,p]) * X[b,p] (act over the SPEAKER axis: 0 none, 1 softmax, 2 tanh); separated (may be NULL)
+ * is the same values as [B,S,TF] (network.py:657-660).  bwd: either upstream gradient may be NULL. */
+ams_status ams_enhance_output_fwd(const float* u, const float* X, float* cost_in, float* separated, int B, int S, long TF,
+                                  int nonlin, void* stream);
+ams_status ams_enhance_output_bwd(const float* u, const float* X, const float* d_cost_in, const float* d_separated, float* du, int B,
+                                  int S, long TF, int nonlin, void* stream);
+
+/* ---- L41 speaker vectors   models/L41.py:60-68: tf.nn.l2_normalize(speaker_centroids, 1) then gather_nd by I ----
+ * table [nspk,E], I int32 [R = B*S] -> vs [R,E]; bwd writes the whole d_table (deterministic order). */
+ams_status ams_l41_speaker_fwd(const float* table, const int* I, float* vs, int R, int E, int nspk, int normalize, void* stream);
+ams_status ams_l41_speaker_bwd(const float* table, const int* I, const float* d_vs, float* d_table, int R, int E, int nspk,
+                               int normalize, void* stream);
+
 /* ---- K24  optimizers     models/network.py:181-194, utils/ops.py:686-703 ---- */
 ams_status ams_opt_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, long n, float lr_t, float beta1,
                            float beta2, float eps, float grad_scale, void* stream);

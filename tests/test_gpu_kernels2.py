@@ -218,3 +218,49 @@ def test_maxpool_front_and_sparse_synthesis(F, Bt, L, W, N, P, hop, S):
     out.backward(dev(dout))
     dv_ref, df2_ref = ofront.synth_unpool_bwd(vals, am_t, f2, dout)
     assert rel(host(vt.grad), dv_ref) < 5 * TOL and rel(host(f2t.grad), df2_ref) < 5 * TOL
+
+
+@pytest.mark.parametrize('B,S,TF,nl', [(2, 2, 1000, 'softmax'), (3, 3, 777, 'tanh'), (1, 2, 4096, 'None'), (2, 4, 513, 'softmax')])
+def test_enhance_output_stage(ops, B, S, TF, nl):
+    """network.py:640-660 output stage and its backward vs torch autograd in float64."""
+    rng = np.random.RandomState(B * 100 + S)
+    u = rng.randn(B * S, TF)
+    X = np.abs(rng.randn(B, TF)) + 0.1
+    gc, gs = rng.randn(B, TF, S), rng.randn(B, S, TF)
+    ut = torch.tensor(u, dtype=torch.float64, requires_grad=True)
+    y = ut.reshape(B, S, TF).transpose(1, 2)
+    if nl == 'softmax':
+        y = torch.softmax(y, dim=2)
+    elif nl == 'tanh':
+        y = torch.tanh(y)
+    ci_ref = y * torch.tensor(X).reshape(B, TF, 1)
+    sp_ref = ci_ref.transpose(1, 2)
+    ((ci_ref * torch.tensor(gc)).sum() + (sp_ref * torch.tensor(gs)).sum()).backward()
+    ud, Xd = dev(u).view(B * S, 1, TF), dev(X).view(B, 1, TF)
+    ci, sp = ops.enhance_output_fwd(ud, Xd, S, nl)
+    assert rel(host(ci), ci_ref.detach().numpy()) < 1e-5 and rel(host(sp), sp_ref.detach().numpy()) < 1e-5
+    du = ops.enhance_output_bwd(ud, Xd, S, nl, dev(gc), dev(gs))
+    assert rel(host(du).reshape(B * S, TF), ut.grad.numpy()) < 1e-4
+    du1 = ops.enhance_output_bwd(ud, Xd, S, nl, dev(gc), None)
+    du2 = ops.enhance_output_bwd(ud, Xd, S, nl, None, dev(gs))
+    assert rel(host(du1) + host(du2), host(du)) < 1e-5
+
+
+@pytest.mark.parametrize('normalize', [True, False])
+def test_l41_speaker_vectors(ops, normalize):
+    """L41.py:60-68 normalise + gather and its scatter backward (repeated speakers accumulate) vs torch autograd."""
+    rng = np.random.RandomState(8)
+    nspk, E, B, S = 17, 40, 6, 3
+    table = rng.randn(nspk, E)
+    I = rng.randint(0, nspk, (B, S))
+    I[0, 0] = I[1, 1] = I[2, 2] = 5                                  # repeats across the batch
+    g = rng.randn(B, S, E)
+    tt = torch.tensor(table, dtype=torch.float64, requires_grad=True)
+    sv = tt * torch.rsqrt(torch.clamp((tt * tt).sum(dim=1, keepdim=True), min=1e-12)) if normalize else tt
+    vs_ref = sv[torch.tensor(I).long()]
+    (vs_ref * torch.tensor(g)).sum().backward()
+    Id = torch.tensor(I, dtype=torch.int32, device='cuda')
+    vs = ops.l41_speaker_fwd(dev(table), Id, normalize)
+    assert rel(host(vs), vs_ref.detach().numpy()) < 1e-6
+    dt = ops.l41_speaker_bwd(dev(table), Id, dev(g), normalize)
+    assert rel(host(dt), tt.grad.numpy()) < 1e-5
