@@ -20,8 +20,10 @@ class Dist(object):
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
             if backend is None:
-                backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-            if backend == 'nccl':
+                # AMS_DIST_BACKEND=gloo lets several ranks share ONE GPU (plumbing tests on a 1-GPU box; RCCL refuses that)
+                backend = os.environ.get('AMS_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+            if torch.cuda.is_available():
+                self.local_rank %= max(1, torch.cuda.device_count())
                 torch.cuda.set_device(self.local_rank)
             td.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
 

@@ -106,7 +106,9 @@ def main():
     import torch
     from ams_hip import ops
     tmp = tempfile.mkdtemp(prefix='ams_bench_')
-    trainer, tfds, dist = build(args, tmp)
+    import contextlib
+    with contextlib.redirect_stdout(sys.stderr):        # the trainer echoes its config like the reference; stdout carries ONE JSON line
+        trainer, tfds, dist = build(args, tmp)
     model, g = trainer.model, trainer.graph
     rank, world = dist.rank, dist.world_size
     if args.gpus != world and rank == 0 and not args.quiet:
