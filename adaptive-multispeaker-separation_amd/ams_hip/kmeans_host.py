@@ -44,9 +44,9 @@ class KMeans(object):
         b, L, E = X.shape
         w = None
         if self.latent_space_tensor is not None:
-            lat = self.latent_space_tensor.value(run).reshape(b, L)
-            mx = lat.max(dim=1, keepdim=True)[0]
-            w = ((torch.log(mx / lat) / np.log(10.0)) < self.threshold).float().contiguous()      # Kmeans_2.py:76-80
+            from . import ops
+            lat = self.latent_space_tensor.value(run).reshape(b, L).contiguous()
+            w = ops.silence_weights(lat, self.threshold)                                        # Kmeans_2.py:76-80
         idx = self._init_idx(run, b * self.nb_tries, L, X.device)
         return F.kmeans(X, idx, self.nb_clusters, self.nb_tries, self.nb_iterations, self.beta, w, self.assign_at_end,
                         self.normalize_input, self.faithful_tile)

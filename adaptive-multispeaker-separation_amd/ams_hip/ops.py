@@ -432,6 +432,40 @@ def dpcl_loss_bwd(V, Y, ws, inv=None, upstream=None):
     return d
 
 
+# ------------------------------------------------------------------ optional input conditioning / weightings
+_PRE = {None: 0, 'None': 0, 'none': 0, 'abs': 1, 'sqrt': 2, 'log': 3}
+_NORM = {None: 0, 'None': 0, 'none': 0, '01': 1, 'meanstd': 2, 'silent': 3}
+_WMODE = {None: 0, 'None': 0, 'none': 0, 'linear': 1, 'sqrt': 2, 'square': 3}
+
+
+def row_transform(x, pre=None, norm=None, thr=0.0):
+    """Per-utterance conditioning of X [B, ...] (network.py:409-454,504-521): pre in {abs, sqrt, log}, norm in {01, meanstd, silent}."""
+    _chk(x)
+    out = torch.empty_like(x)
+    rows = x.shape[0]
+    check(load().ams_row_transform(_p(x), _p(out), rows, x.numel() // rows, _PRE[pre], _NORM[norm], float(thr), _s()), 'ams_row_transform')
+    return out
+
+
+def weight_masks(X, y, mode=None, silence_thr=None):
+    """y [B,TF,S] *= f(|X|/max|X|) and/or the silence-loss mask (network.py:381-396); returns a new tensor."""
+    _chk(X, y)
+    B, TF, S = y.shape
+    out = y.clone()
+    check(load().ams_weight_masks(_p(X), _p(out), B, TF, S, _WMODE[mode], int(silence_thr is not None),
+                                  float(silence_thr if silence_thr is not None else 0.0), _s()), 'ams_weight_masks')
+    return out
+
+
+def silence_weights(lat, thr):
+    """Kmeans_2.py:76-80: notsilent[b,l] = log10(max(lat[b]) / lat[b,l]) < thr."""
+    _chk(lat)
+    w = torch.empty_like(lat)
+    rows = lat.shape[0]
+    check(load().ams_silence_weights(_p(lat), _p(w), rows, lat.numel() // rows, float(thr), _s()), 'ams_silence_weights')
+    return w
+
+
 # ------------------------------------------------------------------ enhance output stage / L41 speaker vectors
 _NONLIN = {None: 0, 'None': 0, 'none': 0, 'softmax': 1, 'tanh': 2}
 

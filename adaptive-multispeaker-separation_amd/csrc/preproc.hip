@@ -1,0 +1,126 @@
+// Per-utterance input conditioning of the separator (reference models/network.py:409-454,504-521) and the magnitude /
+// silence weightings of masks and k-means (network.py:381-396, Kmeans_2.py:76-80).  One workgroup per utterance row;
+// every statistic is a fixed-order block reduction (deterministic).  These flags are off in the shipped launchers, the
+// kernels exist so that turning them on does not put framework arithmetic on the path.
+#include "common.h"
+
+namespace {
+
+enum { PRE_NONE = 0, PRE_ABS = 1, PRE_SQRT = 2, PRE_LOG10 = 3 };
+enum { NORM_NONE = 0, NORM_01 = 1, NORM_MEANSTD = 2, NORM_SILENT = 3 };
+enum { W_NONE = 0, W_LINEAR = 1, W_SQRT = 2, W_SQUARE = 3 };
+
+__device__ __forceinline__ float pre_apply(float x, int pre) {
+    switch (pre) {
+        case PRE_ABS: return fabsf(x);
+        case PRE_SQRT: return sqrtf(x);
+        case PRE_LOG10: return log10f(x + 1e-12f);
+        default: return x;
+    }
+}
+
+struct Red { float mn, mx, sum; };
+
+__device__ __forceinline__ float blk_reduce(float v, float* sm, int op) {       // op 0 sum, 1 min, 2 max; result to all threads
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = __shfl_down(v, o);
+        v = op == 0 ? v + t : (op == 1 ? fminf(v, t) : fmaxf(v, t));
+    }
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[w] = v;
+    __syncthreads();
+    float r = sm[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = op == 0 ? r + sm[i] : (op == 1 ? fminf(r, sm[i]) : fmaxf(r, sm[i]));
+    return r;
+}
+
+// out = norm(pre(x)) per row.  NORM_01: (z - min)/(max - min); NORM_MEANSTD: (z - mean)/sqrt(population var);
+// NORM_SILENT: z * [max - z < thr]  (network.py:440-443, thr = silence_mask_db / 20)
+__global__ __launch_bounds__(256) void row_transform_kernel(const float* __restrict__ x, float* __restrict__ out, long n, int pre,
+                                                            int norm, float thr) {
+    __shared__ float sm[4];
+    const float* xr = x + (long)blockIdx.x * n;
+    float* orow = out + (long)blockIdx.x * n;
+    float a = 0.f, b = 1.f, mxv = 0.f;
+    if (norm == NORM_01 || norm == NORM_SILENT) {
+        float mn = 3.0e38f, mx = -3.0e38f;
+        for (long i = threadIdx.x; i < n; i += 256) { const float z = pre_apply(xr[i], pre); mn = fminf(mn, z); mx = fmaxf(mx, z); }
+        mn = blk_reduce(mn, sm, 1);
+        mx = blk_reduce(mx, sm, 2);
+        a = mn; b = mx - mn; mxv = mx;
+    } else if (norm == NORM_MEANSTD) {
+        float s = 0.f;
+        for (long i = threadIdx.x; i < n; i += 256) s += pre_apply(xr[i], pre);
+        const float mean = blk_reduce(s, sm, 0) / (float)n;
+        float v = 0.f;
+        for (long i = threadIdx.x; i < n; i += 256) { const float d = pre_apply(xr[i], pre) - mean; v += d * d; }
+        const float var = blk_reduce(v, sm, 0) / (float)n;
+        a = mean; b = sqrtf(var);
+    }
+    for (long i = threadIdx.x; i < n; i += 256) {
+        const float z = pre_apply(xr[i], pre);
+        float r;
+        if (norm == NORM_SILENT) r = (mxv - z < thr) ? z : 0.f;
+        else if (norm == NORM_NONE) r = z;
+        else r = (z - a) / b;
+        orow[i] = r;
+    }
+}
+
+// y[b,p,s] *= f(|X[b,p]| / max_p |X[b,:]|)  and/or  [log10(max/|X|) < sil_thr]   (network.py:381-396)
+__global__ __launch_bounds__(256) void weight_masks_kernel(const float* __restrict__ X, float* __restrict__ y, long TF, int S, int mode,
+                                                           int use_sil, float sil_thr) {
+    __shared__ float sm[4];
+    const float* xr = X + (long)blockIdx.x * TF;
+    float* yr = y + (long)blockIdx.x * TF * S;
+    float mx = 0.f;
+    for (long i = threadIdx.x; i < TF; i += 256) mx = fmaxf(mx, fabsf(xr[i]));
+    mx = blk_reduce(mx, sm, 2);
+    for (long i = threadIdx.x; i < TF; i += 256) {
+        const float ax = fabsf(xr[i]);
+        const float r = ax / mx;
+        float w = 1.f;
+        if (mode == W_LINEAR) w = r;
+        else if (mode == W_SQRT) w = sqrtf(r);
+        else if (mode == W_SQUARE) w = r * r;
+        if (use_sil) w *= (log10f(mx / ax) < sil_thr) ? 1.f : 0.f;
+        for (int s = 0; s < S; ++s) yr[i * S + s] *= w;
+    }
+}
+
+// w[b,l] = [log10(max_l lat[b,:] / lat[b,l]) < thr]   (Kmeans_2.py:76-80)
+__global__ __launch_bounds__(256) void silence_weights_kernel(const float* __restrict__ lat, float* __restrict__ w, long n, float thr) {
+    __shared__ float sm[4];
+    const float* r = lat + (long)blockIdx.x * n;
+    float mx = -3.0e38f;
+    for (long i = threadIdx.x; i < n; i += 256) mx = fmaxf(mx, r[i]);
+    mx = blk_reduce(mx, sm, 2);
+    for (long i = threadIdx.x; i < n; i += 256) w[(long)blockIdx.x * n + i] = (log10f(mx / r[i]) < thr) ? 1.f : 0.f;
+}
+
+}  // namespace
+
+extern "C" {
+
+// pre: 0 none, 1 abs, 2 sqrt, 3 log10(x + 1e-12);  norm: 0 none, 1 (z-min)/(max-min), 2 (z-mean)/sqrt(var), 3 z*[max-z < thr]
+ams_status ams_row_transform(const float* x, float* out, int rows, long n, int pre, int norm, float thr, void* stream) {
+    AMS_REQUIRE(x && out && rows > 0 && n > 0 && pre >= 0 && pre <= 3 && norm >= 0 && norm <= 3);
+    hipLaunchKernelGGL(row_transform_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, x, out, n, pre, norm, thr);
+    return ams_check_launch();
+}
+
+// in place on y [B,TF,S]; mode: 0 none, 1 linear, 2 sqrt, 3 square; sil_thr used when use_silence != 0
+ams_status ams_weight_masks(const float* X, float* y, int B, long TF, int S, int mode, int use_silence, float sil_thr, void* stream) {
+    AMS_REQUIRE(X && y && B > 0 && TF > 0 && S > 0 && mode >= 0 && mode <= 3);
+    hipLaunchKernelGGL(weight_masks_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, X, y, TF, S, mode, use_silence, sil_thr);
+    return ams_check_launch();
+}
+
+ams_status ams_silence_weights(const float* lat, float* w, int rows, long n, float thr, void* stream) {
+    AMS_REQUIRE(lat && w && rows > 0 && n > 0);
+    hipLaunchKernelGGL(silence_weights_kernel, dim3(rows), dim3(256), 0, (hipStream_t)stream, lat, w, n, thr);
+    return ams_check_launch();
+}
+
+}  // extern "C"

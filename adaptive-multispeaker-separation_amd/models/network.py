@@ -438,27 +438,19 @@ class Separator(Network):
             self.F = kwargs['window_size'] // 2 + 1
 
     def _weight_masks(self, y, run):
-        """network.py:381-396: magnitude-weighted masks / silence loss mask (torch glue, off the headline path)."""
+        """network.py:381-396: magnitude-weighted masks / silence loss mask (off in the shipped launchers)."""
         if self.function_mask in ('linear', 'sqrt', 'square') or self.loss_with_silence:
             X = self.X.value(run)
-            B = X.shape[0]
-            ax = X.abs().reshape(B, -1)
-            mx = ax.max(dim=1, keepdim=True)[0]
-            if self.function_mask == 'linear':
-                y = y * (ax / mx).unsqueeze(2)
-            elif self.function_mask == 'sqrt':
-                y = y * torch.sqrt(ax / mx).unsqueeze(2)
-            elif self.function_mask == 'square':
-                y = y * torch.square(ax / mx).unsqueeze(2)
-            if self.loss_with_silence:
-                y = y * (log10(mx / ax) < self.threshold_silence_loss).float().unsqueeze(2)
+            mode = self.function_mask if self.function_mask in ('linear', 'sqrt', 'square') else None
+            y = K.weight_masks(X.contiguous(), y.contiguous(), mode,
+                               self.threshold_silence_loss if self.loss_with_silence else None)
         return y
 
     def init_separator(self):
         if self.plugged:
             if self.abs_input:
                 src = self.X
-                self.X = Node('abs_input', lambda run: src.value(run).abs(), register=False)
+                self.X = Node('abs_input', lambda run: K.row_transform(src.value(run).contiguous(), pre='abs'), register=False)
             if self.normalize_input == '01':
                 self.normalization01
             elif self.normalize_input == 'meanstd':
@@ -469,8 +461,7 @@ class Separator(Network):
             self.preprocessing
             if self.pre_func in ('sqrt', 'log'):
                 src, fn = self.X, self.pre_func
-                self.X = Node('pre_func', lambda run: torch.sqrt(src.value(run)) if fn == 'sqrt'
-                              else log10(src.value(run) + 1e-12), register=False)
+                self.X = Node('pre_func', lambda run: K.row_transform(src.value(run).contiguous(), pre=fn), register=False)
             if self.normalize_input == '01':
                 self.normalization01
             elif self.normalize_input == 'meanstd':
@@ -479,9 +470,7 @@ class Separator(Network):
                 src, thr = self.X, self.silent_threshold
 
                 def _sil(run):
-                    X = src.value(run)
-                    mx = X.amax(dim=(1, 2), keepdim=True)
-                    return (mx - X < thr / 20.).float() * X
+                    return K.row_transform(src.value(run).contiguous(), norm='silent', thr=thr / 20.)
                 self.X = Node('silent_mask', _sil, register=False)
             self.prediction
             if self.args['model_folder'] is None:
@@ -522,10 +511,7 @@ class Separator(Network):
         src = self.X
 
         def _n(run):
-            X = src.value(run)
-            mn = X.amin(dim=(1, 2), keepdim=True)
-            mx = X.amax(dim=(1, 2), keepdim=True)
-            return (X - mn) / (mx - mn)
+            return K.row_transform(src.value(run).contiguous(), norm='01')
         self.X = Node('X01', _n)
         return self.X
 
@@ -534,10 +520,7 @@ class Separator(Network):
         src = self.X
 
         def _n(run):
-            X = src.value(run)
-            m = X.mean(dim=(1, 2), keepdim=True)
-            v = ((X - m) ** 2).mean(dim=(1, 2), keepdim=True)
-            return (X - m) / torch.sqrt(v)
+            return K.row_transform(src.value(run).contiguous(), norm='meanstd')
         self.X = Node('Xms', _n)
         return self.X
 

@@ -140,6 +140,15 @@ ams_status ams_l41_speaker_fwd(const float* table, const int* I, float* vs, int 
 ams_status ams_l41_speaker_bwd(const float* table, const int* I, const float* d_vs, float* d_table, int R, int E, int nspk,
                                int normalize, void* stream);
 
+/* ---- optional input conditioning / weightings   models/network.py:381-396,409-454,504-521, models/Kmeans_2.py:76-80 ----
+ * row = one utterance (T*F values).  ams_row_transform: pre 0 none | 1 abs | 2 sqrt | 3 log10(x+1e-12), then norm 0 none |
+ * 1 (z-min)/(max-min) | 2 (z-mean)/sqrt(population var) | 3 z*[max-z < thr] (silence_mask_db/20).
+ * ams_weight_masks: y[b,p,:] *= f(|X|/max|X|) (1 linear, 2 sqrt, 3 square) and/or [log10(max/|X|) < sil_thr], in place.
+ * ams_silence_weights: w = [log10(max(lat)/lat) < thr]  (k-means 'notsilent' weights). */
+ams_status ams_row_transform(const float* x, float* out, int rows, long n, int pre, int norm, float thr, void* stream);
+ams_status ams_weight_masks(const float* X, float* y, int B, long TF, int S, int mode, int use_silence, float sil_thr, void* stream);
+ams_status ams_silence_weights(const float* lat, float* w, int rows, long n, float thr, void* stream);
+
 /* ---- K24  optimizers     models/network.py:181-194, utils/ops.py:686-703 ---- */
 ams_status ams_opt_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, long n, float lr_t, float beta1,
                            float beta2, float eps, float grad_scale, void* stream);

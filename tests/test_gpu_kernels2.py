@@ -264,3 +264,43 @@ def test_l41_speaker_vectors(ops, normalize):
     assert rel(host(vs), vs_ref.detach().numpy()) < 1e-6
     dt = ops.l41_speaker_bwd(dev(table), Id, dev(g), normalize)
     assert rel(host(dt), tt.grad.numpy()) < 1e-5
+
+
+@pytest.mark.parametrize('pre,norm,silent_db', [('sqrt', 'meanstd', 0), ('log', '01', 0), (None, '01', 0), ('sqrt', None, 30.0),
+                                                (None, 'meanstd', 12.0)])
+def test_input_conditioning_matches_oracle(ops, pre, norm, silent_db):
+    """Separator.init_separator STFT branch (network.py:427-443) chained exactly as the host mirror chains it."""
+    from oracle import separate as osep
+    rng = np.random.RandomState(17)
+    X = np.abs(rng.randn(3, 37, 65)) + 1e-3
+    ref = osep.stft_input_pipeline(X.copy(), pre, norm, silent_db)
+    z = dev(X)
+    if pre:
+        z = ops.row_transform(z, pre=pre)
+    if norm:
+        z = ops.row_transform(z, norm=norm)
+    if silent_db > 0:
+        z = ops.row_transform(z, norm='silent', thr=silent_db / 20.)
+    assert rel(host(z), ref) < 2e-5
+    assert rel(host(ops.row_transform(dev(-X), pre='abs')), X) < 1e-7
+
+
+@pytest.mark.parametrize('mode,sil', [('linear', None), ('sqrt', 2.0), ('square', None), (None, 1.0)])
+def test_mask_weighting_and_silence_weights(ops, mode, sil):
+    """network.py:381-396 mask weightings and Kmeans_2.py:76-80 'notsilent' weights."""
+    from oracle import separate as osep
+    rng = np.random.RandomState(23)
+    B, T, Fq, S = 2, 31, 40, 3
+    X = rng.randn(B, T, Fq)
+    y = np.eye(S)[rng.randint(0, S, (B, T, Fq))]
+    ref = y.copy()
+    if mode:
+        ref = osep.function_mask(ref, X, mode)
+    if sil is not None:
+        ref = osep.silence_loss_mask(ref, X, sil)
+    got = ops.weight_masks(dev(X).view(B, T * Fq), dev(y).view(B, T * Fq, S), mode, sil)
+    assert rel(host(got).reshape(ref.shape), ref) < 1e-5
+    w_ref = osep.kmeans_silence_weights(np.abs(X), 1.5)
+    w = ops.silence_weights(dev(np.abs(X)).view(B, T * Fq), 1.5)
+    # a bin sitting exactly on the threshold may flip in fp32: allow a handful
+    assert (host(w) != w_ref).sum() <= 2
