@@ -460,16 +460,23 @@ def overlap_metric(y, B, S):
     return OverlapMetric.apply(_c(y), B, S)
 
 
+class PretrainSeparator(Function):
+    """Adapt.separator pretraining branch (adapt.py:173-196)."""
+
+    @staticmethod
+    def forward(ctx, y, B, S, separation):
+        ctx.cfg = (B, S, separation)
+        return ops.pretrain_separator_fwd(y, B, S, separation)
+
+    @staticmethod
+    def backward(ctx, dout):
+        B, S, separation = ctx.cfg
+        return ops.pretrain_separator_bwd(_c(dout), B, S, separation), None, None, None
+
+
 def pretrain_separator(y, B, S, separation):
-    """Adapt.separator pretraining branch (adapt.py:173-196); elementwise glue on the front output."""
-    T, N = y.shape[1:]
-    mix = y[:B].unsqueeze(1)
-    nm = y[B:].reshape(B, S, T, N)
-    if separation == 'mask':
-        out = mix * (nm / mix)
-    else:
-        out = mix - (nm.sum(dim=1, keepdim=True) - nm)
-    return out.reshape(B * S, T, N)
+    """y [B(1+S), T, N] -> [B*S, T, N]."""
+    return PretrainSeparator.apply(_c(y), B, S, separation)
 
 
 def sumsq(x):

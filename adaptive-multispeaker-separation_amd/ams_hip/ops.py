@@ -466,6 +466,25 @@ def silence_weights(lat, thr):
     return w
 
 
+def pretrain_separator_fwd(y, B, S, separation):
+    """adapt.py:173-196: y [B(1+S), T, N] -> [B*S, T, N]."""
+    _chk(y)
+    TN = y.numel() // y.shape[0]
+    out = torch.empty((B * S,) + tuple(y.shape[1:]), dtype=torch.float32, device=y.device)
+    check(load().ams_pretrain_separator_fwd(_p(y), _p(out), B, S, TN, 0 if separation == 'mask' else 1, _s()),
+          'ams_pretrain_separator_fwd')
+    return out
+
+
+def pretrain_separator_bwd(dout, B, S, separation):
+    _chk(dout)
+    TN = dout.numel() // dout.shape[0]
+    dy = torch.empty((B * (1 + S),) + tuple(dout.shape[1:]), dtype=torch.float32, device=dout.device)
+    check(load().ams_pretrain_separator_bwd(_p(dout), _p(dy), B, S, TN, 0 if separation == 'mask' else 1, _s()),
+          'ams_pretrain_separator_bwd')
+    return dy
+
+
 # ------------------------------------------------------------------ enhance output stage / L41 speaker vectors
 _NONLIN = {None: 0, 'None': 0, 'none': 0, 'softmax': 1, 'tanh': 2}
 

@@ -99,9 +99,58 @@ __global__ __launch_bounds__(256) void silence_weights_kernel(const float* __res
     for (long i = threadIdx.x; i < n; i += 256) w[(long)blockIdx.x * n + i] = (log10f(mx / r[i]) < thr) ? 1.f : 0.f;
 }
 
+// Oracle separator of the pre-training objective (adapt.py:173-196).  y rows: B mixtures then (b,s) sources, TN values each.
+//   mode 0 'mask'    : out[b,s] = mix * (nm[b,s] / mix)          (NaN where mix == 0, quirk C-4, kept)
+//   mode 1 'perfect' : out[b,s] = mix - (sum_s' nm[b,s'] - nm[b,s])
+__global__ __launch_bounds__(256) void pretrain_sep_fwd_kernel(const float* __restrict__ y, float* __restrict__ out, int B, int S,
+                                                               long TN, int mode) {
+    const int b = blockIdx.y;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < TN; p += (long)gridDim.x * 256) {
+        const float mix = y[(long)b * TN + p];
+        float tot = 0.f;
+        if (mode == 1)
+            for (int s = 0; s < S; ++s) tot += y[((long)B + (long)b * S + s) * TN + p];
+        for (int s = 0; s < S; ++s) {
+            const float nm = y[((long)B + (long)b * S + s) * TN + p];
+            out[((long)b * S + s) * TN + p] = mode == 0 ? mix * (nm / mix) : mix - (tot - nm);
+        }
+    }
+}
+// dy (all rows, fully written).  mask: d/d nm = 1, d/d mix = 0 (the two autodiff terms cancel);  perfect: d/d mix = sum_s d,
+// d/d nm[s] = -(sum_s' d - d[s]).
+__global__ __launch_bounds__(256) void pretrain_sep_bwd_kernel(const float* __restrict__ dout, float* __restrict__ dy, int B, int S,
+                                                               long TN, int mode) {
+    const int b = blockIdx.y;
+    for (long p = (long)blockIdx.x * 256 + threadIdx.x; p < TN; p += (long)gridDim.x * 256) {
+        float tot = 0.f;
+        for (int s = 0; s < S; ++s) tot += dout[((long)b * S + s) * TN + p];
+        dy[(long)b * TN + p] = mode == 0 ? 0.f : tot;
+        for (int s = 0; s < S; ++s) {
+            const float d = dout[((long)b * S + s) * TN + p];
+            dy[((long)B + (long)b * S + s) * TN + p] = mode == 0 ? d : -(tot - d);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+// y [B(1+S), TN] -> out [B*S, TN];  mode 0 mask, 1 perfect
+ams_status ams_pretrain_separator_fwd(const float* y, float* out, int B, int S, long TN, int mode, void* stream) {
+    AMS_REQUIRE(y && out && B > 0 && S > 0 && TN > 0 && (mode == 0 || mode == 1));
+    int bx = (int)((TN + 255) / 256);
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(pretrain_sep_fwd_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, y, out, B, S, TN, mode);
+    return ams_check_launch();
+}
+ams_status ams_pretrain_separator_bwd(const float* dout, float* dy, int B, int S, long TN, int mode, void* stream) {
+    AMS_REQUIRE(dout && dy && B > 0 && S > 0 && TN > 0 && (mode == 0 || mode == 1));
+    int bx = (int)((TN + 255) / 256);
+    if (bx > 2048) bx = 2048;
+    hipLaunchKernelGGL(pretrain_sep_bwd_kernel, dim3(bx, B), dim3(256), 0, (hipStream_t)stream, dout, dy, B, S, TN, mode);
+    return ams_check_launch();
+}
 
 // pre: 0 none, 1 abs, 2 sqrt, 3 log10(x + 1e-12);  norm: 0 none, 1 (z-min)/(max-min), 2 (z-mean)/sqrt(var), 3 z*[max-z < thr]
 ams_status ams_row_transform(const float* x, float* out, int rows, long n, int pre, int norm, float thr, void* stream) {

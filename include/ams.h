@@ -149,6 +149,12 @@ ams_status ams_row_transform(const float* x, float* out, int rows, long n, int p
 ams_status ams_weight_masks(const float* X, float* y, int B, long TF, int S, int mode, int use_silence, float sil_thr, void* stream);
 ams_status ams_silence_weights(const float* lat, float* w, int rows, long n, float thr, void* stream);
 
+/* ---- pre-training oracle separator   models/adapt.py:173-196 ----
+ * y [B(1+S), TN] (B mixture rows, then (b,s) source rows) -> out [B*S, TN]; mode 0 'mask' = mix*(nm/mix), 1 'perfect' =
+ * mix - (sum of the other sources).  bwd writes dy for all rows. */
+ams_status ams_pretrain_separator_fwd(const float* y, float* out, int B, int S, long TN, int mode, void* stream);
+ams_status ams_pretrain_separator_bwd(const float* dout, float* dy, int B, int S, long TN, int mode, void* stream);
+
 /* ---- K24  optimizers     models/network.py:181-194, utils/ops.py:686-703 ---- */
 ams_status ams_opt_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, long n, float lr_t, float beta1,
                            float beta2, float eps, float grad_scale, void* stream);
