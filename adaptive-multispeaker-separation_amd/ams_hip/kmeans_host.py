@@ -35,8 +35,20 @@ class KMeans(object):
         if self.init_indices is not None:
             v = self.init_indices.value(run) if hasattr(self.init_indices, 'value') else self.init_indices
             return torch.as_tensor(np.asarray(v), dtype=torch.int32, device=device).contiguous()
-        # Kmeans_2.py:61-65: np.random.choice(range(l), size=C, replace=False) per row, global numpy RNG
-        a = np.array([np.random.choice(range(L), size=self.nb_clusters, replace=False) for _ in range(R)])
+        # Kmeans_2.py:61-65 draws np.random.choice(range(l), size=C, replace=False) per row from the GLOBAL numpy RNG inside a
+        # py_func: C distinct bins per row, uniformly.  That call permutes all l bins for every row (0.2-0.5 ms each, 640 rows at
+        # the benchmark shape = the whole inference budget) and its stream position is not reproducible from the reference anyway
+        # (SURVEY App. C-6), so the same distribution is drawn in one vectorised call from the same global RNG; rows that came
+        # out with a repeated index (probability ~ C^2/2l) are redrawn.
+        C = self.nb_clusters
+        a = np.random.randint(0, L, size=(R, C))
+        if C > 1:
+            while True:
+                srt = np.sort(a, axis=1)
+                bad = np.flatnonzero((srt[:, 1:] == srt[:, :-1]).any(axis=1))
+                if bad.size == 0:
+                    break
+                a[bad] = np.random.randint(0, L, size=(bad.size, C))
         return torch.from_numpy(a.astype(np.int32)).to(device)
 
     def _run(self, run):

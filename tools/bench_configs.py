@@ -1,0 +1,199 @@
+"""Secondary timings for the other BASELINE.json configs -- not the headline metric (bench.py).
+
+usage: python tools/bench_configs.py [--steps 10] [--warmup 3] [--only name,...]  ->  one JSON line per workload.
+Eager launches (no hipGraph), synthetic data, random weights of the named shapes; training steps include the optimizer.
+"""
+import argparse
+import contextlib
+import json
+import os
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, 'adaptive-multispeaker-separation_amd')
+for _p in (ROOT, PKG):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+
+def _args(**kw):
+    from ams_hip import testing
+    a = dict(testing.ADAPT_DEFAULTS)
+    a.update(testing.SEPARATOR_DEFAULTS)
+    a.update(testing.ENHANCE_DEFAULTS)
+    a.update(kw)
+    return a
+
+
+def _time_train(trainer, tfds, L, steps, warmup):
+    import torch
+    g, model = trainer.graph, trainer.model
+    with g.as_default():
+        feed = {tfds.handle: tfds.get_handle(tfds.TRAIN), tfds.chunk_size: L}
+        for i in range(warmup):
+            c = model.train(feed, i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            c = model.train(feed, warmup + i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps, float(c)
+
+
+def _time_infer(trainer, tfds, L, steps, warmup):
+    import torch
+    g, model = trainer.graph, trainer.model
+    with g.as_default():
+        feed = {tfds.handle: tfds.get_handle(tfds.TEST), tfds.chunk_size: L}
+        for i in range(warmup):
+            model.infer(feed, i)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            out = model.infer(feed, warmup + i)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps, float(out[2].float().abs().mean())
+
+
+def _front_dpcl_checkpoint(tmp, sep_cls, typ, B, S, L, N, extra=None):
+    """A folder holding front/back + prediction (+speaker_centroids) variables, as a finished front_<sep> run leaves it."""
+    from ams_hip import testing
+    from utils.trainer import Front_Separator_Trainer
+    folder, params = testing.make_pretrained_adapt(os.path.join(tmp, 'pre'), window_size=1024, filters=N, hop_size=256, chunk_size=L,
+                                                   batch_size=B, nb_speakers=S)
+    a = _args(**params)
+    a.update(model_folder=folder, model_previous=None, pretraining=False, layer_size=600, nb_layers=3, embedding_size=40,
+             batch_size=B, nb_speakers=S, learning_rate=1e-3)
+    a.update(extra or {})
+    a.pop('type')
+    tr = Front_Separator_Trainer(sep_cls, typ, **a)
+    dist, tfds = tr.prepare()
+    return tr, tfds, a
+
+
+def wl_pretraining(steps, warmup, with_max_pool=False, B=64):
+    from utils.trainer import Adapt_Pretrainer
+    L = 20480
+    a = _args(window_size=1024, filters=256, max_pool=256, hop_size=256, chunk_size=L, batch_size=B, nb_speakers=2, loss='sdr+l2',
+              separation='mask', beta=0.0, regularization=0.0, overlap_coef=1.0, with_max_pool=with_max_pool, learning_rate=1e-3)
+    a.pop('type')
+    tr = Adapt_Pretrainer(**a)
+    dist, tfds = tr.prepare()
+    dt, c = _time_train(tr, tfds, L, steps, warmup)
+    return {'workload': 'cfg2 pretraining step, path %s, B=%d, W=1024 hop=256 N=256' % ('B (max-pool)' if with_max_pool else 'A (strided)', B),
+            'batch': B, 'ms_per_step': dt * 1e3, 'mixtures_per_s': B / dt, 'cost': c}
+
+
+def wl_front_dpcl_finetuning(steps, warmup, B=64):
+    from models.dpcl import DPCL
+    from utils.trainer import Front_Separator_Finetuning_Trainer
+    tmp = tempfile.mkdtemp(prefix='ams_bc_')
+    L, S, N = 20480, 2, 256
+    tr0, tfds0, a = _front_dpcl_checkpoint(tmp, DPCL, 'front_DPCL', B, S, L, N)
+    with tr0.graph.as_default():
+        tr0.model.create_saver()
+        tr0.model.save(0)
+        folder = tr0.model._dir()
+    del tr0
+    a.update(model_folder=folder, nb_tries=1, nb_steps=10, beta_kmeans=10.0, with_silence=True, threshold=2.0, end_assign=True,
+             loss='sdr+l2', optimizer='RMSProp', learning_rate=1e-4)
+    tr = Front_Separator_Finetuning_Trainer(DPCL, 'front_L41_finetuning', **a)
+    dist, tfds = tr.prepare()
+    dt, c = _time_train(tr, tfds, L, steps, warmup)
+    return {'workload': 'cfg3(ii) front_DPCL_finetuning step: soft k-means beta=10, 1 try x 10 steps, silence weights, back end, PIT cost, RMSProp',
+            'batch': B, 'ms_per_step': dt * 1e3, 'mixtures_per_s': B / dt, 'cost': c}
+
+
+def wl_front_dpcl_inference(steps, warmup, B=64):
+    from models.dpcl import DPCL
+    from utils.trainer import Front_Separator_Inference
+    tmp = tempfile.mkdtemp(prefix='ams_bc_')
+    L, S, N = 20480, 2, 256
+    tr0, tfds0, a = _front_dpcl_checkpoint(tmp, DPCL, 'front_DPCL', B, S, L, N)
+    with tr0.graph.as_default():
+        tr0.model.create_saver()
+        tr0.model.save(0)
+        folder = tr0.model._dir()
+    del tr0
+    a.update(model_folder=folder, nb_tries=10, nb_steps=10, end_assign=True, out=False)
+    tr = Front_Separator_Inference(DPCL, 'front_DPCL_inference', **a)
+    dist, tfds = tr.prepare()
+    dt, c = _time_infer(tr, tfds, L, steps, warmup)
+    return {'workload': 'front_DPCL inference: front -> 3xBLSTM -> hard k-means (10 tries x 10 steps) -> masks -> back',
+            'batch': B, 'ms_per_step': dt * 1e3, 'mixtures_per_s': B / dt, 'mean_abs_out': c}
+
+
+def wl_stft_l41(steps, warmup, enhance=False, B=64):
+    from models.L41 import L41Model
+    from utils.trainer import STFT_Separator_Trainer, STFT_Separator_enhance_Trainer
+    L, S = 20480, 2
+    a = _args(window_size=512, hop_size=256, chunk_size=L, batch_size=B, nb_speakers=S, layer_size=600, nb_layers=3, embedding_size=40,
+              model_folder=None, learning_rate=1e-3, pretraining=False, tot_speakers=251)
+    for k in ('filters', 'max_pool', 'type'):
+        a.pop(k)
+    tr = STFT_Separator_Trainer(L41Model, 'STFT_L41', **dict(a))
+    dist, tfds = tr.prepare()
+    if not enhance:
+        dt, c = _time_train(tr, tfds, L, steps, warmup)
+        return {'workload': 'cfg4 STFT_L41 training step: |STFT| (W=512) -> 3xBLSTM -> L41 loss, AMSGrad', 'batch': B,
+                'ms_per_step': dt * 1e3, 'mixtures_per_s': B / dt, 'cost': c}
+    with tr.graph.as_default():
+        tr.model.create_saver()
+        tr.model.save(0)
+        folder = tr.model._dir()
+    del tr
+    a.update(model_folder=folder, nb_tries=10, nb_steps=10, end_assign=True, nonlinearity='softmax')
+    tr = STFT_Separator_enhance_Trainer(L41Model, 'STFT_L41_enhance', **a)
+    dist, tfds = tr.prepare()
+    dt, c = _time_train(tr, tfds, L, steps, warmup)
+    return {'workload': 'cfg4 STFT_L41_enhance training step: frozen L41 + hard k-means (10x10) + 3xBLSTM enhance stack, PIT cost', 'batch': B,
+            'ms_per_step': dt * 1e3, 'mixtures_per_s': B / dt, 'cost': c}
+
+
+def wl_front_l41_s3(steps, warmup, B=128):
+    from models.L41 import L41Model
+    tmp = tempfile.mkdtemp(prefix='ams_bc_')
+    L, S, N = 20480, 3, 512
+    tr, tfds, a = _front_dpcl_checkpoint(tmp, L41Model, 'front_L41', B, S, L, N, extra={'tot_speakers': 251})
+    dt, c = _time_train(tr, tfds, L, steps, warmup)
+    return {'workload': 'cfg5 front_L41 training step: S=3, N=512 filters, B=128 per GPU, 3xBLSTM(600), L41 loss', 'batch': B,
+            'ms_per_step': dt * 1e3, 'mixtures_per_s': B / dt, 'cost': c}
+
+
+WORKLOADS = {
+    'pretraining_A': lambda s, w: wl_pretraining(s, w, False),
+    'pretraining_B_maxpool': lambda s, w: wl_pretraining(s, w, True),
+    'front_DPCL_finetuning': wl_front_dpcl_finetuning,
+    'front_DPCL_inference': wl_front_dpcl_inference,
+    'STFT_L41': lambda s, w: wl_stft_l41(s, w, False),
+    'STFT_L41_enhance': lambda s, w: wl_stft_l41(s, w, True),
+    'front_L41_S3_N512_B128': wl_front_l41_s3,
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--only', default='')
+    args = ap.parse_args()
+    os.environ.setdefault('AMS_LOG_DIR', tempfile.mkdtemp(prefix='ams_bc_log_'))
+    names = [n for n in args.only.split(',') if n] or list(WORKLOADS)
+    for n in names:
+        try:
+            with contextlib.redirect_stdout(sys.stderr):
+                r = WORKLOADS[n](args.steps, args.warmup)
+            r = dict(name=n, **{k: (float('%.6g' % v) if isinstance(v, float) else v) for k, v in r.items()})
+        except Exception as e:                                      # keep going: one JSON line per workload either way
+            import traceback
+            traceback.print_exc()
+            r = {'name': n, 'error': '%s: %s' % (type(e).__name__, e)}
+        print(json.dumps(r), flush=True)
+        import torch
+        torch.cuda.empty_cache()
+
+
+if __name__ == '__main__':
+    main()
