@@ -23,18 +23,27 @@ def soft_bwd(xn, inv, init_idx, best, w, trace, dsel, dout, C, tries, iterations
         wsel = w[wrow].contiguous()
     nb = lib.ams_kmeans_workspace_bytes(b, L, E, C)
     ws = ops._ws(nb, xn)
-    dxn = torch.zeros_like(xn)
     g = dsel.contiguous().clone() if dsel is not None else torch.zeros((b, C, E), dtype=torch.float32, device=dev)
     p, s = ops._p, ops._s
+    w_final = None if assign_at_end else wsel
+    # phase 1: centroid gradients only (dx == NULL): one read of xn per pass, no read-modify-write of dx
     if dout is not None:
-        w_final = None if assign_at_end else wsel
-        check(lib.ams_kmeans_soft_bwd_pass(p(xn), p(w_final), p(cents[-1]), p(None), p(None), p(None), p(dout.contiguous()), p(dxn), p(g),
+        dout = dout.contiguous()
+        check(lib.ams_kmeans_soft_bwd_pass(p(xn), p(w_final), p(cents[-1]), p(None), p(None), p(None), p(dout), p(None), p(g),
                                            b, L, E, C, float(beta), 0, p(ws), nb, s()), 'ams_kmeans_soft_bwd_pass(final)')
+    gs = torch.empty((max(iterations, 1), b, C, E), dtype=torch.float32, device=dev)
     for i in range(iterations - 1, -1, -1):
+        gs[i].copy_(g)
         g_new = torch.empty_like(g)
-        check(lib.ams_kmeans_soft_bwd_pass(p(xn), p(wsel), p(cents[i]), p(cents[i + 1]), p(dens[i]), p(g), p(None), p(dxn), p(g_new),
+        check(lib.ams_kmeans_soft_bwd_pass(p(xn), p(wsel), p(cents[i]), p(cents[i + 1]), p(dens[i]), p(gs[i]), p(None), p(None), p(g_new),
                                            b, L, E, C, float(beta), 1, p(ws), nb, s()), 'ams_kmeans_soft_bwd_pass(iter)')
         g = g_new
+    # phase 2: dx of the final assignment and of every iteration in ONE pass over xn
+    dxn = torch.empty_like(xn)
+    cst = torch.stack(cents).contiguous()
+    dst = torch.stack(dens).contiguous() if iterations else None
+    check(lib.ams_kmeans_soft_bwd_dx(p(xn), p(wsel), p(w_final), p(cst), p(gs if iterations else None), p(dst), p(dout), p(dxn),
+                                     b, L, E, C, float(beta), iterations, s()), 'ams_kmeans_soft_bwd_dx')
     # c_0 = xn[idx]: scatter-add the remaining centroid gradient onto the picked points (tiny: b*C rows)
     idx_sel = init_idx[index].long()                                   # [b, C]
     rows = torch.arange(b, device=dev).unsqueeze(1).expand(b, C)

@@ -218,6 +218,12 @@ ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent
 ams_status ams_kmeans_soft_bwd_pass(const float* xn, const float* w, const float* cent, const float* cent_next, const float* den,
                                     const float* g_in, const float* dout, float* dx, float* g_out, int b, long L, int E, int C,
                                     float beta, int iter_mode, void* ws, size_t ws_bytes, void* stream);
+/* two-phase form: call ams_kmeans_soft_bwd_pass with dx == NULL for every iteration (centroid gradients only), then ONE
+ * ams_kmeans_soft_bwd_dx over xn: cents [n_it+1,b,C,E] = c_0..c_n, gs [n_it,b,C,E] = gradient w.r.t. c_{i+1} consumed by
+ * iteration i, dens [n_it,b,C]; dout [b,L,C] (may be NULL) = gradient of the returned soft labels, w_final its weights. */
+ams_status ams_kmeans_soft_bwd_dx(const float* xn, const float* w, const float* w_final, const float* cents, const float* gs,
+                                  const float* dens, const float* dout, float* dx, int b, long L, int E, int C, float beta, int n_it,
+                                  void* stream);
 ams_status ams_kmeans_assign(const float* xn, const float* w, const float* cent, int32_t* labels, float* soft, float* inertia, int b,
                              int tries, long L, int E, int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* stream);
 ams_status ams_kmeans_select(const float* inertia, const float* centroids, int32_t* best, float* selected, int b, int tries, int E,
