@@ -355,9 +355,16 @@ def _diag(t):
     return torch.diagonal(t, dim1=1, dim2=2)
 
 
+_PERM_CACHE = {}
+
+
 def _perm_table(S, device):
-    from itertools import permutations
-    return torch.tensor(list(permutations(range(S))), dtype=torch.long, device=device)      # lexicographic (App. A-14)
+    """[S!, S] permutations in lexicographic order (App. A-14); cached per device so a hipGraph capture never sees the upload."""
+    key = (S, str(device))
+    if key not in _PERM_CACHE:
+        from itertools import permutations
+        _PERM_CACHE[key] = torch.tensor(list(permutations(range(S))), dtype=torch.long, device=device)
+    return _PERM_CACHE[key]
 
 
 def sdr_improvement(x_mix, s_target, s_approx, with_perm=False):
@@ -495,7 +502,7 @@ def abs_colsum(y2):
 def kl_sparsity(p_hat, p):
     def logfunc(a, b):
         return a * torch.log(torch.clamp(a, 1e-10, 1.0) / torch.clamp(b, 1e-10, 1.0))
-    pt = torch.as_tensor(p, dtype=p_hat.dtype, device=p_hat.device)
+    pt = torch.full((), float(p), dtype=p_hat.dtype, device=p_hat.device)      # fill kernel, capturable
     return (logfunc(pt, p_hat) + logfunc(1 - pt, 1 - p_hat)).sum()
 
 

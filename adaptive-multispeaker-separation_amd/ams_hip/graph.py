@@ -28,6 +28,9 @@ class Graph(object):
         self.summaries = OrderedDict()          # name -> Node (scalar summaries, reference tf.summary.scalar)
         self.device = device or torch.device('cuda' if torch.cuda.is_available() else 'cpu')
         self.seed = 42
+        # host-side inputs that must be refreshed before every hipGraph replay (e.g. the k-means seeds drawn from the host RNG):
+        # callables run by Network._train_graphed right before graph.replay()
+        self.pre_replay_hooks = []
 
     @contextlib.contextmanager
     def as_default(self):

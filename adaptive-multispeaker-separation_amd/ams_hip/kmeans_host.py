@@ -31,10 +31,7 @@ class KMeans(object):
         self.network = (Node('centroids', lambda run: self._result.value(run)[0], register=False),
                         Node('labels', lambda run: self._result.value(run)[1], register=False))
 
-    def _init_idx(self, run, R, L, device):
-        if self.init_indices is not None:
-            v = self.init_indices.value(run) if hasattr(self.init_indices, 'value') else self.init_indices
-            return torch.as_tensor(np.asarray(v), dtype=torch.int32, device=device).contiguous()
+    def _draw(self, R, L):
         # Kmeans_2.py:61-65 draws np.random.choice(range(l), size=C, replace=False) per row from the GLOBAL numpy RNG inside a
         # py_func: C distinct bins per row, uniformly.  That call permutes all l bins for every row (0.2-0.5 ms each, 640 rows at
         # the benchmark shape = the whole inference budget) and its stream position is not reproducible from the reference anyway
@@ -49,7 +46,36 @@ class KMeans(object):
                 if bad.size == 0:
                     break
                 a[bad] = np.random.randint(0, L, size=(bad.size, C))
-        return torch.from_numpy(a.astype(np.int32)).to(device)
+        return torch.from_numpy(a.astype(np.int32))
+
+    def _init_idx(self, run, R, L, device):
+        if self.init_indices is not None:
+            v = self.init_indices.value(run) if hasattr(self.init_indices, 'value') else self.init_indices
+            return torch.as_tensor(np.asarray(v), dtype=torch.int32, device=device).contiguous()
+        # persistent device buffer: under hipGraph capture the host draw cannot be part of the graph, so the buffer is
+        # re-filled by a pre-replay hook (graph.pre_replay_hooks) and the captured kernels just read it
+        buf = getattr(self, '_idx_buf', None)
+        capturing = device.type == 'cuda' and torch.cuda.is_current_stream_capturing()
+        if buf is None or tuple(buf.shape) != (R, self.nb_clusters) or buf.device != device:
+            if capturing:
+                raise RuntimeError('k-means seed buffer must exist before hipGraph capture (run an eager step first)')
+            buf = self._idx_buf = torch.empty((R, self.nb_clusters), dtype=torch.int32, device=device)
+            self._idx_host = torch.empty((R, self.nb_clusters), dtype=torch.int32)
+            if device.type == 'cuda':
+                self._idx_host = self._idx_host.pin_memory()        # allocated eagerly: pinning is not allowed while capturing
+            self._hooked = False
+        if capturing:
+            if not getattr(self, '_hooked', False):
+                host = self._idx_host
+
+                def _refresh(buf=buf, host=host, R=R, L=L):
+                    host.copy_(self._draw(R, L))
+                    buf.copy_(host, non_blocking=True)
+                get_default_graph().pre_replay_hooks.append(_refresh)
+                self._hooked = True
+        else:
+            buf.copy_(self._draw(R, L))
+        return buf
 
     def _run(self, run):
         X = self.X_in.value(run)

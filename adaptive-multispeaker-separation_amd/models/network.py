@@ -251,6 +251,8 @@ class Network(object):
             st['graph'], st['cost'], st['run'] = g, cost, run
         for dst, src in zip(st['static'], ins):
             dst.copy_(src)
+        for hook in get_default_graph().pre_replay_hooks:      # host-drawn inputs of captured kernels (k-means seeds)
+            hook()
         st['graph'].replay()
         opt.step()
         self.last_run = st['run']

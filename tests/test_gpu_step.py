@@ -37,3 +37,50 @@ def test_hip_graph_replay_matches_eager():
     assert np.allclose(c_e, c_g, rtol=1e-6, atol=0), (c_e, c_g)
     for n in p_e:
         assert np.array_equal(p_e[n], p_g[n]) or np.abs(p_e[n] - p_g[n]).max() <= 1e-7 * max(1.0, np.abs(p_e[n]).max()), n
+
+
+def test_hip_graph_finetuning_step_refreshes_kmeans_seeds():
+    """--hip_graph on a recipe whose k-means seeds come from the host RNG (front_*_finetuning): the captured kernels read a
+    persistent index buffer that a pre-replay hook re-fills, so replayed steps see fresh seeds and the run equals the eager one
+    when the global numpy RNG is seeded identically."""
+    import os
+    import tempfile
+    from ams_hip import testing
+    from models.dpcl import DPCL
+    from utils.trainer import Front_Separator_Trainer, Front_Separator_Finetuning_Trainer
+    os.environ.setdefault('AMS_LOG_DIR', tempfile.mkdtemp(prefix='ams_log_'))
+
+    def run(graph):
+        tmp = tempfile.mkdtemp(prefix='ams_cgft_')
+        B, S, L, W, N, hop = 3, 2, 1024, 64, 16, 16
+        import utils.ops
+        utils.ops.rng.seed(42)
+        folder, params = testing.make_pretrained_adapt(os.path.join(tmp, 'pre'), window_size=W, filters=N, hop_size=hop, chunk_size=L,
+                                                       batch_size=B, nb_speakers=S)
+        a = dict(params)
+        a.update(testing.SEPARATOR_DEFAULTS)
+        a.update(layer_size=12, nb_layers=2, embedding_size=8, model_folder=folder, model_previous=None, pretraining=False,
+                 learning_rate=1e-3)
+        a.pop('type')
+        tr0 = Front_Separator_Trainer(DPCL, 'front_DPCL', **dict(a))
+        tr0.prepare()
+        with tr0.graph.as_default():
+            tr0.model.create_saver()
+            tr0.model.save(0)
+            folder2 = tr0.model._dir()
+        a.update(model_folder=folder2, nb_tries=2, nb_steps=3, beta_kmeans=4.0, with_silence=True, threshold=2.0, end_assign=True,
+                 loss='sdr+l2', optimizer='RMSProp', learning_rate=1e-4, hip_graph=graph, no_summaries=True)
+        tr = Front_Separator_Finetuning_Trainer(DPCL, 'front_L41_finetuning', **a)
+        dist, tfds = tr.prepare()
+        np.random.seed(7)
+        costs = []
+        with tr.graph.as_default():
+            feed = {tfds.handle: tfds.get_handle(tfds.TRAIN), tfds.chunk_size: L}
+            for i in range(6):
+                costs.append(float(tr.model.train(feed, i)))
+        torch.cuda.synchronize()
+        return costs
+
+    c_e, c_g = run(False), run(True)
+    assert np.allclose(c_e, c_g, rtol=1e-5), (c_e, c_g)
+    assert len(set(np.round(c_g, 6))) > 2                     # the replayed steps are not frozen on one set of seeds / one batch

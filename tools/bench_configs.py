@@ -86,7 +86,7 @@ def wl_pretraining(steps, warmup, with_max_pool=False, B=64):
             'batch': B, 'ms_per_step': dt * 1e3, 'mixtures_per_s': B / dt, 'cost': c}
 
 
-def wl_front_dpcl_finetuning(steps, warmup, B=64):
+def wl_front_dpcl_finetuning(steps, warmup, B=64, graph=False):
     from models.dpcl import DPCL
     from utils.trainer import Front_Separator_Finetuning_Trainer
     tmp = tempfile.mkdtemp(prefix='ams_bc_')
@@ -98,11 +98,12 @@ def wl_front_dpcl_finetuning(steps, warmup, B=64):
         folder = tr0.model._dir()
     del tr0
     a.update(model_folder=folder, nb_tries=1, nb_steps=10, beta_kmeans=10.0, with_silence=True, threshold=2.0, end_assign=True,
-             loss='sdr+l2', optimizer='RMSProp', learning_rate=1e-4)
+             loss='sdr+l2', optimizer='RMSProp', learning_rate=1e-4, hip_graph=graph)
     tr = Front_Separator_Finetuning_Trainer(DPCL, 'front_L41_finetuning', **a)
     dist, tfds = tr.prepare()
     dt, c = _time_train(tr, tfds, L, steps, warmup)
-    return {'workload': 'cfg3(ii) front_DPCL_finetuning step: soft k-means beta=10, 1 try x 10 steps, silence weights, back end, PIT cost, RMSProp',
+    return {'workload': 'cfg3(ii) front_DPCL_finetuning step%s: soft k-means beta=10, 1 try x 10 steps, silence weights, back end, PIT cost, RMSProp'
+                        % (' (hipGraph replay)' if graph else ''),
             'batch': B, 'ms_per_step': dt * 1e3, 'mixtures_per_s': B / dt, 'cost': c}
 
 
@@ -166,6 +167,7 @@ WORKLOADS = {
     'pretraining_A': lambda s, w: wl_pretraining(s, w, False),
     'pretraining_B_maxpool': lambda s, w: wl_pretraining(s, w, True),
     'front_DPCL_finetuning': wl_front_dpcl_finetuning,
+    'front_DPCL_finetuning_graph': lambda s, w: wl_front_dpcl_finetuning(s, max(w, 4), graph=True),
     'front_DPCL_inference': wl_front_dpcl_inference,
     'STFT_L41': lambda s, w: wl_stft_l41(s, w, False),
     'STFT_L41_enhance': lambda s, w: wl_stft_l41(s, w, True),
