@@ -64,44 +64,80 @@ struct KmArgs {
     float beta;
 };
 
-template <int E_, int C_, int MODE>
+typedef float f2 __attribute__((ext_vector_type(2)));
+
+// HAS_W: silence weights present.  Without them the reference multiplies by w = 1 (x*1 == x exactly), so the multiplies are
+// dropped.  Element-wise work is written on 2-vectors (v_pk_mul_f32 / v_pk_add_f32: IEEE per component, no FMA) while every
+// running sum keeps its left-to-right scalar order, so the result is bit-identical to the scalar formulation.
+template <int E_, int C_, int MODE, bool HAS_W>
 __global__ __launch_bounds__(256) void kmeans_pass_kernel(KmArgs a) {
+    static_assert(E_ % 4 == 0, "rows are staged as 16-byte vectors");
     constexpr bool ACC = (MODE == HARD_ACC || MODE == SOFT_ACC);
     constexpr bool SOFT = (MODE == SOFT_ACC || MODE == SOFT_FINAL);
     constexpr int NV = ACC ? C_ * (E_ + 1) : 2 * C_;
-    constexpr int LD = E_ + 1;
+    constexpr int LD = E_ + 4;                     // 16-byte aligned rows; 16 lanes x 16 B at this pitch cover all 64 banks
+    constexpr int V4 = E_ / 4, V2 = E_ / 2;
     constexpr int BUF = (256 * LD > 128 * 64) ? 256 * LD : 128 * 64;
-    __shared__ float buf[BUF];
-    __shared__ float scent[C_ * E_];
+    __shared__ __attribute__((aligned(16))) float buf[BUF];
+    __shared__ __attribute__((aligned(16))) float scent[C_ * E_];
     const int r = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int bi = r / a.tries;
     const float* xb = a.xn + (long)bi * a.L * E_;
-    const float* wb = a.w ? a.w + (long)(a.w_mod_b ? (r % a.b) : bi) * a.L : nullptr;
+    const float* wb = HAS_W ? a.w + (long)(a.w_mod_b ? (r % a.b) : bi) * a.L : nullptr;
     for (int i = tid; i < C_ * E_; i += 256) scent[i] = a.cent[(long)r * C_ * E_ + i];
 
     float acc[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) acc[i] = 0.f;
 
+    // slab j+1 is fetched into registers while slab j is being processed: without it every 256-point slab exposed a full
+    // HBM/L2 round trip (8 per workgroup) and the pass ran at 1/5 of its arithmetic rate
+    float4 pre[V4];
+    auto fetch = [&](int j) {
+        const long q0 = (long)g * CHUNK + (long)j * LANES;
+        const int np = (int)max((long)0, min((long)LANES, a.L - q0));
+        const float4* src = reinterpret_cast<const float4*>(xb + q0 * E_);
+#pragma unroll
+        for (int k = 0; k < V4; ++k) {
+            const int i = tid + 256 * k;
+            pre[k] = (i < np * V4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    fetch(0);
     for (int j = 0; j < PPL; ++j) {
         const long p0 = (long)g * CHUNK + (long)j * LANES;
         const int npts = (int)max((long)0, min((long)LANES, a.L - p0));
         __syncthreads();
-        for (int i = tid; i < npts * E_; i += 256) buf[(i / E_) * LD + (i % E_)] = xb[p0 * E_ + i];
+#pragma unroll
+        for (int k = 0; k < V4; ++k) {
+            const int i = tid + 256 * k;
+            const int row = i / V4, c4 = i - row * V4;
+            *reinterpret_cast<float4*>(&buf[row * LD + c4 * 4]) = pre[k];
+        }
         __syncthreads();
+        if (j + 1 < PPL) fetch(j + 1);
         if (tid < npts) {
             float x[E_];
 #pragma unroll
-            for (int e = 0; e < E_; ++e) x[e] = buf[tid * LD + e];
-            const float wv = wb ? wb[p0 + tid] : 1.0f;
+            for (int q = 0; q < V4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(&buf[tid * LD + q * 4]);
+                x[q * 4 + 0] = v.x; x[q * 4 + 1] = v.y; x[q * 4 + 2] = v.z; x[q * 4 + 3] = v.w;
+            }
+            const float wv = HAS_W ? wb[p0 + tid] : 1.0f;
+            const f2 wv2 = {wv, wv};
             float d2[C_];
 #pragma unroll
             for (int c = 0; c < C_; ++c) {
                 float d = 0.f;
 #pragma unroll
-                for (int e = 0; e < E_; ++e) {
-                    const float diff = __fsub_rn(x[e], scent[c * E_ + e]);
-                    d = __fadd_rn(d, __fmul_rn(__fmul_rn(diff, diff), wv));
+                for (int q = 0; q < V2; ++q) {
+                    const f2 xv = {x[2 * q], x[2 * q + 1]};
+                    const f2 cv = *reinterpret_cast<const f2*>(&scent[c * E_ + 2 * q]);
+                    const f2 diff = xv - cv;
+                    f2 sq = diff * diff;
+                    if (HAS_W) sq = sq * wv2;
+                    d = __fadd_rn(d, sq.x);
+                    d = __fadd_rn(d, sq.y);
                 }
                 d2[c] = d;
             }
@@ -117,8 +153,16 @@ __global__ __launch_bounds__(256) void kmeans_pass_kernel(KmArgs a) {
 #pragma unroll
                     for (int c = 0; c < C_; ++c) {
                         const float m = (lab == c) ? 1.0f : 0.0f;
+                        const f2 m2 = {m, m};
 #pragma unroll
-                        for (int e = 0; e < E_; ++e) acc[c * E_ + e] = __fadd_rn(acc[c * E_ + e], __fmul_rn(__fmul_rn(x[e], wv), m));
+                        for (int q = 0; q < V2; ++q) {
+                            f2 t = {x[2 * q], x[2 * q + 1]};
+                            if (HAS_W) t = t * wv2;
+                            t = t * m2;
+                            f2 av = {acc[c * E_ + 2 * q], acc[c * E_ + 2 * q + 1]};
+                            av = av + t;
+                            acc[c * E_ + 2 * q] = av.x; acc[c * E_ + 2 * q + 1] = av.y;
+                        }
                         acc[C_ * E_ + c] = __fadd_rn(acc[C_ * E_ + c], m);
                     }
                 } else {
@@ -172,7 +216,8 @@ __global__ __launch_bounds__(256) void kmeans_pass_kernel(KmArgs a) {
             }
         }
     }
-    // halving tree over the 256 lanes: s = 128, 64 through LDS (in batches of <= 64 values), s = 32..1 by shuffles.
+    // halving tree over the 256 lanes: s = 128, 64 through LDS (in batches of <= 64 values, VALUE-major so the 64 lanes of a
+    // wave touch 64 consecutive words -- lane-major put every lane on one bank: 64-way conflicts), s = 32..1 by shuffles.
     // NV is a compile-time constant, so both loops unroll fully and `acc` stays in registers.
 #pragma unroll
     for (int v0 = 0; v0 < NV; v0 += 64) {
@@ -180,25 +225,25 @@ __global__ __launch_bounds__(256) void kmeans_pass_kernel(KmArgs a) {
         if (wave >= 2) {
 #pragma unroll
             for (int i = 0; i < 64; ++i)
-                if (v0 + i < NV) buf[((wave - 2) * 64 + lane) * 64 + i] = acc[v0 + i];
+                if (v0 + i < NV) buf[i * 128 + (wave - 2) * 64 + lane] = acc[v0 + i];
         }
         __syncthreads();
         if (wave < 2) {
 #pragma unroll
             for (int i = 0; i < 64; ++i)
-                if (v0 + i < NV) acc[v0 + i] = __fadd_rn(acc[v0 + i], buf[(wave * 64 + lane) * 64 + i]);
+                if (v0 + i < NV) acc[v0 + i] = __fadd_rn(acc[v0 + i], buf[i * 128 + wave * 64 + lane]);
         }
         __syncthreads();
         if (wave == 1) {
 #pragma unroll
             for (int i = 0; i < 64; ++i)
-                if (v0 + i < NV) buf[lane * 64 + i] = acc[v0 + i];
+                if (v0 + i < NV) buf[i * 64 + lane] = acc[v0 + i];
         }
         __syncthreads();
         if (wave == 0) {
 #pragma unroll
             for (int i = 0; i < 64; ++i)
-                if (v0 + i < NV) acc[v0 + i] = __fadd_rn(acc[v0 + i], buf[lane * 64 + i]);
+                if (v0 + i < NV) acc[v0 + i] = __fadd_rn(acc[v0 + i], buf[i * 64 + lane]);
         }
     }
     if (wave == 0) {
@@ -367,25 +412,25 @@ __global__ __launch_bounds__(256) void kmeans_soft_bwd_kernel(KmBwdArgs a) {
         if (wave >= 2) {
 #pragma unroll
             for (int i = 0; i < 64; ++i)
-                if (v0 + i < NV) buf[((wave - 2) * 64 + lane) * 64 + i] = acc[v0 + i];
+                if (v0 + i < NV) buf[i * 128 + (wave - 2) * 64 + lane] = acc[v0 + i];
         }
         __syncthreads();
         if (wave < 2) {
 #pragma unroll
             for (int i = 0; i < 64; ++i)
-                if (v0 + i < NV) acc[v0 + i] += buf[(wave * 64 + lane) * 64 + i];
+                if (v0 + i < NV) acc[v0 + i] += buf[i * 128 + wave * 64 + lane];
         }
         __syncthreads();
         if (wave == 1) {
 #pragma unroll
             for (int i = 0; i < 64; ++i)
-                if (v0 + i < NV) buf[lane * 64 + i] = acc[v0 + i];
+                if (v0 + i < NV) buf[i * 64 + lane] = acc[v0 + i];
         }
         __syncthreads();
         if (wave == 0) {
 #pragma unroll
             for (int i = 0; i < 64; ++i)
-                if (v0 + i < NV) acc[v0 + i] += buf[lane * 64 + i];
+                if (v0 + i < NV) acc[v0 + i] += buf[i * 64 + lane];
         }
     }
     if (wave == 0) {
@@ -511,7 +556,9 @@ __global__ void kmeans_bwd_reduce_kernel(const float* __restrict__ part, float* 
 template <int MODE>
 ams_status launch_pass(const KmArgs& a, int R, int E, int C, hipStream_t st) {
     dim3 grid(a.G, R);
-#define AMS_KM(EE, CC) hipLaunchKernelGGL((kmeans_pass_kernel<EE, CC, MODE>), grid, dim3(256), 0, st, a)
+    const bool hw = a.w != nullptr;
+#define AMS_KM(EE, CC) do { if (hw) hipLaunchKernelGGL((kmeans_pass_kernel<EE, CC, MODE, true>), grid, dim3(256), 0, st, a); \
+                            else hipLaunchKernelGGL((kmeans_pass_kernel<EE, CC, MODE, false>), grid, dim3(256), 0, st, a); } while (0)
     if (E == 40 && C == 2) AMS_KM(40, 2);
     else if (E == 40 && C == 3) AMS_KM(40, 3);
     else if (E == 40 && C == 4) AMS_KM(40, 4);
