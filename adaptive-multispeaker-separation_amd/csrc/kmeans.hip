@@ -103,11 +103,15 @@ __global__ __launch_bounds__(256) void kmeans_pass_kernel(KmArgs a) {
             pre[k] = (i < np * V4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
-    fetch(0);
+    // measured, b = 64, L = 20480, 10 iterations: hard (640 rows, 6400 workgroups) 4.31 -> 3.82 ms with the prefetch; soft
+    // (64 rows, 640 workgroups = 2.5 per CU, exp-heavy) 0.80 -> 1.15 ms -- so it is on for the hard modes only
+    constexpr bool PF = !SOFT;
+    if (PF) fetch(0);
     for (int j = 0; j < PPL; ++j) {
         const long p0 = (long)g * CHUNK + (long)j * LANES;
         const int npts = (int)max((long)0, min((long)LANES, a.L - p0));
         __syncthreads();
+        if (!PF) fetch(j);
 #pragma unroll
         for (int k = 0; k < V4; ++k) {
             const int i = tid + 256 * k;
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(256) void kmeans_pass_kernel(KmArgs a) {
             *reinterpret_cast<float4*>(&buf[row * LD + c4 * 4]) = pre[k];
         }
         __syncthreads();
-        if (j + 1 < PPL) fetch(j + 1);
+        if (PF && j + 1 < PPL) fetch(j + 1);
         if (tid < npts) {
             float x[E_];
 #pragma unroll
@@ -324,9 +328,10 @@ struct KmBwdArgs {
 template <int E_, int C_>
 __global__ __launch_bounds__(256) void kmeans_soft_bwd_kernel(KmBwdArgs a) {
     constexpr int NV = C_ * E_;
-    constexpr int LD = E_ + 1;
+    static_assert(E_ % 4 == 0, "rows are staged as 16-byte vectors");
+    constexpr int LD = E_ + 4, V4 = E_ / 4;
     constexpr int BUF = (256 * LD > 128 * 64) ? 256 * LD : 128 * 64;
-    __shared__ float buf[BUF];
+    __shared__ __attribute__((aligned(16))) float buf[BUF];
     __shared__ float scent[C_ * E_], sdnum[C_ * E_], sdden[C_];
     const int r = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const float* xb = a.xn + (long)r * a.L * E_;
@@ -345,11 +350,28 @@ __global__ __launch_bounds__(256) void kmeans_soft_bwd_kernel(KmBwdArgs a) {
 #pragma unroll
     for (int i = 0; i < NV; ++i) acc[i] = 0.f;
 
+    float4 pre[V4];                                 // 16-byte staging; no run-ahead here (2.5 workgroups per CU: it measured slower)
+    auto fetch = [&](int j) {
+        const long q0 = (long)g * CHUNK + (long)j * LANES;
+        const int np = (int)max((long)0, min((long)LANES, a.L - q0));
+        const float4* src = reinterpret_cast<const float4*>(xb + q0 * E_);
+#pragma unroll
+        for (int k = 0; k < V4; ++k) {
+            const int i = tid + 256 * k;
+            pre[k] = (i < np * V4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
     for (int j = 0; j < PPL; ++j) {
         const long p0 = (long)g * CHUNK + (long)j * LANES;
         const int npts = (int)max((long)0, min((long)LANES, a.L - p0));
         __syncthreads();
-        for (int i = tid; i < npts * E_; i += 256) buf[(i / E_) * LD + (i % E_)] = xb[p0 * E_ + i];
+        fetch(j);
+#pragma unroll
+        for (int k = 0; k < V4; ++k) {
+            const int i = tid + 256 * k;
+            const int row = i / V4, c4 = i - row * V4;
+            *reinterpret_cast<float4*>(&buf[row * LD + c4 * 4]) = pre[k];
+        }
         __syncthreads();
         float dxl[E_];
         if (tid < npts) {
