@@ -30,12 +30,29 @@ def front_maxpool_fwd(x, f, P, hop):
     return y, am
 
 
-def gather_filter_grad(x, v, argmax, W, rdiv):
+def argmax_to_pos(argmax, N):
+    """int64 flattened argmax (l*N + n, TF layout) -> int32 sample positions l; converted once per use site."""
+    pos = torch.empty(argmax.shape, dtype=torch.int32, device=argmax.device)
+    check(load().ams_argmax_to_pos(_p(argmax), _p(pos), argmax.numel(), N, _s()), 'ams_argmax_to_pos')
+    return pos
+
+
+def transpose(m):
+    ops._chk(m)
+    out = torch.empty((m.shape[1], m.shape[0]), dtype=torch.float32, device=m.device)
+    check(load().ams_transpose_f32(_p(m), _p(out), m.shape[0], m.shape[1], _s()), 'ams_transpose_f32')
+    return out
+
+
+def gather_filter_grad(x, v, pos, W, rdiv):
     ops._chk(x, v)
+    lib = load()
     R, L = x.shape
     T, N = v.shape[1:]
     df = torch.empty((W, N), dtype=torch.float32, device=x.device)
-    check(load().ams_gather_filter_grad(_p(x), _p(v), _p(argmax), _p(df), R, L, W, N, T, rdiv, _s()), 'ams_gather_filter_grad')
+    nb = lib.ams_gather_filter_grad_workspace_bytes(R, W, N)
+    ws = ops._ws(nb, x)
+    check(lib.ams_gather_filter_grad(_p(x), _p(v), _p(pos), _p(df), R, L, W, N, T, rdiv, _p(ws), nb, _s()), 'ams_gather_filter_grad')
     return df
 
 
@@ -45,15 +62,15 @@ class FrontMaxPool(Function):
     @staticmethod
     def forward(ctx, x, f, P, hop):
         y, am = front_maxpool_fwd(x, f, P, hop)
-        ctx.save_for_backward(x, am)
+        ctx.save_for_backward(x, argmax_to_pos(am, f.shape[1]))
         ctx.W = f.shape[0]
         ctx.mark_non_differentiable(am)
         return y, am
 
     @staticmethod
     def backward(ctx, dy, _dam):
-        x, am = ctx.saved_tensors
-        df = gather_filter_grad(x, dy.contiguous(), am, ctx.W, 1) if ctx.needs_input_grad[1] else None
+        x, pos = ctx.saved_tensors
+        df = gather_filter_grad(x, dy.contiguous(), pos, ctx.W, 1) if ctx.needs_input_grad[1] else None
         return None, df, None, None
 
 
@@ -66,20 +83,22 @@ class SynthUnpool(Function):
         R, T, N = vals.shape
         W = f2.shape[0]
         out = torch.empty((R, L), dtype=torch.float32, device=vals.device)
-        check(load().ams_synth_unpool_fwd(_p(vals), _p(argmax_mix), _p(f2), _p(out), R, L, W, N, T, P, hop, S, _s()), 'ams_synth_unpool_fwd')
-        ctx.save_for_backward(vals, argmax_mix, f2)
+        pos = argmax_to_pos(argmax_mix, N)
+        f2t = transpose(f2.detach().contiguous())
+        check(load().ams_synth_unpool_fwd(_p(vals), _p(pos), _p(f2t), _p(out), R, L, W, N, T, P, hop, S, _s()), 'ams_synth_unpool_fwd')
+        ctx.save_for_backward(vals, pos, f2t)
         ctx.cfg = (R, T, N, W, L, S)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        vals, am, f2 = ctx.saved_tensors
+        vals, am, f2t = ctx.saved_tensors
         R, T, N, W, L, S = ctx.cfg
         dout = dout.contiguous()
         dvals = df2 = None
         if ctx.needs_input_grad[0]:
             dvals = torch.empty_like(vals)
-            check(load().ams_synth_unpool_bwd_vals(_p(dout), _p(am), _p(f2), _p(dvals), R, L, W, N, T, S, _s()), 'ams_synth_unpool_bwd_vals')
+            check(load().ams_synth_unpool_bwd_vals(_p(dout), _p(am), _p(f2t), _p(dvals), R, L, W, N, T, S, _s()), 'ams_synth_unpool_bwd_vals')
         if ctx.needs_input_grad[2]:
             df2 = gather_filter_grad(dout, vals, am, W, S)
         return dvals, None, df2, None, None, None, None

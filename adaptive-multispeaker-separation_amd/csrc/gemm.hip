@@ -557,31 +557,60 @@ __global__ void maxpool_naive_kernel(const float* __restrict__ x, const float* _
     }
 }
 
-// Gather-form filter gradient shared by the max-pool front and the sparse (unpool) synthesis:
-//   df[k,n] = sum_{r,t} xpad[r, pos(r/rdiv,t,n) + k] * v[r,t,n],   pos = argmax / N.   Thread per tap k; sequential over (r,t).
+// ---- sparse (argmax-position) kernels of path B.  Positions are int32 sample indices (= TF's flattened int64 argmax / N,
+// converted ONCE by argmax_pos_kernel: a 64-bit divide in these inner loops cost more than the arithmetic) and the synthesis
+// filter is read TRANSPOSED, f2t [N, W], so consecutive taps are consecutive addresses (f2[k*N+n] put every lane on its own
+// cache line).  Measured at cfg2 (B=64, S=2, L=20480, W=1024, N=256): 6.8 / 9.5 / 9.3 ms -> see profiles/.
+__global__ void argmax_pos_kernel(const long long* __restrict__ argmax, int32_t* __restrict__ pos, long count, int N) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (long)gridDim.x * blockDim.x)
+        pos[i] = (int32_t)(argmax[i] / N);
+}
+
+__global__ void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int r = r0 + j, c = c0 + threadIdx.x;
+        if (r < rows && c < cols) tile[j][threadIdx.x] = in[(long)r * cols + c];
+    }
+    __syncthreads();
+    for (int j = threadIdx.y; j < 32; j += blockDim.y) {
+        const int c = c0 + j, r = r0 + threadIdx.x;
+        if (r < rows && c < cols) out[(long)c * rows + r] = tile[threadIdx.x][j];
+    }
+}
+
+// df[k,n] = sum_{r,t} xpad[r, pos[r/rdiv,t,n] + k - pl] * v[r,t,n].  Block = 256 consecutive taps k of one filter n and one
+// slice of rows (grid.z): pos / v are uniform per iteration (scalar loads), x is a coalesced 1 KB read.
 __global__ __launch_bounds__(256) void gather_filter_grad_kernel(const float* __restrict__ x, const float* __restrict__ v,
-                                                                 const long long* __restrict__ argmax, float* __restrict__ df, int R,
-                                                                 int L, int W, int N, int T, int pl, int rdiv) {
+                                                                 const int32_t* __restrict__ pos, float* __restrict__ part, int R,
+                                                                 int L, int W, int N, int T, int pl, int rdiv, int rows_per_z) {
     const int n = blockIdx.y;
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= W) return;
+    const int r_lo = blockIdx.z * rows_per_z, r_hi = min(R, r_lo + rows_per_z);
     float s = 0.f;
-    for (int r = 0; r < R; ++r) {
+    for (int r = r_lo; r < r_hi; ++r) {
         const float* xr = x + (long)r * L;
+        const int32_t* pr = pos + ((long)(r / rdiv) * T) * N + n;
+        const float* vr = v + ((long)r * T) * N + n;
         for (int t = 0; t < T; ++t) {
-            const int pos = (int)(argmax[((long)(r / rdiv) * T + t) * N + n] / N);
-            const int p = pos + k - pl;
-            const float val = v[((long)r * T + t) * N + n];
+            const int p = pr[(long)t * N] + k - pl;
+            const float val = vr[(long)t * N];
             if (p >= 0 && p < L) s += xr[p] * val;
         }
     }
-    df[(long)k * N + n] = s;
+    if (k < W) part[((long)blockIdx.z * W + k) * N + n] = s;
+}
+__global__ void gather_filter_reduce_kernel(const float* __restrict__ part, float* __restrict__ df, long WN, int nz) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= WN) return;
+    float s = 0.f;
+    for (int z = 0; z < nz; ++z) s += part[(long)z * WN + i];
+    df[i] = s;
 }
 
-// Sparse synthesis, gather form (never builds the unpooled [R,L,N] tensor; reference adapt.py:210-243, ops.py:94-120):
-//   out[r,l] = sum_n sum_{t in cand(l)} vals[r,t,n] * f2[l - pos + pl, n],  pos = argmax[r/S,t,n] / N
-__global__ __launch_bounds__(256) void synth_unpool_kernel(const float* __restrict__ vals, const long long* __restrict__ argmax,
-                                                           const float* __restrict__ f2, float* __restrict__ out, int R, int L, int W,
+__global__ __launch_bounds__(256) void synth_unpool_kernel(const float* __restrict__ vals, const int32_t* __restrict__ pos,
+                                                           const float* __restrict__ f2t, float* __restrict__ out, int R, int L, int W,
                                                            int N, int T, int P, int hop, int pl, int S) {
     const int r = blockIdx.y;
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
@@ -592,19 +621,19 @@ __global__ __launch_bounds__(256) void synth_unpool_kernel(const float* __restri
     int t1 = (l_hi + pl) / hop;
     if (t1 > T - 1) t1 = T - 1;
     float s = 0.f;
-    const long long* am = argmax + (long)(r / S) * T * N;
-    for (int n = 0; n < N; ++n)
-        for (int t = t0; t <= t1; ++t) {
-            const int pos = (int)(am[(long)t * N + n] / N);
-            const int k = l - pos + pl;
-            if (l < L && k >= 0 && k < W) s += vals[((long)r * T + t) * N + n] * f2[(long)k * N + n];
+    const int32_t* am = pos + (long)(r / S) * T * N;
+    const float* vr = vals + (long)r * T * N;
+    for (int t = t0; t <= t1; ++t)
+        for (int n = 0; n < N; ++n) {
+            const int k = l - am[(long)t * N + n] + pl;                 // uniform offset: consecutive l -> consecutive k
+            if (k >= 0 && k < W) s += vr[(long)t * N + n] * f2t[(long)n * W + k];
         }
     if (l < L) out[(long)r * L + l] = s;
 }
 
 // dvals[r,t,n] = sum_k dout_pad[r, pos + k] * f2[k,n]     (one wave per (r,t,n))
-__global__ __launch_bounds__(256) void synth_unpool_bwd_vals_kernel(const float* __restrict__ dout, const long long* __restrict__ argmax,
-                                                                    const float* __restrict__ f2, float* __restrict__ dvals, long total,
+__global__ __launch_bounds__(256) void synth_unpool_bwd_vals_kernel(const float* __restrict__ dout, const int32_t* __restrict__ pos,
+                                                                    const float* __restrict__ f2t, float* __restrict__ dvals, long total,
                                                                     int L, int W, int N, int T, int pl, int S) {
     const int lane = threadIdx.x & 63;
     const long wid0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, wstride = ((long)gridDim.x * blockDim.x) >> 6;
@@ -612,11 +641,13 @@ __global__ __launch_bounds__(256) void synth_unpool_bwd_vals_kernel(const float*
         const int n = (int)(i % N);
         const long rt = i / N;
         const int t = (int)(rt % T), r = (int)(rt / T);
-        const int pos = (int)(argmax[((long)(r / S) * T + t) * N + n] / N);
+        const int p0 = pos[((long)(r / S) * T + t) * N + n] - pl;
+        const float* dr = dout + (long)r * L;
+        const float* fr = f2t + (long)n * W;
         float s = 0.f;
         for (int k = lane; k < W; k += 64) {
-            const int p = pos + k - pl;
-            if (p >= 0 && p < L) s += dout[(long)r * L + p] * f2[(long)k * N + n];
+            const int p = p0 + k;
+            if (p >= 0 && p < L) s += dr[p] * fr[k];
         }
         s = wave_sum(s);
         if (lane == 0) dvals[i] = s;
@@ -662,32 +693,56 @@ ams_status ams_front_maxpool_fwd(const float* x, const float* f, float* y, long 
     return ams_check_launch();
 }
 
-// df[k,n] = sum_{r,t} xpad[r, argmax[r/rdiv,t,n]/N + k] * v[r,t,n]   (max-pool front: x = waveforms, v = dy, rdiv = 1;
-// sparse synthesis: x = d out, v = pooled values, rdiv = S because the mixture's argmax is tiled over speakers)
-ams_status ams_gather_filter_grad(const float* x, const float* v, const long long* argmax, float* df, int R, int L, int W, int N, int T,
-                                  int rdiv, void* stream) {
-    AMS_REQUIRE(x && v && argmax && df && R > 0 && L > 0 && W > 0 && N > 0 && T > 0 && rdiv > 0);
-    hipLaunchKernelGGL(gather_filter_grad_kernel, dim3(ceil_div(W, 256), N), dim3(256), 0, (hipStream_t)stream, x, v, argmax, df, R, L, W,
-                       N, T, (W - 1) / 2, rdiv);
+// int32 sample positions from TF's flattened int64 argmax (l*N + n)
+ams_status ams_argmax_to_pos(const long long* argmax, int32_t* pos, long count, int N, void* stream) {
+    AMS_REQUIRE(argmax && pos && count > 0 && N > 0);
+    long blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(argmax_pos_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, argmax, pos, count, N);
     return ams_check_launch();
 }
 
-// Path B back: unpool with the mixture's argmax (tiled S times) + stride-1 conv2d_transpose SAME, sparse form.
-ams_status ams_synth_unpool_fwd(const float* vals, const long long* argmax, const float* f2, float* out, int R, int L, int W, int N, int T,
+// out [cols, rows] = in [rows, cols]^T
+ams_status ams_transpose_f32(const float* in, float* out, int rows, int cols, void* stream) {
+    AMS_REQUIRE(in && out && rows > 0 && cols > 0);
+    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(cols, 32), ceil_div(rows, 32)), dim3(32, 8), 0, (hipStream_t)stream, in, out, rows,
+                       cols);
+    return ams_check_launch();
+}
+
+static int gather_nz(int R) { int nz = R / 16; if (nz < 1) nz = 1; if (nz > 16) nz = 16; return nz; }
+size_t ams_gather_filter_grad_workspace_bytes(int R, int W, int N) { return (size_t)gather_nz(R) * W * N * sizeof(float); }
+
+// df[k,n] = sum_{r,t} xpad[r, pos[r/rdiv,t,n] + k - pl] * v[r,t,n]   (max-pool front: x = waveforms, v = dy, rdiv = 1;
+// sparse synthesis: x = d out, v = pooled values, rdiv = S because the mixture's positions are tiled over speakers)
+ams_status ams_gather_filter_grad(const float* x, const float* v, const int32_t* pos, float* df, int R, int L, int W, int N, int T,
+                                  int rdiv, void* ws, size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(x && v && pos && df && ws && R > 0 && L > 0 && W > 0 && N > 0 && T > 0 && rdiv > 0);
+    if (ws_bytes < ams_gather_filter_grad_workspace_bytes(R, W, N)) return AMS_E_WORKSPACE_TOO_SMALL;
+    const int nz = gather_nz(R), rpz = ceil_div(R, nz);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gather_filter_grad_kernel, dim3(ceil_div(W, 256), N, nz), dim3(256), 0, st, x, v, pos, (float*)ws, R, L, W, N, T,
+                       (W - 1) / 2, rdiv, rpz);
+    hipLaunchKernelGGL(gather_filter_reduce_kernel, dim3(ceil_div((long)W * N, 256)), dim3(256), 0, st, (const float*)ws, df, (long)W * N, nz);
+    return ams_check_launch();
+}
+
+// Path B back: unpool with the mixture's positions (tiled S times) + stride-1 conv2d_transpose SAME, sparse form.  f2t [N, W].
+ams_status ams_synth_unpool_fwd(const float* vals, const int32_t* pos, const float* f2t, float* out, int R, int L, int W, int N, int T,
                                 int P, int hop, int S, void* stream) {
-    AMS_REQUIRE(vals && argmax && f2 && out && R > 0 && L > 0 && W > 0 && N > 0 && T > 0 && P > 0 && hop > 0 && S > 0);
-    hipLaunchKernelGGL(synth_unpool_kernel, dim3(ceil_div(L, 256), R), dim3(256), 0, (hipStream_t)stream, vals, argmax, f2, out, R, L, W,
+    AMS_REQUIRE(vals && pos && f2t && out && R > 0 && L > 0 && W > 0 && N > 0 && T > 0 && P > 0 && hop > 0 && S > 0);
+    hipLaunchKernelGGL(synth_unpool_kernel, dim3(ceil_div(L, 256), R), dim3(256), 0, (hipStream_t)stream, vals, pos, f2t, out, R, L, W,
                        N, T, P, hop, (W - 1) / 2, S);
     return ams_check_launch();
 }
 
-ams_status ams_synth_unpool_bwd_vals(const float* dout, const long long* argmax, const float* f2, float* dvals, int R, int L, int W, int N,
+ams_status ams_synth_unpool_bwd_vals(const float* dout, const int32_t* pos, const float* f2t, float* dvals, int R, int L, int W, int N,
                                      int T, int S, void* stream) {
-    AMS_REQUIRE(dout && argmax && f2 && dvals && R > 0 && L > 0 && W > 0 && N > 0 && T > 0 && S > 0);
+    AMS_REQUIRE(dout && pos && f2t && dvals && R > 0 && L > 0 && W > 0 && N > 0 && T > 0 && S > 0);
     const long total = (long)R * T * N;
     long blocks = (total + 3) / 4;
-    if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(synth_unpool_bwd_vals_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dout, argmax, f2, dvals, total,
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(synth_unpool_bwd_vals_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, dout, pos, f2t, dvals, total,
                        L, W, N, T, (W - 1) / 2, S);
     return ams_check_launch();
 }

@@ -52,11 +52,15 @@ ams_status ams_front_conv_bwd_filter(const float* x, const float* dy, float* df,
 size_t ams_front_maxpool_workspace_bytes(int Bt, int L, int N);
 ams_status ams_front_maxpool_fwd(const float* x, const float* f, float* y, long long* argmax, int Bt, int L, int W, int N, int P, int hop,
                                  void* ws, size_t ws_bytes, void* stream);
-ams_status ams_gather_filter_grad(const float* x, const float* v, const long long* argmax, float* df, int R, int L, int W, int N, int T,
-                                  int rdiv, void* stream);
-ams_status ams_synth_unpool_fwd(const float* vals, const long long* argmax, const float* f2, float* out, int R, int L, int W, int N, int T,
+/* the sparse kernels take int32 sample positions (argmax / N, converted once) and the synthesis filter TRANSPOSED, f2t [N, W] */
+ams_status ams_argmax_to_pos(const long long* argmax, int32_t* pos, long count, int N, void* stream);
+ams_status ams_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
+size_t ams_gather_filter_grad_workspace_bytes(int R, int W, int N);
+ams_status ams_gather_filter_grad(const float* x, const float* v, const int32_t* pos, float* df, int R, int L, int W, int N, int T,
+                                  int rdiv, void* ws, size_t ws_bytes, void* stream);
+ams_status ams_synth_unpool_fwd(const float* vals, const int32_t* pos, const float* f2t, float* out, int R, int L, int W, int N, int T,
                                 int P, int hop, int S, void* stream);
-ams_status ams_synth_unpool_bwd_vals(const float* dout, const long long* argmax, const float* f2, float* dvals, int R, int L, int W, int N,
+ams_status ams_synth_unpool_bwd_vals(const float* dout, const int32_t* pos, const float* f2t, float* dvals, int R, int L, int W, int N,
                                      int T, int S, void* stream);
 
 /* ---- dense contractions (tf.matmul / tf.nn.conv1d k=1 / dynamic_rnn input projection) ----
