@@ -184,6 +184,24 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False
     return out
 
 
+def gemm_batched2(A0, A1, B0, B1, C0, C1, transA, transB, M, N, K, lda, ldb, ldc, accumulate=False, mask=(0, 0)):
+    """Two products of one shape in ONE launch (operand pairs given as tensors/views; offsets taken from their addresses)."""
+    lib = load()
+    for t_ in (A0, A1, B0, B1, C0, C1):
+        if t_.dtype != torch.float32 or not t_.is_cuda:
+            raise AmsError('gemm_batched2: operands must be fp32 device tensors')
+    da, db_, dc = (A1.data_ptr() - A0.data_ptr()), (B1.data_ptr() - B0.data_ptr()), (C1.data_ptr() - C0.data_ptr())
+    if da % 4 or db_ % 4 or dc % 4:
+        raise AmsError('gemm_batched2: operand offsets must be whole floats')
+    nb = lib.ams_gemm_batched_workspace_bytes(M, N, K, 2)
+    ws = _ws(nb, A0) if nb else None
+    ev = PROFILE.begin() if PROFILE.enabled else None
+    check(lib.ams_gemm_f32_batched(int(transA), int(transB), M, N, K, _p(A0), lda, da // 4, _p(B0), ldb, db_ // 4, _p(C0), ldc, dc // 4, 2,
+                                   int(accumulate), mask[0], mask[1], _p(ws), nb, _s()), 'ams_gemm_f32_batched')
+    if ev is not None:
+        PROFILE.end(ev, 2 * 2.0 * M * N * K, 2 * 4.0 * (M * K + K * N + M * N), 'gemm<%d,%d>' % (int(bool(transA)), int(bool(transB))))
+
+
 # ------------------------------------------------------------------ masks
 def make_masks(rep_non_mix, B, S, a, b, take_abs, want_argmax=False):
     """rep_non_mix: [B*S, ...] rows (b,s) row-major.  Returns Y [B, TF, S] (and int32 argmax [B, TF])."""
@@ -326,10 +344,15 @@ def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate, part='all'):
     if part in ('all', 'u'):
         # forward dir pairs out[b,t-1] with dZ[b,t]; backward dir pairs out[b,t+1] with dZ[b,t]
         of = out.view(-1)
-        gemm(of, dZf[8 * H:], transA=True, out=dKf[D:], accumulate=acc, M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H,
-             ldc=dKf.stride(0), mask=(T, T - 1))
-        gemm(of[2 * H + H:], dZb, transA=True, out=dKb[D:], accumulate=acc, M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H,
-             ldc=dKb.stride(0), mask=(T, T - 1))
+        if dKf.stride(0) == dKb.stride(0):
+            # both directions in ONE launch: 2 x (3 x 10) tiles share the chip instead of queueing behind each other
+            gemm_batched2(of, of[2 * H + H:], dZf[8 * H:], dZb, dKf[D:], dKb[D:], True, False, H, 4 * H, M - 1, 2 * H, 8 * H,
+                          dKf.stride(0), accumulate=acc, mask=(T, T - 1))
+        else:
+            gemm(of, dZf[8 * H:], transA=True, out=dKf[D:], accumulate=acc, M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H,
+                 ldc=dKf.stride(0), mask=(T, T - 1))
+            gemm(of[2 * H + H:], dZb, transA=True, out=dKb[D:], accumulate=acc, M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H,
+                 ldc=dKb.stride(0), mask=(T, T - 1))
 
 
 def blstm_bwd(x, Kf, Kb, out, G, cst, dout, need_dx=True):

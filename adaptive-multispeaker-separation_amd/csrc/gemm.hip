@@ -49,6 +49,8 @@ struct GemmArgs {
     float* partial;            // [splits, M, N] when splits > 1
     int a_vec, b_vec;          // 16-byte vector loads legal
     int32_t* pidx;             // EPI_MAXPOOL: per (row-tile, column) arg-max row
+    // batch (grid.z): element offsets added per batch index to A, B, C (any sign); partial slabs are z-major
+    long a_zs, b_zs, c_zs;
 };
 
 template <int AMODE>
@@ -87,6 +89,11 @@ template <int AMODE, int BMODE, int EPI = EPI_STORE>
 #define AMS_GEMM_WPE 2
 #endif
 __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g) {
+    if (gridDim.z > 1) {                            // batched launch: same shape, shifted operands
+        const long z = blockIdx.z;
+        g.A += z * g.a_zs; g.B += z * g.b_zs; g.C += z * g.c_zs;
+        if (g.partial) g.partial += z * (long)g.splits * g.M * g.N;
+    }
     constexpr bool AK = AKContig<AMODE>::v;
     constexpr bool BKc = (BMODE == B_COL);
     constexpr int LDA_S = BM + (AK ? PAD_T : PAD_V);
@@ -311,8 +318,10 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, const float* __restrict__ bias,
-                                     int M, int N, long ldc, int splits, int accumulate) {
+                                     int M, int N, long ldc, int splits, int accumulate, long c_zs) {
     const long total = (long)M * N;
+    partial += (long)blockIdx.y * splits * total;
+    C += (long)blockIdx.y * c_zs;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int m = (int)(i / N), n = (int)(i - (long)m * N);
         float s = 0.f;
@@ -329,8 +338,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* _
 // n = ceil(tiles*s/256) workgroups end up on the busiest CU (equal-work workgroups time-share a CU's four
 // SIMDs, so the launch ends when that CU drains); occ(n) discounts CUs holding only 1-3 workgroups, whose
 // barrier stalls are not covered by a neighbour's MFMAs; the last term is the fp32 partial-slab round trip.
-inline int choose_splits(int M, int N, int K) {
-    const int tiles = ceil_div(M, BM) * ceil_div(N, BN);
+inline int choose_splits(int M, int N, int K, int nbatch = 1) {
+    const int tiles = ceil_div(M, BM) * ceil_div(N, BN) * nbatch;
     int best = 1;
     double best_t = 1e30;
     for (int s = 1; s <= 32; ++s) {
@@ -340,7 +349,7 @@ inline int choose_splits(int M, int N, int K) {
         const int n = ceil_div((long)tiles * s2, 256);
         const double occ = n <= 1 ? 0.62 : (n == 2 ? 0.80 : (n == 3 ? 0.92 : 1.0));
         double t = n * ((kps / 16.0) * 1.024 + 5.0) / occ;
-        if (s2 > 1) t += (double)(s2 + 1) * M * N * 4.0 / 2.5e6;
+        if (s2 > 1) t += (double)(s2 + 1) * M * N * nbatch * 4.0 / 2.5e6;
         if (t < best_t - 1e-9) { best_t = t; best = s2; }
     }
     return best;
@@ -361,14 +370,14 @@ inline int choose_group_m(int tiles_m, int tiles_n) {
 }
 
 template <int AMODE, int BMODE>
-ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st) {
+ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nbatch = 1) {
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
     g.group_m = choose_group_m(ceil_div(g.M, BM), ceil_div(g.N, BN));
     int splits = 1;
     if (ws) {
-        splits = choose_splits(g.M, g.N, g.K);
+        splits = choose_splits(g.M, g.N, g.K, nbatch);
         if (const char* f = getenv("AMS_GEMM_SPLITS")) { const int v = atoi(f); if (v > 0) splits = v; }   // tuning aid
-        while (splits > 1 && (size_t)splits * g.M * g.N * sizeof(float) > ws_bytes) --splits;
+        while (splits > 1 && (size_t)nbatch * splits * g.M * g.N * sizeof(float) > ws_bytes) --splits;
     }
     int kps = ceil_div(g.K, splits);
     kps = ceil_div(kps, BK) * BK;
@@ -376,7 +385,7 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st) {
     g.splits = splits;
     g.k_per_split = kps;
     g.partial = (float*)ws;
-    dim3 grid(tiles, splits);
+    dim3 grid(tiles, splits, nbatch);
     // Occupancy cap for launches that are meant to run BESIDE latency-critical kernels (weight-gradient products on
     // the side stream): unused dynamic LDS limits how many of these workgroups a CU admits, leaving registers/slots
     // for the recurrent step kernels.  Thread-local, set through ams_gemm_set_lds_pad().
@@ -395,8 +404,8 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st) {
         const long total = (long)g.M * g.N;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, g.partial, g.C, g.bias, g.M, g.N, g.ldc,
-                           splits, g.accumulate);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, nbatch), dim3(256), 0, st, g.partial, g.C, g.bias, g.M, g.N, g.ldc,
+                           splits, g.accumulate, g.c_zs);
         s = ams_check_launch();
     }
     return s;
@@ -433,6 +442,33 @@ ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float
     if (!transA && transB) return launch<A_ROW, B_COL>(g, ws, ws_bytes, st);
     if (transA && !transB) return launch<A_COL, B_ROW>(g, ws, ws_bytes, st);
     return launch<A_COL, B_COL>(g, ws, ws_bytes, st);
+}
+
+// nbatch products of one shape in ONE launch (grid.z): operand z is at A + z*a_zs etc. (element offsets, any sign).
+// Used for the two directions' recurrent-kernel gradients: 2 x 30 tiles fill the chip better than 30 twice.
+size_t ams_gemm_batched_workspace_bytes(int M, int N, int K, int nbatch) {
+    int splits = choose_splits(M, N, K, nbatch);
+    if (const char* f = getenv("AMS_GEMM_SPLITS")) { const int v = atoi(f); if (v > 0) splits = v; }
+    if (splits <= 1) return 0;
+    return (size_t)nbatch * splits * M * N * sizeof(float);
+}
+ams_status ams_gemm_f32_batched(int transA, int transB, int M, int N, int K, const float* A, long lda, long a_zs, const float* B,
+                                long ldb, long b_zs, float* C, long ldc, long c_zs, int nbatch, int accumulate, int mask_period,
+                                int mask_skip, void* ws, size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C && nbatch >= 1 && nbatch <= 64);
+    GemmArgs g{};
+    g.A = A; g.B = B; g.C = C; g.bias = nullptr;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.accumulate = accumulate;
+    g.mask_period = mask_period; g.mask_skip = mask_skip;
+    g.a_zs = a_zs; g.b_zs = b_zs; g.c_zs = c_zs;
+    g.a_vec = aligned16(A) && (lda % 4 == 0) && (a_zs % 4 == 0);
+    g.b_vec = aligned16(B) && (ldb % 4 == 0) && (b_zs % 4 == 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (!transA && !transB) return launch<A_ROW, B_ROW>(g, ws, ws_bytes, st, nbatch);
+    if (!transA && transB) return launch<A_ROW, B_COL>(g, ws, ws_bytes, st, nbatch);
+    if (transA && !transB) return launch<A_COL, B_ROW>(g, ws, ws_bytes, st, nbatch);
+    return launch<A_COL, B_COL>(g, ws, ws_bytes, st, nbatch);
 }
 
 // Adaptive analysis filterbank, path A (reference models/adapt.py:122): y[b,t,n] = sum_k xpad[b,t*hop+k-pl] f[k,n]

@@ -74,6 +74,12 @@ void ams_gemm_set_lds_pad(int bytes);
 ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C,
                         long ldc, const float* bias, int accumulate, int mask_period, int mask_skip, void* ws, size_t ws_bytes,
                         void* stream);
+/* nbatch products of ONE shape in one launch; operand z lives at A + z*a_zs, B + z*b_zs, C + z*c_zs (element offsets, any
+ * sign).  No bias.  Used for the two BLSTM directions' recurrent-kernel gradients (h_prev^T . dZ). */
+size_t ams_gemm_batched_workspace_bytes(int M, int N, int K, int nbatch);
+ams_status ams_gemm_f32_batched(int transA, int transB, int M, int N, int K, const float* A, long lda, long a_zs, const float* B,
+                                long ldb, long b_zs, float* C, long ldc, long c_zs, int nbatch, int accumulate, int mask_period,
+                                int mask_skip, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- K7  dominant-speaker masks: one_hot(argmax_s |rep|, S, a, b)   models/network.py:377-378, :501-502 ----
  * rep_non_mix rows are (b,s) row-major, each TF long; Y [B,TF,S]; argmax [B,TF] int32 (may be NULL). */
