@@ -1,9 +1,14 @@
-"""Input pipeline mirror (reference data/dataset.py:532-645 ``TFDataset``) backed by a synthetic-mixture source.
+"""Input pipeline mirror (reference data/dataset.py:532-645 ``TFDataset``).
 
-The reference builds a tf.data pipeline over LibriSpeech TFRecords (decode -> chunk -> zip S speakers -> sum);
-those need TF/h5py/librosa and real audio and are out of scope for the GPU hot path.
-This class honours the same OUTPUT contract -- ``next_mix [B,L]``, ``next_non_mix [B,S,L]``, ``next_ind [B,S]``
-with ``x_mix = sum_s x_s`` exactly as dataset.py:462-468 -- from the synthetic generator SURVEY 8(d) specifies.
+Two sources honour the same OUTPUT contract -- ``next_mix [B,L]``, ``next_non_mix [B,S,L]``, ``next_ind [B,S]`` with
+``x_mix = sum_s x_s`` exactly as dataset.py:462-468:
+  * ``--dataset synthetic`` (default of the tests and benches): the generator SURVEY 8(d) specifies;
+  * any other ``--dataset``: the reference's TFRecord files ``{train,valid,test,test_other}_{M,F}.tfrecords`` under
+    ``config.workdir``, read without TensorFlow by data/tfrecord.py and run through the same stages
+    (decode -> optional per-utterance normalise -> shuffle(100) -> keep utterances longer than the chunk -> chunk -> shuffle(10)
+    -> zip S gender streams -> drop tuples with a repeated speaker -> sum -> batch), see ``RecordStream`` / ``MixtureStream``.
+    tf.data's shuffle buffers draw from TF's own RNG, so the ORDER of examples differs from a TensorFlow run; the set of examples
+    an epoch yields and every per-example value are the same.
 """
 import numpy as np
 import torch
@@ -47,6 +52,88 @@ def synthetic_mixtures(indices, S, L, tot_speakers=251):
     return mix, non_mix, ind
 
 
+def _shuffle_buffer(it, size, rng):
+    """tf.data.Dataset.shuffle(size) semantics: keep `size` elements, emit a uniformly drawn one, refill."""
+    buf = []
+    for x in it:
+        if len(buf) < size:
+            buf.append(x)
+            continue
+        j = rng.randint(0, size)
+        out, buf[j] = buf[j], x
+        yield out
+    while buf:
+        j = rng.randint(0, len(buf))
+        yield buf.pop(j)
+
+
+class RecordStream(object):
+    """One gender stream of the reference (TFDataset.get_data, dataset.py:519-527): an iterable of (chunk [L] float32, key)."""
+
+    def __init__(self, path, chunk_size, seed, normalize=False):
+        self.path, self.chunk_size, self.seed, self.normalize = path, int(chunk_size), int(seed), bool(normalize)
+
+    def __iter__(self):
+        from data import tfrecord
+        rng1, rng2 = np.random.RandomState(self.seed), np.random.RandomState(self.seed + 7919)
+        L = self.chunk_size
+
+        def utterances():
+            for audio, key in tfrecord.read_audio_records(self.path):
+                if self.normalize:                                   # dataset.py:454-458: population moments over the utterance
+                    audio = (audio - audio.mean()) / np.sqrt(audio.var())
+                yield audio, key
+
+        def chunks():
+            for audio, key in _shuffle_buffer(utterances(), 100, rng1):
+                if not L < audio.shape[0]:                           # is_long_enough: chunk_size < length (strict, :470-471)
+                    continue
+                for i in range(audio.shape[0] // L):                 # chunk(): floor(L_utt / chunk) pieces (:482-491)
+                    yield audio[i * L:(i + 1) * L], key
+        return _shuffle_buffer(chunks(), 10, rng2)
+
+
+class MixtureStream(object):
+    """zip of S RecordStreams -> filter distinct speakers (dataset.py:473-480) -> mix (:462-468) -> batch."""
+
+    def __init__(self, streams, batch_size):
+        self.streams, self.batch_size = streams, int(batch_size)
+
+    def __iter__(self):
+        mixes, nms, keys = [], [], []
+        for items in zip(*self.streams):
+            ks = [k for _, k in items]
+            if len(set(ks)) != len(ks):
+                continue
+            nm = np.stack([c for c, _ in items]).astype(np.float32)
+            mixes.append(nm.sum(axis=0))
+            nms.append(nm)
+            keys.append(np.asarray(ks, np.int32))
+            if len(mixes) == self.batch_size:
+                yield np.stack(mixes), np.stack(nms), np.stack(keys)
+                mixes, nms, keys = [], [], []
+        if mixes:                                                     # tf.data batch() keeps the short final batch
+            yield np.stack(mixes), np.stack(nms), np.stack(keys)
+
+
+def record_mixture_stream(folder, split, sex, S, chunk_size, batch_size, normalize=False, no_random_picking=True):
+    """The `no_random_picking` branch of TFDataset.__init__ (dataset.py:561-566,586-605): speaker i comes from the M file when i is
+    even and the F file when odd (both genders requested), stream i is seeded with i."""
+    import os
+
+    def stream(g, i):
+        return RecordStream(os.path.join(folder, '%s_%s.tfrecords' % (split, g)), chunk_size, i, normalize)
+    if 'M' in sex and 'F' in sex:
+        if not no_random_picking:
+            raise NotImplementedError('random picking over all gender combinations (dataset.py:567-575) is not built; '
+                                      'pass --no_random_picking')
+        streams = [stream('M' if i % 2 == 0 else 'F', i) for i in range(S)]
+    else:
+        g = 'M' if 'M' in sex else 'F'
+        streams = [stream(g, i) for i in range(S)]
+    return MixtureStream(streams, batch_size)
+
+
 class TFDataset(object):
     TRAIN, VALID, TEST, TEST_OTHER = 'train', 'valid', 'test', 'test_other'
 
@@ -63,6 +150,20 @@ class TFDataset(object):
         self.cursor = dict.fromkeys(self.nb_batches, 0)
         self.pool = {}
         self.pool_batches = int(kwargs.get('synthetic_pool') or 8)
+        # real data: the reference's TFRecord files next to config.workdir (or AMS_DATA_DIR)
+        self.records = None
+        name = kwargs.get('dataset')
+        if name and name != 'synthetic':
+            import os
+            import config
+            folder = os.environ.get('AMS_DATA_DIR', config.workdir)
+            if not os.path.exists(os.path.join(folder, 'train_M.tfrecords')) and not os.path.exists(os.path.join(folder, 'train_F.tfrecords')):
+                raise IOError('--dataset %s: no {split}_{M,F}.tfrecords under %s (set AMS_DATA_DIR, or use --dataset synthetic)'
+                              % (name, folder))
+            self.records = dict(folder=folder, sex=kwargs.get('sex') or ['M', 'F'], normalize=bool(kwargs.get('dataset_normalize')),
+                                no_random_picking=bool(kwargs.get('no_random_picking', True)))
+            self._iters = {}
+            self._lengths = {}
 
         g = get_default_graph()
         with g.variable_scope('dataset'):
@@ -85,8 +186,36 @@ class TFDataset(object):
 
     def initialize(self, split):
         self.cursor[split] = 0
+        if self.records is not None:
+            self._iters.pop(split, None)
+
+    def _record_batch(self, split, L):
+        """Next batch of the TFRecord pipeline; with N ranks each rank keeps every N-th batch (utterance-level sharding)."""
+        world = self.dist.world_size if self.dist is not None else 1
+        rank = self.dist.rank if self.dist is not None else 0
+        it = self._iters.get(split)
+        if it is None:
+            r = self.records
+            it = self._iters[split] = iter(record_mixture_stream(r['folder'], split, r['sex'], self.S, L, self.batch_size, r['normalize'],
+                                                                   r['no_random_picking']))
+        out = None
+        for k in range(world):
+            b = next(it)                                            # StopIteration = end of epoch, like tf.errors.OutOfRangeError
+            if k == rank:
+                out = b
+        return tuple(torch.from_numpy(a).to(self.device) for a in out)
 
     def length(self, split):
+        if self.records is not None:
+            # dataset.py:667-676: count the batches of one pass over the split (cached); each rank sees every world-th batch
+            key = (split, self.default_chunk)
+            if key not in self._lengths:
+                r = self.records
+                n = sum(1 for _ in record_mixture_stream(r['folder'], split, r['sex'], self.S, self.default_chunk, self.batch_size,
+                                                         r['normalize'], r['no_random_picking']))
+                world = self.dist.world_size if self.dist is not None else 1
+                self._lengths[key] = n // world
+            return self._lengths[key]
         return self.nb_batches[split]
 
     # -- batches -----------------------------------------------------------------------
@@ -99,6 +228,8 @@ class TFDataset(object):
     def _next(self, run):
         split = run.feeds[self.handle]
         L = int(run.feeds.get(self.chunk_size, self.default_chunk))
+        if self.records is not None:
+            return self._record_batch(split, L)
         b = self.cursor[split] % self.nb_batches[split]
         self.cursor[split] += 1
         key = (split, b % self.pool_batches, L)

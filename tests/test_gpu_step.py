@@ -84,3 +84,49 @@ def test_hip_graph_finetuning_step_refreshes_kmeans_seeds():
     c_e, c_g = run(False), run(True)
     assert np.allclose(c_e, c_g, rtol=1e-5), (c_e, c_g)
     assert len(set(np.round(c_g, 6))) > 2                     # the replayed steps are not frozen on one set of seeds / one batch
+
+
+def test_training_from_tfrecord_files(tmp_path):
+    """--dataset <name> + AMS_DATA_DIR: the reference's {split}_{M,F}.tfrecords drive the same trainer."""
+    import os
+    import sys
+    import tempfile
+    from ams_hip import testing
+    from data import tfrecord
+    from models.dpcl import DPCL
+    from utils.trainer import Front_Separator_Trainer
+    os.environ.setdefault('AMS_LOG_DIR', tempfile.mkdtemp(prefix='ams_log_'))
+    rng = np.random.RandomState(3)
+    L, B, S = 1024, 3, 2
+    for split in ('train', 'valid', 'test', 'test_other'):
+        for g_, base in (('M', 0), ('F', 100)):
+            tfrecord.write_audio_records(str(tmp_path / ('%s_%s.tfrecords' % (split, g_))),
+                                         [((0.05 * rng.randn(rng.randint(L + 1, 4 * L))).astype(np.float32), base + i) for i in range(6)])
+    os.environ['AMS_DATA_DIR'] = str(tmp_path)
+    try:
+        folder, params = testing.make_pretrained_adapt(os.path.join(str(tmp_path), 'pre'), window_size=64, filters=16, hop_size=16,
+                                                       chunk_size=L, batch_size=B, nb_speakers=S)
+        a = dict(params)
+        a.update(testing.SEPARATOR_DEFAULTS)
+        a.update(layer_size=12, nb_layers=2, embedding_size=8, model_folder=folder, model_previous=None, pretraining=False,
+                 learning_rate=1e-3, dataset='h5py_files/train-clean-100-8-s.h5', no_summaries=True)
+        a.pop('type')
+        tr = Front_Separator_Trainer(DPCL, 'front_DPCL', **a)
+        dist, tfds = tr.prepare()
+        n_train = tfds.length(tfds.TRAIN)
+        assert n_train >= 1
+        tfds.initialize(tfds.TRAIN)
+        with tr.graph.as_default():
+            feed = {tfds.handle: tfds.get_handle(tfds.TRAIN), tfds.chunk_size: L}
+            costs = [float(tr.model.train(feed, i)) for i in range(n_train)]
+            run = tr.model.last_run
+            xm, xn, I = (tr.model.x_mix.value(run), tr.model.x_non_mix.value(run), tr.model.I.value(run))
+        assert all(np.isfinite(costs))
+        assert xm.shape[1] == L and xn.shape[1:] == (S, L) and torch.allclose(xm, xn.sum(1), atol=1e-6)
+        assert int(I[:, 0].max()) < 100 <= int(I[:, 1].min())           # speaker 0 from the M file, speaker 1 from the F file
+        with pytest.raises(StopIteration):                               # end of epoch, like tf.errors.OutOfRangeError
+            with tr.graph.as_default():
+                for i in range(1000):
+                    tr.model.train(feed, i)
+    finally:
+        os.environ.pop('AMS_DATA_DIR', None)
