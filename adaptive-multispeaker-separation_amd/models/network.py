@@ -138,6 +138,22 @@ class Network(object):
     # Restore last checkpoint of the current graph using the total path (network.py:139-140)
     def restore_model(self, path):
         g = get_default_graph()
+        # a folder written by the REFERENCE (tf.train.Saver: text `checkpoint` file + model-N.index/.data-*) is read directly
+        from ams_hip import tf_checkpoint
+        marker = os.path.join(path, 'checkpoint')
+        is_tf = os.path.exists(marker) and open(marker).read(22).startswith('model_checkpoint_path')
+        if is_tf:
+            prefix = tf_checkpoint.latest_checkpoint(path)
+            bundle = tf_checkpoint.read_bundle(prefix, names=set(self.saver))
+            for name in self.saver:
+                if name not in bundle:
+                    raise KeyError('variable %s not found in TensorFlow checkpoint %s' % (name, prefix))
+                v = g.variables[name]
+                if tuple(bundle[name].shape) != tuple(v.shape):
+                    raise ValueError('variable %s: checkpoint shape %s, graph shape %s' % (name, bundle[name].shape, tuple(v.shape)))
+                v.data.copy_(torch.from_numpy(bundle[name].astype(np.float32)).to(v.device))
+                g.initialized.add(name)
+            return
         data = np.load(self._latest_checkpoint(path))
         for name in self.saver:
             key = name.replace('/', '.')

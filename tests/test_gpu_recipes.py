@@ -500,3 +500,36 @@ def test_front_l41_inference_and_finetuning():
     c_ref = cost_fn(Pg)
     assert abs(cost - c_ref) < 1e-3 * abs(c_ref), (cost, c_ref)
     _fd_check(cost_fn, Pg, grads, ('prediction/W',))
+
+
+def test_restore_from_tensorflow_bundle_matches_npz():
+    """A model folder in the REFERENCE's on-disk format (text `checkpoint` + model-N.index/.data-*, `params` JSON) restores to
+    the same inference output as the npz form (bundle written by ams_hip/tf_checkpoint.py)."""
+    import json
+    import shutil
+    from ams_hip import tf_checkpoint
+    from models.dpcl import DPCL
+    from utils.trainer import Front_Separator_Inference
+    tmp = tempfile.mkdtemp(prefix='ams_tfck_')
+    rng = np.random.RandomState(71)
+    B, S, L, W, N, hop, LS, NL, E, tries, steps = 2, 2, 1024, 64, 16, 16, 12, 2, 8, 2, 3
+    folder, params, P = _full_checkpoint(tmp, rng, W, N, hop, L, B, S, LS, NL, E, N, N)
+    tf_folder = os.path.join(tmp, 'tf')
+    os.makedirs(tf_folder)
+    shutil.copy(os.path.join(folder, 'params'), os.path.join(tf_folder, 'params'))
+    extra = dict(P)
+    extra['global_epoch'] = np.array(0, np.int32)                    # the reference also saves optimizer state / counters
+    extra['prediction/W/AMSGrad'] = np.zeros_like(P['prediction/W'])
+    tf_checkpoint.write_bundle(os.path.join(tf_folder, 'model-7'), extra)
+    with open(os.path.join(tf_folder, 'checkpoint'), 'w') as f:
+        f.write('model_checkpoint_path: "model-7"\nall_model_checkpoint_paths: "model-7"\n')
+    T = -(-L // hop)
+    idx = np.stack([rng.choice(T * N, S, replace=False) for _ in range(B * tries)]).astype(np.int32)
+    outs = []
+    for fol in (folder, tf_folder):
+        a = base_args(**params)
+        a.update(model_folder=fol, nb_tries=tries, nb_steps=steps, end_assign=True, kmeans_init_indices=idx, out=False)
+        a.pop('type')
+        tr = Front_Separator_Inference(DPCL, 'front_DPCL_inference', **a)
+        outs.append(_infer(tr, L)[2])
+    assert np.array_equal(outs[0], outs[1])
