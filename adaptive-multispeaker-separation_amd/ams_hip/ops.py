@@ -344,7 +344,11 @@ def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate, part='all'):
     if part in ('all', 'u'):
         # forward dir pairs out[b,t-1] with dZ[b,t]; backward dir pairs out[b,t+1] with dZ[b,t]
         of = out.view(-1)
-        if dKf.stride(0) == dKb.stride(0):
+        if M - 1 <= 0:                         # a single (batch, time) row has no previous state: dU = 0
+            if not acc:
+                dKf[D:].zero_()
+                dKb[D:].zero_()
+        elif dKf.stride(0) == dKb.stride(0):
             # both directions in ONE launch: 2 x (3 x 10) tiles share the chip instead of queueing behind each other
             gemm_batched2(of, of[2 * H + H:], dZf[8 * H:], dZb, dKf[D:], dKb[D:], True, False, H, 4 * H, M - 1, 2 * H, 8 * H,
                           dKf.stride(0), accumulate=acc, mask=(T, T - 1))

@@ -420,6 +420,7 @@ extern "C" {
 void ams_gemm_set_lds_pad(int bytes) { t_gemm_lds_pad = bytes < 0 ? 0 : bytes; }
 
 size_t ams_gemm_workspace_bytes(int M, int N, int K) {
+    if (M <= 0 || N <= 0 || K <= 0) return 0;
     int splits = choose_splits(M, N, K);
     if (const char* f = getenv("AMS_GEMM_SPLITS")) { const int v = atoi(f); if (v > 0) splits = v; }
     if (splits <= 1) return 0;
@@ -447,6 +448,7 @@ ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float
 // nbatch products of one shape in ONE launch (grid.z): operand z is at A + z*a_zs etc. (element offsets, any sign).
 // Used for the two directions' recurrent-kernel gradients: 2 x 30 tiles fill the chip better than 30 twice.
 size_t ams_gemm_batched_workspace_bytes(int M, int N, int K, int nbatch) {
+    if (M <= 0 || N <= 0 || K <= 0 || nbatch <= 0) return 0;
     int splits = choose_splits(M, N, K, nbatch);
     if (const char* f = getenv("AMS_GEMM_SPLITS")) { const int v = atoi(f); if (v > 0) splits = v; }
     if (splits <= 1) return 0;
