@@ -92,14 +92,17 @@ __global__ __launch_bounds__(256) void kmeans_pass_kernel(KmArgs a) {
 
     // slab j+1 is fetched into registers while slab j is being processed: without it every 256-point slab exposed a full
     // HBM/L2 round trip (8 per workgroup) and the pass ran at 1/5 of its arithmetic rate
+    // Each WAVE stages the 64 rows its own lanes consume (rows wave*64 .. +63 of the slab) and never waits for the other three
+    // waves inside the slab loop: LDS operations of one wave retire in issue order, so a fence + wave barrier is all the
+    // ordering a wave needs between its writes and its reads.  (Workgroup barriers per slab left 41 % of the wave cycles parked.)
     float4 pre[V4];
     auto fetch = [&](int j) {
-        const long q0 = (long)g * CHUNK + (long)j * LANES;
-        const int np = (int)max((long)0, min((long)LANES, a.L - q0));
+        const long q0 = (long)g * CHUNK + (long)j * LANES + wave * 64;
+        const int np = (int)max((long)0, min((long)64, a.L - q0));
         const float4* src = reinterpret_cast<const float4*>(xb + q0 * E_);
 #pragma unroll
         for (int k = 0; k < V4; ++k) {
-            const int i = tid + 256 * k;
+            const int i = lane + 64 * k;
             pre[k] = (i < np * V4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
         }
     };
@@ -107,18 +110,21 @@ __global__ __launch_bounds__(256) void kmeans_pass_kernel(KmArgs a) {
     // (64 rows, 640 workgroups = 2.5 per CU, exp-heavy) 0.80 -> 1.15 ms -- so it is on for the hard modes only
     constexpr bool PF = !SOFT;
     if (PF) fetch(0);
+    float* wbuf = buf + wave * 64 * LD;
     for (int j = 0; j < PPL; ++j) {
         const long p0 = (long)g * CHUNK + (long)j * LANES;
         const int npts = (int)max((long)0, min((long)LANES, a.L - p0));
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");      // this wave's reads of the previous slab are complete
+        __builtin_amdgcn_wave_barrier();
         if (!PF) fetch(j);
 #pragma unroll
         for (int k = 0; k < V4; ++k) {
-            const int i = tid + 256 * k;
+            const int i = lane + 64 * k;
             const int row = i / V4, c4 = i - row * V4;
-            *reinterpret_cast<float4*>(&buf[row * LD + c4 * 4]) = pre[k];
+            *reinterpret_cast<float4*>(&wbuf[row * LD + c4 * 4]) = pre[k];
         }
-        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
         if (PF && j + 1 < PPL) fetch(j + 1);
         if (tid < npts) {
             float x[E_];
