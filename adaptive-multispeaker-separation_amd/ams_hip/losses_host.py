@@ -4,7 +4,6 @@
 Kept out of models/adapt.py so that file reads like the reference's class; every heavy op is a HIP kernel via
 ams_hip.functional.
 """
-import torch
 
 from . import functional as F
 from .graph import Node, get_default_graph, get_scope_variable

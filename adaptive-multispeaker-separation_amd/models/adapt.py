@@ -5,11 +5,9 @@ Learned analysis filterbank (1-D conv, optional max-pool with argmax / average p
 separator (ideal mask / perfect subtraction), synthesis (unpool + transposed conv), costs, and the
 connect_* wiring used by the front_* recipes.
 """
-import os
 
 import torch
 
-import config
 from ams_hip import functional as F
 from ams_hip.graph import Node, get_default_graph, scope, get_scope_variable
 from models.network import Network

@@ -18,7 +18,7 @@ from ams_hip import functional as F
 from ams_hip import ops as K
 from ams_hip.graph import Node, Placeholder, Run, get_default_graph, scope
 from ams_hip.optim import FlatOptimizer
-from utils.ops import BLSTM, Conv1D, f_props, log10
+from utils.ops import BLSTM, Conv1D, f_props
 
 _ADJ = ['autumn', 'hidden', 'bitter', 'misty', 'silent', 'empty', 'dry', 'dark', 'summer', 'icy', 'quiet', 'white', 'cool',
         'spring', 'winter', 'patient', 'twilight', 'dawn', 'crimson', 'wispy', 'weathered', 'blue', 'billowing', 'broken']

@@ -1,7 +1,6 @@
 """GPU, BASELINE.json full sizes (SURVEY 8d cfg3 / cfg1 geometry): size-independent properties of the hot path, checked where the
 oracle would take minutes -- utterance-shard invariance of the training step (what the N>1 data-parallel path relies on),
 unit-norm embeddings, adjointness of the analysis / synthesis filterbank, STFT->iSTFT round trip, k-means invariants."""
-import os
 import tempfile
 
 import numpy as np

@@ -505,7 +505,6 @@ def test_front_l41_inference_and_finetuning():
 def test_restore_from_tensorflow_bundle_matches_npz():
     """A model folder in the REFERENCE's on-disk format (text `checkpoint` + model-N.index/.data-*, `params` JSON) restores to
     the same inference output as the npz form (bundle written by ams_hip/tf_checkpoint.py)."""
-    import json
     import shutil
     from ams_hip import tf_checkpoint
     from models.dpcl import DPCL

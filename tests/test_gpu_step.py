@@ -89,7 +89,6 @@ def test_hip_graph_finetuning_step_refreshes_kmeans_seeds():
 def test_training_from_tfrecord_files(tmp_path):
     """--dataset <name> + AMS_DATA_DIR: the reference's {split}_{M,F}.tfrecords drive the same trainer."""
     import os
-    import sys
     import tempfile
     from ams_hip import testing
     from data import tfrecord

@@ -5,7 +5,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from oracle import front, stft, blstm, dense, dpcl, l41, separate, losses, optim, step
+from oracle import front, stft, blstm, dense, dpcl, l41, losses, optim, step
 
 RNG = np.random.RandomState(0)
 
