@@ -39,10 +39,13 @@ class _Overlap(object):
             t.record_stream(s)
         return s
 
-    def cap(self, on):
+    def cap(self, on, kind='dense'):
         import os
         from ._lib import load
-        load().ams_gemm_set_lds_pad(int(os.environ.get('AMS_SIDE_LDS_PAD', '70000')) if on else 0)
+        pad = int(os.environ.get('AMS_SIDE_LDS_PAD', '70000'))
+        if kind == 'lstm':
+            pad = int(os.environ.get('AMS_SIDE_LDS_PAD_LSTM', str(pad)))
+        load().ams_gemm_set_lds_pad(pad if on else 0)
 
     def join(self):
         if self.stream is not None:
@@ -118,7 +121,7 @@ class BLSTMLayer(Function):
                 ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx')
                 return None, None, None, None, None
             with torch.cuda.stream(s):
-                OVERLAP.cap(True)
+                OVERLAP.cap(True, 'lstm')
                 ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True)
                 OVERLAP.cap(False)
             if dx is None and need_dx:
