@@ -1,13 +1,5 @@
-# coding: utf-8
-"""python -m experiments.training.front_DPCL_enhance  (reference experiments/training/front_DPCL_enhance.py)."""
-from utils.trainer import MyArgs, Front_Separator_Enhance_Trainer
-from models.dpcl import DPCL
+"""python -m experiments.training.front_DPCL_enhance -- see experiments/training/_recipes.py."""
+from experiments.training._recipes import main
 
 if __name__ == '__main__':
-    p = MyArgs()
-    p.parser.add_argument('--model_folder', help='Path to the model folder to load', required=True)
-    p.add_separator_args()
-    p.add_enhance_layer_args()
-    args = p.get_args()
-    trainer = Front_Separator_Enhance_Trainer(DPCL, 'front_DPCL_enhance', pretraining=False, **vars(args))
-    trainer.train()
+    main('front_DPCL_enhance')

@@ -1,13 +1,5 @@
-# coding: utf-8
-"""python -m experiments.training.front_L41  (reference experiments/training/front_L41.py)."""
-from utils.trainer import MyArgs, Front_Separator_Trainer
-from models.L41 import L41Model
+"""python -m experiments.training.front_L41 -- see experiments/training/_recipes.py."""
+from experiments.training._recipes import main
 
 if __name__ == '__main__':
-    p = MyArgs()
-    p.parser.add_argument('--model_folder', help='Path to the model folder to load', required=True)
-    p.parser.add_argument('--model_previous', help='Path to previous folder to load', required=False, default=None)
-    p.add_separator_args()
-    args = p.get_args()
-    trainer = Front_Separator_Trainer(L41Model, 'front_L41', pretraining=False, **vars(args))
-    trainer.train()
+    main('front_L41')

@@ -1,13 +1,5 @@
-# coding: utf-8
-"""python -m experiments.training.front_L41_enhance  (reference experiments/training/front_L41_enhance.py)."""
-from utils.trainer import MyArgs, Front_Separator_Enhance_Trainer
-from models.L41 import L41Model
+"""python -m experiments.training.front_L41_enhance -- see experiments/training/_recipes.py."""
+from experiments.training._recipes import main
 
 if __name__ == '__main__':
-    p = MyArgs()
-    p.parser.add_argument('--model_folder', help='Path to the model folder to load', required=True)
-    p.add_separator_args()
-    p.add_enhance_layer_args()
-    args = p.get_args()
-    trainer = Front_Separator_Enhance_Trainer(L41Model, 'front_L41_enhance', pretraining=False, **vars(args))
-    trainer.train()
+    main('front_L41_enhance')

@@ -1,11 +1,5 @@
-# coding: utf-8
-"""python -m experiments.training.pretraining  (reference experiments/training/pretraining.py)."""
-from utils.trainer import MyArgs, Adapt_Pretrainer
-
+"""python -m experiments.training.pretraining -- see experiments/training/_recipes.py."""
+from experiments.training._recipes import main
 
 if __name__ == '__main__':
-    p = MyArgs()
-    p.add_adapt_args()
-    args = p.get_args()
-    trainer = Adapt_Pretrainer(pretraining=True, **vars(args))
-    trainer.train()
+    main('pretraining')

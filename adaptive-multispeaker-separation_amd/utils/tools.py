@@ -2,8 +2,9 @@
 
 
 def getETA(batchTime, nbBatch, batchIndex, nbEpoch, epoch):
-    """Remaining training time as a string (reference utils/tools.py:4-8)."""
-    seconds = int(batchTime * (nbBatch - batchIndex) + batchTime * nbBatch * (nbEpoch - epoch))
-    m, s = divmod(seconds, 60)
-    h, m = divmod(m, 60)
-    return "%dh%02dm%02ds" % (h, m, s)
+    """Remaining training time, 'HhMMmSSs': batches left in this epoch plus all batches of the epochs still to run,
+    times the last batch duration (reference utils/tools.py:4-8)."""
+    batches_left = (nbBatch - batchIndex) + nbBatch * (nbEpoch - epoch)
+    total = int(batchTime * batches_left)
+    hours, rest = total // 3600, total % 3600
+    return "%dh%02dm%02ds" % (hours, rest // 60, rest % 60)

@@ -55,6 +55,37 @@ def test_every_entry_point_exists_and_imports():
         importlib.import_module('experiments.training.' + n)
 
 
+def test_entry_point_table_registers_the_reference_flags():
+    """experiments/training/_recipes.py: per script the Trainer class, the separator, the `type` string and the flag groups of the
+    reference's entry points (experiments/training/*.py)."""
+    from experiments.training import _recipes as R
+    import utils.trainer as T
+    assert set(R.RECIPES) == {'pretraining', 'STFT_DPCL', 'STFT_L41', 'STFT_DPCL_enhance', 'STFT_L41_enhance', 'STFT_DPCL_finetuning',
+                              'STFT_L41_finetuning', 'front_DPCL', 'front_L41', 'front_DPCL_enhance', 'front_L41_enhance',
+                              'front_DPCL_finetuning', 'front_L41_finetuning', 'front_DPCL_enhance_finetuning',
+                              'front_L41_enhance_finetuning'}
+    for name, (trainer, sep, typ, need_folder, has_prev, groups, pre) in R.RECIPES.items():
+        assert hasattr(T, trainer), trainer
+        argv = ['--men', '--women', '--nb_speakers', '2']
+        if need_folder:
+            argv += ['--model_folder', 'log/x']
+        a = R.build_parser(name).get_args(argv)
+        assert a.sex == ['M', 'F'] and a.nb_speakers == 2
+        assert hasattr(a, 'model_folder') == (need_folder is not None)
+        assert hasattr(a, 'model_previous') == has_prev
+        assert hasattr(a, 'nb_tries') == ('separator' in groups) and hasattr(a, 'train') == ('finetuning' in groups)
+        assert hasattr(a, 'nonlinearity') == ('enhance_layer' in groups)
+        assert hasattr(a, 'filters') == ('adapt' in groups)
+        if 'stft' in groups:
+            assert a.window_size == 512 and a.hop_size == 256
+        elif 'adapt' in groups:
+            assert a.window_size == 1024
+    # the reference quirks kept: STFT_{DPCL,L41} do not require --model_folder; the DPCL fine-tuning script passes 'front_L41_finetuning'
+    assert R.RECIPES['STFT_DPCL'][3] is False and R.RECIPES['front_DPCL_finetuning'][2] == 'front_L41_finetuning'
+    with pytest.raises(SystemExit):
+        R.build_parser('front_DPCL').get_args(['--men'])             # --model_folder is required there
+
+
 def test_front_dpcl_construction_names_and_freeze(tmp_path):
     from tests.smoke_step import build_front_dpcl
     trainer, tfds = build_front_dpcl(str(tmp_path), B=2, L=256, W=32, N=8, hop=8, layer_size=8, nb_layers=2, E=4)
