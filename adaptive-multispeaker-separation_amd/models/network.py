@@ -259,7 +259,8 @@ class Network(object):
                 run.cache[id(node)] = t
             g = torch.cuda.CUDAGraph()
             torch.cuda.synchronize()
-            with torch.cuda.graph(g, stream=side):
+            # thread_local: a collective library's watchdog thread (RCCL at N > 1) must not be able to invalidate this capture
+            with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
                 opt.zero_grad()
                 cost = self.cost_model.value(run)
                 cost.reshape(-1)[0].backward()
