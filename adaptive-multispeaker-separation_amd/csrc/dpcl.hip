@@ -167,12 +167,13 @@ __device__ __forceinline__ void load_counts(const float* __restrict__ cntp, int 
     }
 }
 
-template <int NT, int EC>                          // EC: compile-time E (0 = use the run-time value)
+template <int NT, int EC, int SC>                  // EC / SC: compile-time E / S (0 = use the run-time value; EC != 0 implies 16-byte rows)
 __global__ __launch_bounds__(256) void dpcl_gram_u_kernel(const float* __restrict__ U, const float* __restrict__ Y,
                                                           const float* __restrict__ cntp, float* __restrict__ inv_out,
                                                           float* __restrict__ V_out, float* __restrict__ part, long TF, int E_rt,
-                                                          int S, int nchunk) {
+                                                          int S_rt, int nchunk) {
     const int E = EC ? EC : E_rt;
+    const int S = SC ? SC : S_rt;
     constexpr int Z = NT * 16;
     constexpr int ZP = Z + 4;                       // row pitch: 16-byte aligned rows, 16 lanes x 16 B cover all banks
     constexpr int PTS = NT <= 3 ? 256 : 128;        // points staged per iteration
@@ -196,20 +197,21 @@ __global__ __launch_bounds__(256) void dpcl_gram_u_kernel(const float* __restric
     const long p_begin = (long)c * UCHUNK, p_end = min(TF, p_begin + UCHUNK);
     const float* Ub = U + (long)b * TF * E;
     const float* Yb = Y + (long)b * TF * S;
-    const bool vec = (E % 4 == 0) && (((uintptr_t)U & 15) == 0);
+    const bool vec = EC ? true : ((E % 4 == 0) && (((uintptr_t)U & 15) == 0));      // EC path: the launcher checked alignment
     const int nvec = PTS * E / 4;                   // 16-byte groups per full slab (vec path)
 
     float4 pre[NV];
     float yv[8];
+    // Loads are UNCONDITIONAL with clamped indices (out-of-range lanes re-read the last valid vector and are zeroed when the
+    // slab is stored to LDS): exec-masked branches around the loads made hipcc fall back to s_waitcnt vmcnt(0) right after
+    // issuing them, which serialised the "prefetch" with the HBM round trip.
     auto fetch = [&](long p0) {
         const int npts = (int)min((long)PTS, p_end - p0);
         if (vec) {
             const float4* src = reinterpret_cast<const float4*>(Ub + p0 * E);
+            const int last = npts * E / 4 - 1;
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int i4 = tid + 256 * j;
-                pre[j] = (i4 < nvec && i4 * 4 < npts * E) ? src[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int j = 0; j < NV; ++j) pre[j] = src[min(tid + 256 * j, last)];
         } else {
             const float* src = Ub + p0 * E;
 #pragma unroll
@@ -224,8 +226,9 @@ __global__ __launch_bounds__(256) void dpcl_gram_u_kernel(const float* __restric
             }
         }
         if (tid < PTS) {
+            const float* yr = Yb + (p0 + min(tid, npts - 1)) * S;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) yv[s] = (s < S && tid < npts) ? Yb[(p0 + tid) * S + s] : 0.f;
+            for (int s = 0; s < 8; ++s) yv[s] = (s < S) ? yr[s] : 0.f;
         }
     };
 
@@ -239,7 +242,7 @@ __global__ __launch_bounds__(256) void dpcl_gram_u_kernel(const float* __restric
                 const int i4 = tid + 256 * j;
                 if (i4 < nvec) {
                     const int pnt = (i4 * 4) / E, e = i4 * 4 - pnt * E;
-                    *reinterpret_cast<float4*>(&zt[pnt * ZP + e]) = pre[j];
+                    *reinterpret_cast<float4*>(&zt[pnt * ZP + e]) = (i4 * 4 < npts * E) ? pre[j] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
         } else {
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(256) void dpcl_gram_u_kernel(const float* __restric
             float diag = 0.f;
 #pragma unroll
             for (int s = 0; s < 8; ++s)
-                if (s < S) { zt[tid * ZP + E + s] = yv[s]; diag += yv[s] * cn[s]; }
+                if (s < S) { const float y = tid < npts ? yv[s] : 0.f; zt[tid * ZP + E + s] = y; diag += y * cn[s]; }
             dsh[tid] = (tid < npts && diag > 0.f) ? 1.0f / sqrtf(diag) : 0.f;    // all-zero Y row: reference has D = inf
         }
         __syncthreads();
@@ -447,12 +450,13 @@ __global__ __launch_bounds__(256) void dpcl_bwd_kernel(const float* __restrict__
 // on the fly.  The l2-normalise Jacobian (a 16-lane dot per point) is applied on the accumulators and dU goes back
 // through LDS so global traffic is 16-byte coalesced both ways; slab i+1 is fetched while slab i is in the MFMA phase.
 // Algorithmic HBM bytes per utterance: TF*(2E+S+1)*4.
-template <int NT, int EC>                          // EC: compile-time E (0 = use the run-time value)
+template <int NT, int EC, int SC>                  // EC / SC: compile-time E / S (0 = run-time; EC != 0 implies 16-byte rows)
 __global__ __launch_bounds__(256, 2) void dpcl_bwd_u_kernel(const float* __restrict__ U, const float* __restrict__ Y,
                                                          const float* __restrict__ cntp, const float* __restrict__ mats,
                                                          const float* __restrict__ inv, const float* __restrict__ upstream,
-                                                         float* __restrict__ dU, long TF, int E_rt, int S) {
+                                                         float* __restrict__ dU, long TF, int E_rt, int S_rt) {
     const int E = EC ? EC : E_rt;
+    const int S = SC ? SC : S_rt;
     constexpr int Z = NT * 16, ZP = Z + 4, KT = Z / 4;
     constexpr int PTS = NT <= 3 ? 256 : 128;
     constexpr int NV = PTS * Z / 4 / 256;
@@ -491,21 +495,22 @@ __global__ __launch_bounds__(256, 2) void dpcl_bwd_u_kernel(const float* __restr
     const float* Yb = Y + (long)b * TF * S;
     const float* ib = inv + (long)b * TF;
     float* dUb = dU + (long)b * TF * E;
-    const bool vec = (E % 4 == 0) && (((uintptr_t)U & 15) == 0) && (((uintptr_t)dU & 15) == 0);
+    const bool vec = EC ? true : ((E % 4 == 0) && (((uintptr_t)U & 15) == 0) && (((uintptr_t)dU & 15) == 0));
     const int nvec = PTS * E / 4;
 
     float4 pre[NV];
     float yv[8];
     float ivp = 0.f;
+    // Loads are UNCONDITIONAL with clamped indices (out-of-range lanes re-read the last valid vector and are zeroed when the
+    // slab is stored to LDS): exec-masked branches around the loads made hipcc fall back to s_waitcnt vmcnt(0) right after
+    // issuing them, which serialised the "prefetch" with the HBM round trip.
     auto fetch = [&](long p0) {
         const int npts = (int)min((long)PTS, p_end - p0);
         if (vec) {
             const float4* src = reinterpret_cast<const float4*>(Ub + p0 * E);
+            const int last = npts * E / 4 - 1;
 #pragma unroll
-            for (int j = 0; j < NV; ++j) {
-                const int i4 = tid + 256 * j;
-                pre[j] = (i4 < nvec && i4 * 4 < npts * E) ? src[i4] : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
+            for (int j = 0; j < NV; ++j) pre[j] = src[min(tid + 256 * j, last)];
         } else {
             const float* src = Ub + p0 * E;
 #pragma unroll
@@ -520,9 +525,11 @@ __global__ __launch_bounds__(256, 2) void dpcl_bwd_u_kernel(const float* __restr
             }
         }
         if (tid < PTS) {
+            const int pt = min(tid, npts - 1);
+            const float* yr = Yb + (p0 + pt) * S;
 #pragma unroll
-            for (int s = 0; s < 8; ++s) yv[s] = (s < S && tid < npts) ? Yb[(p0 + tid) * S + s] : 0.f;
-            ivp = (tid < npts) ? ib[p0 + tid] : 0.f;
+            for (int s = 0; s < 8; ++s) yv[s] = (s < S) ? yr[s] : 0.f;
+            ivp = ib[p0 + pt];
         }
     };
 
@@ -536,7 +543,7 @@ __global__ __launch_bounds__(256, 2) void dpcl_bwd_u_kernel(const float* __restr
                 const int i4 = tid + 256 * j;
                 if (i4 < nvec) {
                     const int pnt = (i4 * 4) / E, e = i4 * 4 - pnt * E;
-                    *reinterpret_cast<float4*>(&zt[pnt * ZP + e]) = pre[j];
+                    *reinterpret_cast<float4*>(&zt[pnt * ZP + e]) = (i4 * 4 < npts * E) ? pre[j] : make_float4(0.f, 0.f, 0.f, 0.f);
                 }
             }
         } else {
@@ -554,9 +561,9 @@ __global__ __launch_bounds__(256, 2) void dpcl_bwd_u_kernel(const float* __restr
             float diag = 0.f;
 #pragma unroll
             for (int s = 0; s < 8; ++s)
-                if (s < S) { zt[tid * ZP + E + s] = yv[s]; diag += yv[s] * cn[s]; }
+                if (s < S) { const float y = tid < npts ? yv[s] : 0.f; zt[tid * ZP + E + s] = y; diag += y * cn[s]; }
             dsh[tid] = (tid < npts && diag > 0.f) ? up / sqrtf(diag) : 0.f;     // all-zero Y row contributes nothing
-            ivs[tid] = ivp;
+            ivs[tid] = tid < npts ? ivp : 0.f;
         }
         __syncthreads();
         if (p0 + PTS < p_end) fetch(p0 + PTS);
@@ -700,13 +707,16 @@ ams_status ams_dpcl_loss_fwd_u(const float* U, const float* Y, float* inv, float
     hipLaunchKernelGGL(dpcl_count_part_kernel, dim3(CP, B), dim3(256), 0, st, Y, cntp, TF, S);
     dim3 grid(nchunk, B);
     switch (NT) {
-        case 1: hipLaunchKernelGGL((dpcl_gram_u_kernel<1, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
-        case 2: hipLaunchKernelGGL((dpcl_gram_u_kernel<2, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
-        case 3:
-            if (E == 40) hipLaunchKernelGGL((dpcl_gram_u_kernel<3, 40>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk);
-            else hipLaunchKernelGGL((dpcl_gram_u_kernel<3, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk);
+        case 1: hipLaunchKernelGGL((dpcl_gram_u_kernel<1, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
+        case 2: hipLaunchKernelGGL((dpcl_gram_u_kernel<2, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
+        case 3: {
+            const bool al = (((uintptr_t)U & 15) == 0);
+            if (E == 40 && S == 2 && al) hipLaunchKernelGGL((dpcl_gram_u_kernel<3, 40, 2>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk);
+            else if (E == 40 && S == 3 && al) hipLaunchKernelGGL((dpcl_gram_u_kernel<3, 40, 3>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk);
+            else hipLaunchKernelGGL((dpcl_gram_u_kernel<3, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk);
             break;
-        default: hipLaunchKernelGGL((dpcl_gram_u_kernel<4, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
+        }
+        default: hipLaunchKernelGGL((dpcl_gram_u_kernel<4, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
     }
     hipLaunchKernelGGL(dpcl_finish_kernel, dim3(B), dim3(256), Z * Z * sizeof(float), st, part, per_utt, mats, E, S, Z, nchunk, B);
     hipLaunchKernelGGL(dpcl_mean_kernel, dim3(1), dim3(64), 0, st, per_utt, out, B);
@@ -724,13 +734,16 @@ ams_status ams_dpcl_loss_bwd_u(const float* U, const float* Y, const float* inv,
     if (E + S > 64) return AMS_E_INVALID_ARG;
     dim3 grid(ceil_div(TF, UCHUNK), B);
     switch (NT) {
-        case 1: hipLaunchKernelGGL((dpcl_bwd_u_kernel<1, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S); break;
-        case 2: hipLaunchKernelGGL((dpcl_bwd_u_kernel<2, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S); break;
-        case 3:
-            if (E == 40) hipLaunchKernelGGL((dpcl_bwd_u_kernel<3, 40>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S);
-            else hipLaunchKernelGGL((dpcl_bwd_u_kernel<3, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S);
+        case 1: hipLaunchKernelGGL((dpcl_bwd_u_kernel<1, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S); break;
+        case 2: hipLaunchKernelGGL((dpcl_bwd_u_kernel<2, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S); break;
+        case 3: {
+            const bool al = (((uintptr_t)U & 15) == 0) && (((uintptr_t)dU & 15) == 0);
+            if (E == 40 && S == 2 && al) hipLaunchKernelGGL((dpcl_bwd_u_kernel<3, 40, 2>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S);
+            else if (E == 40 && S == 3 && al) hipLaunchKernelGGL((dpcl_bwd_u_kernel<3, 40, 3>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S);
+            else hipLaunchKernelGGL((dpcl_bwd_u_kernel<3, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S);
             break;
-        default: hipLaunchKernelGGL((dpcl_bwd_u_kernel<4, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S); break;
+        }
+        default: hipLaunchKernelGGL((dpcl_bwd_u_kernel<4, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S); break;
     }
     return ams_check_launch();
 }
