@@ -22,6 +22,7 @@ class _Overlap(object):
     def __init__(self):
         self.enabled = False
         self.stream = None
+        self.n_cap = 0
 
     def side(self):
         if self.stream is None:
@@ -42,12 +43,21 @@ class _Overlap(object):
     def cap(self, on, kind='dense'):
         import os
         from ._lib import load
-        pad = int(os.environ.get('AMS_SIDE_LDS_PAD', '70000'))
+        # residency cap of side-stream products via a dynamic-LDS pad: dense dW (beside the top layer's BPTT, whose step
+        # kernels hold 16 KB of LDS) runs 2 workgroups per CU, the LSTM weight gradients 1 per CU -- measured best with the
+        # step kernels at s_setprio 3 (9.62 k vs 9.32 k mixtures/s for 1 per CU everywhere; 3 per CU: 9.3 k)
+        pad = int(os.environ.get('AMS_SIDE_LDS_PAD', '40000'))
         if kind == 'lstm':
-            pad = int(os.environ.get('AMS_SIDE_LDS_PAD_LSTM', str(pad)))
+            pad = int(os.environ.get('AMS_SIDE_LDS_PAD_LSTM', '70000'))
+        tab = os.environ.get('AMS_SIDE_PADS')           # tuning aid: one pad per capped launch group, in issue order
+        if on and tab:
+            tab = [int(v) for v in tab.split(',')]
+            pad = tab[min(self.n_cap, len(tab) - 1)]
+            self.n_cap += 1
         load().ams_gemm_set_lds_pad(pad if on else 0)
 
     def join(self):
+        self.n_cap = 0
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
 
@@ -90,6 +100,37 @@ _ORDER = int(_os.environ.get('AMS_OVERLAP_ORDER', '2'))
 # dense layer backward: 0 = dX first, dW capped beside the next recurrence (9.30 k mixtures/s); 1 = dW || dX uncapped (9.05 k);
 # 2 = dW alone, then dX (8.97 k) -- measured on the B=64 step, kept as a tuning aid
 _DENSE_MODE = int(_os.environ.get('AMS_DENSE_MODE', '0'))
+_L1_TAIL = int(_os.environ.get('AMS_L1_TAIL', '0'))
+
+
+_NEXT = []
+
+
+def hint_next(kind=None, *params):
+    """Tell the next blstm() call which row-wise product consumes its output: ('proj', Kf, bf, Kb, bb) = another BLSTM layer,
+    ('dense', W, b) = the width-1 Conv1D.  One-shot; see ops.TAIL_CUTS."""
+    del _NEXT[:]
+    if kind is not None:
+        _NEXT.append((kind,) + tuple(params))
+
+
+def _take_hint(in_dim):
+    if not _NEXT:
+        return None
+    h = _NEXT.pop()
+    if h[0] == 'proj':
+        Kf, bf, Kb, bb = h[1:]
+        H4 = Kf.shape[1]
+        D = Kf.shape[0] - H4 // 4
+        if D != in_dim or not Kf.is_cuda or not ops._twin(Kf, Kb):     # zero-copy [D, 8H] view only (FlatOptimizer layout)
+            return None
+        W = ops.blstm_wcat(Kf, Kb, D)
+        bias = torch.as_strided(bf, (2 * H4,), (1,)) if ops._twin(bf, bb) else torch.cat([bf, bb])
+        return ('proj', W.detach(), bias.detach())
+    W, b = h[1:]
+    if W.shape[0] != in_dim or not W.is_cuda or W.stride(1) != 1:
+        return None
+    return ('dense', W.detach(), b.detach())
 
 
 class BLSTMLayer(Function):
@@ -97,7 +138,7 @@ class BLSTMLayer(Function):
 
     @staticmethod
     def forward(ctx, x, Kf, bf, Kb, bb):
-        out, G, cst = ops.blstm_fwd(x, Kf, bf, Kb, bb)
+        out, G, cst = ops.blstm_fwd(x, Kf, bf, Kb, bb, consumer=_take_hint(Kf.shape[1] // 2))
         ctx.save_for_backward(x, Kf, Kb, out, G, cst)
         ctx.biases = (bf, bb)
         return out
@@ -116,13 +157,22 @@ class BLSTMLayer(Function):
             s = OVERLAP.fork(x, out, G)
             if not need_dx:
                 # first layer: no recurrence follows -- both streams work on the weight gradients, uncapped
-                with torch.cuda.stream(s):
+                if _L1_TAIL == 0:
+                    with torch.cuda.stream(s):
+                        ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u')
+                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx')
+                elif _L1_TAIL == 1:
+                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx')
                     ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u')
-                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx')
+                else:
+                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u')
+                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx')
                 return None, None, None, None, None
             with torch.cuda.stream(s):
                 OVERLAP.cap(True, 'lstm')
-                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True)
+                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx')
+                OVERLAP.cap(True, 'lstm')
+                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u')
                 OVERLAP.cap(False)
             if dx is None and need_dx:
                 dx = ops.blstm_bwd_dx(G, Kf, Kb, B, T, D)
@@ -138,9 +188,7 @@ class Dense(Function):
     def forward(ctx, x, W, b):
         ctx.save_for_backward(x, W)
         ctx.bias = b
-        x2 = x.reshape(-1, x.shape[-1])
-        u = ops.gemm(x2, W, bias=b)
-        return u.view(x.shape[:-1] + (W.shape[1],))
+        return ops.dense_fwd(x, W, b)
 
     @staticmethod
     def backward(ctx, du):

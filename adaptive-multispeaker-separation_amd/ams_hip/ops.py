@@ -224,9 +224,11 @@ def persist_errors():
     return sum(int(t[:1].view(torch.int32).item() != 0) for t in LAST_SYNC)
 
 
-def blstm_fwd(x, Kf, bf, Kb, bb):
+def blstm_fwd(x, Kf, bf, Kb, bb, consumer=None):
     """One BLSTM layer (utils/ops.py:358-383).  x [B,T,D]; K* [D+H,4H]; b* [4H].
-    Returns out [B,T,2H] and the tensors the backward needs (G = activated gates, cst = cell states)."""
+    Returns out [B,T,2H] and the tensors the backward needs (G = activated gates, cst = cell states).
+    consumer: optional (kind, W [2H, Dout] row-major view, bias [Dout]) of the row-wise product that will read `out` next
+    (the next layer's input projection or the dense layer) -- see the TAIL_* note below."""
     _chk(x, bf, bb)
     _chk_rows(Kf, Kb)
     lib = load()
@@ -235,17 +237,33 @@ def blstm_fwd(x, Kf, bf, Kb, bb):
     ldu = Kf.stride(0)
     if Kb.stride(0) != ldu:
         raise AmsError('blstm: the two direction kernels must share one row stride')
-    G = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=x.device)
     x2 = x.view(B * T, D)
+    Wcat = blstm_wcat(Kf, Kb, D)
+    bias = torch.as_strided(bf, (8 * H,), (1,)) if _twin(bf, bb) else torch.cat([bf, bb])
+    pre = _take_precomputed(x, Wcat, 8 * H)
+    if pre is not None:
+        G = pre['Y'].view(B, T, 2, 4 * H)
+    else:
+        G = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=x.device)
     # hoisted input projection of BOTH directions as ONE MFMA GEMM [B*T, D] x [D, 8H]: the two [D,4H] halves of the TF
     # kernels are gathered side by side (a 2 x D x 4H copy) so N = 8H gives 19 x 40 = 760 tiles = 2.97 per CU instead of
     # two launches of 400 (1.56 per CU, i.e. 22 % of the CU-time idle).
-    Wcat = blstm_wcat(Kf, Kb, D)
-    bias = torch.as_strided(bf, (8 * H,), (1,)) if _twin(bf, bb) else torch.cat([bf, bb])
-    gemm(x2, Wcat, bias=bias, out=G, M=B * T, N=8 * H, K=D, lda=D, ldb=8 * H, ldc=8 * H, label='blstm_input_gemm')
     out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
     cst = torch.empty((B, T, 2, H), dtype=torch.float32, device=x.device)
     pack = torch.empty(lib.ams_blstm_pack_floats(H, 0), dtype=torch.float32, device=x.device)
+    bands = _fwd_bands(T) if not (LSTM_PERSIST or pre is not None or consumer is not None) else None
+    if bands:
+        _blstm_fwd_banded(lib, x2, Wcat, bias, G, out, cst, pack, Kf[D:], Kb[D:], ldu, B, T, D, H, bands)
+        return out, G, cst
+    if pre is not None:
+        _finish_precomputed(lib, pre, x2, Wcat, 8 * H, bias, B, T, D, 'blstm_input_gemm')
+    else:
+        gemm(x2, Wcat, bias=bias, out=G, M=B * T, N=8 * H, K=D, lda=D, ldb=8 * H, ldc=8 * H, label='blstm_input_gemm')
+    cuts = _tail_cuts(consumer[0], T) if (consumer is not None and not LSTM_PERSIST) else None
+    if cuts:
+        check(lib.ams_blstm_pack(_p(Kf[D:]), _p(Kb[D:]), ldu, _p(pack), H, 0, _s()), 'ams_blstm_pack')
+        _fwd_steps_feeding(lib, G, out, cst, pack, B, T, H, consumer, cuts)
+        return out, G, cst
     nsync = lib.ams_blstm_persist_sync_bytes(B, H, 0) if LSTM_PERSIST else 0
     if nsync:
         sync = _ws(nsync, x)
@@ -257,6 +275,164 @@ def blstm_fwd(x, Kf, bf, Kb, bb):
         check(lib.ams_blstm_recurrent_fwd(_p(G), _p(out), _p(cst), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(pack), B, T, H, _s()),
               'ams_blstm_recurrent_fwd')
     return out, G, cst
+
+
+# Time-banded input projection: the recurrence of a layer is a chain of T dependent launches that leaves ~100 CUs idle, and
+# step s only needs the projected rows of time s (forward direction) / T-1-s (backward direction).  So only the first band of
+# steps is projected before the recurrence starts; the remaining bands run on a side stream (residency-capped, like the
+# weight-gradient products of the backward pass) while the recurrence works through the earlier ones, each band guarded by an
+# event.  AMS_FWD_BANDS = comma-separated step boundaries (e.g. "8,26,52"); default "0" = one product up front: measured
+# 9.38-9.54 k vs 9.59 k mixtures/s -- the first band is a latency-bound 50-70 us launch whatever its size, and the side bands
+# slow ~70 steps by 0.7 us each.  Kept as a tuning aid; the cross-layer form below (TAIL_*) is the one that pays.
+FWD_BANDS = _os.environ.get('AMS_FWD_BANDS', '0')
+_BAND_STREAM = []
+
+
+def _fwd_bands(T):
+    if FWD_BANDS in ('', '0'):
+        return None
+    cuts = sorted(set(int(v) for v in FWD_BANDS.split(',') if 0 < int(v) < T))
+    if not cuts or T < 16:
+        return None
+    edges = [0] + cuts + [T]
+    return list(zip(edges[:-1], edges[1:]))
+
+
+def _band_gemm(lib, x2, Wcat, bias, G, B, T, D, H, s0, s1):
+    """Project steps [s0, s1) of both directions: rows (b, s0..s1) for z = 0 and (b, T-s1..T-s0) for z = 1."""
+    n = s1 - s0
+    M = B * n
+    nb = lib.ams_gemm_batched_workspace_bytes(M, 4 * H, D, 2)
+    ws = _ws(nb, x2) if nb else None
+    ev = PROFILE.begin() if PROFILE.enabled else None
+    check(lib.ams_gemm_f32_rowseg(M, 4 * H, D, _p(x2), D, _p(Wcat), 8 * H, 4 * H, _p(G), 8 * H, 4 * H, _p(bias), 4 * H,
+                                  n, T, s0, T - s1 - s0, 2, _p(ws), nb, _s()), 'ams_gemm_f32_rowseg')
+    if ev is not None:
+        PROFILE.end(ev, 2 * 2.0 * M * 4 * H * D, 2 * 4.0 * (M * D + D * 4 * H + M * 4 * H), 'gemm<0,0>', 'blstm_input_gemm')
+
+
+def _blstm_fwd_banded(lib, x2, Wcat, bias, G, out, cst, pack, Uf, Ub, ldu, B, T, D, H, bands):
+    main = torch.cuda.current_stream()
+    if not _BAND_STREAM:
+        _BAND_STREAM.append(torch.cuda.Stream())
+    side = _BAND_STREAM[0]
+    side.wait_stream(main)                               # x is ready
+    for t_ in (x2, Wcat, bias, G):
+        t_.record_stream(side)
+    events = []
+    with torch.cuda.stream(side):
+        lib.ams_gemm_set_lds_pad(int(_os.environ.get('AMS_BAND_LDS_PAD', '70000')))
+        for s0, s1 in bands[1:]:
+            _band_gemm(lib, x2, Wcat, bias, G, B, T, D, H, s0, s1)
+            events.append(side.record_event())
+        lib.ams_gemm_set_lds_pad(0)
+    _band_gemm(lib, x2, Wcat, bias, G, B, T, D, H, bands[0][0], bands[0][1])
+    check(lib.ams_blstm_pack(_p(Uf), _p(Ub), ldu, _p(pack), H, 0, _s()), 'ams_blstm_pack')
+    for i, (s0, s1) in enumerate(bands):
+        if i > 0:
+            main.wait_event(events[i - 1])
+        check(lib.ams_blstm_recurrent_fwd_steps(_p(G), _p(out), _p(cst), _p(pack), B, T, H, s0, s1, _s()),
+              'ams_blstm_recurrent_fwd_steps')
+
+
+# Cross-layer tail overlap.  Row (b, t) of a BLSTM layer's output is complete once BOTH directions have passed time t, i.e.
+# after s recurrence steps the rows with T-s <= t < s are final -- the middle of the sequence first, the two ends last.  Whatever
+# reads `out` row by row next (the next layer's input projection [2H -> 8H], or the dense layer [2H -> F*E]) can therefore start
+# on those rows while the recurrence is still working through its last steps with ~100 CUs idle: at each cut the host records
+# an event behind the step launches and a side stream runs the consumer product for the newly completed rows (row-segmented
+# GEMM, residency-capped like the weight-gradient products).  The consumer later finds the partly filled result, computes only
+# the two end bands and joins the side stream.  (The reference runs each layer's while_loop to completion first,
+# utils/ops.py:358-383, then the next matmul.)
+# MEASURED, default OFF ("0"; e.g. AMS_TAIL_CUTS_PROJ=48,64 AMS_TAIL_CUTS_DENSE=48 turns it on): 9.33-9.43 k (projections) /
+# 9.58-9.60 k (dense only) vs 9.60 k mixtures/s without.  A 128x128x8-tile GEMM needs ~3+ workgroups per CU to cover its fetch
+# latency, so the 40 % end-band product takes 66 % of the full product's time, its split-K reduce another 45 us, the steps
+# that share CUs with a band run 0.7-1.7 us slower, and a stream join inside a replayed hipGraph showed up as a 40-55 us
+# bubble on the main chain.  Kept as a tuning aid for other shapes (longer T, larger B).
+TAIL_CUTS = {'proj': _os.environ.get('AMS_TAIL_CUTS_PROJ', '0'), 'dense': _os.environ.get('AMS_TAIL_CUTS_DENSE', '0')}
+TAIL_PAD = {'proj': int(_os.environ.get('AMS_TAIL_PAD_PROJ', '70000')), 'dense': int(_os.environ.get('AMS_TAIL_PAD_DENSE', '40000'))}
+_PRE = {}
+
+
+def _tail_cuts(kind, T):
+    spec = TAIL_CUTS.get(kind, '0')
+    if spec in ('', '0') or T < 16:
+        return None
+    ref_T = 80                                        # cuts are quoted for the benchmark's 80 steps and scaled to T
+    cuts = sorted(set(int(round(int(v) * T / float(ref_T))) for v in spec.split(',')))
+    cuts = [c for c in cuts if T - c < c < T]
+    return cuts or None
+
+
+def _rows_gemm(lib, x2, W, ldw, Dout, bias, Y, B, T, K, segs, label):
+    """Y[(b,t), :] = x2[(b,t), :] . W + bias for t in the given equal-length segment(s) [(t0, t1)] or [(t0, t1), (u0, u1)]."""
+    n = segs[0][1] - segs[0][0]
+    nz = len(segs)
+    M = B * n
+    nb = lib.ams_gemm_batched_workspace_bytes(M, Dout, K, nz)
+    ws = _ws(nb, x2) if nb else None
+    ev = PROFILE.begin() if PROFILE.enabled else None
+    check(lib.ams_gemm_f32_rowseg(M, Dout, K, _p(x2), K, _p(W), ldw, 0, _p(Y), Dout, 0, _p(bias), 0, n, T, segs[0][0],
+                                  (segs[1][0] - segs[0][0]) if nz > 1 else 0, nz, _p(ws), nb, _s()), 'ams_gemm_f32_rowseg')
+    if ev is not None:
+        PROFILE.end(ev, nz * 2.0 * M * Dout * K, nz * 4.0 * (M * K + K * Dout + M * Dout), 'gemm<0,0>', label)
+
+
+def _fwd_steps_feeding(lib, G, out, cst, pack, B, T, H, consumer, cuts):
+    kind, W, bias = consumer
+    Dout = W.shape[1]
+    Y = torch.empty((B, T, Dout), dtype=torch.float32, device=out.device)
+    out2 = out.view(B * T, 2 * H)
+    main = torch.cuda.current_stream()
+    if not _BAND_STREAM:
+        _BAND_STREAM.append(torch.cuda.Stream())
+    side = _BAND_STREAM[0]
+    for t_ in (out, W, bias, Y):
+        t_.record_stream(side)
+    lo = hi = None
+    s_prev = 0
+    for s in cuts:
+        check(lib.ams_blstm_recurrent_fwd_steps(_p(G), _p(out), _p(cst), _p(pack), B, T, H, s_prev, s, _s()),
+              'ams_blstm_recurrent_fwd_steps')
+        side.wait_event(main.record_event())
+        with torch.cuda.stream(side):
+            lib.ams_gemm_set_lds_pad(TAIL_PAD[kind])
+            segs = [(T - s, s)] if lo is None else [(T - s, lo), (hi, s)]
+            _rows_gemm(lib, out2, W, W.stride(0), Dout, bias, Y, B, T, 2 * H, segs, 'tail_' + kind)
+            lib.ams_gemm_set_lds_pad(0)
+        lo, hi, s_prev = T - s, s, s
+    check(lib.ams_blstm_recurrent_fwd_steps(_p(G), _p(out), _p(cst), _p(pack), B, T, H, s_prev, T, _s()),
+          'ams_blstm_recurrent_fwd_steps')
+    _PRE.clear()
+    _PRE[out.data_ptr()] = {'Y': Y, 'lo': lo, 'hi': hi, 'event': side.record_event(), 'W': W.data_ptr(), 'Dout': Dout,
+                            'shape': (B, T, 2 * H)}
+
+
+def _take_precomputed(x, W, Dout):
+    e = _PRE.pop(x.data_ptr(), None) if _PRE else None
+    if e is None:
+        return None
+    if e['W'] != W.data_ptr() or e['Dout'] != Dout or tuple(x.shape) != e['shape']:
+        torch.cuda.current_stream().wait_event(e['event'])     # not ours: drop the partial result, but stay ordered behind it
+        return None
+    return e
+
+
+def _finish_precomputed(lib, e, x2, W, Dout, bias, B, T, K, label):
+    """The two end bands [0, lo) and [hi, T) on the current stream, then join the side stream that filled the middle."""
+    _rows_gemm(lib, x2, W, W.stride(0), Dout, bias, e['Y'], B, T, K, [(0, e['lo']), (e['hi'], T)], label)
+    torch.cuda.current_stream().wait_event(e['event'])
+
+
+def dense_fwd(x, W, b):
+    """u = x.W + b over the last axis (utils/ops.py:486-503), picking up rows a preceding blstm_fwd(consumer=...) already
+    produced."""
+    x2 = x.reshape(-1, x.shape[-1])
+    e = _take_precomputed(x, W, W.shape[1]) if x.dim() == 3 else None
+    if e is None:
+        return gemm(x2, W, bias=b).view(x.shape[:-1] + (W.shape[1],))
+    B, T, K = x.shape
+    _finish_precomputed(load(), e, x2, W, W.shape[1], b, B, T, K, 'dense')
+    return e['Y']
 
 
 def blstm_wcat(Kf, Kb, D):

@@ -26,8 +26,6 @@ thread_local int t_gemm_lds_pad = 0;
 #define AMS_GEMM_BK 8
 #endif
 constexpr int BM = 128, BN = 128, BK = AMS_GEMM_BK;
-constexpr int NLD = BK / 8;       // float4 loads per thread per operand per k-tile
-constexpr int KQ = BK / 4;        // float4 per row of a k-contiguous operand tile
 constexpr int PAD_T = 2;   // k-contiguous source, transposed scalar LDS writes: stride 130 -> conflict-free
 constexpr int PAD_V = 4;   // m/n-contiguous source, float4 LDS writes: stride 132 keeps 16B alignment
 
@@ -51,12 +49,20 @@ struct GemmArgs {
     int32_t* pidx;             // EPI_MAXPOOL: per (row-tile, column) arg-max row
     // batch (grid.z): element offsets added per batch index to A, B, C (any sign); partial slabs are z-major
     long a_zs, b_zs, c_zs;
+    // row segments (A_ROW only): logical row m of A and C lives at row (m / seg_len) * seg_stride + seg_off + m % seg_len;
+    // seg_len 0 = identity.  Batch index z shifts seg_off by z * seg_off_zs and bias by z * bias_zs.
+    int seg_len;
+    long seg_stride, seg_off, seg_off_zs, bias_zs;
 };
+
+__device__ __forceinline__ long rowmap(const GemmArgs& g, int m) {
+    return g.seg_len ? (long)(m / g.seg_len) * g.seg_stride + g.seg_off + (m % g.seg_len) : (long)m;
+}
 
 template <int AMODE>
 __device__ __forceinline__ float loadA1(const GemmArgs& g, int m, int k) {
     if (m >= g.M || k >= g.K) return 0.f;
-    if (AMODE == A_ROW) return g.A[(long)m * g.lda + k];
+    if (AMODE == A_ROW) return g.A[rowmap(g, m) * g.lda + k];
     if (AMODE == A_COL) {
         if (g.mask_period && (k % g.mask_period) == g.mask_skip) return 0.f;
         return g.A[(long)k * g.lda + m];
@@ -84,14 +90,20 @@ template <int AMODE> struct AKContig { static constexpr bool v = (AMODE == A_ROW
 
 enum { EPI_STORE = 0, EPI_MAXPOOL = 1 };
 
-template <int AMODE, int BMODE, int EPI = EPI_STORE>
 #ifndef AMS_GEMM_WPE
 #define AMS_GEMM_WPE 2
 #endif
+// BKT = k-depth of one LDS tile.  8 is best at ~5 workgroups per CU (+4..10 % over 16).  A deeper tile for the residency-capped
+// side-stream launches was measured too (BKT = 16 at 1-2 workgroups per CU): the capped products themselves got 0-19 % faster
+// but the recurrent step kernels sharing the CU slowed from 9 to 21 us, 9.14 k vs 9.60 k mixtures/s overall -- not used.
+template <int AMODE, int BMODE, int EPI = EPI_STORE, int BKT = AMS_GEMM_BK>
 __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g) {
+    constexpr int BK = BKT, NLD = BK / 8, KQ = BK / 4;
     if (gridDim.z > 1) {                            // batched launch: same shape, shifted operands
         const long z = blockIdx.z;
         g.A += z * g.a_zs; g.B += z * g.b_zs; g.C += z * g.c_zs;
+        g.seg_off += z * g.seg_off_zs;
+        if (g.bias) g.bias += z * g.bias_zs;
         if (g.partial) g.partial += z * (long)g.splits * g.M * g.N;
     }
     constexpr bool AK = AKContig<AMODE>::v;
@@ -139,6 +151,9 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[NLD], rb[NLD];
+    long arow[NLD];                                 // A_ROW: element offset of this thread's operand row(s), mapped once
+#pragma unroll
+    for (int h = 0; h < NLD; ++h) arow[h] = (AMODE == A_ROW) ? rowmap(g, min(m0 + (tid + h * 256) / KQ, g.M - 1)) * g.lda : 0;
 
     auto fetch = [&](int kt) {
         const int k0 = k_begin + kt * BK;
@@ -154,7 +169,7 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
                     if (p >= 0 && p + 3 < g.fr_L) ra[h] = *reinterpret_cast<const float4*>(g.A + (long)b * g.fr_L + p);
                     else fast = false;
                 } else if (fast) {
-                    ra[h] = *reinterpret_cast<const float4*>(g.A + (long)m * g.lda + k);
+                    ra[h] = *reinterpret_cast<const float4*>(g.A + arow[h] + k);
                 }
                 if (!fast) {
                     ra[h].x = (k + 0 < k_end) ? loadA1<AMODE>(g, m, k + 0) : 0.f;
@@ -309,7 +324,7 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (row < g.M) {
                     float v = acc[i][j][r] + bv;
-                    float* p = out + (long)row * ldo + col;
+                    float* p = out + ((g.splits == 1 && g.seg_len) ? rowmap(g, row) : (long)row) * ldo + col;
                     if (g.splits == 1 && g.accumulate) v += *p;
                     *p = v;
                 }
@@ -318,16 +333,19 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, const float* __restrict__ bias,
-                                     int M, int N, long ldc, int splits, int accumulate, long c_zs) {
+                                     int M, int N, long ldc, int splits, int accumulate, long c_zs, int seg_len, long seg_stride,
+                                     long seg_off, long seg_off_zs, long bias_zs) {
     const long total = (long)M * N;
     partial += (long)blockIdx.y * splits * total;
     C += (long)blockIdx.y * c_zs;
+    seg_off += (long)blockIdx.y * seg_off_zs;
+    if (bias) bias += (long)blockIdx.y * bias_zs;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int m = (int)(i / N), n = (int)(i - (long)m * N);
         float s = 0.f;
         for (int k = 0; k < splits; ++k) s += partial[(long)k * total + i];
         if (bias) s += bias[n];
-        float* p = C + (long)m * ldc + n;
+        float* p = C + (seg_len ? (long)(m / seg_len) * seg_stride + seg_off + (m % seg_len) : (long)m) * ldc + n;
         if (accumulate) s += *p;
         *p = s;
     }
@@ -405,7 +423,7 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
         int blocks = (int)((total + 255) / 256);
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, nbatch), dim3(256), 0, st, g.partial, g.C, g.bias, g.M, g.N, g.ldc,
-                           splits, g.accumulate, g.c_zs);
+                           splits, g.accumulate, g.c_zs, g.seg_len, g.seg_stride, g.seg_off, g.seg_off_zs, g.bias_zs);
         s = ams_check_launch();
     }
     return s;
@@ -471,6 +489,27 @@ ams_status ams_gemm_f32_batched(int transA, int transB, int M, int N, int K, con
     if (!transA && transB) return launch<A_ROW, B_COL>(g, ws, ws_bytes, st, nbatch);
     if (transA && !transB) return launch<A_COL, B_ROW>(g, ws, ws_bytes, st, nbatch);
     return launch<A_COL, B_COL>(g, ws, ws_bytes, st, nbatch);
+}
+
+// Row-segmented batched product (A_ROW x B_ROW): for z < nbatch and logical row r < M,
+//   row(z, r) = (r / seg_len) * seg_stride + seg_off + z * seg_off_zs + r % seg_len
+//   C[row * ldc + z * c_zs + n] = sum_k A[row * lda + k] * B[k * ldb + z * b_zs + n] + bias[z * bias_zs + n]
+// A and C share the row map.  This is the BLSTM input projection restricted to a band of time steps of every utterance
+// (rows (b, t0..t0+len) of a [B, T, .] buffer: seg_len = len, seg_stride = T, seg_off = t0), with the two directions as
+// z = 0, 1 taking their bands from opposite ends of the sequence (reference utils/ops.py:366-383 computes the same
+// product inside dynamic_rnn, step by step).
+ams_status ams_gemm_f32_rowseg(int M, int N, int K, const float* A, long lda, const float* B, long ldb, long b_zs, float* C,
+                               long ldc, long c_zs, const float* bias, long bias_zs, int seg_len, long seg_stride, long seg_off,
+                               long seg_off_zs, int nbatch, void* ws, size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C && nbatch >= 1 && nbatch <= 64 && seg_len >= 0);
+    GemmArgs g{};
+    g.A = A; g.B = B; g.C = C; g.bias = bias;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.b_zs = b_zs; g.c_zs = c_zs; g.bias_zs = bias_zs;
+    g.seg_len = seg_len; g.seg_stride = seg_stride; g.seg_off = seg_off; g.seg_off_zs = seg_off_zs;
+    g.a_vec = aligned16(A) && (lda % 4 == 0);
+    g.b_vec = aligned16(B) && (ldb % 4 == 0) && (b_zs % 4 == 0);
+    return launch<A_ROW, B_ROW>(g, ws, ws_bytes, (hipStream_t)stream, nbatch);
 }
 
 // Adaptive analysis filterbank, path A (reference models/adapt.py:122): y[b,t,n] = sum_k xpad[b,t*hop+k-pl] f[k,n]

@@ -93,6 +93,7 @@ __device__ __forceinline__ float4 ld4_guard(const float* p, int k, int kmax, boo
 }
 
 __global__ __launch_bounds__(NWF * 64) void lstm_step_fwd_kernel(StepArgs a) {
+    __builtin_amdgcn_s_setprio(3);      // latency-bound: win issue arbitration over the weight-gradient GEMM waves sharing the CU
     __shared__ __attribute__((aligned(16))) float red[NWF][4][64][4];   // [wave][gate][lane][reg]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ut = blockIdx.x, bt = blockIdx.y, dir = blockIdx.z;
@@ -184,6 +185,7 @@ __global__ __launch_bounds__(NWF * 64) void lstm_step_fwd_kernel(StepArgs a) {
 
 // Backward step s: forward direction handles t = T-1-s, backward direction t = s.
 __global__ __launch_bounds__(NWB * 64) void lstm_step_bwd_kernel(StepArgs a) {
+    __builtin_amdgcn_s_setprio(3);      // latency-bound: win issue arbitration over the weight-gradient GEMM waves sharing the CU
     __shared__ __attribute__((aligned(16))) float red[NWB][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ut = blockIdx.x, bt = blockIdx.y, dir = blockIdx.z;
@@ -306,6 +308,23 @@ ams_status ams_blstm_recurrent_fwd(float* G, float* out, float* cst, const float
     a.B = B; a.T = T; a.H = H; a.n_ut = n_ut; a.n_g = n_g;
     dim3 grid(n_ut, ceil_div(B, TB), 2);
     for (int s = 0; s < T; ++s) {
+        a.s = s;
+        hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(NWF * 64), 0, st, a);
+    }
+    return ams_check_launch();
+}
+
+// Steps [s_begin, s_end) of the forward recurrence on an already packed recurrent matrix (ams_blstm_pack): lets the host
+// interleave the step launches with events of a time-banded input projection running on another stream.
+ams_status ams_blstm_recurrent_fwd_steps(float* G, float* out, float* cst, const float* pack, int B, int T, int H, int s_begin,
+                                         int s_end, void* stream) {
+    AMS_REQUIRE(G && out && cst && pack && B > 0 && T > 0 && H > 0 && s_begin >= 0 && s_begin <= s_end && s_end <= T);
+    hipStream_t st = (hipStream_t)stream;
+    StepArgs a{};
+    a.G = G; a.out = out; a.cst = cst; a.pk = const_cast<float*>(pack);
+    a.B = B; a.T = T; a.H = H; a.n_ut = ceil_div(H, TU); a.n_g = ceil_div(H, 16);
+    dim3 grid(a.n_ut, ceil_div(B, TB), 2);
+    for (int s = s_begin; s < s_end; ++s) {
         a.s = s;
         hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(NWF * 64), 0, st, a);
     }

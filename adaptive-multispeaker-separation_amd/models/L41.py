@@ -47,7 +47,7 @@ class L41Model(Separator):
 
         def _pred(run):
             x = x_node.value(run)
-            u = conv.f_prop(f_props(layers, x))
+            u = conv.f_prop(f_props(layers, x, then=conv))
             if normalize:
                 return F.l2norm(u, E)
             return u.reshape(u.shape[:-1] + (Fq, E))

@@ -27,7 +27,7 @@ class DPCL(Separator):
 
         def _embed(run):
             x = x_node.value(run)
-            return conv.f_prop(f_props(layers, x))             # [B, T, F*E]  (column = f*E + e)
+            return conv.f_prop(f_props(layers, x, then=conv))             # [B, T, F*E]  (column = f*E + e)
         self._embed = Node('embed', _embed, register=False)
         # Reshape + Normalize(3); only evaluated when the embeddings themselves are fetched (inference / k-means):
         # a training step goes u -> fused normalise+loss kernel and never writes V.

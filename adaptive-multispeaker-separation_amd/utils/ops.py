@@ -15,10 +15,19 @@ from ams_hip.graph import scope, get_scope_variable, get_default_graph  # noqa: 
 rng = np.random.RandomState(42)          # reference utils/ops.py:5 (module-level, shared by Conv1D inits)
 
 
-def f_props(layers, x):
-    """utils/ops.py:82-85."""
-    for layer in layers:
+def f_props(layers, x, then=None):
+    """utils/ops.py:82-85.  `then` (an addition) names the layer that will be applied to the result, so that the last BLSTM of
+    the list can start feeding it while its own recurrence finishes (ams_hip/ops.py TAIL_CUTS)."""
+    for i, layer in enumerate(layers):
+        nxt = layers[i + 1] if i + 1 < len(layers) else then
+        if isinstance(layer, BLSTM) and isinstance(nxt, BLSTM):
+            F.hint_next('proj', nxt.Kf, nxt.bf, nxt.Kb, nxt.bb)
+        elif isinstance(layer, BLSTM) and isinstance(nxt, Conv1D):
+            F.hint_next('dense', nxt.W, nxt.b)
+        else:
+            F.hint_next(None)
         x = layer.f_prop(x)
+    F.hint_next(None)
     return x
 
 

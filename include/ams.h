@@ -81,6 +81,15 @@ ams_status ams_gemm_f32_batched(int transA, int transB, int M, int N, int K, con
                                 long ldb, long b_zs, float* C, long ldc, long c_zs, int nbatch, int accumulate, int mask_period,
                                 int mask_skip, void* ws, size_t ws_bytes, void* stream);
 
+/* Row-segmented batched product (no transposes): for z < nbatch and logical row r < M,
+ *   row(z,r) = (r / seg_len) * seg_stride + seg_off + z * seg_off_zs + r % seg_len      (seg_len 0: row = r)
+ *   C[row*ldc + z*c_zs + n] = sum_k A[row*lda + k] * B[k*ldb + z*b_zs + n] + bias[z*bias_zs + n]   (bias may be NULL)
+ * = the BLSTM input projection (utils/ops.py:366-383: dynamic_rnn applies [x,h].K per step) restricted to a band of time
+ * steps of every utterance, both directions in one launch; workspace: ams_gemm_batched_workspace_bytes(M, N, K, nbatch). */
+ams_status ams_gemm_f32_rowseg(int M, int N, int K, const float* A, long lda, const float* B, long ldb, long b_zs, float* C,
+                               long ldc, long c_zs, const float* bias, long bias_zs, int seg_len, long seg_stride, long seg_off,
+                               long seg_off_zs, int nbatch, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- K7  dominant-speaker masks: one_hot(argmax_s |rep|, S, a, b)   models/network.py:377-378, :501-502 ----
  * rep_non_mix rows are (b,s) row-major, each TF long; Y [B,TF,S]; argmax [B,TF] int32 (may be NULL). */
 ams_status ams_make_masks(const float* rep_non_mix, float* Y, int32_t* argmax, int B, int S, long TF, float a, float b,
@@ -95,6 +104,10 @@ ams_status ams_blstm_recurrent_fwd(float* G, float* out, float* cst, const float
                                    int B, int T, int H, void* stream);
 ams_status ams_blstm_recurrent_bwd(float* G, const float* cst, const float* dout, float* dc, const float* Uf, const float* Ub,
                                    long ldu, float* pack, int B, int T, int H, void* stream);
+/* Steps [s_begin, s_end) of the forward recurrence (step s: t = s for the forward direction, T-1-s for the backward one)
+ * on a matrix already packed by ams_blstm_pack(..., backward = 0): the host may put stream waits between step ranges. */
+ams_status ams_blstm_recurrent_fwd_steps(float* G, float* out, float* cst, const float* pack, int B, int T, int H, int s_begin,
+                                         int s_end, void* stream);
 
 /* Persistent form of the same recurrence: one launch per layer and pass; workgroup rings exchange h_t / da_t in-launch
  * through epoch-tagged 8-byte granules (csrc/lstm_persist.hip).  ams_blstm_persist_sync_bytes returns 0 when the shape
