@@ -289,22 +289,34 @@ class DPCLLossFromU(Function):
 
 class DPCLLossU(Function):
     """l2-normalise + DPCL loss in ONE pass over u (dense output before Normalize): V is never materialised in a
-    training step; backward recomputes v = u/|u| (models/dpcl.py:41-87 + utils/ops.py:323-324)."""
+    training step; backward recomputes v = u/|u| (models/dpcl.py:41-87 + utils/ops.py:323-324).
+    Two outputs -- the cost as a 1-element tensor and all 4 terms (cost + the three summaries) -- so that the training step
+    differentiates the cost output directly: slicing terms[0:1] and selecting [0] put five fill/copy launches between the
+    loss kernels of every step."""
 
     @staticmethod
     def forward(ctx, u, Y):
         out, inv, _, ws = ops.dpcl_loss_fwd_u(u, Y)
         ctx.save_for_backward(u, inv, Y, ws)
-        return out
+        ctx.set_materialize_grads(False)
+        return out.narrow(0, 0, 1), out
 
     @staticmethod
-    def backward(ctx, dout):
+    def backward(ctx, dcost, dterms):
         u, inv, Y, ws = ctx.saved_tensors
-        return ops.dpcl_loss_bwd_u(u, Y, inv, ws, upstream=_c(dout)), None
+        if dterms is not None:                       # someone differentiated a summary term: only term 0 carries a gradient
+            up = _c(dterms).clone()
+            if dcost is not None:
+                up[0:1] += dcost
+        elif dcost is None:
+            return None, None
+        else:
+            up = _c(dcost)
+        return ops.dpcl_loss_bwd_u(u, Y, inv, ws, upstream=up), None
 
 
 def dpcl_loss_u(u, Y, E):
-    """u [B, ..., F*E] (column = f*E + e) -> the 4 loss terms; Y [B, TF, S]."""
+    """u [B, ..., F*E] (column = f*E + e) -> (cost [1], the 4 loss terms [4]); Y [B, TF, S]."""
     B = u.shape[0]
     return DPCLLossU.apply(_c(u).reshape(B, -1, E), _c(Y))
 

@@ -350,7 +350,7 @@ def _blstm_fwd_banded(lib, x2, Wcat, bias, G, out, cst, pack, Uf, Ub, ldu, B, T,
 # bubble on the main chain.  Kept as a tuning aid for other shapes (longer T, larger B).
 TAIL_CUTS = {'proj': _os.environ.get('AMS_TAIL_CUTS_PROJ', '0'), 'dense': _os.environ.get('AMS_TAIL_CUTS_DENSE', '0')}
 TAIL_PAD = {'proj': int(_os.environ.get('AMS_TAIL_PAD_PROJ', '70000')), 'dense': int(_os.environ.get('AMS_TAIL_PAD_DENSE', '40000'))}
-_PRE = {}
+_TAIL_READY = {}
 
 
 def _tail_cuts(kind, T):
@@ -402,13 +402,13 @@ def _fwd_steps_feeding(lib, G, out, cst, pack, B, T, H, consumer, cuts):
         lo, hi, s_prev = T - s, s, s
     check(lib.ams_blstm_recurrent_fwd_steps(_p(G), _p(out), _p(cst), _p(pack), B, T, H, s_prev, T, _s()),
           'ams_blstm_recurrent_fwd_steps')
-    _PRE.clear()
-    _PRE[out.data_ptr()] = {'Y': Y, 'lo': lo, 'hi': hi, 'event': side.record_event(), 'W': W.data_ptr(), 'Dout': Dout,
+    _TAIL_READY.clear()
+    _TAIL_READY[out.data_ptr()] = {'Y': Y, 'lo': lo, 'hi': hi, 'event': side.record_event(), 'W': W.data_ptr(), 'Dout': Dout,
                             'shape': (B, T, 2 * H)}
 
 
 def _take_precomputed(x, W, Dout):
-    e = _PRE.pop(x.data_ptr(), None) if _PRE else None
+    e = _TAIL_READY.pop(x.data_ptr(), None) if _TAIL_READY else None
     if e is None:
         return None
     if e['W'] != W.data_ptr() or e['Dout'] != Dout or tuple(x.shape) != e['shape']:

@@ -44,8 +44,9 @@ class DPCL(Separator):
             u = embed.value(run)
             Y = y.value(run)
             return F.dpcl_loss_u(u, Y.reshape(u.shape[0], -1, Y.shape[-1]), E)
-        terms = Node('terms', _terms)
-        cost = Node('cost_value', lambda run: terms.value(run)[0:1])
+        both = Node('loss', _terms)
+        terms = Node('terms', lambda run: both.value(run)[1])
+        cost = Node('cost_value', lambda run: both.value(run)[0])
         g.summaries['cost/cost'] = cost
         for k, name in ((1, '1'), (2, '2'), (3, '3')):           # dpcl.py:83-85
             g.summaries['cost/' + name] = Node(name, lambda run, k=k: terms.value(run)[k])

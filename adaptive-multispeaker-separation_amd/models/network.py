@@ -247,7 +247,7 @@ class Network(object):
                         run.cache[id(node)] = t
                     opt.zero_grad()
                     cost = self.cost_model.value(run)
-                    cost.reshape(-1)[0].backward()
+                    self._backward(cost)
                     F.OVERLAP.join()
                 torch.cuda.current_stream().wait_stream(side)
                 opt.step()
@@ -263,7 +263,7 @@ class Network(object):
             with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
                 opt.zero_grad()
                 cost = self.cost_model.value(run)
-                cost.reshape(-1)[0].backward()
+                self._backward(cost)
                 F.OVERLAP.join()
             st['graph'], st['cost'], st['run'] = g, cost, run
         for dst, src in zip(st['static'], ins):
@@ -275,6 +275,17 @@ class Network(object):
         self.last_run = st['run']
         return st['cost'].detach().reshape(-1)[0]
 
+    def _backward(self, cost):
+        """d cost[0]: a 1-element cost is seeded with a cached ones tensor (no select / fill launches on the way back)."""
+        c = cost.reshape(-1)
+        if c.numel() != 1:
+            c[0].backward()
+            return
+        seed = self.__dict__.get('_seed')
+        if seed is None or seed.device != c.device:
+            seed = self.__dict__['_seed'] = torch.ones(1, dtype=c.dtype, device=c.device)
+        c.backward(seed)
+
     def train(self, feed_dict, step):
         if self.args.get('hip_graph'):
             c = self._train_graphed(feed_dict, step)
@@ -284,7 +295,7 @@ class Network(object):
         opt = self.optimize
         opt.zero_grad()
         cost = self.cost_model.value(run)
-        cost.reshape(-1)[0].backward()
+        self._backward(cost)
         F.OVERLAP.join()
         opt.step()
         if self.summaries_enabled and getattr(self, 'merged_train', None):

@@ -332,7 +332,7 @@ def test_blstm_banded_and_tail_overlap_match_plain(ops, monkeypatch, B, T, D, H)
     out2, _, _ = ops.blstm_fwd(xd, Kfd, bfd, Kbd, bbd, consumer=('dense', Wd, bd))
     u = ops.dense_fwd(out2, Wd, bd)
     torch.cuda.synchronize()
-    assert not ops._PRE                                             # the partial result was picked up
+    assert not ops._TAIL_READY                                             # the partial result was picked up
     assert rel(host(out2), out_ref) < TOL
     assert rel(host(u), out_ref.reshape(B * T, 2 * H).dot(W).reshape(B, T, 50) + b) < TOL
     # a consumer that does not match drops the partial result and recomputes

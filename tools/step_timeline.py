@@ -48,6 +48,21 @@ def main():
             short = n[n.index('gemm_f32'):n.index('gemm_f32') + 24]
         print('%9.1f %8.1f  %-44s grid=%s,%s st=%s' % ((r[1] - t0) / 1e3, (r[2] - r[1]) / 1e3, short[:44], r[3], r[4], r[5]))
     flush()
+    # idle accounting: time inside the step during which NO kernel was running, and the gaps that make it up
+    seg = sorted((r[1], r[2], r[0]) for r in rows[a + 1:b + 1])
+    idle, cur_end, prev_name, gaps = 0.0, seg[0][0], '', []
+    for st, en, name in seg:
+        if st > cur_end:
+            g = (st - cur_end) / 1e3
+            idle += g
+            if g >= 3.0:
+                gaps.append((g, (cur_end - t0) / 1e3, prev_name, name))
+        if en > cur_end:
+            cur_end, prev_name = en, name
+    print('# idle (no kernel running): %.1f us in %d gaps >= 3 us' % (idle, len(gaps)))
+    for g, at, pn, nn in sorted(gaps, reverse=True)[:25]:
+        sh = lambda n: (n[n.index('gemm_f32'):n.index('gemm_f32') + 24] if 'gemm_f32' in n else n.split('(')[0].replace('(anonymous namespace)::', '').replace('void ', ''))[:40]  # noqa: E731
+        print('#   %6.1f us at %8.1f  after %-40s before %s' % (g, at, sh(pn), sh(nn)))
 
 
 if __name__ == '__main__':
