@@ -96,7 +96,12 @@ enum { EPI_STORE = 0, EPI_MAXPOOL = 1 };
 // BKT = k-depth of one LDS tile.  8 is best at ~5 workgroups per CU (+4..10 % over 16).  A deeper tile for the residency-capped
 // side-stream launches was measured too (BKT = 16 at 1-2 workgroups per CU): the capped products themselves got 0-19 % faster
 // but the recurrent step kernels sharing the CU slowed from 9 to 21 us, 9.14 k vs 9.60 k mixtures/s overall -- not used.
-template <int AMODE, int BMODE, int EPI = EPI_STORE, int BKT = AMS_GEMM_BK>
+// VEC: every operand fetch is ONE unconditional 16-byte load on a clamped address; validity (k beyond the split, masked rows)
+// is a predicate applied when the registers are written to LDS.  The guarded form below merges a vector path and a scalar
+// path per operand; each merge is a USE of the loaded value, so hipcc put `s_waitcnt vmcnt(0)` between the A fetch and the B
+// fetch and the MFMAs started only after A had landed: two exposed memory round trips per k-tile, hidden only when ~5
+// workgroups share a CU.  The host picks VEC whenever both operands are 16-byte addressable along their contiguous axis.
+template <int AMODE, int BMODE, int EPI = EPI_STORE, int BKT = AMS_GEMM_BK, bool VEC = false>
 __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g) {
     constexpr int BK = BKT, NLD = BK / 8, KQ = BK / 4;
     if (gridDim.z > 1) {                            // batched launch: same shape, shifted operands
@@ -155,8 +160,34 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
 #pragma unroll
     for (int h = 0; h < NLD; ++h) arow[h] = (AMODE == A_ROW) ? rowmap(g, min(m0 + (tid + h * 256) / KQ, g.M - 1)) * g.lda : 0;
 
+    bool va[NLD], vb[NLD];                          // VEC: validity of the staged registers
     auto fetch = [&](int kt) {
         const int k0 = k_begin + kt * BK;
+        if (VEC) {
+#pragma unroll
+            for (int h = 0; h < NLD; ++h) {
+                const int q = tid + h * 256;
+                if (AK) {                               // A_ROW: float4 along k (K % 4 == 0, so k < k_end covers all four)
+                    const int k = k0 + (q % KQ) * 4;
+                    va[h] = k < k_end;
+                    ra[h] = *reinterpret_cast<const float4*>(g.A + arow[h] + min(k, g.K - 4));
+                } else {                                // A_COL: float4 along m (M % 4 == 0)
+                    const int k = k0 + (q >> 5), m = m0 + (q & 31) * 4;
+                    va[h] = k < k_end && !(g.mask_period && (k % g.mask_period) == g.mask_skip);
+                    ra[h] = *reinterpret_cast<const float4*>(g.A + (long)min(k, g.K - 1) * g.lda + min(m, g.M - 4));
+                }
+                if (BKc) {                              // B_COL: float4 along k
+                    const int n = n0 + (q / KQ), k = k0 + (q % KQ) * 4;
+                    vb[h] = k < k_end;
+                    rb[h] = *reinterpret_cast<const float4*>(g.B + (long)min(n, g.N - 1) * g.ldb + min(k, g.K - 4));
+                } else {                                // B_ROW: float4 along n (N % 4 == 0)
+                    const int k = k0 + (q >> 5), n = n0 + (q & 31) * 4;
+                    vb[h] = k < k_end;
+                    rb[h] = *reinterpret_cast<const float4*>(g.B + (long)min(k, g.K - 1) * g.ldb + min(n, g.N - 4));
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int h = 0; h < NLD; ++h) {
             const int q = tid + h * 256;
@@ -218,6 +249,11 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
         float* bs = Bs + buf * BK * LDB_S;
 #pragma unroll
         for (int h = 0; h < NLD; ++h) {
+            if (VEC) {
+                const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (!va[h]) ra[h] = z;
+                if (!vb[h]) rb[h] = z;
+            }
             const int q = tid + h * 256;
             if (AK) {
                 const int mi = q / KQ, kq = (q % KQ) * 4;
@@ -415,6 +451,22 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
             raised = t_gemm_lds_pad;
         }
     }
+    constexpr bool AKc = (AMODE == A_ROW), BKcc = (BMODE == B_COL);
+    static const bool vec_off = getenv("AMS_GEMM_NOVEC") != nullptr;                                   // tuning aid
+    const bool vec = (AMODE == A_ROW || AMODE == A_COL) && g.a_vec && g.b_vec && !vec_off &&
+                     (AKc ? (g.K % 4 == 0 && g.K >= 4) : (g.M % 4 == 0 && g.M >= 4)) &&
+                     (BKcc ? (g.K % 4 == 0 && g.K >= 4) : (g.N % 4 == 0 && g.N >= 4));
+    if (vec) {
+        if (t_gemm_lds_pad > 40 * 1024) {
+            static thread_local int raised_v = 0;
+            if (raised_v < t_gemm_lds_pad) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<AMODE, BMODE, 0, AMS_GEMM_BK, true>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, t_gemm_lds_pad);
+                raised_v = t_gemm_lds_pad;
+            }
+        }
+        hipLaunchKernelGGL((gemm_f32_kernel<AMODE, BMODE, 0, AMS_GEMM_BK, true>), grid, dim3(256), (size_t)t_gemm_lds_pad, st, g);
+    } else
     hipLaunchKernelGGL((gemm_f32_kernel<AMODE, BMODE>), grid, dim3(256), (size_t)t_gemm_lds_pad, st, g);
     ams_status s = ams_check_launch();
     if (s != AMS_OK) return s;
