@@ -43,10 +43,11 @@ class _Overlap(object):
     def cap(self, on, kind='dense'):
         import os
         from ._lib import load
-        # residency cap of side-stream products via a dynamic-LDS pad: dense dW (beside the top layer's BPTT, whose step
-        # kernels hold 16 KB of LDS) runs 2 workgroups per CU, the LSTM weight gradients 1 per CU -- measured best with the
-        # step kernels at s_setprio 3 (9.62 k vs 9.32 k mixtures/s for 1 per CU everywhere; 3 per CU: 9.3 k)
-        pad = int(os.environ.get('AMS_SIDE_LDS_PAD', '40000'))
+        # residency cap of side-stream products via a dynamic-LDS pad: 1 workgroup per CU for all of them, with the step kernels
+        # at s_setprio 3.  (Measured history: before the GEMM's operand fetch was made branch-free a capped product was
+        # latency-bound at 54 TFLOP/s and the dense dW product paid off at 2 per CU, 9.62 k vs 9.32 k mixtures/s; with the
+        # branch-free fetch 1 per CU reaches 72 TFLOP/s alone and wins, 9.85 k vs 9.74 k; without the priority 9.52 k.)
+        pad = int(os.environ.get('AMS_SIDE_LDS_PAD', '70000'))
         if kind == 'lstm':
             pad = int(os.environ.get('AMS_SIDE_LDS_PAD_LSTM', '70000'))
         tab = os.environ.get('AMS_SIDE_PADS')           # tuning aid: one pad per capped launch group, in issue order
