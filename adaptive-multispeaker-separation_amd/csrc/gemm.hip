@@ -101,7 +101,14 @@ enum { EPI_STORE = 0, EPI_MAXPOOL = 1 };
 // path per operand; each merge is a USE of the loaded value, so hipcc put `s_waitcnt vmcnt(0)` between the A fetch and the B
 // fetch and the MFMAs started only after A had landed: two exposed memory round trips per k-tile, hidden only when ~5
 // workgroups share a CU.  The host picks VEC whenever both operands are 16-byte addressable along their contiguous axis.
-template <int AMODE, int BMODE, int EPI = EPI_STORE, int BKT = AMS_GEMM_BK, bool VEC = false>
+// PF (VEC only) = register stages of operand prefetch: with 2, a fetch issued behind the MFMAs of tile kt is consumed behind
+// those of tile kt+2 (112-124 VGPRs -> 4 waves/SIMD).  Measured (-DAMS_GEMM_PF=2): products alone get faster (dense forward
+// 567 -> 542 us = 116 TFLOP/s, 1 workgroup/CU 72 -> 92 TFLOP/s) but the whole step does not (9.91-9.95 k vs 9.95-9.96 k
+// mixtures/s: the recurrent step kernels ran 8-10 % slower in the same replay), so the default stays 1.
+#ifndef AMS_GEMM_PF
+#define AMS_GEMM_PF 1
+#endif
+template <int AMODE, int BMODE, int EPI = EPI_STORE, int BKT = AMS_GEMM_BK, bool VEC = false, int PF = 1>
 __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g) {
     constexpr int BK = BKT, NLD = BK / 8, KQ = BK / 4;
     if (gridDim.z > 1) {                            // batched launch: same shape, shifted operands
@@ -155,15 +162,15 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[NLD], rb[NLD];
+    float4 ra[NLD], rb[NLD], ra2[NLD], rb2[NLD];
     long arow[NLD];                                 // A_ROW: element offset of this thread's operand row(s), mapped once
 #pragma unroll
     for (int h = 0; h < NLD; ++h) arow[h] = (AMODE == A_ROW) ? rowmap(g, min(m0 + (tid + h * 256) / KQ, g.M - 1)) * g.lda : 0;
 
-    bool va[NLD], vb[NLD];                          // VEC: validity of the staged registers
-    auto fetch = [&](int kt) {
+    bool va[NLD], vb[NLD], va2[NLD], vb2[NLD];      // VEC: validity of the staged registers
+    auto fetch_v = [&](int kt, float4 (&ra)[NLD], float4 (&rb)[NLD], bool (&va)[NLD], bool (&vb)[NLD]) {
         const int k0 = k_begin + kt * BK;
-        if (VEC) {
+        {
 #pragma unroll
             for (int h = 0; h < NLD; ++h) {
                 const int q = tid + h * 256;
@@ -186,8 +193,11 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
                     rb[h] = *reinterpret_cast<const float4*>(g.B + (long)min(k, g.K - 1) * g.ldb + min(n, g.N - 4));
                 }
             }
-            return;
         }
+    };
+    auto fetch = [&](int kt) {
+        const int k0 = k_begin + kt * BK;
+        if (VEC) { fetch_v(kt, ra, rb, va, vb); return; }
 #pragma unroll
         for (int h = 0; h < NLD; ++h) {
             const int q = tid + h * 256;
@@ -244,7 +254,7 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
         }
     };
 
-    auto stash = [&](int buf) {
+    auto stash_s = [&](int buf, float4 (&ra)[NLD], float4 (&rb)[NLD], bool (&va)[NLD], bool (&vb)[NLD]) {
         float* as = As + buf * BK * LDA_S;
         float* bs = Bs + buf * BK * LDB_S;
 #pragma unroll
@@ -277,22 +287,12 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
             }
         }
     };
-
-    if (nk > 0) {
-        fetch(0);
-        stash(0);
-    }
-    __syncthreads();
+    auto stash = [&](int buf) { stash_s(buf, ra, rb, va, vb); };
 
     const int l31 = lane & 31, lk = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) fetch(kt + 1);
+    auto mfma_tile = [&](int buf) {
         const float* as = As + buf * BK * LDA_S + wm * 64 + l31;
         const float* bs = Bs + buf * BK * LDB_S + wn * 64 + l31;
-#ifdef AMS_GEMM_SETPRIO
-        __builtin_amdgcn_s_setprio(1);
-#endif
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const float a0 = as[(kk + lk) * LDA_S];
@@ -304,11 +304,37 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
-#ifdef AMS_GEMM_SETPRIO
-        __builtin_amdgcn_s_setprio(0);
-#endif
-        if (kt + 1 < nk) stash(buf ^ 1);
+    };
+
+    if (nk > 0) {
+        fetch(0);
+        stash(0);
+    }
+    if (VEC && PF == 2) {
+        // No conditionals around the MFMAs or the staging: tiles past the end of the split are fetched from clamped
+        // addresses with their validity predicate false, i.e. staged as zeros (an odd tile count runs one zero tile).
+        fetch_v(1, ra, rb, va, vb);
+        fetch_v(2, ra2, rb2, va2, vb2);
         __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            mfma_tile(0);
+            stash_s(1, ra, rb, va, vb);
+            fetch_v(kt + 3, ra, rb, va, vb);
+            __syncthreads();
+            mfma_tile(1);
+            stash_s(0, ra2, rb2, va2, vb2);
+            fetch_v(kt + 4, ra2, rb2, va2, vb2);
+            __syncthreads();
+        }
+    } else {
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int buf = kt & 1;
+            if (kt + 1 < nk) fetch(kt + 1);
+            mfma_tile(buf);
+            if (kt + 1 < nk) stash(buf ^ 1);
+            __syncthreads();
+        }
     }
 
     if (EPI == EPI_MAXPOOL) {
@@ -460,12 +486,12 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
         if (t_gemm_lds_pad > 40 * 1024) {
             static thread_local int raised_v = 0;
             if (raised_v < t_gemm_lds_pad) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<AMODE, BMODE, 0, AMS_GEMM_BK, true>),
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<AMODE, BMODE, 0, AMS_GEMM_BK, true, AMS_GEMM_PF>),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, t_gemm_lds_pad);
                 raised_v = t_gemm_lds_pad;
             }
         }
-        hipLaunchKernelGGL((gemm_f32_kernel<AMODE, BMODE, 0, AMS_GEMM_BK, true>), grid, dim3(256), (size_t)t_gemm_lds_pad, st, g);
+        hipLaunchKernelGGL((gemm_f32_kernel<AMODE, BMODE, 0, AMS_GEMM_BK, true, AMS_GEMM_PF>), grid, dim3(256), (size_t)t_gemm_lds_pad, st, g);
     } else
     hipLaunchKernelGGL((gemm_f32_kernel<AMODE, BMODE>), grid, dim3(256), (size_t)t_gemm_lds_pad, st, g);
     ams_status s = ams_check_launch();
