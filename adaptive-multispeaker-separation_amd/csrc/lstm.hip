@@ -184,6 +184,13 @@ __global__ __launch_bounds__(NWF * 64) void lstm_step_fwd_kernel(StepArgs a) {
 }
 
 // Backward step s: forward direction handles t = T-1-s, backward direction t = s.
+// VEC4 (H % 4 == 0) is a COMPILE-TIME switch here, and the operand fetch is ONE unconditional 16-byte load on a row clamped to
+// the batch (rows >= B only feed values that are never stored).  With the guarded fetch (runtime flag, vector / scalar paths
+// merged per operand) every merge is a use of the loaded value and hipcc placed `s_waitcnt vmcnt(0)` in front of each k-group's
+// load: 5 dependent memory round trips per step instead of one.  Layer BPTT 0.525 -> 0.512 ms alone, step +1 %.
+// (The forward kernel keeps the guarded form: the same change measured 1-2 % SLOWER there -- its 95 KB per workgroup arrive
+// in three bursts instead of one and the per-CU load path is the bottleneck)
+template <bool VEC4>
 __global__ __launch_bounds__(NWB * 64) void lstm_step_bwd_kernel(StepArgs a) {
     __builtin_amdgcn_s_setprio(3);      // latency-bound: win issue arbitration over the weight-gradient GEMM waves sharing the CU
     __shared__ __attribute__((aligned(16))) float red[NWB][64][4];
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(NWB * 64) void lstm_step_bwd_kernel(StepArgs a) {
     const bool has_next = a.s > 0;
     const bool has_prev = (tp >= 0 && tp < T);
     const int b_row = bt * TB + (lane & 15);
-    const bool vec = (H % 4 == 0);
+    constexpr bool vec = VEC4;
 
     const int bl = tid >> 4, ul = tid & 15;
     const int b = bt * TB + bl, u = ut * TU + ul;
@@ -214,7 +221,7 @@ __global__ __launch_bounds__(NWB * 64) void lstm_step_bwd_kernel(StepArgs a) {
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     if (has_next) {
-        const float* darow = a.G + (((long)b_row * T + tn) * 2 + dir) * (4 * H);
+        const float* darow = a.G + (((long)min(b_row, a.B - 1) * T + tn) * 2 + dir) * (4 * H);
         const float* pk = a.pk + (((long)dir * a.n_ut + ut) * a.n_g) * (64 * 4) + lane * 4;
         constexpr int CH = (75 + NWB - 1) / NWB;            // k-groups per wave per chunk (4H = 1200: 75 groups / NWB waves)
         for (int g0 = wave; g0 < a.n_g; g0 += NWB * CH) {
@@ -223,7 +230,8 @@ __global__ __launch_bounds__(NWB * 64) void lstm_step_bwd_kernel(StepArgs a) {
             for (int i = 0; i < CH; ++i) {
                 const int g = g0 + NWB * i;
                 if (g < a.n_g) {
-                    av[i] = ld4_guard(darow, g * 16 + (lane >> 4) * 4, 4 * H, b_row < a.B, vec);
+                    if (vec) av[i] = *reinterpret_cast<const float4*>(darow + g * 16 + (lane >> 4) * 4);
+                    else av[i] = ld4_guard(darow, g * 16 + (lane >> 4) * 4, 4 * H, true, false);
                     bv[i] = *reinterpret_cast<const float4*>(pk + (long)g * 256);
                 }
             }
@@ -349,7 +357,8 @@ ams_status ams_blstm_recurrent_bwd(float* G, const float* cst, const float* dout
     dim3 grid(n_ut, ceil_div(B, TB), 2);
     for (int s = 0; s < T; ++s) {
         a.s = s;
-        hipLaunchKernelGGL(lstm_step_bwd_kernel, grid, dim3(NWB * 64), 0, st, a);
+        if (H % 4 == 0) hipLaunchKernelGGL(lstm_step_bwd_kernel<true>, grid, dim3(NWB * 64), 0, st, a);
+        else hipLaunchKernelGGL(lstm_step_bwd_kernel<false>, grid, dim3(NWB * 64), 0, st, a);
     }
     return ams_check_launch();
 }
