@@ -19,6 +19,7 @@
 //   out  [B,T,2H]    h, forward dir in cols [0,H), backward dir in [H,2H)   (utils/ops.py:383 concat)
 //   cst  [B,T,2,H]   cell states
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -76,10 +77,28 @@ struct StepArgs {
     float* G; float* out; float* cst;
     const float* pk;
     int B, T, H, n_ut, n_g, s;     // s = step index
+    int xcd_map;                   // 1: 1-D grid, workgroups that read the same packed weights share an XCD (see block_coords)
     // backward only
     const float* dout;             // [B,T,2H] gradient w.r.t. layer output
     float* dc;                     // [B,2,H] running dc
 };
+
+// Workgroup -> (unit tile, batch tile, direction).  The n_bt batch tiles of one (direction, unit tile) read the SAME 76 KB slice
+// of the packed recurrent matrix every step.  Workgroup ids are dealt round-robin to the 8 XCDs (id % 8), each with a private
+// 4 MB L2; in the plain 3-D grid the tiles sharing a slice sit 19 ids apart, i.e. on different XCDs, so every L2 has to hold
+// nearly the whole 2.9 MB matrix next to the streaming gate/state traffic.  The 1-D form gives the sharers ids that are equal
+// modulo 8: each L2 then serves 1/8 of the matrix to all its readers.  (Measured slower -- see step_grid.)
+__device__ __forceinline__ bool block_coords(const StepArgs& a, int& ut, int& bt, int& dir) {
+    if (!a.xcd_map) { ut = blockIdx.x; bt = blockIdx.y; dir = blockIdx.z; return true; }
+    const int n_bt = (a.B + TB - 1) / TB;
+    const int id = blockIdx.x, xcd = id & 7, r = id >> 3;
+    bt = r % n_bt;
+    const int j = (r / n_bt) * 8 + xcd;
+    if (j >= 2 * a.n_ut) return false;
+    dir = j / a.n_ut;
+    ut = j - dir * a.n_ut;
+    return true;
+}
 
 __device__ __forceinline__ float4 ld4_guard(const float* p, int k, int kmax, bool row_ok, bool vec) {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -96,7 +115,8 @@ __global__ __launch_bounds__(NWF * 64) void lstm_step_fwd_kernel(StepArgs a) {
     __builtin_amdgcn_s_setprio(3);      // latency-bound: win issue arbitration over the weight-gradient GEMM waves sharing the CU
     __shared__ __attribute__((aligned(16))) float red[NWF][4][64][4];   // [wave][gate][lane][reg]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ut = blockIdx.x, bt = blockIdx.y, dir = blockIdx.z;
+    int ut, bt, dir;
+    if (!block_coords(a, ut, bt, dir)) return;
     const int H = a.H, T = a.T;
     const int t = dir ? (T - 1 - a.s) : a.s;
     const int tp = dir ? t + 1 : t - 1;                 // time index holding h_{prev}, c_{prev}
@@ -183,6 +203,106 @@ __global__ __launch_bounds__(NWF * 64) void lstm_step_fwd_kernel(StepArgs a) {
     a.out[((long)b * T + t) * (2 * H) + dir * H + u] = h;
 }
 
+// Pipelined-fetch form of the forward step (H % 4 == 0 and NWF < n_g <= 3 * NWF, i.e. 132 <= H <= 384).
+__global__ __launch_bounds__(NWF * 64) void lstm_step_fwd_pipe_kernel(StepArgs a) {
+    __builtin_amdgcn_s_setprio(3);      // latency-bound: win issue arbitration over the weight-gradient GEMM waves sharing the CU
+    __shared__ __attribute__((aligned(16))) float red[NWF][4][64][4];   // [wave][gate][lane][reg]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int ut, bt, dir;
+    if (!block_coords(a, ut, bt, dir)) return;
+    const int H = a.H, T = a.T;
+    const int t = dir ? (T - 1 - a.s) : a.s;
+    const int tp = dir ? t + 1 : t - 1;                 // time index holding h_{prev}, c_{prev}
+    const bool has_prev = a.s > 0;
+    const int b_row = bt * TB + (lane & 15);
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // Epilogue operands (this thread's (batch,unit) element) are fetched FIRST so their latency hides under
+    // the recurrent product.  thread -> (batch row, unit); C/D layout: row = (lane>>4)*4 + reg, col = lane&15
+    const int bl = tid >> 4, ul = tid & 15;
+    const int b = bt * TB + bl, u = ut * TU + ul;
+    const bool live = (tid < 256 && b < a.B && u < H);
+    float* grow = a.G + (((long)(live ? b : 0) * T + t) * 2 + dir) * (4 * H);
+    float zq[4] = {0.f, 0.f, 0.f, 0.f};
+    float c_prev = 0.f;
+    if (live) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) zq[q] = grow[q * H + u];
+        if (has_prev) c_prev = a.cst[(((long)b * T + tp) * 2 + dir) * H + u];
+    }
+
+    if (has_prev) {
+        // H % 4 == 0, n_g <= 3 * NWF.  Software-pipelined fetch: groups 0 and 1 are requested together, group 0's MFMAs run
+        // while group 1 (and 2) are still in flight.  Unconditional 16-byte loads on clamped addresses (columns >= H meet zero
+        // rows of the packed matrix, rows >= B are never stored), the optional third group in its own branch with its own
+        // copy of the MFMAs, so every s_waitcnt counts exactly.
+        const float* hrow = a.out + ((long)min(b_row, a.B - 1) * T + tp) * (2 * H) + dir * H;
+        const float* pk = a.pk + (((long)dir * a.n_ut + ut) * a.n_g) * (4 * 64 * 4) + lane * 4;
+        const int kq = (lane >> 4) * 4;
+        const int g0 = wave, g1 = wave + NWF, g2 = wave + 2 * NWF;
+        auto ldh = [&](int g) { return *reinterpret_cast<const float4*>(hrow + min(g * 16 + kq, H - 4)); };
+        auto ldw = [&](int g, int q) { return *reinterpret_cast<const float4*>(pk + ((long)g * 4 + q) * 256); };
+        auto mm = [&](const float4& av, const float4 (&bv)[4]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv[q].x, acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv[q].y, acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv[q].z, acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv[q].w, acc[q], 0, 0, 0);
+        };
+        const int g1c = min(g1, a.n_g - 1);                 // n_g > NWF in every shape this kernel is chosen for
+        float4 a0 = ldh(g0), b0[4], a1 = ldh(g1c), b1[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b0[q] = ldw(g0, q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) b1[q] = ldw(g1c, q);
+        if (g2 < a.n_g) {
+            float4 a2 = ldh(g2), b2[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) b2[q] = ldw(g2, q);
+            __builtin_amdgcn_sched_barrier(0);              // keep the third group's loads AHEAD of the MFMAs (hipcc sinks them)
+            mm(a0, b0);
+            mm(a1, b1);
+            mm(a2, b2);
+        } else {
+            mm(a0, b0);
+            if (g1 < a.n_g) mm(a1, b1);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) *reinterpret_cast<f32x4*>(&red[wave][q][lane][0]) = acc[q];
+    __syncthreads();
+
+    if (!live) return;
+    const int src_lane = (bl >> 2) * 16 + ul, src_reg = bl & 3;
+    float pre[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        float s = zq[q];
+#pragma unroll
+        for (int w = 0; w < NWF; ++w) s += red[w][q][src_lane][src_reg];
+        pre[q] = s;
+    }
+    const float ig = 1.0f / (1.0f + expf(-pre[0]));
+    const float gg = tanhf(pre[1]);
+    const float fg = 1.0f / (1.0f + expf(-(pre[2] + 1.0f)));     // forget_bias = 1.0
+    const float og = 1.0f / (1.0f + expf(-pre[3]));
+    const float c = c_prev * fg + ig * gg;
+    const float h = tanhf(c) * og;
+    grow[0 * H + u] = ig;
+    grow[1 * H + u] = gg;
+    grow[2 * H + u] = fg;
+    grow[3 * H + u] = og;
+    a.cst[(((long)b * T + t) * 2 + dir) * H + u] = c;
+    a.out[((long)b * T + t) * (2 * H) + dir * H + u] = h;
+}
+
+
 // Backward step s: forward direction handles t = T-1-s, backward direction t = s.
 // VEC4 (H % 4 == 0) is a COMPILE-TIME switch here, and the operand fetch is ONE unconditional 16-byte load on a row clamped to
 // the batch (rows >= B only feed values that are never stored).  With the guarded fetch (runtime flag, vector / scalar paths
@@ -195,7 +315,8 @@ __global__ __launch_bounds__(NWB * 64) void lstm_step_bwd_kernel(StepArgs a) {
     __builtin_amdgcn_s_setprio(3);      // latency-bound: win issue arbitration over the weight-gradient GEMM waves sharing the CU
     __shared__ __attribute__((aligned(16))) float red[NWB][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int ut = blockIdx.x, bt = blockIdx.y, dir = blockIdx.z;
+    int ut, bt, dir;
+    if (!block_coords(a, ut, bt, dir)) return;
     const int H = a.H, T = a.T;
     const int t = dir ? a.s : (T - 1 - a.s);
     const int tn = dir ? t - 1 : t + 1;                 // step processed just before in BPTT order (its da feeds dh)
@@ -268,6 +389,23 @@ __global__ __launch_bounds__(NWB * 64) void lstm_step_bwd_kernel(StepArgs a) {
     *dcp = dcv * fg;
 }
 
+inline dim3 step_grid(StepArgs& a) {
+    // MEASURED, default off (AMS_LSTM_XCD=1 turns it on): 0.645 / 0.536 ms per forward / backward layer vs 0.632 / 0.524 for the
+    // plain 3-D grid, 9.86 k vs 10.03 k mixtures/s -- four sharers hammering one L2 lose to four L2s serving one reader each.
+    static const bool off = !(getenv("AMS_LSTM_XCD") && atoi(getenv("AMS_LSTM_XCD")) == 1);               // tuning aid
+    const int n_bt = ceil_div(a.B, TB);
+    a.xcd_map = off ? 0 : 1;
+    if (off) return dim3(a.n_ut, n_bt, 2);
+    return dim3(8 * n_bt * ceil_div(2 * a.n_ut, 8));
+}
+
+inline bool fwd_pipe_ok(int H, int n_g) {
+    // MEASURED, default off: 0.646 vs 0.625 ms per forward layer, 9.82 k vs 10.02 k mixtures/s.  Requesting a workgroup's 95 KB
+    // earlier does not help the forward step -- the guarded kernel's three dependent bursts are faster than one big one.
+    static const bool on = getenv("AMS_LSTM_FWD_PIPE") && atoi(getenv("AMS_LSTM_FWD_PIPE")) == 1;      // tuning aid
+    return on && H % 4 == 0 && n_g > NWF && n_g <= 3 * NWF;
+}
+
 }  // namespace
 
 extern "C" {
@@ -314,10 +452,12 @@ ams_status ams_blstm_recurrent_fwd(float* G, float* out, float* cst, const float
     StepArgs a{};
     a.G = G; a.out = out; a.cst = cst; a.pk = pack;
     a.B = B; a.T = T; a.H = H; a.n_ut = n_ut; a.n_g = n_g;
-    dim3 grid(n_ut, ceil_div(B, TB), 2);
+    dim3 grid = step_grid(a);
+    const bool use_pipe = fwd_pipe_ok(H, n_g);
     for (int s = 0; s < T; ++s) {
         a.s = s;
-        hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(NWF * 64), 0, st, a);
+        if (use_pipe) hipLaunchKernelGGL(lstm_step_fwd_pipe_kernel, grid, dim3(NWF * 64), 0, st, a);
+        else hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(NWF * 64), 0, st, a);
     }
     return ams_check_launch();
 }
@@ -331,10 +471,12 @@ ams_status ams_blstm_recurrent_fwd_steps(float* G, float* out, float* cst, const
     StepArgs a{};
     a.G = G; a.out = out; a.cst = cst; a.pk = const_cast<float*>(pack);
     a.B = B; a.T = T; a.H = H; a.n_ut = ceil_div(H, TU); a.n_g = ceil_div(H, 16);
-    dim3 grid(a.n_ut, ceil_div(B, TB), 2);
+    dim3 grid = step_grid(a);
+    const bool use_pipe = fwd_pipe_ok(H, a.n_g);
     for (int s = s_begin; s < s_end; ++s) {
         a.s = s;
-        hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(NWF * 64), 0, st, a);
+        if (use_pipe) hipLaunchKernelGGL(lstm_step_fwd_pipe_kernel, grid, dim3(NWF * 64), 0, st, a);
+        else hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(NWF * 64), 0, st, a);
     }
     return ams_check_launch();
 }
@@ -354,7 +496,7 @@ ams_status ams_blstm_recurrent_bwd(float* G, const float* cst, const float* dout
     StepArgs a{};
     a.G = G; a.cst = const_cast<float*>(cst); a.pk = pack; a.dout = dout; a.dc = dc;
     a.B = B; a.T = T; a.H = H; a.n_ut = n_ut; a.n_g = n_g;
-    dim3 grid(n_ut, ceil_div(B, TB), 2);
+    dim3 grid = step_grid(a);
     for (int s = 0; s < T; ++s) {
         a.s = s;
         if (H % 4 == 0) hipLaunchKernelGGL(lstm_step_bwd_kernel<true>, grid, dim3(NWB * 64), 0, st, a);
