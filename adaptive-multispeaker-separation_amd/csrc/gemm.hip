@@ -166,6 +166,16 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
     long arow[NLD];                                 // A_ROW: element offset of this thread's operand row(s), mapped once
 #pragma unroll
     for (int h = 0; h < NLD; ++h) arow[h] = (AMODE == A_ROW) ? rowmap(g, min(m0 + (tid + h * 256) / KQ, g.M - 1)) * g.lda : 0;
+    int fp0[NLD];                                   // A_FRAMES (VEC): first sample of this thread's frame, relative to its row
+    if (AMODE == A_FRAMES) {
+#pragma unroll
+        for (int h = 0; h < NLD; ++h) {
+            const int m = min(m0 + (tid + h * 256) / KQ, g.M - 1);
+            const int b = m / g.fr_T, t = m - b * g.fr_T;
+            arow[h] = (long)b * g.fr_L;
+            fp0[h] = t * g.fr_hop - g.fr_pl;
+        }
+    }
 
     bool va[NLD], vb[NLD], va2[NLD], vb2[NLD];      // VEC: validity of the staged registers
     auto fetch_v = [&](int kt, float4 (&ra)[NLD], float4 (&rb)[NLD], bool (&va)[NLD], bool (&vb)[NLD]) {
@@ -174,7 +184,12 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
 #pragma unroll
             for (int h = 0; h < NLD; ++h) {
                 const int q = tid + h * 256;
-                if (AK) {                               // A_ROW: float4 along k (K % 4 == 0, so k < k_end covers all four)
+                if (AMODE == A_FRAMES) {                // frame taps: float4 along k; hop, pad and L are multiples of 4, so a
+                    const int k = k0 + (q % KQ) * 4;    // float4 is entirely inside the signal or entirely in the zero padding
+                    const int p = fp0[h] + k;
+                    va[h] = k < k_end && p >= 0 && p < g.fr_L;
+                    ra[h] = *reinterpret_cast<const float4*>(g.A + arow[h] + min(max(p, 0), g.fr_L - 4));
+                } else if (AK) {                        // A_ROW: float4 along k (K % 4 == 0, so k < k_end covers all four)
                     const int k = k0 + (q % KQ) * 4;
                     va[h] = k < k_end;
                     ra[h] = *reinterpret_cast<const float4*>(g.A + arow[h] + min(k, g.K - 4));
@@ -479,8 +494,8 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
     }
     constexpr bool AKc = (AMODE == A_ROW), BKcc = (BMODE == B_COL);
     static const bool vec_off = getenv("AMS_GEMM_NOVEC") != nullptr;                                   // tuning aid
-    const bool vec = (AMODE == A_ROW || AMODE == A_COL) && g.a_vec && g.b_vec && !vec_off &&
-                     (AKc ? (g.K % 4 == 0 && g.K >= 4) : (g.M % 4 == 0 && g.M >= 4)) &&
+    const bool vec = (AMODE == A_ROW || AMODE == A_COL || AMODE == A_FRAMES) && g.a_vec && g.b_vec && !vec_off &&
+                     (AMODE == A_FRAMES ? (g.K % 4 == 0 && g.fr_L >= 4) : AKc ? (g.K % 4 == 0 && g.K >= 4) : (g.M % 4 == 0 && g.M >= 4)) &&
                      (BKcc ? (g.K % 4 == 0 && g.K >= 4) : (g.N % 4 == 0 && g.N >= 4));
     if (vec) {
         if (t_gemm_lds_pad > 40 * 1024) {
