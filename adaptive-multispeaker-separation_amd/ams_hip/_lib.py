@@ -49,6 +49,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: the ROCm wheel ships its own libamdhip64; loading ours afterwards makes the dynamic loader reuse that copy
+    # (same SONAME).  The other order puts TWO HIP runtimes in the process and launches fail with hipErrorNoDevice.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise AmsError('libams_hip.so not found at %s -- the HIP extension is required (no CPU fallback); '
                        'run __graft_entry__.build()' % LIB_PATH)

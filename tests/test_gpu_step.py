@@ -1,4 +1,6 @@
 """GPU: whole training steps through the host mirror (reference API) vs the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -129,3 +131,15 @@ def test_training_from_tfrecord_files(tmp_path):
                     tr.model.train(feed, i)
     finally:
         os.environ.pop('AMS_DATA_DIR', None)
+
+
+@pytest.mark.gpu
+def test_entry_build_then_smoke_in_one_process():
+    """__graft_entry__.build() followed by smoke() in ONE fresh process: the HIP libraries must not be loaded ahead of torch's own
+    HIP runtime (two runtimes in a process make every launch fail with hipErrorNoDevice)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = 'import __graft_entry__ as g; g.build(); g.smoke(); print("ENTRY_OK")'
+    out = subprocess.run([sys.executable, '-c', code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and 'ENTRY_OK' in out.stdout, out.stderr[-2000:]
