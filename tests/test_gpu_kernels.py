@@ -36,6 +36,10 @@ def ops():
     (130, 70, 45, 0, 0), (130, 70, 45, 0, 1), (130, 70, 45, 1, 0), (130, 70, 45, 1, 1),
     (257, 1200, 600, 0, 0), (300, 1200, 2049, 1, 0), (512, 256, 1024, 0, 1), (64, 10240, 600, 0, 0),
     (33, 17, 5, 0, 0), (128, 128, 16, 0, 0), (600, 520, 5120, 1, 0),
+    # branch-free 16-byte fetch path (all leading dimensions multiples of 4) with ragged tiles and a k-tail that is not a
+    # multiple of the 8-deep tile; and its neighbours that must fall back to the guarded path (odd K / M / N)
+    (132, 260, 604, 0, 0), (132, 260, 604, 0, 1), (132, 260, 604, 1, 0), (132, 260, 604, 1, 1),
+    (4, 4, 4, 0, 0), (4, 8, 12, 1, 1), (260, 132, 2052, 1, 0), (132, 260, 603, 0, 1), (131, 260, 604, 1, 0), (132, 262, 604, 0, 0),
 ])
 def test_gemm(ops, M, N, K, tA, tB):
     rng = np.random.RandomState(M + N + K)
