@@ -53,6 +53,7 @@ struct GemmArgs {
     // seg_len 0 = identity.  Batch index z shifts seg_off by z * seg_off_zs and bias by z * bias_zs.
     int seg_len;
     long seg_stride, seg_off, seg_off_zs, bias_zs;
+    int hiprio;                // 1: launch is on the critical path (not residency-capped) -> waves raise their issue priority
 };
 
 __device__ __forceinline__ long rowmap(const GemmArgs& g, int m) {
@@ -111,6 +112,7 @@ enum { EPI_STORE = 0, EPI_MAXPOOL = 1 };
 template <int AMODE, int BMODE, int EPI = EPI_STORE, int BKT = AMS_GEMM_BK, bool VEC = false, int PF = 1>
 __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g) {
     constexpr int BK = BKT, NLD = BK / 8, KQ = BK / 4;
+    if (g.hiprio) __builtin_amdgcn_s_setprio(2);    // above a capped side-stream product sharing the CU, below the LSTM step kernels (3)
     if (gridDim.z > 1) {                            // batched launch: same shape, shifted operands
         const long z = blockIdx.z;
         g.A += z * g.a_zs; g.B += z * g.b_zs; g.C += z * g.c_zs;
@@ -481,6 +483,8 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
     g.k_per_split = kps;
     g.partial = (float*)ws;
     dim3 grid(tiles, splits, nbatch);
+    static const bool prio_off = getenv("AMS_GEMM_NOPRIO") != nullptr;                                 // tuning aid
+    g.hiprio = (t_gemm_lds_pad == 0 && !prio_off) ? 1 : 0;
     // Occupancy cap for launches that are meant to run BESIDE latency-critical kernels (weight-gradient products on
     // the side stream): unused dynamic LDS limits how many of these workgroups a CU admits, leaving registers/slots
     // for the recurrent step kernels.  Thread-local, set through ams_gemm_set_lds_pad().
