@@ -20,6 +20,8 @@ def f_props(layers, x, then=None):
     the list can start feeding it while its own recurrence finishes (ams_hip/ops.py TAIL_CUTS)."""
     for i, layer in enumerate(layers):
         nxt = layers[i + 1] if i + 1 < len(layers) else then
+        if isinstance(layer, BLSTM):                 # the layer whose backward runs just before the first layer's (functional.py)
+            layer._last_capped = (i == 1 and isinstance(layers[0], BLSTM))
         if isinstance(layer, BLSTM) and isinstance(nxt, BLSTM):
             F.hint_next('proj', nxt.Kf, nxt.bf, nxt.Kb, nxt.bb)
         elif isinstance(layer, BLSTM) and isinstance(nxt, Conv1D):
@@ -106,7 +108,7 @@ class BLSTM:
         self.Kf._ams_twin, self.bf._ams_twin = self.Kb, self.bb      # storage hint for FlatOptimizer (interleaved rows)
 
     def f_prop(self, x):
-        return F.blstm(x, self.Kf, self.bf, self.Kb, self.bb)
+        return F.blstm(x, self.Kf, self.bf, self.Kb, self.bb, getattr(self, '_last_capped', False))
 
 
 class Conv1D:
