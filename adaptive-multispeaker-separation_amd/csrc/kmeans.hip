@@ -168,9 +168,9 @@ __global__ __launch_bounds__(256) void kmeans_pass_kernel(KmArgs a) {
                         for (int q = 0; q < V2; ++q) {
                             f2 t = {x[2 * q], x[2 * q + 1]};
                             if (HAS_W) t = t * wv2;
-                            t = t * m2;
                             f2 av = {acc[c * E_ + 2 * q], acc[c * E_ + 2 * q + 1]};
-                            av = av + t;
+                            // m is 0 or 1, so t * m is exact and the fused form rounds exactly like multiply-then-add
+                            av = __builtin_elementwise_fma(t, m2, av);
                             acc[c * E_ + 2 * q] = av.x; acc[c * E_ + 2 * q + 1] = av.y;
                         }
                         acc[C_ * E_ + c] = __fadd_rn(acc[C_ * E_ + c], m);
