@@ -21,7 +21,7 @@ def front_maxpool_fwd(x, f, P, hop):
     T = (L - P) // hop + 1
     y = torch.empty((Bt, T, N), dtype=torch.float32, device=x.device)
     am = _ll((Bt, T, N), x.device)
-    nb = lib.ams_front_maxpool_workspace_bytes(Bt, L, N)
+    nb = lib.ams_front_maxpool_workspace_bytes_w(Bt, L, N, W)
     ws = ops._ws(nb, x)
     ev = ops.PROFILE.begin() if ops.PROFILE.enabled else None
     check(lib.ams_front_maxpool_fwd(_p(x), _p(f), _p(y), _p(am), Bt, L, W, N, P, hop, _p(ws), nb, _s()), 'ams_front_maxpool_fwd')

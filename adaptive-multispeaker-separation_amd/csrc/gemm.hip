@@ -828,12 +828,29 @@ __global__ __launch_bounds__(256) void synth_unpool_bwd_vals_kernel(const float*
     }
 }
 
+// xp[b, pl + l] = x[b, l], zero elsewhere (row pitch Lp): with the SAME padding materialised every frame of the stride-1
+// product is a plain in-range window, so its operand fetch needs no per-element validity.
+__global__ void pad_rows_kernel(const float* __restrict__ x, float* __restrict__ xp, int Bt, int L, int Lp, int pl) {
+    const long total = (long)Bt * Lp;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / Lp), p = (int)(i - (long)b * Lp) - pl;
+        xp[i] = (p >= 0 && p < L) ? x[(long)b * L + p] : 0.f;
+    }
+}
+
+inline int maxpool_padded_len(int L, int W) { return (L + W + 3 + 3) / 4 * 4; }
+
 }  // namespace
 
 extern "C" {
 
 size_t ams_front_maxpool_workspace_bytes(int Bt, int L, int N) {
     return (size_t)Bt * (L / BM + 1) * N * (sizeof(float) + sizeof(int32_t));
+}
+// with room for the zero-padded copy of the signals (enables the branch-free 16-byte operand fetch of the stride-1 product)
+size_t ams_front_maxpool_workspace_bytes_w(int Bt, int L, int N, int W) {
+    const size_t base = (ams_front_maxpool_workspace_bytes(Bt, L, N) + 15) / 16 * 16;
+    return base + (size_t)Bt * maxpool_padded_len(L, W) * sizeof(float);
 }
 
 // Path B front: y [Bt,T,N], argmax int64 [Bt,T,N], T = (L-P)/hop + 1   (reference models/adapt.py:115-117)
@@ -858,6 +875,19 @@ ams_status ams_front_maxpool_fwd(const float* x, const float* f, float* y, long 
         g.C = (float*)ws;
         g.pidx = (int32_t*)((float*)ws + (size_t)tiles_m * N);
         dim3 grid(tiles_m * ceil_div(N, BN), 1);
+        g.group_m = 1;
+        const size_t base = (ams_front_maxpool_workspace_bytes(Bt, L, N) + 15) / 16 * 16;
+        const int Lp = maxpool_padded_len(L, W);
+        if (g.b_vec && W % 4 == 0 && ws_bytes >= base + (size_t)Bt * Lp * sizeof(float) && !getenv("AMS_GEMM_NOVEC")) {
+            // stride-1 frames are not 16-byte aligned and would straddle the zero padding: run the product on a padded copy,
+            // where every 4-tap fetch is one unconditional (dword-aligned) 16-byte load
+            float* xp = (float*)((char*)ws + base);
+            int pb = (int)(((long)Bt * Lp + 255) / 256);
+            if (pb > 4096) pb = 4096;
+            hipLaunchKernelGGL(pad_rows_kernel, dim3(pb), dim3(256), 0, st, x, xp, Bt, L, Lp, pl);
+            g.A = xp; g.fr_L = Lp; g.fr_pl = 0; g.a_vec = 1;
+            hipLaunchKernelGGL((gemm_f32_kernel<A_FRAMES, B_ROW, EPI_MAXPOOL, AMS_GEMM_BK, true>), grid, dim3(256), 0, st, g);
+        } else
         hipLaunchKernelGGL((gemm_f32_kernel<A_FRAMES, B_ROW, EPI_MAXPOOL>), grid, dim3(256), 0, st, g);
         hipLaunchKernelGGL(maxpool_window_kernel, dim3(blocks), dim3(256), 0, st, (const float*)g.C, (const int32_t*)g.pidx, y, argmax, Bt,
                            L, N, P, hop, T);

@@ -50,6 +50,7 @@ ams_status ams_front_conv_bwd_filter(const float* x, const float* dy, float* df,
  * argmax int64 = l*N + n (no batch term).  Sparse (unpool-free) synthesis and gather-form filter
  * gradients (models/adapt.py:210-243, utils/ops.py:94-120). ---- */
 size_t ams_front_maxpool_workspace_bytes(int Bt, int L, int N);
+size_t ams_front_maxpool_workspace_bytes_w(int Bt, int L, int N, int W);   /* + room for the zero-padded signal copy (faster product) */
 ams_status ams_front_maxpool_fwd(const float* x, const float* f, float* y, long long* argmax, int Bt, int L, int W, int N, int P, int hop,
                                  void* ws, size_t ws_bytes, void* stream);
 /* the sparse kernels take int32 sample positions (argmax / N, converted once) and the synthesis filter TRANSPOSED, f2t [N, W] */
