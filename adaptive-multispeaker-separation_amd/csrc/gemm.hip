@@ -195,6 +195,13 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
                     const int k = k0 + (q % KQ) * 4;
                     va[h] = k < k_end;
                     ra[h] = *reinterpret_cast<const float4*>(g.A + arow[h] + min(k, g.K - 4));
+                } else if (AMODE == A_FRAMES_T) {        // filter gradient: m = tap (float4 along taps), k = frame (b, t)
+                    const int k = k0 + (q >> 5), m = m0 + (q & 31) * 4;
+                    const int kc = min(k, g.K - 1);
+                    const int b = kc / g.fr_T, t = kc - b * g.fr_T;
+                    const int p = t * g.fr_hop + m - g.fr_pl;          // multiple of 4: inside the signal or inside the padding
+                    va[h] = k < k_end && m < g.M && p >= 0 && p < g.fr_L;
+                    ra[h] = *reinterpret_cast<const float4*>(g.A + (long)b * g.fr_L + min(max(p, 0), g.fr_L - 4));
                 } else {                                // A_COL: float4 along m (M % 4 == 0)
                     const int k = k0 + (q >> 5), m = m0 + (q & 31) * 4;
                     va[h] = k < k_end && !(g.mask_period && (k % g.mask_period) == g.mask_skip);
@@ -498,8 +505,9 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
     }
     constexpr bool AKc = (AMODE == A_ROW), BKcc = (BMODE == B_COL);
     static const bool vec_off = getenv("AMS_GEMM_NOVEC") != nullptr;                                   // tuning aid
-    const bool vec = (AMODE == A_ROW || AMODE == A_COL || AMODE == A_FRAMES) && g.a_vec && g.b_vec && !vec_off &&
-                     (AMODE == A_FRAMES ? (g.K % 4 == 0 && g.fr_L >= 4) : AKc ? (g.K % 4 == 0 && g.K >= 4) : (g.M % 4 == 0 && g.M >= 4)) &&
+    const bool vec = g.a_vec && g.b_vec && !vec_off &&
+                     (AMODE == A_FRAMES ? (g.K % 4 == 0 && g.fr_L >= 4) : AMODE == A_FRAMES_T ? (g.M % 4 == 0 && g.fr_L >= 4) :
+                      AKc ? (g.K % 4 == 0 && g.K >= 4) : (g.M % 4 == 0 && g.M >= 4)) &&
                      (BKcc ? (g.K % 4 == 0 && g.K >= 4) : (g.N % 4 == 0 && g.N >= 4));
     if (vec) {
         if (t_gemm_lds_pad > 40 * 1024) {
@@ -654,7 +662,7 @@ ams_status ams_frames_matmul_bwd_filter(const float* x, const float* dy, float* 
     g.A = x; g.B = dy; g.C = dB; g.bias = nullptr;
     g.M = W; g.N = N; g.K = R * T; g.lda = 0; g.ldb = N; g.ldc = N;
     g.fr_L = L; g.fr_T = T; g.fr_hop = hop; g.fr_pl = pad_left; g.fr_W = W;
-    g.a_vec = 0;
+    g.a_vec = aligned16(x) && (L % 4 == 0) && (hop % 4 == 0) && (pad_left % 4 == 0);
     g.b_vec = aligned16(dy) && (N % 4 == 0);
     return launch<A_FRAMES_T, B_ROW>(g, ws, ws_bytes, (hipStream_t)stream);
 }
@@ -675,7 +683,7 @@ ams_status ams_front_conv_bwd_filter(const float* x, const float* dy, float* df,
     g.A = x; g.B = dy; g.C = df; g.bias = nullptr;
     g.M = W; g.N = N; g.K = Bt * T; g.lda = 0; g.ldb = N; g.ldc = N;
     g.fr_L = L; g.fr_T = T; g.fr_hop = hop; g.fr_pl = pad_total / 2; g.fr_W = W;
-    g.a_vec = 0;
+    g.a_vec = aligned16(x) && (L % 4 == 0) && (hop % 4 == 0) && (g.fr_pl % 4 == 0);
     g.b_vec = aligned16(dy) && (N % 4 == 0);
     return launch<A_FRAMES_T, B_ROW>(g, ws, ws_bytes, (hipStream_t)stream);
 }
