@@ -73,16 +73,16 @@ def _front_dpcl_checkpoint(tmp, sep_cls, typ, B, S, L, N, extra=None):
     return tr, tfds, a
 
 
-def wl_pretraining(steps, warmup, with_max_pool=False, B=64):
+def wl_pretraining(steps, warmup, with_max_pool=False, B=64, graph=False):
     from utils.trainer import Adapt_Pretrainer
     L = 20480
     a = _args(window_size=1024, filters=256, max_pool=256, hop_size=256, chunk_size=L, batch_size=B, nb_speakers=2, loss='sdr+l2',
-              separation='mask', beta=0.0, regularization=0.0, overlap_coef=1.0, with_max_pool=with_max_pool, learning_rate=1e-3)
+              separation='mask', beta=0.0, regularization=0.0, overlap_coef=1.0, with_max_pool=with_max_pool, learning_rate=1e-3, hip_graph=graph)
     a.pop('type')
     tr = Adapt_Pretrainer(**a)
     dist, tfds = tr.prepare()
     dt, c = _time_train(tr, tfds, L, steps, warmup)
-    return {'workload': 'cfg2 pretraining step, path %s, B=%d, W=1024 hop=256 N=256' % ('B (max-pool)' if with_max_pool else 'A (strided)', B),
+    return {'workload': 'cfg2 pretraining step%s, path %s, B=%d, W=1024 hop=256 N=256' % (' (hipGraph replay)' if graph else '', 'B (max-pool)' if with_max_pool else 'A (strided)', B),
             'batch': B, 'ms_per_step': dt * 1e3, 'mixtures_per_s': B / dt, 'cost': c}
 
 
@@ -126,19 +126,19 @@ def wl_front_dpcl_inference(steps, warmup, B=64):
             'batch': B, 'ms_per_step': dt * 1e3, 'mixtures_per_s': B / dt, 'mean_abs_out': c}
 
 
-def wl_stft_l41(steps, warmup, enhance=False, B=64):
+def wl_stft_l41(steps, warmup, enhance=False, B=64, graph=False):
     from models.L41 import L41Model
     from utils.trainer import STFT_Separator_Trainer, STFT_Separator_enhance_Trainer
     L, S = 20480, 2
     a = _args(window_size=512, hop_size=256, chunk_size=L, batch_size=B, nb_speakers=S, layer_size=600, nb_layers=3, embedding_size=40,
-              model_folder=None, learning_rate=1e-3, pretraining=False, tot_speakers=251)
+              model_folder=None, learning_rate=1e-3, pretraining=False, tot_speakers=251, hip_graph=graph)
     for k in ('filters', 'max_pool', 'type'):
         a.pop(k)
     tr = STFT_Separator_Trainer(L41Model, 'STFT_L41', **dict(a))
     dist, tfds = tr.prepare()
     if not enhance:
         dt, c = _time_train(tr, tfds, L, steps, warmup)
-        return {'workload': 'cfg4 STFT_L41 training step: |STFT| (W=512) -> 3xBLSTM -> L41 loss, AMSGrad', 'batch': B,
+        return {'workload': 'cfg4 STFT_L41 training step%s: |STFT| (W=512) -> 3xBLSTM -> L41 loss, AMSGrad' % (' (hipGraph replay)' if graph else ''), 'batch': B,
                 'ms_per_step': dt * 1e3, 'mixtures_per_s': B / dt, 'cost': c}
     with tr.graph.as_default():
         tr.model.create_saver()
@@ -149,22 +149,23 @@ def wl_stft_l41(steps, warmup, enhance=False, B=64):
     tr = STFT_Separator_enhance_Trainer(L41Model, 'STFT_L41_enhance', **a)
     dist, tfds = tr.prepare()
     dt, c = _time_train(tr, tfds, L, steps, warmup)
-    return {'workload': 'cfg4 STFT_L41_enhance training step: frozen L41 + hard k-means (10x10) + 3xBLSTM enhance stack, PIT cost', 'batch': B,
+    return {'workload': 'cfg4 STFT_L41_enhance training step' + (' (hipGraph replay)' if graph else '') + ': frozen L41 + hard k-means (10x10) + 3xBLSTM enhance stack, PIT cost', 'batch': B,
             'ms_per_step': dt * 1e3, 'mixtures_per_s': B / dt, 'cost': c}
 
 
-def wl_front_l41_s3(steps, warmup, B=128):
+def wl_front_l41_s3(steps, warmup, B=128, graph=False):
     from models.L41 import L41Model
     tmp = tempfile.mkdtemp(prefix='ams_bc_')
     L, S, N = 20480, 3, 512
-    tr, tfds, a = _front_dpcl_checkpoint(tmp, L41Model, 'front_L41', B, S, L, N, extra={'tot_speakers': 251})
+    tr, tfds, a = _front_dpcl_checkpoint(tmp, L41Model, 'front_L41', B, S, L, N, extra={'tot_speakers': 251, 'hip_graph': graph})
     dt, c = _time_train(tr, tfds, L, steps, warmup)
-    return {'workload': 'cfg5 front_L41 training step: S=3, N=512 filters, B=128 per GPU, 3xBLSTM(600), L41 loss', 'batch': B,
+    return {'workload': 'cfg5 front_L41 training step' + (' (hipGraph replay)' if graph else '') + ': S=3, N=512 filters, B=128 per GPU, 3xBLSTM(600), L41 loss', 'batch': B,
             'ms_per_step': dt * 1e3, 'mixtures_per_s': B / dt, 'cost': c}
 
 
 WORKLOADS = {
     'pretraining_A': lambda s, w: wl_pretraining(s, w, False),
+    'pretraining_A_graph': lambda s, w: wl_pretraining(s, max(w, 4), False, graph=True),
     'pretraining_B_maxpool': lambda s, w: wl_pretraining(s, w, True),
     'front_DPCL_finetuning': wl_front_dpcl_finetuning,
     'front_DPCL_finetuning_graph': lambda s, w: wl_front_dpcl_finetuning(s, max(w, 4), graph=True),
@@ -172,6 +173,9 @@ WORKLOADS = {
     'STFT_L41': lambda s, w: wl_stft_l41(s, w, False),
     'STFT_L41_enhance': lambda s, w: wl_stft_l41(s, w, True),
     'front_L41_S3_N512_B128': wl_front_l41_s3,
+    'STFT_L41_graph': lambda s, w: wl_stft_l41(s, max(w, 4), False, graph=True),
+    'STFT_L41_enhance_graph': lambda s, w: wl_stft_l41(s, max(w, 4), True, graph=True),
+    'front_L41_S3_N512_B128_graph': lambda s, w: wl_front_l41_s3(s, max(w, 4), graph=True),
 }
 
 
