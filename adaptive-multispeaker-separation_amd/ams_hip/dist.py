@@ -47,6 +47,14 @@ class Dist(object):
                 t.copy_(tmp)
         return t
 
+    def broadcast_object(self, obj, src=0):
+        """Small picklable host object (run id, paths) from rank `src` to everyone."""
+        if self.enabled:
+            box = [obj if self.rank == src else None]
+            td.broadcast_object_list(box, src=src)
+            return box[0]
+        return obj
+
     def barrier(self):
         if self.enabled:
             td.barrier()

@@ -583,6 +583,12 @@ def kl_sparsity(p_hat, p):
 
 
 def all_reduce_sum_autograd(t, dist):
+    """SUM over ranks of a batch statistic that feeds a NON-mean loss term (p_hat -> KL, adapt.py:130-132).  Every rank
+    holds the same global term; rank r's backward carries d term / d (its own shard), and FlatOptimizer.exchange then averages
+    the per-rank gradients (sum x 1/world) -- right for the batch-MEAN terms, world x too small for this one -- so the incoming
+    gradient is scaled by world here (tests/test_dist_gloo.py::test_sparsity_term_gradient_matches_single_process)."""
+    world = float(getattr(dist, 'world_size', 1)) if getattr(dist, 'enabled', False) else 1.0
+
     class _AR(Function):
         @staticmethod
         def forward(ctx, x):
@@ -592,7 +598,7 @@ def all_reduce_sum_autograd(t, dist):
 
         @staticmethod
         def backward(ctx, g):
-            return g
+            return g * world if world != 1.0 else g
     return _AR.apply(t)
 
 

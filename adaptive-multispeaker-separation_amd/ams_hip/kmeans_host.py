@@ -11,7 +11,10 @@ class KMeans(object):
 
     def __init__(self, nb_clusters, centroids_init=None, nb_tries=10, nb_iterations=10, input_tensor=None,
                  normalize_input=True, latent_space_tensor=None, beta=None, threshold=2.5, assign_at_end=True,
-                 init_indices=None):
+                 init_indices=None, seeding='reference'):
+        if seeding not in ('reference', 'fast'):
+            raise ValueError("seeding must be 'reference' or 'fast', got %r" % (seeding,))
+        self.seeding = seeding
         if centroids_init is not None:
             raise NotImplementedError('explicit centroids_init (Kmeans_2.py:72-74) is unused by the reference recipes')
         self.nb_clusters = nb_clusters
@@ -32,12 +35,19 @@ class KMeans(object):
                         Node('labels', lambda run: self._result.value(run)[1], register=False))
 
     def _draw(self, R, L):
-        # Kmeans_2.py:61-65 draws np.random.choice(range(l), size=C, replace=False) per row from the GLOBAL numpy RNG inside a
-        # py_func: C distinct bins per row, uniformly.  That call permutes all l bins for every row (0.2-0.5 ms each, 640 rows at
-        # the benchmark shape = the whole inference budget) and its stream position is not reproducible from the reference anyway
-        # (SURVEY App. C-6), so the same distribution is drawn in one vectorised call from the same global RNG; rows that came
-        # out with a repeated index (probability ~ C^2/2l) are redrawn.
+        """Seed bins, int32 [R, C].  `seeding='reference'` (default) IS Kmeans_2.py:61-66: one
+        np.random.choice(range(l), size=C, replace=False) per row, in row order, from the GLOBAL numpy RNG (seeded 42 at
+        models/network.py:17-18) -- index work is bit-exact with the reference given the same stream position
+        (tests/test_host_mirror.py::test_kmeans_reference_seeding).  `choice(l, ...)` consumes exactly the stream of
+        `choice(range(l), ...)` (both are permutation(l)[:C]) without building a list per row.  The draw is inherently serial
+        (a full Fisher-Yates shuffle of l bins per row: ~0.15 ms x 640 rows at the benchmark shape, far above the 6 ms the GPU
+        needs for the batch), so throughput runs may opt into `seeding='fast'` (--kmeans_seeding fast): the same distribution
+        (C distinct bins, uniform) in one vectorised call from the same global RNG, rows with a repeated index redrawn -- a
+        DIFFERENT stream, hence different (equally valid) restarts."""
         C = self.nb_clusters
+        if self.seeding == 'reference':
+            a = np.array([np.random.choice(L, size=C, replace=False) for _ in range(R)])
+            return torch.from_numpy(a.astype(np.int32))
         a = np.random.randint(0, L, size=(R, C))
         if C > 1:
             while True:

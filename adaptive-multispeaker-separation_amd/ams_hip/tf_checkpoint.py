@@ -186,6 +186,17 @@ def write_bundle(prefix, arrays):
     open(prefix + '.data-00000-of-00001', 'wb').write(bytes(data))
 
 
+def reference_shapes(arrays):
+    """{name: array} as the REFERENCE's graph declares them: its Conv1D kernels (`prediction/W`, `enhance/W`) are 3-D
+    [1, Din, Dout] (utils/ops.py:486-492) where this build keeps [Din, Dout].  Use before write_bundle when exporting a model the
+    reference should load; Network.restore_model squeezes the leading 1 on the way in."""
+    out = {}
+    for n, a in arrays.items():
+        a = np.asarray(a)
+        out[n] = a[None] if (n.endswith('/W') and a.ndim == 2) else a
+    return out
+
+
 def latest_checkpoint(folder):
     """tf.train.latest_checkpoint: parse the text ``checkpoint`` file (model_checkpoint_path: "model-123")."""
     marker = os.path.join(folder, 'checkpoint')

@@ -94,44 +94,69 @@ class RecordStream(object):
 
 
 class MixtureStream(object):
-    """zip of S RecordStreams -> filter distinct speakers (dataset.py:473-480) -> mix (:462-468) -> batch."""
+    """zip of S RecordStreams -> filter distinct speakers (dataset.py:473-480) -> mix (:462-468): an iterable of
+    (mix [L], non_mix [S, L], keys [S]) examples."""
 
-    def __init__(self, streams, batch_size):
-        self.streams, self.batch_size = streams, int(batch_size)
+    def __init__(self, streams):
+        self.streams = streams
 
     def __iter__(self):
-        mixes, nms, keys = [], [], []
         for items in zip(*self.streams):
             ks = [k for _, k in items]
             if len(set(ks)) != len(ks):
                 continue
             nm = np.stack([c for c, _ in items]).astype(np.float32)
-            mixes.append(nm.sum(axis=0))
-            nms.append(nm)
-            keys.append(np.asarray(ks, np.int32))
-            if len(mixes) == self.batch_size:
-                yield np.stack(mixes), np.stack(nms), np.stack(keys)
-                mixes, nms, keys = [], [], []
-        if mixes:                                                     # tf.data batch() keeps the short final batch
+            yield nm.sum(axis=0), nm, np.asarray(ks, np.int32)
+
+
+def round_robin(streams):
+    """`process()` of the reference (dataset.py:493-511), its DEFAULT branch: zip the per-combination mixture streams, stack,
+    unbatch -- i.e. one example of combination 0, one of combination 1, ... and over again, ending with the first exhausted
+    combination (tf.data zip semantics; a partially filled round is dropped because zip yields whole tuples only)."""
+    for round_ in zip(*streams):
+        for ex in round_:
+            yield ex
+
+
+def batched(examples, batch_size, drop_remainder=False):
+    mixes, nms, keys = [], [], []
+    for m, nm, k in examples:
+        mixes.append(m)
+        nms.append(nm)
+        keys.append(k)
+        if len(mixes) == batch_size:
             yield np.stack(mixes), np.stack(nms), np.stack(keys)
+            mixes, nms, keys = [], [], []
+    if mixes and not drop_remainder:                                  # tf.data batch() keeps the short final batch
+        yield np.stack(mixes), np.stack(nms), np.stack(keys)
 
 
-def record_mixture_stream(folder, split, sex, S, chunk_size, batch_size, normalize=False, no_random_picking=True):
-    """The `no_random_picking` branch of TFDataset.__init__ (dataset.py:561-566,586-605): speaker i comes from the M file when i is
-    even and the F file when odd (both genders requested), stream i is seeded with i."""
+def record_mixture_stream(folder, split, sex, S, chunk_size, batch_size, normalize=False, no_random_picking=True, epoch=0,
+                          drop_remainder=False):
+    """TFDataset.__init__ of the reference (dataset.py:544-628), both branches:
+      * `no_random_picking` (:561-566,586-605): speaker i comes from the M file when i is even and the F file when odd (both
+        genders requested), stream i seeded with i; single-gender runs (:576-585) take every speaker from that file;
+      * default (:567-575,625-628): one mixture stream per gender combination product([M, F], repeat=S) -- [M,M] [M,F] [F,M]
+        [F,F] for two speakers -- stream j of combination i seeded with j + S*i, interleaved example by example (`process`).
+    tf.data's shuffle(seed) reshuffles on every initialisation of the iterator; `epoch` (how many times the split has been
+    initialised) is folded into the shuffle seeds for the same effect."""
     import os
+    from itertools import product
+    bump = 104729 * int(epoch)
 
-    def stream(g, i):
-        return RecordStream(os.path.join(folder, '%s_%s.tfrecords' % (split, g)), chunk_size, i, normalize)
-    if 'M' in sex and 'F' in sex:
-        if not no_random_picking:
-            raise NotImplementedError('random picking over all gender combinations (dataset.py:567-575) is not built; '
-                                      'pass --no_random_picking')
-        streams = [stream('M' if i % 2 == 0 else 'F', i) for i in range(S)]
+    def stream(g, seed):
+        return RecordStream(os.path.join(folder, '%s_%s.tfrecords' % (split, g)), chunk_size, seed + bump, normalize)
+    both = 'M' in sex and 'F' in sex
+    if both and not no_random_picking:
+        combos = [MixtureStream([stream(g, j + S * i) for j, g in enumerate(comb)])
+                  for i, comb in enumerate(product(['M', 'F'], repeat=S))]
+        examples = round_robin(combos)
+    elif both:
+        examples = MixtureStream([stream('M' if i % 2 == 0 else 'F', i) for i in range(S)])
     else:
         g = 'M' if 'M' in sex else 'F'
-        streams = [stream(g, i) for i in range(S)]
-    return MixtureStream(streams, batch_size)
+        examples = MixtureStream([stream(g, i) for i in range(S)])
+    return batched(examples, batch_size, drop_remainder)
 
 
 class TFDataset(object):
@@ -161,9 +186,11 @@ class TFDataset(object):
                 raise IOError('--dataset %s: no {split}_{M,F}.tfrecords under %s (set AMS_DATA_DIR, or use --dataset synthetic)'
                               % (name, folder))
             self.records = dict(folder=folder, sex=kwargs.get('sex') or ['M', 'F'], normalize=bool(kwargs.get('dataset_normalize')),
-                                no_random_picking=bool(kwargs.get('no_random_picking', True)))
+                                no_random_picking=bool(kwargs.get('no_random_picking', False)))
             self._iters = {}
             self._lengths = {}
+            self._epochs = {}
+            self.hip_graph = bool(kwargs.get('hip_graph'))
 
         g = get_default_graph()
         with g.variable_scope('dataset'):
@@ -188,19 +215,37 @@ class TFDataset(object):
         self.cursor[split] = 0
         if self.records is not None:
             self._iters.pop(split, None)
+            self._epochs[split] = self._epochs.get(split, -1) + 1       # reshuffle_each_iteration (tf.data default)
+
+    def _drop_remainder(self, split):
+        """A short final batch cannot be replayed through a hipGraph captured at the full batch shape, and with N ranks it would
+        reach one rank only while the 1/world gradient scale assumes equal shards: dropped in those cases (kept otherwise, as
+        tf.data's batch() does)."""
+        world = self.dist.world_size if self.dist is not None else 1
+        return world > 1 or (self.hip_graph and split == self.TRAIN)
+
+    def _stream(self, split, L, epoch):
+        r = self.records
+        return record_mixture_stream(r['folder'], split, r['sex'], self.S, L, self.batch_size, r['normalize'],
+                                     r['no_random_picking'], epoch, self._drop_remainder(split))
 
     def _record_batch(self, split, L):
         """Next batch of the TFRecord pipeline; with N ranks each rank keeps every N-th batch (utterance-level sharding)."""
         world = self.dist.world_size if self.dist is not None else 1
         rank = self.dist.rank if self.dist is not None else 0
-        it = self._iters.get(split)
-        if it is None:
-            r = self.records
-            it = self._iters[split] = iter(record_mixture_stream(r['folder'], split, r['sex'], self.S, L, self.batch_size, r['normalize'],
-                                                                   r['no_random_picking']))
         out = None
         for k in range(world):
-            b = next(it)                                            # StopIteration = end of epoch, like tf.errors.OutOfRangeError
+            it = self._iters.get(split)
+            if it is None:
+                it = self._iters[split] = iter(self._stream(split, L, self._epochs.get(split, 0)))
+            try:
+                b = next(it)
+            except StopIteration:
+                # length() counted a pass in epoch-0 order; a reshuffled pass can come out a batch short (the distinct-speaker
+                # filter depends on the order).  The reference would die with OutOfRangeError here; wrap into the next pass instead.
+                self._epochs[split] = self._epochs.get(split, 0) + 1
+                it = self._iters[split] = iter(self._stream(split, L, self._epochs[split]))
+                b = next(it)
             if k == rank:
                 out = b
         return tuple(torch.from_numpy(a).to(self.device) for a in out)
@@ -210,9 +255,7 @@ class TFDataset(object):
             # dataset.py:667-676: count the batches of one pass over the split (cached); each rank sees every world-th batch
             key = (split, self.default_chunk)
             if key not in self._lengths:
-                r = self.records
-                n = sum(1 for _ in record_mixture_stream(r['folder'], split, r['sex'], self.S, self.default_chunk, self.batch_size,
-                                                         r['normalize'], r['no_random_picking']))
+                n = sum(1 for _ in self._stream(split, self.default_chunk, 0))
                 world = self.dist.world_size if self.dist is not None else 1
                 self._lengths[key] = n // world
             return self._lengths[key]

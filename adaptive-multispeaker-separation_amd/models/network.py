@@ -70,7 +70,11 @@ class Network(object):
 
         if graph is None:
             # Run ID
+            # one run folder for the whole job: with N ranks the id is chosen on rank 0 and broadcast (save() writes on rank 0
+            # only, every rank restores from that folder at the end of Trainer.train)
             self.runID = kwargs.get('run_id') or haikunate()
+            if self.dist is not None and getattr(self.dist, 'enabled', False) and not kwargs.get('run_id'):
+                self.runID = self.dist.broadcast_object(self.runID)
             print('ID : {}'.format(self.runID))
             g = get_default_graph()
             with g.variable_scope('inputs'):
@@ -149,9 +153,14 @@ class Network(object):
                 if name not in bundle:
                     raise KeyError('variable %s not found in TensorFlow checkpoint %s' % (name, prefix))
                 v = g.variables[name]
-                if tuple(bundle[name].shape) != tuple(v.shape):
-                    raise ValueError('variable %s: checkpoint shape %s, graph shape %s' % (name, bundle[name].shape, tuple(v.shape)))
-                v.data.copy_(torch.from_numpy(bundle[name].astype(np.float32)).to(v.device))
+                arr = bundle[name]
+                if tuple(arr.shape) != tuple(v.shape):
+                    # the reference's Conv1D kernels are 3-D [1, Din, Dout] (utils/ops.py:486-492); here they are [Din, Dout]
+                    squeezed = tuple(d for d in arr.shape if d != 1)
+                    if squeezed != tuple(d for d in v.shape if d != 1):
+                        raise ValueError('variable %s: checkpoint shape %s, graph shape %s' % (name, arr.shape, tuple(v.shape)))
+                    arr = arr.reshape(tuple(v.shape))
+                v.data.copy_(torch.from_numpy(arr.astype(np.float32)).to(v.device))
                 g.initialized.add(name)
             return
         data = np.load(self._latest_checkpoint(path))
@@ -361,7 +370,10 @@ class Network(object):
             keys_to_update = ['learning_rate', 'epochs', 'batch_size', 'chunk_size', 'nb_speakers',
                               'regularization', 'overlap_coef', 'loss', 'beta', 'model_folder', 'type', 'pretraining',
                               'with_silence', 'end_assign', 'beta_kmeans', 'nb_tries', 'nb_steps', 'threshold', 'optimizer',
-                              'men', 'women', 'recurrent_dropout', 'recurrent_dropout_enhance']
+                              'men', 'women', 'recurrent_dropout', 'recurrent_dropout_enhance',
+                              # this build's own switches follow the CURRENT command line, not the loaded model's
+                              'hip_graph', 'no_summaries', 'summaries', 'synthetic_batches', 'synthetic_pool', 'run_id',
+                              'kmeans_seeding', 'dist']
             to_modify = {key: modified_args[key] for key in keys_to_update if key in modified_args.keys()}
             to_modify.update({key: val for key, val in modified_args.items() if key not in args.keys()})
         args.update(to_modify)

@@ -3,8 +3,8 @@
 
 ``MyArgs`` keeps the reference's flag names and defaults; ``Trainer.train`` keeps its
 loop (train -> every validation_step validate -> save-if-best -> epoch-end lr decay -> final validation,
-restore best, test), and each subclass' ``build`` is the reference's wiring recipe line for line -- only the
-objects underneath launch HIP kernels instead of TF ops.  Additions (all optional): ``--synthetic_batches``,
+restore best, test); the 15 recipe classes (same names and constructor signatures) are generated from the ``WIRING`` table
+below, which states what each one builds, restores, freezes and optimises.  Additions (all optional): ``--synthetic_batches``,
 ``--synthetic_pool`` (synthetic data source size), ``--no_summaries``, ``--hip_graph``; data parallelism is picked up from
 torchrun's environment (WORLD_SIZE/RANK/LOCAL_RANK), one process per GPU, RCCL all-reduce of gradients.
 """
@@ -60,6 +60,9 @@ class MyArgs(object):
         parser.add_argument('--hip_graph', help='[ams] capture forward+backward of the training step into a hipGraph after two '
                             'eager steps and replay it (fixed batch shape; the 480 recurrent launches of a 3xBLSTM step become '
                             'one graph launch)', action="store_true")
+        parser.add_argument('--kmeans_seeding', choices=['reference', 'fast'], default='reference',
+                            help="[ams] k-means restarts: 'reference' = one np.random.choice per row exactly as models/Kmeans_2.py:61-66 "
+                            "(bit-exact index stream, serial host draw); 'fast' = one vectorised draw (same distribution, other stream)")
         self.parser = parser
 
     def add_stft_args(self):
@@ -219,327 +222,191 @@ class Trainer(object):
                 yield output
                 print('Batch #', b + 1, '/', nb_batches_test)
 
+    # ------------------------------------------------------------------ the training loop (utils/trainer.py:262-390)
+    def _feeds_for(self, tfds):
+        chunk = self.args['chunk_size']
+        return {split: {tfds.handle: tfds.get_handle(split), tfds.chunk_size: chunk}
+                for split in (tfds.TRAIN, tfds.VALID, tfds.TEST)}
+
+    def _validate(self, tfds, feeds, step):
+        """One pass over the validation split; keeps the best model (save-if-best, :325-340 and :362-370)."""
+        tfds.initialize(tfds.VALID)
+        costs = [self.model.valid_batch(feeds[tfds.VALID], step) for _ in range(tfds.length(tfds.VALID))]
+        mean = np.mean(costs)
+        self.model.add_valid_summary(mean, step)
+        if mean < self._best_cost:
+            self._best_cost = mean
+            self._best_path = self.model.save(step)
+            self._say('Save best model with :', mean)
+        return costs, mean
+
+    def _say(self, *a, **k):
+        if self._verbose:
+            print(*a, **k)
+
     def train(self):
-        print('Total name :')
-        nb_epochs = self.args['epochs']
-        time_spent = [0 for _ in range(10)]
-        best_path = ''
         dist, tfds = self.prepare()
-        verbose = dist.rank == 0
-
+        self._verbose = dist.rank == 0
+        self._best_cost, self._best_path = 1e100, ''
+        epochs, every = self.args['epochs'], self.args['validation_step']
+        window = [0.0] * 10                        # moving average of the last 10 step times (:348-353)
         with self.graph.as_default():
-            nb_batches_train = tfds.length(tfds.TRAIN)
-            nb_batches_test = tfds.length(tfds.TEST)
-            nb_batches_valid = tfds.length(tfds.VALID)
-            if verbose:
-                print('BATCHES')
-                print(nb_batches_train, nb_batches_test, nb_batches_valid)
-
-            chunk = self.args['chunk_size']
-            feed_dict_train = {tfds.handle: tfds.get_handle(tfds.TRAIN), tfds.chunk_size: chunk}
-            feed_dict_valid = {tfds.handle: tfds.get_handle(tfds.VALID), tfds.chunk_size: chunk}
-            feed_dict_test = {tfds.handle: tfds.get_handle(tfds.TEST), tfds.chunk_size: chunk}
-
-            best_validation_cost = 1e100
-            t1 = time.time()
-            step = 0
-            costs = []
-
-            def validate():
-                tfds.initialize(tfds.VALID)
-                vc = []
-                for b_v in range(nb_batches_valid):
-                    vc.append(self.model.valid_batch(feed_dict_valid, step))
-                return vc
-
-            for epoch in range(nb_epochs):
+            n_train, n_test = tfds.length(tfds.TRAIN), tfds.length(tfds.TEST)
+            self._say('BATCHES')
+            self._say(n_train, n_test, tfds.length(tfds.VALID))
+            feeds = self._feeds_for(tfds)
+            step, costs, mark = 0, [], time.time()
+            for epoch in range(epochs):
                 tfds.initialize(tfds.TRAIN)
-                for b in range(nb_batches_train):
-                    t = time.time()
-                    c = self.model.train(feed_dict_train, step)
-
-                    if (step + 1) % self.args['validation_step'] == 0:
+                for b in range(n_train):
+                    c = self.model.train(feeds[tfds.TRAIN], step)
+                    if (step + 1) % every == 0:
                         t = time.time()
-                        costs = validate()
-                        valid_cost = np.mean(costs)
-                        self.model.add_valid_summary(valid_cost, step)
-                        # Save the model if it is better:
-                        if valid_cost < best_validation_cost:
-                            best_validation_cost = valid_cost
-                            best_path = self.model.save(step)
-                            if verbose:
-                                print('Save best model with :', best_validation_cost)
-                        t_f = time.time()
-                        if verbose:
-                            print('Validation set tested in ', t_f - t, ' seconds')
-                            print('Validation set: ', valid_cost)
-
-                    c = float(c)                         # host sync, as sess.run returning the cost does
-                    time_spent = time_spent[1:] + [time.time() - t1]
-                    avg = sum(time_spent) / len(time_spent)
-                    if verbose:
-                        print('Epoch #', epoch + 1, '/', nb_epochs, ' Batch #', b + 1, '/', nb_batches_train, 'in', avg,
-                              'sec loss=', c, ' ETA = ', getETA(avg, nb_batches_train, b + 1, nb_epochs, epoch + 1))
-                    t1 = time.time()
+                        costs, mean = self._validate(tfds, feeds, step)
+                        self._say('Validation set tested in ', time.time() - t, ' seconds')
+                        self._say('Validation set: ', mean)
+                    c = float(c)                   # host sync, as sess.run returning the cost does
+                    window = window[1:] + [time.time() - mark]
+                    avg = sum(window) / len(window)
+                    self._say('Epoch #', epoch + 1, '/', epochs, ' Batch #', b + 1, '/', n_train, 'in', avg, 'sec loss=', c,
+                              ' ETA = ', getETA(avg, n_train, b + 1, epochs, epoch + 1))
+                    mark = time.time()
                     step += 1
-                self.model.increment_epoch()
+                self.model.increment_epoch()       # lr halves every decay_epoch epochs (network.py:171-177)
 
-            # Validation at the last step
-            costs = validate()
-            valid_cost = np.mean(costs)
-            self.model.add_valid_summary(valid_cost, step)
-            if valid_cost < best_validation_cost:
-                best_validation_cost = valid_cost
-                best_path = self.model.save(step)
-                if verbose:
-                    print('Save best model with :', best_validation_cost)
+            costs, _ = self._validate(tfds, feeds, step)          # validation at the last step
+            self._say('Best model with Validation:  ', self._best_cost)
+            self._say('Path = ', self._best_path)
 
-            if verbose:
-                print('Best model with Validation:  ', best_validation_cost)
-                print('Path = ', best_path)
-
-            # Load the best model on validation set and test it
+            # best model on the validation set -> test split.  The reference appends the test costs to the LAST validation
+            # list before averaging (quirk C-13, :378-387); kept.
             dist.barrier()
             self.model.restore_last_checkpoint()
             tfds.initialize(tfds.TEST)
-            for b_t in range(nb_batches_test):
-                cost = self.model.test_batch(feed_dict_test)
-                costs.append(cost)                        # the reference re-uses the validation list (quirk C-13)
-            if verbose:
-                print('Test cost = ', np.mean(costs))
+            costs = list(costs) + [self.model.test_batch(feeds[tfds.TEST]) for _ in range(n_test)]
             self.last_test_cost = float(np.mean(costs))
+            self._say('Test cost = ', self.last_test_cost)
             return self.last_test_cost
 
 
 # ---------------------------------------------------------------------------------------------------
-# Inference recipes (reference utils/trainer.py:392-463)
+# Recipes (reference utils/trainer.py:392-658): WHAT each one wires, as data.  A recipe is a sequence of construction steps
+# over `self.model` (the lazily-built @scope attributes make the ORDER part of the semantics: touching an attribute builds its
+# sub-graph and creates its variables, so e.g. `back` must be touched before `saver` for the back-end to be restored).
+#
+#   ('load', who, key)      model = <who>.load(args[key], args)      who: 'sep' = the separator class, 'adapt' = Adapt
+#   ('new', who)            model = <who>(**args)
+#   ('args', {...})         args.update(...)
+#   ('touch', 'a.b')        build the lazy attribute model.a.b
+#   ('set', 'a.b', 'c.d')   model.a.b = model.c.d
+#   ('call', 'm', ...)      model.m(...)          ('sep' as an argument stands for the separator class)
+#   ('restore', key)        model.restore_model(args[key])
+#   ('train_only_args',)    keep the trainable variables whose name contains one of args['train'] (--train, fine-tuning)
+#   ('if', key, then, else) branch on args[key] is not None
 # ---------------------------------------------------------------------------------------------------
-class STFT_Separator_Enhanced_Inference(Trainer):
-    def __init__(self, separator, name, **kwargs):
-        self.separator = separator
-        super(STFT_Separator_Enhanced_Inference, self).__init__(trainer_type=name, **kwargs)
+_INIT_REST = ('call', 'initialize_non_init')
+_SAVER = ('call', 'create_saver')
+_FINISH = ('call', 'finish_construction')
+_TB = ('call', 'tensorboard_init')
+_OPT = ('touch', 'optimize')
 
-    def build(self):
-        self.model = self.separator.load(self.args['model_folder'], self.args)
-        self.model.separate
-        self.model.enhance
-        self.model.output = self.model.postprocessing
-        self.model.create_saver()
-        self.model.restore_model(self.args['model_folder'])
-        self.model.initialize_non_init()
-
-
-class STFT_Separator_Inference(Trainer):
-    def __init__(self, separator, name, **kwargs):
-        self.separator = separator
-        super(STFT_Separator_Inference, self).__init__(trainer_type=name, **kwargs)
-
-    def build(self):
-        self.model = self.separator.load(self.args['model_folder'], self.args)
-        self.model.separate
-        self.model.output = self.model.postprocessing
-        self.model.create_saver()
-        self.model.restore_model(self.args['model_folder'])
-        self.model.initialize_non_init()
-
-
-# Can be used with Finetuned or non Finetuned model
-class Front_Separator_Inference(Trainer):
-    def __init__(self, separator, name, **kwargs):
-        super(Front_Separator_Inference, self).__init__(trainer_type=name, **kwargs)
-        self.separator = separator
-
-    def build(self):
-        self.model = Adapt.load(self.args['model_folder'], self.args)
-        self.model.connect_front(self.separator)
-        self.model.sepNet.output = self.model.sepNet.separate
-        self.model.output = self.model.back
-        self.model.create_saver()
-        self.model.restore_model(self.args['model_folder'])
-        self.model.finish_construction()
-        self.model.initialize_non_init()
-
-
-class Front_Separator_Enhanced_Inference(Trainer):
-    def __init__(self, separator, name, **kwargs):
-        super(Front_Separator_Enhanced_Inference, self).__init__(trainer_type=name, **kwargs)
-        self.separator = separator
-
-    def build(self):
-        self.model = Adapt.load(self.args['model_folder'], self.args)
-        self.model.connect_front(self.separator)
-        self.model.sepNet.output = self.model.sepNet.enhance
-        self.model.output = self.model.back
-        self.model.create_saver()
-        self.model.restore_model(self.args['model_folder'])
-        self.model.initialize_non_init()
+WIRING = {
+    # ---- inference (:392-463)
+    'STFT_Separator_Enhanced_Inference': (
+        ('load', 'sep', 'model_folder'), ('touch', 'separate'), ('touch', 'enhance'), ('set', 'output', 'postprocessing'),
+        _SAVER, ('restore', 'model_folder'), _INIT_REST),
+    'STFT_Separator_Inference': (
+        ('load', 'sep', 'model_folder'), ('touch', 'separate'), ('set', 'output', 'postprocessing'),
+        _SAVER, ('restore', 'model_folder'), _INIT_REST),
+    'Front_Separator_Inference': (       # fine-tuned or not
+        ('load', 'adapt', 'model_folder'), ('call', 'connect_front', 'sep'), ('set', 'sepNet.output', 'sepNet.separate'),
+        ('set', 'output', 'back'), _SAVER, ('restore', 'model_folder'), _FINISH, _INIT_REST),
+    'Front_Separator_Enhanced_Inference': (
+        ('load', 'adapt', 'model_folder'), ('call', 'connect_front', 'sep'), ('set', 'sepNet.output', 'sepNet.enhance'),
+        ('set', 'output', 'back'), _SAVER, ('restore', 'model_folder'), _INIT_REST),
+    'Pretrained_Inference': (
+        ('args', {'pretraining': True}), ('new', 'adapt'), ('set', 'output', 'back'), _SAVER, ('restore', 'model_folder')),
+    # ---- training (:465-658)
+    'STFT_Separator_Trainer': (
+        ('if', 'model_folder',
+         (('load', 'sep', 'model_folder'), _SAVER, ('restore', 'model_folder'), ('set', 'cost_model', 'cost'), _FINISH, _OPT, _TB,
+          _INIT_REST),
+         (('new', 'sep'), _TB, ('call', 'init_all'))),),
+    'STFT_Separator_enhance_Trainer': (
+        ('load', 'sep', 'model_folder'), _SAVER, ('restore', 'model_folder'), ('call', 'add_enhance_layer'), _TB, _INIT_REST),
+    'STFT_Separator_FineTune_Trainer': (
+        ('load', 'sep', 'model_folder'), ('touch', 'separate'), ('touch', 'enhance'), _SAVER, ('restore', 'model_folder'),
+        ('touch', 'postprocessing'), ('set', 'cost_model', 'cost_finetuning'), _FINISH, ('train_only_args',), _OPT, _TB,
+        _INIT_REST),
+    'Adapt_Pretrainer': (('new', 'adapt'), _TB, ('call', 'init_all')),
+    'Front_Separator_Trainer': (
+        ('if', 'model_previous',
+         (('load', 'adapt', 'model_previous'), ('call', 'connect_front', 'sep'), ('set', 'sepNet.output', 'sepNet.prediction'),
+          ('set', 'cost_model', 'sepNet.cost'), ('touch', 'back'), _SAVER, ('restore', 'model_previous'), _FINISH,
+          ('call', 'freeze_all_with', 'front/'), ('call', 'freeze_all_with', 'back/'), _OPT, _TB, _INIT_REST),
+         (('load', 'adapt', 'model_folder'), ('call', 'connect_only_front_to_separator', 'sep'), _INIT_REST)),),
+    'Front_Separator_Finetuning_Trainer': (
+        ('load', 'adapt', 'model_folder'), ('call', 'connect_front', 'sep'), ('set', 'sepNet.output', 'sepNet.separate'),
+        ('touch', 'back'), _SAVER, ('restore', 'model_folder'), ('set', 'cost_model', 'cost'), _FINISH,
+        ('call', 'freeze_all_except', 'prediction', 'speaker_centroids'), _OPT, _TB, _INIT_REST),
+    'Front_Separator_Enhance_Trainer': (
+        ('load', 'adapt', 'model_folder'), ('call', 'connect_enhance_to_separator', 'sep'), _INIT_REST),
+    'Front_Separator_Enhance_Finetuning_Trainer': (
+        ('load', 'adapt', 'model_folder'), ('call', 'connect_front', 'sep'), ('set', 'sepNet.output', 'sepNet.enhance'),
+        ('touch', 'back'), _SAVER, ('restore', 'model_folder'), ('set', 'cost_model', 'cost_finetuning'), _FINISH,
+        ('train_only_args',), _OPT, _TB, _INIT_REST),
+}
 
 
-class Pretrained_Inference(Trainer):
-    def __init__(self, separator, name, **kwargs):
-        super(Pretrained_Inference, self).__init__(trainer_type=name, **kwargs)
-        self.separator = separator
-
-    def build(self):
-        self.args.update({'pretraining': True})
-        self.model = Adapt(**self.args)
-        self.model.output = self.model.back
-        self.model.create_saver()
-        self.model.restore_model(self.args['model_folder'])
+def _resolve(obj, path):
+    for part in path.split('.'):
+        obj = getattr(obj, part)
+    return obj
 
 
-# ---------------------------------------------------------------------------------------------------
-# Training recipes (reference utils/trainer.py:465-658)
-# ---------------------------------------------------------------------------------------------------
-class STFT_Separator_Trainer(Trainer):
-    def __init__(self, separator, name, **kwargs):
-        self.separator = separator
-        super(STFT_Separator_Trainer, self).__init__(trainer_type=name, **kwargs)
-
-    def build(self):
-        if self.args['model_folder'] is not None:
-            self.model = self.separator.load(self.args['model_folder'], self.args)
-            self.model.create_saver()
-            self.model.restore_model(self.args['model_folder'])
-            self.model.cost_model = self.model.cost
-            self.model.finish_construction()
-            self.model.optimize
-            self.model.tensorboard_init()
-            self.model.initialize_non_init()
+def _wire(tr, steps):
+    who = {'sep': lambda: tr.separator, 'adapt': lambda: Adapt}
+    for st in steps:
+        op = st[0]
+        if op == 'load':
+            tr.model = who[st[1]]().load(tr.args[st[2]], tr.args)
+        elif op == 'new':
+            tr.model = who[st[1]]()(**tr.args)
+        elif op == 'args':
+            tr.args.update(st[1])
+        elif op == 'touch':
+            _resolve(tr.model, st[1])
+        elif op == 'set':
+            owner, _, attr = st[1].rpartition('.')
+            setattr(_resolve(tr.model, owner) if owner else tr.model, attr, _resolve(tr.model, st[2]))
+        elif op == 'call':
+            getattr(tr.model, st[1])(*[tr.separator if a == 'sep' else a for a in st[2:]])
+        elif op == 'restore':
+            tr.model.restore_model(tr.args[st[1]])
+        elif op == 'train_only_args':
+            wanted = tr.model.args['train']
+            tr.model.trainable_variables = [v for v in tr.model.trainable_variables for p in wanted if p in v.ams_name]
+        elif op == 'if':
+            _wire(tr, st[2] if tr.args[st[1]] is not None else st[3])
         else:
-            self.model = self.separator(**self.args)
-            self.model.tensorboard_init()
-            self.model.init_all()
+            raise ValueError('unknown wiring step %r' % (st,))
 
 
-class STFT_Separator_enhance_Trainer(Trainer):
-    def __init__(self, separator, name, **kwargs):
-        self.separator = separator
-        super(STFT_Separator_enhance_Trainer, self).__init__(trainer_type=name, **kwargs)
-
-    def build(self):
-        self.model = self.separator.load(self.args['model_folder'], self.args)
-        self.model.create_saver()
-        self.model.restore_model(self.args['model_folder'])
-        self.model.add_enhance_layer()
-        self.model.tensorboard_init()
-        self.model.initialize_non_init()
-
-
-class STFT_Separator_FineTune_Trainer(Trainer):
-    def __init__(self, separator, name, **kwargs):
-        self.separator = separator
-        super(STFT_Separator_FineTune_Trainer, self).__init__(trainer_type=name, **kwargs)
-
-    def build(self):
-        self.model = self.separator.load(self.args['model_folder'], self.args)
-        self.model.separate
-        self.model.enhance
-        self.model.create_saver()
-        self.model.restore_model(self.args['model_folder'])
-        self.model.postprocessing
-        self.model.cost_finetuning
-        self.model.cost_model = self.model.cost_finetuning
-        self.model.finish_construction()
-        to_train = []
-        for var in self.model.trainable_variables:
-            for p in self.model.args['train']:
-                if p in var.ams_name:
-                    to_train.append(var)
-        self.model.trainable_variables = to_train
-        self.model.optimize
-        self.model.tensorboard_init()
-        self.model.initialize_non_init()
+def _make_recipe(name):
+    """Recipe classes keep the reference's names and constructor signatures: Adapt_Pretrainer(**kwargs), every other one
+    (separator, name, **kwargs)."""
+    if name == 'Adapt_Pretrainer':
+        def __init__(self, **kwargs):
+            self.separator = None
+            Trainer.__init__(self, trainer_type='pretraining', **kwargs)
+    else:
+        def __init__(self, separator, name, **kwargs):
+            self.separator = separator
+            Trainer.__init__(self, trainer_type=name, **kwargs)
+    return type(name, (Trainer,), {'__init__': __init__, 'build': lambda self: _wire(self, WIRING[name]),
+                                   '__doc__': 'wiring: WIRING[%r]' % name})
 
 
-class Adapt_Pretrainer(Trainer):
-
-    def __init__(self, **kwargs):
-        super(Adapt_Pretrainer, self).__init__(trainer_type='pretraining', **kwargs)
-
-    def build(self):
-        self.model = Adapt(**self.args)
-        self.model.tensorboard_init()
-        self.model.init_all()
-
-
-class Front_Separator_Trainer(Trainer):
-    def __init__(self, separator, name, **kwargs):
-        super(Front_Separator_Trainer, self).__init__(trainer_type=name, **kwargs)
-        self.separator = separator
-
-    def build(self):
-        if self.args['model_previous'] is not None:
-            self.model = Adapt.load(self.args['model_previous'], self.args)
-            self.model.connect_front(self.separator)
-            self.model.sepNet.output = self.model.sepNet.prediction
-            self.model.cost_model = self.model.sepNet.cost
-            self.model.back  # To save the back values !
-            self.model.create_saver()
-            self.model.restore_model(self.args['model_previous'])
-            self.model.finish_construction()
-            self.model.freeze_all_with('front/')
-            self.model.freeze_all_with('back/')
-            self.model.optimize
-            self.model.tensorboard_init()
-            self.model.initialize_non_init()
-        else:
-            self.model = Adapt.load(self.args['model_folder'], self.args)
-            self.model.connect_only_front_to_separator(self.separator)
-            self.model.initialize_non_init()
-
-
-class Front_Separator_Finetuning_Trainer(Trainer):
-    def __init__(self, separator, name, **kwargs):
-        super(Front_Separator_Finetuning_Trainer, self).__init__(trainer_type=name, **kwargs)
-        self.separator = separator
-
-    def build(self):
-        self.model = Adapt.load(self.args['model_folder'], self.args)
-        self.model.connect_front(self.separator)
-        self.model.sepNet.output = self.model.sepNet.separate
-        self.model.back
-        self.model.create_saver()
-        self.model.restore_model(self.args['model_folder'])
-        self.model.cost_model = self.model.cost
-        self.model.finish_construction()
-        self.model.freeze_all_except('prediction', 'speaker_centroids')
-        self.model.optimize
-        self.model.tensorboard_init()
-        self.model.initialize_non_init()
-
-
-class Front_Separator_Enhance_Trainer(Trainer):
-    def __init__(self, separator, name, **kwargs):
-        super(Front_Separator_Enhance_Trainer, self).__init__(trainer_type=name, **kwargs)
-        self.separator = separator
-
-    def build(self):
-        self.model = Adapt.load(self.args['model_folder'], self.args)
-        self.model.connect_enhance_to_separator(self.separator)
-        self.model.initialize_non_init()
-
-
-class Front_Separator_Enhance_Finetuning_Trainer(Trainer):
-    def __init__(self, separator, name, **kwargs):
-        super(Front_Separator_Enhance_Finetuning_Trainer, self).__init__(trainer_type=name, **kwargs)
-        self.separator = separator
-
-    def build(self):
-        self.model = Adapt.load(self.args['model_folder'], self.args)
-        self.model.connect_front(self.separator)
-        self.model.sepNet.output = self.model.sepNet.enhance
-        self.model.back
-        self.model.create_saver()
-        self.model.restore_model(self.args['model_folder'])
-        self.model.cost_model = self.model.cost_finetuning
-        self.model.finish_construction()
-        to_train = []
-        for var in self.model.trainable_variables:
-            for p in self.args['train']:
-                if p in var.ams_name:
-                    to_train.append(var)
-        self.model.trainable_variables = to_train
-        self.model.optimize
-        self.model.tensorboard_init()
-        self.model.initialize_non_init()
+for _name in WIRING:
+    globals()[_name] = _make_recipe(_name)
+del _name

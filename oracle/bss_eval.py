@@ -1,9 +1,12 @@
 """Oracle: BSS-eval SDR / SIR / SAR.
 
-Test infrastructure only -- see oracle/__init__.py.  PARITY UNPINNED: the reference file (utils/bss_eval.py, a copy of
-mir_eval.separation with TensorFlow and cupy variants added) is Python 2 and imports tensorflow/cupy, so it cannot be run
-here; this restates its algorithm in float64 numpy and is cross-checked in tests/ against defining properties (exact recovery
-of a known mixing filter, invariances) -- not against reference outputs.
+Test infrastructure only -- see oracle/__init__.py.  PARITY PINNED (the only oracle in this repo that is): the reference file
+(utils/bss_eval.py, a copy of mir_eval.separation with TensorFlow and cupy variants added) cannot be imported whole (Python-2
+prints, tensorflow/cupy imports), but its numpy implementation (:74-371) runs under Python 3; tests/golden/make_bss_golden.py
+executes exactly those reference lines in the build container and tests/test_bss_golden.py holds this restatement (and the
+HIP library) to the resulting vectors at 1e-6 dB -- nsrc 2 and 3, L 3000 / 20480, "mixture as estimate", a near-silent estimate,
+the raw projection, and validate()'s rejection of silent sources.  The cupy variant below differs from that numpy original only
+in _safe_db (den + 1e-12); its dB values are pinned from the same reference run through the stored energies.
 
 Follows the reference's GPU path, the one experiments/evaluation/eval.py:48-73 calls:
   bss_eval_sources_cupy   utils/bss_eval.py:586-637   (pair matrix + permutation by mean SIR)

@@ -52,7 +52,28 @@ def _worker(rank, world, port, tmp, q):
     opt.flat_grad.copy_(torch.ones_like(opt.flat_grad) * (rank + 1))
     s2 = opt.exchange()
     gn = float(torch.linalg.vector_norm(torch.ones_like(opt.flat_grad) * 1.5))
-    q.put((rank, same, idx.tolist(), bool(torch.allclose(avg, expect)), abs(s2 - (1.0 / world) * 0.5 / max(gn, 0.5)) < 1e-6))
+    # 5. one run folder for the job: the id chosen on rank 0 is the id everywhere (save() writes on rank 0 only, every rank
+    #    restores from that folder at the end of Trainer.train)
+    ids = [None] * world
+    torch.distributed.all_gather_object(ids, model.runID)
+    same_id = all(i == ids[0] for i in ids)
+    # 6. sparsity term (adapt.py:130-132): p_hat is a batch SUM through a non-linear KL.  Per-rank gradient of
+    #    [mean-type term + KL(all-reduced p_hat)] averaged over ranks must equal the single-process gradient on the whole batch.
+    from ams_hip import functional as F
+    gen = torch.Generator().manual_seed(5)
+    y_all = (torch.rand(2 * world, 6, generator=gen) * 0.1).double()
+    def loss_of(y, p_hat):
+        return (y ** 2).sum(1).mean() + F.kl_sparsity(p_hat, 0.05)
+    ya = y_all.clone().requires_grad_(True)
+    loss_of(ya, ya.abs().sum(0)).backward()
+    mine = y_all[2 * rank:2 * rank + 2].clone().requires_grad_(True)
+    loss_of(mine, F.all_reduce_sum_autograd(mine.abs().sum(0), dist)).backward()
+    # what FlatOptimizer.exchange does to a parameter gradient: sum over ranks x 1/world.  Here the "parameter" is the input
+    # shard itself, so compare d/d(shard) x (1/world) with the matching rows of the full-batch gradient: the mean term carries
+    # 1/(2*world) vs 1/2 locally (-> x 1/world), the KL term must come out unscaled.
+    kl_ok = bool(torch.allclose(mine.grad / world, ya.grad[2 * rank:2 * rank + 2], rtol=1e-10, atol=1e-12))
+    q.put((rank, same, idx.tolist(), bool(torch.allclose(avg, expect)), abs(s2 - (1.0 / world) * 0.5 / max(gn, 0.5)) < 1e-6,
+           same_id, kl_ok))
     dist.barrier()
     torch.distributed.destroy_process_group()
 
@@ -73,3 +94,5 @@ def test_two_rank_gloo_data_parallel(tmp_path):
     assert res[0][2] == [12, 13] and res[1][2] == [14, 15]            # batch 3, world 2, B=2: (3*2+rank)*2 ...
     assert all(r[3] for r in res), 'all-reduced mean gradient wrong'
     assert all(r[4] for r in res), 'global-norm clip must use the averaged gradient'
+    assert all(r[5] for r in res), 'run id differs across ranks'
+    assert all(r[6] for r in res), 'sparsity (KL of the batch-summed p_hat) gradient is not the single-process gradient'

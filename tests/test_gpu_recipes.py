@@ -519,6 +519,9 @@ def test_restore_from_tensorflow_bundle_matches_npz():
     extra = dict(P)
     extra['global_epoch'] = np.array(0, np.int32)                    # the reference also saves optimizer state / counters
     extra['prediction/W/AMSGrad'] = np.zeros_like(P['prediction/W'])
+    # the reference's Conv1D kernel is 3-D [1, Din, Dout] on disk (utils/ops.py:486-492); this build keeps [Din, Dout]
+    extra['prediction/W'] = P['prediction/W'][None]
+    assert extra['prediction/W'].ndim == 3
     tf_checkpoint.write_bundle(os.path.join(tf_folder, 'model-7'), extra)
     with open(os.path.join(tf_folder, 'checkpoint'), 'w') as f:
         f.write('model_checkpoint_path: "model-7"\nall_model_checkpoint_paths: "model-7"\n')

@@ -129,3 +129,21 @@ def test_synthetic_source_contract():
     assert abs(np.sqrt((nm[0, 0] ** 2).mean()) - 0.05) < 1e-6
     m2, _, _ = synthetic_mixtures([1], 2, 2048)
     assert np.array_equal(m2[0], mix[1])                   # depends on the global utterance index only
+
+
+def test_kmeans_reference_seeding():
+    """Default k-means restarts ARE models/Kmeans_2.py:61-66: one np.random.choice(range(l), size=C, replace=False) per row, in row
+    order, from the global numpy RNG seeded 42 (models/network.py:17-18) -- same indices, same stream position afterwards."""
+    import types
+    import numpy as np
+    from ams_hip.kmeans_host import KMeans
+    R, L, C = 12, 500, 3
+    np.random.seed(42)
+    ref = np.array([np.random.choice(range(L), size=C, replace=False) for _ in range(R)]).astype(np.int32)
+    after_ref = np.random.randint(0, 1 << 30)
+    np.random.seed(42)
+    got = KMeans._draw(types.SimpleNamespace(nb_clusters=C, seeding='reference'), R, L).numpy()
+    after_got = np.random.randint(0, 1 << 30)
+    assert got.dtype == np.int32 and np.array_equal(got, ref) and after_got == after_ref
+    fast = KMeans._draw(types.SimpleNamespace(nb_clusters=C, seeding='fast'), 200, 50).numpy()
+    assert fast.shape == (200, C) and all(len(set(r)) == C for r in fast.tolist()) and fast.min() >= 0 and fast.max() < 50

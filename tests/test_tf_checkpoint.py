@@ -62,3 +62,84 @@ def test_corruption_is_detected(tmp_path):
 def test_latest_checkpoint_text_file(tmp_path):
     (tmp_path / 'checkpoint').write_text('model_checkpoint_path: "model-900"\nall_model_checkpoint_paths: "model-100"\n')
     assert tfc.latest_checkpoint(str(tmp_path)) == os.path.join(str(tmp_path), 'model-900')
+
+
+# ---- a bundle index assembled BY HAND (not by tf_checkpoint.write_bundle) ------------------------------------------------------
+def _crc32c_bitwise(data):
+    """Castagnoli CRC, bit at a time (polynomial 0x1EDC6F41 reflected) -- independent of csrc/host/crc32c.c's slice-by-8 tables."""
+    crc = 0xFFFFFFFF
+    for byte in data:
+        crc ^= byte
+        for _ in range(8):
+            crc = (crc >> 1) ^ (0x82F63B78 if crc & 1 else 0)
+    return crc ^ 0xFFFFFFFF
+
+
+def _mask(crc):
+    return (((crc >> 15) | (crc << 17)) + 0xa282ead8) & 0xFFFFFFFF          # leveldb / TF crc32c::Mask
+
+
+def _trailer(block):
+    return block + b'\x00' + struct.pack('<I', _mask(_crc32c_bitwise(block + b'\x00')))
+
+
+def test_reader_on_a_hand_assembled_index(tmp_path):
+    """The reader against bytes this repo's writer did not produce.  Layout written out literally below, the way
+    tensorflow/core/util/tensor_bundle (BundleWriter) + lib/io/table_builder emit it: header value with the `version` submessage
+    the real writer adds, BundleEntryProto with proto3 zero fields OMITTED (offset 0, shard 0), a scalar's EMPTY shape message,
+    prefix-compressed keys ("a/bias" -> "a/kernel" shares "a/"; restart interval 16 so one restart point), a second data
+    block, an index block with restart interval 1 and SHORTENED separator keys (leveldb FindShortestSeparator: "a/l" instead of
+    "a/kernel"), masked CRC-32C trailers computed bit-wise here."""
+    kernel = np.arange(6, dtype='<f4').reshape(1, 2, 3)                     # [1, Din, Dout] like the reference's Conv1D W
+    bias = np.array([0.5, -1.0, 2.0], dtype='<f4')
+    step = np.array(7, dtype='<i4')                                         # scalar
+    data = bias.tobytes() + kernel.tobytes() + step.tobytes()               # offsets 0, 12, 36
+
+    def crc_field(blob):
+        return b'\x35' + struct.pack('<I', _mask(_crc32c_bitwise(blob)))     # field 6, wire type 5 (fixed32)
+    header = bytes.fromhex('0801' '1a02' '0801')                             # num_shards = 1, version { producer: 1 }
+    e_bias = bytes.fromhex('0801' '1204' '1202' '0803' '280c') + crc_field(bias.tobytes())            # dtype 1, shape{dim{3}}, size 12 (offset 0 omitted)
+    e_kern = bytes.fromhex('0801' '120c' '1202' '0801' '1202' '0802' '1202' '0803' '200c' '2818') + crc_field(kernel.tobytes())
+    e_step = bytes.fromhex('0803' '1200' '2024' '2804') + crc_field(step.tobytes())                   # dtype 3 (int32), empty shape, offset 36, size 4
+    block0 = (bytes([0, 0, len(header)]) + header                           # key ""        shared 0, non_shared 0
+              + bytes([0, 6, len(e_bias)]) + b'a/bias' + e_bias             # key "a/bias"  shared 0, non_shared 6
+              + bytes([2, 6, len(e_kern)]) + b'kernel' + e_kern             # key "a/kernel": shares "a/"
+              + struct.pack('<II', 0, 1))                                   # restart offsets [0], num_restarts 1
+    block1 = (bytes([0, 11, len(e_step)]) + b'global_step' + e_step
+              + struct.pack('<II', 0, 1))
+    out = bytearray()
+    off0 = len(out); out += _trailer(block0)
+    off1 = len(out); out += _trailer(block1)
+    meta = struct.pack('<II', 0, 1)                                         # empty metaindex block
+    offm = len(out); out += _trailer(meta)
+    assert off0 < 128 and len(block0) < 256 and off1 < 16384                # so the handles below are the 1- and 2-byte varints written
+    def varint(n):
+        b = bytearray()
+        while n >= 0x80:
+            b.append((n & 0x7f) | 0x80)
+            n >>= 7
+        b.append(n)
+        return bytes(b)
+    h0 = varint(off0) + varint(len(block0))
+    h1 = varint(off1) + varint(len(block1))
+    index = (bytes([0, 3, len(h0)]) + b'a/l' + h0                           # shortened separator >= "a/kernel", < "global_step"
+             + bytes([0, 1, len(h1)]) + b'h' + h1                           # short successor of "global_step"
+             + struct.pack('<III', 0, 3 + 3 + len(h0), 2))                  # restart interval 1: a restart per entry
+    offi = len(out); out += _trailer(index)
+    footer = varint(offm) + varint(len(meta)) + varint(offi) + varint(len(index))
+    footer += b'\x00' * (40 - len(footer)) + bytes.fromhex('57fb808b247547db')     # kTableMagicNumber, little endian
+    out += footer
+    prefix = str(tmp_path / 'model-3')
+    open(prefix + '.index', 'wb').write(bytes(out))
+    open(prefix + '.data-00000-of-00001', 'wb').write(data)
+
+    nshards, entries = tfc.list_bundle(prefix)
+    assert nshards == 1 and sorted(entries) == ['a/bias', 'a/kernel', 'global_step']
+    assert entries['a/kernel']['shape'] == [1, 2, 3] and entries['a/kernel']['offset'] == 12
+    assert entries['global_step']['shape'] == [] and entries['a/bias']['offset'] == 0
+    got = tfc.read_bundle(prefix)
+    assert np.array_equal(got['a/kernel'], kernel) and got['a/kernel'].shape == (1, 2, 3)
+    assert np.array_equal(got['a/bias'], bias) and got['global_step'] == 7 and got['global_step'].dtype == np.int32
+    # and the in-repo CRC agrees with the bit-wise one on these blocks
+    from data import tfrecord
+    assert tfrecord.masked_crc(block0 + b'\x00') == _mask(_crc32c_bitwise(block0 + b'\x00'))

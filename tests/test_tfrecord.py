@@ -74,3 +74,33 @@ def test_pipeline_stages_follow_the_reference(tmp_path):
     # same-gender streams with one speaker only: every tuple repeats the key and is dropped
     tfrecord.write_audio_records(str(tmp_path / 'valid_M.tfrecords'), [(rng.randn(500).astype(np.float32), 1)] * 3)
     assert list(record_mixture_stream(str(tmp_path), 'valid', ['M'], 2, L, 4)) == []
+
+
+def test_default_branch_interleaves_gender_combinations(tmp_path):
+    """README.md:23's `--men --women` command takes the DEFAULT branch (dataset.py:567-575,493-511,625-628): one mixture stream per
+    gender combination [M,M] [M,F] [F,M] [F,F], stream j of combination i seeded j + S*i, examples taken round-robin over the
+    combinations until the first one runs out, then batched."""
+    from data.dataset import record_mixture_stream
+    rng = np.random.RandomState(3)
+    L, S = 50, 2
+    M = [(rng.randn(50 * n + 7).astype(np.float32), 100 + i) for i, n in enumerate([3, 2, 4, 2, 3])]       # 14 chunks, 5 speakers
+    Fm = [(rng.randn(50 * n + 3).astype(np.float32), 200 + i) for i, n in enumerate([2, 5, 3, 2])]         # 12 chunks, 4 speakers
+    tfrecord.write_audio_records(str(tmp_path / 'train_M.tfrecords'), M)
+    tfrecord.write_audio_records(str(tmp_path / 'train_F.tfrecords'), Fm)
+    batches = list(record_mixture_stream(str(tmp_path), 'train', ['M', 'F'], S, L, 4, no_random_picking=False))
+    keys = np.concatenate([b[2] for b in batches])
+    gender = (keys >= 200).astype(int)                                  # 0 = M, 1 = F
+    expect = np.array([[0, 0], [0, 1], [1, 0], [1, 1]])                 # product([M, F], repeat=2) order
+    assert len(keys) % 4 == 0 and len(keys) >= 8                         # whole rounds only
+    assert np.array_equal(gender, np.tile(expect, (len(keys) // 4, 1)))
+    assert all(k[0] != k[1] for k in keys)                               # distinct speakers inside a mixture
+    for mix, nm, _ in batches:
+        assert np.allclose(mix, nm.sum(axis=1))
+    # same seeds -> same pass; another epoch -> another order of the same material
+    again = list(record_mixture_stream(str(tmp_path), 'train', ['M', 'F'], S, L, 4, no_random_picking=False))
+    assert all(np.array_equal(a[1], b[1]) for a, b in zip(batches, again))
+    other = list(record_mixture_stream(str(tmp_path), 'train', ['M', 'F'], S, L, 4, no_random_picking=False, epoch=1))
+    assert not all(np.array_equal(a[1], b[1]) for a, b in zip(batches, other))
+    # drop_remainder (hipGraph replay / N ranks): only full batches
+    full = list(record_mixture_stream(str(tmp_path), 'train', ['M', 'F'], S, L, 3, no_random_picking=False, drop_remainder=True))
+    assert full and all(b[0].shape[0] == 3 for b in full)
