@@ -612,7 +612,10 @@ def dpcl_loss_fwd_u(U, Y, want_V=False):
     out = torch.empty(4, dtype=torch.float32, device=U.device)
     inv = torch.empty(B, TF, dtype=torch.float32, device=U.device)
     V = torch.empty_like(U) if want_V else None
+    ev = PROFILE.begin() if PROFILE.enabled else None
     check(lib.ams_dpcl_loss_fwd_u(_p(U), _p(Y), _p(inv), _p(V), _p(out), B, TF, E, S, _p(ws), nb, _s()), 'ams_dpcl_loss_fwd_u')
+    if ev is not None:      # algorithmic bytes: read U and Y once, write 1/|u| (+ V when asked)   
+        PROFILE.end(ev, 2.0 * B * TF * (E + S) * (E + S), 4.0 * B * TF * (E + S + 1 + (E if want_V else 0)), 'dpcl_gram_u', 'dpcl')
     return out, inv, V, ws
 
 
@@ -621,8 +624,11 @@ def dpcl_loss_bwd_u(U, Y, inv, ws, upstream=None):
     B, TF, E = U.shape
     S = Y.shape[2]
     d = torch.empty_like(U)
+    ev = PROFILE.begin() if PROFILE.enabled else None
     check(load().ams_dpcl_loss_bwd_u(_p(U), _p(Y), _p(inv), _p(upstream), _p(d), B, TF, E, S, _p(ws), _s()),
           'ams_dpcl_loss_bwd_u')
+    if ev is not None:      # read U, Y, 1/|u|; write dU
+        PROFILE.end(ev, 2.0 * B * TF * (E + S) * E, 4.0 * B * TF * (2 * E + S + 1), 'dpcl_bwd_u', 'dpcl')
     return d
 
 

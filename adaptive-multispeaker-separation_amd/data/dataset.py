@@ -241,13 +241,17 @@ class TFDataset(object):
             try:
                 b = next(it)
             except StopIteration:
-                # length() counted a pass in epoch-0 order; a reshuffled pass can come out a batch short (the distinct-speaker
-                # filter depends on the order).  The reference would die with OutOfRangeError here; wrap into the next pass instead.
+                # End of the pass = tf.errors.OutOfRangeError.  One exception: length() counted a pass in epoch-0 order and a
+                # RESHUFFLED pass can come out a batch short (the distinct-speaker filter depends on the order); the reference
+                # would die mid-epoch there.  While the caller is still inside the counted epoch, continue with the next pass.
+                if self.cursor[split] >= self._lengths.get((split, L), 0):
+                    raise
                 self._epochs[split] = self._epochs.get(split, 0) + 1
                 it = self._iters[split] = iter(self._stream(split, L, self._epochs[split]))
                 b = next(it)
             if k == rank:
                 out = b
+        self.cursor[split] += 1
         return tuple(torch.from_numpy(a).to(self.device) for a in out)
 
     def length(self, split):

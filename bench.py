@@ -32,9 +32,12 @@ HBM_PEAK_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=64, help='mixtures per GPU (weak scaling)')
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch', type=int, default=64, help='mixtures per GPU (weak scaling) / in total (strong scaling)')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help="weak (headline): --batch mixtures per GPU; strong: --batch mixtures in total, split evenly over the ranks "
+                         "(SURVEY 8d: global batch 64)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the cfg3(ii) fine-tuning step timing (N=1 only)')
     ap.add_argument('--cpu-batch', type=int, default=16)
@@ -50,6 +53,12 @@ def parse():
 
 def build(args, tmp):
     os.environ.setdefault('AMS_LOG_DIR', os.path.join(tmp, 'log'))
+    if args.scaling == 'strong':
+        world = int(os.environ.get('WORLD_SIZE', '1'))
+        if args.batch % world:
+            raise SystemExit('--scaling strong: global batch %d is not divisible by %d ranks' % (args.batch, world))
+        args.global_batch = args.batch
+        args.batch = args.batch // world           # per-rank shard of the fixed global batch
     from ams_hip import testing
     from models.dpcl import DPCL
     from utils.trainer import Front_Separator_Trainer
@@ -71,6 +80,18 @@ def build(args, tmp):
     W.data.copy_((torch.rand(W.shape, generator=gen) * 0.1 - 0.05).to(W.device))
     trainer._sync_replicas(dist)
     return trainer, tfds, dist
+
+
+def _newest_profile(suffix):
+    """(parsed JSON, repo-relative path) of the highest-round profiles/rNN<suffix>, or (None, None)."""
+    import glob
+    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]' + suffix)))
+    if not cands:
+        return None, None
+    try:
+        return json.load(open(cands[-1])), os.path.relpath(cands[-1], ROOT)
+    except Exception:
+        return None, None
 
 
 def cpu_baseline(args):
@@ -166,6 +187,7 @@ def main():
     # ---- roofline of the dominant kernel: the fp32 MFMA GEMM family (dense 600->F*E, its two gradients, LSTM projections)
     prof = ops.PROFILE.summary(prefix='gemm')
     roof = None
+    tj = None
     if prof['launches']:
         avg_ms = prof['ms'] / prof['launches']
         flops_per_launch = prof['flops'] / prof['launches']
@@ -177,25 +199,54 @@ def main():
                 'measured': ('HIP events around each launch, %d eager steps after the graph-replayed timed region' % prof_steps)
                 if args.graph else 'HIP events around each launch inside the timed region',
                 'by_variant': {}}
-        # HBM traffic of the same kernels: rocprofv3 PMC passes cannot run inside this process, so the per-launch figure
-        # comes from the committed summary of `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this very workload
-        # (tools/pmc_summary.py; gfx950 x2 read correction applied there).  null for any other shape.
-        tpath = os.path.join(ROOT, 'profiles', 'r01_c_hbm_traffic.json')
-        if os.path.exists(tpath) and (B, L, N) == (64, 20480, 256):
-            tj = json.load(open(tpath))
+        # HBM traffic of the same kernels: rocprofv3 PMC passes cannot run inside this process, so the per-launch figure is CITED
+        # from the newest committed summary of `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this very workload
+        # (tools/pmc_traffic.sh -> tools/pmc_summary.py; gfx950 x2 read correction applied there), tagged with the commit the
+        # counters were collected at.  null for any other shape or when no summary is committed.
+        tj, tfile = _newest_profile('_c_hbm_traffic.json')
+        if tj is not None and (B, L, N) == (64, 20480, 256):
             gk = [v for k, v in tj.items() if k.startswith('gemm_f32_kernel')]
             calls = sum(v['calls'] for v in gk)
             if calls:
                 mb = sum(v['calls'] * (v['read_MB_per_launch'] + v['write_MB_per_launch']) for v in gk) / calls
                 roof['traffic'] = round(mb * 1e6)
-                roof['traffic_unit'] = 'bytes per launch (memory-side L2 requests, profiles/r01_c_hbm_traffic.txt)'
+                roof['traffic_unit'] = 'bytes per launch (memory-side L2 requests)'
+                roof['traffic_source'] = {'file': tfile, 'counted_at_commit': (tj.get('_meta') or {}).get('commit', '1a73b9d')}
                 roof['algorithmic_bytes_per_launch'] = round(prof['bytes'] / prof['launches'])
+        # the same kernels inside the REPLAYED (timed) hipGraph: per-variant averages of a rocprofv3 --kernel-trace pass over
+        # `bench.py --graph 1` (tools/prof_step.sh), cited by file
+        rj, rfile = _newest_profile('_b_replay_kernels.json')
+        if rj is not None and (B, L, N) == (64, 20480, 256):
+            roof['replayed_region'] = {'file': rfile, 'counted_at_commit': (rj.get('_meta') or {}).get('commit'),
+                                       'by_kernel': {k: v for k, v in rj.items() if k != '_meta'}}
         for tag in ops.PROFILE.tags():
+            if not tag.startswith('gemm'):
+                continue
             pv = ops.PROFILE.summary(tag)
             if pv['launches']:
                 roof['by_variant']['gemm_f32_kernel' + tag[4:]] = {
                     'launches_per_step': pv['launches'] / prof_steps, 'avg_launch_us': round(pv['ms'] / pv['launches'] * 1e3, 2),
                     'TFLOP/s': round(pv['flops'] / (pv['ms'] * 1e-3) / 1e12, 2)}
+
+    # ---- second roofline entry: the HBM-bound loss kernels (fused l2norm + DPCL Gram pass, its backward)
+    roof_hbm = None
+    pd = ops.PROFILE.summary(label='dpcl')
+    if pd['launches']:
+        ach = pd['bytes'] / (pd['ms'] * 1e-3) / 1e9
+        roof_hbm = {'bound': 'hbm', 'kernel': 'dpcl_gram_u_kernel + dpcl_bwd_u_kernel', 'achieved': round(ach, 1), 'peak': HBM_PEAK_GBS,
+                    'unit': 'GB/s', 'frac': round(ach / HBM_PEAK_GBS, 4), 'traffic': None, 'by_kernel': {},
+                    'measured': 'HIP events around each launch, same steps as `roofline`'}
+        for tag in ('dpcl_gram_u', 'dpcl_bwd_u'):
+            pv = ops.PROFILE.summary(tag)
+            if pv['launches']:
+                roof_hbm['by_kernel'][tag + '_kernel'] = {
+                    'avg_launch_us': round(pv['ms'] / pv['launches'] * 1e3, 2), 'GB/s': round(pv['bytes'] / (pv['ms'] * 1e-3) / 1e9, 1),
+                    'algorithmic_bytes_per_launch': round(pv['bytes'] / pv['launches'])}
+        if tj is not None and (B, L, N) == (64, 20480, 256):
+            dk = [v for k, v in tj.items() if k.startswith('dpcl_gram_u') or k.startswith('dpcl_bwd_u')]
+            if dk:
+                roof_hbm['traffic'] = round(sum(v['read_MB_per_launch'] + v['write_MB_per_launch'] for v in dk) / len(dk) * 1e6)
+                roof_hbm['traffic_source'] = roof.get('traffic_source') if roof else None
 
     # ---- the two kernels north_star names a target for (same HIP-event records)
     targets = {}
@@ -218,13 +269,13 @@ def main():
     out = {
         'metric': 'mixtures/sec training throughput (2-spk, 256-filter adapt+BLSTM-DPCL)',
         'value': round(value, 2), 'unit': 'mixtures/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-        'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': 'weak',
+        'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': args.scaling,
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': 'front_DPCL training step (SURVEY 8d cfg3(i)): frozen adaptive front W=1024 hop=256 N=%d -> '
                                '3xBLSTM(600) -> dense 600->%d -> l2norm -> DPCL loss, fwd+bwd+AMSGrad' % (N, N * E),
                    'batch_per_gpu': B, 'global_batch': B * world, 'nb_speakers': S, 'chunk_size': L, 'frames': T,
                    'parallelism': 'dp%d' % world, 'hip_graph': bool(args.graph)},
-        'roofline': roof, 'north_star_targets': targets, 'final_cost': last_cost,
+        'roofline': roof, 'roofline_hbm': roof_hbm, 'north_star_targets': targets, 'final_cost': last_cost,
     }
     if rank == 0:
         if world == 1 and not args.no_secondary and (B, L, N) == (64, 20480, 256):

@@ -99,6 +99,22 @@ def front_l41_loss(x_mix, x_non_mix, I, P, hop, nb_layers, E, normalize=True, wa
     return cost, grads, V, Y
 
 
+def stft_l41_loss(x_mix, x_non_mix, I, P, W, hop, nb_layers, E, normalize=True, want_grads=True):
+    """cfg4 STFT_L41 step (trainer.py:468-486 with L41Model): |STFT| magnitudes (network.py:480-502), masks
+    y = one_hot(argmax_s |STFT(x_s)|) with (on, off) = (1, -1) (L41.py:9-10), 3xBLSTM -> Conv1D -> [l2norm], cost L41.py:47-186."""
+    B, S, L = x_non_mix.shape
+    X, X_nm, _ = stft.stft_preprocessing(x_mix, x_non_mix, W, hop)
+    Y, _ = separate.make_masks(X_nm, 1.0, -1.0)
+    V, cache = prediction_fwd(X, P, nb_layers, E, normalize)
+    cost = l41.l41_cost(V, Y, P['speaker_centroids'], I, normalize)
+    if not want_grads:
+        return cost, V, Y
+    dV, dspk = l41.l41_cost_bwd(V, Y, P['speaker_centroids'], I, normalize)
+    grads = prediction_bwd(dV, cache, P, nb_layers)
+    grads['speaker_centroids'] = dspk
+    return cost, grads, V, Y
+
+
 def init_params(rng, dtype, front_W=None, N=None, D_in=None, layer_size=600, nb_layers=3, E=40, F=None,
                 conv1d_scale=None, tot_speakers=None):
     """Random parameters with the reference's shapes/initialisers (ops.py:489-494)."""

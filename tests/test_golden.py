@@ -86,3 +86,48 @@ def test_hip_matches_kmeans_and_stft_goldens():
     assert rel(mag.cpu().numpy(), s['mag']) < 1e-4
     rec = F.istft(mag, ph, 256, 128, 1)
     assert rel(rec.cpu().numpy(), s['rec']) < 1e-4
+
+
+@pytest.mark.gpu
+def test_hip_matches_pretraining_golden():
+    """HIP pre-training step (Adapt_Pretrainer, loss sdr+l2, separation mask, overlap_coef 1.0 -- the README.md:23 recipe) on the
+    inputs and filterbank stored in front_dpcl_step.npz vs pretraining_step.npz: cost, reconstructed waveforms, all 4 gradients."""
+    import os
+    import tempfile
+    import torch
+    from ams_hip import testing, functional as F
+    from utils.trainer import Adapt_Pretrainer
+    os.environ.setdefault('AMS_LOG_DIR', tempfile.mkdtemp(prefix='ams_log_'))
+    d, gp = load('front_dpcl_step.npz'), load('pretraining_step.npz')
+    B, S, L, W, N, hop, LS, NL, E = [int(v) for v in d['cfg']]
+    a = dict(testing.ADAPT_DEFAULTS)
+    a.update(batch_size=B, nb_speakers=S, chunk_size=L, window_size=W, filters=N, hop_size=hop, loss='sdr+l2', separation='mask',
+             overlap_coef=1.0, learning_rate=1e-3, pretraining=True)
+    a.pop('type')
+    tr = Adapt_Pretrainer(**a)
+    dist, tfds = tr.prepare()
+    g, model = tr.graph, tr.model
+    names = ('front/window/w', 'front/bases/bases', 'back/window/value', 'back/bases/value')
+    with g.as_default():
+        for n in names:
+            v = g.variables[n]
+            v.data.copy_(torch.from_numpy(d['P/' + n].astype(np.float32)).to(v.device))
+        feed = {tfds.handle: tfds.get_handle(tfds.TRAIN), tfds.chunk_size: L}
+        run = model._feeds(feed, True)
+        dev = lambda x, dt=np.float32: torch.from_numpy(np.ascontiguousarray(x, dtype=dt)).cuda()       # noqa: E731
+        for node, t in zip((model.x_mix, model.x_non_mix), (dev(d['x_mix']), dev(d['x_non_mix']))):
+            run.cache[id(node)] = t
+        opt = model.optimize
+        opt.zero_grad()
+        cost = model.cost_model.value(run)
+        cost.reshape(-1)[0].backward()
+        F.OVERLAP.join()
+        torch.cuda.synchronize()
+        back = model.back.value(run).detach().cpu().numpy()
+        grads = {v.ams_name: v.grad.detach().cpu().numpy() for v in model.trainable_variables}
+    c = float(cost.detach().reshape(-1)[0])
+    assert abs(c - float(gp['cost'])) < 1e-4 * abs(float(gp['cost'])), (c, float(gp['cost']))
+    assert rel(back.reshape(gp['back'].shape), gp['back']) < 1e-3
+    assert sorted(grads) == sorted(names)
+    for n in names:
+        assert rel(grads[n], gp['G/' + n]) < 1e-3, (n, rel(grads[n], gp['G/' + n]))

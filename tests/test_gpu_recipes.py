@@ -12,6 +12,11 @@ from oracle import step as ostep, recipes as orec, optim as ooptim
 
 os.environ.setdefault('AMS_LOG_DIR', tempfile.mkdtemp(prefix='ams_log_'))
 
+# Separated waveforms vs the float64 oracle, relative L2.  north_star: masks within 1e-3.  Hard k-means labels are bit-exact given
+# the same float32 embeddings (test_gpu_kernels2.py::test_kmeans_hard_bit_exact); here the oracle clusters its OWN float64
+# embeddings, the seeds are injected, and no label flips at these sizes -- so the fp32 pipeline's round-off is all that is left.
+INFER_TOL = 1e-3
+
 
 def rel(a, b):
     b = np.asarray(b, np.float64)
@@ -163,7 +168,7 @@ def test_front_separator_inference(beta, with_silence):
     assert out.shape == (B, S, L)
     # embeddings agree to round-off; a label may flip only at a numerical tie, so compare the waveforms in norm
     err = np.linalg.norm(out.cpu().numpy() - out_ref) / np.linalg.norm(out_ref)
-    assert err < 2e-2, err
+    assert err < INFER_TOL, err
 
 
 def test_stft_separator_inference():
@@ -191,7 +196,7 @@ def test_stft_separator_inference():
                                                        NL, E, idx, tries, steps, end_assign=True)
     assert out.shape == (B, S, (T - 1) * hop + W)
     err = np.linalg.norm(out.cpu().numpy() - out_ref) / np.linalg.norm(out_ref)
-    assert err < 2e-2, err
+    assert err < INFER_TOL, err
 
 
 def test_front_dpcl_finetuning_step():
@@ -423,7 +428,7 @@ def test_front_separator_enhanced_inference():
     out_ref = orec.front_separate_enhanced_infer(xm, xn, P64, hop, NL, E, NLE, idx, tries, steps)
     assert out.shape == (B, S, L)
     err = np.linalg.norm(out - out_ref) / np.linalg.norm(out_ref)
-    assert err < 2e-2, err
+    assert err < INFER_TOL, err
 
 
 def test_stft_separator_enhanced_inference():
@@ -447,7 +452,7 @@ def test_stft_separator_enhanced_inference():
     out_ref = orec.stft_separate_enhanced_infer(xm, xn, P64, W, hop, NL, E, NLE, idx, tries, steps)
     assert out.shape == out_ref.shape == (B, S, (T - 1) * hop + W)
     err = np.linalg.norm(out - out_ref) / np.linalg.norm(out_ref)
-    assert err < 2e-2, err
+    assert err < INFER_TOL, err
 
 
 @pytest.mark.parametrize('separation', ['mask', 'perfect'])
@@ -489,7 +494,7 @@ def test_front_l41_inference_and_finetuning():
     xm, xn, out = _infer(tr, L)
     P64 = {k: v.astype(np.float64) for k, v in P.items()}
     out_ref, _, _ = orec.front_separate_infer(xm, xn, P64, hop, NL, E, idx, tries, steps, beta=beta, with_silence=True, end_assign=True)
-    assert np.linalg.norm(out - out_ref) / np.linalg.norm(out_ref) < 2e-2
+    assert np.linalg.norm(out - out_ref) / np.linalg.norm(out_ref) < INFER_TOL
 
     a.update(loss='sdr+l2', optimizer='RMSProp', learning_rate=1e-4)
     tr = Front_Separator_Finetuning_Trainer(L41Model, 'front_L41_finetuning', **dict(a))

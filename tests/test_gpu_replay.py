@@ -1,0 +1,139 @@
+"""GPU: --hip_graph replay == eager launches for EVERY recipe tools/bench_configs.py replays (front_DPCL and the fine-tuning
+recipe are covered in test_gpu_step.py): pre-training (path A), STFT_L41, STFT_L41_enhance (host-drawn k-means seeds refreshed
+before each replay), front_L41 with S = 3.  Same seeds, same batches, 6 steps: per-step costs and the final weights must agree --
+the graph holds the same kernels in the same order, so only atomics-free round-off identity is expected."""
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+from tests.test_gpu_recipes import base_args
+
+os.environ.setdefault('AMS_LOG_DIR', tempfile.mkdtemp(prefix='ams_log_'))
+STEPS = 6
+
+
+def _run(trainer, tfds, L):
+    g, model = trainer.graph, trainer.model
+    np.random.seed(7)                                          # host-drawn k-means seeds (Kmeans_2.py:61-66) follow the same stream
+    costs = []
+    with g.as_default():
+        feed = {tfds.handle: tfds.get_handle(tfds.TRAIN), tfds.chunk_size: L}
+        tfds.initialize(tfds.TRAIN)
+        for i in range(STEPS):
+            costs.append(float(model.train(feed, i)))
+    torch.cuda.synchronize()
+    return costs, {v.ams_name: v.detach().cpu().numpy().copy() for v in model.trainable_variables}
+
+
+def _compare(make):
+    import utils.ops
+    outs = []
+    for graph in (False, True):
+        utils.ops.rng.seed(42)
+        torch.manual_seed(0)
+        tr, tfds, L = make(graph)
+        outs.append(_run(tr, tfds, L))
+    (c_e, p_e), (c_g, p_g) = outs
+    assert np.all(np.isfinite(c_e)) and np.allclose(c_e, c_g, rtol=1e-5, atol=0), (c_e, c_g)
+    assert len(set(np.round(c_g, 9))) > 2                      # replays are not frozen on one batch
+    for n in p_e:
+        d = np.abs(p_e[n] - p_g[n]).max()
+        assert d <= 1e-6 * max(1.0, np.abs(p_e[n]).max()), (n, d)
+
+
+@pytest.mark.parametrize('loss,separation', [('sdr+l2', 'mask'), ('l2', 'perfect')])
+def test_pretraining_replay_matches_eager(loss, separation):
+    """cfg2 (README.md:23 flags): front -> mask/perfect separator -> back -> sdr+l2 cost, all four filterbank variables train."""
+    from utils.trainer import Adapt_Pretrainer
+
+    def make(graph):
+        B, S, L, W, N, hop = 4, 2, 2048, 64, 16, 16
+        a = base_args(batch_size=B, nb_speakers=S, chunk_size=L, window_size=W, filters=N, hop_size=hop, loss=loss,
+                      separation=separation, beta=0.0, regularization=0.0, overlap_coef=1.0, learning_rate=1e-3, pretraining=True,
+                      hip_graph=graph, no_summaries=True)
+        a.pop('type')
+        tr = Adapt_Pretrainer(**a)
+        dist, tfds = tr.prepare()
+        return tr, tfds, L
+    _compare(make)
+
+
+def test_pretraining_with_sparsity_and_regularisers_replay_matches_eager():
+    """Same recipe with every optional term on (--beta, --regularization, --non_negativity): their scalar glue is captured too."""
+    from utils.trainer import Adapt_Pretrainer
+
+    def make(graph):
+        B, S, L, W, N, hop = 3, 2, 1024, 64, 16, 16
+        a = base_args(batch_size=B, nb_speakers=S, chunk_size=L, window_size=W, filters=N, hop_size=hop, loss='sdr+l2',
+                      separation='mask', beta=0.01, sparsity=0.05, regularization=1e-3, overlap_coef=0.5, learning_rate=1e-3,
+                      pretraining=True, hip_graph=graph, no_summaries=True)
+        a.pop('type')
+        tr = Adapt_Pretrainer(**a)
+        dist, tfds = tr.prepare()
+        return tr, tfds, L
+    _compare(make)
+
+
+def _stft_l41(graph, **kw):
+    from models.L41 import L41Model
+    from utils.trainer import STFT_Separator_Trainer
+    B, S, L, W, hop = 3, 2, 2048, 64, 32
+    a = base_args(batch_size=B, nb_speakers=S, chunk_size=L, window_size=W, hop_size=hop, layer_size=12, nb_layers=2, embedding_size=8,
+                  model_folder=None, learning_rate=1e-3, pretraining=False, tot_speakers=251, hip_graph=graph, no_summaries=True)
+    a.update(kw)
+    for k in ('filters', 'max_pool', 'type'):
+        a.pop(k, None)
+    tr = STFT_Separator_Trainer(L41Model, 'STFT_L41', **dict(a))
+    dist, tfds = tr.prepare()
+    return tr, tfds, L, a
+
+
+def test_stft_l41_replay_matches_eager():
+    _compare(lambda graph: _stft_l41(graph)[:3])
+
+
+def test_stft_l41_enhance_replay_matches_eager():
+    """cfg4's second stage: frozen L41 separator + hard k-means (seeds drawn on the host before every replay) + enhance stack."""
+    from models.L41 import L41Model
+    from utils.trainer import STFT_Separator_enhance_Trainer
+
+    def make(graph):
+        tr0, tfds0, L, a = _stft_l41(False)
+        with tr0.graph.as_default():
+            tr0.model.create_saver()
+            tr0.model.save(0)
+            folder = tr0.model._dir()
+        del tr0
+        a = dict(a)
+        a.update(model_folder=folder, nb_tries=2, nb_steps=3, end_assign=True, nonlinearity='softmax', layer_size_enhance=8,
+                 nb_layers_enhance=2, hip_graph=graph)
+        tr = STFT_Separator_enhance_Trainer(L41Model, 'STFT_L41_enhance', **a)
+        dist, tfds = tr.prepare()
+        return tr, tfds, L
+    _compare(make)
+
+
+def test_front_l41_three_speakers_replay_matches_eager():
+    """cfg5 family: plugged L41 on the frozen front, S = 3."""
+    from ams_hip import testing
+    from models.L41 import L41Model
+    from utils.trainer import Front_Separator_Trainer
+
+    def make(graph):
+        tmp = tempfile.mkdtemp(prefix='ams_rp_')
+        B, S, L, W, N, hop = 3, 3, 1024, 64, 16, 16
+        folder, params = testing.make_pretrained_adapt(os.path.join(tmp, 'pre'), window_size=W, filters=N, hop_size=hop, chunk_size=L,
+                                                       batch_size=B, nb_speakers=S)
+        a = base_args(**params)
+        a.update(layer_size=12, nb_layers=2, embedding_size=8, model_folder=folder, model_previous=None, pretraining=False,
+                 learning_rate=1e-3, tot_speakers=251, hip_graph=graph, no_summaries=True)
+        a.pop('type')
+        tr = Front_Separator_Trainer(L41Model, 'front_L41', **a)
+        dist, tfds = tr.prepare()
+        return tr, tfds, L
+    _compare(make)
