@@ -216,6 +216,9 @@ def make_masks(rep_non_mix, B, S, a, b, take_abs, want_argmax=False):
 # ------------------------------------------------------------------ BLSTM
 import os as _os
 LSTM_PERSIST = _os.environ.get('AMS_LSTM_PERSIST', '0') != '0'     # persistent in-launch recurrence (csrc/lstm_persist.hip)
+# chain-per-XCD ring recurrence (csrc/lstm_ring.hip), the default: 1 = on, 0 = per-step kernels, 'safe' = on with the
+# placement-independent (write-through) hand-off forced
+LSTM_RING = _os.environ.get('AMS_LSTM_RING', '1')
 LAST_SYNC = []                                                      # most recent sync buffers (word 0 = timeout flag)
 
 
@@ -251,7 +254,9 @@ def blstm_fwd(x, Kf, bf, Kb, bb, consumer=None):
     out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
     cst = torch.empty((B, T, 2, H), dtype=torch.float32, device=x.device)
     pack = torch.empty(lib.ams_blstm_pack_floats(H, 0), dtype=torch.float32, device=x.device)
-    bands = _fwd_bands(T) if not (LSTM_PERSIST or pre is not None or consumer is not None) else None
+    ring = LSTM_RING != '0' and not LSTM_PERSIST
+    nring = lib.ams_blstm_ring_sync_bytes(B, H, 0) if ring else 0
+    bands = _fwd_bands(T) if not (LSTM_PERSIST or nring or pre is not None or consumer is not None) else None
     if bands:
         _blstm_fwd_banded(lib, x2, Wcat, bias, G, out, cst, pack, Kf[D:], Kb[D:], ldu, B, T, D, H, bands)
         return out, G, cst
@@ -259,10 +264,17 @@ def blstm_fwd(x, Kf, bf, Kb, bb, consumer=None):
         _finish_precomputed(lib, pre, x2, Wcat, 8 * H, bias, B, T, D, 'blstm_input_gemm')
     else:
         gemm(x2, Wcat, bias=bias, out=G, M=B * T, N=8 * H, K=D, lda=D, ldb=8 * H, ldc=8 * H, label='blstm_input_gemm')
-    cuts = _tail_cuts(consumer[0], T) if (consumer is not None and not LSTM_PERSIST) else None
+    cuts = _tail_cuts(consumer[0], T) if (consumer is not None and not LSTM_PERSIST and not nring) else None
     if cuts:
         check(lib.ams_blstm_pack(_p(Kf[D:]), _p(Kb[D:]), ldu, _p(pack), H, 0, _s()), 'ams_blstm_pack')
         _fwd_steps_feeding(lib, G, out, cst, pack, B, T, H, consumer, cuts)
+        return out, G, cst
+    if nring:
+        sync = _ws(nring, x)
+        check(lib.ams_blstm_ring_fwd(_p(G), _p(out), _p(cst), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring, B, T, H,
+                                     int(LSTM_RING == 'safe'), _s()), 'ams_blstm_ring_fwd')
+        LAST_SYNC.append(sync)
+        del LAST_SYNC[:-8]
         return out, G, cst
     nsync = lib.ams_blstm_persist_sync_bytes(B, H, 0) if LSTM_PERSIST else 0
     if nsync:
@@ -455,6 +467,14 @@ def blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout):
     B, T, D = x.shape
     H = Kf.shape[1] // 4
     ldu = Kf.stride(0)
+    nring = lib.ams_blstm_ring_sync_bytes(B, H, 1) if (LSTM_RING != '0' and not LSTM_PERSIST) else 0
+    if nring:
+        sync = _ws(nring, x)
+        check(lib.ams_blstm_ring_bwd(_p(G), _p(cst), _p(dout), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring, B, T, H,
+                                     int(LSTM_RING == 'safe'), _s()), 'ams_blstm_ring_bwd')
+        LAST_SYNC.append(sync)
+        del LAST_SYNC[:-8]
+        return
     pack = torch.empty(lib.ams_blstm_pack_floats(H, 1), dtype=torch.float32, device=x.device)
     nsync = lib.ams_blstm_persist_sync_bytes(B, H, 1) if LSTM_PERSIST else 0
     if nsync:

@@ -121,6 +121,19 @@ ams_status ams_blstm_persist_fwd(float* G, float* out, float* cst, const float* 
 ams_status ams_blstm_persist_bwd(float* G, const float* cst, const float* dout, const float* Uf, const float* Ub, long ldu, float* pack,
                                  void* sync, size_t sync_bytes, int B, int T, int H, void* stream);
 
+/* Ring form of the same recurrence (csrc/lstm_ring.hip), the default: one launch per layer and pass; a chain = (direction,
+ * 16-row batch tile) is a ring of ceil(H/12) resident workgroups on ONE XCD (verified in-launch through HW_REG_XCC_ID; chains
+ * whose members do not share an L2, or safe != 0, use write-through stores instead of plain ones).  Forward: h_t travels as
+ * 16-byte {3 values, step tag} granules; backward: partial dh tiles (reduce-scatter) + one flag per producer.
+ * ams_blstm_ring_sync_bytes returns 0 when the shape cannot use it (H > 336, or more than 512 workgroups): callers then use
+ * ams_blstm_recurrent_fwd/bwd.  sync word 0 (uint32) is non-zero after the launch if a bounded in-launch wait timed out.
+ * Replaces the same dynamic_rnn while_loop (utils/ops.py:358-383). */
+size_t ams_blstm_ring_sync_bytes(int B, int H, int backward);
+ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, const float* Uf, const float* Ub, long ldu, void* sync, size_t sync_bytes,
+                              int B, int T, int H, int safe, void* stream);
+ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* dout, const float* Uf, const float* Ub, long ldu, void* sync,
+                              size_t sync_bytes, int B, int T, int H, int safe, void* stream);
+
 /* ---- K13  tf.nn.l2_normalize over groups of E       utils/ops.py:323-324 ---- */
 ams_status ams_l2norm_fwd(const float* u, float* v, float* inv, long rows, int E, void* stream);
 ams_status ams_l2norm_bwd(const float* v, const float* inv, const float* dv, float* du, long rows, int E, void* stream);

@@ -42,12 +42,15 @@ def ops():
     return o
 
 
-@pytest.mark.parametrize('D', [600, 256])
-def test_blstm_layer_at_benchmark_shape(ops, D):
+@pytest.mark.parametrize('D,ring', [(600, '1'), (256, '1'), (600, 'safe'), (600, '0')])
+def test_blstm_layer_at_benchmark_shape(ops, monkeypatch, D, ring):
     """One BLSTM layer, B=64, T=80, H=300, D=600 (layers 1-2) / 256 (layer 0): forward and full backward through the DEFAULT
-    step-kernel grid (AMS_LSTM_XCD=2, chain-per-XCD; reference utils/ops.py:358-383)."""
+    recurrence -- 8 chain-per-XCD rings of 25 workgroups (csrc/lstm_ring.hip) -- plus its write-through hand-off and the per-step
+    kernels (AMS_LSTM_XCD=2 grid) it falls back to (reference utils/ops.py:358-383)."""
     import os
     assert os.environ.get('AMS_LSTM_XCD', '2') == '2'
+    monkeypatch.setattr(ops, 'LSTM_RING', ring)
+    assert ops.load().ams_blstm_ring_sync_bytes(B, H, 0) != 0 and ops.load().ams_blstm_ring_sync_bytes(B, H, 1) != 0
     rng = np.random.RandomState(D)
     lim = np.sqrt(6.0 / (D + 5 * H))
     x = rng.randn(B, T, D) * 0.5
@@ -65,6 +68,7 @@ def test_blstm_layer_at_benchmark_shape(ops, D):
     print('blstm bench shape D=%d' % D, errs)
     assert e_fwd < FWD_TOL, errs
     assert max(v for k, v in errs.items() if k != 'out') < BWD_TOL, errs
+    assert ops.persist_errors() == 0
 
 
 def test_dense_l2norm_dpcl_at_benchmark_shape(ops):
@@ -191,3 +195,43 @@ def test_front_dpcl_step_at_benchmark_shape(hip_graph):
     assert errs['cost'] < FWD_TOL, worst
     assert max(v for k, v in errs.items() if k.startswith('grad ')) < BWD_TOL, worst
     assert max(v for k, v in errs.items() if k.startswith('update ')) < 1e-5, worst
+
+
+def test_ring_recurrence_is_bit_stable_under_uneven_load(ops):
+    """The in-launch hand-off of csrc/lstm_ring.hip (plain stores through the chain's L2 + L1-bypassing loads, tags / flags) must
+    not depend on what else the chip is doing: a stale or torn read would change bits.  One BLSTM layer at the benchmark shape,
+    forward + BPTT, 12 times while a second stream keeps the CUs busy with large products (uneven: the load starts and stops at
+    random points of the recurrence) -- every repetition must reproduce the idle run bit for bit, and no bounded wait may time out."""
+    D = 256
+    rng = np.random.RandomState(11)
+    lim = np.sqrt(6.0 / (D + 5 * H))
+    x = dev(rng.randn(B, T, D) * 0.5)
+    Kf, Kb = dev(rng.uniform(-lim, lim, (D + H, 4 * H)) * 2), dev(rng.uniform(-lim, lim, (D + H, 4 * H)) * 2)
+    bf, bb = dev(rng.randn(4 * H) * 0.1), dev(rng.randn(4 * H) * 0.1)
+    dout = dev(rng.randn(B, T, 2 * H) * 0.1)
+    assert ops.LSTM_RING == '1'
+
+    def layer():
+        out, G, cst = ops.blstm_fwd(x, Kf, bf, Kb, bb)
+        grads = ops.blstm_bwd(x, Kf, Kb, out, G, cst, dout)
+        return [out] + list(grads)
+    ref = [t.clone() for t in layer()]
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    a = torch.randn(4096, 2048, device='cuda')
+    bmat = torch.randn(2048, 4096, device='cuda')
+    gen = np.random.RandomState(3)
+    for rep in range(12):
+        n_before, n_during = int(gen.randint(0, 3)), int(gen.randint(1, 6))
+        with torch.cuda.stream(side):
+            for _ in range(n_before):
+                ops.gemm(a, bmat)
+        got = None
+        with torch.cuda.stream(side):
+            for _ in range(n_during):
+                ops.gemm(a, bmat)
+        got = layer()
+        torch.cuda.synchronize()
+        for g, r in zip(got, ref):
+            assert torch.equal(g, r), 'repetition %d differs from the idle run' % rep
+    assert ops.persist_errors() == 0

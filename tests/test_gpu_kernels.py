@@ -107,8 +107,15 @@ def test_make_masks(ops):
         assert np.array_equal(host(Y).reshape(B, T, F, S), Y_ref)
 
 
-@pytest.mark.parametrize('B,T,D,H', [(5, 7, 12, 8), (20, 9, 24, 20), (3, 4, 16, 300), (17, 6, 10, 6)])
-def test_blstm_layer(ops, B, T, D, H):
+@pytest.mark.parametrize('ring', ['1', 'safe', '0'])
+@pytest.mark.parametrize('B,T,D,H', [(5, 7, 12, 8), (20, 9, 24, 20), (3, 4, 16, 300), (17, 6, 10, 6), (33, 12, 8, 37), (4, 5, 6, 336),
+                                       (2, 3, 4, 340)])
+def test_blstm_layer(ops, monkeypatch, B, T, D, H, ring):
+    """ring = '1': chain-per-XCD ring recurrence (csrc/lstm_ring.hip; plain-store hand-off where the chain shares an L2),
+    'safe': the same with the placement-independent write-through hand-off forced, '0': per-step kernels (csrc/lstm.hip).
+    H = 340 exceeds the ring's register-resident weight budget and takes the per-step path in every mode."""
+    monkeypatch.setattr(ops, 'LSTM_RING', ring)
+    assert (ops.load().ams_blstm_ring_sync_bytes(B, H, 0) != 0) == (H <= 336)
     rng = np.random.RandomState(B * T + H)
     lim = np.sqrt(6.0 / (D + 5 * H))
     x = rng.randn(B, T, D)
@@ -124,6 +131,7 @@ def test_blstm_layer(ops, B, T, D, H):
     assert rel(host(dx), dx_ref) < 5 * TOL
     assert rel(host(dKf), dKf_r) < 5 * TOL and rel(host(dKb), dKb_r) < 5 * TOL
     assert rel(host(dbf), dbf_r) < 5 * TOL and rel(host(dbb), dbb_r) < 5 * TOL
+    assert ops.persist_errors() == 0                            # no bounded in-launch wait timed out
 
 
 @pytest.mark.parametrize('B,TF,E,S', [(2, 300, 8, 2), (3, 5000, 40, 2), (2, 2049, 40, 3), (2, 77, 3, 2), (1, 700, 20, 4),
