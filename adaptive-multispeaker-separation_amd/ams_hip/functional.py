@@ -47,14 +47,17 @@ class _Overlap(object):
         # at s_setprio 3.  (Measured history: before the GEMM's operand fetch was made branch-free a capped product was
         # latency-bound at 54 TFLOP/s and the dense dW product paid off at 2 per CU, 9.62 k vs 9.32 k mixtures/s; with the
         # branch-free fetch 1 per CU reaches 72 TFLOP/s alone and wins, 9.85 k vs 9.74 k; without the priority 9.52 k.)
-        # With the ring recurrence (csrc/lstm_ring.hip, default) the BPTT is ONE resident launch that needs no fresh wave slots per
-        # step, so the side products may take 3 workgroups per CU (35 KB pad): 12.6 k -> 13.5 k mixtures/s; uncapped 13.1 k.
+        # With the ring recurrence (csrc/lstm_ring.hip, default) the BPTT is ONE resident, latency-bound launch whose hand-offs queue in
+        # each CU's memory pipeline behind whatever streams there (MI355X_MICROARCH.md, handoff-1to1 by streaming waves): beside an
+        # UNCAPPED dense weight-gradient product the top layer's BPTT took 900 us instead of 240 alone.  2 workgroups per CU (50 KB
+        # pad) for every side product is the measured optimum with the PF=2 GEMM: pad 0 / 20 / 35 / 50 / 70 KB = 13.54 / 13.54 /
+        # 13.29 / 14.02 / 13.66 k mixtures/s (same box, 100 steps); no overlap at all 12.99 k.
         ring = ops.LSTM_RING != '0'
-        pad = int(os.environ.get('AMS_SIDE_LDS_PAD', '35000' if ring else '70000'))
+        pad = int(os.environ.get('AMS_SIDE_LDS_PAD', '50000' if ring else '70000'))
         if kind == 'lstm':
-            pad = int(os.environ.get('AMS_SIDE_LDS_PAD_LSTM', '35000' if ring else '70000'))
+            pad = int(os.environ.get('AMS_SIDE_LDS_PAD_LSTM', '50000' if ring else '70000'))
         if kind == 'lstm_last':
-            pad = int(os.environ.get('AMS_SIDE_LDS_PAD_LAST', '35000' if ring else '40000'))
+            pad = int(os.environ.get('AMS_SIDE_LDS_PAD_LAST', '50000' if ring else '40000'))
         tab = os.environ.get('AMS_SIDE_PADS')           # tuning aid: one pad per capped launch group, in issue order
         if on and tab:
             tab = [int(v) for v in tab.split(',')]

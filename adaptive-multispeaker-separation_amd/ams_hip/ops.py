@@ -251,11 +251,12 @@ def blstm_fwd(x, Kf, bf, Kb, bb, consumer=None):
     # hoisted input projection of BOTH directions as ONE MFMA GEMM [B*T, D] x [D, 8H]: the two [D,4H] halves of the TF
     # kernels are gathered side by side (a 2 x D x 4H copy) so N = 8H gives 19 x 40 = 760 tiles = 2.97 per CU instead of
     # two launches of 400 (1.56 per CU, i.e. 22 % of the CU-time idle).
-    out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
-    cst = torch.empty((B, T, 2, H), dtype=torch.float32, device=x.device)
-    pack = torch.empty(lib.ams_blstm_pack_floats(H, 0), dtype=torch.float32, device=x.device)
     ring = LSTM_RING != '0' and not LSTM_PERSIST
     nring = lib.ams_blstm_ring_sync_bytes(B, H, 0) if ring else 0
+    out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
+    # ring recurrence: plane 0 = c_t (what every backward reads as `cst`), plane 1 = tanh(c_t) for the backward ring
+    cst = torch.empty(((2, B, T, 2, H) if nring else (B, T, 2, H)), dtype=torch.float32, device=x.device)
+    pack = torch.empty(lib.ams_blstm_pack_floats(H, 0), dtype=torch.float32, device=x.device)
     bands = _fwd_bands(T) if not (LSTM_PERSIST or nring or pre is not None or consumer is not None) else None
     if bands:
         _blstm_fwd_banded(lib, x2, Wcat, bias, G, out, cst, pack, Kf[D:], Kb[D:], ldu, B, T, D, H, bands)
@@ -271,7 +272,7 @@ def blstm_fwd(x, Kf, bf, Kb, bb, consumer=None):
         return out, G, cst
     if nring:
         sync = _ws(nring, x)
-        check(lib.ams_blstm_ring_fwd(_p(G), _p(out), _p(cst), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring, B, T, H,
+        check(lib.ams_blstm_ring_fwd(_p(G), _p(out), _p(cst[0]), _p(cst[1]), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring, B, T, H,
                                      int(LSTM_RING == 'safe'), _s()), 'ams_blstm_ring_fwd')
         LAST_SYNC.append(sync)
         del LAST_SYNC[:-8]
@@ -467,10 +468,11 @@ def blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout):
     B, T, D = x.shape
     H = Kf.shape[1] // 4
     ldu = Kf.stride(0)
-    nring = lib.ams_blstm_ring_sync_bytes(B, H, 1) if (LSTM_RING != '0' and not LSTM_PERSIST) else 0
+    # cst with a leading plane axis = written by the forward ring (plane 1 = tanh(c_t)); a 4-D cst came from the step kernels
+    nring = lib.ams_blstm_ring_sync_bytes(B, H, 1) if (LSTM_RING != '0' and not LSTM_PERSIST and cst.dim() == 5) else 0
     if nring:
         sync = _ws(nring, x)
-        check(lib.ams_blstm_ring_bwd(_p(G), _p(cst), _p(dout), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring, B, T, H,
+        check(lib.ams_blstm_ring_bwd(_p(G), _p(cst[0]), _p(cst[1]), _p(dout), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring, B, T, H,
                                      int(LSTM_RING == 'safe'), _s()), 'ams_blstm_ring_bwd')
         LAST_SYNC.append(sync)
         del LAST_SYNC[:-8]

@@ -107,7 +107,10 @@ enum { EPI_STORE = 0, EPI_MAXPOOL = 1 };
 // 567 -> 542 us = 116 TFLOP/s, 1 workgroup/CU 72 -> 92 TFLOP/s) but the whole step does not (9.91-9.95 k vs 9.95-9.96 k
 // mixtures/s: the recurrent step kernels ran 8-10 % slower in the same replay), so the default stays 1.
 #ifndef AMS_GEMM_PF
-#define AMS_GEMM_PF 1
+#define AMS_GEMM_PF 2      // round 2: beside the ring recurrence (csrc/lstm_ring.hip) the deeper prefetch pays in the step too: +5..6 % on every product alone, 13.47 -> 13.58 k mixtures/s
+#endif
+#ifndef AMS_GEMM_FRAG
+#define AMS_GEMM_FRAG 0
 #endif
 template <int AMODE, int BMODE, int EPI = EPI_STORE, int BKT = AMS_GEMM_BK, bool VEC = false, int PF = 1>
 __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g) {
@@ -314,9 +317,28 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
     auto stash = [&](int buf) { stash_s(buf, ra, rb, va, vb); };
 
     const int l31 = lane & 31, lk = lane >> 5;
+    // AMS_GEMM_FRAG: 0 = fragments of one k-pair are read right before its four MFMAs (a wave alone stalls ~LDS latency per pair and
+    // relies on its 4 SIMD neighbours to fill the pipe); 1 = all fragments of the LDS tile first, then BK/2 x 4 MFMAs back to back.
     auto mfma_tile = [&](int buf) {
         const float* as = As + buf * BK * LDA_S + wm * 64 + l31;
         const float* bs = Bs + buf * BK * LDB_S + wn * 64 + l31;
+#if AMS_GEMM_FRAG
+        float fa0[BK / 2], fa1[BK / 2], fb0[BK / 2], fb1[BK / 2];
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            fa0[kk / 2] = as[(kk + lk) * LDA_S];
+            fa1[kk / 2] = as[(kk + lk) * LDA_S + 32];
+            fb0[kk / 2] = bs[(kk + lk) * LDB_S];
+            fb1[kk / 2] = bs[(kk + lk) * LDB_S + 32];
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[kk], fb0[kk], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa0[kk], fb1[kk], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[kk], fb0[kk], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa1[kk], fb1[kk], acc[1][1], 0, 0, 0);
+        }
+#else
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const float a0 = as[(kk + lk) * LDA_S];
@@ -328,6 +350,7 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
             acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
             acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
         }
+#endif
     };
 
     if (nk > 0) {

@@ -32,6 +32,15 @@
 #include "common.h"
 #include <stdlib.h>
 
+// tuning aids (A/B builds through AMS_HIP_LIB): where the backward kernel requests the next step's operands
+//   0 = right behind this step's waits (ahead of the MFMA chain)   1 = behind the flag store (in flight during the next wait)
+#ifndef AMS_RING_FETCH_LATE
+#define AMS_RING_FETCH_LATE 0
+#endif
+#ifndef AMS_RING_FWD_FETCH_LATE
+#define AMS_RING_FWD_FETCH_LATE 0
+#endif
+
 namespace {
 
 typedef int i32x4 __attribute__((ext_vector_type(4)));
@@ -45,13 +54,13 @@ constexpr int IDS_STRIDE = 32;  // per-chain slots in the id / flag tables (NW <
 constexpr unsigned SPIN_LIMIT = 1u << 20;
 
 struct RingArgs {
-    float* G; float* out; float* cst; const float* dout;
+    float* G; float* out; float* cst; float* tch; const float* dout;   // tch [B,T,2,H] = tanh(c_t), written by the forward ring
     const float* Uf; const float* Ub; long ldu;
     unsigned* err;              // word 0 of the sync buffer
     unsigned* ids;              // [n_chains][IDS_STRIDE]   XCC id + 1 of every workgroup (placement agreement)
     unsigned* flags;            // [n_chains][IDS_STRIDE]   backward: last published step + 1
     float* xbuf;                // forward: granules [n_chains][2][TB][NW*4] float4; backward: partial tiles [n_chains][2][NW][NW][UW*TB]
-    int B, T, H, NW, n_chains, force_safe;
+    int B, T, H, NW, n_chains, force_safe, trace;
 };
 
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
@@ -69,6 +78,31 @@ __device__ __forceinline__ void st16(rsrc_t rs, float* base, unsigned byte_off, 
     else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), rs, byte_off, 0, 16);   // write-through
 }
 
+// Gate non-linearities of the ring epilogue: ~1 ulp like libm's, without its branches and special-case paths (the epilogue is on
+// the hand-off cycle: 1300 -> ~800 cycles per step).  e^x = 2^(x log2 e) with the product split as n + r, |r| <= 1/2, r carried
+// with the low word of log2(e) so that v_exp_f32 sees an argument good to ~2^-30; scaling by v_ldexp_f32.  tanh: an odd minimax
+// polynomial (degree 11, max rel. error 1.35e-7) below 0.55, 1 - 2 / (1 + e^{2|x|}) above (abs. error ~1e-7 where tanh > 0.5).
+// NOT __expf: its single-product argument is off by |x| * 2^-24 relative, which the 80-step recurrence amplifies.
+__device__ __forceinline__ float ring_exp(float x) {
+    x = fminf(fmaxf(x, -87.3f), 88.7f);
+    const float n = rintf(x * 1.4426950408889634f);
+    float r = fmaf(x, 1.4426950408889634f, -n);
+    r = fmaf(x, 1.925963033500180e-8f, r);
+    return ldexpf(__builtin_amdgcn_exp2f(r), (int)n);
+}
+__device__ __forceinline__ float ring_sigmoid(float x) { return 1.0f / (1.0f + ring_exp(-x)); }
+__device__ __forceinline__ float ring_tanh(float x) {
+    const float ax = fabsf(x), y = x * x;
+    float p = -0.006332100369036198f;
+    p = fmaf(p, y, 0.02110716514289379f);
+    p = fmaf(p, y, -0.053859058767557144f);
+    p = fmaf(p, y, 0.1333262026309967f);
+    p = fmaf(p, y, -0.33333316445350647f);
+    p = fmaf(p, y, 1.0f);
+    const float big = 1.0f - 2.0f / (1.0f + ring_exp(2.0f * ax));
+    return ax < 0.55f ? x * p : copysignf(big, x);
+}
+
 // returns true when the wait must be abandoned (timeout here, or another ring already gave up)
 __device__ __forceinline__ bool spin_check(unsigned& spins, unsigned* err) {
     ++spins;
@@ -78,6 +112,27 @@ __device__ __forceinline__ bool spin_check(unsigned& spins, unsigned* err) {
     }
     return false;
 }
+
+// Phase anatomy (tools/ring_anatomy.py): when `trace` is set, thread 0 of (chain 0, member 0) accumulates shader-clock cycles per
+// phase into words 8.. of the sync header.  One uniform branch per stamp; off in production launches.
+struct Trace {
+    unsigned long long* out; unsigned long long last; unsigned acc[8]; bool on;
+    __device__ __forceinline__ void begin(unsigned long long* p, bool enable) {
+        out = p; on = enable;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = 0;
+        if (on) last = __builtin_readcyclecounter();
+    }
+    __device__ __forceinline__ void stamp(int slot) {             // slot is a literal: acc[] stays in registers
+        if (on) { const unsigned long long now = __builtin_readcyclecounter(); acc[slot] += (unsigned)(now - last); last = now; }
+    }
+    __device__ __forceinline__ void end() {
+        if (on) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) out[i] = acc[i];
+        }
+    }
+};
 
 // block -> (chain, member); chain c = 8 * cgrp + x lives on ids = x mod 8.  false: surplus block of a partly filled chain group.
 __device__ __forceinline__ bool ring_coords(const RingArgs& a, int& chain, int& w) {
@@ -167,26 +222,39 @@ __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
     const int rowl = lane & 15;
     float c_state = 0.f;
 
-    auto gaddr = [&](int t) { return a.G + (((long)(live ? b : 0) * T + t) * 2 + dir) * (4 * H) + (live ? u : 0); };
-    float zq[4] = {0.f, 0.f, 0.f, 0.f};
-    if (live) {
-        const float* g0 = gaddr(dir ? T - 1 : 0);
+    // per-thread base pointers (time 0) and per-time-step strides, computed once: dead threads alias element (0, 0)
+    const long bl_ = live ? b : 0, ul_ = live ? u : 0;
+    float* const gp = a.G + ((bl_ * T) * 2 + dir) * (4 * H) + ul_;            // + t * 8H + gate * H
+    float* const cp = a.cst + ((bl_ * T) * 2 + dir) * H + ul_;                // + t * 2H
+    float* const tp_ = a.tch + ((bl_ * T) * 2 + dir) * H + ul_;               // + t * 2H
+    float* const op = a.out + (bl_ * T) * (2 * H) + dir * H + ul_;            // + t * 2H
+    const int gst = 8 * H, cst_st = 2 * H;
+    float zq[4];
+    {
+        const float* g0 = gp + (dir ? T - 1 : 0) * gst;
 #pragma unroll
         for (int g = 0; g < 4; ++g) zq[g] = g0[g * H];
     }
 
+    Trace tr;
+    tr.begin(reinterpret_cast<unsigned long long*>(a.err) + 8, a.trace && chain == 0 && w == 0 && tid == 0);
     for (int s = 0; s < T; ++s) {
         const int t = dir ? (T - 1 - s) : s;
         const int par = s & 1;
         f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        if (s > 0) {
+        float zn[4];
+        // Next step's pre-activations are requested AFTER this step's wait has ended and before its MFMA chain: vmcnt retires in
+        // issue order, so a load issued ahead of the poll would put its own (HBM / MALL) latency in front of every poll round.
+        // UNCONDITIONAL loads on clamped addresses (dead threads read element (0, 0), the last step re-reads its own row): a load
+        // inside a branch is waited for at the join (s_waitcnt vmcnt(0) in front of the MFMA chain).
+        {
             float4 hv[NR];
 #pragma unroll
             for (int i = 0; i < NR; ++i) hv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            unsigned spins = 0;
-            const unsigned want = (unsigned)s;                  // h_{s-1} carries tag s
-            const unsigned rbase = (unsigned)(((par ^ 1) * TB + rowl) * NG) * 16u;
-            if (!abort) {
+            if (s > 0 && !abort) {
+                unsigned spins = 0;
+                const unsigned want = (unsigned)s;              // h_{s-1} carries tag s
+                const unsigned rbase = (unsigned)(((par ^ 1) * TB + rowl) * NG) * 16u;
                 for (;;) {
 #pragma unroll
                     for (int i = 0; i < NR; ++i) {
@@ -201,19 +269,31 @@ __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
                     if (spin_check(spins, a.err)) { abort = true; break; }
                 }
             }
+            tr.stamp(0);                                        // wait for h_{s-1}
+#if !AMS_RING_FWD_FETCH_LATE
+            {
+                const float* gn = gp + min(max(dir ? t - 1 : t + 1, 0), T - 1) * gst;
 #pragma unroll
-            for (int i = 0; i < NR; ++i) {
+                for (int g = 0; g < 4; ++g) zn[g] = gn[g * H];
+            }
+#endif
+            if (s > 0) {
 #pragma unroll
-                for (int t3 = 0; t3 < 3; ++t3) acc[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i].x, bw[i][0][t3], acc[t3], 0, 0, 0);
+                for (int i = 0; i < NR; ++i) {
 #pragma unroll
-                for (int t3 = 0; t3 < 3; ++t3) acc[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i].y, bw[i][1][t3], acc[t3], 0, 0, 0);
+                    for (int t3 = 0; t3 < 3; ++t3) acc[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i].x, bw[i][0][t3], acc[t3], 0, 0, 0);
 #pragma unroll
-                for (int t3 = 0; t3 < 3; ++t3) acc[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i].z, bw[i][2][t3], acc[t3], 0, 0, 0);
+                    for (int t3 = 0; t3 < 3; ++t3) acc[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i].y, bw[i][1][t3], acc[t3], 0, 0, 0);
+#pragma unroll
+                    for (int t3 = 0; t3 < 3; ++t3) acc[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i].z, bw[i][2][t3], acc[t3], 0, 0, 0);
+                }
             }
         }
 #pragma unroll
         for (int t3 = 0; t3 < 3; ++t3) *reinterpret_cast<f32x4*>(&red[par][wave][t3][lane][0]) = acc[t3];
+        tr.stamp(1);                                            // MFMA chain + accumulators to LDS
         __syncthreads();
+        tr.stamp(2);                                            // barrier (slowest wave)
 
         float pre[4];
         const float* rp = &red[par][0][0][0][0];
@@ -224,39 +304,56 @@ __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
             for (int wv = 0; wv < 4; ++wv) v += rp[wv * (3 * 64 * 4) + src_off[g]];
             pre[g] = v;
         }
-        const float ig = 1.0f / (1.0f + expf(-pre[0]));
-        const float gg = tanhf(pre[1]);
-        const float fg = 1.0f / (1.0f + expf(-(pre[2] + 1.0f)));     // forget_bias = 1.0
-        const float og = 1.0f / (1.0f + expf(-pre[3]));
+        const float ig = ring_sigmoid(pre[0]);
+        const float gg = ring_tanh(pre[1]);
+        const float fg = ring_sigmoid(pre[2] + 1.0f);                 // forget_bias = 1.0
+        const float og = ring_sigmoid(pre[3]);
         const float c = c_state * fg + ig * gg;
-        const float h = live ? tanhf(c) * og : 0.f;                   // dead rows / units publish zeros
+        const float tc = ring_tanh(c);
+        const float h = live ? tc * og : 0.f;                         // dead rows / units publish zeros
         c_state = c;
         // hand h_s to the ring first: lanes ul = 0, 3, 6, 9 assemble {h[ul], h[ul+1], h[ul+2], tag}
         const float h1 = __shfl_down(h, 1, 64), h2 = __shfl_down(h, 2, 64);
         if (ul < UW && ul % 3 == 0)
             st16(rs, xb, (unsigned)(((par * TB + row) * NG) + w * 4 + ul / 3) * 16u, make_float4(h, h1, h2, __uint_as_float((unsigned)(s + 1))), fast);
+        tr.stamp(3);                                            // gate epilogue up to the granule store
+        // what the backward pass needs -- issued behind the publish: these stores overlap the hand-off's transit (measured: moving
+        // them beside the next MFMA chain instead lengthened the step by 0.26 us)
         if (live) {
-            float* gr = gaddr(t);
+            float* gr = gp + t * gst;
             gr[0 * H] = ig;
             gr[1 * H] = gg;
             gr[2 * H] = fg;
             gr[3 * H] = og;
-            a.cst[(((long)b * T + t) * 2 + dir) * H + u] = c;
-            a.out[((long)b * T + t) * (2 * H) + dir * H + u] = h;
-            if (s + 1 < T) {                                           // next step's pre-activations: in flight during the wait
-                const float* gn = gaddr(dir ? t - 1 : t + 1);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) zq[g] = gn[g * H];
-            }
+            cp[t * cst_st] = c;
+            tp_[t * cst_st] = tc;
+            op[t * cst_st] = h;
         }
+#if AMS_RING_FWD_FETCH_LATE
+        {
+            const float* gn = gp + min(max(dir ? t - 1 : t + 1, 0), T - 1) * gst;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) zn[g] = gn[g * H];
+        }
+#endif
+#pragma unroll
+        for (int g = 0; g < 4; ++g) zq[g] = zn[g];
+        tr.stamp(4);                                            // G / cst / tanh(c) / out stores
     }
+    tr.end();
 }
 
 // ----------------------------------------------------------------------------------------------------- backward
 // NI = ceil(NT / 4) output-tile rounds per wave (compile-time, as NR above); NP = 4 * ceil(NW / 4) partial tiles summed per element.
-template <int NI, int NP>
+// Partial tiles are read with 16-byte loads: a dword load costs the CU's address unit the same 16 cycles per wave-instruction as
+// a dwordx4 one, and 28 of them per thread (112 per workgroup and step) were ~1800 cycles of the step.  Thread (group g, slot n,
+// row quad i), g < PG = 5, reads producers g, g + 5, ... (NPG = ceil(NW / 5) float4 loads), the PG group sums meet in LDS and are
+// added in group order -- a fixed order, so the result is deterministic.
+constexpr int PG = 5;
+template <int NI, int NPG>
 __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
     __shared__ __attribute__((aligned(16))) float lds_a[TB][4 * UW + 1];    // da of this workgroup: [row][gate * 12 + local unit]
+    __shared__ __attribute__((aligned(16))) float psum[PG][UW * TB];         // partial dh sums of the PG producer groups
     __shared__ int lds_flag;
     int chain, w;
     if (!ring_coords(a, chain, w)) return;
@@ -289,22 +386,43 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
     const size_t tile_f = (size_t)UW * TB;                      // floats per partial tile
     float* pb = a.xbuf + (size_t)chain * 2 * NW * NW * tile_f;
     const rsrc_t rs = make_rsrc(pb, (unsigned)((size_t)2 * NW * NW * tile_f * 4));
+    // where this lane's column of output tile (wave + 4 i) goes: consumer = unit / 12, slot = unit % 12 (computed once)
+    int toff[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int unit = (wave + 4 * i) * 16 + n16;
+        toff[i] = (unit < NW * UW) ? (int)((((size_t)(unit / UW) * NW + w) * tile_f + (unit % UW) * TB + 4 * q) * 4u) : -1;
+    }
     unsigned* fl = a.flags + chain * IDS_STRIDE;
     const rsrc_t rf = make_rsrc(fl, IDS_STRIDE * 4);
     float dc_state = 0.f;
 
-    auto gaddr = [&](int t) { return a.G + (((long)(live ? b : 0) * T + t) * 2 + dir) * (4 * H) + (live ? u : 0); };
-    float dh = 0.f, ig = 0.f, gg = 0.f, fg = 0.f, og = 0.f, c = 0.f, c_prev = 0.f;
-    auto fetch = [&](int t) {
-        const int tp = dir ? t + 1 : t - 1;
-        dh = a.dout[((long)b * T + t) * (2 * H) + dir * H + u];
-        const float* gr = gaddr(t);
-        ig = gr[0 * H]; gg = gr[1 * H]; fg = gr[2 * H]; og = gr[3 * H];
-        c = a.cst[(((long)b * T + t) * 2 + dir) * H + u];
-        c_prev = (tp >= 0 && tp < T) ? a.cst[(((long)b * T + tp) * 2 + dir) * H + u] : 0.f;
+    // per-thread base pointers (time 0) and per-time-step strides; dead threads alias element (0, 0)
+    const long bl_ = live ? b : 0, ul_ = live ? u : 0;
+    float* const gp = a.G + ((bl_ * T) * 2 + dir) * (4 * H) + ul_;            // + t * 8H + gate * H
+    const float* const cp = a.cst + ((bl_ * T) * 2 + dir) * H + ul_;          // + t * 2H
+    const float* const tp_ = a.tch + ((bl_ * T) * 2 + dir) * H + ul_;         // + t * 2H
+    const float* const dp = a.dout + (bl_ * T) * (2 * H) + dir * H + ul_;     // + t * 2H
+    const int gst = 8 * H, cst_st = 2 * H;
+    struct Ops { float dh, ig, gg, fg, og, tc, c_prev; };
+    // unconditional loads on clamped addresses (see the forward kernel): out-of-range times read their nearest valid neighbour,
+    // validity is applied to the VALUES afterwards.  tanh(c_t) comes from the forward ring (tch), not from libm again.
+    auto fetch = [&](int t_raw) {
+        Ops o;
+        const int t = min(max(t_raw, 0), T - 1);
+        const int tp = dir ? t + 1 : t - 1, tpc = min(max(tp, 0), T - 1);
+        o.dh = dp[t * cst_st];
+        const float* gr = gp + t * gst;
+        o.ig = gr[0 * H]; o.gg = gr[1 * H]; o.fg = gr[2 * H]; o.og = gr[3 * H];
+        o.tc = tp_[t * cst_st];
+        // x 0/1, not a select: hipcc sinks a load that only one side of a (uniform) branch uses INTO that branch and waits there
+        o.c_prev = cp[tpc * cst_st] * ((tp >= 0 && tp < T) ? 1.0f : 0.0f);
+        return o;
     };
-    if (live) fetch(dir ? 0 : T - 1);
+    Ops cur = fetch(dir ? 0 : T - 1);
 
+    Trace tr;
+    tr.begin(reinterpret_cast<unsigned long long*>(a.err) + 8, a.trace && chain == 0 && w == 0 && tid == 0);
     for (int s = 0; s < T; ++s) {
         const int t = dir ? s : (T - 1 - s);
         const int par = s & 1;
@@ -316,17 +434,37 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
                 if (spin_check(spins, a.err)) { abort = true; break; }
             }
         }
-        float part[NP];
+        tr.stamp(0);                                            // flag wait
+        float dh = cur.dh;
+        const float ig = cur.ig, gg = cur.gg, fg = cur.fg, og = cur.og, tc = cur.tc, c_prev = cur.c_prev;
         if (s > 0) {
-            const unsigned base = (unsigned)((((size_t)(par ^ 1) * NW + w) * NW) * tile_f + (nl < UW ? nl : 0) * TB + r) * 4u;
+            // thread -> (group pg, float4 index f4 = slot * 4 + row quad); 240 of 256 threads take part
+            const int pg = tid / 48, f4 = tid - pg * 48;
+            if (pg < PG) {
+                const unsigned base = (unsigned)((((size_t)(par ^ 1) * NW + w) * NW) * tile_f + f4 * 4) * 4u;
+                float4 pv[NPG];
 #pragma unroll
-            for (int p = 0; p < NP; ++p) part[p] = ld4_l2(rs, base + (unsigned)(min(p, NW - 1) * tile_f) * 4u);
-            __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < NPG; ++k) pv[k] = ld16_l2(rs, base + (unsigned)(min(pg + PG * k, NW - 1) * tile_f) * 4u);
+                __builtin_amdgcn_sched_barrier(0);
+                float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
-                if (p < NW) dh += part[p];                       // scalar (uniform) test; fixed order: deterministic
+                for (int k = 0; k < NPG; ++k) {
+                    const float m = (pg + PG * k < NW) ? 1.0f : 0.0f;          // clamped duplicates count as zero
+                    sum.x += pv[k].x * m; sum.y += pv[k].y * m; sum.z += pv[k].z * m; sum.w += pv[k].w * m;
+                }
+                *reinterpret_cast<float4*>(&psum[pg][f4 * 4]) = sum;
+            }
+            __syncthreads();
+            const int e = (nl < UW ? nl : 0) * TB + r;
+#pragma unroll
+            for (int g = 0; g < PG; ++g) dh += psum[g][e];
         }
-        const float tc = tanhf(c);
+        tr.stamp(1);                                            // partial tiles loaded + summed
+        // next step's operands: requested now (after this step's waits, ~2000 cycles of MFMA work ahead), not behind the publish --
+        // vmcnt retires in issue order, so loads issued ahead of the next poll would put their HBM latency in front of it
+#if !AMS_RING_FETCH_LATE
+        const Ops nxt = fetch(dir ? t + 1 : t - 1);
+#endif
         const float d_o = dh * tc;
         const float dcv = dc_state + dh * og * (1.0f - tc * tc);
         const float da0 = live ? dcv * gg * ig * (1.0f - ig) : 0.f;
@@ -340,32 +478,32 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
             lds_a[r][2 * UW + nl] = da2;
             lds_a[r][3 * UW + nl] = da3;
         }
+        tr.stamp(2);                                            // gate derivative math + LDS write
         __syncthreads();
+        tr.stamp(3);                                            // barrier
         if (s + 1 < T) {
-            // partial dh_{next} = da_own [16 x 48] . U^T slice [48 x NT*16]
+            // partial dh_{next} = da_own [16 x 48] . U^T slice [48 x NT*16]; the 12 A fragments of this lane first, ONE wait
+            float av[UW];
+            const float* arow = &lds_a[lane & 15][q];
+#pragma unroll
+            for (int kk = 0; kk < UW; ++kk) av[kk] = arow[4 * kk];
             f32x4 acc[NI];
 #pragma unroll
             for (int i = 0; i < NI; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            const float* arow = &lds_a[lane & 15][q];
 #pragma unroll
             for (int kk = 0; kk < UW; ++kk) {
-                const float av = arow[4 * kk];
 #pragma unroll
-                for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bw[i][kk], acc[i], 0, 0, 0);
+                for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bw[i][kk], acc[i], 0, 0, 0);
             }
             // tile column n16 of output tile tl = unit tl*16 + n16 -> consumer unit / 12, slot unit % 12; rows 4q..4q+3 contiguous
+            const unsigned pbase = (unsigned)((size_t)par * NW * NW * tile_f * 4u);
 #pragma unroll
-            for (int i = 0; i < NI; ++i) {
-                const int unit = (wave + 4 * i) * 16 + n16;
-                if (unit < NW * UW) {
-                    const int cw = unit / UW, slot = unit % UW;
-                    const unsigned off = (unsigned)((((size_t)par * NW + cw) * NW + w) * tile_f + slot * TB + 4 * q) * 4u;
-                    st16(rs, pb, off, make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]), fast);
-                }
-            }
+            for (int i = 0; i < NI; ++i)
+                if (toff[i] >= 0) st16(rs, pb, pbase + (unsigned)toff[i], make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]), fast);
+            tr.stamp(4);                                        // MFMA chain + tile stores issued
         }
         if (live) {
-            float* gr = gaddr(t);
+            float* gr = gp + t * gst;
             gr[0 * H] = da0;
             gr[1 * H] = da1;
             gr[2 * H] = da2;
@@ -373,14 +511,21 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
         }
         if (s + 1 < T) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every tile of this wave has reached the L2 (or memory, write-through)
+            tr.stamp(5);                                        // store drain (also covers the prefetched operands)
             __syncthreads();                                    // ... of every wave; also: lds_a may be rewritten from here on
+            tr.stamp(6);                                        // barrier
             if (tid == 0) {
                 if (fast) fl[w] = (unsigned)(s + 1);
                 else __hip_atomic_store(fl + w, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
-            if (live) fetch(dir ? t + 1 : t - 1);               // next step's operands: in flight during the wait
         }
+#if AMS_RING_FETCH_LATE
+        const Ops nxt = fetch(dir ? t + 1 : t - 1);
+#endif
+        cur = nxt;
+        tr.stamp(7);                                            // flag store
     }
+    tr.end();
 }
 
 inline bool ring_shape(int B, int H, int& NW, int& n_chains) {
@@ -420,10 +565,11 @@ size_t ams_blstm_ring_sync_bytes(int B, int H, int backward) {
 }
 
 // Same contract as ams_blstm_recurrent_fwd (G: pre-activations in, activated gates out; out; cst), plus `sync`
-// (ams_blstm_ring_sync_bytes(B, H, 0) bytes, word 0 = timeout flag).  safe != 0 forces the placement-independent hand-off.
-ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, const float* Uf, const float* Ub, long ldu, void* sync, size_t sync_bytes,
-                              int B, int T, int H, int safe, void* stream) {
-    AMS_REQUIRE(G && out && cst && Uf && Ub && sync && B > 0 && T > 0 && H > 0);
+// (ams_blstm_ring_sync_bytes(B, H, 0) bytes, word 0 = timeout flag) and `tch` [B,T,2,H] = tanh(c_t), which the backward ring reads
+// instead of calling tanhf again.  safe bit 0 forces the placement-independent hand-off, bit 1 turns the phase trace on.
+ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, const float* Uf, const float* Ub, long ldu, void* sync,
+                              size_t sync_bytes, int B, int T, int H, int safe, void* stream) {
+    AMS_REQUIRE(G && out && cst && tch && Uf && Ub && sync && B > 0 && T > 0 && H > 0);
     int NW, n_chains;
     AMS_REQUIRE(ring_shape(B, H, NW, n_chains));
     const RingLayout L = ring_layout(NW, n_chains, 0);
@@ -431,10 +577,10 @@ ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, const float* Uf,
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(sync, 0, L.head, st) != hipSuccess) return AMS_E_LAUNCH_FAILED;
     RingArgs a{};
-    a.G = G; a.out = out; a.cst = cst; a.Uf = Uf; a.Ub = Ub; a.ldu = ldu;
+    a.G = G; a.out = out; a.cst = cst; a.tch = tch; a.Uf = Uf; a.Ub = Ub; a.ldu = ldu;
     a.err = (unsigned*)sync; a.ids = (unsigned*)((char*)sync + L.ids); a.flags = (unsigned*)((char*)sync + L.flags);
     a.xbuf = (float*)((char*)sync + L.x);
-    a.B = B; a.T = T; a.H = H; a.NW = NW; a.n_chains = n_chains; a.force_safe = (safe || ring_force_safe()) ? 1 : 0;
+    a.B = B; a.T = T; a.H = H; a.NW = NW; a.n_chains = n_chains; a.force_safe = ((safe & 1) || ring_force_safe()) ? 1 : 0; a.trace = (safe & 2) ? 1 : 0;
     const dim3 grid(8 * NW * ceil_div(n_chains, 8));
     switch (ceil_div(NW, 4)) {
         case 1: hipLaunchKernelGGL(lstm_ring_fwd_kernel<1>, grid, dim3(256), 0, st, a); break;
@@ -449,9 +595,9 @@ ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, const float* Uf,
 }
 
 // Same contract as ams_blstm_recurrent_bwd (on return G holds da), without the dc workspace (the running dc lives in registers).
-ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* dout, const float* Uf, const float* Ub, long ldu, void* sync,
-                              size_t sync_bytes, int B, int T, int H, int safe, void* stream) {
-    AMS_REQUIRE(G && cst && dout && Uf && Ub && sync && B > 0 && T > 0 && H > 0);
+ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* tch, const float* dout, const float* Uf, const float* Ub, long ldu,
+                              void* sync, size_t sync_bytes, int B, int T, int H, int safe, void* stream) {
+    AMS_REQUIRE(G && cst && tch && dout && Uf && Ub && sync && B > 0 && T > 0 && H > 0);
     int NW, n_chains;
     AMS_REQUIRE(ring_shape(B, H, NW, n_chains));
     const RingLayout L = ring_layout(NW, n_chains, 1);
@@ -459,19 +605,20 @@ ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* dout, con
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(sync, 0, L.head, st) != hipSuccess) return AMS_E_LAUNCH_FAILED;
     RingArgs a{};
-    a.G = G; a.cst = const_cast<float*>(cst); a.dout = dout; a.Uf = Uf; a.Ub = Ub; a.ldu = ldu;
+    a.G = G; a.cst = const_cast<float*>(cst); a.tch = const_cast<float*>(tch); a.dout = dout; a.Uf = Uf; a.Ub = Ub; a.ldu = ldu;
     a.err = (unsigned*)sync; a.ids = (unsigned*)((char*)sync + L.ids); a.flags = (unsigned*)((char*)sync + L.flags);
     a.xbuf = (float*)((char*)sync + L.x);
-    a.B = B; a.T = T; a.H = H; a.NW = NW; a.n_chains = n_chains; a.force_safe = (safe || ring_force_safe()) ? 1 : 0;
+    a.B = B; a.T = T; a.H = H; a.NW = NW; a.n_chains = n_chains; a.force_safe = ((safe & 1) || ring_force_safe()) ? 1 : 0; a.trace = (safe & 2) ? 1 : 0;
     const dim3 grid(8 * NW * ceil_div(n_chains, 8));
-    // NW = 1..28 -> NT = ceil(12 NW / 16) = 1..21 -> NI = ceil(NT / 4) = 1..6; partials summed: NP = 4 * ceil(NW / 4) >= NW
+    // NW = 1..28 -> NT = ceil(12 NW / 16) = 1..21 -> NI = ceil(NT / 4) = 1..6; producers per group: NPG = ceil(NW / 5) = 1..6
     const int NI = ceil_div(ceil_div(NW * UW, 16), 4);
-    if (NW <= 4)       hipLaunchKernelGGL((lstm_ring_bwd_kernel<1, 4>), grid, dim3(256), 0, st, a);       // NT <= 3
-    else if (NI <= 2)  hipLaunchKernelGGL((lstm_ring_bwd_kernel<2, 12>), grid, dim3(256), 0, st, a);      // NW <= 10
-    else if (NI <= 3)  hipLaunchKernelGGL((lstm_ring_bwd_kernel<3, 16>), grid, dim3(256), 0, st, a);      // NW <= 16
-    else if (NI <= 4)  hipLaunchKernelGGL((lstm_ring_bwd_kernel<4, 24>), grid, dim3(256), 0, st, a);      // NW <= 21
-    else if (NI <= 5)  hipLaunchKernelGGL((lstm_ring_bwd_kernel<5, 28>), grid, dim3(256), 0, st, a);      // NW <= 26
-    else               hipLaunchKernelGGL((lstm_ring_bwd_kernel<6, 28>), grid, dim3(256), 0, st, a);      // NW <= 28
+    if (NW <= 5)       hipLaunchKernelGGL((lstm_ring_bwd_kernel<1, 1>), grid, dim3(256), 0, st, a);       // NT <= 4
+    else if (NW <= 10) hipLaunchKernelGGL((lstm_ring_bwd_kernel<2, 2>), grid, dim3(256), 0, st, a);       // NT <= 8
+    else if (NW <= 15) hipLaunchKernelGGL((lstm_ring_bwd_kernel<3, 3>), grid, dim3(256), 0, st, a);       // NT <= 12
+    else if (NW <= 20) hipLaunchKernelGGL((lstm_ring_bwd_kernel<4, 4>), grid, dim3(256), 0, st, a);       // NT <= 15
+    else if (NW <= 25) hipLaunchKernelGGL((lstm_ring_bwd_kernel<5, 5>), grid, dim3(256), 0, st, a);       // NT <= 19
+    else               hipLaunchKernelGGL((lstm_ring_bwd_kernel<6, 6>), grid, dim3(256), 0, st, a);       // NT <= 21
+    (void)NI;
     return ams_check_launch();
 }
 

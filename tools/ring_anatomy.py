@@ -1,0 +1,46 @@
+"""Cycle anatomy of one ring-recurrence workgroup (csrc/lstm_ring.hip, trace bit of the `safe` argument): shader cycles per phase
+and step, thread 0 of (chain 0, member 0), benchmark shape B=64 T=80 H=300.   python tools/ring_anatomy.py"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _p in (ROOT, os.path.join(ROOT, 'adaptive-multispeaker-separation_amd')):
+    sys.path.insert(0, _p)
+import numpy as np
+import torch
+from ams_hip import ops
+
+B, T, D, H = 64, 80, 600, 300
+rng = np.random.RandomState(0)
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()      # noqa: E731
+lim = np.sqrt(6.0 / (D + 5 * H))
+x = dev(rng.randn(B, T, D) * 0.5)
+Kf, Kb = dev(rng.uniform(-lim, lim, (D + H, 4 * H)) * 2), dev(rng.uniform(-lim, lim, (D + H, 4 * H)) * 2)
+bf, bb, dout = dev(rng.randn(4 * H) * 0.1), dev(rng.randn(4 * H) * 0.1), dev(rng.randn(B, T, 2 * H) * 0.1)
+lib = ops.load()
+out, G, cst = ops.blstm_fwd(x, Kf, bf, Kb, bb)
+G0 = G.clone()
+Gz = torch.empty_like(G)
+ops.gemm(x.view(B * T, D), ops.blstm_wcat(Kf, Kb, D), bias=torch.cat([bf, bb]), out=Gz, M=B * T, N=8 * H, K=D, lda=D, ldb=8 * H, ldc=8 * H)
+ldu = Kf.stride(0)
+p = lambda t: t.data_ptr()                                                                  # noqa: E731
+st = torch.cuda.current_stream().cuda_stream
+names = {'fwd': ['wait for h', 'MFMA + acc to LDS', 'barrier', 'gate epilogue + granule store', 'G/cst/out stores'],
+         'bwd': ['flag wait', 'partial tiles load + sum', 'gate math + LDS write', 'barrier', 'MFMA + tile stores', 'store drain', 'barrier',
+                 'flag store']}
+for mode, safe in (('plain stores (same L2)', 2), ('write-through', 3)):
+    for kind in ('fwd', 'bwd'):
+        n = lib.ams_blstm_ring_sync_bytes(B, H, int(kind == 'bwd'))
+        sync = torch.zeros(n // 4 + 1, dtype=torch.float32, device='cuda')
+        G.copy_(Gz if kind == 'fwd' else G0)
+        torch.cuda.synchronize()
+        if kind == 'fwd':
+            ops.check(lib.ams_blstm_ring_fwd(p(G), p(out), p(cst[0]), p(cst[1]), p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, B, T, H, safe, st), 'f')
+        else:
+            ops.check(lib.ams_blstm_ring_bwd(p(G), p(cst[0]), p(cst[1]), p(dout), p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, B, T, H, safe, st), 'b')
+        torch.cuda.synchronize()
+        w = sync[:64].view(torch.int64).cpu().numpy()
+        ph = w[8:8 + len(names[kind])] / float(T)
+        print('%s, %s: %.0f cycles per step' % (kind, mode, ph.sum()))
+        for nm, v in zip(names[kind], ph):
+            print('    %-34s %7.0f' % (nm, v))
