@@ -22,6 +22,20 @@ namespace {
 
 thread_local int t_gemm_lds_pad = 0;
 
+// Tuning overrides (A/B runs only): read from the environment ONCE per process, never on the launch path.
+struct GemmTuning { int group_m, splits; bool noprio, novec; };
+inline const GemmTuning& tuning() {
+    static const GemmTuning t = [] {
+        GemmTuning v{0, 0, false, false};
+        if (const char* f = getenv("AMS_GEMM_GROUP_M")) v.group_m = atoi(f);
+        if (const char* f = getenv("AMS_GEMM_SPLITS")) v.splits = atoi(f);
+        v.noprio = getenv("AMS_GEMM_NOPRIO") != nullptr;
+        v.novec = getenv("AMS_GEMM_NOVEC") != nullptr;
+        return v;
+    }();
+    return t;
+}
+
 #ifndef AMS_GEMM_BK
 #define AMS_GEMM_BK 8
 #endif
@@ -492,7 +506,7 @@ inline int choose_group_m(int tiles_m, int tiles_n) {
     if (gm > tiles_m) gm = tiles_m;
     if (ceil_div(c, gm) > tiles_n) gm = ceil_div(c, tiles_n);
     if (gm > tiles_m) gm = tiles_m;
-    if (const char* f = getenv("AMS_GEMM_GROUP_M")) { const int v = atoi(f); if (v > 0) gm = v; }   // tuning aid
+    if (tuning().group_m > 0) gm = tuning().group_m;
     return gm;
 }
 
@@ -503,7 +517,7 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
     int splits = 1;
     if (ws) {
         splits = choose_splits(g.M, g.N, g.K, nbatch);
-        if (const char* f = getenv("AMS_GEMM_SPLITS")) { const int v = atoi(f); if (v > 0) splits = v; }   // tuning aid
+        if (tuning().splits > 0) splits = tuning().splits;
         while (splits > 1 && (size_t)nbatch * splits * g.M * g.N * sizeof(float) > ws_bytes) --splits;
     }
     int kps = ceil_div(g.K, splits);
@@ -513,7 +527,7 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
     g.k_per_split = kps;
     g.partial = (float*)ws;
     dim3 grid(tiles, splits, nbatch);
-    static const bool prio_off = getenv("AMS_GEMM_NOPRIO") != nullptr;                                 // tuning aid
+    const bool prio_off = tuning().noprio;
     g.hiprio = (t_gemm_lds_pad == 0 && !prio_off) ? 1 : 0;
     // Occupancy cap for launches that are meant to run BESIDE latency-critical kernels (weight-gradient products on
     // the side stream): unused dynamic LDS limits how many of these workgroups a CU admits, leaving registers/slots
@@ -527,7 +541,7 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
         }
     }
     constexpr bool AKc = (AMODE == A_ROW), BKcc = (BMODE == B_COL);
-    static const bool vec_off = getenv("AMS_GEMM_NOVEC") != nullptr;                                   // tuning aid
+    const bool vec_off = tuning().novec;
     const bool vec = g.a_vec && g.b_vec && !vec_off &&
                      (AMODE == A_FRAMES ? (g.K % 4 == 0 && g.fr_L >= 4) : AMODE == A_FRAMES_T ? (g.M % 4 == 0 && g.fr_L >= 4) :
                       AKc ? (g.K % 4 == 0 && g.K >= 4) : (g.M % 4 == 0 && g.M >= 4)) &&
@@ -568,7 +582,7 @@ void ams_gemm_set_lds_pad(int bytes) { t_gemm_lds_pad = bytes < 0 ? 0 : bytes; }
 size_t ams_gemm_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;
     int splits = choose_splits(M, N, K);
-    if (const char* f = getenv("AMS_GEMM_SPLITS")) { const int v = atoi(f); if (v > 0) splits = v; }
+    if (tuning().splits > 0) splits = tuning().splits;
     if (splits <= 1) return 0;
     return (size_t)splits * M * N * sizeof(float);
 }
@@ -596,7 +610,7 @@ ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float
 size_t ams_gemm_batched_workspace_bytes(int M, int N, int K, int nbatch) {
     if (M <= 0 || N <= 0 || K <= 0 || nbatch <= 0) return 0;
     int splits = choose_splits(M, N, K, nbatch);
-    if (const char* f = getenv("AMS_GEMM_SPLITS")) { const int v = atoi(f); if (v > 0) splits = v; }
+    if (tuning().splits > 0) splits = tuning().splits;
     if (splits <= 1) return 0;
     return (size_t)nbatch * splits * M * N * sizeof(float);
 }
@@ -909,7 +923,7 @@ ams_status ams_front_maxpool_fwd(const float* x, const float* f, float* y, long 
         g.group_m = 1;
         const size_t base = (ams_front_maxpool_workspace_bytes(Bt, L, N) + 15) / 16 * 16;
         const int Lp = maxpool_padded_len(L, W);
-        if (g.b_vec && W % 4 == 0 && ws_bytes >= base + (size_t)Bt * Lp * sizeof(float) && !getenv("AMS_GEMM_NOVEC")) {
+        if (g.b_vec && W % 4 == 0 && ws_bytes >= base + (size_t)Bt * Lp * sizeof(float) && !tuning().novec) {
             // stride-1 frames are not 16-byte aligned and would straddle the zero padding: run the product on a padded copy,
             // where every 4-tap fetch is one unconditional (dword-aligned) 16-byte load
             float* xp = (float*)((char*)ws + base);

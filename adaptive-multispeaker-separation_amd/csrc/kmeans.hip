@@ -62,6 +62,7 @@ struct KmArgs {
     int b, tries, G;
     int w_mod_b;           // 1: weight row = r % b (reference tile quirk), 0: r / tries
     float beta;
+    float one;             // 1.0f, opaque to the compiler (see the HARD modes of kmeans_pass_kernel)
 };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -69,8 +70,10 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // HAS_W: silence weights present.  Without them the reference multiplies by w = 1 (x*1 == x exactly), so the multiplies are
 // dropped.  Element-wise work is written on 2-vectors (v_pk_mul_f32 / v_pk_add_f32: IEEE per component, no FMA) while every
 // running sum keeps its left-to-right scalar order, so the result is bit-identical to the scalar formulation.
+// __launch_bounds__(256, 3): at least 3 waves per SIMD, i.e. <= 168 VGPRs -- without the bound hipcc settles at 222-256 registers
+// (2 waves, or 1) by hoisting the slab's LDS reads and the centroids into registers.
 template <int E_, int C_, int MODE, bool HAS_W>
-__global__ __launch_bounds__(256) void kmeans_pass_kernel(KmArgs a) {
+__global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? 3 : 1) void kmeans_pass_kernel(KmArgs a) {
     static_assert(E_ % 4 == 0, "rows are staged as 16-byte vectors");
     constexpr bool ACC = (MODE == HARD_ACC || MODE == SOFT_ACC);
     constexpr bool SOFT = (MODE == SOFT_ACC || MODE == SOFT_FINAL);
@@ -127,29 +130,68 @@ __global__ __launch_bounds__(256) void kmeans_pass_kernel(KmArgs a) {
         __builtin_amdgcn_wave_barrier();
         if (PF && j + 1 < PPL) fetch(j + 1);
         if (tid < npts) {
-            float x[E_];
+            // HARD modes: the point is NOT held in registers (40 VGPRs): it is re-read from this wave's LDS rows as 16-byte vectors
+            // (conflict-free at the LD = E + 4 pitch) once for the distances and once for the accumulation -- with the 82
+            // accumulators and the 40 prefetch registers that is what keeps the kernel under 168 VGPRs = 3 waves per SIMD
+            // (it ran at 236 VGPRs / 2 waves with ~44 % of the wave cycles waiting).  Same operations in the same order as before.
+            const float* xrow = &buf[tid * LD];
+            // the centroids stay in LDS (broadcast reads): without this clobber hipcc hoists all C*E of them out of the slab loop into
+            // VGPRs (80 registers at E = 40, C = 2)
+            if (!SOFT) asm volatile("" ::: "memory");
+            float x[SOFT ? E_ : 1];
+            if (SOFT) {
 #pragma unroll
-            for (int q = 0; q < V4; ++q) {
-                const float4 v = *reinterpret_cast<const float4*>(&buf[tid * LD + q * 4]);
-                x[q * 4 + 0] = v.x; x[q * 4 + 1] = v.y; x[q * 4 + 2] = v.z; x[q * 4 + 3] = v.w;
-            }
-            const float wv = HAS_W ? wb[p0 + tid] : 1.0f;
-            const f2 wv2 = {wv, wv};
-            float d2[C_];
-#pragma unroll
-            for (int c = 0; c < C_; ++c) {
-                float d = 0.f;
-#pragma unroll
-                for (int q = 0; q < V2; ++q) {
-                    const f2 xv = {x[2 * q], x[2 * q + 1]};
-                    const f2 cv = *reinterpret_cast<const f2*>(&scent[c * E_ + 2 * q]);
-                    const f2 diff = xv - cv;
-                    f2 sq = diff * diff;
-                    if (HAS_W) sq = sq * wv2;
-                    d = __fadd_rn(d, sq.x);
-                    d = __fadd_rn(d, sq.y);
+                for (int q = 0; q < V4; ++q) {
+                    const float4 v = *reinterpret_cast<const float4*>(xrow + q * 4);
+                    x[(q * 4 + 0) % (SOFT ? E_ : 1)] = v.x; x[(q * 4 + 1) % (SOFT ? E_ : 1)] = v.y;
+                    x[(q * 4 + 2) % (SOFT ? E_ : 1)] = v.z; x[(q * 4 + 3) % (SOFT ? E_ : 1)] = v.w;
                 }
-                d2[c] = d;
+            }
+            // without silence weights the HARD modes still multiply by w = a.one (x * 1 == x bit for bit): the multiply-free form of
+            // the same loops made hipcc spill 85 registers under the 168-VGPR bound (8.6 ms instead of 3.7 ms per 10 x 10 run)
+            const float wv = HAS_W ? wb[p0 + tid] : (SOFT ? 1.0f : a.one);
+            const f2 wv2 = {wv, wv};
+            constexpr bool MULW = HAS_W || !SOFT;
+            float d2[C_];
+            if (SOFT) {
+#pragma unroll
+                for (int c = 0; c < C_; ++c) {
+                    float d = 0.f;
+#pragma unroll
+                    for (int q = 0; q < V2; ++q) {
+                        const f2 xv = {x[(2 * q) % (SOFT ? E_ : 1)], x[(2 * q + 1) % (SOFT ? E_ : 1)]};
+                        const f2 cv = *reinterpret_cast<const f2*>(&scent[c * E_ + 2 * q]);
+                        const f2 diff = xv - cv;
+                        f2 sq = diff * diff;
+                        if (HAS_W) sq = sq * wv2;
+                        d = __fadd_rn(d, sq.x);
+                        d = __fadd_rn(d, sq.y);
+                    }
+                    d2[c] = d;
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < C_; ++c) d2[c] = 0.f;
+#pragma unroll
+                for (int q4 = 0; q4 < V4; ++q4) {              // q outer, c inner: each d2[c] still adds its terms in e order
+                    asm volatile("" ::: "memory");              // LDS operands just in time: no wholesale preload into VGPRs
+                    const float4 v = *reinterpret_cast<const float4*>(xrow + q4 * 4);
+#pragma unroll
+                    for (int c = 0; c < C_; ++c) {
+                        const f2 c0 = *reinterpret_cast<const f2*>(&scent[c * E_ + 4 * q4]);
+                        const f2 c1 = *reinterpret_cast<const f2*>(&scent[c * E_ + 4 * q4 + 2]);
+                        const f2 x0 = {v.x, v.y}, x1 = {v.z, v.w};
+                        const f2 df0 = x0 - c0, df1 = x1 - c1;
+                        f2 s0 = df0 * df0, s1 = df1 * df1;
+                        if (MULW) { s0 = s0 * wv2; s1 = s1 * wv2; }
+                        float d = d2[c];
+                        d = __fadd_rn(d, s0.x);
+                        d = __fadd_rn(d, s0.y);
+                        d = __fadd_rn(d, s1.x);
+                        d = __fadd_rn(d, s1.y);
+                        d2[c] = d;
+                    }
+                }
             }
             if (!SOFT) {
                 int lab = 0;
@@ -160,20 +202,29 @@ __global__ __launch_bounds__(256) void kmeans_pass_kernel(KmArgs a) {
                     if (dc < best) { best = dc; lab = c; }
                 }
                 if (MODE == HARD_ACC) {
+                    f2 mm[C_];
 #pragma unroll
                     for (int c = 0; c < C_; ++c) {
                         const float m = (lab == c) ? 1.0f : 0.0f;
-                        const f2 m2 = {m, m};
-#pragma unroll
-                        for (int q = 0; q < V2; ++q) {
-                            f2 t = {x[2 * q], x[2 * q + 1]};
-                            if (HAS_W) t = t * wv2;
-                            f2 av = {acc[c * E_ + 2 * q], acc[c * E_ + 2 * q + 1]};
-                            // m is 0 or 1, so t * m is exact and the fused form rounds exactly like multiply-then-add
-                            av = __builtin_elementwise_fma(t, m2, av);
-                            acc[c * E_ + 2 * q] = av.x; acc[c * E_ + 2 * q + 1] = av.y;
-                        }
+                        mm[c] = (f2){m, m};
                         acc[C_ * E_ + c] = __fadd_rn(acc[C_ * E_ + c], m);
+                    }
+#pragma unroll
+                    for (int q4 = 0; q4 < V4; ++q4) {
+                        asm volatile("" ::: "memory");
+                        const float4 v = *reinterpret_cast<const float4*>(xrow + q4 * 4);
+                        f2 t0 = {v.x, v.y}, t1 = {v.z, v.w};
+                        if (MULW) { t0 = t0 * wv2; t1 = t1 * wv2; }
+#pragma unroll
+                        for (int c = 0; c < C_; ++c) {
+                            f2 a0 = {acc[c * E_ + 4 * q4], acc[c * E_ + 4 * q4 + 1]};
+                            f2 a1 = {acc[c * E_ + 4 * q4 + 2], acc[c * E_ + 4 * q4 + 3]};
+                            // m is 0 or 1, so t * m is exact and the fused form rounds exactly like multiply-then-add
+                            a0 = __builtin_elementwise_fma(t0, mm[c], a0);
+                            a1 = __builtin_elementwise_fma(t1, mm[c], a1);
+                            acc[c * E_ + 4 * q4] = a0.x; acc[c * E_ + 4 * q4 + 1] = a0.y;
+                            acc[c * E_ + 4 * q4 + 2] = a1.x; acc[c * E_ + 4 * q4 + 3] = a1.y;
+                        }
                     }
                 } else {
                     // inertia terms: unweighted distance to the assigned centroid (Kmeans_2.py:131-136)
@@ -184,7 +235,7 @@ __global__ __launch_bounds__(256) void kmeans_pass_kernel(KmArgs a) {
                             float d = 0.f;
 #pragma unroll
                             for (int e = 0; e < E_; ++e) {
-                                const float diff = __fsub_rn(x[e], scent[c * E_ + e]);
+                                const float diff = __fsub_rn(xrow[e], scent[c * E_ + e]);
                                 d = __fadd_rn(d, __fmul_rn(diff, diff));
                             }
                             dist = d;
@@ -638,7 +689,7 @@ ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent
     hipStream_t st = (hipStream_t)stream;
     KmArgs a{};
     a.xn = xn; a.w = w; a.cent = cent_in; a.part = (float*)ws; a.L = L; a.b = b; a.tries = tries; a.G = ceil_div(L, CHUNK);
-    a.w_mod_b = w_mod_b; a.beta = beta;
+    a.w_mod_b = w_mod_b; a.beta = beta; a.one = 1.0f;
     ams_status s = beta < 0.f ? launch_pass<HARD_ACC>(a, R, E, C, st) : launch_pass<SOFT_ACC>(a, R, E, C, st);
     if (s != AMS_OK) return s;
     hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(ceil_div((long)R * C * E, 256)), dim3(256), 0, st, (const float*)ws, cent_out, den_out, R,
@@ -655,7 +706,7 @@ ams_status ams_kmeans_assign(const float* xn, const float* w, const float* cent,
     hipStream_t st = (hipStream_t)stream;
     KmArgs a{};
     a.xn = xn; a.w = w; a.cent = cent; a.part = (float*)ws; a.labels = labels; a.soft = soft; a.L = L; a.b = b; a.tries = tries;
-    a.G = ceil_div(L, CHUNK); a.w_mod_b = w_mod_b; a.beta = beta;
+    a.G = ceil_div(L, CHUNK); a.w_mod_b = w_mod_b; a.beta = beta; a.one = 1.0f;
     ams_status s = beta < 0.f ? launch_pass<HARD_FINAL>(a, R, E, C, st) : launch_pass<SOFT_FINAL>(a, R, E, C, st);
     if (s != AMS_OK) return s;
     if (inertia) {

@@ -40,6 +40,14 @@
 #ifndef AMS_RING_FWD_FETCH_LATE
 #define AMS_RING_FWD_FETCH_LATE 0
 #endif
+// s_sleep units (64 cycles each) before the FIRST poll round of a step: every member of a chain publishes at about the same time,
+// a round issued right behind the own publish returns mostly stale granules and costs a full extra round
+#ifndef AMS_RING_FWD_SLEEP
+#define AMS_RING_FWD_SLEEP 0
+#endif
+#ifndef AMS_RING_BWD_SLEEP
+#define AMS_RING_BWD_SLEEP 0
+#endif
 
 namespace {
 
@@ -90,7 +98,13 @@ __device__ __forceinline__ float ring_exp(float x) {
     r = fmaf(x, 1.925963033500180e-8f, r);
     return ldexpf(__builtin_amdgcn_exp2f(r), (int)n);
 }
-__device__ __forceinline__ float ring_sigmoid(float x) { return 1.0f / (1.0f + ring_exp(-x)); }
+// 1 / d for d in [1, 2^127]: v_rcp_f32 (1 ulp) + one Newton step (~0.5 ulp) instead of the IEEE division sequence (scale / fmas /
+// fixup, ~12 instructions) -- five of them per element sat on the hand-off cycle
+__device__ __forceinline__ float ring_rcp(float d) {
+    const float r = __builtin_amdgcn_rcpf(d);
+    return fmaf(r, fmaf(-d, r, 1.0f), r);
+}
+__device__ __forceinline__ float ring_sigmoid(float x) { return ring_rcp(1.0f + ring_exp(-x)); }
 __device__ __forceinline__ float ring_tanh(float x) {
     const float ax = fabsf(x), y = x * x;
     float p = -0.006332100369036198f;
@@ -99,7 +113,7 @@ __device__ __forceinline__ float ring_tanh(float x) {
     p = fmaf(p, y, 0.1333262026309967f);
     p = fmaf(p, y, -0.33333316445350647f);
     p = fmaf(p, y, 1.0f);
-    const float big = 1.0f - 2.0f / (1.0f + ring_exp(2.0f * ax));
+    const float big = 1.0f - 2.0f * ring_rcp(1.0f + ring_exp(2.0f * ax));
     return ax < 0.55f ? x * p : copysignf(big, x);
 }
 
@@ -255,6 +269,7 @@ __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
                 unsigned spins = 0;
                 const unsigned want = (unsigned)s;              // h_{s-1} carries tag s
                 const unsigned rbase = (unsigned)(((par ^ 1) * TB + rowl) * NG) * 16u;
+                if (AMS_RING_FWD_SLEEP) __builtin_amdgcn_s_sleep(AMS_RING_FWD_SLEEP);
                 for (;;) {
 #pragma unroll
                     for (int i = 0; i < NR; ++i) {
@@ -428,6 +443,7 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
         const int par = s & 1;
         if (s > 0 && !abort) {
             unsigned spins = 0;
+            if (AMS_RING_BWD_SLEEP) __builtin_amdgcn_s_sleep(AMS_RING_BWD_SLEEP);
             for (;;) {                                          // every wave watches its chain's flags itself: no extra barrier
                 const unsigned v = (lane < NW) ? (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rf, lane * 4, 0, 16) : 0xffffffffu;
                 if (__all(v >= (unsigned)s)) break;

@@ -69,8 +69,11 @@ ams_status ams_synth_unpool_bwd_vals(const float* dout, const int32_t* pos, cons
  * mask_period/mask_skip (transA only): reduction rows k with k % period == skip are treated as zero
  * (used for the time-shifted h_{t-1}^T . da product).  utils/ops.py:366-383, :501-503. */
 size_t ams_gemm_workspace_bytes(int M, int N, int K);
-/* thread-local launch hint: extra (unused) dynamic LDS bytes per GEMM workgroup, to cap its CU occupancy when it is
- * launched beside latency-critical kernels on another stream; 0 = off */
+/* The ONE piece of state behind this ABI (per host thread, default 0): a launch attribute of the GEMM entry points below --
+ * extra (unused) dynamic LDS bytes per workgroup, which caps the product's CU occupancy when it is launched beside the
+ * latency-bound recurrence on another stream (0 = off).  It changes scheduling only, never results; every GEMM call made
+ * by the thread until the next set uses it.  Environment overrides of tile order / split count (AMS_GEMM_*) are read once
+ * per process, not per launch. */
 void ams_gemm_set_lds_pad(int bytes);
 ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C,
                         long ldc, const float* bias, int accumulate, int mask_period, int mask_skip, void* ws, size_t ws_bytes,
