@@ -160,27 +160,27 @@ class BLSTMLayer(Function):
         need_dx = ctx.needs_input_grad[0]
         if OVERLAP.usable(Kf, Kb, bf, bb) and all(ctx.needs_input_grad[1:5]):
             B, T, D = x.shape
-            ops.blstm_bwd_recurrent(x, Kf, Kb, G, cst, _c(dout))
+            dbpart = ops.blstm_bwd_recurrent(x, Kf, Kb, G, cst, _c(dout))
             dx = None
             if _ORDER >= 2 and need_dx:
                 dx = ops.blstm_bwd_dx(G, Kf, Kb, B, T, D)
-            s = OVERLAP.fork(x, out, G)
+            s = OVERLAP.fork(x, out, G, *([dbpart] if dbpart is not None else []))
             if not need_dx:
                 # first layer: no recurrence follows -- both streams work on the weight gradients, uncapped
                 if _L1_TAIL == 0:
                     with torch.cuda.stream(s):
                         ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u')
-                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx')
+                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart)
                 elif _L1_TAIL == 1:
-                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx')
+                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart)
                     ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u')
                 else:
                     ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u')
-                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx')
+                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart)
                 return None, None, None, None, None, None
             with torch.cuda.stream(s):
                 OVERLAP.cap(True, 'lstm')
-                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx')
+                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart)
                 # the LAST capped product of the backward pass (recurrent-kernel gradient of the layer above the first one) ends
                 # after the BPTT it hides behind: 2 workgroups per CU there (+0.6 %)
                 OVERLAP.cap(True, 'lstm_last' if ctx.last_capped else 'lstm')

@@ -461,7 +461,9 @@ def blstm_wcat(Kf, Kb, D):
 
 
 def blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout):
-    """BPTT recurrence of one BLSTM layer: overwrites G (activated gates) with d pre-activation."""
+    """BPTT recurrence of one BLSTM layer: overwrites G (activated gates) with d pre-activation.  Returns None, or (ring
+    recurrence) dbpart [B, 2, 4H] = sum over t of d pre-activation, which blstm_bwd_weights turns into the bias gradients with a
+    column sum over B rows instead of B*T."""
     _chk(x, G, cst, dout)
     _chk_rows(Kf, Kb)
     lib = load()
@@ -472,11 +474,12 @@ def blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout):
     nring = lib.ams_blstm_ring_sync_bytes(B, H, 1) if (LSTM_RING != '0' and not LSTM_PERSIST and cst.dim() == 5) else 0
     if nring:
         sync = _ws(nring, x)
-        check(lib.ams_blstm_ring_bwd(_p(G), _p(cst[0]), _p(cst[1]), _p(dout), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring, B, T, H,
-                                     int(LSTM_RING == 'safe'), _s()), 'ams_blstm_ring_bwd')
+        dbpart = torch.empty((B, 2, 4 * H), dtype=torch.float32, device=x.device)
+        check(lib.ams_blstm_ring_bwd(_p(G), _p(cst[0]), _p(cst[1]), _p(dout), _p(dbpart), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring,
+                                     B, T, H, int(LSTM_RING == 'safe'), _s()), 'ams_blstm_ring_bwd')
         LAST_SYNC.append(sync)
         del LAST_SYNC[:-8]
-        return
+        return dbpart
     pack = torch.empty(lib.ams_blstm_pack_floats(H, 1), dtype=torch.float32, device=x.device)
     nsync = lib.ams_blstm_persist_sync_bytes(B, H, 1) if LSTM_PERSIST else 0
     if nsync:
@@ -501,7 +504,7 @@ def blstm_bwd_dx(G, Kf, Kb, B, T, D):
     return dx
 
 
-def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate, part='all'):
+def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate, part='all', dbpart=None):
     """Weight gradients of one BLSTM layer from dZ (= G after blstm_bwd_recurrent), written (or accumulated) into the given
     buffers: dWx = x^T dZ, dU = h_prev^T dZ (time-shifted, masked at sequence boundaries), db = column sums.
     part: 'all' | 'wx' (input kernels + biases) | 'u' (recurrent kernels) -- the two halves are independent and may be
@@ -529,7 +532,17 @@ def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate, part='all'):
             else:
                 dKf[:D].copy_(dWcat[:, :4 * H])
                 dKb[:D].copy_(dWcat[:, 4 * H:])
-        if _twin(dbf, dbb):                    # adjacent bias gradients: one column-sum over all 8H columns of dZ
+        if dbpart is not None and _twin(dbf, dbb):      # ring BPTT already summed dZ over time: column sum over B rows only
+            nb = lib.ams_colsum_workspace_bytes(B, 8 * H)
+            ws = _ws(nb, x)
+            check(lib.ams_colsum(_p(dbpart), _p(dbf), B, 8 * H, 8 * H, int(acc), _p(ws), nb, _s()), 'ams_colsum')
+        elif dbpart is not None:
+            nb = lib.ams_colsum_workspace_bytes(B, 4 * H)
+            ws = _ws(nb, x)
+            check(lib.ams_colsum(_p(dbpart), _p(dbf), B, 4 * H, 8 * H, int(acc), _p(ws), nb, _s()), 'ams_colsum')
+            ws2 = _ws(nb, x)
+            check(lib.ams_colsum(_p(dbpart.view(-1)[4 * H:]), _p(dbb), B, 4 * H, 8 * H, int(acc), _p(ws2), nb, _s()), 'ams_colsum')
+        elif _twin(dbf, dbb):                  # adjacent bias gradients: one column-sum over all 8H columns of dZ
             nb = lib.ams_colsum_workspace_bytes(M, 8 * H)
             ws = _ws(nb, x)
             check(lib.ams_colsum(_p(dZf), _p(dbf), M, 8 * H, 8 * H, int(acc), _p(ws), nb, _s()), 'ams_colsum')
@@ -562,12 +575,12 @@ def blstm_bwd(x, Kf, Kb, out, G, cst, dout, need_dx=True):
     _chk(x, out, G, cst, dout)
     B, T, D = x.shape
     H = Kf.shape[1] // 4
-    blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout)
+    dbpart = blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout)
     dKf = torch.empty(Kf.shape, dtype=torch.float32, device=x.device)
     dKb = torch.empty(Kb.shape, dtype=torch.float32, device=x.device)
     dbf = torch.empty(4 * H, dtype=torch.float32, device=x.device)
     dbb = torch.empty(4 * H, dtype=torch.float32, device=x.device)
-    blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, False)
+    blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, False, dbpart=dbpart)
     dx = blstm_bwd_dx(G, Kf, Kb, B, T, D) if need_dx else None
     return dx, dKf, dbf, dKb, dbb
 

@@ -63,6 +63,7 @@ constexpr unsigned SPIN_LIMIT = 1u << 20;
 
 struct RingArgs {
     float* G; float* out; float* cst; float* tch; const float* dout;   // tch [B,T,2,H] = tanh(c_t), written by the forward ring
+    float* dbpart;              // backward, optional: [B,2,4H] = sum over t of da[b,t,dir,:] (bias-gradient partials)
     const float* Uf; const float* Ub; long ldu;
     unsigned* err;              // word 0 of the sync buffer
     unsigned* ids;              // [n_chains][IDS_STRIDE]   XCC id + 1 of every workgroup (placement agreement)
@@ -411,6 +412,7 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
     unsigned* fl = a.flags + chain * IDS_STRIDE;
     const rsrc_t rf = make_rsrc(fl, IDS_STRIDE * 4);
     float dc_state = 0.f;
+    float dbs[4] = {0.f, 0.f, 0.f, 0.f};                       // running sum over t of this element's four da (bias gradient)
 
     // per-thread base pointers (time 0) and per-time-step strides; dead threads alias element (0, 0)
     const long bl_ = live ? b : 0, ul_ = live ? u : 0;
@@ -488,6 +490,7 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
         const float da2 = live ? dcv * c_prev * fg * (1.0f - fg) : 0.f;
         const float da3 = live ? d_o * og * (1.0f - og) : 0.f;
         dc_state = dcv * fg;
+        dbs[0] += da0; dbs[1] += da1; dbs[2] += da2; dbs[3] += da3;
         if (nl < UW) {
             lds_a[r][0 * UW + nl] = da0;
             lds_a[r][1 * UW + nl] = da1;
@@ -540,6 +543,11 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
 #endif
         cur = nxt;
         tr.stamp(7);                                            // flag store
+    }
+    if (a.dbpart && live) {
+        float* o = a.dbpart + ((long)b * 2 + dir) * (4 * H) + u;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) o[g * H] = dbs[g];
     }
     tr.end();
 }
@@ -611,8 +619,9 @@ ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, cons
 }
 
 // Same contract as ams_blstm_recurrent_bwd (on return G holds da), without the dc workspace (the running dc lives in registers).
-ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* tch, const float* dout, const float* Uf, const float* Ub, long ldu,
-                              void* sync, size_t sync_bytes, int B, int T, int H, int safe, void* stream) {
+// dbpart (optional, [B,2,4H]): receives sum_t da[b,t,dir,:] -- the bias gradient is then a column sum over B rows instead of B*T.
+ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* tch, const float* dout, float* dbpart, const float* Uf, const float* Ub,
+                              long ldu, void* sync, size_t sync_bytes, int B, int T, int H, int safe, void* stream) {
     AMS_REQUIRE(G && cst && tch && dout && Uf && Ub && sync && B > 0 && T > 0 && H > 0);
     int NW, n_chains;
     AMS_REQUIRE(ring_shape(B, H, NW, n_chains));
@@ -621,7 +630,7 @@ ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* tch, cons
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(sync, 0, L.head, st) != hipSuccess) return AMS_E_LAUNCH_FAILED;
     RingArgs a{};
-    a.G = G; a.cst = const_cast<float*>(cst); a.tch = const_cast<float*>(tch); a.dout = dout; a.Uf = Uf; a.Ub = Ub; a.ldu = ldu;
+    a.G = G; a.cst = const_cast<float*>(cst); a.tch = const_cast<float*>(tch); a.dout = dout; a.dbpart = dbpart; a.Uf = Uf; a.Ub = Ub; a.ldu = ldu;
     a.err = (unsigned*)sync; a.ids = (unsigned*)((char*)sync + L.ids); a.flags = (unsigned*)((char*)sync + L.flags);
     a.xbuf = (float*)((char*)sync + L.x);
     a.B = B; a.T = T; a.H = H; a.NW = NW; a.n_chains = n_chains; a.force_safe = ((safe & 1) || ring_force_safe()) ? 1 : 0; a.trace = (safe & 2) ? 1 : 0;

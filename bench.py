@@ -205,7 +205,7 @@ def main():
         # counters were collected at.  null for any other shape or when no summary is committed.
         tj, tfile = _newest_profile('_c_hbm_traffic.json')
         if tj is not None and (B, L, N) == (64, 20480, 256):
-            gk = [v for k, v in tj.items() if k.startswith('gemm_f32_kernel')]
+            gk = [v for k, v in tj.items() if k.startswith('gemm_f32_kernel') and isinstance(v, dict)]
             calls = sum(v['calls'] for v in gk)
             if calls:
                 mb = sum(v['calls'] * (v['read_MB_per_launch'] + v['write_MB_per_launch']) for v in gk) / calls

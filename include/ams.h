@@ -132,12 +132,13 @@ ams_status ams_blstm_persist_bwd(float* G, const float* cst, const float* dout, 
  * ams_blstm_recurrent_fwd/bwd.  sync word 0 (uint32) is non-zero after the launch if a bounded in-launch wait timed out.
  * tch [B,T,2,H]: tanh(c_t), written by the forward ring and read by the backward one (cst keeps c_t).  safe: bit 0 forces the
  * write-through hand-off, bit 1 records a per-phase cycle trace in the sync header (tools/ring_anatomy.py).
+ * dbpart (backward, may be NULL): [B,2,4H] receives sum_t d pre-activation[b,t,dir,:]; the bias gradients are its column sums.
  * Replaces the same dynamic_rnn while_loop (utils/ops.py:358-383). */
 size_t ams_blstm_ring_sync_bytes(int B, int H, int backward);
 ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, const float* Uf, const float* Ub, long ldu, void* sync,
                               size_t sync_bytes, int B, int T, int H, int safe, void* stream);
-ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* tch, const float* dout, const float* Uf, const float* Ub, long ldu,
-                              void* sync, size_t sync_bytes, int B, int T, int H, int safe, void* stream);
+ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* tch, const float* dout, float* dbpart, const float* Uf, const float* Ub,
+                              long ldu, void* sync, size_t sync_bytes, int B, int T, int H, int safe, void* stream);
 
 /* ---- K13  tf.nn.l2_normalize over groups of E       utils/ops.py:323-324 ---- */
 ams_status ams_l2norm_fwd(const float* u, float* v, float* inv, long rows, int E, void* stream);

@@ -44,6 +44,8 @@ def main():
         js[short(n)] = {'calls': calls, 'read_MB_per_launch': round(rd, 4), 'write_MB_per_launch': round(wr, 4)}
     open(sys.argv[3], 'w').write('\n'.join(lines) + '\n')
     if len(sys.argv) > 4 and sys.argv[4]:
+        import os
+        js['_meta'] = {'commit': os.environ.get('AMS_COMMIT', 'unknown'), 'command': desc}
         json.dump(js, open(sys.argv[4], 'w'), indent=1, sort_keys=True)
     print('\n'.join(lines[:24]))
 

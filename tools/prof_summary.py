@@ -19,5 +19,20 @@ def main(db, out, note=''):
             f.write('%-100s %8d %12.1f %10.2f %10.2f %10.2f %6.2f\n' % (n[:100], k, s / 1e3, a / 1e3, mn / 1e3, mx / 1e3, 100.0 * s / tot))
 
 
+def write_json(db, out_json, commit):
+    """Per-kernel call count and average duration (us) of the whole traced run, for bench.py's `roofline.replayed_region`."""
+    import json
+    c = sqlite3.connect(db)
+    rows = list(c.execute("select name, count(*), avg(duration) from kernels group by name order by sum(duration) desc"))
+    js = {'_meta': {'commit': commit, 'source': 'rocprofv3 --kernel-trace of `python bench.py --no-cpu-baseline --no-secondary` (hipGraph replay)'}}
+    for n, k, a in rows[:16]:
+        key = n.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:70]
+        js[key] = {'calls': k, 'avg_us': round(a / 1e3, 2)}
+    json.dump(js, open(out_json, 'w'), indent=1, sort_keys=True)
+
+
 if __name__ == '__main__':
+    import os
     main(sys.argv[1], sys.argv[2], ' '.join(sys.argv[3:]))
+    if os.environ.get('AMS_PROF_JSON'):
+        write_json(sys.argv[1], os.environ['AMS_PROF_JSON'], os.environ.get('AMS_COMMIT', 'unknown'))

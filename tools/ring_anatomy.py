@@ -37,7 +37,7 @@ for mode, safe in (('plain stores (same L2)', 2), ('write-through', 3)):
         if kind == 'fwd':
             ops.check(lib.ams_blstm_ring_fwd(p(G), p(out), p(cst[0]), p(cst[1]), p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, B, T, H, safe, st), 'f')
         else:
-            ops.check(lib.ams_blstm_ring_bwd(p(G), p(cst[0]), p(cst[1]), p(dout), p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, B, T, H, safe, st), 'b')
+            ops.check(lib.ams_blstm_ring_bwd(p(G), p(cst[0]), p(cst[1]), p(dout), None, p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, B, T, H, safe, st), 'b')
         torch.cuda.synchronize()
         w = sync[:64].view(torch.int64).cpu().numpy()
         ph = w[8:8 + len(names[kind])] / float(T)
