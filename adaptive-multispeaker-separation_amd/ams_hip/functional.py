@@ -215,9 +215,13 @@ class Dense(Function):
             s = OVERLAP.fork(x2, du2)
             with torch.cuda.stream(s):
                 OVERLAP.cap(_DENSE_MODE == 0)
-                ops.gemm(x2, du2, transA=True, out=W.grad, accumulate=True)
+                # dW = x^T dU and db = colsum(dU) from ONE pass over dU (210 MB at the benchmark shape)
+                fused = ops.gemm_at_b_colsum(x2, du2, W.grad, b.grad, accumulate=True)
+                if not fused:
+                    ops.gemm(x2, du2, transA=True, out=W.grad, accumulate=True)
                 OVERLAP.cap(False)
-                ops.colsum_into(du2, b.grad, True)
+                if not fused:
+                    ops.colsum_into(du2, b.grad, True)
             if _DENSE_MODE == 2 and ctx.needs_input_grad[0]:
                 # the weight-gradient product runs FIRST and alone (uncapped), dX after it: nothing of the dense layer is left
                 # on the side stream when the recurrence below starts

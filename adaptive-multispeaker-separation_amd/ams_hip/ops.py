@@ -184,6 +184,28 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False
     return out
 
 
+def gemm_at_b_colsum(A, B, out, bsum, accumulate=True):
+    """out[M,N] (+)= A^T B and bsum[N] (+)= column sums of B in ONE pass over B (A [K,M], B [K,N] row-major).  Returns False when
+    the shapes / alignments do not allow the fused form (the caller then uses gemm + colsum)."""
+    K, M = A.shape
+    N = B.shape[1]
+    ok = (M % 4 == 0 and N % 4 == 0 and A.stride(0) % 4 == 0 and B.stride(0) % 4 == 0 and A.stride(1) == 1 and B.stride(1) == 1
+          and out.stride(-1) == 1 and bsum.is_contiguous()
+          and all(t.data_ptr() % 16 == 0 for t in (A, B)) and _os.environ.get('AMS_GEMM_NOVEC') is None)
+    if not ok:
+        return False
+    lib = load()
+    nb = lib.ams_gemm_workspace_bytes(M, N, K)
+    ws = _ws(nb, A) if nb else None
+    bws = _ws(32 * N * 4, A)
+    ev = PROFILE.begin() if PROFILE.enabled else None
+    check(lib.ams_gemm_f32_at_b_colsum(M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), int(accumulate),
+                                       _p(bsum), int(accumulate), _p(bws), _p(ws), nb, _s()), 'ams_gemm_f32_at_b_colsum')
+    if ev is not None:
+        PROFILE.end(ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N), 'gemm<1,0>', '')
+    return True
+
+
 def gemm_batched2(A0, A1, B0, B1, C0, C1, transA, transB, M, N, K, lda, ldb, ldc, accumulate=False, mask=(0, 0)):
     """Two products of one shape in ONE launch (operand pairs given as tensors/views; offsets taken from their addresses)."""
     lib = load()

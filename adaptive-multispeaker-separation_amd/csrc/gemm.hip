@@ -68,6 +68,9 @@ struct GemmArgs {
     int seg_len;
     long seg_stride, seg_off, seg_off_zs, bias_zs;
     int hiprio;                // 1: launch is on the critical path (not residency-capped) -> waves raise their issue priority
+    // column sums of B (B_ROW, VEC path): the tile_m == 0 workgroups add up the B rows they stage anyway and write one partial
+    // row per split to bsum_part [splits, N]; a finishing kernel adds the splits into bsum_out (bias gradient = colsum(dY))
+    float* bsum_part;
 };
 
 __device__ __forceinline__ long rowmap(const GemmArgs& g, int m) {
@@ -295,6 +298,8 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
         }
     };
 
+    const bool do_bsum = VEC && !BKc && g.bsum_part != nullptr && tile_m == 0;      // workgroup-uniform
+    float4 bsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto stash_s = [&](int buf, float4 (&ra)[NLD], float4 (&rb)[NLD], bool (&va)[NLD], bool (&vb)[NLD]) {
         float* as = As + buf * BK * LDA_S;
         float* bs = Bs + buf * BK * LDB_S;
@@ -304,6 +309,7 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
                 const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
                 if (!va[h]) ra[h] = z;
                 if (!vb[h]) rb[h] = z;
+                if (!BKc && do_bsum) { bsum4.x += rb[h].x; bsum4.y += rb[h].y; bsum4.z += rb[h].z; bsum4.w += rb[h].w; }
             }
             const int q = tid + h * 256;
             if (AK) {
@@ -398,6 +404,22 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
         }
     }
 
+    if (VEC && !BKc && do_bsum) {
+        // thread q staged row (q >> 5) of every k-tile, columns (q & 31) * 4 .. + 3: the 8 threads of a column group meet in LDS
+        // (fixed order -> deterministic).  PF == 2 runs up to two zero tiles past the end: they add nothing.
+        float4* sb = reinterpret_cast<float4*>(smem);
+        __syncthreads();
+        sb[tid] = bsum4;
+        __syncthreads();
+        if (tid < 32) {
+            float4 t = sb[tid];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) { const float4 v = sb[tid + 32 * j]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            const int n = n0 + tid * 4;
+            if (n < g.N) *reinterpret_cast<float4*>(g.bsum_part + (long)split * g.N + n) = t;      // N % 4 == 0 on the VEC path
+        }
+        __syncthreads();
+    }
     if (EPI == EPI_MAXPOOL) {
         // Fused max-pool partial (reference models/adapt.py:115-117: stride-1 conv + max_pool_with_argmax): the [Bt,L,N]
         // conv output is never written; each 128-row tile emits, per column, its maximum and the row that holds it
@@ -503,6 +525,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __r
     }
 }
 
+__global__ void bsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int N, int splits, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += part[(long)k * N + n];
+    out[n] = accumulate ? out[n] + s : s;
+}
+
 // Split-K factor from a small cost model calibrated on MI355X (scratch sweep, round 1):
 //   t(s) = n * (k_iters * 1.02us + 5us) / occ(n)  +  (s+1)*M*N*4 B / 2.5 TB/s        [s > 1]
 // n = ceil(tiles*s/256) workgroups end up on the busiest CU (equal-work workgroups time-share a CU's four
@@ -540,7 +570,8 @@ inline int choose_group_m(int tiles_m, int tiles_n) {
 }
 
 template <int AMODE, int BMODE>
-ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nbatch = 1) {
+ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nbatch = 1, float* bsum_out = nullptr,
+                  int bsum_accumulate = 0, float* bsum_ws = nullptr) {
     const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
     g.group_m = choose_group_m(ceil_div(g.M, BM), ceil_div(g.N, BN));
     int splits = 1;
@@ -555,6 +586,7 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
     g.splits = splits;
     g.k_per_split = kps;
     g.partial = (float*)ws;
+    g.bsum_part = bsum_out ? bsum_ws : nullptr;
     dim3 grid(tiles, splits, nbatch);
     const bool prio_off = tuning().noprio;
     g.hiprio = (t_gemm_lds_pad == 0 && !prio_off) ? 1 : 0;
@@ -606,6 +638,11 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
         }
         s = ams_check_launch();
     }
+    if (s == AMS_OK && bsum_out) {
+        if (!vec || BMODE != B_ROW) return AMS_E_INVALID_ARG;          // only the 16-byte B_ROW fetch path accumulates the sums
+        hipLaunchKernelGGL(bsum_finish_kernel, dim3(ceil_div(g.N, 256)), dim3(256), 0, st, bsum_ws, bsum_out, g.N, splits, bsum_accumulate);
+        s = ams_check_launch();
+    }
     return s;
 }
 
@@ -623,6 +660,22 @@ size_t ams_gemm_workspace_bytes(int M, int N, int K) {
     if (tuning().splits > 0) splits = tuning().splits;
     if (splits <= 1) return 0;
     return (size_t)splits * M * N * sizeof(float);
+}
+
+// C (+)= A^T . B  AND  bsum_out[N] (+)= column sums of B, in one pass over B (reference: the weight and bias gradients of a
+// width-1 Conv1D, utils/ops.py:501-503 under tf.gradients).  bsum_ws: 32 * N floats (one row per possible split).
+ams_status ams_gemm_f32_at_b_colsum(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                                    int accumulate, float* bsum_out, int bsum_accumulate, float* bsum_ws, void* ws, size_t ws_bytes,
+                                    void* stream) {
+    AMS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C && bsum_out && bsum_ws);
+    GemmArgs g{};
+    g.A = A; g.B = B; g.C = C;
+    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
+    g.accumulate = accumulate;
+    g.a_vec = aligned16(A) && (lda % 4 == 0);
+    g.b_vec = aligned16(B) && (ldb % 4 == 0);
+    AMS_REQUIRE(g.a_vec && g.b_vec && M % 4 == 0 && N % 4 == 0 && aligned16(bsum_ws) && !tuning().novec);
+    return launch<A_COL, B_ROW>(g, ws, ws_bytes, (hipStream_t)stream, 1, bsum_out, bsum_accumulate, bsum_ws);
 }
 
 ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,

@@ -78,6 +78,12 @@ void ams_gemm_set_lds_pad(int bytes);
 ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C,
                         long ldc, const float* bias, int accumulate, int mask_period, int mask_skip, void* ws, size_t ws_bytes,
                         void* stream);
+/* C[M,N] (+)= A^T . B with A stored [K, M] and B [K, N], AND bsum_out[N] (+)= column sums of B in the same pass over B: the
+ * weight and bias gradients of Conv1D (utils/ops.py:501-503) from one read of dY.  M, N, lda, ldb multiples of 4, 16-byte
+ * aligned operands; bsum_ws = 32 * N floats of scratch. */
+ams_status ams_gemm_f32_at_b_colsum(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                                    int accumulate, float* bsum_out, int bsum_accumulate, float* bsum_ws, void* ws, size_t ws_bytes,
+                                    void* stream);
 /* nbatch products of ONE shape in one launch; operand z lives at A + z*a_zs, B + z*b_zs, C + z*c_zs (element offsets, any
  * sign).  No bias.  Used for the two BLSTM directions' recurrent-kernel gradients (h_prev^T . dZ). */
 size_t ams_gemm_batched_workspace_bytes(int M, int N, int K, int nbatch);

@@ -207,3 +207,21 @@ def test_optimizers(ops):
         ops.opt_momentum(p, dev(g[k]), acc, 0.01)
     assert rel(host(p), pr) < 1e-5
     assert abs(host(ops.sumsq(dev(g[0])))[0] - np.sum(g[0].astype(np.float32).astype(np.float64) ** 2)) < 1e-4 * n
+
+
+@pytest.mark.parametrize('M,N,K', [(600, 10240, 5120), (64, 128, 40), (600, 256, 5120), (16, 64, 3000), (132, 388, 777)])
+def test_gemm_at_b_colsum(ops, M, N, K):
+    """dW = x^T dY and db = colsum(dY) from one pass over dY (Conv1D gradients, utils/ops.py:501-503): the fused launch against the
+    oracle's two separate formulas, with and without accumulation, across split-K counts (K = 5120 splits, K = 40 does not)."""
+    rng = np.random.RandomState(M + N + K)
+    A, Bm = rng.randn(K, M), rng.randn(K, N)
+    C0, b0 = rng.randn(M, N), rng.randn(N)
+    out, bsum = dev(C0), dev(b0)
+    assert ops.gemm_at_b_colsum(dev(A), dev(Bm), out, bsum, accumulate=True)
+    assert rel(host(out), C0 + A.T.dot(Bm)) < TOL
+    assert rel(host(bsum), b0 + Bm.sum(0)) < TOL
+    out2, bsum2 = torch.empty(M, N, device='cuda'), torch.empty(N, device='cuda')
+    assert ops.gemm_at_b_colsum(dev(A), dev(Bm), out2, bsum2, accumulate=False)
+    assert rel(host(out2), A.T.dot(Bm)) < TOL and rel(host(bsum2), Bm.sum(0)) < TOL
+    # a shape the fused form does not take (N not a multiple of 4): the wrapper says so instead of guessing
+    assert not ops.gemm_at_b_colsum(dev(A), dev(Bm[:, :N - 1].copy()), torch.empty(M, N - 1, device='cuda'), torch.empty(N - 1, device='cuda'))
