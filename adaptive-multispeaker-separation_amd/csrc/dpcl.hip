@@ -135,7 +135,10 @@ __global__ __launch_bounds__(256) void dpcl_gram_kernel(const float* __restrict_
 //   * normalisation is applied on the MFMA operand fetch (per-lane factor: 1/|u| for embedding columns, 1 for
 //     label columns), the rows in LDS stay raw.
 constexpr int CP = 8;                  // label-count partials per utterance
-constexpr int UCHUNK = 2560;           // points per workgroup in the fused pass
+#ifndef AMS_DPCL_UCHUNK
+#define AMS_DPCL_UCHUNK 2560
+#endif
+constexpr int UCHUNK = AMS_DPCL_UCHUNK;           // points per workgroup in the fused pass
 
 __global__ __launch_bounds__(256) void dpcl_count_part_kernel(const float* __restrict__ Y, float* __restrict__ cntp, long TF, int S) {
     __shared__ float sm[4][8];
