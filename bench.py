@@ -289,6 +289,7 @@ def main():
                     r = bench_configs.wl_front_dpcl_finetuning(10, 4, B=B, graph=bool(args.graph))
                 out['secondary'] = {'front_DPCL_finetuning_step': {'mixtures_per_s': round(r['mixtures_per_s'], 1),
                                                                    'ms_per_step': round(r['ms_per_step'], 3),
+                                                                   'kmeans_seeding': bench_configs.SEEDING,
                                                                    'workload': r['workload']}}
             except Exception as e:                       # the headline line must still be printed
                 out['secondary'] = {'error': '%s: %s' % (type(e).__name__, e)}

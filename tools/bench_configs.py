@@ -104,7 +104,7 @@ def wl_front_dpcl_finetuning(steps, warmup, B=64, graph=False):
         folder = tr0.model._dir()
     del tr0
     a.update(model_folder=folder, nb_tries=1, nb_steps=10, beta_kmeans=10.0, with_silence=True, threshold=2.0, end_assign=True,
-             loss='sdr+l2', optimizer='RMSProp', learning_rate=1e-4, hip_graph=graph)
+             loss='sdr+l2', optimizer='RMSProp', learning_rate=1e-4, hip_graph=graph, kmeans_seeding=SEEDING)
     tr = Front_Separator_Finetuning_Trainer(DPCL, 'front_L41_finetuning', **a)
     dist, tfds = tr.prepare()
     dt, c = _time_train(tr, tfds, L, steps, warmup)
