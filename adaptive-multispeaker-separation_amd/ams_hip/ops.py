@@ -241,6 +241,9 @@ LSTM_PERSIST = _os.environ.get('AMS_LSTM_PERSIST', '0') != '0'     # persistent 
 # chain-per-XCD ring recurrence (csrc/lstm_ring.hip), the default: 1 = on, 0 = per-step kernels, 'safe' = on with the
 # placement-independent (write-through) hand-off forced
 LSTM_RING = _os.environ.get('AMS_LSTM_RING', '1')
+# 1 = the forward ring computes the layer's own input projection with four extra waves per workgroup (ams_blstm_ring_fwd_proj).
+# Parity-tested, measured SLOWER than the separate product, so off by default.
+LSTM_RING_PROJ = _os.environ.get('AMS_LSTM_RING_PROJ', '0') != '0'
 LAST_SYNC = []                                                      # most recent sync buffers (word 0 = timeout flag)
 
 
@@ -279,6 +282,18 @@ def blstm_fwd(x, Kf, bf, Kb, bb, consumer=None):
     # ring recurrence: plane 0 = c_t (what every backward reads as `cst`), plane 1 = tanh(c_t) for the backward ring
     cst = torch.empty(((2, B, T, 2, H) if nring else (B, T, 2, H)), dtype=torch.float32, device=x.device)
     pack = torch.empty(lib.ams_blstm_pack_floats(H, 0), dtype=torch.float32, device=x.device)
+    if (nring and LSTM_RING_PROJ and pre is None and lib.ams_blstm_ring_proj_ok(B, H, D) and x.is_contiguous() and x.data_ptr() % 16 == 0
+            and bf.is_contiguous() and bb.is_contiguous()):
+        sync = _ws(nring, x)
+        ev = PROFILE.begin() if PROFILE.enabled else None
+        check(lib.ams_blstm_ring_fwd_proj(_p(x), D, _p(Kf), _p(Kb), ldu, _p(bf), _p(bb), _p(G), _p(out), _p(cst[0]), _p(cst[1]),
+                                          _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring, B, T, H, int(LSTM_RING == 'safe'), _s()),
+              'ams_blstm_ring_fwd_proj')
+        if ev is not None:      # the projection's flops, attributed to the ring launch that now contains them
+            PROFILE.end(ev, 2 * 2.0 * B * T * 4 * H * (D + H), 4.0 * (B * T * (D + 8 * H + 2 * H)), 'ring_fwd_proj', 'blstm_input_gemm_in_ring')
+        LAST_SYNC.append(sync)
+        del LAST_SYNC[:-8]
+        return out, G, cst
     bands = _fwd_bands(T) if not (LSTM_PERSIST or nring or pre is not None or consumer is not None) else None
     if bands:
         _blstm_fwd_banded(lib, x2, Wcat, bias, G, out, cst, pack, Kf[D:], Kb[D:], ldu, B, T, D, H, bands)

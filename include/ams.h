@@ -143,6 +143,14 @@ ams_status ams_blstm_persist_bwd(float* G, const float* cst, const float* dout, 
 size_t ams_blstm_ring_sync_bytes(int B, int H, int backward);
 ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, const float* Uf, const float* Ub, long ldu, void* sync,
                               size_t sync_bytes, int B, int T, int H, int safe, void* stream);
+/* Forward ring with the layer's input projection z_t = x_t.Wx + b computed INSIDE it by four extra waves per workgroup that work one step
+ * ahead of the ring (the ring's MFMA pipes idle ~55 % of a step otherwise): replaces ams_gemm_f32 (projection) + ams_blstm_ring_fwd.  G is output only (activated gates).
+ * x [B,T,D]; Wxf / Wxb: the input rows of the two direction kernels, row stride ldw; ams_blstm_ring_proj_ok(B, H, D): D % 4 == 0,
+ * D <= 640 and at most 256 workgroups (8 waves each, one per CU: 4 ring waves + 4 projection waves). */
+int ams_blstm_ring_proj_ok(int B, int H, int D);
+ams_status ams_blstm_ring_fwd_proj(const float* x, int D, const float* Wxf, const float* Wxb, long ldw, const float* bf, const float* bb,
+                                   float* G, float* out, float* cst, float* tch, const float* Uf, const float* Ub, long ldu, void* sync,
+                                   size_t sync_bytes, int B, int T, int H, int safe, void* stream);
 ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* tch, const float* dout, float* dbpart, const float* Uf, const float* Ub,
                               long ldu, void* sync, size_t sync_bytes, int B, int T, int H, int safe, void* stream);
 

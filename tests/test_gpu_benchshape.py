@@ -42,14 +42,15 @@ def ops():
     return o
 
 
-@pytest.mark.parametrize('D,ring', [(600, '1'), (256, '1'), (600, 'safe'), (600, '0')])
+@pytest.mark.parametrize('D,ring', [(600, '1'), (256, '1'), (600, 'safe'), (600, '0'), (600, 'proj')])
 def test_blstm_layer_at_benchmark_shape(ops, monkeypatch, D, ring):
     """One BLSTM layer, B=64, T=80, H=300, D=600 (layers 1-2) / 256 (layer 0): forward and full backward through the DEFAULT
     recurrence -- 8 chain-per-XCD rings of 25 workgroups (csrc/lstm_ring.hip) -- plus its write-through hand-off and the per-step
     kernels (AMS_LSTM_XCD=2 grid) it falls back to (reference utils/ops.py:358-383)."""
     import os
     assert os.environ.get('AMS_LSTM_XCD', '2') == '2'
-    monkeypatch.setattr(ops, 'LSTM_RING', ring)
+    monkeypatch.setattr(ops, 'LSTM_RING', '1' if ring == 'proj' else ring)
+    monkeypatch.setattr(ops, 'LSTM_RING_PROJ', ring == 'proj')
     assert ops.load().ams_blstm_ring_sync_bytes(B, H, 0) != 0 and ops.load().ams_blstm_ring_sync_bytes(B, H, 1) != 0
     rng = np.random.RandomState(D)
     lim = np.sqrt(6.0 / (D + 5 * H))

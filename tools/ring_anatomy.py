@@ -25,16 +25,20 @@ ops.gemm(x.view(B * T, D), ops.blstm_wcat(Kf, Kb, D), bias=torch.cat([bf, bb]), 
 ldu = Kf.stride(0)
 p = lambda t: t.data_ptr()                                                                  # noqa: E731
 st = torch.cuda.current_stream().cuda_stream
-names = {'fwd': ['wait for h', 'MFMA + acc to LDS', 'barrier', 'gate epilogue + granule store', 'G/cst/out stores'],
+names = {'fwdp': ['wait for h + projection chunks', 'x prefetch + MFMA + acc to LDS', 'barrier', 'gate epilogue + granule store', 'G/cst/out stores'],
+         'fwd': ['wait for h', 'MFMA + acc to LDS', 'barrier', 'gate epilogue + granule store', 'G/cst/out stores'],
          'bwd': ['flag wait', 'partial tiles load + sum', 'gate math + LDS write', 'barrier', 'MFMA + tile stores', 'store drain', 'barrier',
                  'flag store']}
 for mode, safe in (('plain stores (same L2)', 2), ('write-through', 3)):
-    for kind in ('fwd', 'bwd'):
+    for kind in ('fwd', 'fwdp', 'bwd'):
         n = lib.ams_blstm_ring_sync_bytes(B, H, int(kind == 'bwd'))
         sync = torch.zeros(n // 4 + 1, dtype=torch.float32, device='cuda')
-        G.copy_(Gz if kind == 'fwd' else G0)
+        G.copy_(G0 if kind == 'bwd' else Gz)
         torch.cuda.synchronize()
-        if kind == 'fwd':
+        if kind == 'fwdp':
+            ops.check(lib.ams_blstm_ring_fwd_proj(p(x), D, p(Kf), p(Kb), ldu, p(bf), p(bb), p(G), p(out), p(cst[0]), p(cst[1]), p(Kf[D:]), p(Kb[D:]),
+                                                  ldu, p(sync), n, B, T, H, safe, st), 'fp')
+        elif kind == 'fwd':
             ops.check(lib.ams_blstm_ring_fwd(p(G), p(out), p(cst[0]), p(cst[1]), p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, B, T, H, safe, st), 'f')
         else:
             ops.check(lib.ams_blstm_ring_bwd(p(G), p(cst[0]), p(cst[1]), p(dout), None, p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, B, T, H, safe, st), 'b')
