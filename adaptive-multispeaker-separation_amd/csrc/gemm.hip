@@ -51,6 +51,7 @@ struct GemmArgs {
     int M, N, K;
     long lda, ldb, ldc;
     int accumulate;            // C += result
+    int nbatch;                // batch count (flat grid: batch x split x tile)
     // frames loader
     int fr_L, fr_T, fr_hop, fr_pl, fr_W;
     int group_m;                  // tile rows per band of the XCD-aware tile order
@@ -126,6 +127,9 @@ enum { EPI_STORE = 0, EPI_MAXPOOL = 1 };
 #ifndef AMS_GEMM_PF
 #define AMS_GEMM_PF 2      // round 2: beside the ring recurrence (csrc/lstm_ring.hip) the deeper prefetch pays in the step too: +5..6 % on every product alone, 13.47 -> 13.58 k mixtures/s
 #endif
+#ifndef AMS_GEMM_XCD_FLAT
+#define AMS_GEMM_XCD_FLAT 1
+#endif
 #ifndef AMS_GEMM_FRAG
 #define AMS_GEMM_FRAG 0
 #endif
@@ -133,13 +137,6 @@ template <int AMODE, int BMODE, int EPI = EPI_STORE, int BKT = AMS_GEMM_BK, bool
 __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g) {
     constexpr int BK = BKT, NLD = BK / 8, KQ = BK / 4;
     if (g.hiprio) __builtin_amdgcn_s_setprio(2);    // above a capped side-stream product sharing the CU, below the LSTM step kernels (3)
-    if (gridDim.z > 1) {                            // batched launch: same shape, shifted operands
-        const long z = blockIdx.z;
-        g.A += z * g.a_zs; g.B += z * g.b_zs; g.C += z * g.c_zs;
-        g.seg_off += z * g.seg_off_zs;
-        if (g.bias) g.bias += z * g.bias_zs;
-        if (g.partial) g.partial += z * (long)g.splits * g.M * g.N;
-    }
     constexpr bool AK = AKContig<AMODE>::v;
     constexpr bool BKc = (BMODE == B_COL);
     constexpr int LDA_S = BM + (AK ? PAD_T : PAD_V);
@@ -157,12 +154,41 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
     // form a near-square patch: they share group_m A row-panels and a few B column-panels in that XCD's private 4 MB L2.
     // Row-major runs re-fetched every B panel once per tile row: 971 MB of fabric reads for the 5120x10240x600 dense
     // product whose operands are 37 MB (rocprofv3 FETCH_SIZE, profiles/r01_c_hbm_traffic.txt).
+    //
+    // The grid is FLAT (1-D) over work items = (batch z, k-split, tile), batch outermost, tile innermost: the dispatcher deals
+    // consecutive workgroup ids round-robin to the XCDs, so XCD x receives the x-th contiguous run of that order -- with 8
+    // splits each XCD owns one k-slice of both operands (read once: ~1x algorithmic), with fewer splits a patch of one slice.
+    // (A (tiles, splits, batch) grid broke the b % 8 assumption for every y, z > 0 whenever tiles % 8 != 0: the weight-gradient
+    // products re-fetched their panels ~3x, profiles/r02_c_hbm_traffic.txt.)
     const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
     const int ntiles = tiles_m * tiles_n;
-    int bid = blockIdx.x;
+    int bid, split, zb;
     {
+        const int nz = g.nbatch > 1 ? g.nbatch : 1;
+        const int items = ntiles * g.splits * nz;               // == gridDim.x
+        int item = blockIdx.x;
+#if AMS_GEMM_XCD_FLAT
+        const int q = items / 8, r = items % 8, xcd = item % 8, idx = item / 8;
+        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        zb = item / (ntiles * g.splits);
+        item -= zb * (ntiles * g.splits);
+        split = item / ntiles;
+        bid = item - split * ntiles;
+#else
+        zb = item / (ntiles * g.splits);                       // round-1 order: per-(z, split) plane, tiles dealt by x % 8
+        item -= zb * (ntiles * g.splits);
+        split = item / ntiles;
+        bid = item - split * ntiles;
         const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+#endif
+    }
+    if (g.nbatch > 1) {                             // batched launch: same shape, shifted operands
+        const long z = zb;
+        g.A += z * g.a_zs; g.B += z * g.b_zs; g.C += z * g.c_zs;
+        g.seg_off += z * g.seg_off_zs;
+        if (g.bias) g.bias += z * g.bias_zs;
+        if (g.partial) g.partial += z * (long)g.splits * g.M * g.N;
     }
     const int GROUP_M = g.group_m > 0 ? g.group_m : 1;        // chosen per launch (choose_group_m)
     const int band = bid / (GROUP_M * tiles_n), within = bid - band * (GROUP_M * tiles_n);
@@ -171,7 +197,6 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
     const int tile_m = band * GROUP_M + (within - tile_n * band_rows);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
-    const int split = blockIdx.y;
     const int k_begin = split * g.k_per_split;
     const int k_end = min(g.K, k_begin + g.k_per_split);
     const int nk = (k_end - k_begin + BK - 1) / BK;
@@ -587,7 +612,8 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
     g.k_per_split = kps;
     g.partial = (float*)ws;
     g.bsum_part = bsum_out ? bsum_ws : nullptr;
-    dim3 grid(tiles, splits, nbatch);
+    g.nbatch = nbatch;
+    dim3 grid((unsigned)((long)tiles * splits * nbatch));
     const bool prio_off = tuning().noprio;
     g.hiprio = (t_gemm_lds_pad == 0 && !prio_off) ? 1 : 0;
     // Occupancy cap for launches that are meant to run BESIDE latency-critical kernels (weight-gradient products on

@@ -177,6 +177,29 @@ def main():
                 ops.PROFILE.enabled = False
             torch.cuda.current_stream().wait_stream(side)
             torch.cuda.synchronize()
+        # Per-launch durations above are taken INSIDE the step, where weight-gradient products share the chip with the ring
+        # recurrence and with each other (side stream, residency cap): two products that run side by side each look half as fast.
+        # The same launches timed ALONE (same model, same batches, side stream off, no cap) say what the kernel itself reaches.
+        alone = None
+        if prof_steps and args.roofline_steps:
+            from ams_hip import functional as F
+            was, main_prof = F.OVERLAP.enabled, ops.PROFILE
+            F.OVERLAP.enabled = False
+            ops.PROFILE = type(main_prof)()
+            was_graph = model.args.get('hip_graph')
+            model.args['hip_graph'] = False
+            try:
+                one_step(args.warmup + args.steps)
+                ops.PROFILE.reset(enabled=True)
+                for i in range(min(prof_steps, 3)):
+                    one_step(args.warmup + args.steps + 1 + i)
+                ops.PROFILE.enabled = False
+                torch.cuda.synchronize()
+                alone = {'steps': min(prof_steps, 3), 'family': ops.PROFILE.summary(prefix='gemm'),
+                         'by_tag': {t: ops.PROFILE.summary(t) for t in ops.PROFILE.tags() if t.startswith('gemm')}}
+            finally:
+                F.OVERLAP.enabled, ops.PROFILE = was, main_prof
+                model.args['hip_graph'] = was_graph
 
     el = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
     dist.all_reduce_max(el)
@@ -219,6 +242,19 @@ def main():
         if rj is not None and (B, L, N) == (64, 20480, 256):
             roof['replayed_region'] = {'file': rfile, 'counted_at_commit': (rj.get('_meta') or {}).get('commit'),
                                        'by_kernel': {k: v for k, v in rj.items() if k != '_meta'}}
+        if alone is not None and alone['family']['launches']:
+            fa = alone['family']
+            ach = fa['flops'] / (fa['ms'] * 1e-3) / 1e12
+            roof['standalone'] = {
+                'achieved': round(ach, 2), 'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4), 'unit': 'TFLOP/s',
+                'measured': 'HIP events around each launch, %d eager steps with the side stream off (no co-resident kernel, no residency '
+                            'cap): the kernel alone at the step\'s own shapes' % alone['steps'],
+                'by_variant': {'gemm_f32_kernel' + t[4:]: {'avg_launch_us': round(v['ms'] / v['launches'] * 1e3, 2),
+                                                            'TFLOP/s': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)}
+                               for t, v in alone['by_tag'].items() if v['launches']},
+                'sustained_mfma_ceiling_TFLOP/s': 125.0,
+                'ceiling_note': 'tools/mfma_peak.hip on the same boxes: dependent-free v_mfma_f32_32x32x2_f32 streams reach 152-156 TFLOP/s '
+                                'for ~100 us and settle at ~125 TFLOP/s when sustained (power management), DESIGN.md 4'}
         for tag in ops.PROFILE.tags():
             if not tag.startswith('gemm'):
                 continue

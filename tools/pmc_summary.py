@@ -7,6 +7,7 @@ the 128-byte fabric requests of wide coalesced reads at 64 B, so it is DOUBLED h
 (uncalibrated).  Infinity-Cache hits are counted, so 'traffic' is memory-side L2 traffic, an upper bound on DRAM bytes.
 """
 import json
+import re
 import sqlite3
 import sys
 
@@ -17,12 +18,17 @@ def per_kernel(path, counter):
                       (counter,)).fetchall()
     out = {}
     for name, gx, gy, v in rows:
-        out.setdefault(name, []).append(float(v))
+        # the fp32 product family runs many shapes under one name: keep them apart by launch grid
+        m = re.search(r'gemm_f32_kernel<[^>]*>', name)
+        key = name if m is None else '%s grid=%d' % (m.group(0), int(gx) // 256)
+        out.setdefault(key, []).append(float(v))
     return out
 
 
 def short(n):
     n = n.replace('(anonymous namespace)::', '').replace('void ', '')
+    if ' grid=' in n:
+        return n[:70]
     return n.split('(')[0][:70]
 
 

@@ -48,3 +48,35 @@ for mode, safe in (('plain stores (same L2)', 2), ('write-through', 3)):
         print('%s, %s: %.0f cycles per step' % (kind, mode, ph.sum()))
         for nm, v in zip(names[kind], ph):
             print('    %-34s %7.0f' % (nm, v))
+
+# ---- the backward ring BESIDE a residency-capped weight-gradient product (the situation inside the training step): which phases stretch?
+if '--beside' in sys.argv:
+    side = torch.cuda.Stream()
+    A = torch.randn(B * T, 2 * H, device='cuda')
+    Bm = torch.randn(B * T, 10240, device='cuda')
+    Cm = torch.empty(2 * H, 10240, device='cuda')
+    for pad in (50000, 70000, 0):
+        for kind in ('bwd', 'fwd'):
+            n = lib.ams_blstm_ring_sync_bytes(B, H, int(kind == 'bwd'))
+            sync = torch.zeros(n // 4 + 1, dtype=torch.float32, device='cuda')
+            G.copy_(G0 if kind == 'bwd' else Gz)
+            torch.cuda.synchronize()
+            with torch.cuda.stream(side):
+                lib.ams_gemm_set_lds_pad(pad)
+                for _ in range(3):
+                    ops.gemm(A, Bm, transA=True, out=Cm)
+                lib.ams_gemm_set_lds_pad(0)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            torch.cuda._sleep(200000)                         # let the product fill the chip first (~100 us)
+            e0.record()
+            if kind == 'bwd':
+                ops.check(lib.ams_blstm_ring_bwd(p(G), p(cst[0]), p(cst[1]), p(dout), None, p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, B, T, H, 2, st), 'b')
+            else:
+                ops.check(lib.ams_blstm_ring_fwd(p(G), p(out), p(cst[0]), p(cst[1]), p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, B, T, H, 2, st), 'f')
+            e1.record()
+            torch.cuda.synchronize()
+            w = sync[:64].view(torch.int64).cpu().numpy()
+            ph = w[8:8 + len(names[kind])] / float(T)
+            print('%s beside a dense dW product capped with a %d-byte LDS pad: %.0f cycles per step, launch %.0f us' % (kind, pad, ph.sum(), e0.elapsed_time(e1) * 1e3))
+            for nm, v in zip(names[kind], ph):
+                print('    %-34s %7.0f' % (nm, v))
