@@ -14,6 +14,7 @@
 // Algorithmic bytes per pass: L*E*4 per row (+ L*4 weights); x[b] is shared by the `tries` rows of an utterance
 // through L2.
 #include "common.h"
+#include <type_traits>
 // Bit-exact parity with oracle/kmeans.py needs IEEE mul/add (no FMA contraction), sqrt and divide: contraction is
 // switched off for this translation unit (see Makefile) and sqrtf / operator/ are the correctly rounded forms
 // (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).  NB: without OCML_BASIC_ROUNDED_OPERATIONS the
@@ -72,6 +73,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // running sum keeps its left-to-right scalar order, so the result is bit-identical to the scalar formulation.
 // __launch_bounds__(256, 3): at least 3 waves per SIMD, i.e. <= 168 VGPRs -- without the bound hipcc settles at 222-256 registers
 // (2 waves, or 1) by hoisting the slab's LDS reads and the centroids into registers.
+#ifndef AMS_KM_SGPR_CENT
+#define AMS_KM_SGPR_CENT 1
+#endif
 template <int E_, int C_, int MODE, bool HAS_W>
 __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? 3 : 1) void kmeans_pass_kernel(KmArgs a) {
     static_assert(E_ % 4 == 0, "rows are staged as 16-byte vectors");
@@ -88,6 +92,17 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? 3 :
     const float* xb = a.xn + (long)bi * a.L * E_;
     const float* wb = HAS_W ? a.w + (long)(a.w_mod_b ? (r % a.b) : bi) * a.L : nullptr;
     for (int i = tid; i < C_ * E_; i += 256) scent[i] = a.cent[(long)r * C_ * E_ + i];
+#if AMS_KM_SGPR_CENT
+    // HARD modes: the row's centroids are wave-uniform -> held in SGPRs (C*E = 80 scalars at E = 40, C = 2) and fed to the packed
+    // VALU operations as scalar operands.  As LDS broadcast reads they were 40 ds_read_b64 per point and try beside the 20
+    // ds_read_b128 of the point itself: the pass was LDS-issue-bound (~120 us of LDS pipe per pass against ~90 us of VALU).
+    float cs[SOFT ? 1 : C_ * E_];
+    if (!SOFT) {
+        const float* cg = a.cent + (long)r * C_ * E_;
+#pragma unroll
+        for (int i = 0; i < C_ * E_; ++i) cs[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cg[i])));
+    }
+#endif
 
     float acc[NV];
 #pragma unroll
@@ -147,11 +162,11 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? 3 :
                     x[(q * 4 + 2) % (SOFT ? E_ : 1)] = v.z; x[(q * 4 + 3) % (SOFT ? E_ : 1)] = v.w;
                 }
             }
-            // without silence weights the HARD modes still multiply by w = a.one (x * 1 == x bit for bit): the multiply-free form of
-            // the same loops made hipcc spill 85 registers under the 168-VGPR bound (8.6 ms instead of 3.7 ms per 10 x 10 run)
-            const float wv = HAS_W ? wb[p0 + tid] : (SOFT ? 1.0f : a.one);
+            // without silence weights the reference multiplies by w = 1 (x * 1 == x bit for bit): the multiplies are dropped.  (That form
+            // used to spill 85 registers under the 168-VGPR bound -- see the note on the running sums below -- and the kernel
+            // multiplied by an opaque 1.0f instead.)
+            const float wv = HAS_W ? wb[p0 + tid] : 1.0f;
             const f2 wv2 = {wv, wv};
-            constexpr bool MULW = HAS_W || !SOFT;
             float d2[C_];
             if (SOFT) {
 #pragma unroll
@@ -170,28 +185,46 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? 3 :
                     d2[c] = d;
                 }
             } else {
+                // WT = per-term weights (d2 = sum_e w (x - c)^2, Kmeans_2.py:175-181); without weights the loop is multiply-free
+                auto dist = [&](auto WT) {
+                    constexpr bool W = decltype(WT)::value;
 #pragma unroll
-                for (int c = 0; c < C_; ++c) d2[c] = 0.f;
+                    for (int c = 0; c < C_; ++c) d2[c] = 0.f;
 #pragma unroll
-                for (int q4 = 0; q4 < V4; ++q4) {              // q outer, c inner: each d2[c] still adds its terms in e order
-                    asm volatile("" ::: "memory");              // LDS operands just in time: no wholesale preload into VGPRs
-                    const float4 v = *reinterpret_cast<const float4*>(xrow + q4 * 4);
+                    for (int q4 = 0; q4 < V4; ++q4) {              // q outer, c inner: each d2[c] still adds its terms in e order
+                        asm volatile("" ::: "memory");              // LDS operands just in time: no wholesale preload into VGPRs
+                        // ... and the running sums are DUE here: the squares of all ten groups are independent while each d2[c] is one
+                        // serial chain, so the scheduler computed every square first (80 live registers, 72-105 spilled under the
+                        // 168-VGPR bound) and ran the add chains at the end
 #pragma unroll
-                    for (int c = 0; c < C_; ++c) {
-                        const f2 c0 = *reinterpret_cast<const f2*>(&scent[c * E_ + 4 * q4]);
-                        const f2 c1 = *reinterpret_cast<const f2*>(&scent[c * E_ + 4 * q4 + 2]);
-                        const f2 x0 = {v.x, v.y}, x1 = {v.z, v.w};
-                        const f2 df0 = x0 - c0, df1 = x1 - c1;
-                        f2 s0 = df0 * df0, s1 = df1 * df1;
-                        if (MULW) { s0 = s0 * wv2; s1 = s1 * wv2; }
-                        float d = d2[c];
-                        d = __fadd_rn(d, s0.x);
-                        d = __fadd_rn(d, s0.y);
-                        d = __fadd_rn(d, s1.x);
-                        d = __fadd_rn(d, s1.y);
-                        d2[c] = d;
+                        for (int c = 0; c < C_; ++c) if (!W) asm volatile("" : "+v"(d2[c]));      // the weighted form fits as scheduled
+                        const float4 v = *reinterpret_cast<const float4*>(xrow + q4 * 4);
+#pragma unroll
+                        for (int c = 0; c < C_; ++c) {
+#if AMS_KM_SGPR_CENT
+                            const f2 c0 = {cs[(c * E_ + 4 * q4) % (SOFT ? 1 : C_ * E_)], cs[(c * E_ + 4 * q4 + 1) % (SOFT ? 1 : C_ * E_)]};
+                            const f2 c1 = {cs[(c * E_ + 4 * q4 + 2) % (SOFT ? 1 : C_ * E_)], cs[(c * E_ + 4 * q4 + 3) % (SOFT ? 1 : C_ * E_)]};
+#else
+                            const f2 c0 = *reinterpret_cast<const f2*>(&scent[c * E_ + 4 * q4]);
+                            const f2 c1 = *reinterpret_cast<const f2*>(&scent[c * E_ + 4 * q4 + 2]);
+#endif
+                            const f2 x0 = {v.x, v.y}, x1 = {v.z, v.w};
+                            const f2 df0 = x0 - c0, df1 = x1 - c1;
+                            f2 s0 = df0 * df0, s1 = df1 * df1;
+                            if (W) { s0 = s0 * wv2; s1 = s1 * wv2; }
+                            float d = d2[c];
+                            d = __fadd_rn(d, s0.x);
+                            d = __fadd_rn(d, s0.y);
+                            d = __fadd_rn(d, s1.x);
+                            d = __fadd_rn(d, s1.y);
+                            d2[c] = d;
+                        }
                     }
-                }
+                };
+                // (a 0/1 weight could be folded into one multiply per point -- w * sum == sum of w * terms bit for bit -- with the
+                // per-term loop kept for other values; both loops in one kernel spill 21-72 VGPRs under the 168 bound and the
+                // pass gets slower, 3.54 vs 3.39 ms per 10 x 10 run: measured, not used)
+                if (HAS_W) dist(std::true_type{}); else dist(std::false_type{});
             }
             if (!SOFT) {
                 int lab = 0;
@@ -209,23 +242,27 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? 3 :
                         mm[c] = (f2){m, m};
                         acc[C_ * E_ + c] = __fadd_rn(acc[C_ * E_ + c], m);
                     }
+                    auto accum = [&](auto WT) {
+                        constexpr bool W = decltype(WT)::value;
 #pragma unroll
-                    for (int q4 = 0; q4 < V4; ++q4) {
-                        asm volatile("" ::: "memory");
-                        const float4 v = *reinterpret_cast<const float4*>(xrow + q4 * 4);
-                        f2 t0 = {v.x, v.y}, t1 = {v.z, v.w};
-                        if (MULW) { t0 = t0 * wv2; t1 = t1 * wv2; }
+                        for (int q4 = 0; q4 < V4; ++q4) {
+                            asm volatile("" ::: "memory");
+                            const float4 v = *reinterpret_cast<const float4*>(xrow + q4 * 4);
+                            f2 t0 = {v.x, v.y}, t1 = {v.z, v.w};
+                            if (W) { t0 = t0 * wv2; t1 = t1 * wv2; }
 #pragma unroll
-                        for (int c = 0; c < C_; ++c) {
-                            f2 a0 = {acc[c * E_ + 4 * q4], acc[c * E_ + 4 * q4 + 1]};
-                            f2 a1 = {acc[c * E_ + 4 * q4 + 2], acc[c * E_ + 4 * q4 + 3]};
-                            // m is 0 or 1, so t * m is exact and the fused form rounds exactly like multiply-then-add
-                            a0 = __builtin_elementwise_fma(t0, mm[c], a0);
-                            a1 = __builtin_elementwise_fma(t1, mm[c], a1);
-                            acc[c * E_ + 4 * q4] = a0.x; acc[c * E_ + 4 * q4 + 1] = a0.y;
-                            acc[c * E_ + 4 * q4 + 2] = a1.x; acc[c * E_ + 4 * q4 + 3] = a1.y;
+                            for (int c = 0; c < C_; ++c) {
+                                f2 a0 = {acc[c * E_ + 4 * q4], acc[c * E_ + 4 * q4 + 1]};
+                                f2 a1 = {acc[c * E_ + 4 * q4 + 2], acc[c * E_ + 4 * q4 + 3]};
+                                // m is 0 or 1, so t * m is exact and the fused form rounds exactly like multiply-then-add
+                                a0 = __builtin_elementwise_fma(t0, mm[c], a0);
+                                a1 = __builtin_elementwise_fma(t1, mm[c], a1);
+                                acc[c * E_ + 4 * q4] = a0.x; acc[c * E_ + 4 * q4 + 1] = a0.y;
+                                acc[c * E_ + 4 * q4 + 2] = a1.x; acc[c * E_ + 4 * q4 + 3] = a1.y;
+                            }
                         }
-                    }
+                    };
+                    if (HAS_W) accum(std::true_type{}); else accum(std::false_type{});
                 } else {
                     // inertia terms: unweighted distance to the assigned centroid (Kmeans_2.py:131-136)
                     float dist = 0.f;

@@ -156,14 +156,21 @@ def test_l41_loss(F, normalize):
 
 
 @pytest.mark.parametrize('b,L,E,C,tries,with_w,end', [(3, 5000, 40, 2, 2, False, True), (2, 4100, 40, 3, 3, True, False),
-                                                       (2, 2500, 8, 2, 1, True, True), (1, 20480, 40, 2, 2, False, True)])
+                                                       (2, 2500, 8, 2, 1, True, True), (1, 20480, 40, 2, 2, False, True),
+                                                       (2, 4100, 40, 2, 3, 'real', False), (2, 3000, 40, 2, 2, 'mixed', True)])
 def test_kmeans_hard_bit_exact(F, ops, b, L, E, C, tries, with_w, end):
-    """Labels must be IDENTICAL to the float32 oracle (same summation order, no FMA, IEEE sqrt/div)."""
+    """Labels must be IDENTICAL to the float32 oracle (same summation order, no FMA, IEEE sqrt/div).  with_w True = the 0/1
+    silence mask the reference builds (Kmeans_2.py:76-82; the kernel folds such a weight into one multiply per point); 'real' /
+    'mixed' = arbitrary positive weights on every / every third point (the per-term form of Kmeans_2.py:175-181)."""
     rng = np.random.RandomState(L + C)
     centers = rng.randn(C, E).astype(np.float32) * 2.0
     lab_true = rng.randint(0, C, (b, L))
     X = (centers[lab_true] + rng.randn(b, L, E).astype(np.float32) * 0.7).astype(np.float32)
     w = (rng.rand(b, L) > 0.2).astype(np.float32) if with_w else None
+    if with_w == 'real':
+        w = rng.uniform(0.05, 1.7, (b, L)).astype(np.float32)
+    elif with_w == 'mixed':
+        w[:, ::3] = rng.uniform(0.05, 1.7, (b, L))[:, ::3].astype(np.float32)
     idx = np.stack([rng.choice(L, C, replace=False) for _ in range(b * tries)]).astype(np.int32)
     cent_ref, lab_ref, best_ref = okm.kmeans(X, idx, C, tries, 4, beta=None, notsilent=w, assign_at_end=end)
     xn = ops.kmeans_normalize(dev(X))
