@@ -649,6 +649,22 @@ class L41Loss(Function):
         return demb, None, dvs
 
 
+class L41LossNS(Function):
+    """models/L41.py:150-178 plus the negative-sampling term (:143-147,165-166) on gathered vectors."""
+
+    @staticmethod
+    def forward(ctx, emb, y, vspk, negs, ns_rate):
+        ctx.save_for_backward(emb, y, vspk, negs)
+        ctx.ns_rate = float(ns_rate)
+        return ops.l41_loss_ns_fwd(emb, y, vspk, negs, ns_rate)
+
+    @staticmethod
+    def backward(ctx, g):
+        emb, y, vspk, negs = ctx.saved_tensors
+        demb, dvs, dnegs = ops.l41_loss_ns_bwd(emb, y, vspk, negs, _c(g), ctx.ns_rate)
+        return demb, None, dvs, dnegs, None
+
+
 class L41Speakers(Function):
     """tf.nn.l2_normalize(speaker_centroids, 1) + gather_nd by I (models/L41.py:60-68); backward scatters through the
     normalise Jacobian in a fixed order."""
@@ -666,12 +682,43 @@ class L41Speakers(Function):
         return ops.l41_speaker_bwd(table, I32, _c(d_vs), ctx.normalize), None, None
 
 
-def l41_loss(emb, y, speaker_vectors, I, normalize):
-    """emb [B,T,F,E], y [B,T,F,S]; speaker_vectors [251,E], I [B,S]."""
+def l41_knearest(speaker_vectors, I, K, normalize):
+    """Indices [B,S,K] of the K rows of the (normalised) speaker table nearest to each mixture speaker (L41.py:95-104: tf.nn.top_k
+    of the dot products; the speaker itself is among them).  Index selection only -- no gradient (TF's top_k indices carry none)."""
+    with torch.no_grad():
+        table = speaker_vectors.detach()
+        if normalize:
+            table = table * torch.rsqrt(torch.clamp((table * table).sum(1, keepdim=True), min=1e-12))
+        prod = table[I.long()] @ table.t()                                            # [B,S,|S|]
+        return torch.topk(prod, int(K), dim=2, sorted=False).indices.to(torch.int32).contiguous()
+
+
+def l41_random_negatives(I, tot_speakers, K):
+    """Indices [B,1,K]: K speakers drawn without replacement among those NOT in the mixture, one set per utterance (L41.py:123-134,
+    tf.random_shuffle of the available indices, first K).  Drawn on the device from torch's generator (graph-capturable, advances
+    on every replay); TensorFlow's own stream is not reproducible -- the distribution (a uniform K-subset) is."""
+    B = I.shape[0]
+    score = torch.rand(B, int(tot_speakers), device=I.device)
+    score.scatter_(1, I.long(), 2.0)                                                   # mixture speakers sort last
+    return torch.topk(score, int(K), dim=1, largest=False).indices.to(torch.int32).reshape(B, 1, int(K)).contiguous()
+
+
+def l41_loss(emb, y, speaker_vectors, I, normalize, neg_idx=None, ns_rate=0.1):
+    """emb [B,T,F,E], y [B,T,F,S]; speaker_vectors [251,E], I [B,S].  neg_idx (optional, int [B,NSEL,K], NSEL = 1 or S): rows of the
+    speaker table used as negatives (--sampling, L41.py:69-147): the cost gains ns_rate * mean_k -log(sigmoid(-<neg_k, emb>))."""
     B, E = emb.shape[0], emb.shape[-1]
     S = y.shape[-1]
-    vs = L41Speakers.apply(_c(speaker_vectors), I, bool(normalize))                  # [B,S,E]
-    return L41Loss.apply(_c(emb).reshape(B, -1, E), _c(y).reshape(B, -1, S), vs)
+    table = _c(speaker_vectors)
+    if neg_idx is None:
+        vs = L41Speakers.apply(table, I, bool(normalize))                             # [B,S,E]
+        return L41Loss.apply(_c(emb).reshape(B, -1, E), _c(y).reshape(B, -1, S), vs)
+    NSEL, K = neg_idx.shape[1], neg_idx.shape[2]
+    # ONE gather through the normalise Jacobian for the mixture speakers and the negatives: [B, S + NSEL*K, E]
+    allidx = torch.cat([I.to(torch.int32).reshape(B, S), neg_idx.to(torch.int32).reshape(B, NSEL * K)], dim=1).contiguous()
+    allv = L41Speakers.apply(table, allidx, bool(normalize))
+    vs = allv[:, :S].contiguous()
+    negs = allv[:, S:].reshape(B, NSEL, K, E).contiguous()
+    return L41LossNS.apply(_c(emb).reshape(B, -1, E), _c(y).reshape(B, -1, S), vs, negs, float(ns_rate))
 
 
 class EnhanceOutput(Function):

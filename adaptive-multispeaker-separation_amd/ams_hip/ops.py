@@ -966,6 +966,35 @@ def l41_loss_bwd(emb, y, vspk, upstream):
     return demb, dvs
 
 
+def l41_loss_ns_fwd(emb, y, vspk, negs, ns_rate):
+    """L41 loss with negative sampling (L41.py:69-147,165-166): negs [B,NSEL,K,E], NSEL = 1 or S."""
+    _chk(emb, y, vspk, negs)
+    lib = load()
+    B, TF, E = emb.shape
+    S = y.shape[2]
+    NSEL, K = negs.shape[1], negs.shape[2]
+    nb = lib.ams_l41_ns_workspace_bytes(B, TF, E, S, NSEL, K)
+    ws = _ws(nb, emb)
+    cost = torch.empty(1, dtype=torch.float32, device=emb.device)
+    check(lib.ams_l41_loss_ns_fwd(_p(emb), _p(y), _p(vspk), _p(negs), _p(cost), B, TF, E, S, NSEL, K, float(ns_rate), _p(ws), nb, _s()),
+          'ams_l41_loss_ns_fwd')
+    return cost
+
+
+def l41_loss_ns_bwd(emb, y, vspk, negs, upstream, ns_rate):
+    _chk(emb, y, vspk, negs, upstream)
+    lib = load()
+    B, TF, E = emb.shape
+    S = y.shape[2]
+    NSEL, K = negs.shape[1], negs.shape[2]
+    nb = lib.ams_l41_ns_workspace_bytes(B, TF, E, S, NSEL, K)
+    ws = _ws(nb, emb)
+    demb, dvs, dnegs = torch.empty_like(emb), torch.empty_like(vspk), torch.empty_like(negs)
+    check(lib.ams_l41_loss_ns_bwd(_p(emb), _p(y), _p(vspk), _p(negs), _p(upstream), _p(demb), _p(dvs), _p(dnegs), B, TF, E, S, NSEL, K,
+                                  float(ns_rate), _p(ws), nb, _s()), 'ams_l41_loss_ns_bwd')
+    return demb, dvs, dnegs
+
+
 # ------------------------------------------------------------------ k-means
 def kmeans_normalize(x):
     _chk(x)

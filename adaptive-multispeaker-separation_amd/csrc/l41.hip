@@ -3,35 +3,55 @@
 // The reference broadcasts a [B,T,F,S,E] temporary (420 MB at the benchmark shape); here emb is streamed once per
 // pass, thread-per-point with the S speaker vectors in LDS, points transposed through LDS for coalesced traffic.
 // HBM-bound: algorithmic bytes = TF*(E+S)*4 per utterance forward, + TF*E*4 written backward.
+//
+// Negative sampling (`--sampling K`, models/L41.py:69-147,165-166): K further (already gathered / normalised) speaker vectors
+// per bin enter with label -1 and weight ns_rate / K:  cost[b,t,f] += ns_rate * mean_k -log(sigmoid(-<neg_k, emb>)).  The caller
+// passes negs [B, NSEL, K, E]: NSEL = 1 -- one set per utterance ('random', :117-139) -- or NSEL = S -- the set of the bin's
+// dominant speaker argmax_s y ('k-nearest', :91-116).  Same kernel, same pass over emb.
 #include "common.h"
 
 namespace {
 
 constexpr int MAXS = 4;
+constexpr int MAXK = 16;          // negatives per set
+constexpr int MAXN = 32;          // NSEL * K
 
 __device__ __forceinline__ float softplus_neg(float z) {      // -log(sigmoid(z)) = log(1 + exp(-z)), stable
     return z > 0.f ? log1pf(expf(-z)) : -z + log1pf(expf(z));
 }
 
-template <int E_, bool BWD>
+struct NegArgs {
+    const float* negs;            // [B, NSEL, K, E]; nullptr = no negative sampling
+    float* dneg_part;             // [B, nblk, NSEL*K*E] (backward)
+    int NSEL, K;
+    float wn;                     // ns_rate * S / K: weight of one negative term relative to one speaker term
+};
+
+template <int E_, bool BWD, bool NEG>
 __global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb, const float* __restrict__ y,
                                                   const float* __restrict__ vs, const float* __restrict__ upstream,
                                                   float* __restrict__ part, float* __restrict__ demb, float* __restrict__ dvs_part,
-                                                  long TF, int S, int nblk, float scale) {
+                                                  long TF, int S, int nblk, float scale, NegArgs na) {
     constexpr int LD = E_ + 1;
     __shared__ float tile[256 * LD];
     __shared__ float svs[MAXS * E_];
     __shared__ float red[4][MAXS * E_ + 1];
+    __shared__ float sneg[NEG ? MAXN * E_ : 1];
+    __shared__ float sdz[NEG && BWD ? 256 * MAXK : 1];          // d cost / d <neg_k, emb> of every point
+    __shared__ int ssel[NEG && BWD ? 256 : 1];
     const int b = blockIdx.y, tid = threadIdx.x;
     const long p0 = (long)blockIdx.x * 256;
     const int npts = (int)min((long)256, TF - p0);
     const float* eb = emb + ((long)b * TF + p0) * E_;
     for (int i = tid; i < npts * E_; i += 256) tile[(i / E_) * LD + (i % E_)] = eb[i];
     for (int i = tid; i < S * E_; i += 256) svs[i] = vs[(long)b * S * E_ + i];
+    if (NEG)
+        for (int i = tid; i < na.NSEL * na.K * E_; i += 256) sneg[i] = na.negs[(long)b * na.NSEL * na.K * E_ + i];
     __syncthreads();
     float cost = 0.f;
     float dz[MAXS] = {0.f, 0.f, 0.f, 0.f};
     float v[E_];
+    int sel = 0;
     if (tid < npts) {
 #pragma unroll
         for (int e = 0; e < E_; ++e) v[e] = tile[tid * LD + e];
@@ -45,6 +65,21 @@ __global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb,
             cost += softplus_neg(z);
             if (BWD) dz[s] = -ys * up / (1.0f + expf(z));          // d/d dot of -log sigmoid(y dot) = -y sigmoid(-z)
         }
+        if (NEG) {
+            if (na.NSEL > 1) {                                     // dominant speaker: first maximum of y (tf.argmax, L41.py:75)
+                float best = yp[0];
+                for (int s = 1; s < S; ++s) { const float ys = yp[s]; if (ys > best) { best = ys; sel = s; } }
+            }
+            for (int k = 0; k < na.K; ++k) {
+                const float* nv = &sneg[(sel * na.K + k) * E_];
+                float dot = 0.f;
+#pragma unroll
+                for (int e = 0; e < E_; ++e) dot += v[e] * nv[e];
+                cost += na.wn * softplus_neg(-dot);
+                if (BWD) sdz[tid * MAXK + k] = na.wn * up / (1.0f + expf(-dot));       // d/d dot of -log sigmoid(-dot) = sigmoid(dot)
+            }
+            if (BWD) ssel[tid] = sel;
+        }
     }
     if (!BWD) {
         cost = wave_sum(cost);
@@ -55,11 +90,26 @@ __global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb,
     }
     // backward: demb = sum_s dz_s * Vs_s ; dVs_s += dz_s * emb (block partial)
     __syncthreads();
+    if (NEG) {
+        // d negs of this block: output (set j, negative k, e) = sum over the block's points that used set j, in point order
+        // (fixed order -> deterministic); `tile` still holds emb here
+        const int nout = na.NSEL * na.K * E_;
+        for (int o = tid; o < nout; o += 256) {
+            const int e = o % E_, jk = o / E_, k = jk % na.K, j = jk / na.K;
+            float acc = 0.f;
+            for (int p = 0; p < npts; ++p)
+                if (ssel[p] == j) acc += sdz[p * MAXK + k] * tile[p * LD + e];
+            na.dneg_part[((long)b * nblk + blockIdx.x) * nout + o] = acc;
+        }
+        __syncthreads();
+    }
     if (tid < npts) {
 #pragma unroll
         for (int e = 0; e < E_; ++e) {
             float d = 0.f;
             for (int s = 0; s < S; ++s) d += dz[s] * svs[s * E_ + e];
+            if (NEG)
+                for (int k = 0; k < na.K; ++k) d += sdz[tid * MAXK + k] * sneg[(sel * na.K + k) * E_ + e];
             tile[tid * LD + e] = d;
         }
     }
@@ -105,16 +155,16 @@ size_t ams_l41_workspace_bytes(int B, long TF, int E, int S) {
     return sizeof(float) * (size_t)B * nblk * (S * E > 1 ? S * E : 1);
 }
 
-#define AMS_L41_DISPATCH(BWD, ...)                                                                       \
-    switch (E) {                                                                                         \
-        case 40: hipLaunchKernelGGL((l41_kernel<40, BWD>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
-        case 32: hipLaunchKernelGGL((l41_kernel<32, BWD>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
-        case 20: hipLaunchKernelGGL((l41_kernel<20, BWD>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
-        case 16: hipLaunchKernelGGL((l41_kernel<16, BWD>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
-        case 8: hipLaunchKernelGGL((l41_kernel<8, BWD>), grid, dim3(256), 0, st, __VA_ARGS__); break;     \
-        case 4: hipLaunchKernelGGL((l41_kernel<4, BWD>), grid, dim3(256), 0, st, __VA_ARGS__); break;     \
-        case 3: hipLaunchKernelGGL((l41_kernel<3, BWD>), grid, dim3(256), 0, st, __VA_ARGS__); break;     \
-        default: return AMS_E_INVALID_ARG;                                                               \
+#define AMS_L41_DISPATCH(BWD, NEG, ...)                                                                       \
+    switch (E) {                                                                                              \
+        case 40: hipLaunchKernelGGL((l41_kernel<40, BWD, NEG>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 32: hipLaunchKernelGGL((l41_kernel<32, BWD, NEG>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 20: hipLaunchKernelGGL((l41_kernel<20, BWD, NEG>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 16: hipLaunchKernelGGL((l41_kernel<16, BWD, NEG>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
+        case 8: hipLaunchKernelGGL((l41_kernel<8, BWD, NEG>), grid, dim3(256), 0, st, __VA_ARGS__); break;     \
+        case 4: hipLaunchKernelGGL((l41_kernel<4, BWD, NEG>), grid, dim3(256), 0, st, __VA_ARGS__); break;     \
+        case 3: hipLaunchKernelGGL((l41_kernel<3, BWD, NEG>), grid, dim3(256), 0, st, __VA_ARGS__); break;     \
+        default: return AMS_E_INVALID_ARG;                                                                    \
     }
 
 // emb [B,TF,E], y [B,TF,S] (+1/-1), vspk [B,S,E] (already gathered / normalised) -> cost[0]
@@ -126,7 +176,7 @@ ams_status ams_l41_loss_fwd(const float* emb, const float* y, const float* vspk,
     const int nblk = ceil_div(TF, 256);
     dim3 grid(nblk, B);
     const float scale = 1.0f / ((float)B * (float)TF * S);
-    AMS_L41_DISPATCH(false, emb, y, vspk, (const float*)nullptr, (float*)ws, (float*)nullptr, (float*)nullptr, TF, S, nblk, scale)
+    AMS_L41_DISPATCH(false, false, emb, y, vspk, (const float*)nullptr, (float*)ws, (float*)nullptr, (float*)nullptr, TF, S, nblk, scale, NegArgs{})
     hipLaunchKernelGGL(l41_cost_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, cost, (long)B * nblk, scale);
     return ams_check_launch();
 }
@@ -140,8 +190,50 @@ ams_status ams_l41_loss_bwd(const float* emb, const float* y, const float* vspk,
     const int nblk = ceil_div(TF, 256);
     dim3 grid(nblk, B);
     const float scale = 1.0f / ((float)B * (float)TF * S);
-    AMS_L41_DISPATCH(true, emb, y, vspk, upstream, (float*)nullptr, demb, (float*)ws, TF, S, nblk, scale)
+    AMS_L41_DISPATCH(true, false, emb, y, vspk, upstream, (float*)nullptr, demb, (float*)ws, TF, S, nblk, scale, NegArgs{})
     hipLaunchKernelGGL(l41_dvs_final_kernel, dim3(ceil_div(B * S * E, 256)), dim3(256), 0, st, (const float*)ws, dvspk, nblk, S * E, B);
+    return ams_check_launch();
+}
+
+// ---- the same loss with negative sampling (models/L41.py:69-147,165-166).  negs [B,NSEL,K,E]: NSEL = 1 or S, NSEL * K <= 32, K <= 16.
+size_t ams_l41_ns_workspace_bytes(int B, long TF, int E, int S, int NSEL, int K) {
+    const int nblk = ceil_div(TF, 256);
+    return sizeof(float) * (size_t)B * nblk * ((size_t)S * E + (size_t)NSEL * K * E);
+}
+
+ams_status ams_l41_loss_ns_fwd(const float* emb, const float* y, const float* vspk, const float* negs, float* cost, int B, long TF, int E,
+                               int S, int NSEL, int K, float ns_rate, void* ws, size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(emb && y && vspk && negs && cost && ws && B > 0 && TF > 0 && S > 0 && S <= MAXS);
+    AMS_REQUIRE((NSEL == 1 || NSEL == S) && K > 0 && K <= MAXK && NSEL * K <= MAXN);
+    if (ws_bytes < ams_l41_ns_workspace_bytes(B, TF, E, S, NSEL, K)) return AMS_E_WORKSPACE_TOO_SMALL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = ceil_div(TF, 256);
+    dim3 grid(nblk, B);
+    const float scale = 1.0f / ((float)B * (float)TF * S);
+    NegArgs na{negs, nullptr, NSEL, K, ns_rate * (float)S / (float)K};
+    AMS_L41_DISPATCH(false, true, emb, y, vspk, (const float*)nullptr, (float*)ws, (float*)nullptr, (float*)nullptr, TF, S, nblk, scale, na)
+    hipLaunchKernelGGL(l41_cost_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, cost, (long)B * nblk, scale);
+    return ams_check_launch();
+}
+
+// demb [B,TF,E], dvspk [B,S,E], dnegs [B,NSEL,K,E]
+ams_status ams_l41_loss_ns_bwd(const float* emb, const float* y, const float* vspk, const float* negs, const float* upstream, float* demb,
+                               float* dvspk, float* dnegs, int B, long TF, int E, int S, int NSEL, int K, float ns_rate, void* ws,
+                               size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(emb && y && vspk && negs && upstream && demb && dvspk && dnegs && ws && B > 0 && TF > 0 && S > 0 && S <= MAXS);
+    AMS_REQUIRE((NSEL == 1 || NSEL == S) && K > 0 && K <= MAXK && NSEL * K <= MAXN);
+    if (ws_bytes < ams_l41_ns_workspace_bytes(B, TF, E, S, NSEL, K)) return AMS_E_WORKSPACE_TOO_SMALL;
+    hipStream_t st = (hipStream_t)stream;
+    const int nblk = ceil_div(TF, 256);
+    dim3 grid(nblk, B);
+    const float scale = 1.0f / ((float)B * (float)TF * S);
+    float* dvs_part = (float*)ws;
+    float* dneg_part = dvs_part + (size_t)B * nblk * S * E;
+    NegArgs na{negs, dneg_part, NSEL, K, ns_rate * (float)S / (float)K};
+    AMS_L41_DISPATCH(true, true, emb, y, vspk, upstream, (float*)nullptr, demb, dvs_part, TF, S, nblk, scale, na)
+    hipLaunchKernelGGL(l41_dvs_final_kernel, dim3(ceil_div(B * S * E, 256)), dim3(256), 0, st, (const float*)dvs_part, dvspk, nblk, S * E, B);
+    const int NE = NSEL * K * E;
+    hipLaunchKernelGGL(l41_dvs_final_kernel, dim3(ceil_div(B * NE, 256)), dim3(256), 0, st, (const float*)dneg_part, dnegs, nblk, NE, B);
     return ams_check_launch();
 }
 

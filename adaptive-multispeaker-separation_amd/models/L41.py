@@ -17,7 +17,13 @@ class L41Model(Separator):
         super(L41Model, self).__init__(graph, **kwargs)
 
         if self.sampling is not None:
-            raise NotImplementedError('--sampling (negative sampling, L41.py:69-147) is off by default and not on the HIP path')
+            # negative sampling (L41.py:69-147): limits of the loss kernel (csrc/l41.hip)
+            K, S = int(self.sampling), int(self.S)
+            if K < 1 or K > 16 or (self.ns_method == 'k-nearest' and S * K > 32):
+                raise ValueError('--sampling %d: the L41 loss kernel takes 1..16 negatives per set and at most 32 per utterance '
+                                 '(nb_speakers * sampling for k-nearest)' % K)
+            if K > self.num_speakers - (0 if self.ns_method == 'k-nearest' else S):
+                raise ValueError('--sampling %d exceeds the speakers available (%d)' % (K, self.num_speakers))
 
         # Define the speaker vectors to use during training (L41.py:16-18): truncated normal, stddev sqrt(2/E)
         E = self.embedding_size
@@ -55,11 +61,19 @@ class L41Model(Separator):
 
     @scope
     def cost(self):
-        # L41.py:47-186 (sampling=None)
+        # L41.py:47-186; --sampling K adds ns_rate * mean_k -log(sigmoid(-<neg_k, emb>)) per bin (:69-147,165-166)
         pred, y, I, spk, normalize = self.prediction, self.y, self.I, self.speaker_vectors, self.normalize
+        sampling, ns_rate, ns_method, tot = self.sampling, self.ns_rate, self.ns_method, self.num_speakers
 
         def _cost(run):
-            return F.l41_loss(pred.value(run), y.value(run), spk, I.value(run), normalize)
+            Iv = I.value(run)
+            neg = None
+            if sampling is not None:
+                if ns_method == 'k-nearest':
+                    neg = F.l41_knearest(spk, Iv, sampling, normalize)                 # [B,S,K], set of the bin's dominant speaker
+                else:
+                    neg = F.l41_random_negatives(Iv, tot, sampling)                    # [B,1,K], one set per utterance
+            return F.l41_loss(pred.value(run), y.value(run), spk, Iv, normalize, neg_idx=neg, ns_rate=ns_rate)
         cost = Node('cost_value', _cost)
         get_default_graph().summaries['cost/cost'] = cost
         return cost

@@ -261,6 +261,17 @@ ams_status ams_l41_loss_fwd(const float* emb, const float* y, const float* vspk,
                             size_t ws_bytes, void* stream);
 ams_status ams_l41_loss_bwd(const float* emb, const float* y, const float* vspk, const float* upstream, float* demb, float* dvspk,
                             int B, long TF, int E, int S, void* ws, size_t ws_bytes, void* stream);
+/* ... with negative sampling (--sampling K)   models/L41.py:69-147,165-166:
+ *   cost[b,t,f] += ns_rate * mean_k -log(sigmoid(-<negs[b, sel, k, :], emb[b,t,f,:]>))
+ * negs [B,NSEL,K,E] = rows of the (normalised) speaker table the caller gathered: NSEL = 1 -- one set per utterance, ns_method
+ * 'random' (:117-139) -- or NSEL = S -- sel = argmax_s y[b,t,f,s], the K nearest neighbours of the bin's dominant speaker,
+ * ns_method 'k-nearest' (:91-116).  K <= 16, NSEL*K <= 32.  dnegs [B,NSEL,K,E] is overwritten. */
+size_t ams_l41_ns_workspace_bytes(int B, long TF, int E, int S, int NSEL, int K);
+ams_status ams_l41_loss_ns_fwd(const float* emb, const float* y, const float* vspk, const float* negs, float* cost, int B, long TF, int E,
+                               int S, int NSEL, int K, float ns_rate, void* ws, size_t ws_bytes, void* stream);
+ams_status ams_l41_loss_ns_bwd(const float* emb, const float* y, const float* vspk, const float* negs, const float* upstream, float* demb,
+                               float* dvspk, float* dnegs, int B, long TF, int E, int S, int NSEL, int K, float ns_rate, void* ws,
+                               size_t ws_bytes, void* stream);
 
 /* ---- K16-K19 batched k-means   models/Kmeans_2.py:40-188 ----
  * xn [b,L,E] normalised input (ams_kmeans_normalize); rows r = b_idx*tries + try; centroids [b*tries, C, E];

@@ -90,26 +90,30 @@ def front_l41_loss(x_mix, x_non_mix, I, P, hop, nb_layers, E, normalize=True, wa
     X, X_nm = separate.split_front(y, B, S)
     Y, _ = separate.make_masks(np.abs(X_nm), 1.0, -1.0)
     V, cache = prediction_fwd(X, P, nb_layers, E, normalize)
-    cost = l41.l41_cost(V, Y, P['speaker_centroids'], I, normalize)
+    # --sampling K --ns_method k-nearest (L41.py:91-116): the neighbour sets follow from the speaker table itself
+    neg = l41.knearest_indices(P['speaker_centroids'], I, sampling, normalize) if sampling is not None else None
+    cost = l41.l41_cost(V, Y, P['speaker_centroids'], I, normalize, neg, ns_rate)
     if not want_grads:
         return cost, V, Y
-    dV, dspk = l41.l41_cost_bwd(V, Y, P['speaker_centroids'], I, normalize)
+    dV, dspk = l41.l41_cost_bwd(V, Y, P['speaker_centroids'], I, normalize, neg, ns_rate)
     grads = prediction_bwd(dV, cache, P, nb_layers)
     grads['speaker_centroids'] = dspk
     return cost, grads, V, Y
 
 
-def stft_l41_loss(x_mix, x_non_mix, I, P, W, hop, nb_layers, E, normalize=True, want_grads=True):
+def stft_l41_loss(x_mix, x_non_mix, I, P, W, hop, nb_layers, E, normalize=True, want_grads=True, sampling=None, ns_rate=0.1):
     """cfg4 STFT_L41 step (trainer.py:468-486 with L41Model): |STFT| magnitudes (network.py:480-502), masks
     y = one_hot(argmax_s |STFT(x_s)|) with (on, off) = (1, -1) (L41.py:9-10), 3xBLSTM -> Conv1D -> [l2norm], cost L41.py:47-186."""
     B, S, L = x_non_mix.shape
     X, X_nm, _ = stft.stft_preprocessing(x_mix, x_non_mix, W, hop)
     Y, _ = separate.make_masks(X_nm, 1.0, -1.0)
     V, cache = prediction_fwd(X, P, nb_layers, E, normalize)
-    cost = l41.l41_cost(V, Y, P['speaker_centroids'], I, normalize)
+    # --sampling K --ns_method k-nearest (L41.py:91-116): the neighbour sets follow from the speaker table itself
+    neg = l41.knearest_indices(P['speaker_centroids'], I, sampling, normalize) if sampling is not None else None
+    cost = l41.l41_cost(V, Y, P['speaker_centroids'], I, normalize, neg, ns_rate)
     if not want_grads:
         return cost, V, Y
-    dV, dspk = l41.l41_cost_bwd(V, Y, P['speaker_centroids'], I, normalize)
+    dV, dspk = l41.l41_cost_bwd(V, Y, P['speaker_centroids'], I, normalize, neg, ns_rate)
     grads = prediction_bwd(dV, cache, P, nb_layers)
     grads['speaker_centroids'] = dspk
     return cost, grads, V, Y

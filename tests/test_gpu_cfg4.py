@@ -35,6 +35,51 @@ def test_stft_l41_step(normalize):
     check_step(cost, c_ref, grads, g_ref, P, P_new, ooptim.AMSGrad(1e-3))
 
 
+def test_stft_l41_step_with_knearest_negative_sampling():
+    """`--sampling 3 --ns_method k-nearest --ns_rate 0.25` (utils/trainer.py:101-105, models/L41.py:69-116,143-147,165-166): the
+    whole training step against the oracle -- cost, every gradient (speaker_centroids receives the negatives' share too), AMSGrad."""
+    from models.L41 import L41Model
+    from utils.trainer import STFT_Separator_Trainer
+    B, S, L, W, hop, LS, NL, E, K, rate = 4, 2, 2048, 64, 32, 12, 2, 8, 3, 0.25
+    a = base_args(batch_size=B, nb_speakers=S, chunk_size=L, window_size=W, hop_size=hop, layer_size=LS, nb_layers=NL,
+                  embedding_size=E, model_folder=None, learning_rate=1e-3, no_normalize=True, sampling=K, ns_method='k-nearest',
+                  ns_rate=rate)
+    a.pop('type')
+    tr = STFT_Separator_Trainer(L41Model, 'STFT_L41', **a)
+    dist, tfds = tr.prepare()
+    P, cost, xm, xn, I, grads, P_new = one_train_step(tr, tfds, L)
+    c_ref, g_ref, V, Y = ostep.stft_l41_loss(xm, xn, I, P, W, hop, NL, E, True, sampling=K, ns_rate=rate)
+    c_plain = ostep.stft_l41_loss(xm, xn, I, P, W, hop, NL, E, True, want_grads=False)[0]
+    assert c_ref > c_plain + 1e-3                                        # the negatives are part of the cost
+    check_step(cost, c_ref, grads, g_ref, P, P_new, ooptim.AMSGrad(1e-3))
+
+
+@pytest.mark.parametrize('graph', [False, True])
+def test_stft_l41_random_negative_sampling_trains(graph):
+    """`--sampling 4` with the default ns_method 'random' (L41.py:117-139): a fresh set of non-mixture speakers per utterance and
+    step, drawn on the device -- also from inside a replayed hipGraph.  The draw is not TensorFlow's, so: finite costs above the
+    plain L41 cost of the same weights, and different costs on repeated evaluations of ONE batch (new negatives each time)."""
+    from models.L41 import L41Model
+    from utils.trainer import STFT_Separator_Trainer
+    B, S, L, W, hop, LS, NL, E = 3, 2, 2048, 64, 32, 12, 2, 8
+    a = base_args(batch_size=B, nb_speakers=S, chunk_size=L, window_size=W, hop_size=hop, layer_size=LS, nb_layers=NL,
+                  embedding_size=E, model_folder=None, learning_rate=0.0, no_normalize=True, sampling=4, ns_rate=0.5,
+                  hip_graph=graph, no_summaries=True, synthetic_batches=1, synthetic_pool=1)
+    a.pop('type')
+    tr = STFT_Separator_Trainer(L41Model, 'STFT_L41', **a)
+    dist, tfds = tr.prepare()
+    g, model = tr.graph, tr.model
+    costs = []
+    with g.as_default():
+        feed = {tfds.handle: tfds.get_handle(tfds.TRAIN), tfds.chunk_size: L}
+        tfds.initialize(tfds.TRAIN)
+        for i in range(6):
+            costs.append(float(model.train(feed, i)))
+    torch.cuda.synchronize()
+    assert np.all(np.isfinite(costs)) and min(costs) > 0.0
+    assert len(set(np.round(costs[2:], 7))) > 1, costs                   # lr = 0, one batch: only the negatives change
+
+
 @pytest.mark.parametrize('nonlinearity', ['softmax', 'tanh'])
 def test_stft_l41_enhance_step(nonlinearity):
     """experiments.training.STFT_L41_enhance: restored STFT + L41 separator (checkpoint carries speaker_centroids) -> hard k-means

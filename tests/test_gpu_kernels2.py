@@ -155,6 +155,50 @@ def test_l41_loss(F, normalize):
     assert rel(host(et.grad), de) < 5 * TOL and rel(host(st.grad), ds) < 5 * TOL
 
 
+@pytest.mark.parametrize('normalize', [True, False])
+@pytest.mark.parametrize('method,S,K', [('k-nearest', 2, 5), ('random', 2, 7), ('k-nearest', 3, 4), ('random', 3, 16)])
+def test_l41_loss_negative_sampling(F, normalize, method, S, K):
+    """--sampling K (models/L41.py:69-147,165-166): cost and both gradients against the oracle, with the neighbour sets the HIP
+    side selects itself ('k-nearest': torch.topk == oracle argsort as SETS) or with injected sets ('random')."""
+    rng = np.random.RandomState(60 + K)
+    B, T, Fq, E, NS, rate = 3, 4, 70, 40, 23, 0.3
+    emb, spk = rng.randn(B, T, Fq, E) * 0.3, rng.randn(NS, E)
+    I = np.stack([rng.choice(NS, S, replace=False) for _ in range(B)]).astype(np.int32)
+    lab = rng.randint(0, S, (B, T, Fq))
+    y = np.where(np.eye(S)[lab] > 0, 1.0, -1.0)
+    y[0, 0, :5] = -1.0                                          # bins with no dominant speaker: argmax -> 0
+    et, st = dev(emb).requires_grad_(), dev(spk).requires_grad_()
+    if method == 'k-nearest':
+        idx_ref = ol41.knearest_indices(spk, I, K, normalize)
+        idx = F.l41_knearest(st, dev(I, np.int32), K, normalize)
+        assert idx.shape == (B, S, K)
+        assert np.array_equal(np.sort(idx.cpu().numpy(), axis=2), np.sort(idx_ref, axis=2))
+        assert all(I[b, s] in idx_ref[b, s] for b in range(B) for s in range(S))      # the speaker itself is its nearest neighbour
+    else:
+        idx_ref = ol41.random_indices(I, NS, K, np.random.RandomState(3))
+        idx = dev(idx_ref, np.int32)
+    c = F.l41_loss(et, dev(y), st, dev(I, np.int32), normalize, neg_idx=idx, ns_rate=rate)
+    c_ref = ol41.l41_cost(emb, y, spk, I, normalize, idx_ref, rate)
+    assert abs(float(c) - c_ref) < TOL * max(1.0, abs(c_ref))
+    assert abs(c_ref - ol41.l41_cost(emb, y, spk, I, normalize)) > 1e-3               # the term is really there
+    c.backward()
+    de, ds = ol41.l41_cost_bwd(emb, y, spk, I, normalize, idx_ref, rate)
+    assert rel(host(et.grad), de) < 5 * TOL and rel(host(st.grad), ds) < 5 * TOL
+
+
+def test_l41_random_negatives_exclude_the_mixture(F):
+    """L41.py:123-134: K distinct speakers per utterance, none of them in I[b]; a fresh draw per call."""
+    torch.manual_seed(5)
+    B, S, NS, K = 16, 3, 40, 9
+    I = torch.stack([torch.randperm(NS)[:S] for _ in range(B)]).to(torch.int32).cuda()
+    a, b2 = F.l41_random_negatives(I, NS, K), F.l41_random_negatives(I, NS, K)
+    assert a.shape == (B, 1, K) and a.dtype == torch.int32
+    an, In = a.cpu().numpy()[:, 0], I.cpu().numpy()
+    for r in range(B):
+        assert len(set(an[r])) == K and not (set(an[r]) & set(In[r])) and an[r].min() >= 0 and an[r].max() < NS
+    assert not torch.equal(a, b2)
+
+
 @pytest.mark.parametrize('b,L,E,C,tries,with_w,end', [(3, 5000, 40, 2, 2, False, True), (2, 4100, 40, 3, 3, True, False),
                                                        (2, 2500, 8, 2, 1, True, True), (1, 20480, 40, 2, 2, False, True),
                                                        (2, 4100, 40, 2, 3, 'real', False), (2, 3000, 40, 2, 2, 'mixed', True)])

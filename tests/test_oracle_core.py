@@ -229,6 +229,38 @@ def test_l41_grads(normalize):
     assert rel(de, et.grad.numpy()) < 1e-11 and rel(ds, st.grad.numpy()) < 1e-11
 
 
+@pytest.mark.parametrize('normalize', [True, False])
+@pytest.mark.parametrize('method', ['k-nearest', 'random'])
+def test_l41_negative_sampling_grads(normalize, method):
+    """--sampling K (models/L41.py:69-147,165-166) restated with torch-CPU autograd: gather of the neighbour / random sets,
+    -log(sigmoid(-dot)) averaged over K, scaled by ns_rate, added per bin before the batch mean."""
+    B, T, Fq, E, S, NS, K, rate = 2, 3, 4, 5, 2, 9, 3, 0.3
+    emb, spk = RNG.randn(B, T, Fq, E), RNG.randn(NS, E)
+    I = np.array([[0, 3], [5, 1]])
+    lab = RNG.randint(0, S, (B, T, Fq))
+    y = np.where(np.eye(S)[lab] > 0, 1.0, -1.0)
+    et, st = t(emb).requires_grad_(), t(spk).requires_grad_()
+    sv = F.normalize(st, dim=1, eps=1e-6) if normalize else st
+    vs = sv[t(I)]
+    if method == 'k-nearest':
+        idx = l41.knearest_indices(spk, I, K, normalize)
+        top = torch.topk(torch.einsum('bse,ne->bsn', vs, sv), K, dim=2).indices.numpy()
+        assert np.array_equal(np.sort(top, 2), np.sort(idx, 2)) and idx.shape == (B, S, K)
+        vec = sv[t(idx)][torch.arange(B)[:, None, None], t(np.argmax(y, -1))]          # [B,T,F,K,E]: set of the dominant speaker
+    else:
+        idx = l41.random_indices(I, NS, K, np.random.RandomState(4))
+        assert idx.shape == (B, 1, K) and all(not (set(idx[b, 0]) & set(I[b])) and len(set(idx[b, 0])) == K for b in range(B))
+        vec = sv[t(idx)][:, 0][:, None, None].expand(B, T, Fq, K, E)
+    dot = torch.einsum('btfe,bse->btfs', et, vs)
+    doto = (vec * et[:, :, :, None, :]).sum(-1)
+    cost = (-torch.log(torch.sigmoid(t(y) * dot))).mean(3) + rate * (-torch.log(torch.sigmoid(-doto))).mean(-1)
+    cost = cost.mean(0).mean()
+    cost.backward()
+    assert abs(l41.l41_cost(emb, y, spk, I, normalize, idx, rate) - cost.item()) < 1e-12
+    de, ds = l41.l41_cost_bwd(emb, y, spk, I, normalize, idx, rate)
+    assert rel(de, et.grad.numpy()) < 1e-11 and rel(ds, st.grad.numpy()) < 1e-11
+
+
 # ---------------------------------------------------------------- losses
 def test_pretrain_and_pit_costs_grads():
     B, S, L = 3, 2, 50
