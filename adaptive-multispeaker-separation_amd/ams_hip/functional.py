@@ -425,12 +425,35 @@ class PairStats(Function):
 
 
 def pair_stats(target, est, mix):
-    """Returns dict of views D,Q [B,S,S], Na,Nt,Tm [B,S], Nm [B]."""
+    """Returns dict of views D,Q [B,S,S], Na,Nt,Tm [B,S], Nm [B]; 'table' is the [B, 2S^2+3S+1] tensor they are views of."""
     B, S, L = est.shape
     st = PairStats.apply(_c(target), _c(est), _c(mix) if mix is not None else None)
     SS = S * S
     return {'D': st[:, :SS].reshape(B, S, S), 'Q': st[:, SS:2 * SS].reshape(B, S, S), 'Na': st[:, 2 * SS:2 * SS + S],
-            'Nt': st[:, 2 * SS + S:2 * SS + 2 * S], 'Tm': st[:, 2 * SS + 2 * S:2 * SS + 3 * S], 'Nm': st[:, 2 * SS + 3 * S]}
+            'Nt': st[:, 2 * SS + S:2 * SS + 2 * S], 'Tm': st[:, 2 * SS + 2 * S:2 * SS + 3 * S], 'Nm': st[:, 2 * SS + 3 * S],
+            'table': st, 'S': S, 'L': L}
+
+
+class PairCombine(Function):
+    """The [B,S,S] arithmetic between the pair table and the scalar costs in ONE launch each way (csrc/synth.hip
+    pair_combine_*): mode 0 pre-training (adapt.py:321-330), 1 PIT squared error (adapt.py:404-431, network.py:662-724),
+    2 Adapt.cost non-pretraining branch with the cross-batch SDR table D2 [S,B,B] (adapt.py:339-365).  As torch glue these
+    were 30-80 launches of ~5 us on 64 x 2 x 2 numbers: 12 % of the fine-tuning step, 11 % of the pre-training step."""
+
+    @staticmethod
+    def forward(ctx, table, D2, S, mode, cl, cs):
+        perms = _perm_table32(S, table.device) if mode != 0 else None
+        out, pbest, jbest = ops.pair_combine_fwd(table, D2, perms, S, mode, cl, cs)
+        ctx.save_for_backward(table, D2, perms, pbest, jbest)
+        ctx.cfg = (S, mode, cl, cs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        table, D2, perms, pbest, jbest = ctx.saved_tensors
+        S, mode, cl, cs = ctx.cfg
+        gst, gD2 = ops.pair_combine_bwd(table, D2, perms, _c(g), pbest, jbest, S, mode, cl, cs)
+        return gst, gD2, None, None, None, None
 
 
 def _log10(x):
@@ -453,6 +476,13 @@ def _perm_table(S, device):
     return _PERM_CACHE[key]
 
 
+def _perm_table32(S, device):
+    key = (S, str(device), 'i32')
+    if key not in _PERM_CACHE:
+        _PERM_CACHE[key] = _perm_table(S, device).to(torch.int32).contiguous()
+    return _PERM_CACHE[key]
+
+
 def sdr_improvement(x_mix, s_target, s_approx, with_perm=False):
     """Network.sdr_improvement (network.py:196-221) for [B,S,L] operands (identity pairing)."""
     st = pair_stats(s_target, s_approx, x_mix)
@@ -464,17 +494,23 @@ def sdr_improvement(x_mix, s_target, s_approx, with_perm=False):
     return val, (Nt * Na) / (D * D + 1e-12)
 
 
-def pretrain_cost(x_mix, x_non_mix, back):
-    """Adapt.cost pretraining branch (adapt.py:321-330) -> tensor [3] = (l2, sdr, sdr_improvement)."""
-    st = pair_stats(x_non_mix, back, x_mix)
-    D, Q, Na, Nt, Tm, Nm = _diag(st['D']), _diag(st['Q']), st['Na'], st['Nt'], st['Tm'], st['Nm'].unsqueeze(1)
-    l2 = Q.sum(dim=1).mean()
-    sdr = ((Nt * Na) / (D * D + 1e-12)).mean()
+def pretrain_cost(x_mix, x_non_mix, back, want_imp=True, st=None):
+    """Adapt.cost pretraining branch (adapt.py:321-330) -> tensor [3] = (l2, sdr, sdr_improvement); [2] without the (summary-only,
+    gradient-free) improvement term.  `st`: a pair_stats table computed earlier in the same run."""
+    st = pair_stats(x_non_mix, back, x_mix) if st is None else st
+    out = PairCombine.apply(st['table'], None, st['S'], 0, 1.0, 1.0)            # l2 = mean_b sum_s Q_ss, sdr = mean Nt Na / (D_ss^2 + 1e-12)
+    if not want_imp:
+        return out
+    return torch.cat([out, pretrain_improvement(st).reshape(1)])
+
+
+def pretrain_improvement(st):
+    """SDR improvement of the identity pairing (network.py:200-219) from a pair_stats table; no gradient."""
     with torch.no_grad():
+        D, Na, Nt, Tm, Nm = _diag(st['D']), st['Na'], st['Nt'], st['Tm'], st['Nm'].unsqueeze(1)
         sep = 10.0 * _log10(1.0 / ((Nt * Na) / (D * D) - 1.0))
         non = 10.0 * _log10(1.0 / ((Nt * Nm) / (Tm * Tm) - 1.0))
-        imp = (sep - non).mean()
-    return torch.stack([l2, sdr, imp])
+        return (sep - non).mean()
 
 
 class CrossDots(Function):
@@ -503,37 +539,44 @@ class CrossDots(Function):
         return None, da
 
 
-def pit_cost_adapt(x_mix, x_non_mix, back):
-    """Adapt.cost non-pretraining branch (adapt.py:339-365) -> tensor [3] = (l2, sdr, sdr_improvement)."""
+def pit_adapt_tables(x_mix, x_non_mix, back):
+    """What both the cost and its summary need: the pair table and the cross-batch dots D2[i,j,s] = <t[i,s], a[j,s]> (quirk C-3)."""
+    return pair_stats(x_non_mix, back, x_mix), CrossDots.apply(_c(x_non_mix), _c(back))
+
+
+def pit_cost_adapt(x_mix, x_non_mix, back, want_imp=True, tables=None):
+    """Adapt.cost non-pretraining branch (adapt.py:339-365) -> tensor [3] = (l2, sdr, sdr_improvement); [2] without the
+    (summary-only, gradient-free) improvement term."""
     B, S, L = back.shape
-    st = pair_stats(x_non_mix, back, x_mix)
-    P = _perm_table(S, back.device)
-    Qp = st['Q'][:, torch.arange(S, device=back.device).unsqueeze(0), P]          # [B, P, S]: Q[b, s, perm[p][s]]
-    l2 = (Qp / L).sum(dim=-1).min(dim=-1)[0].mean()
-    D2 = CrossDots.apply(_c(x_non_mix), _c(back))                                   # [i, j, s]
-    sdr_t = (st['Nt'].unsqueeze(1) * st['Na'].unsqueeze(0)) / (D2 * D2 + 1e-12)     # [B,B,S]
-    sdr = sdr_t.min(dim=1)[0].sum(dim=-1).mean()
+    st, D2 = pit_adapt_tables(x_mix, x_non_mix, back) if tables is None else tables
+    # l2 = mean_b min_p sum_s Q[b,s,p(s)] / L;  sdr = mean_i sum_s min_j Nt[i,s] Na[j,s] / (D2[i,j,s]^2 + 1e-12)
+    out = PairCombine.apply(st['table'], D2.permute(2, 0, 1), S, 2, 1.0 / L, 1.0)   # D2 is a [i,j,s] view of a dense [S,B,B] tensor
+    if not want_imp:
+        return out
+    return torch.cat([out, pit_adapt_improvement(x_mix, x_non_mix, (st, D2)).reshape(1)])
+
+
+def pit_adapt_improvement(x_mix, x_non_mix, tables):
+    """The SDR-improvement summary of the same branch (network.py:200-219 on the broadcast operands); no gradient."""
+    st, D2 = tables
+    B, S = st['Nt'].shape
+    L = x_mix.shape[-1]
     with torch.no_grad():
-        Nm, Tm = st['Nm'], st['Tm']
+        Nm = st['Nm']
+        D2 = D2.detach()
         sep = 10.0 * _log10(1.0 / ((st['Nt'].unsqueeze(1) * st['Na'].unsqueeze(0)) / (D2 * D2) - 1.0))
         # mix term broadcasts the same way: target i against mix j
         Tm2 = CrossDots.apply(_c(x_non_mix), _c(x_mix.unsqueeze(1).expand(B, S, L).contiguous()))
         non = 10.0 * _log10(1.0 / ((st['Nt'].unsqueeze(1) * Nm.view(1, B, 1)) / (Tm2 * Tm2) - 1.0))
-        imp = (sep - non).mean(dim=-1).mean(dim=0).max()
-    return torch.stack([l2, sdr, imp])
+        return (sep - non).mean(dim=-1).mean(dim=0).max()
 
 
 def pit_l2(x_non_mix, est, reduce_l, reduce_s, scale=1.0):
     """Generic PIT squared error from the pair table (cost_finetuning / enhance_cost)."""
     B, S, L = est.shape
     st = pair_stats(x_non_mix, est, None)
-    P = _perm_table(S, est.device)
-    Qp = st['Q'][:, torch.arange(S, device=est.device).unsqueeze(0), P]
-    if reduce_l == 'mean':
-        Qp = Qp / L
-    Qp = Qp * scale
-    c = Qp.sum(dim=-1) if reduce_s == 'sum' else Qp.mean(dim=-1)
-    return c.min(dim=-1)[0].mean().reshape(1)
+    cl = float(scale) / L if reduce_l == 'mean' else float(scale)
+    return PairCombine.apply(st['table'], None, S, 1, cl, 1.0 if reduce_s == 'sum' else 1.0 / S)[0:1]
 
 
 class OverlapMetric(Function):

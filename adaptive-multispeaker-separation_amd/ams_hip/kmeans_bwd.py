@@ -11,33 +11,46 @@ def soft_bwd(xn, inv, init_idx, best, w, trace, dsel, dout, C, tries, iterations
     lib = load()
     b, L, E = xn.shape
     dev = xn.device
-    index = best.long() + torch.arange(b, device=dev) * tries
-    cents = [trace[0][index].contiguous()]
+    if tries == 1:
+        # one try per utterance: row r IS utterance r -- no gathers (they were 2 launches per unrolled iteration)
+        index = None
+        pick = lambda t: t                                                  # noqa: E731
+    else:
+        index = best.long() + torch.arange(b, device=dev) * tries
+        pick = lambda t: t[index].contiguous()                              # noqa: E731
+    cents = [pick(trace[0])]
     dens = []
     for i in range(iterations):
-        cents.append(trace[1 + 2 * i][index].contiguous())
-        dens.append(trace[2 + 2 * i][index].contiguous())
+        cents.append(pick(trace[1 + 2 * i]))
+        dens.append(pick(trace[2 + 2 * i]))
     wsel = None
     if w is not None:
-        wrow = (index % b) if faithful_tile else (index // tries)
-        wsel = w[wrow].contiguous()
+        if index is None:
+            wsel = w
+        else:
+            wrow = (index % b) if faithful_tile else (index // tries)
+            wsel = w[wrow].contiguous()
     nb = lib.ams_kmeans_workspace_bytes(b, L, E, C)
     ws = ops._ws(nb, xn)
-    g = dsel.contiguous().clone() if dsel is not None else torch.zeros((b, C, E), dtype=torch.float32, device=dev)
+    # G[i] = d loss / d c_i: the final pass accumulates into G[iterations], iteration i reads G[i+1] and writes G[i] -- the
+    # per-iteration gradients phase 2 needs are then the slice G[1:], with no copies in between
+    G = torch.empty((iterations + 1, b, C, E), dtype=torch.float32, device=dev)
+    if dsel is not None:
+        G[iterations].copy_(dsel)
+    else:
+        G[iterations].zero_()
     p, s = ops._p, ops._s
     w_final = None if assign_at_end else wsel
     # phase 1: centroid gradients only (dx == NULL): one read of xn per pass, no read-modify-write of dx
     if dout is not None:
         dout = dout.contiguous()
-        check(lib.ams_kmeans_soft_bwd_pass(p(xn), p(w_final), p(cents[-1]), p(None), p(None), p(None), p(dout), p(None), p(g),
+        check(lib.ams_kmeans_soft_bwd_pass(p(xn), p(w_final), p(cents[-1]), p(None), p(None), p(None), p(dout), p(None), p(G[iterations]),
                                            b, L, E, C, float(beta), 0, p(ws), nb, s()), 'ams_kmeans_soft_bwd_pass(final)')
-    gs = torch.empty((max(iterations, 1), b, C, E), dtype=torch.float32, device=dev)
     for i in range(iterations - 1, -1, -1):
-        gs[i].copy_(g)
-        g_new = torch.empty_like(g)
-        check(lib.ams_kmeans_soft_bwd_pass(p(xn), p(wsel), p(cents[i]), p(cents[i + 1]), p(dens[i]), p(gs[i]), p(None), p(None), p(g_new),
+        check(lib.ams_kmeans_soft_bwd_pass(p(xn), p(wsel), p(cents[i]), p(cents[i + 1]), p(dens[i]), p(G[i + 1]), p(None), p(None), p(G[i]),
                                            b, L, E, C, float(beta), 1, p(ws), nb, s()), 'ams_kmeans_soft_bwd_pass(iter)')
-        g = g_new
+    g = G[0]
+    gs = G[1:]
     # phase 2: dx of the final assignment and of every iteration in ONE pass over xn
     dxn = torch.empty_like(xn)
     cst = torch.stack(cents).contiguous()
@@ -45,9 +58,10 @@ def soft_bwd(xn, inv, init_idx, best, w, trace, dsel, dout, C, tries, iterations
     check(lib.ams_kmeans_soft_bwd_dx(p(xn), p(wsel), p(w_final), p(cst), p(gs if iterations else None), p(dst), p(dout), p(dxn),
                                      b, L, E, C, float(beta), iterations, s()), 'ams_kmeans_soft_bwd_dx')
     # c_0 = xn[idx]: scatter-add the remaining centroid gradient onto the picked points (tiny: b*C rows)
-    idx_sel = init_idx[index].long()                                   # [b, C]
-    rows = torch.arange(b, device=dev).unsqueeze(1).expand(b, C)
-    dxn.index_put_((rows.reshape(-1), idx_sel.reshape(-1)), g.reshape(b * C, E), accumulate=True)
+    # (the C picks of a row are distinct -- np.random.choice without replacement, Kmeans_2.py:63 -- so no two updates collide)
+    idx_sel = (init_idx if index is None else init_idx[index]).long()   # [b, C]
+    flat = (idx_sel + torch.arange(b, device=dev).unsqueeze(1) * L).reshape(-1)
+    dxn.view(b * L, E).index_add_(0, flat, g.reshape(b * C, E))
     if inv is None:
         return dxn
     return ops.l2norm_bwd(xn.view(b, L * E), inv, dxn.view(b, L * E), E).view(b, L, E)

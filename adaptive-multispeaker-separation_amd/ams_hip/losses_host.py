@@ -86,14 +86,24 @@ def build_adapt_cost(m):
     x_mix, x_non_mix = m.x_mix, m.x_non_mix
     f1, f2 = m.conv_filter, m.conv_filter_2
 
+    # the pair table (one pass over the waveforms) is shared by the cost and by the SDR-improvement summary; the summary's own
+    # arithmetic (gradient-free, for pit_cost_adapt two more cross-batch products) runs only in a step that fetches it
+    def _tables(run):
+        xm, xn, bk = x_mix.value(run), x_non_mix.value(run), back.value(run)
+        return F.pair_stats(xn, bk, xm) if m.pretraining else F.pit_adapt_tables(xm, xn, bk)
+    tables = Node('tables', _tables, register=False)
+
     def _parts(run):
         xm, xn, bk = x_mix.value(run), x_non_mix.value(run), back.value(run)
         if m.pretraining:
-            out = F.pretrain_cost(xm, xn, bk)               # tensor [3] = l2, sdr, sdr_improvement
-        else:
-            out = F.pit_cost_adapt(xm, xn, bk)              # tensor [3] = l2, sdr (quirk C-3), sdr_improvement
-        return out
+            return F.pretrain_cost(xm, xn, bk, want_imp=False, st=tables.value(run))        # tensor [2] = l2, sdr
+        return F.pit_cost_adapt(xm, xn, bk, want_imp=False, tables=tables.value(run))      # l2, sdr (quirk C-3)
     parts = Node('parts', _parts)
+
+    def _imp(run):
+        if m.pretraining:
+            return F.pretrain_improvement(tables.value(run))
+        return F.pit_adapt_improvement(x_mix.value(run), x_non_mix.value(run), tables.value(run))
 
     def _cost(run):
         p = parts.value(run)
@@ -120,7 +130,7 @@ def build_adapt_cost(m):
     cost = Node('cost_value', _cost)
     g.summaries['cost/loss_values/l2_loss'] = Node('l2_loss', lambda run: parts.value(run)[0])
     g.summaries['cost/loss_values/SDR'] = Node('SDR', lambda run: parts.value(run)[1])
-    g.summaries['cost/loss_values/SDR_improvement'] = Node('SDR_improvement', lambda run: parts.value(run)[2])
+    g.summaries['cost/loss_values/SDR_improvement'] = Node('SDR_improvement', _imp)
     g.summaries['cost/loss_values/loss'] = cost
     m.sdr_imp = g.summaries['cost/loss_values/SDR_improvement']
     return cost

@@ -880,6 +880,31 @@ def pair_stats_bwd(target, est, gstats):
     return dest
 
 
+def pair_combine_fwd(stats, D2, perms, S, mode, cl, cs):
+    """Costs from the pair table in one launch (csrc/synth.hip pair_combine_*): returns (out [2], pbest, jbest)."""
+    _chk(stats)
+    B = stats.shape[0]
+    dev = stats.device
+    out = torch.empty(2, dtype=torch.float32, device=dev)
+    P = 0 if perms is None else perms.shape[0]
+    pbest = torch.empty(B, dtype=torch.int32, device=dev) if mode != 0 else None
+    jbest = torch.empty((B, S), dtype=torch.int32, device=dev) if mode == 2 else None
+    check(load().ams_pair_combine_fwd(_p(stats), _p(D2), _p(perms), _p(out), _p(pbest), _p(jbest), B, S, P, mode, float(cl), float(cs),
+                                      _s()), 'ams_pair_combine_fwd')
+    return out, pbest, jbest
+
+
+def pair_combine_bwd(stats, D2, perms, gout, pbest, jbest, S, mode, cl, cs):
+    _chk(stats, gout)
+    B = stats.shape[0]
+    P = 0 if perms is None else perms.shape[0]
+    gst = torch.empty_like(stats)
+    gD2 = torch.empty_like(D2) if mode == 2 else None
+    check(load().ams_pair_combine_bwd(_p(stats), _p(D2), _p(perms), _p(gout), _p(pbest), _p(jbest), _p(gst), _p(gD2), B, S, P, mode,
+                                      float(cl), float(cs), _s()), 'ams_pair_combine_bwd')
+    return gst, gD2
+
+
 def apply_masks_fwd(X, masks):
     """X [B,TF], masks [B,TF,S] -> [B*S, TF]."""
     _chk(X, masks)

@@ -197,6 +197,134 @@ __global__ void overlap_bwd_kernel(const float* __restrict__ y, const float* __r
     }
 }
 
+
+// ---- costs from the pair table: one workgroup, fixed-order reductions (the [B,S,S] glue of adapt.py:321-372, network.py:662-724) ----
+// mode 0  PRETRAIN  out[0] = mean_b sum_s Q[b,s,s]                    out[1] = mean_{b,s} Nt Na / (D[b,s,s]^2 + 1e-12)
+// mode 1  PIT_L2    out[0] = mean_b min_p red_s (Q[b,s,p(s)] * cl)     out[1] = 0          red_s = sum (cs = 1) or mean (cs = 1/S)
+// mode 2  ADAPT     out[0] = mean_b min_p sum_s Q[b,s,p(s)] / L        out[1] = mean_i sum_s min_j Nt[i,s] Na[j,s] / (D2[s,i,j]^2 + 1e-12)
+//                   (the cross-batch minimum is the reference's broadcast of [B,1,S,L] against [B,S,L], adapt.py:361-365)
+// perms [P,S] int32 in lexicographic order; ties keep the first minimum (tf.reduce_min / torch.min sub-gradient convention).
+constexpr int PC_PRETRAIN = 0, PC_ADAPT = 2;     // (1 = PIT_L2: the generic branch)
+
+__device__ __forceinline__ float block_sum_256(float v, float* sm) {
+    const int tid = threadIdx.x;
+    sm[tid] = v;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (tid < s) sm[tid] += sm[tid + s];
+        __syncthreads();
+    }
+    const float r = sm[0];
+    __syncthreads();
+    return r;
+}
+
+__global__ __launch_bounds__(256) void pair_combine_fwd_kernel(const float* __restrict__ st, const float* __restrict__ D2,
+                                                               const int* __restrict__ perms, float* __restrict__ out,
+                                                               int* __restrict__ pbest, int* __restrict__ jbest, int B, int S, int P,
+                                                               int mode, float cl, float cs) {
+    __shared__ float sm[256];
+    const int SS = S * S, NS = 2 * SS + 3 * S + 1, tid = threadIdx.x;
+    float a0 = 0.f, a1 = 0.f;
+    if (mode == PC_PRETRAIN) {
+        for (int b = tid; b < B; b += 256) {
+            const float* r = st + (long)b * NS;
+            float q = 0.f;
+            for (int s = 0; s < S; ++s) {
+                q += r[SS + s * S + s];
+                const float d = r[s * S + s];
+                a1 += r[2 * SS + S + s] * r[2 * SS + s] / (d * d + 1e-12f);
+            }
+            a0 += q;
+        }
+        const float l2 = block_sum_256(a0, sm), sdr = block_sum_256(a1, sm);
+        if (tid == 0) { out[0] = l2 / (float)B; out[1] = sdr / ((float)B * (float)S); }
+        return;
+    }
+    for (int b = tid; b < B; b += 256) {
+        const float* q = st + (long)b * NS + SS;
+        float best = 0.f;
+        int bp = 0;
+        for (int p = 0; p < P; ++p) {
+            float c = 0.f;
+            for (int s = 0; s < S; ++s) c += q[s * S + perms[p * S + s]] * cl;
+            c *= cs;
+            if (p == 0 || c < best) { best = c; bp = p; }
+        }
+        pbest[b] = bp;
+        a0 += best;
+    }
+    if (mode == PC_ADAPT) {
+        for (int e = tid; e < B * S; e += 256) {
+            const int i = e / S, s = e - i * S;
+            const float nt = st[(long)i * NS + 2 * SS + S + s];
+            const float* drow = D2 + ((long)s * B + i) * B;
+            float best = 0.f;
+            int bj = 0;
+            for (int j = 0; j < B; ++j) {
+                const float d = drow[j];
+                const float v = nt * st[(long)j * NS + 2 * SS + s] / (d * d + 1e-12f);
+                if (j == 0 || v < best) { best = v; bj = j; }
+            }
+            jbest[e] = bj;
+            a1 += best;
+        }
+    }
+    const float l2 = block_sum_256(a0, sm), sdr = block_sum_256(a1, sm);
+    if (tid == 0) { out[0] = l2 / (float)B; out[1] = sdr / (float)B; }
+}
+
+// gstats [B,NS] and gD2 [S,B,B] are fully written (zeros where nothing flows)
+__global__ __launch_bounds__(256) void pair_combine_bwd_kernel(const float* __restrict__ st, const float* __restrict__ D2,
+                                                               const int* __restrict__ perms, const float* __restrict__ g,
+                                                               const int* __restrict__ pbest, const int* __restrict__ jbest,
+                                                               float* __restrict__ gst, float* __restrict__ gD2, int B, int S, int P,
+                                                               int mode, float cl, float cs) {
+    const int SS = S * S, NS = 2 * SS + 3 * S + 1, tid = threadIdx.x;
+    const float g0 = g[0], g1 = g[1];
+    for (long i = tid; i < (long)B * NS; i += 256) gst[i] = 0.f;
+    if (mode == PC_ADAPT)
+        for (long i = tid; i < (long)S * B * B; i += 256) gD2[i] = 0.f;
+    __syncthreads();
+    if (mode == PC_PRETRAIN) {
+        for (int e = tid; e < B * S; e += 256) {
+            const int b = e / S, s = e - b * S;
+            const float* r = st + (long)b * NS;
+            float* o = gst + (long)b * NS;
+            const float d = r[s * S + s], nt = r[2 * SS + S + s], na = r[2 * SS + s];
+            const float den = d * d + 1e-12f, w = g1 / ((float)B * (float)S);
+            o[SS + s * S + s] = g0 / (float)B;
+            o[2 * SS + s] = w * nt / den;                                   // d/d Na
+            o[s * S + s] = -w * nt * na * 2.0f * d / (den * den);           // d/d D
+        }
+        return;
+    }
+    for (int e = tid; e < B * S; e += 256) {
+        const int b = e / S, s = e - b * S;
+        gst[(long)b * NS + SS + s * S + perms[pbest[b] * S + s]] = g0 * cl * cs / (float)B;
+    }
+    if (mode == PC_ADAPT) {
+        // d/d Na[j,s]: every (i, s) whose minimum sits at j contributes -- gathered per (j, s) in i order (deterministic)
+        for (int e = tid; e < B * S; e += 256) {
+            const int j = e / S, s = e - j * S;
+            float acc = 0.f;
+            for (int i = 0; i < B; ++i) {
+                if (jbest[i * S + s] != j) continue;
+                const float d = D2[((long)s * B + i) * B + j];
+                acc += st[(long)i * NS + 2 * SS + S + s] / (d * d + 1e-12f);
+            }
+            gst[(long)j * NS + 2 * SS + s] = acc * g1 / (float)B;
+        }
+        for (int e = tid; e < B * S; e += 256) {
+            const int i = e / S, s = e - i * S, j = jbest[e];
+            const float d = D2[((long)s * B + i) * B + j];
+            const float den = d * d + 1e-12f;
+            const float nt = st[(long)i * NS + 2 * SS + S + s], na = st[(long)j * NS + 2 * SS + s];
+            gD2[((long)s * B + i) * B + j] = -(g1 / (float)B) * nt * na * 2.0f * d / (den * den);
+        }
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -277,6 +405,31 @@ ams_status ams_overlap_metric_bwd(const float* y, const float* upstream, float* 
     const int npairs = S * (S - 1) / 2;
     hipLaunchKernelGGL(overlap_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, y, upstream, dy, B, S, TN,
                        1.0f / ((float)B * npairs * TN));
+    return ams_check_launch();
+}
+
+// Costs from the pair table in one launch (see pair_combine_fwd_kernel): mode 0 pre-training (l2, sdr), 1 PIT squared error
+// (out[0]; cl multiplies every entry -- scale, or scale / L -- cs = 1 or 1/S), 2 Adapt.cost non-pretraining branch (l2 / L, the
+// cross-batch SDR term; D2 [S,B,B], cl = 1/L).  perms [P,S] int32 (lexicographic); pbest [B] / jbest [B,S] int32 are written by
+// the forward pass and read by the backward pass.  gD2 may be NULL unless mode == 2.
+ams_status ams_pair_combine_fwd(const float* stats, const float* D2, const int* perms, float* out, int* pbest, int* jbest, int B, int S,
+                                int P, int mode, float cl, float cs, void* stream) {
+    AMS_REQUIRE(stats && out && B > 0 && S > 0 && S <= 4 && mode >= 0 && mode <= 2);
+    AMS_REQUIRE(mode == PC_PRETRAIN || (perms && pbest && P > 0));
+    AMS_REQUIRE(mode != PC_ADAPT || (D2 && jbest));
+    hipLaunchKernelGGL(pair_combine_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, D2, perms, out, pbest, jbest, B, S, P,
+                       mode, cl, cs);
+    return ams_check_launch();
+}
+
+ams_status ams_pair_combine_bwd(const float* stats, const float* D2, const int* perms, const float* gout, const int* pbest,
+                                const int* jbest, float* gstats, float* gD2, int B, int S, int P, int mode, float cl, float cs,
+                                void* stream) {
+    AMS_REQUIRE(stats && gout && gstats && B > 0 && S > 0 && S <= 4 && mode >= 0 && mode <= 2);
+    AMS_REQUIRE(mode == PC_PRETRAIN || (perms && pbest && P > 0));
+    AMS_REQUIRE(mode != PC_ADAPT || (D2 && jbest && gD2));
+    hipLaunchKernelGGL(pair_combine_bwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, stats, D2, perms, gout, pbest, jbest, gstats,
+                       gD2, B, S, P, mode, cl, cs);
     return ams_check_launch();
 }
 

@@ -241,6 +241,17 @@ ams_status ams_pair_stats_fwd(const float* target, const float* est, const float
                               size_t ws_bytes, void* stream);
 ams_status ams_pair_stats_bwd(const float* target, const float* est, const float* gstats, float* dest, int B, int S, long L,
                               void* stream);
+/* costs from the stats table in ONE launch (the [B,S,S] arithmetic of adapt.py:321-372, network.py:662-724), table layout
+ * D[S*S] | Q[S*S] (|t_s - a_s'|^2) | Na | Nt | Tm | Nm:  mode 0 pre-training -> out = (mean_b sum_s Q_ss, mean_bs Nt Na/(D_ss^2+1e-12));
+ * mode 1 PIT squared error -> out[0] = mean_b min_p red_s(Q[b,s,p(s)] * cl), red = sum (cs = 1) or mean (cs = 1/S);
+ * mode 2 Adapt.cost non-pretraining branch -> out = (mean_b min_p sum_s Q/L, mean_i sum_s min_j Nt[i,s] Na[j,s]/(D2[s,i,j]^2+1e-12)),
+ * D2 [S,B,B] the cross-batch dot products (adapt.py:361-365).  perms [P,S] int32, lexicographic; pbest [B], jbest [B,S] int32
+ * carry the arg-minima from the forward to the backward call; gstats [B,NS] / gD2 [S,B,B] are fully overwritten. */
+ams_status ams_pair_combine_fwd(const float* stats, const float* D2, const int* perms, float* out, int* pbest, int* jbest, int B, int S,
+                                int P, int mode, float cl, float cs, void* stream);
+ams_status ams_pair_combine_bwd(const float* stats, const float* D2, const int* perms, const float* gout, const int* pbest,
+                                const int* jbest, float* gstats, float* gD2, int B, int S, int P, int mode, float cl, float cs,
+                                void* stream);
 
 /* ---- K20 mask application   models/network.py:577-581 ---- */
 ams_status ams_apply_masks_fwd(const float* X, const float* masks, float* sep, int B, int S, long TF, void* stream);

@@ -83,7 +83,7 @@ def stft_dpcl_loss(x_mix, x_non_mix, P, W, hop, nb_layers, E, want_grads=True):
     return cost, prediction_bwd(dV, cache, P, nb_layers), V, Y
 
 
-def front_l41_loss(x_mix, x_non_mix, I, P, hop, nb_layers, E, normalize=True, want_grads=True):
+def front_l41_loss(x_mix, x_non_mix, I, P, hop, nb_layers, E, normalize=True, want_grads=True, sampling=None, ns_rate=0.1):
     """front_L41 step (cfg5 shape): plugged L41Model on the frozen front."""
     B, S, L = x_non_mix.shape
     y = front_rep(x_mix, x_non_mix, P, hop)
