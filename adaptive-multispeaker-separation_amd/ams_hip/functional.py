@@ -521,8 +521,8 @@ class CrossDots(Function):
     def forward(ctx, t, a):
         B, S, L = a.shape
         out = torch.empty((S, B, B), dtype=torch.float32, device=a.device)
-        for s in range(S):
-            ops.gemm(t.view(-1)[s * L:], a.view(-1)[s * L:], transB=True, out=out[s], M=B, N=B, K=L, lda=S * L, ldb=S * L, ldc=B)
+        # speaker s: rows t[:, s, :] . a[:, s, :]^T -- S products of one shape, one launch (operand s starts s*L floats further)
+        ops.gemm_batched(t, a, out, S, L, L, B * B, False, True, B, B, L, S * L, S * L, B)
         ctx.save_for_backward(t)
         ctx.shape = (B, S, L)
         return out.permute(1, 2, 0)
@@ -533,9 +533,8 @@ class CrossDots(Function):
         B, S, L = ctx.shape
         gs = _c(g.permute(2, 0, 1))                                        # [S, i, j]
         da = torch.empty((B, S, L), dtype=torch.float32, device=t.device)
-        for s in range(S):
-            # da[j, s, :] = sum_i g[i,j,s] t[i,s,:]
-            ops.gemm(gs[s], t.view(-1)[s * L:], transA=True, out=da.view(-1)[s * L:], M=B, N=L, K=B, lda=B, ldb=S * L, ldc=S * L)
+        # da[j, s, :] = sum_i g[i,j,s] t[i,s,:]
+        ops.gemm_batched(gs, t, da, S, B * B, L, L, True, False, B, L, B, B, S * L, S * L)
         return None, da
 
 

@@ -224,6 +224,21 @@ def gemm_batched2(A0, A1, B0, B1, C0, C1, transA, transB, M, N, K, lda, ldb, ldc
         PROFILE.end(ev, 2 * 2.0 * M * N * K, 2 * 4.0 * (M * K + K * N + M * N), 'gemm<%d,%d>' % (int(bool(transA)), int(bool(transB))))
 
 
+def gemm_batched(A, B, C, nbatch, a_zs, b_zs, c_zs, transA, transB, M, N, K, lda, ldb, ldc, accumulate=False):
+    """nbatch products of one shape in ONE launch: batch z reads A + z*a_zs, B + z*b_zs and writes C + z*c_zs (element strides)."""
+    lib = load()
+    for t_ in (A, B, C):
+        if t_.dtype != torch.float32 or not t_.is_cuda:
+            raise AmsError('gemm_batched: operands must be fp32 device tensors')
+    nb = lib.ams_gemm_batched_workspace_bytes(M, N, K, nbatch)
+    ws = _ws(nb, A) if nb else None
+    ev = PROFILE.begin() if PROFILE.enabled else None
+    check(lib.ams_gemm_f32_batched(int(transA), int(transB), M, N, K, _p(A), lda, a_zs, _p(B), ldb, b_zs, _p(C), ldc, c_zs, nbatch,
+                                   int(accumulate), 0, 0, _p(ws), nb, _s()), 'ams_gemm_f32_batched')
+    if ev is not None:
+        PROFILE.end(ev, nbatch * 2.0 * M * N * K, nbatch * 4.0 * (M * K + K * N + M * N), 'gemm<%d,%d>' % (int(bool(transA)), int(bool(transB))))
+
+
 # ------------------------------------------------------------------ masks
 def make_masks(rep_non_mix, B, S, a, b, take_abs, want_argmax=False):
     """rep_non_mix: [B*S, ...] rows (b,s) row-major.  Returns Y [B, TF, S] (and int32 argmax [B, TF])."""

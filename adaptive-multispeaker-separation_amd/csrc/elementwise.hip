@@ -97,6 +97,102 @@ __global__ void l2norm_bwd_kernel(const float* __restrict__ v, const float* __re
     }
 }
 
+// 16-byte, LDS-staged forms of the two kernels above for E % 4 == 0: a workgroup moves a slab of 256 rows (256 * E floats,
+// contiguous in memory) with coalesced 16-byte accesses, and thread t works on row t out of LDS (row pitch E + 4 floats: 16-byte
+// aligned rows, conflict-free 16-byte reads).  The quarter-wave kernels issue 4-byte accesses in 64-byte runs and reach
+// 3.2-3.5 TB/s on the 210 MB embedding tensor; these are HBM-speed passes.
+template <int E_>
+__global__ __launch_bounds__(256) void l2norm_fwd_slab_kernel(const float* __restrict__ u, float* __restrict__ v, float* __restrict__ inv,
+                                                              long rows) {
+    constexpr int V4 = E_ / 4, LD = E_ + 4;
+    __shared__ __attribute__((aligned(16))) float tile[256 * LD];
+    const int tid = threadIdx.x;
+    const long r0 = (long)blockIdx.x * 256;
+    const int nr = (int)min((long)256, rows - r0);
+    const float4* src = reinterpret_cast<const float4*>(u + r0 * E_);
+    float4 pre[V4];
+#pragma unroll
+    for (int k = 0; k < V4; ++k) pre[k] = src[min(tid + 256 * k, nr * V4 - 1)];           // unconditional, clamped
+#pragma unroll
+    for (int k = 0; k < V4; ++k) {
+        const int i = tid + 256 * k, row = i / V4, c4 = i - row * V4;
+        *reinterpret_cast<float4*>(&tile[row * LD + c4 * 4]) = pre[k];
+    }
+    __syncthreads();
+    if (tid < nr) {
+        float4* p = reinterpret_cast<float4*>(&tile[tid * LD]);
+        float4 x[V4];
+        float ss = 0.f;
+#pragma unroll
+        for (int k = 0; k < V4; ++k) { x[k] = p[k]; ss += x[k].x * x[k].x + x[k].y * x[k].y + x[k].z * x[k].z + x[k].w * x[k].w; }
+        const float iv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+#pragma unroll
+        for (int k = 0; k < V4; ++k) p[k] = make_float4(x[k].x * iv, x[k].y * iv, x[k].z * iv, x[k].w * iv);
+        if (inv) inv[r0 + tid] = iv;
+    }
+    __syncthreads();
+    float4* dst = reinterpret_cast<float4*>(v + r0 * E_);
+#pragma unroll
+    for (int k = 0; k < V4; ++k) {
+        const int i = tid + 256 * k, row = i / V4, c4 = i - row * V4;
+        if (i < nr * V4) dst[i] = *reinterpret_cast<const float4*>(&tile[row * LD + c4 * 4]);
+    }
+}
+
+template <int E_>
+__global__ __launch_bounds__(256) void l2norm_bwd_slab_kernel(const float* __restrict__ v, const float* __restrict__ inv,
+                                                              const float* __restrict__ dv, float* __restrict__ du, long rows) {
+    constexpr int V4 = E_ / 4, LD = E_ + 4;
+    __shared__ __attribute__((aligned(16))) float tile[256 * LD];
+    const int tid = threadIdx.x;
+    const long r0 = (long)blockIdx.x * 256;
+    const int nr = (int)min((long)256, rows - r0);
+    const float4* sv = reinterpret_cast<const float4*>(v + r0 * E_);
+    const float4* sd = reinterpret_cast<const float4*>(dv + r0 * E_);
+    float4 pv[V4], pd[V4];
+#pragma unroll
+    for (int k = 0; k < V4; ++k) pv[k] = sv[min(tid + 256 * k, nr * V4 - 1)];
+#pragma unroll
+    for (int k = 0; k < V4; ++k) pd[k] = sd[min(tid + 256 * k, nr * V4 - 1)];
+    const float iv = inv[r0 + min(tid, nr - 1)];
+    // v through LDS into this thread's row registers, then dv through the same buffer
+    float4 xv[V4], xd[V4];
+#pragma unroll
+    for (int k = 0; k < V4; ++k) {
+        const int i = tid + 256 * k, row = i / V4, c4 = i - row * V4;
+        *reinterpret_cast<float4*>(&tile[row * LD + c4 * 4]) = pv[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < V4; ++k) xv[k] = *reinterpret_cast<const float4*>(&tile[tid * LD + k * 4]);
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < V4; ++k) {
+        const int i = tid + 256 * k, row = i / V4, c4 = i - row * V4;
+        *reinterpret_cast<float4*>(&tile[row * LD + c4 * 4]) = pd[k];
+    }
+    __syncthreads();
+    float dot = 0.f;
+#pragma unroll
+    for (int k = 0; k < V4; ++k) {
+        xd[k] = *reinterpret_cast<const float4*>(&tile[tid * LD + k * 4]);
+        dot += xv[k].x * xd[k].x + xv[k].y * xd[k].y + xv[k].z * xd[k].z + xv[k].w * xd[k].w;
+    }
+    const bool active = iv < 0.999999e6f;
+    const float dd = active ? dot : 0.f;                      // clamp active -> du = dv * inv
+#pragma unroll
+    for (int k = 0; k < V4; ++k)
+        *reinterpret_cast<float4*>(&tile[tid * LD + k * 4]) =
+            make_float4((xd[k].x - xv[k].x * dd) * iv, (xd[k].y - xv[k].y * dd) * iv, (xd[k].z - xv[k].z * dd) * iv, (xd[k].w - xv[k].w * dd) * iv);
+    __syncthreads();
+    float4* dst = reinterpret_cast<float4*>(du + r0 * E_);
+#pragma unroll
+    for (int k = 0; k < V4; ++k) {
+        const int i = tid + 256 * k, row = i / V4, c4 = i - row * V4;
+        if (i < nr * V4) dst[i] = *reinterpret_cast<const float4*>(&tile[row * LD + c4 * 4]);
+    }
+}
+
 // Column sums of a [rows, cols] matrix (bias gradients).  Two-stage, deterministic.
 // Stage 1: a block owns 64 columns x `rows_per_block` rows; its 4 waves take interleaved rows (256-byte coalesced
 // segments), then meet in LDS.  Stage 2 adds the few per-block partials in fixed order.
@@ -235,13 +331,27 @@ ams_status ams_make_masks(const float* rep_non_mix, float* Y, int32_t* argmax, i
 
 ams_status ams_l2norm_fwd(const float* u, float* v, float* inv, long rows, int E, void* stream) {
     AMS_REQUIRE(u && v && rows > 0 && E > 0);
-    hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(stream_blocks(rows * 16)), dim3(256), 0, (hipStream_t)stream, u, v, inv, rows, E);
+    const bool vec = (((uintptr_t)u | (uintptr_t)v) & 15) == 0 && rows < (1L << 31) * 256;
+    const dim3 sgrid((unsigned)ceil_div(rows, 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (vec && E == 40) hipLaunchKernelGGL(l2norm_fwd_slab_kernel<40>, sgrid, dim3(256), 0, st, u, v, inv, rows);
+    else if (vec && E == 32) hipLaunchKernelGGL(l2norm_fwd_slab_kernel<32>, sgrid, dim3(256), 0, st, u, v, inv, rows);
+    else if (vec && E == 20) hipLaunchKernelGGL(l2norm_fwd_slab_kernel<20>, sgrid, dim3(256), 0, st, u, v, inv, rows);
+    else if (vec && E == 8) hipLaunchKernelGGL(l2norm_fwd_slab_kernel<8>, sgrid, dim3(256), 0, st, u, v, inv, rows);
+    else hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(stream_blocks(rows * 16)), dim3(256), 0, st, u, v, inv, rows, E);
     return ams_check_launch();
 }
 
 ams_status ams_l2norm_bwd(const float* v, const float* inv, const float* dv, float* du, long rows, int E, void* stream) {
     AMS_REQUIRE(v && inv && dv && du && rows > 0 && E > 0);
-    hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(stream_blocks(rows * 16)), dim3(256), 0, (hipStream_t)stream, v, inv, dv, du, rows, E);
+    const bool vec = (((uintptr_t)v | (uintptr_t)dv | (uintptr_t)du) & 15) == 0 && rows < (1L << 31) * 256;
+    const dim3 sgrid((unsigned)ceil_div(rows, 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (vec && E == 40) hipLaunchKernelGGL(l2norm_bwd_slab_kernel<40>, sgrid, dim3(256), 0, st, v, inv, dv, du, rows);
+    else if (vec && E == 32) hipLaunchKernelGGL(l2norm_bwd_slab_kernel<32>, sgrid, dim3(256), 0, st, v, inv, dv, du, rows);
+    else if (vec && E == 20) hipLaunchKernelGGL(l2norm_bwd_slab_kernel<20>, sgrid, dim3(256), 0, st, v, inv, dv, du, rows);
+    else if (vec && E == 8) hipLaunchKernelGGL(l2norm_bwd_slab_kernel<8>, sgrid, dim3(256), 0, st, v, inv, dv, du, rows);
+    else hipLaunchKernelGGL(l2norm_bwd_kernel, dim3(stream_blocks(rows * 16)), dim3(256), 0, st, v, inv, dv, du, rows, E);
     return ams_check_launch();
 }
 
