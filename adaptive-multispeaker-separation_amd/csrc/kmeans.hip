@@ -73,8 +73,27 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // running sum keeps its left-to-right scalar order, so the result is bit-identical to the scalar formulation.
 // __launch_bounds__(256, 3): at least 3 waves per SIMD, i.e. <= 168 VGPRs -- without the bound hipcc settles at 222-256 registers
 // (2 waves, or 1) by hoisting the slab's LDS reads and the centroids into registers.
+// value of lane (l + S) for the lanes l that have one (S = 32: lanes 0..31, S = 16: lanes 0..15 of each 32, S < 16: within 16-lane rows)
+template <int S>
+__device__ __forceinline__ float lane_above(float v) {
+    const unsigned b = __builtin_bit_cast(unsigned, v);
+    if constexpr (S == 32 || S == 16) {
+        // "swap the upper half (S = 32) / the odd 16-lane rows (S = 16) of the first register with the lower half / even rows of the
+        // second": afterwards lane l of `lo` holds what lane l + S of `hi` held.  Written as asm: with the builtin hipcc (ROCm 7.2)
+        // picked the other result register in some contexts (tools/lane_probe*.hip).
+        unsigned hi = b, lo = 0u;
+        if constexpr (S == 32) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(hi), "+v"(lo));
+        else asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(hi), "+v"(lo));
+        return __builtin_bit_cast(float, lo);
+    }
+    else return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, b, 0x100 | S, 0xf, 0xf, true));      // row_shl:S
+}
+
 #ifndef AMS_KM_SGPR_CENT
 #define AMS_KM_SGPR_CENT 1
+#endif
+#ifndef AMS_KM_ACC_DEPTH
+#define AMS_KM_ACC_DEPTH 1
 #endif
 template <int E_, int C_, int MODE, bool HAS_W>
 __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? 3 : 1) void kmeans_pass_kernel(KmArgs a) {
@@ -87,7 +106,20 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? 3 :
     constexpr int BUF = (256 * LD > 128 * 64) ? 256 * LD : 128 * 64;
     __shared__ __attribute__((aligned(16))) float buf[BUF];
     __shared__ __attribute__((aligned(16))) float scent[C_ * E_];
-    const int r = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    // Work order.  The grid is flat; the dispatcher deals consecutive workgroup ids round-robin to the 8 XCDs, so XCD x sees ids
+    // x, x + 8, ...  Utterance bi = 8 * (n / M) + x is given to XCD x as a whole (M = G * tries workgroups, n = id / 8), chunk by
+    // chunk with the `tries` rows of a chunk adjacent: one utterance's embeddings (3.3 MB at L = 20480, E = 40) then sit in THAT
+    // XCD's 4 MB L2 while its 10 tries read them.  In (chunk, row) order every try's read went out to the fabric: 2.1 GB per pass
+    // at the benchmark shape, a prefetched slab took ~6 us to arrive and the waves sat idle 55 % of the time (-DAMS_KM_TRACE).
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    int r, g;
+    {
+        const int M = a.G * a.tries, xcd = blockIdx.x & 7, n = blockIdx.x >> 3;
+        const int ub = (n / M) * 8 + xcd, m = n - (n / M) * M;
+        if (ub >= a.b) return;                                     // padding of the last group of 8 utterances (whole workgroup)
+        g = m / a.tries;
+        r = ub * a.tries + (m - g * a.tries);
+    }
     const int bi = r / a.tries;
     const float* xb = a.xn + (long)bi * a.L * E_;
     const float* wb = HAS_W ? a.w + (long)(a.w_mod_b ? (r % a.b) : bi) * a.L : nullptr;
@@ -121,7 +153,11 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? 3 :
 #pragma unroll
         for (int k = 0; k < V4; ++k) {
             const int i = lane + 64 * k;
+#ifdef AMS_KM_NOLOAD            /* timing experiment only: the pass without its global reads */
+            pre[k] = make_float4((float)i, 1.f, (float)j, 0.5f);
+#else
             pre[k] = (i < np * V4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
         }
     };
     // measured, b = 64, L = 20480, 10 iterations: hard (640 rows, 6400 workgroups) 4.31 -> 3.82 ms with the prefetch; soft
@@ -244,10 +280,21 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? 3 :
                     }
                     auto accum = [&](auto WT) {
                         constexpr bool W = decltype(WT)::value;
+                        // ACC_DEPTH vector groups of the point are in flight ahead of the one being accumulated: the distance
+                        // temporaries are dead here, so the extra registers are free, and a group's 4 packed FMAs (16 cycles)
+                        // no longer wait out a full LDS round trip each
+                        constexpr int D = AMS_KM_ACC_DEPTH;
+                        float4 vq[D + 1];
+#pragma unroll
+                        for (int d = 0; d < D; ++d) {
+                            asm volatile("" ::: "memory");
+                            vq[d] = *reinterpret_cast<const float4*>(xrow + (d < V4 ? d : V4 - 1) * 4);
+                        }
 #pragma unroll
                         for (int q4 = 0; q4 < V4; ++q4) {
                             asm volatile("" ::: "memory");
-                            const float4 v = *reinterpret_cast<const float4*>(xrow + q4 * 4);
+                            if (q4 + D < V4) vq[(q4 + D) % (D + 1)] = *reinterpret_cast<const float4*>(xrow + (q4 + D) * 4);
+                            const float4 v = vq[q4 % (D + 1)];
                             f2 t0 = {v.x, v.y}, t1 = {v.z, v.w};
                             if (W) { t0 = t0 * wv2; t1 = t1 * wv2; }
 #pragma unroll
@@ -348,8 +395,16 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? 3 :
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             float v = acc[i];
-#pragma unroll
-            for (int s = 32; s >= 1; s >>= 1) v = __fadd_rn(v, __shfl_down(v, s, 64));
+            // lane j += lane j + s for s = 32 .. 1 -- the halving tree of the summation order -- on the VALU: gfx950's
+            // v_permlane32_swap / v_permlane16_swap bring the upper half / the odd 16-lane rows down, row_shl DPP does the rest.
+            // (As __shfl_down this was 6 ds_bpermute round trips per value, 492 per workgroup, all on wave 0: the tail of the
+            // workgroup was 27 % of its lifetime.)
+            v = __fadd_rn(v, lane_above<32>(v));
+            v = __fadd_rn(v, lane_above<16>(v));
+            v = __fadd_rn(v, lane_above<8>(v));
+            v = __fadd_rn(v, lane_above<4>(v));
+            v = __fadd_rn(v, lane_above<2>(v));
+            v = __fadd_rn(v, lane_above<1>(v));
             if (lane == 0) a.part[((long)r * a.G + g) * NV + i] = v;
         }
     }
@@ -452,7 +507,11 @@ __global__ __launch_bounds__(256) void kmeans_soft_bwd_kernel(KmBwdArgs a) {
 #pragma unroll
         for (int k = 0; k < V4; ++k) {
             const int i = tid + 256 * k;
+#ifdef AMS_KM_NOLOAD            /* timing experiment only: the pass without its global reads */
+            pre[k] = make_float4((float)i, 1.f, (float)j, 0.5f);
+#else
             pre[k] = (i < np * V4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+#endif
         }
     };
     for (int j = 0; j < PPL; ++j) {
@@ -671,7 +730,7 @@ __global__ void kmeans_bwd_reduce_kernel(const float* __restrict__ part, float* 
 
 template <int MODE>
 ams_status launch_pass(const KmArgs& a, int R, int E, int C, hipStream_t st) {
-    dim3 grid(a.G, R);
+    dim3 grid((unsigned)(ceil_div(a.b, 8) * 8 * a.G * a.tries));   // flat: see the work order at the top of kmeans_pass_kernel
     const bool hw = a.w != nullptr;
 #define AMS_KM(EE, CC) do { if (hw) hipLaunchKernelGGL((kmeans_pass_kernel<EE, CC, MODE, true>), grid, dim3(256), 0, st, a); \
                             else hipLaunchKernelGGL((kmeans_pass_kernel<EE, CC, MODE, false>), grid, dim3(256), 0, st, a); } while (0)
