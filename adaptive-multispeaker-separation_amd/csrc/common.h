@@ -31,6 +31,33 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+// value of lane (l + S) for the lanes l that have one (S = 32: lanes 0..31, S = 16: lanes 0..15 of each 32, S < 16: within 16-lane rows)
+template <int S>
+__device__ __forceinline__ float lane_above(float v) {
+    const unsigned b = __builtin_bit_cast(unsigned, v);
+    if constexpr (S == 32 || S == 16) {
+        // "swap the upper half (S = 32) / the odd 16-lane rows (S = 16) of the first register with the lower half / even rows of the
+        // second": afterwards lane l of `lo` holds what lane l + S of `hi` held.  Written as asm: with the builtin hipcc (ROCm 7.2)
+        // picked the other result register in some contexts (tools/lane_probe*.hip).
+        unsigned hi = b, lo = 0u;
+        if constexpr (S == 32) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(hi), "+v"(lo));
+        else asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(hi), "+v"(lo));
+        return __builtin_bit_cast(float, lo);
+    }
+    else return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, b, 0x100 | S, 0xf, 0xf, true));      // row_shl:S
+}
+
+// Sum of the 64 lanes, valid in LANE 0 ONLY, as the halving tree l += l + s (s = 32 .. 1) on the VALU: 6 instructions instead of the
+// 6 ds_bpermute round trips of the butterfly above.  For per-block reductions of many values (one result lane is all they need).
+__device__ __forceinline__ float wave_sum_lane0(float v) {
+    v += lane_above<32>(v);
+    v += lane_above<16>(v);
+    v += lane_above<8>(v);
+    v += lane_above<4>(v);
+    v += lane_above<2>(v);
+    v += lane_above<1>(v);
+    return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));

@@ -73,22 +73,6 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 // running sum keeps its left-to-right scalar order, so the result is bit-identical to the scalar formulation.
 // __launch_bounds__(256, 3): at least 3 waves per SIMD, i.e. <= 168 VGPRs -- without the bound hipcc settles at 222-256 registers
 // (2 waves, or 1) by hoisting the slab's LDS reads and the centroids into registers.
-// value of lane (l + S) for the lanes l that have one (S = 32: lanes 0..31, S = 16: lanes 0..15 of each 32, S < 16: within 16-lane rows)
-template <int S>
-__device__ __forceinline__ float lane_above(float v) {
-    const unsigned b = __builtin_bit_cast(unsigned, v);
-    if constexpr (S == 32 || S == 16) {
-        // "swap the upper half (S = 32) / the odd 16-lane rows (S = 16) of the first register with the lower half / even rows of the
-        // second": afterwards lane l of `lo` holds what lane l + S of `hi` held.  Written as asm: with the builtin hipcc (ROCm 7.2)
-        // picked the other result register in some contexts (tools/lane_probe*.hip).
-        unsigned hi = b, lo = 0u;
-        if constexpr (S == 32) asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(hi), "+v"(lo));
-        else asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(hi), "+v"(lo));
-        return __builtin_bit_cast(float, lo);
-    }
-    else return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0u, b, 0x100 | S, 0xf, 0xf, true));      // row_shl:S
-}
-
 #ifndef AMS_KM_SGPR_CENT
 #define AMS_KM_SGPR_CENT 1
 #endif

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb,
     for (int s = 0; s < S; ++s) {
 #pragma unroll
         for (int e = 0; e < E_; ++e) {
-            const float c = wave_sum((tid < npts) ? dz[s] * v[e] : 0.f);
+            const float c = wave_sum_lane0((tid < npts) ? dz[s] * v[e] : 0.f);       // S * E of these per block: VALU tree, not bpermutes
             if ((tid & 63) == 0) red[tid >> 6][s * E_ + e] = c;
         }
     }
