@@ -262,7 +262,16 @@ class Network(object):
                 opt.step()
                 self.last_run = run
                 return cost.detach().reshape(-1)[0]
-            st['static'] = [t.clone() for t in ins]
+            # x_mix [B,L] and x_non_mix [B,S,L] live back to back in one buffer: Adapt's concat([x_mix, x_non_mix rows]) is then a view
+            xm, xn = ins[0], ins[1]
+            if xm.dtype == xn.dtype and xm.dim() == 2 and xn.dim() == 3 and xm.shape[-1] == xn.shape[-1]:
+                flat = torch.empty(xm.numel() + xn.numel(), dtype=xm.dtype, device=xm.device)
+                sm, sn = flat[:xm.numel()].view(xm.shape), flat[xm.numel():].view(xn.shape)
+                sm.copy_(xm)
+                sn.copy_(xn)
+                st['static'] = [sm, sn] + [t.clone() for t in ins[2:]]
+            else:
+                st['static'] = [t.clone() for t in ins]
             run = self._feeds(feed_dict, True)
             for node, t in zip((self.x_mix, self.x_non_mix, self.I), st['static']):
                 run.cache[id(node)] = t
