@@ -14,7 +14,8 @@ module and by structural checks (tests/test_tf_checkpoint.py).  Variable names a
   keys   = "" -> BundleHeaderProto{1 num_shards, 2 endianness, 3 version}; variable name -> BundleEntryProto{1 dtype, 2 shape
            (TensorShapeProto{2 dim{1 size}}), 3 shard_id, 4 offset, 5 size, 6 crc32c (fixed32, masked)}.
 ``.data-*`` holds the raw little-endian tensor bytes at [offset, offset+size).
-Snappy-compressed blocks are not supported (BundleWriter writes raw blocks); they raise a clear error.
+BundleWriter writes raw blocks; a table written with snappy block compression (type 1) is decoded by `_snappy_raw` below
+(the raw snappy format: varint32 uncompressed length, then literal / copy elements), so such an index loads as well.
 """
 import os
 import struct
@@ -26,6 +27,55 @@ from data import tfrecord as _tr
 _MAGIC = 0xdb4775248b80fb57
 _DT = {1: np.float32, 2: np.float64, 3: np.int32, 9: np.int64, 4: np.uint8, 6: np.int8, 5: np.int16, 10: np.bool_}
 _DT_INV = {np.dtype(v): k for k, v in _DT.items()}
+
+
+def _snappy_raw(buf):
+    """Decoder of the raw snappy format (format_description.txt of the snappy library): preamble = uncompressed length as a
+    varint32; elements tagged by the low two bits of their first byte: 00 literal (length-1 in the upper six bits, or in the next
+    1-4 bytes for 60-63), 01 copy with 11-bit offset (length 4-11), 10 copy with 16-bit offset, 11 copy with 32-bit offset
+    (length 1-64).  Copies may overlap their own output (run-length form), so they are expanded byte-wise when they do."""
+    n, pos = _uvarint(buf, 0)
+    out = bytearray()
+    L = len(buf)
+    while pos < L:
+        tag = buf[pos]
+        pos += 1
+        kind = tag & 3
+        if kind == 0:
+            ln = tag >> 2
+            if ln >= 60:
+                nb = ln - 59
+                ln = int.from_bytes(buf[pos:pos + nb], 'little')
+                pos += nb
+            ln += 1
+            if pos + ln > L:
+                raise IOError('snappy: literal runs past the end of the block')
+            out += buf[pos:pos + ln]
+            pos += ln
+            continue
+        if kind == 1:
+            ln = 4 + ((tag >> 2) & 7)
+            off = ((tag >> 5) << 8) | buf[pos]
+            pos += 1
+        elif kind == 2:
+            ln = (tag >> 2) + 1
+            off = int.from_bytes(buf[pos:pos + 2], 'little')
+            pos += 2
+        else:
+            ln = (tag >> 2) + 1
+            off = int.from_bytes(buf[pos:pos + 4], 'little')
+            pos += 4
+        if off == 0 or off > len(out):
+            raise IOError('snappy: copy offset %d outside the %d bytes produced so far' % (off, len(out)))
+        start = len(out) - off
+        if off >= ln:
+            out += out[start:start + ln]
+        else:
+            for i in range(ln):
+                out.append(out[start + i])
+    if len(out) != n:
+        raise IOError('snappy: block expands to %d bytes, header says %d' % (len(out), n))
+    return bytes(out)
 
 
 def _uvarint(buf, pos):
@@ -44,8 +94,10 @@ def _read_block(raw, off, size, verify=True):
     (crc,) = struct.unpack('<I', raw[off + size + 1:off + size + 5])
     if verify and crc != _tr.masked_crc(raw[off:off + size + 1]):
         raise IOError('TF checkpoint index: block CRC mismatch at offset %d' % off)
-    if typ != 0:
-        raise NotImplementedError('TF checkpoint index: compressed block (type %d); only raw blocks are supported' % typ)
+    if typ == 1:
+        body = _snappy_raw(body)
+    elif typ != 0:
+        raise NotImplementedError('TF checkpoint index: block compression type %d (0 = raw and 1 = snappy are defined)' % typ)
     (nrestart,) = struct.unpack('<I', body[-4:])
     end = len(body) - 4 * (nrestart + 1)
     pos, key = 0, b''

@@ -143,3 +143,79 @@ def test_reader_on_a_hand_assembled_index(tmp_path):
     # and the in-repo CRC agrees with the bit-wise one on these blocks
     from data import tfrecord
     assert tfrecord.masked_crc(block0 + b'\x00') == _mask(_crc32c_bitwise(block0 + b'\x00'))
+
+
+# ---- snappy-compressed table blocks (block type 1) --------------------------------------------------------------------------------
+def test_snappy_decoder_known_streams():
+    """The raw snappy format, element by element (format_description.txt): a hand-assembled stream with a literal, the three
+    copy encodings and a copy that overlaps its own output (run-length form), then streams from an independent ENCODER (pyarrow's
+    snappy codec), including a literal longer than 60 bytes (length in trailing bytes) and incompressible input."""
+    stream = (bytes([23])                                  # uncompressed length 23
+              + bytes([(4 - 1) << 2]) + b'abcd'            # literal "abcd"
+              + bytes([0b000_001_01, 4])                   # copy-1: len 4 + 1 = 5, offset 4  -> "abcda" (overlaps: off < len)
+              + bytes([((6 - 1) << 2) | 2, 9, 0])          # copy-2: len 6, offset 9         -> "abcdab"
+              + bytes([((8 - 1) << 2) | 3, 2, 0, 0, 0]))   # copy-4: len 8, offset 2         -> "abababab"
+    assert tfc._snappy_raw(stream) == b'abcd' + b'abcda' + b'abcdab' + b'abababab'
+    pa = pytest.importorskip('pyarrow')
+    rng = np.random.RandomState(0)
+    for blob in (b'', b'x', b'abcabcabcabcabcabc hello hello hello' * 40, bytes(rng.randint(0, 256, 5000, dtype=np.uint8)),
+                 bytes(rng.randint(0, 4, 70000, dtype=np.uint8)), b'q' * 100000):
+        assert tfc._snappy_raw(pa.compress(blob, codec='snappy', asbytes=True)) == blob
+    with pytest.raises(IOError):
+        tfc._snappy_raw(bytes([5]) + bytes([(3 - 1) << 2]) + b'abc')          # expands to 3 bytes, header says 5
+    with pytest.raises(IOError):
+        tfc._snappy_raw(bytes([4]) + bytes([0b000_000_01, 9]))                 # copy before anything was produced
+
+
+def test_reader_on_snappy_compressed_blocks(tmp_path):
+    """A table written with block compression on: every block of a bundle index re-encoded as type 1 (snappy body, CRC over
+    compressed body + type byte, as table_builder.cc does) must read back like the raw one."""
+    pa = pytest.importorskip('pyarrow')
+    rng = np.random.RandomState(3)
+    arrays = _arrays(rng, n=40)
+    prefix = str(tmp_path / 'model-5')
+    tfc.write_bundle(prefix, arrays)
+    raw = open(prefix + '.index', 'rb').read()
+    footer = raw[-48:]
+    pos = 0
+    offm, pos = tfc._uvarint(footer, pos); szm, pos = tfc._uvarint(footer, pos)
+    offi, pos = tfc._uvarint(footer, pos); szi, pos = tfc._uvarint(footer, pos)
+    index_entries = tfc._read_block(raw, offi, szi)                          # [(separator key, handle bytes)]
+
+    def varint(n):
+        b = bytearray()
+        while n >= 0x80:
+            b.append((n & 0x7f) | 0x80)
+            n >>= 7
+        b.append(n)
+        return bytes(b)
+
+    def packed(body):
+        comp = pa.compress(body, codec='snappy', asbytes=True)
+        return comp + b'\x01' + struct.pack('<I', _mask(_crc32c_bitwise(comp + b'\x01'))), len(comp)
+    out = bytearray()
+    new_index = bytearray()
+    restarts = []
+    for key, handle in index_entries:
+        off, size, _ = tfc._handle(handle, 0)
+        blob, clen = packed(raw[off:off + size])
+        h = varint(len(out)) + varint(clen)
+        out += blob
+        restarts.append(len(new_index))
+        new_index += bytes([0]) + varint(len(key)) + varint(len(h)) + key + h
+    new_index += b''.join(struct.pack('<I', r) for r in restarts) + struct.pack('<I', len(restarts))
+    meta_blob, mlen = packed(raw[offm:offm + szm])
+    offm2 = len(out); out += meta_blob
+    idx_blob, ilen = packed(bytes(new_index))
+    offi2 = len(out); out += idx_blob
+    foot = varint(offm2) + varint(mlen) + varint(offi2) + varint(ilen)
+    out += foot + b'\x00' * (40 - len(foot)) + bytes.fromhex('57fb808b247547db')
+    prefix2 = str(tmp_path / 'model-6')
+    open(prefix2 + '.index', 'wb').write(bytes(out))
+    for f in os.listdir(str(tmp_path)):
+        if f.startswith('model-5.data'):
+            open(os.path.join(str(tmp_path), f.replace('model-5', 'model-6')), 'wb').write(open(os.path.join(str(tmp_path), f), 'rb').read())
+    got = tfc.read_bundle(prefix2)
+    assert sorted(got) == sorted(arrays)
+    for k in arrays:
+        assert np.array_equal(got[k], arrays[k]) and got[k].dtype == arrays[k].dtype
