@@ -595,7 +595,7 @@ __global__ __launch_bounds__(256) void kmeans_soft_bwd_kernel(KmBwdArgs a) {
     if (wave == 0) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const float v = wave_sum(acc[i]);
+            const float v = wave_sum_lane0(acc[i]);                  // VALU tree: 80+ values per workgroup (was 6 ds_bpermute each)
             if (lane == 0) a.part[((long)r * a.G + g) * NV + i] = v;
         }
     }
