@@ -139,6 +139,10 @@ constexpr int CP = 8;                  // label-count partials per utterance
 #define AMS_DPCL_UCHUNK 2560
 #endif
 constexpr int UCHUNK = AMS_DPCL_UCHUNK;           // points per workgroup in the fused pass
+#ifndef AMS_DPCL_BCHUNK
+#define AMS_DPCL_BCHUNK 2560
+#endif
+constexpr int BCHUNK = AMS_DPCL_BCHUNK;           // ... in the backward pass (no per-workgroup partials there: may be smaller)
 
 __global__ __launch_bounds__(256) void dpcl_count_part_kernel(const float* __restrict__ Y, float* __restrict__ cntp, long TF, int S) {
     __shared__ float sm[4][8];
@@ -504,7 +508,7 @@ __global__ __launch_bounds__(256, 2) void dpcl_bwd_u_kernel(const float* __restr
             }
     }
 
-    const long p_begin = (long)c * UCHUNK, p_end = min(TF, p_begin + UCHUNK);
+    const long p_begin = (long)c * BCHUNK, p_end = min(TF, p_begin + BCHUNK);
     const float* Ub = U + (long)b * TF * E;
     const float* Yb = Y + (long)b * TF * S;
     const float* ib = inv + (long)b * TF;
@@ -746,7 +750,7 @@ ams_status ams_dpcl_loss_bwd_u(const float* U, const float* Y, const float* inv,
     const float* mats = cntp + (size_t)B * CP * S + (size_t)B * 4;
     const int NT = ceil_div(E + S, 16);
     if (E + S > 64) return AMS_E_INVALID_ARG;
-    dim3 grid(ceil_div(TF, UCHUNK), B);
+    dim3 grid(ceil_div(TF, BCHUNK), B);
     switch (NT) {
         case 1: hipLaunchKernelGGL((dpcl_bwd_u_kernel<1, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S); break;
         case 2: hipLaunchKernelGGL((dpcl_bwd_u_kernel<2, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S); break;
