@@ -17,10 +17,12 @@
 // fixed order (deterministic) and applies bias / accumulate.
 #include "common.h"
 #include <stdlib.h>
+#include <atomic>
 
 namespace {
 
 thread_local int t_gemm_lds_pad = 0;
+std::atomic<int> g_gemm_arith{-1};        // -1: not chosen yet (AMS_GEMM_X6, default 1), 0: native f32 MFMA, 1: bf16x6
 
 // Tuning overrides (A/B runs only): read from the environment ONCE per process, never on the launch path.
 struct GemmTuning { int group_m, splits; bool noprio, novec; };
@@ -39,7 +41,26 @@ inline const GemmTuning& tuning() {
 #ifndef AMS_GEMM_BK
 #define AMS_GEMM_BK 8
 #endif
+#ifndef AMS_GEMM_XCD_FLAT
+#define AMS_GEMM_XCD_FLAT 1
+#endif
+// Arithmetic of the 16-byte-fetch products: 1 = bf16x6 (exact 3-way bf16 split of both f32 operands, six bf16 MFMA products, f32
+// accumulation: f32-level error at 2.7x the f32 MFMA ceiling), 0 = native v_mfma_f32_32x32x2_f32.  Process-wide; the default comes
+// from AMS_GEMM_X6 (read once), ams_gemm_set_arith() changes it (tests and A/B runs hold both kernels against float64).
+inline bool use_x6() {
+    int v = g_gemm_arith.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char* f = getenv("AMS_GEMM_X6");
+        v = (f && atoi(f) == 0) ? 0 : 1;
+        g_gemm_arith.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
 constexpr int BM = 128, BN = 128, BK = AMS_GEMM_BK;
+constexpr int X6_BK = 32;           // k-tile of the bf16x6 kernel
+#ifndef AMS_GEMM_X6_US16
+#define AMS_GEMM_X6_US16 0.45
+#endif
 constexpr int PAD_T = 2;   // k-contiguous source, transposed scalar LDS writes: stride 130 -> conflict-free
 constexpr int PAD_V = 4;   // m/n-contiguous source, float4 LDS writes: stride 132 keeps 16B alignment
 
@@ -104,6 +125,71 @@ __device__ __forceinline__ float loadB1(const GemmArgs& g, int k, int n) {
     return g.B[(long)n * g.ldb + k];
 }
 
+// Work item of this workgroup: (batch z, k-split, output tile).  Shifts the operand pointers of a batched launch.
+__device__ __forceinline__ void locate_tile(GemmArgs& g, int& split, int& tile_m, int& tile_n) {
+    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+    const int ntiles = tiles_m * tiles_n;
+    int bid, zb;
+    {
+        const int nz = g.nbatch > 1 ? g.nbatch : 1;
+        const int items = ntiles * g.splits * nz;               // == gridDim.x
+        int item = blockIdx.x;
+#if AMS_GEMM_XCD_FLAT
+        const int q = items / 8, r = items % 8, xcd = item % 8, idx = item / 8;
+        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+        zb = item / (ntiles * g.splits);
+        item -= zb * (ntiles * g.splits);
+        split = item / ntiles;
+        bid = item - split * ntiles;
+#else
+        zb = item / (ntiles * g.splits);                       // round-1 order: per-(z, split) plane, tiles dealt by x % 8
+        item -= zb * (ntiles * g.splits);
+        split = item / ntiles;
+        bid = item - split * ntiles;
+        const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+#endif
+    }
+    if (g.nbatch > 1) {                             // batched launch: same shape, shifted operands
+        const long z = zb;
+        g.A += z * g.a_zs; g.B += z * g.b_zs; g.C += z * g.c_zs;
+        g.seg_off += z * g.seg_off_zs;
+        if (g.bias) g.bias += z * g.bias_zs;
+        if (g.partial) g.partial += z * (long)g.splits * g.M * g.N;
+    }
+    const int GROUP_M = g.group_m > 0 ? g.group_m : 1;        // chosen per launch (choose_group_m)
+    const int band = bid / (GROUP_M * tiles_n), within = bid - band * (GROUP_M * tiles_n);
+    const int band_rows = min(GROUP_M, tiles_m - band * GROUP_M);
+    tile_n = within / band_rows;
+    tile_m = band * GROUP_M + (within - tile_n * band_rows);
+}
+
+// Epilogue shared by the f32 and the bf16x6 kernel (the C/D layout of the 32x32 MFMAs does not depend on the input type):
+// col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
+__device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16 (&acc)[2][2], int split, int m0, int n0, int wm, int wn,
+                                           int l31, int lk) {
+    float* out = g.splits > 1 ? g.partial + (long)split * g.M * g.N : g.C;
+    const long ldo = g.splits > 1 ? g.N : g.ldc;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + l31;
+            if (col >= g.N) continue;
+            const float bv = (g.splits == 1 && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (row < g.M) {
+                    float v = acc[i][j][r] + bv;
+                    float* p = out + ((g.splits == 1 && g.seg_len) ? rowmap(g, row) : (long)row) * ldo + col;
+                    if (g.splits == 1 && g.accumulate) v += *p;
+                    *p = v;
+                }
+            }
+        }
+}
+
 // Is operand A contiguous along k (-> transposed LDS writes) ?
 template <int AMODE> struct AKContig { static constexpr bool v = (AMODE == A_ROW || AMODE == A_FRAMES); };
 
@@ -126,9 +212,6 @@ enum { EPI_STORE = 0, EPI_MAXPOOL = 1 };
 // mixtures/s: the recurrent step kernels ran 8-10 % slower in the same replay), so the default stays 1.
 #ifndef AMS_GEMM_PF
 #define AMS_GEMM_PF 2      // round 2: beside the ring recurrence (csrc/lstm_ring.hip) the deeper prefetch pays in the step too: +5..6 % on every product alone, 13.47 -> 13.58 k mixtures/s
-#endif
-#ifndef AMS_GEMM_XCD_FLAT
-#define AMS_GEMM_XCD_FLAT 1
 #endif
 #ifndef AMS_GEMM_FRAG
 #define AMS_GEMM_FRAG 0
@@ -160,41 +243,8 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
     // splits each XCD owns one k-slice of both operands (read once: ~1x algorithmic), with fewer splits a patch of one slice.
     // (A (tiles, splits, batch) grid broke the b % 8 assumption for every y, z > 0 whenever tiles % 8 != 0: the weight-gradient
     // products re-fetched their panels ~3x, profiles/r02_c_hbm_traffic.txt.)
-    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
-    const int ntiles = tiles_m * tiles_n;
-    int bid, split, zb;
-    {
-        const int nz = g.nbatch > 1 ? g.nbatch : 1;
-        const int items = ntiles * g.splits * nz;               // == gridDim.x
-        int item = blockIdx.x;
-#if AMS_GEMM_XCD_FLAT
-        const int q = items / 8, r = items % 8, xcd = item % 8, idx = item / 8;
-        item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-        zb = item / (ntiles * g.splits);
-        item -= zb * (ntiles * g.splits);
-        split = item / ntiles;
-        bid = item - split * ntiles;
-#else
-        zb = item / (ntiles * g.splits);                       // round-1 order: per-(z, split) plane, tiles dealt by x % 8
-        item -= zb * (ntiles * g.splits);
-        split = item / ntiles;
-        bid = item - split * ntiles;
-        const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-#endif
-    }
-    if (g.nbatch > 1) {                             // batched launch: same shape, shifted operands
-        const long z = zb;
-        g.A += z * g.a_zs; g.B += z * g.b_zs; g.C += z * g.c_zs;
-        g.seg_off += z * g.seg_off_zs;
-        if (g.bias) g.bias += z * g.bias_zs;
-        if (g.partial) g.partial += z * (long)g.splits * g.M * g.N;
-    }
-    const int GROUP_M = g.group_m > 0 ? g.group_m : 1;        // chosen per launch (choose_group_m)
-    const int band = bid / (GROUP_M * tiles_n), within = bid - band * (GROUP_M * tiles_n);
-    const int band_rows = min(GROUP_M, tiles_m - band * GROUP_M);
-    const int tile_n = within / band_rows;
-    const int tile_m = band * GROUP_M + (within - tile_n * band_rows);
+    int split, tile_m, tile_n;
+    locate_tile(g, split, tile_m, tile_n);
     const int m0 = tile_m * BM, n0 = tile_n * BN;
 
     const int k_begin = split * g.k_per_split;
@@ -479,27 +529,269 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
         }
         return;
     }
-    // Epilogue.  C/D layout of 32x32: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5).
-    float* out = g.splits > 1 ? g.partial + (long)split * g.M * g.N : g.C;
-    const long ldo = g.splits > 1 ? g.N : g.ldc;
+    store_tile(g, acc, split, m0, n0, wm, wn, l31, lk);
+}
+
+// ---- f32 products on the bf16 matrix pipe: exact 3-way operand split, six bf16 MFMA products, f32 accumulation ----------------------
+//
+// gfx950 runs v_mfma_f32_32x32x16_bf16 at 16x the rate of v_mfma_f32_32x32x2_f32 (2.5 PFLOP/s against 157 TFLOP/s).  Every f32 x
+// is EXACTLY hi + mid + lo with hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (round to nearest even; 3 x 8 significant
+// bits cover the 24 of an f32, both subtractions are exact), and every bf16 x bf16 product is exact in f32.  Of the nine partial
+// products of a.b the kernel accumulates six in f32 -- lo.hi, hi.lo, mid.mid, mid.hi, hi.mid, hi.hi, smallest first -- and drops
+// mid.lo, lo.mid, lo.lo, which are <= 2^-26 |a.b| together: a quarter of the half-ulp an f32 product rounding would cost.  The
+// result is an f32 product with f32-level error (tests/test_gpu_gemm_x6.py holds it against float64 next to the native f32 MFMA
+// kernel), at 16/6 = 2.7x the f32 MFMA ceiling.  Inf/NaN inputs give NaN (inf - inf in the split).
+//
+// Tile 128 x 128 x 32, 4 waves in 2 x 2, 64 x 64 per wave = 2 x 2 MFMA tiles x 2 k-steps x 6 products = 48 MFMAs per k-tile.  The
+// operand fetch is the f32 kernel's (one unconditional 16-byte load per operand quarter on a clamped address, validity applied
+// at the LDS write); the split happens ONCE per element, between the staging registers and LDS.  LDS image per operand and part:
+// four planes (one per group of 8 k) of 128 rows x 16 bytes, so that an MFMA operand (lane l: row l & 31, k-group l >> 5) is ONE
+// ds_read_b128.  Sources that are contiguous along k (A_ROW, A_FRAMES, B_COL) are written as 16-byte rows by threads holding 8
+// consecutive k of a row; sources contiguous along m/n (A_COL, A_FRAMES_T, B_ROW) by threads holding a 4 (k) x 4 (m) block, 8 bytes
+// per m, into rows permuted by x6_slot() so that neither those writes nor the 16-lane groups of the reads pile up on a bank.
+// One LDS buffer (48.75 KB) and a register-staged prefetch: tile kt+1 sits in registers while tile kt is multiplied.
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int X6_PLANE = 128 * 16 + 32;     // bytes; +32: the four planes start 8 banks apart (16-byte row writes of one wave hit all four)
+constexpr int X6_PART = 4 * X6_PLANE;
+constexpr int X6_OPER = 3 * X6_PART;
+constexpr int X6_LDS = 2 * X6_OPER;
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {           // v_cvt_pk_bf16_f32: a -> bits 0..15, b -> bits 16..31
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
+}
+__device__ __forceinline__ void split3(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = pk_bf16(a, b);
+    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+    mid = pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xffff0000u);
+    lo = pk_bf16(sa, sb);
+}
+// LDS row of operand row n (0..127) for m/n-contiguous sources: the four rows a thread's float4 covers go to four 32-row blocks,
+// rotated by 4 rows per block (read groups {0-3,12-15,20-27} / {4-11,16-19,28-31} of ds_read_b128 then touch 16 different slots).
+__device__ __forceinline__ int x6_slot(int n) { return (n & 3) * 32 + (((n >> 2) + 4 * (n & 3)) & 31); }
+__device__ __forceinline__ float comp4(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs g) {
+    constexpr int BK = X6_BK;
+    if (g.hiprio) __builtin_amdgcn_s_setprio(2);
+    constexpr bool AK = AKContig<AMODE>::v;
+    constexpr bool BKc = (BMODE == B_COL);
+    __shared__ __attribute__((aligned(16))) unsigned char smem[X6_LDS];
+    unsigned char* const As = smem;
+    unsigned char* const Bs = smem + X6_OPER;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, lk = lane >> 5;
+
+    int split, tile_m, tile_n;
+    locate_tile(g, split, tile_m, tile_n);
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    const int k_begin = split * g.k_per_split;
+    const int k_end = min(g.K, k_begin + g.k_per_split);
+    const int nk = (k_end - k_begin + BK - 1) / BK;
+
+    f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + l31;
-            if (col >= g.N) continue;
-            const float bv = (g.splits == 1 && g.bias) ? g.bias[col] : 0.f;
+        for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (row < g.M) {
-                    float v = acc[i][j][r] + bv;
-                    float* p = out + ((g.splits == 1 && g.seg_len) ? rowmap(g, row) : (long)row) * ldo + col;
-                    if (g.splits == 1 && g.accumulate) v += *p;
-                    *p = v;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // k-contiguous operands: thread -> rows (tid >> 2) and (tid >> 2) + 64, k-group tid & 3 (8 consecutive k = two float4)
+    // m/n-contiguous operands: thread -> columns 4 * (tid & 31) .. + 3, k rows 4 * (tid >> 5) .. + 3 (four float4)
+    const int kgrp = tid & 3, krow = tid >> 2;
+    const int mb = tid & 31, kb = tid >> 5;
+    long arow[2] = {0, 0};
+    int fp0[2] = {0, 0};
+    if (AMODE == A_ROW) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) arow[h] = rowmap(g, min(m0 + krow + 64 * h, g.M - 1)) * g.lda;
+    }
+    if (AMODE == A_FRAMES) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = min(m0 + krow + 64 * h, g.M - 1);
+            const int b = m / g.fr_T, t = m - b * g.fr_T;
+            arow[h] = (long)b * g.fr_L;
+            fp0[h] = t * g.fr_hop - g.fr_pl;
+        }
+    }
+    long brow[2] = {0, 0};
+    if (BKc) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) brow[h] = (long)min(n0 + krow + 64 * h, g.N - 1) * g.ldb;
+    }
+
+    float4 ra[4], rb[4];
+    bool va[4], vb[4];
+    auto fetch = [&](int kt) {
+        const int k0 = k_begin + kt * BK;
+        if (AK) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int k = k0 + kgrp * 8 + 4 * c;
+                    if (AMODE == A_FRAMES) {            // hop, pad and L are multiples of 4: a float4 is all signal or all padding
+                        const int p = fp0[h] + k;
+                        va[2 * h + c] = k < k_end && p >= 0 && p < g.fr_L;
+                        ra[2 * h + c] = *reinterpret_cast<const float4*>(g.A + arow[h] + min(max(p, 0), g.fr_L - 4));
+                    } else {                            // A_ROW (K % 4 == 0)
+                        va[2 * h + c] = k < k_end;
+                        ra[2 * h + c] = *reinterpret_cast<const float4*>(g.A + arow[h] + min(k, g.K - 4));
+                    }
+                }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + 4 * kb + r, m = m0 + 4 * mb;
+                const int kc = min(k, g.K - 1);
+                if (AMODE == A_FRAMES_T) {              // filter gradient: m = tap, k = frame (b, t)
+                    const int b = kc / g.fr_T, t = kc - b * g.fr_T;
+                    const int p = t * g.fr_hop + m - g.fr_pl;
+                    va[r] = k < k_end && m < g.M && p >= 0 && p < g.fr_L;
+                    ra[r] = *reinterpret_cast<const float4*>(g.A + (long)b * g.fr_L + min(max(p, 0), g.fr_L - 4));
+                } else {                                // A_COL (M % 4 == 0)
+                    va[r] = k < k_end && !(g.mask_period && (k % g.mask_period) == g.mask_skip);
+                    ra[r] = *reinterpret_cast<const float4*>(g.A + (long)kc * g.lda + min(m, g.M - 4));
                 }
             }
         }
+        if (BKc) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const int k = k0 + kgrp * 8 + 4 * c;
+                    vb[2 * h + c] = k < k_end;
+                    rb[2 * h + c] = *reinterpret_cast<const float4*>(g.B + brow[h] + min(k, g.K - 4));
+                }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int k = k0 + 4 * kb + r, n = n0 + 4 * mb;
+                vb[r] = k < k_end;
+                rb[r] = *reinterpret_cast<const float4*>(g.B + (long)min(k, g.K - 1) * g.ldb + min(n, g.N - 4));
+            }
+        }
+    };
+
+    const bool do_bsum = !BKc && g.bsum_part != nullptr && tile_m == 0;      // workgroup-uniform
+    float4 bsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // split the staged f32 values and write the three bf16 images of one operand
+    auto stash_one = [&](unsigned char* base, bool kcontig, float4 (&rv)[4], bool (&vv)[4]) {
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) if (!vv[q]) rv[q] = z;
+        if (kcontig) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                uint4 hi, mid, lo;
+                split3(rv[2 * h].x, rv[2 * h].y, hi.x, mid.x, lo.x);
+                split3(rv[2 * h].z, rv[2 * h].w, hi.y, mid.y, lo.y);
+                split3(rv[2 * h + 1].x, rv[2 * h + 1].y, hi.z, mid.z, lo.z);
+                split3(rv[2 * h + 1].z, rv[2 * h + 1].w, hi.w, mid.w, lo.w);
+                unsigned char* p = base + kgrp * X6_PLANE + (krow + 64 * h) * 16;
+                *reinterpret_cast<uint4*>(p) = hi;
+                *reinterpret_cast<uint4*>(p + X6_PART) = mid;
+                *reinterpret_cast<uint4*>(p + 2 * X6_PART) = lo;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                uint2 hi, mid, lo;
+                split3(comp4(rv[0], j), comp4(rv[1], j), hi.x, mid.x, lo.x);
+                split3(comp4(rv[2], j), comp4(rv[3], j), hi.y, mid.y, lo.y);
+                unsigned char* p = base + (kb >> 1) * X6_PLANE + x6_slot(4 * mb + j) * 16 + (kb & 1) * 8;
+                *reinterpret_cast<uint2*>(p) = hi;
+                *reinterpret_cast<uint2*>(p + X6_PART) = mid;
+                *reinterpret_cast<uint2*>(p + 2 * X6_PART) = lo;
+            }
+        }
+    };
+    auto stash = [&]() {
+        stash_one(As, AK, ra, va);
+        stash_one(Bs, BKc, rb, vb);
+        if (!BKc && do_bsum) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { bsum4.x += rb[r].x; bsum4.y += rb[r].y; bsum4.z += rb[r].z; bsum4.w += rb[r].w; }
+        }
+    };
+
+    // MFMA operand addresses: lane l reads row (l & 31) of its 32-row tile, k-group 2 * kstep + (l >> 5)
+    const unsigned char* ap[2];
+    const unsigned char* bp[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ar = wm * 64 + i * 32 + l31, br = wn * 64 + i * 32 + l31;
+        ap[i] = As + (AK ? ar : x6_slot(ar)) * 16 + lk * X6_PLANE;
+        bp[i] = Bs + (BKc ? br : x6_slot(br)) * 16 + lk * X6_PLANE;
+    }
+    auto mfma_tile = [&]() {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8_t a[2][3], b[2][3];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+                    a[i][p] = *reinterpret_cast<const bf16x8_t*>(ap[i] + p * X6_PART + ks * 2 * X6_PLANE);
+                    b[i][p] = *reinterpret_cast<const bf16x8_t*>(bp[i] + p * X6_PART + ks * 2 * X6_PLANE);
+                }
+            // smallest partial products first; the four accumulators alternate, so dependent MFMAs are four issues apart
+            constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+            constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (nk > 0) {
+        fetch(0);
+        stash();
+        fetch(1);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        mfma_tile();
+        if (kt + 1 < nk) {                          // workgroup-uniform
+            __syncthreads();
+            stash();                                // tile kt + 1 (fetched one iteration ago)
+            fetch(kt + 2);                          // clamped addresses; invalid quarters are staged as zeros
+            __syncthreads();
+        }
+    }
+
+    if (!BKc && do_bsum) {
+        // thread (kb, mb) summed rows 4 kb .. 4 kb + 3 of every k-tile, columns 4 mb .. + 3: the 8 threads of a column group meet
+        // in LDS in a fixed order (deterministic)
+        float4* sb = reinterpret_cast<float4*>(smem);
+        __syncthreads();
+        sb[tid] = bsum4;
+        __syncthreads();
+        if (tid < 32) {
+            float4 t = sb[tid];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) { const float4 v = sb[tid + 32 * j]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            const int n = n0 + tid * 4;
+            if (n < g.N) *reinterpret_cast<float4*>(g.bsum_part + (long)split * g.N + n) = t;
+        }
+    }
+    store_tile(g, acc, split, m0, n0, wm, wn, l31, lk);
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, const float* __restrict__ bias,
@@ -565,15 +857,18 @@ __global__ void bsum_finish_kernel(const float* __restrict__ part, float* __rest
 // barrier stalls are not covered by a neighbour's MFMAs; the last term is the fp32 partial-slab round trip.
 inline int choose_splits(int M, int N, int K, int nbatch = 1) {
     const int tiles = ceil_div(M, BM) * ceil_div(N, BN) * nbatch;
+    const bool x6 = use_x6();                  // bf16x6 kernel: 32-deep k-tiles, ~0.45 us per 16 k and workgroup
+    const int bk = x6 ? X6_BK : BK;
+    const double us16 = x6 ? AMS_GEMM_X6_US16 : 1.024;
     int best = 1;
     double best_t = 1e30;
     for (int s = 1; s <= 32; ++s) {
         if (s > 1 && K / s < 128) break;
-        const int kps = ceil_div(ceil_div(K, s), BK) * BK;
+        const int kps = ceil_div(ceil_div(K, s), bk) * bk;
         const int s2 = ceil_div(K, kps);
         const int n = ceil_div((long)tiles * s2, 256);
         const double occ = n <= 1 ? 0.62 : (n == 2 ? 0.80 : (n == 3 ? 0.92 : 1.0));
-        double t = n * ((kps / 16.0) * 1.024 + 5.0) / occ;
+        double t = n * ((kps / 16.0) * us16 + 5.0) / occ;
         if (s2 > 1) t += (double)(s2 + 1) * M * N * nbatch * 4.0 / 2.5e6;
         if (t < best_t - 1e-9) { best_t = t; best = s2; }
     }
@@ -605,8 +900,16 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
         if (tuning().splits > 0) splits = tuning().splits;
         while (splits > 1 && (size_t)nbatch * splits * g.M * g.N * sizeof(float) > ws_bytes) --splits;
     }
+    constexpr bool AKc = (AMODE == A_ROW), BKcc = (BMODE == B_COL);
+    const bool vec_off = tuning().novec;
+    const bool vec = g.a_vec && g.b_vec && !vec_off &&
+                     (AMODE == A_FRAMES ? (g.K % 4 == 0 && g.fr_L >= 4) : AMODE == A_FRAMES_T ? (g.M % 4 == 0 && g.fr_L >= 4) :
+                      AKc ? (g.K % 4 == 0 && g.K >= 4) : (g.M % 4 == 0 && g.M >= 4)) &&
+                     (BKcc ? (g.K % 4 == 0 && g.K >= 4) : (g.N % 4 == 0 && g.N >= 4));
+    const bool x6 = vec && use_x6();
+    const int bk = x6 ? X6_BK : BK;
     int kps = ceil_div(g.K, splits);
-    kps = ceil_div(kps, BK) * BK;
+    kps = ceil_div(kps, bk) * bk;
     splits = ceil_div(g.K, kps);
     g.splits = splits;
     g.k_per_split = kps;
@@ -627,13 +930,25 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
             raised = t_gemm_lds_pad;
         }
     }
-    constexpr bool AKc = (AMODE == A_ROW), BKcc = (BMODE == B_COL);
-    const bool vec_off = tuning().novec;
-    const bool vec = g.a_vec && g.b_vec && !vec_off &&
-                     (AMODE == A_FRAMES ? (g.K % 4 == 0 && g.fr_L >= 4) : AMODE == A_FRAMES_T ? (g.M % 4 == 0 && g.fr_L >= 4) :
-                      AKc ? (g.K % 4 == 0 && g.K >= 4) : (g.M % 4 == 0 && g.M >= 4)) &&
-                     (BKcc ? (g.K % 4 == 0 && g.K >= 4) : (g.N % 4 == 0 && g.N >= 4));
-    if (vec) {
+    if (x6) {
+        // same residency (workgroups per CU) as the pad asks of the 16.8 KB f32 kernel, restated for 48.75 KB of static LDS
+        int pad = 0;
+        if (t_gemm_lds_pad > 0) {
+            int wg = 163840 / (17152 + t_gemm_lds_pad);
+            if (wg < 1) wg = 1;
+            pad = 163840 / wg - X6_LDS - 1024;
+            if (pad < 0) pad = 0;
+        }
+        if (X6_LDS + pad > 64 * 1024) {
+            static thread_local int raised_x = 0;
+            if (raised_x < pad) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<AMODE, BMODE>),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, pad);
+                raised_x = pad;
+            }
+        }
+        hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE>), grid, dim3(256), (size_t)pad, st, g);
+    } else if (vec) {
         if (t_gemm_lds_pad > 40 * 1024) {
             static thread_local int raised_v = 0;
             if (raised_v < t_gemm_lds_pad) {
@@ -679,6 +994,8 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 extern "C" {
 
 void ams_gemm_set_lds_pad(int bytes) { t_gemm_lds_pad = bytes < 0 ? 0 : bytes; }
+void ams_gemm_set_arith(int mode) { g_gemm_arith.store(mode ? 1 : 0, std::memory_order_relaxed); }
+int ams_gemm_get_arith(void) { return use_x6() ? 1 : 0; }
 
 size_t ams_gemm_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;

@@ -75,6 +75,14 @@ size_t ams_gemm_workspace_bytes(int M, int N, int K);
  * by the thread until the next set uses it.  Environment overrides of tile order / split count (AMS_GEMM_*) are read once
  * per process, not per launch. */
 void ams_gemm_set_lds_pad(int bytes);
+/* Arithmetic of the products below (process-wide; default 1, or AMS_GEMM_X6 read once): 1 = "bf16x6" -- both f32 operands are
+ * split EXACTLY into three bf16 terms (hi + mid + lo, round-to-nearest) and six of the nine bf16 x bf16 partial products (all but
+ * mid.lo, lo.mid, lo.lo <= 2^-26 |a.b|) are accumulated in f32 on v_mfma_f32_32x32x16_bf16, which gfx950 issues at 16x the rate
+ * of its f32 MFMA; results carry f32-level error (tests/test_gpu_gemm_x6.py: against float64, next to mode 0).  0 = native
+ * v_mfma_f32_32x32x2_f32.  Launches whose operands are not 16-byte addressable use mode 0 whatever the setting.  The workspace
+ * size of a product depends on the mode: size and launch under the same one. */
+void ams_gemm_set_arith(int mode);
+int ams_gemm_get_arith(void);
 ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C,
                         long ldc, const float* bias, int accumulate, int mask_period, int mask_skip, void* ws, size_t ws_bytes,
                         void* stream);
