@@ -25,14 +25,15 @@ thread_local int t_gemm_lds_pad = 0;
 std::atomic<int> g_gemm_arith{-1};        // -1: not chosen yet (AMS_GEMM_X6, default 1), 0: native f32 MFMA, 1: bf16x6
 
 // Tuning overrides (A/B runs only): read from the environment ONCE per process, never on the launch path.
-struct GemmTuning { int group_m, splits; bool noprio, novec; };
+struct GemmTuning { int group_m, splits; bool noprio, novec, x6ws; };
 inline const GemmTuning& tuning() {
     static const GemmTuning t = [] {
-        GemmTuning v{0, 0, false, false};
+        GemmTuning v{0, 0, false, false, false};
         if (const char* f = getenv("AMS_GEMM_GROUP_M")) v.group_m = atoi(f);
         if (const char* f = getenv("AMS_GEMM_SPLITS")) v.splits = atoi(f);
         v.noprio = getenv("AMS_GEMM_NOPRIO") != nullptr;
         v.novec = getenv("AMS_GEMM_NOVEC") != nullptr;
+        if (const char* f = getenv("AMS_GEMM_X6WS")) v.x6ws = atoi(f) != 0;   // 1: wave-specialised form (measured slower, see x6_body)
         return v;
     }();
     return t;
@@ -549,11 +550,24 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
 // ds_read_b128.  Sources that are contiguous along k (A_ROW, A_FRAMES, B_COL) are written as 16-byte rows by threads holding 8
 // consecutive k of a row; sources contiguous along m/n (A_COL, A_FRAMES_T, B_ROW) by threads holding a 4 (k) x 4 (m) block, 8 bytes
 // per m, into rows permuted by x6_slot() so that neither those writes nor the 16-lane groups of the reads pile up on a bank.
-// One LDS buffer (48.75 KB) and a register-staged prefetch: tile kt+1 sits in registers while tile kt is multiplied.
+// One LDS buffer (48.75 KB) and a two-deep register-staged prefetch: tiles kt+1 and kt+2 are in registers / in flight while
+// tile kt is multiplied.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
+#ifndef AMS_X6_DBG
+#define AMS_X6_DBG 0        // timing anatomy only (WRONG results): 1 no split arithmetic, 2 no LDS writes, 4 no MFMAs, 8 no LDS reads, 16 no fetch in the loop
+#endif
+#ifndef AMS_X6_TRACE
+#define AMS_X6_TRACE 0      // 1: workgroup 0 stamps wall_clock64() (100 MHz) at its phase boundaries (tools/x6_trace.py); adds waits
+#endif
+#if AMS_X6_TRACE
+__device__ unsigned long long g_x6_trace[2][64][4];
+#define X6_STAMP(role, kt, slot) do { if (blockIdx.x == 0 && lane == 0 && wave == 0 && (kt) < 64) g_x6_trace[role][kt][slot] = wall_clock64(); } while (0)
+#else
+#define X6_STAMP(role, kt, slot) do { } while (0)
+#endif
 constexpr int X6_PLANE = 128 * 16 + 32;     // bytes; +32: the four planes start 8 banks apart (16-byte row writes of one wave hit all four)
 constexpr int X6_PART = 4 * X6_PLANE;
 constexpr int X6_OPER = 3 * X6_PART;
@@ -564,6 +578,9 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {           // v_c
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ void split3(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+#if AMS_X6_DBG & 1
+    hi = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u); mid = hi; lo = hi; return;
+#endif
     hi = pk_bf16(a, b);
     const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
     mid = pk_bf16(ra, rb);
@@ -575,20 +592,32 @@ __device__ __forceinline__ void split3(float a, float b, unsigned& hi, unsigned&
 __device__ __forceinline__ int x6_slot(int n) { return (n & 3) * 32 + (((n >> 2) + 4 * (n & 3)) & 31); }
 __device__ __forceinline__ float comp4(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
-template <int AMODE, int BMODE>
-__global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs g) {
+// WS = false: 256 threads, every wave fetches, splits, writes LDS and multiplies in turn (one LDS buffer, two barriers per k-tile).
+// WS = true ("wave-specialised"): 512 threads -- waves 0-3 only read LDS and issue MFMAs, waves 4-7 only fetch, split and write the
+// NEXT tile into the other LDS buffer (2 x 48.75 KB, one workgroup per CU), one barrier per k-tile.  Why: timing anatomy of the
+// WS = false form (profiles/r02_i_gemm_x6_anatomy.txt) showed MFMA time and everything-else time ADDING (4096^3: 876 us = ~340 us of
+// MFMA + 438 us with the MFMAs compiled out) -- the two co-resident workgroups of a CU run in lock-step, both multiplying, then both
+// splitting -- whereas a consumer wave and a producer wave that share a SIMD interleave instruction by instruction.
+template <int AMODE, int BMODE, bool WS>
+__device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) {
     constexpr int BK = X6_BK;
-    if (g.hiprio) __builtin_amdgcn_s_setprio(2);
     constexpr bool AK = AKContig<AMODE>::v;
     constexpr bool BKc = (BMODE == B_COL);
-    __shared__ __attribute__((aligned(16))) unsigned char smem[X6_LDS];
-    unsigned char* const As = smem;
-    unsigned char* const Bs = smem + X6_OPER;
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const bool producer = WS && wave_all >= 4;          // wave-uniform
+    const bool consumer = !WS || wave_all < 4;
+    const int tid = threadIdx.x & 255;                  // index within the role
+    const int lane = tid & 63, wave = wave_all & 3;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, lk = lane >> 5;
+    // issue priority: consumers above producers (an MFMA needs one issue slot per 32 cycles, the split fills the rest); critical-path
+    // launches one level above residency-capped side-stream ones; the recurrence rings run at 3
+    if (WS) {
+        if (producer) { if (g.hiprio) __builtin_amdgcn_s_setprio(1); }
+        else if (g.hiprio) __builtin_amdgcn_s_setprio(2);
+        else __builtin_amdgcn_s_setprio(1);
+    } else if (g.hiprio) __builtin_amdgcn_s_setprio(2);
 
     int split, tile_m, tile_n;
     locate_tile(g, split, tile_m, tile_n);
@@ -630,9 +659,11 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs g) {
         for (int h = 0; h < 2; ++h) brow[h] = (long)min(n0 + krow + 64 * h, g.N - 1) * g.ldb;
     }
 
-    float4 ra[4], rb[4];
-    bool va[4], vb[4];
-    auto fetch = [&](int kt) {
+    // two staging sets: a tile is fetched two k-tiles before it is split (one MFMA phase of 48 MFMAs = 0.64 us does not cover a
+    // memory round trip at 2 workgroups per CU; the first version waited ~1 us per k-tile here)
+    float4 ra0[4], rb0[4], ra1[4], rb1[4];
+    bool va0[4], vb0[4], va1[4], vb1[4];
+    auto fetch = [&](int kt, float4 (&ra)[4], float4 (&rb)[4], bool (&va)[4], bool (&vb)[4]) {
         const int k0 = k_begin + kt * BK;
         if (AK) {
 #pragma unroll
@@ -701,6 +732,7 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs g) {
                 split3(rv[2 * h + 1].x, rv[2 * h + 1].y, hi.z, mid.z, lo.z);
                 split3(rv[2 * h + 1].z, rv[2 * h + 1].w, hi.w, mid.w, lo.w);
                 unsigned char* p = base + kgrp * X6_PLANE + (krow + 64 * h) * 16;
+                if (AMS_X6_DBG & 2) { asm volatile("" :: "v"(hi.x ^ hi.y ^ hi.z ^ hi.w ^ mid.x ^ mid.y ^ mid.z ^ mid.w ^ lo.x ^ lo.y ^ lo.z ^ lo.w)); continue; }
                 *reinterpret_cast<uint4*>(p) = hi;
                 *reinterpret_cast<uint4*>(p + X6_PART) = mid;
                 *reinterpret_cast<uint4*>(p + 2 * X6_PART) = lo;
@@ -712,15 +744,16 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs g) {
                 split3(comp4(rv[0], j), comp4(rv[1], j), hi.x, mid.x, lo.x);
                 split3(comp4(rv[2], j), comp4(rv[3], j), hi.y, mid.y, lo.y);
                 unsigned char* p = base + (kb >> 1) * X6_PLANE + x6_slot(4 * mb + j) * 16 + (kb & 1) * 8;
+                if (AMS_X6_DBG & 2) { asm volatile("" :: "v"(hi.x ^ hi.y ^ mid.x ^ mid.y ^ lo.x ^ lo.y)); continue; }
                 *reinterpret_cast<uint2*>(p) = hi;
                 *reinterpret_cast<uint2*>(p + X6_PART) = mid;
                 *reinterpret_cast<uint2*>(p + 2 * X6_PART) = lo;
             }
         }
     };
-    auto stash = [&]() {
-        stash_one(As, AK, ra, va);
-        stash_one(Bs, BKc, rb, vb);
+    auto stash = [&](int buf, float4 (&ra)[4], float4 (&rb)[4], bool (&va)[4], bool (&vb)[4]) {
+        stash_one(smem + buf * X6_LDS, AK, ra, va);
+        stash_one(smem + buf * X6_LDS + X6_OPER, BKc, rb, vb);
         if (!BKc && do_bsum) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) { bsum4.x += rb[r].x; bsum4.y += rb[r].y; bsum4.z += rb[r].z; bsum4.w += rb[r].w; }
@@ -733,10 +766,10 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         const int ar = wm * 64 + i * 32 + l31, br = wn * 64 + i * 32 + l31;
-        ap[i] = As + (AK ? ar : x6_slot(ar)) * 16 + lk * X6_PLANE;
-        bp[i] = Bs + (BKc ? br : x6_slot(br)) * 16 + lk * X6_PLANE;
+        ap[i] = smem + (AK ? ar : x6_slot(ar)) * 16 + lk * X6_PLANE;
+        bp[i] = smem + X6_OPER + (BKc ? br : x6_slot(br)) * 16 + lk * X6_PLANE;
     }
-    auto mfma_tile = [&]() {
+    auto mfma_tile = [&](int buf) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             bf16x8_t a[2][3], b[2][3];
@@ -744,8 +777,13 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs g) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int p = 0; p < 3; ++p) {
-                    a[i][p] = *reinterpret_cast<const bf16x8_t*>(ap[i] + p * X6_PART + ks * 2 * X6_PLANE);
-                    b[i][p] = *reinterpret_cast<const bf16x8_t*>(bp[i] + p * X6_PART + ks * 2 * X6_PLANE);
+                    if (AMS_X6_DBG & 8) {
+                        const uint4 c = {0x3f803f80u + (unsigned)i, 0x3f803f80u + (unsigned)p, 0x3f803f80u, 0x3f803f80u + (unsigned)ks};
+                        a[i][p] = __builtin_bit_cast(bf16x8_t, c); b[i][p] = __builtin_bit_cast(bf16x8_t, c);
+                        continue;
+                    }
+                    a[i][p] = *reinterpret_cast<const bf16x8_t*>(ap[i] + buf * X6_LDS + p * X6_PART + ks * 2 * X6_PLANE);
+                    b[i][p] = *reinterpret_cast<const bf16x8_t*>(bp[i] + buf * X6_LDS + p * X6_PART + ks * 2 * X6_PLANE);
                 }
             // smallest partial products first; the four accumulators alternate, so dependent MFMAs are four issues apart
             constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
@@ -755,24 +793,66 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs g) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < 2; ++j) {
+                        if (AMS_X6_DBG & 4) { asm volatile("" :: "v"(a[i][PA[t]]), "v"(b[j][PB[t]])); continue; }
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
+                    }
         }
     };
 
-    if (nk > 0) {
-        fetch(0);
-        stash();
-        fetch(1);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        mfma_tile();
-        if (kt + 1 < nk) {                          // workgroup-uniform
+    if (!WS) {
+        fetch(0, ra0, rb0, va0, vb0);
+        stash(0, ra0, rb0, va0, vb0);
+        fetch(1, ra0, rb0, va0, vb0);               // tiles past the split's end: clamped addresses, staged as zeros if ever used
+        fetch(2, ra1, rb1, va1, vb1);
+        __syncthreads();
+        for (int kt = 0;; kt += 2) {                // every branch below is workgroup-uniform
+            mfma_tile(0);                           // tile kt
+            if (kt + 1 >= nk) break;
             __syncthreads();
-            stash();                                // tile kt + 1 (fetched one iteration ago)
-            fetch(kt + 2);                          // clamped addresses; invalid quarters are staged as zeros
+            stash(0, ra0, rb0, va0, vb0);           // tile kt + 1
+            if (!(AMS_X6_DBG & 16)) fetch(kt + 3, ra0, rb0, va0, vb0);
             __syncthreads();
+            mfma_tile(0);                           // tile kt + 1
+            if (kt + 2 >= nk) break;
+            __syncthreads();
+            stash(0, ra1, rb1, va1, vb1);           // tile kt + 2
+            if (!(AMS_X6_DBG & 16)) fetch(kt + 4, ra1, rb1, va1, vb1);
+            __syncthreads();
+        }
+    } else {
+        // tile j is split into LDS buffer j & 1 while tile j - 1 is multiplied out of the other one; it was fetched two tiles
+        // earlier into staging set (j - 1) & 1.  One barrier per k-tile; every branch is wave-uniform.
+        if (producer) {
+            fetch(0, ra0, rb0, va0, vb0);
+            stash(0, ra0, rb0, va0, vb0);
+            fetch(1, ra0, rb0, va0, vb0);
+            fetch(2, ra1, rb1, va1, vb1);
+        }
+        __syncthreads();
+        for (int kt = 0;; kt += 2) {
+            X6_STAMP(producer ? 1 : 0, kt, 0);
+            if (consumer) { mfma_tile(0); X6_STAMP(0, kt, 1); }             // tile kt
+            else if (kt + 1 < nk) {
+                stash(1, ra0, rb0, va0, vb0);       // tile kt + 1
+                X6_STAMP(1, kt, 1);
+                if (!(AMS_X6_DBG & 16)) fetch(kt + 3, ra0, rb0, va0, vb0);
+                X6_STAMP(1, kt, 2);
+            }
+            __syncthreads();
+            X6_STAMP(producer ? 1 : 0, kt, 3);
+            if (kt + 1 >= nk) break;
+            X6_STAMP(producer ? 1 : 0, kt + 1, 0);
+            if (consumer) { mfma_tile(1); X6_STAMP(0, kt + 1, 1); }         // tile kt + 1
+            else if (kt + 2 < nk) {
+                stash(0, ra1, rb1, va1, vb1);       // tile kt + 2
+                X6_STAMP(1, kt + 1, 1);
+                if (!(AMS_X6_DBG & 16)) fetch(kt + 4, ra1, rb1, va1, vb1);
+                X6_STAMP(1, kt + 1, 2);
+            }
+            __syncthreads();
+            X6_STAMP(producer ? 1 : 0, kt + 1, 3);
+            if (kt + 2 >= nk) break;
         }
     }
 
@@ -781,9 +861,9 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs g) {
         // in LDS in a fixed order (deterministic)
         float4* sb = reinterpret_cast<float4*>(smem);
         __syncthreads();
-        sb[tid] = bsum4;
+        if (!WS || producer) sb[tid] = bsum4;
         __syncthreads();
-        if (tid < 32) {
+        if ((!WS || producer) && tid < 32) {
             float4 t = sb[tid];
 #pragma unroll
             for (int j = 1; j < 8; ++j) { const float4 v = sb[tid + 32 * j]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
@@ -791,7 +871,18 @@ __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs g) {
             if (n < g.N) *reinterpret_cast<float4*>(g.bsum_part + (long)split * g.N + n) = t;
         }
     }
-    store_tile(g, acc, split, m0, n0, wm, wn, l31, lk);
+    if (consumer) store_tile(g, acc, split, m0, n0, wm, wn, l31, lk);
+}
+
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[X6_LDS];
+    x6_body<AMODE, BMODE, false>(g, smem);
+}
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(512, 1) void gemm_x6ws_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * X6_LDS];
+    x6_body<AMODE, BMODE, true>(g, smem);
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, const float* __restrict__ bias,
@@ -947,7 +1038,8 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
                 raised_x = pad;
             }
         }
-        hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE>), grid, dim3(256), (size_t)pad, st, g);
+        if (tuning().x6ws) hipLaunchKernelGGL((gemm_x6ws_kernel<AMODE, BMODE>), grid, dim3(512), 0, st, g);    // one workgroup per CU by its own LDS
+        else hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE>), grid, dim3(256), (size_t)pad, st, g);
     } else if (vec) {
         if (t_gemm_lds_pad > 40 * 1024) {
             static thread_local int raised_v = 0;
@@ -996,6 +1088,9 @@ extern "C" {
 void ams_gemm_set_lds_pad(int bytes) { t_gemm_lds_pad = bytes < 0 ? 0 : bytes; }
 void ams_gemm_set_arith(int mode) { g_gemm_arith.store(mode ? 1 : 0, std::memory_order_relaxed); }
 int ams_gemm_get_arith(void) { return use_x6() ? 1 : 0; }
+#if AMS_X6_TRACE
+int ams_gemm_x6_trace_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x6_trace), sizeof(g_x6_trace)); }
+#endif
 
 size_t ams_gemm_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;

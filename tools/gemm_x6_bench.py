@@ -35,10 +35,15 @@ SHAPES = [
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--only', default='', help='comma-separated substrings of the product labels to run')
+    ap.add_argument('--modes', default='0,1', help='arithmetics to time: 0 native f32, 1 bf16x6')
     a = ap.parse_args()
     lib = load()
     rng = np.random.RandomState(0)
+    only = [w for w in a.only.split(',') if w]
     for label, M, N, K, tA, tB in SHAPES:
+        if only and not any(w in label for w in only):
+            continue
         A = torch.from_numpy(rng.randn(*((K, M) if tA else (M, K))).astype(np.float32)).cuda()
         B = torch.from_numpy(rng.randn(*((N, K) if tB else (K, N))).astype(np.float32)).cuda()
         out = torch.empty(M, N, device='cuda')
@@ -47,7 +52,7 @@ def main():
         B64 = (B.T if tB else B).cpu().numpy().astype(np.float64)
         ref = A64 @ B64
         scale = (np.linalg.norm(A64, axis=1)[:, None] * np.linalg.norm(B64, axis=0)[None, :]).max()
-        for mode in (0, 1):
+        for mode in [int(m) for m in a.modes.split(',')]:
             lib.ams_gemm_set_arith(mode)
             for _ in range(3):
                 ops.gemm(A, B, transA=bool(tA), transB=bool(tB), out=out)
