@@ -18,6 +18,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <atomic>
+#include <type_traits>
 
 namespace {
 
@@ -25,15 +26,15 @@ thread_local int t_gemm_lds_pad = 0;
 std::atomic<int> g_gemm_arith{-1};        // -1: not chosen yet (AMS_GEMM_X6, default 1), 0: native f32 MFMA, 1: bf16x6
 
 // Tuning overrides (A/B runs only): read from the environment ONCE per process, never on the launch path.
-struct GemmTuning { int group_m, splits; bool noprio, novec, x6ws; };
+struct GemmTuning { int group_m, splits, x6mode; bool noprio, novec; };
 inline const GemmTuning& tuning() {
     static const GemmTuning t = [] {
-        GemmTuning v{0, 0, false, false, false};
+        GemmTuning v{0, 0, 0, false, false};
         if (const char* f = getenv("AMS_GEMM_GROUP_M")) v.group_m = atoi(f);
         if (const char* f = getenv("AMS_GEMM_SPLITS")) v.splits = atoi(f);
         v.noprio = getenv("AMS_GEMM_NOPRIO") != nullptr;
         v.novec = getenv("AMS_GEMM_NOVEC") != nullptr;
-        if (const char* f = getenv("AMS_GEMM_X6WS")) v.x6ws = atoi(f) != 0;   // 1: wave-specialised form (measured slower, see x6_body)
+        if (const char* f = getenv("AMS_GEMM_X6MODE")) v.x6mode = atoi(f);     // bf16x6 kernel form: 0 plain, 1 wave-specialised, 2 fused stream
         return v;
     }();
     return t;
@@ -557,11 +558,18 @@ typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 #ifndef AMS_X6_DBG
-#define AMS_X6_DBG 0        // timing anatomy only (WRONG results): 1 no split arithmetic, 2 no LDS writes, 4 no MFMAs, 8 no LDS reads, 16 no fetch in the loop
+#define AMS_X6_DBG 0        // timing anatomy only (WRONG results): 1 no split arithmetic, 2 no LDS writes, 4 no MFMAs, 8 no LDS reads, 16 no fetch in the loop, 32 no split and no LDS writes (fused-stream form)
+#endif
+#ifndef AMS_X6_FS_SCHED
+#define AMS_X6_FS_SCHED 1
+#endif
+#ifndef AMS_X6_FS_VALU
+#define AMS_X6_FS_VALU 4
 #endif
 #ifndef AMS_X6_TRACE
 #define AMS_X6_TRACE 0      // 1: workgroup 0 stamps wall_clock64() (100 MHz) at its phase boundaries (tools/x6_trace.py); adds waits
 #endif
+__device__ float4 g_x6_zero16;       // invalid operand quarters are FETCHED from here (fused-stream form): no validity state between fetch and split
 #if AMS_X6_TRACE
 __device__ unsigned long long g_x6_trace[2][64][4];
 #define X6_STAMP(role, kt, slot) do { if (blockIdx.x == 0 && lane == 0 && wave == 0 && (kt) < 64) g_x6_trace[role][kt][slot] = wall_clock64(); } while (0)
@@ -598,8 +606,9 @@ __device__ __forceinline__ float comp4(const float4& v, int j) { return j == 0 ?
 // WS = false form (profiles/r02_i_gemm_x6_anatomy.txt) showed MFMA time and everything-else time ADDING (4096^3: 876 us = ~340 us of
 // MFMA + 438 us with the MFMAs compiled out) -- the two co-resident workgroups of a CU run in lock-step, both multiplying, then both
 // splitting -- whereas a consumer wave and a producer wave that share a SIMD interleave instruction by instruction.
-template <int AMODE, int BMODE, bool WS>
+template <int AMODE, int BMODE, int MODE>
 __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) {
+    constexpr bool WS = (MODE == 1), FS = (MODE == 2);
     constexpr int BK = X6_BK;
     constexpr bool AK = AKContig<AMODE>::v;
     constexpr bool BKc = (BMODE == B_COL);
@@ -800,7 +809,175 @@ __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) 
         }
     };
 
-    if (!WS) {
+    // FS: ONE instruction stream per wave carries the 48 MFMAs of tile kt (out of LDS buffer kt & 1), the split of tile kt + 1 into the
+    // other buffer and the fetch of tile kt + 3, interleaved by the scheduler groups below (1 MFMA : 4 VALU : 1 LDS/VMEM op): a wave's
+    // OWN independent instructions issue in the shadow of its MFMAs (up to ~5 per 32-cycle MFMA), another wave's barely do (WS trace).
+    // FS: the wave's ONE instruction stream is laid out by hand as 48 units of [one MFMA of tile kt | one slice of the split of tile
+    // kt + 1 | at most one LDS or global memory instruction], fenced by sched_barrier(0) so that hipcc keeps the order: a wave's OWN
+    // independent instructions issue in the shadow of its MFMAs (up to ~5 per 32-cycle MFMA), another wave's barely do (WS trace).
+    // A split3 of two values is three slices: {zero invalid, hi, residual} {mid, residual} {lo, LDS writes of a finished group}.
+    auto split_slice = [&](unsigned char* base, bool kcontig, float4 (&rv)[4], int v, int sl, uint4& H, uint4& Mi, uint4& L,
+                           float& r0, float& r1, bool is_b) {
+        if (kcontig) {
+            const int h = v >> 2, q = v & 3, f = 2 * h + (q >> 1);
+            if (sl == 0) {
+                const float x0 = (q & 1) ? rv[f].z : rv[f].x, x1 = (q & 1) ? rv[f].w : rv[f].y;
+                const unsigned hi = pk_bf16(x0, x1);
+                r0 = x0 - __uint_as_float(hi << 16); r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+                (q == 0 ? H.x : q == 1 ? H.y : q == 2 ? H.z : H.w) = hi;
+            } else if (sl == 1) {
+                const unsigned mid = pk_bf16(r0, r1);
+                r0 -= __uint_as_float(mid << 16); r1 -= __uint_as_float(mid & 0xffff0000u);
+                (q == 0 ? Mi.x : q == 1 ? Mi.y : q == 2 ? Mi.z : Mi.w) = mid;
+            } else {
+                (q == 0 ? L.x : q == 1 ? L.y : q == 2 ? L.z : L.w) = pk_bf16(r0, r1);
+                if (q == 3) {
+                    unsigned char* p = base + kgrp * X6_PLANE + (krow + 64 * h) * 16;
+                    *reinterpret_cast<uint4*>(p) = H;
+                    *reinterpret_cast<uint4*>(p + X6_PART) = Mi;
+                    *reinterpret_cast<uint4*>(p + 2 * X6_PART) = L;
+                }
+            }
+        } else {
+            const int j = v >> 1, q = v & 1;
+            if (sl == 0) {
+                const float x0 = comp4(rv[2 * q], j), x1 = comp4(rv[2 * q + 1], j);
+                if (is_b) { const float t = x0 + x1; (j == 0 ? bsum4.x : j == 1 ? bsum4.y : j == 2 ? bsum4.z : bsum4.w) += t; }
+                const unsigned hi = pk_bf16(x0, x1);
+                r0 = x0 - __uint_as_float(hi << 16); r1 = x1 - __uint_as_float(hi & 0xffff0000u);
+                (q == 0 ? H.x : H.y) = hi;
+            } else if (sl == 1) {
+                const unsigned mid = pk_bf16(r0, r1);
+                r0 -= __uint_as_float(mid << 16); r1 -= __uint_as_float(mid & 0xffff0000u);
+                (q == 0 ? Mi.x : Mi.y) = mid;
+            } else {
+                (q == 0 ? L.x : L.y) = pk_bf16(r0, r1);
+                if (q == 1) {
+                    unsigned char* p = base + (kb >> 1) * X6_PLANE + x6_slot(4 * mb + j) * 16 + (kb & 1) * 8;
+                    *reinterpret_cast<uint2*>(p) = make_uint2(H.x, H.y);
+                    *reinterpret_cast<uint2*>(p + X6_PART) = make_uint2(Mi.x, Mi.y);
+                    *reinterpret_cast<uint2*>(p + 2 * X6_PART) = make_uint2(L.x, L.y);
+                }
+            }
+        }
+    };
+    // one quarter of a tile fetch: the q-th 16-byte load of operand A (is_b = false) or B; a quarter that is not valid (past the
+    // split's end, masked row, frame padding) is loaded from a 16-byte zero page instead -- the validity lives in the ADDRESS
+    auto fetch_q = [&](int kt, int q, bool is_b, float4 (&rv)[4]) {
+        const int k0 = k_begin + kt * BK;
+        const float* zero = reinterpret_cast<const float*>(&g_x6_zero16);
+        const float* src;
+        bool ok;
+        if (!is_b) {
+            if (AK) {
+                const int h = q >> 1, c = q & 1;
+                const int k = k0 + kgrp * 8 + 4 * c;
+                if (AMODE == A_FRAMES) {
+                    const int p = fp0[h] + k;
+                    ok = k < k_end && p >= 0 && p < g.fr_L;
+                    src = g.A + arow[h] + p;
+                } else {
+                    ok = k < k_end;
+                    src = g.A + arow[h] + k;
+                }
+            } else {
+                const int k = k0 + 4 * kb + q, m = m0 + 4 * mb;
+                if (AMODE == A_FRAMES_T) {
+                    const int kc = min(k, g.K - 1);
+                    const int b = kc / g.fr_T, t = kc - b * g.fr_T;
+                    const int p = t * g.fr_hop + m - g.fr_pl;
+                    ok = k < k_end && m < g.M && p >= 0 && p < g.fr_L;
+                    src = g.A + (long)b * g.fr_L + p;
+                } else {
+                    ok = k < k_end && m < g.M && !(g.mask_period && (k % g.mask_period) == g.mask_skip);
+                    src = g.A + (long)k * g.lda + m;
+                }
+            }
+        } else if (BKc) {
+            const int h = q >> 1, c = q & 1;
+            const int k = k0 + kgrp * 8 + 4 * c;
+            ok = k < k_end;
+            src = g.B + brow[h] + k;
+        } else {
+            const int k = k0 + 4 * kb + q, n = n0 + 4 * mb;
+            ok = k < k_end && n < g.N;
+            src = g.B + (long)k * g.ldb + n;
+        }
+        rv[q] = *reinterpret_cast<const float4*>(ok ? src : zero);
+    };
+    auto fused = [&](int bufR, int bufW, float4 (&ra)[4], float4 (&rb)[4], int kt_fetch) {
+        bf16x8_t a[2][2][3], b[2][2][3];
+        auto read_frag = [&](int ks, int n) {       // n = 0..11: operand (A, B) x tile (0, 1) x part (0..2)
+            const int i = (n >> 1) & 1, p = n >> 2;
+            if (AMS_X6_DBG & 8) {
+                const uint4 c = {0x3f803f80u + (unsigned)n, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u + (unsigned)ks};
+                if (n & 1) b[ks][i][p] = __builtin_bit_cast(bf16x8_t, c); else a[ks][i][p] = __builtin_bit_cast(bf16x8_t, c);
+                return;
+            }
+            if (n & 1) b[ks][i][p] = *reinterpret_cast<const bf16x8_t*>(bp[i] + bufR * X6_LDS + p * X6_PART + ks * 2 * X6_PLANE);
+            else a[ks][i][p] = *reinterpret_cast<const bf16x8_t*>(ap[i] + bufR * X6_LDS + p * X6_PART + ks * 2 * X6_PLANE);
+        };
+#pragma unroll
+        for (int n = 0; n < 12; ++n) read_frag(0, n);
+        __builtin_amdgcn_sched_barrier(0);
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+        uint4 H, Mi, L;
+        float r0 = 0.f, r1 = 0.f;
+        unsigned char* const wa = smem + bufW * X6_LDS;
+        unsigned char* const wb = wa + X6_OPER;
+        // the 48 units are expanded with compile-time indices (a `#pragma unroll` loop of this size is left rolled by hipcc: fragment
+        // arrays in scratch memory, MFMA operands picked through a constant table)
+        auto unit = [&](auto uc) {
+            constexpr int u = decltype(uc)::value;
+            constexpr int ks = u / 24, t = (u % 24) >> 2, i = (u >> 1) & 1, j = u & 1;
+            if (AMS_X6_DBG & 4) asm volatile("" :: "v"(a[ks][i][PA[t]]), "v"(b[ks][j][PB[t]]));
+            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i][PA[t]], b[ks][j][PB[t]], acc[i][j], 0, 0, 0);
+            if (u < 12) read_frag(1, u);                                        // second k-step's fragments (needed from unit 24)
+            if (AMS_X6_DBG & 32) { }
+            else if (u < 24) split_slice(wa, AK, ra, u / 3, u % 3, H, Mi, L, r0, r1, false);
+            else split_slice(wb, BKc, rb, (u - 24) / 3, u % 3, H, Mi, L, r0, r1, true);
+            if (!(AMS_X6_DBG & 16) && u >= 24 && u < 28) fetch_q(kt_fetch, u - 24, false, ra);     // A's staging registers are free
+            __builtin_amdgcn_sched_barrier(0);
+        };
+#define X6_U1(n) unit(std::integral_constant<int, (n)>{});
+#define X6_U4(n) X6_U1(n) X6_U1((n) + 1) X6_U1((n) + 2) X6_U1((n) + 3)
+#define X6_U16(n) X6_U4(n) X6_U4((n) + 4) X6_U4((n) + 8) X6_U4((n) + 12)
+        X6_U16(0) X6_U16(16) X6_U16(32)
+#undef X6_U16
+#undef X6_U4
+#undef X6_U1
+        if (!(AMS_X6_DBG & 16)) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fetch_q(kt_fetch, q, true, rb);
+        }
+    };
+    if (FS) {
+        auto fetch_all = [&](int kt, float4 (&ra)[4], float4 (&rb)[4]) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) { fetch_q(kt, q, false, ra); fetch_q(kt, q, true, rb); }
+        };
+        bool all[4] = {true, true, true, true};
+        fetch_all(0, ra0, rb0);
+        stash(0, ra0, rb0, all, all);               // bsum (B_ROW) of tile 0 is added here, of every later tile in split_slice
+        fetch_all(1, ra0, rb0);
+        fetch_all(2, ra1, rb1);
+        __syncthreads();
+        for (int kt = 0;; kt += 2) {                // one barrier per k-tile; the tile split behind the last one is a zero tile
+            X6_STAMP(0, kt, 0);
+            fused(0, 1, ra0, rb0, kt + 3);
+            X6_STAMP(0, kt, 1);
+            __syncthreads();
+            X6_STAMP(0, kt, 3);
+            if (kt + 1 >= nk) break;
+            X6_STAMP(0, kt + 1, 0);
+            fused(1, 0, ra1, rb1, kt + 4);
+            X6_STAMP(0, kt + 1, 1);
+            __syncthreads();
+            X6_STAMP(0, kt + 1, 3);
+            if (kt + 2 >= nk) break;
+        }
+    } else if (!WS) {
         fetch(0, ra0, rb0, va0, vb0);
         stash(0, ra0, rb0, va0, vb0);
         fetch(1, ra0, rb0, va0, vb0);               // tiles past the split's end: clamped addresses, staged as zeros if ever used
@@ -877,12 +1054,17 @@ __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) 
 template <int AMODE, int BMODE>
 __global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[X6_LDS];
-    x6_body<AMODE, BMODE, false>(g, smem);
+    x6_body<AMODE, BMODE, 0>(g, smem);
+}
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256, 1) void gemm_x6fs_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * X6_LDS];
+    x6_body<AMODE, BMODE, 2>(g, smem);
 }
 template <int AMODE, int BMODE>
 __global__ __launch_bounds__(512, 1) void gemm_x6ws_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * X6_LDS];
-    x6_body<AMODE, BMODE, true>(g, smem);
+    x6_body<AMODE, BMODE, 1>(g, smem);
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, const float* __restrict__ bias,
@@ -1038,7 +1220,8 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
                 raised_x = pad;
             }
         }
-        if (tuning().x6ws) hipLaunchKernelGGL((gemm_x6ws_kernel<AMODE, BMODE>), grid, dim3(512), 0, st, g);    // one workgroup per CU by its own LDS
+        if (tuning().x6mode == 2) hipLaunchKernelGGL((gemm_x6fs_kernel<AMODE, BMODE>), grid, dim3(256), 0, st, g);   // one workgroup per CU by its own LDS
+        else if (tuning().x6mode == 1) hipLaunchKernelGGL((gemm_x6ws_kernel<AMODE, BMODE>), grid, dim3(512), 0, st, g);
         else hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE>), grid, dim3(256), (size_t)pad, st, g);
     } else if (vec) {
         if (t_gemm_lds_pad > 40 * 1024) {

@@ -26,8 +26,10 @@ buf = (ctypes.c_ulonglong * (2 * 64 * 4))()
 raw = ctypes.CDLL(os.environ['AMS_HIP_LIB'])
 assert raw.ams_gemm_x6_trace_read(buf) == 0
 t = np.array(buf, dtype=np.uint64).reshape(2, 64, 4).astype(np.int64) * 10          # ns
-for role, name, cols in ((0, 'consumer', ('start->mfma issued', 'mfma issued->barrier passed')),
-                         (1, 'producer', ('start->split+LDS writes done', '->fetch issued', '->barrier passed'))):
+mode = os.environ.get('AMS_GEMM_X6MODE', '2')
+roles = ((0, 'fused stream', ('start->stream issued', 'stream issued->barrier passed')),) if mode == '2' else ((0, 'consumer', ('start->mfma issued', 'mfma issued->barrier passed')),
+                         (1, 'producer', ('start->split+LDS writes done', '->fetch issued', '->barrier passed')))
+for role, name, cols in roles:
     print(name)
     for kt in range(2, 14):
         r = t[role, kt]
