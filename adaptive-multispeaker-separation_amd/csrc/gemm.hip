@@ -26,15 +26,15 @@ thread_local int t_gemm_lds_pad = 0;
 std::atomic<int> g_gemm_arith{-1};        // -1: not chosen yet (AMS_GEMM_X6, default 1), 0: native f32 MFMA, 1: bf16x6
 
 // Tuning overrides (A/B runs only): read from the environment ONCE per process, never on the launch path.
-struct GemmTuning { int group_m, splits, x6mode; bool noprio, novec; };
+struct GemmTuning { int group_m, splits, x6cfg; bool noprio, novec; };
 inline const GemmTuning& tuning() {
     static const GemmTuning t = [] {
-        GemmTuning v{0, 0, 0, false, false};
+        GemmTuning v{0, 0, -1, false, false};
         if (const char* f = getenv("AMS_GEMM_GROUP_M")) v.group_m = atoi(f);
         if (const char* f = getenv("AMS_GEMM_SPLITS")) v.splits = atoi(f);
         v.noprio = getenv("AMS_GEMM_NOPRIO") != nullptr;
         v.novec = getenv("AMS_GEMM_NOVEC") != nullptr;
-        if (const char* f = getenv("AMS_GEMM_X6MODE")) v.x6mode = atoi(f);     // bf16x6 kernel form: 0 plain, 1 wave-specialised, 2 fused stream
+        if (const char* f = getenv("AMS_GEMM_X6CFG")) v.x6cfg = atoi(f);       // force one bf16x6 tile configuration (0..3, X6Cfg)
         return v;
     }();
     return t;
@@ -60,8 +60,15 @@ inline bool use_x6() {
 }
 constexpr int BM = 128, BN = 128, BK = AMS_GEMM_BK;
 constexpr int X6_BK = 32;           // k-tile of the bf16x6 kernel
+// split-K cost model: microseconds per 16 k and workgroup of the bf16x6 tile configurations (measured: 128 x 128 0.84 at 4096^3)
 #ifndef AMS_GEMM_X6_US16
-#define AMS_GEMM_X6_US16 0.45
+#define AMS_GEMM_X6_US16 0.84
+#endif
+#ifndef AMS_GEMM_X6_US16_1
+#define AMS_GEMM_X6_US16_1 2.35
+#endif
+#ifndef AMS_GEMM_X6_US16_2
+#define AMS_GEMM_X6_US16_2 1.35
 #endif
 constexpr int PAD_T = 2;   // k-contiguous source, transposed scalar LDS writes: stride 130 -> conflict-free
 constexpr int PAD_V = 4;   // m/n-contiguous source, float4 LDS writes: stride 132 keeps 16B alignment
@@ -128,8 +135,8 @@ __device__ __forceinline__ float loadB1(const GemmArgs& g, int k, int n) {
 }
 
 // Work item of this workgroup: (batch z, k-split, output tile).  Shifts the operand pointers of a batched launch.
-__device__ __forceinline__ void locate_tile(GemmArgs& g, int& split, int& tile_m, int& tile_n) {
-    const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + BN - 1) / BN;
+__device__ __forceinline__ void locate_tile(GemmArgs& g, int& split, int& tile_m, int& tile_n, int bm = BM, int bn = BN) {
+    const int tiles_m = (g.M + bm - 1) / bm, tiles_n = (g.N + bn - 1) / bn;
     const int ntiles = tiles_m * tiles_n;
     int bid, zb;
     {
@@ -544,42 +551,45 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
 // result is an f32 product with f32-level error (tests/test_gpu_gemm_x6.py holds it against float64 next to the native f32 MFMA
 // kernel), at 16/6 = 2.7x the f32 MFMA ceiling.  Inf/NaN inputs give NaN (inf - inf in the split).
 //
-// Tile 128 x 128 x 32, 4 waves in 2 x 2, 64 x 64 per wave = 2 x 2 MFMA tiles x 2 k-steps x 6 products = 48 MFMAs per k-tile.  The
-// operand fetch is the f32 kernel's (one unconditional 16-byte load per operand quarter on a clamped address, validity applied
-// at the LDS write); the split happens ONCE per element, between the staging registers and LDS.  LDS image per operand and part:
-// four planes (one per group of 8 k) of 128 rows x 16 bytes, so that an MFMA operand (lane l: row l & 31, k-group l >> 5) is ONE
-// ds_read_b128.  Sources that are contiguous along k (A_ROW, A_FRAMES, B_COL) are written as 16-byte rows by threads holding 8
-// consecutive k of a row; sources contiguous along m/n (A_COL, A_FRAMES_T, B_ROW) by threads holding a 4 (k) x 4 (m) block, 8 bytes
-// per m, into rows permuted by x6_slot() so that neither those writes nor the 16-lane groups of the reads pile up on a bank.
-// One LDS buffer (48.75 KB) and a two-deep register-staged prefetch: tiles kt+1 and kt+2 are in registers / in flight while
-// tile kt is multiplied.
+// Block tile BMX x BNX x 32 (X6Cfg below), waves of TM x TN MFMA tiles; per k-tile a wave issues 2 k-steps x 6 products x TM x TN
+// MFMAs.  The operand fetch is the f32 kernel's (one unconditional 16-byte load per operand quarter on a clamped address, validity
+// applied at the LDS write); the split happens ONCE per element and workgroup, between the staging registers and LDS.  LDS image
+// per operand and part: four planes (one per group of 8 k) of R rows x 16 bytes, so that an MFMA operand (lane l: row l & 31,
+// k-group l >> 5) is ONE ds_read_b128.  Sources that are contiguous along k (A_ROW, A_FRAMES, B_COL) are written as 16-byte rows by
+// threads holding 8 consecutive k of a row; sources contiguous along m/n (A_COL, A_FRAMES_T, B_ROW) by threads holding a 4 (k) x 4
+// (m) block, 8 bytes per m, into rows permuted by x6_slot() so that neither those writes nor the 16-lane groups of the reads pile up
+// on a bank.  One LDS buffer, register-staged prefetch of the next k-tile, two barriers per k-tile.
+//
+// What was measured on the way (profiles/r02_i_*; 4096^3, 128 x 128 tile): the MFMAs of a k-tile take 0.83 us per workgroup and
+// everything else (fetch, ~4.5 VALU per element of split arithmetic, LDS traffic) 0.86-1.1 us, and the two ADD instead of
+// overlapping -- (a) two co-resident workgroups run in lock-step (876 us = 340 + 438 with the MFMAs compiled out); (b) a
+// wave-specialised form (4 MFMA waves + 4 split waves, two LDS buffers) was slower: a split wave progresses ~2 VALU instructions
+// per MFMA of its SIMD partner (phase trace: 1.6 us per tile for ~220 instructions); (c) a fused stream (one wave = MFMA + one
+// slice of the next tile's split per MFMA, hand-laid behind sched_barrier fences, 1 wave per SIMD) measured the same as the plain
+// form (873 us; its MFMA-only stream 426 us, its split-only stream 567 us).  Both forms are in the history (commits "wave-
+// specialised" / "fused-stream").  What does help is LESS split work per MFMA: a 256 x 256 tile splits each element once for
+// twice as many MFMAs -- hence the tile configurations below.
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
 #ifndef AMS_X6_DBG
-#define AMS_X6_DBG 0        // timing anatomy only (WRONG results): 1 no split arithmetic, 2 no LDS writes, 4 no MFMAs, 8 no LDS reads, 16 no fetch in the loop, 32 no split and no LDS writes (fused-stream form)
+#define AMS_X6_DBG 0        // timing anatomy only (WRONG results): 1 no split arithmetic, 2 no LDS writes, 4 no MFMAs, 8 no LDS reads, 16 no fetch in the loop
 #endif
-#ifndef AMS_X6_FS_SCHED
-#define AMS_X6_FS_SCHED 1
-#endif
-#ifndef AMS_X6_FS_VALU
-#define AMS_X6_FS_VALU 4
-#endif
-#ifndef AMS_X6_TRACE
-#define AMS_X6_TRACE 0      // 1: workgroup 0 stamps wall_clock64() (100 MHz) at its phase boundaries (tools/x6_trace.py); adds waits
-#endif
-__device__ float4 g_x6_zero16;       // invalid operand quarters are FETCHED from here (fused-stream form): no validity state between fetch and split
-#if AMS_X6_TRACE
-__device__ unsigned long long g_x6_trace[2][64][4];
-#define X6_STAMP(role, kt, slot) do { if (blockIdx.x == 0 && lane == 0 && wave == 0 && (kt) < 64) g_x6_trace[role][kt][slot] = wall_clock64(); } while (0)
-#else
-#define X6_STAMP(role, kt, slot) do { } while (0)
-#endif
-constexpr int X6_PLANE = 128 * 16 + 32;     // bytes; +32: the four planes start 8 banks apart (16-byte row writes of one wave hit all four)
-constexpr int X6_PART = 4 * X6_PLANE;
-constexpr int X6_OPER = 3 * X6_PART;
-constexpr int X6_LDS = 2 * X6_OPER;
+
+// Tile configurations: block BMX x BNX, WMC x WNC waves of (TM x 32) x (TN x 32).
+template <int CFG> struct X6Cfg;
+template <> struct X6Cfg<0> { static constexpr int BMX = 128, BNX = 128, WMC = 2, WNC = 2, TM = 2, TN = 2; };   // 4 waves, 48.75 KB
+template <> struct X6Cfg<1> { static constexpr int BMX = 256, BNX = 256, WMC = 2, WNC = 4, TM = 4, TN = 2; };   // 8 waves, 96.75 KB
+template <> struct X6Cfg<2> { static constexpr int BMX = 256, BNX = 128, WMC = 4, WNC = 2, TM = 2, TN = 2; };   // 8 waves, 72.75 KB
+template <> struct X6Cfg<3> { static constexpr int BMX = 128, BNX = 256, WMC = 2, WNC = 4, TM = 2, TN = 2; };   // 8 waves, 72.75 KB
+constexpr int x6_plane(int rows) { return rows * 16 + 32; }     // bytes; +32: the four planes start 8 banks apart (16-byte row writes of one wave hit all four)
+constexpr int x6_oper(int rows) { return 3 * 4 * x6_plane(rows); }
+constexpr int x6_lds(int cfg) {
+    return cfg == 0 ? x6_oper(128) + x6_oper(128) : cfg == 1 ? x6_oper(256) + x6_oper(256) : x6_oper(256) + x6_oper(128);
+}
+constexpr int x6_bm(int cfg) { return (cfg == 1 || cfg == 2) ? 256 : 128; }
+constexpr int x6_bn(int cfg) { return (cfg == 1 || cfg == 3) ? 256 : 128; }
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {           // v_cvt_pk_bf16_f32: a -> bits 0..15, b -> bits 16..31
     const f32x2_t v = {a, b};
@@ -595,68 +605,62 @@ __device__ __forceinline__ void split3(float a, float b, unsigned& hi, unsigned&
     const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xffff0000u);
     lo = pk_bf16(sa, sb);
 }
-// LDS row of operand row n (0..127) for m/n-contiguous sources: the four rows a thread's float4 covers go to four 32-row blocks,
+// LDS row of operand row n (0..R-1) for m/n-contiguous sources: the four rows a thread's float4 covers go to four R/4-row blocks,
 // rotated by 4 rows per block (read groups {0-3,12-15,20-27} / {4-11,16-19,28-31} of ds_read_b128 then touch 16 different slots).
-__device__ __forceinline__ int x6_slot(int n) { return (n & 3) * 32 + (((n >> 2) + 4 * (n & 3)) & 31); }
+template <int R>
+__device__ __forceinline__ int x6_slot(int n) { return (n & 3) * (R / 4) + (((n >> 2) + 4 * (n & 3)) & (R / 4 - 1)); }
 __device__ __forceinline__ float comp4(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
-// WS = false: 256 threads, every wave fetches, splits, writes LDS and multiplies in turn (one LDS buffer, two barriers per k-tile).
-// WS = true ("wave-specialised"): 512 threads -- waves 0-3 only read LDS and issue MFMAs, waves 4-7 only fetch, split and write the
-// NEXT tile into the other LDS buffer (2 x 48.75 KB, one workgroup per CU), one barrier per k-tile.  Why: timing anatomy of the
-// WS = false form (profiles/r02_i_gemm_x6_anatomy.txt) showed MFMA time and everything-else time ADDING (4096^3: 876 us = ~340 us of
-// MFMA + 438 us with the MFMAs compiled out) -- the two co-resident workgroups of a CU run in lock-step, both multiplying, then both
-// splitting -- whereas a consumer wave and a producer wave that share a SIMD interleave instruction by instruction.
-template <int AMODE, int BMODE, int MODE>
+template <int AMODE, int BMODE, int CFG>
 __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) {
-    constexpr bool WS = (MODE == 1), FS = (MODE == 2);
-    constexpr int BK = X6_BK;
+    using C = X6Cfg<CFG>;
+    constexpr int BK = X6_BK, BMX = C::BMX, BNX = C::BNX, TM = C::TM, TN = C::TN;
+    constexpr int NT = C::WMC * C::WNC * 64;
     constexpr bool AK = AKContig<AMODE>::v;
     constexpr bool BKc = (BMODE == B_COL);
+    constexpr int A_PLANE = x6_plane(BMX), B_PLANE = x6_plane(BNX), A_PART = 4 * A_PLANE, B_PART = 4 * B_PLANE;
+    unsigned char* const As = smem;
+    unsigned char* const Bs = smem + x6_oper(BMX);
+    if (g.hiprio) __builtin_amdgcn_s_setprio(2);
 
-    const int wave_all = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool producer = WS && wave_all >= 4;          // wave-uniform
-    const bool consumer = !WS || wave_all < 4;
-    const int tid = threadIdx.x & 255;                  // index within the role
-    const int lane = tid & 63, wave = wave_all & 3;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / C::WNC, wn = wave % C::WNC;
     const int l31 = lane & 31, lk = lane >> 5;
-    // issue priority: consumers above producers (an MFMA needs one issue slot per 32 cycles, the split fills the rest); critical-path
-    // launches one level above residency-capped side-stream ones; the recurrence rings run at 3
-    if (WS) {
-        if (producer) { if (g.hiprio) __builtin_amdgcn_s_setprio(1); }
-        else if (g.hiprio) __builtin_amdgcn_s_setprio(2);
-        else __builtin_amdgcn_s_setprio(1);
-    } else if (g.hiprio) __builtin_amdgcn_s_setprio(2);
 
     int split, tile_m, tile_n;
-    locate_tile(g, split, tile_m, tile_n);
-    const int m0 = tile_m * BM, n0 = tile_n * BN;
+    locate_tile(g, split, tile_m, tile_n, BMX, BNX);
+    const int m0 = tile_m * BMX, n0 = tile_n * BNX;
     const int k_begin = split * g.k_per_split;
     const int k_end = min(g.K, k_begin + g.k_per_split);
     const int nk = (k_end - k_begin + BK - 1) / BK;
 
-    f32x16 acc[2][2];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // k-contiguous operands: thread -> rows (tid >> 2) and (tid >> 2) + 64, k-group tid & 3 (8 consecutive k = two float4)
-    // m/n-contiguous operands: thread -> columns 4 * (tid & 31) .. + 3, k rows 4 * (tid >> 5) .. + 3 (four float4)
+    // Operand of R rows, NT threads.  k-contiguous source: slot = (row, k-group of 8), R * 4 slots, thread -> rows (tid >> 2) + (NT / 4) h,
+    // k-group tid & 3, two float4 per slot.  m/n-contiguous source: 4 (k) x 4 (m) blocks, R / 4 x 8 of them, thread -> block
+    // (tid % (R / 4), tid / (R / 4)) while tid < R * 2, four float4.  Either way at most four float4 per thread and operand.
+    constexpr int NSA = BMX * 4 / NT, NSB = BNX * 4 / NT;          // k-contiguous slots per thread (1 or 2)
     const int kgrp = tid & 3, krow = tid >> 2;
-    const int mb = tid & 31, kb = tid >> 5;
+    const int mbA = tid % (BMX / 4), kbA = tid / (BMX / 4);
+    const int mbB = tid % (BNX / 4), kbB = tid / (BNX / 4);
+    const bool actA = AK || tid < BMX * 2, actB = BKc || tid < BNX * 2;     // wave-uniform (multiples of 64)
     long arow[2] = {0, 0};
     int fp0[2] = {0, 0};
     if (AMODE == A_ROW) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) arow[h] = rowmap(g, min(m0 + krow + 64 * h, g.M - 1)) * g.lda;
+        for (int h = 0; h < NSA; ++h) arow[h] = rowmap(g, min(m0 + krow + (NT / 4) * h, g.M - 1)) * g.lda;
     }
     if (AMODE == A_FRAMES) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int m = min(m0 + krow + 64 * h, g.M - 1);
+        for (int h = 0; h < NSA; ++h) {
+            const int m = min(m0 + krow + (NT / 4) * h, g.M - 1);
             const int b = m / g.fr_T, t = m - b * g.fr_T;
             arow[h] = (long)b * g.fr_L;
             fp0[h] = t * g.fr_hop - g.fr_pl;
@@ -665,18 +669,16 @@ __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) 
     long brow[2] = {0, 0};
     if (BKc) {
 #pragma unroll
-        for (int h = 0; h < 2; ++h) brow[h] = (long)min(n0 + krow + 64 * h, g.N - 1) * g.ldb;
+        for (int h = 0; h < NSB; ++h) brow[h] = (long)min(n0 + krow + (NT / 4) * h, g.N - 1) * g.ldb;
     }
 
-    // two staging sets: a tile is fetched two k-tiles before it is split (one MFMA phase of 48 MFMAs = 0.64 us does not cover a
-    // memory round trip at 2 workgroups per CU; the first version waited ~1 us per k-tile here)
-    float4 ra0[4], rb0[4], ra1[4], rb1[4];
-    bool va0[4], vb0[4], va1[4], vb1[4];
-    auto fetch = [&](int kt, float4 (&ra)[4], float4 (&rb)[4], bool (&va)[4], bool (&vb)[4]) {
+    float4 ra[4], rb[4];
+    bool va[4], vb[4];
+    auto fetch = [&](int kt) {
         const int k0 = k_begin + kt * BK;
         if (AK) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < NSA; ++h)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const int k = k0 + kgrp * 8 + 4 * c;
@@ -689,10 +691,10 @@ __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) 
                         ra[2 * h + c] = *reinterpret_cast<const float4*>(g.A + arow[h] + min(k, g.K - 4));
                     }
                 }
-        } else {
+        } else if (actA) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int k = k0 + 4 * kb + r, m = m0 + 4 * mb;
+                const int k = k0 + 4 * kbA + r, m = m0 + 4 * mbA;
                 const int kc = min(k, g.K - 1);
                 if (AMODE == A_FRAMES_T) {              // filter gradient: m = tap, k = frame (b, t)
                     const int b = kc / g.fr_T, t = kc - b * g.fr_T;
@@ -707,17 +709,17 @@ __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) 
         }
         if (BKc) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < NSB; ++h)
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
                     const int k = k0 + kgrp * 8 + 4 * c;
                     vb[2 * h + c] = k < k_end;
                     rb[2 * h + c] = *reinterpret_cast<const float4*>(g.B + brow[h] + min(k, g.K - 4));
                 }
-        } else {
+        } else if (actB) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int k = k0 + 4 * kb + r, n = n0 + 4 * mb;
+                const int k = k0 + 4 * kbB + r, n = n0 + 4 * mbB;
                 vb[r] = k < k_end;
                 rb[r] = *reinterpret_cast<const float4*>(g.B + (long)min(k, g.K - 1) * g.ldb + min(n, g.N - 4));
             }
@@ -727,344 +729,162 @@ __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) 
     const bool do_bsum = !BKc && g.bsum_part != nullptr && tile_m == 0;      // workgroup-uniform
     float4 bsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
-    // split the staged f32 values and write the three bf16 images of one operand
-    auto stash_one = [&](unsigned char* base, bool kcontig, float4 (&rv)[4], bool (&vv)[4]) {
+    // split the staged f32 values and write the three bf16 images of one operand (R rows; plane / part strides PL / PT)
+    auto stash_k = [&](unsigned char* base, int PL, int PT, int NS, float4 (&rv)[4], bool (&vv)[4]) {      // k-contiguous source
+        const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            if (h >= NS) break;
+            if (!vv[2 * h]) rv[2 * h] = z;
+            if (!vv[2 * h + 1]) rv[2 * h + 1] = z;
+            uint4 hi, mid, lo;
+            split3(rv[2 * h].x, rv[2 * h].y, hi.x, mid.x, lo.x);
+            split3(rv[2 * h].z, rv[2 * h].w, hi.y, mid.y, lo.y);
+            split3(rv[2 * h + 1].x, rv[2 * h + 1].y, hi.z, mid.z, lo.z);
+            split3(rv[2 * h + 1].z, rv[2 * h + 1].w, hi.w, mid.w, lo.w);
+            unsigned char* p = base + kgrp * PL + (krow + (NT / 4) * h) * 16;
+            if (AMS_X6_DBG & 2) { asm volatile("" :: "v"(hi.x ^ hi.y ^ hi.z ^ hi.w ^ mid.x ^ mid.y ^ mid.z ^ mid.w ^ lo.x ^ lo.y ^ lo.z ^ lo.w)); continue; }
+            *reinterpret_cast<uint4*>(p) = hi;
+            *reinterpret_cast<uint4*>(p + PT) = mid;
+            *reinterpret_cast<uint4*>(p + 2 * PT) = lo;
+        }
+    };
+    auto stash_m = [&](unsigned char* base, int PL, int PT, int kb, int slot0, int slot1, int slot2, int slot3, float4 (&rv)[4],
+                       bool (&vv)[4]) {                                                                     // m/n-contiguous source
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (!vv[q]) rv[q] = z;
-        if (kcontig) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                uint4 hi, mid, lo;
-                split3(rv[2 * h].x, rv[2 * h].y, hi.x, mid.x, lo.x);
-                split3(rv[2 * h].z, rv[2 * h].w, hi.y, mid.y, lo.y);
-                split3(rv[2 * h + 1].x, rv[2 * h + 1].y, hi.z, mid.z, lo.z);
-                split3(rv[2 * h + 1].z, rv[2 * h + 1].w, hi.w, mid.w, lo.w);
-                unsigned char* p = base + kgrp * X6_PLANE + (krow + 64 * h) * 16;
-                if (AMS_X6_DBG & 2) { asm volatile("" :: "v"(hi.x ^ hi.y ^ hi.z ^ hi.w ^ mid.x ^ mid.y ^ mid.z ^ mid.w ^ lo.x ^ lo.y ^ lo.z ^ lo.w)); continue; }
-                *reinterpret_cast<uint4*>(p) = hi;
-                *reinterpret_cast<uint4*>(p + X6_PART) = mid;
-                *reinterpret_cast<uint4*>(p + 2 * X6_PART) = lo;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                uint2 hi, mid, lo;
-                split3(comp4(rv[0], j), comp4(rv[1], j), hi.x, mid.x, lo.x);
-                split3(comp4(rv[2], j), comp4(rv[3], j), hi.y, mid.y, lo.y);
-                unsigned char* p = base + (kb >> 1) * X6_PLANE + x6_slot(4 * mb + j) * 16 + (kb & 1) * 8;
-                if (AMS_X6_DBG & 2) { asm volatile("" :: "v"(hi.x ^ hi.y ^ mid.x ^ mid.y ^ lo.x ^ lo.y)); continue; }
-                *reinterpret_cast<uint2*>(p) = hi;
-                *reinterpret_cast<uint2*>(p + X6_PART) = mid;
-                *reinterpret_cast<uint2*>(p + 2 * X6_PART) = lo;
-            }
+        for (int j = 0; j < 4; ++j) {
+            uint2 hi, mid, lo;
+            split3(comp4(rv[0], j), comp4(rv[1], j), hi.x, mid.x, lo.x);
+            split3(comp4(rv[2], j), comp4(rv[3], j), hi.y, mid.y, lo.y);
+            const int slot = j == 0 ? slot0 : j == 1 ? slot1 : j == 2 ? slot2 : slot3;
+            unsigned char* p = base + (kb >> 1) * PL + slot * 16 + (kb & 1) * 8;
+            if (AMS_X6_DBG & 2) { asm volatile("" :: "v"(hi.x ^ hi.y ^ mid.x ^ mid.y ^ lo.x ^ lo.y)); continue; }
+            *reinterpret_cast<uint2*>(p) = hi;
+            *reinterpret_cast<uint2*>(p + PT) = mid;
+            *reinterpret_cast<uint2*>(p + 2 * PT) = lo;
         }
     };
-    auto stash = [&](int buf, float4 (&ra)[4], float4 (&rb)[4], bool (&va)[4], bool (&vb)[4]) {
-        stash_one(smem + buf * X6_LDS, AK, ra, va);
-        stash_one(smem + buf * X6_LDS + X6_OPER, BKc, rb, vb);
-        if (!BKc && do_bsum) {
+    const int sa0 = x6_slot<BMX>(4 * mbA), sa1 = x6_slot<BMX>(4 * mbA + 1), sa2 = x6_slot<BMX>(4 * mbA + 2), sa3 = x6_slot<BMX>(4 * mbA + 3);
+    const int sb0 = x6_slot<BNX>(4 * mbB), sb1 = x6_slot<BNX>(4 * mbB + 1), sb2 = x6_slot<BNX>(4 * mbB + 2), sb3 = x6_slot<BNX>(4 * mbB + 3);
+    auto stash = [&]() {
+        if (AK) stash_k(As, A_PLANE, A_PART, NSA, ra, va);
+        else if (actA) stash_m(As, A_PLANE, A_PART, kbA, sa0, sa1, sa2, sa3, ra, va);
+        if (BKc) stash_k(Bs, B_PLANE, B_PART, NSB, rb, vb);
+        else if (actB) {
+            stash_m(Bs, B_PLANE, B_PART, kbB, sb0, sb1, sb2, sb3, rb, vb);
+            if (do_bsum) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { bsum4.x += rb[r].x; bsum4.y += rb[r].y; bsum4.z += rb[r].z; bsum4.w += rb[r].w; }
+                for (int r = 0; r < 4; ++r) { bsum4.x += rb[r].x; bsum4.y += rb[r].y; bsum4.z += rb[r].z; bsum4.w += rb[r].w; }
+            }
         }
     };
 
-    // MFMA operand addresses: lane l reads row (l & 31) of its 32-row tile, k-group 2 * kstep + (l >> 5)
-    const unsigned char* ap[2];
-    const unsigned char* bp[2];
+    // MFMA operand addresses: lane l reads row (l & 31) of a 32-row tile, k-group 2 * kstep + (l >> 5)
+    const unsigned char* ap[TM];
+    const unsigned char* bp[TN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ar = wm * 64 + i * 32 + l31, br = wn * 64 + i * 32 + l31;
-        ap[i] = smem + (AK ? ar : x6_slot(ar)) * 16 + lk * X6_PLANE;
-        bp[i] = smem + X6_OPER + (BKc ? br : x6_slot(br)) * 16 + lk * X6_PLANE;
+    for (int i = 0; i < TM; ++i) {
+        const int ar = (wm * TM + i) * 32 + l31;
+        ap[i] = As + (AK ? ar : x6_slot<BMX>(ar)) * 16 + lk * A_PLANE;
     }
-    auto mfma_tile = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int br = (wn * TN + j) * 32 + l31;
+        bp[j] = Bs + (BKc ? br : x6_slot<BNX>(br)) * 16 + lk * B_PLANE;
+    }
+    auto frag = [&](const unsigned char* p) {
+        if (AMS_X6_DBG & 8) { const uint4 c = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; return __builtin_bit_cast(bf16x8_t, c); }
+        return *reinterpret_cast<const bf16x8_t*>(p);
+    };
+    auto mfma_tile = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_t a[2][3], b[2][3];
+            bf16x8_t b[TN][3];
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) {
-                    if (AMS_X6_DBG & 8) {
-                        const uint4 c = {0x3f803f80u + (unsigned)i, 0x3f803f80u + (unsigned)p, 0x3f803f80u, 0x3f803f80u + (unsigned)ks};
-                        a[i][p] = __builtin_bit_cast(bf16x8_t, c); b[i][p] = __builtin_bit_cast(bf16x8_t, c);
-                        continue;
-                    }
-                    a[i][p] = *reinterpret_cast<const bf16x8_t*>(ap[i] + buf * X6_LDS + p * X6_PART + ks * 2 * X6_PLANE);
-                    b[i][p] = *reinterpret_cast<const bf16x8_t*>(bp[i] + buf * X6_LDS + p * X6_PART + ks * 2 * X6_PLANE);
-                }
-            // smallest partial products first; the four accumulators alternate, so dependent MFMAs are four issues apart
-            constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-            constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+                for (int p = 0; p < 3; ++p) b[j][p] = frag(bp[j] + p * B_PART + ks * 2 * B_PLANE);
 #pragma unroll
-            for (int t = 0; t < 6; ++t)
+            for (int ip = 0; ip < TM; ip += 2) {        // two m-tiles at a time: 24 MFMAs on four alternating accumulators
+                bf16x8_t a[2][3];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
-                        if (AMS_X6_DBG & 4) { asm volatile("" :: "v"(a[i][PA[t]]), "v"(b[j][PB[t]])); continue; }
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[i][j], 0, 0, 0);
-                    }
+                    for (int p = 0; p < 3; ++p) a[i][p] = frag(ap[ip + i] + p * A_PART + ks * 2 * A_PLANE);
+                // smallest partial products first
+                constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
+                constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int t = 0; t < 6; ++t)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j) {
+                            if (AMS_X6_DBG & 4) { asm volatile("" :: "v"(a[i][PA[t]]), "v"(b[j][PB[t]])); continue; }
+                            acc[ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[ip + i][j], 0, 0, 0);
+                        }
+            }
         }
     };
 
-    // FS: ONE instruction stream per wave carries the 48 MFMAs of tile kt (out of LDS buffer kt & 1), the split of tile kt + 1 into the
-    // other buffer and the fetch of tile kt + 3, interleaved by the scheduler groups below (1 MFMA : 4 VALU : 1 LDS/VMEM op): a wave's
-    // OWN independent instructions issue in the shadow of its MFMAs (up to ~5 per 32-cycle MFMA), another wave's barely do (WS trace).
-    // FS: the wave's ONE instruction stream is laid out by hand as 48 units of [one MFMA of tile kt | one slice of the split of tile
-    // kt + 1 | at most one LDS or global memory instruction], fenced by sched_barrier(0) so that hipcc keeps the order: a wave's OWN
-    // independent instructions issue in the shadow of its MFMAs (up to ~5 per 32-cycle MFMA), another wave's barely do (WS trace).
-    // A split3 of two values is three slices: {zero invalid, hi, residual} {mid, residual} {lo, LDS writes of a finished group}.
-    auto split_slice = [&](unsigned char* base, bool kcontig, float4 (&rv)[4], int v, int sl, uint4& H, uint4& Mi, uint4& L,
-                           float& r0, float& r1, bool is_b) {
-        if (kcontig) {
-            const int h = v >> 2, q = v & 3, f = 2 * h + (q >> 1);
-            if (sl == 0) {
-                const float x0 = (q & 1) ? rv[f].z : rv[f].x, x1 = (q & 1) ? rv[f].w : rv[f].y;
-                const unsigned hi = pk_bf16(x0, x1);
-                r0 = x0 - __uint_as_float(hi << 16); r1 = x1 - __uint_as_float(hi & 0xffff0000u);
-                (q == 0 ? H.x : q == 1 ? H.y : q == 2 ? H.z : H.w) = hi;
-            } else if (sl == 1) {
-                const unsigned mid = pk_bf16(r0, r1);
-                r0 -= __uint_as_float(mid << 16); r1 -= __uint_as_float(mid & 0xffff0000u);
-                (q == 0 ? Mi.x : q == 1 ? Mi.y : q == 2 ? Mi.z : Mi.w) = mid;
-            } else {
-                (q == 0 ? L.x : q == 1 ? L.y : q == 2 ? L.z : L.w) = pk_bf16(r0, r1);
-                if (q == 3) {
-                    unsigned char* p = base + kgrp * X6_PLANE + (krow + 64 * h) * 16;
-                    *reinterpret_cast<uint4*>(p) = H;
-                    *reinterpret_cast<uint4*>(p + X6_PART) = Mi;
-                    *reinterpret_cast<uint4*>(p + 2 * X6_PART) = L;
-                }
-            }
-        } else {
-            const int j = v >> 1, q = v & 1;
-            if (sl == 0) {
-                const float x0 = comp4(rv[2 * q], j), x1 = comp4(rv[2 * q + 1], j);
-                if (is_b) { const float t = x0 + x1; (j == 0 ? bsum4.x : j == 1 ? bsum4.y : j == 2 ? bsum4.z : bsum4.w) += t; }
-                const unsigned hi = pk_bf16(x0, x1);
-                r0 = x0 - __uint_as_float(hi << 16); r1 = x1 - __uint_as_float(hi & 0xffff0000u);
-                (q == 0 ? H.x : H.y) = hi;
-            } else if (sl == 1) {
-                const unsigned mid = pk_bf16(r0, r1);
-                r0 -= __uint_as_float(mid << 16); r1 -= __uint_as_float(mid & 0xffff0000u);
-                (q == 0 ? Mi.x : Mi.y) = mid;
-            } else {
-                (q == 0 ? L.x : L.y) = pk_bf16(r0, r1);
-                if (q == 1) {
-                    unsigned char* p = base + (kb >> 1) * X6_PLANE + x6_slot(4 * mb + j) * 16 + (kb & 1) * 8;
-                    *reinterpret_cast<uint2*>(p) = make_uint2(H.x, H.y);
-                    *reinterpret_cast<uint2*>(p + X6_PART) = make_uint2(Mi.x, Mi.y);
-                    *reinterpret_cast<uint2*>(p + 2 * X6_PART) = make_uint2(L.x, L.y);
-                }
-            }
-        }
-    };
-    // one quarter of a tile fetch: the q-th 16-byte load of operand A (is_b = false) or B; a quarter that is not valid (past the
-    // split's end, masked row, frame padding) is loaded from a 16-byte zero page instead -- the validity lives in the ADDRESS
-    auto fetch_q = [&](int kt, int q, bool is_b, float4 (&rv)[4]) {
-        const int k0 = k_begin + kt * BK;
-        const float* zero = reinterpret_cast<const float*>(&g_x6_zero16);
-        const float* src;
-        bool ok;
-        if (!is_b) {
-            if (AK) {
-                const int h = q >> 1, c = q & 1;
-                const int k = k0 + kgrp * 8 + 4 * c;
-                if (AMODE == A_FRAMES) {
-                    const int p = fp0[h] + k;
-                    ok = k < k_end && p >= 0 && p < g.fr_L;
-                    src = g.A + arow[h] + p;
-                } else {
-                    ok = k < k_end;
-                    src = g.A + arow[h] + k;
-                }
-            } else {
-                const int k = k0 + 4 * kb + q, m = m0 + 4 * mb;
-                if (AMODE == A_FRAMES_T) {
-                    const int kc = min(k, g.K - 1);
-                    const int b = kc / g.fr_T, t = kc - b * g.fr_T;
-                    const int p = t * g.fr_hop + m - g.fr_pl;
-                    ok = k < k_end && m < g.M && p >= 0 && p < g.fr_L;
-                    src = g.A + (long)b * g.fr_L + p;
-                } else {
-                    ok = k < k_end && m < g.M && !(g.mask_period && (k % g.mask_period) == g.mask_skip);
-                    src = g.A + (long)k * g.lda + m;
-                }
-            }
-        } else if (BKc) {
-            const int h = q >> 1, c = q & 1;
-            const int k = k0 + kgrp * 8 + 4 * c;
-            ok = k < k_end;
-            src = g.B + brow[h] + k;
-        } else {
-            const int k = k0 + 4 * kb + q, n = n0 + 4 * mb;
-            ok = k < k_end && n < g.N;
-            src = g.B + (long)k * g.ldb + n;
-        }
-        rv[q] = *reinterpret_cast<const float4*>(ok ? src : zero);
-    };
-    auto fused = [&](int bufR, int bufW, float4 (&ra)[4], float4 (&rb)[4], int kt_fetch) {
-        bf16x8_t a[2][2][3], b[2][2][3];
-        auto read_frag = [&](int ks, int n) {       // n = 0..11: operand (A, B) x tile (0, 1) x part (0..2)
-            const int i = (n >> 1) & 1, p = n >> 2;
-            if (AMS_X6_DBG & 8) {
-                const uint4 c = {0x3f803f80u + (unsigned)n, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u + (unsigned)ks};
-                if (n & 1) b[ks][i][p] = __builtin_bit_cast(bf16x8_t, c); else a[ks][i][p] = __builtin_bit_cast(bf16x8_t, c);
-                return;
-            }
-            if (n & 1) b[ks][i][p] = *reinterpret_cast<const bf16x8_t*>(bp[i] + bufR * X6_LDS + p * X6_PART + ks * 2 * X6_PLANE);
-            else a[ks][i][p] = *reinterpret_cast<const bf16x8_t*>(ap[i] + bufR * X6_LDS + p * X6_PART + ks * 2 * X6_PLANE);
-        };
-#pragma unroll
-        for (int n = 0; n < 12; ++n) read_frag(0, n);
-        __builtin_amdgcn_sched_barrier(0);
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-        constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
-        uint4 H, Mi, L;
-        float r0 = 0.f, r1 = 0.f;
-        unsigned char* const wa = smem + bufW * X6_LDS;
-        unsigned char* const wb = wa + X6_OPER;
-        // the 48 units are expanded with compile-time indices (a `#pragma unroll` loop of this size is left rolled by hipcc: fragment
-        // arrays in scratch memory, MFMA operands picked through a constant table)
-        auto unit = [&](auto uc) {
-            constexpr int u = decltype(uc)::value;
-            constexpr int ks = u / 24, t = (u % 24) >> 2, i = (u >> 1) & 1, j = u & 1;
-            if (AMS_X6_DBG & 4) asm volatile("" :: "v"(a[ks][i][PA[t]]), "v"(b[ks][j][PB[t]]));
-            else acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[ks][i][PA[t]], b[ks][j][PB[t]], acc[i][j], 0, 0, 0);
-            if (u < 12) read_frag(1, u);                                        // second k-step's fragments (needed from unit 24)
-            if (AMS_X6_DBG & 32) { }
-            else if (u < 24) split_slice(wa, AK, ra, u / 3, u % 3, H, Mi, L, r0, r1, false);
-            else split_slice(wb, BKc, rb, (u - 24) / 3, u % 3, H, Mi, L, r0, r1, true);
-            if (!(AMS_X6_DBG & 16) && u >= 24 && u < 28) fetch_q(kt_fetch, u - 24, false, ra);     // A's staging registers are free
-            __builtin_amdgcn_sched_barrier(0);
-        };
-#define X6_U1(n) unit(std::integral_constant<int, (n)>{});
-#define X6_U4(n) X6_U1(n) X6_U1((n) + 1) X6_U1((n) + 2) X6_U1((n) + 3)
-#define X6_U16(n) X6_U4(n) X6_U4((n) + 4) X6_U4((n) + 8) X6_U4((n) + 12)
-        X6_U16(0) X6_U16(16) X6_U16(32)
-#undef X6_U16
-#undef X6_U4
-#undef X6_U1
-        if (!(AMS_X6_DBG & 16)) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) fetch_q(kt_fetch, q, true, rb);
-        }
-    };
-    if (FS) {
-        auto fetch_all = [&](int kt, float4 (&ra)[4], float4 (&rb)[4]) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) { fetch_q(kt, q, false, ra); fetch_q(kt, q, true, rb); }
-        };
-        bool all[4] = {true, true, true, true};
-        fetch_all(0, ra0, rb0);
-        stash(0, ra0, rb0, all, all);               // bsum (B_ROW) of tile 0 is added here, of every later tile in split_slice
-        fetch_all(1, ra0, rb0);
-        fetch_all(2, ra1, rb1);
+    fetch(0);
+    stash();
+    fetch(1);                                       // tiles past the split's end: clamped addresses, staged as zeros if ever used
+    __syncthreads();
+    for (int kt = 0;; ++kt) {                       // every branch below is workgroup-uniform
+        mfma_tile();                                // tile kt
+        if (kt + 1 >= nk) break;
         __syncthreads();
-        for (int kt = 0;; kt += 2) {                // one barrier per k-tile; the tile split behind the last one is a zero tile
-            X6_STAMP(0, kt, 0);
-            fused(0, 1, ra0, rb0, kt + 3);
-            X6_STAMP(0, kt, 1);
-            __syncthreads();
-            X6_STAMP(0, kt, 3);
-            if (kt + 1 >= nk) break;
-            X6_STAMP(0, kt + 1, 0);
-            fused(1, 0, ra1, rb1, kt + 4);
-            X6_STAMP(0, kt + 1, 1);
-            __syncthreads();
-            X6_STAMP(0, kt + 1, 3);
-            if (kt + 2 >= nk) break;
-        }
-    } else if (!WS) {
-        fetch(0, ra0, rb0, va0, vb0);
-        stash(0, ra0, rb0, va0, vb0);
-        fetch(1, ra0, rb0, va0, vb0);               // tiles past the split's end: clamped addresses, staged as zeros if ever used
-        fetch(2, ra1, rb1, va1, vb1);
+        stash();                                    // tile kt + 1 (fetched one iteration ago)
+        if (!(AMS_X6_DBG & 16)) fetch(kt + 2);
         __syncthreads();
-        for (int kt = 0;; kt += 2) {                // every branch below is workgroup-uniform
-            mfma_tile(0);                           // tile kt
-            if (kt + 1 >= nk) break;
-            __syncthreads();
-            stash(0, ra0, rb0, va0, vb0);           // tile kt + 1
-            if (!(AMS_X6_DBG & 16)) fetch(kt + 3, ra0, rb0, va0, vb0);
-            __syncthreads();
-            mfma_tile(0);                           // tile kt + 1
-            if (kt + 2 >= nk) break;
-            __syncthreads();
-            stash(0, ra1, rb1, va1, vb1);           // tile kt + 2
-            if (!(AMS_X6_DBG & 16)) fetch(kt + 4, ra1, rb1, va1, vb1);
-            __syncthreads();
-        }
-    } else {
-        // tile j is split into LDS buffer j & 1 while tile j - 1 is multiplied out of the other one; it was fetched two tiles
-        // earlier into staging set (j - 1) & 1.  One barrier per k-tile; every branch is wave-uniform.
-        if (producer) {
-            fetch(0, ra0, rb0, va0, vb0);
-            stash(0, ra0, rb0, va0, vb0);
-            fetch(1, ra0, rb0, va0, vb0);
-            fetch(2, ra1, rb1, va1, vb1);
-        }
-        __syncthreads();
-        for (int kt = 0;; kt += 2) {
-            X6_STAMP(producer ? 1 : 0, kt, 0);
-            if (consumer) { mfma_tile(0); X6_STAMP(0, kt, 1); }             // tile kt
-            else if (kt + 1 < nk) {
-                stash(1, ra0, rb0, va0, vb0);       // tile kt + 1
-                X6_STAMP(1, kt, 1);
-                if (!(AMS_X6_DBG & 16)) fetch(kt + 3, ra0, rb0, va0, vb0);
-                X6_STAMP(1, kt, 2);
-            }
-            __syncthreads();
-            X6_STAMP(producer ? 1 : 0, kt, 3);
-            if (kt + 1 >= nk) break;
-            X6_STAMP(producer ? 1 : 0, kt + 1, 0);
-            if (consumer) { mfma_tile(1); X6_STAMP(0, kt + 1, 1); }         // tile kt + 1
-            else if (kt + 2 < nk) {
-                stash(0, ra1, rb1, va1, vb1);       // tile kt + 2
-                X6_STAMP(1, kt + 1, 1);
-                if (!(AMS_X6_DBG & 16)) fetch(kt + 4, ra1, rb1, va1, vb1);
-                X6_STAMP(1, kt + 1, 2);
-            }
-            __syncthreads();
-            X6_STAMP(producer ? 1 : 0, kt + 1, 3);
-            if (kt + 2 >= nk) break;
-        }
     }
 
     if (!BKc && do_bsum) {
         // thread (kb, mb) summed rows 4 kb .. 4 kb + 3 of every k-tile, columns 4 mb .. + 3: the 8 threads of a column group meet
         // in LDS in a fixed order (deterministic)
-        float4* sb = reinterpret_cast<float4*>(smem);
+        float4* sbuf = reinterpret_cast<float4*>(smem);
         __syncthreads();
-        if (!WS || producer) sb[tid] = bsum4;
+        if (actB) sbuf[tid] = bsum4;
         __syncthreads();
-        if ((!WS || producer) && tid < 32) {
-            float4 t = sb[tid];
+        if (tid < BNX / 4) {
+            float4 t = sbuf[tid];
 #pragma unroll
-            for (int j = 1; j < 8; ++j) { const float4 v = sb[tid + 32 * j]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+            for (int j = 1; j < 8; ++j) { const float4 v = sbuf[tid + (BNX / 4) * j]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
             const int n = n0 + tid * 4;
             if (n < g.N) *reinterpret_cast<float4*>(g.bsum_part + (long)split * g.N + n) = t;
         }
     }
-    if (consumer) store_tile(g, acc, split, m0, n0, wm, wn, l31, lk);
+    // Epilogue.  C/D layout of a 32x32 MFMA (any input type): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+    float* out = g.splits > 1 ? g.partial + (long)split * g.M * g.N : g.C;
+    const long ldo = g.splits > 1 ? g.N : g.ldc;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + (wn * TN + j) * 32 + l31;
+            if (col >= g.N) continue;
+            const float bv = (g.splits == 1 && g.bias) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                if (row < g.M) {
+                    float v = acc[i][j][r] + bv;
+                    float* p = out + ((g.splits == 1 && g.seg_len) ? rowmap(g, row) : (long)row) * ldo + col;
+                    if (g.splits == 1 && g.accumulate) v += *p;
+                    *p = v;
+                }
+            }
+        }
 }
 
-template <int AMODE, int BMODE>
-__global__ __launch_bounds__(256, 2) void gemm_x6_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[X6_LDS];
-    x6_body<AMODE, BMODE, 0>(g, smem);
-}
-template <int AMODE, int BMODE>
-__global__ __launch_bounds__(256, 1) void gemm_x6fs_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * X6_LDS];
-    x6_body<AMODE, BMODE, 2>(g, smem);
-}
-template <int AMODE, int BMODE>
-__global__ __launch_bounds__(512, 1) void gemm_x6ws_kernel(GemmArgs g) {
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * X6_LDS];
-    x6_body<AMODE, BMODE, 1>(g, smem);
+template <int AMODE, int BMODE, int CFG>
+__global__ __launch_bounds__(X6Cfg<CFG>::WMC * X6Cfg<CFG>::WNC * 64, CFG == 0 ? 2 : 1) void gemm_x6_kernel(GemmArgs g) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[x6_lds(CFG)];
+    x6_body<AMODE, BMODE, CFG>(g, smem);
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, const float* __restrict__ bias,
@@ -1128,24 +948,38 @@ __global__ void bsum_finish_kernel(const float* __restrict__ part, float* __rest
 // n = ceil(tiles*s/256) workgroups end up on the busiest CU (equal-work workgroups time-share a CU's four
 // SIMDs, so the launch ends when that CU drains); occ(n) discounts CUs holding only 1-3 workgroups, whose
 // barrier stalls are not covered by a neighbour's MFMAs; the last term is the fp32 partial-slab round trip.
-inline int choose_splits(int M, int N, int K, int nbatch = 1) {
-    const int tiles = ceil_div(M, BM) * ceil_div(N, BN) * nbatch;
-    const bool x6 = use_x6();                  // bf16x6 kernel: 32-deep k-tiles, ~0.45 us per 16 k and workgroup
-    const int bk = x6 ? X6_BK : BK;
-    const double us16 = x6 ? AMS_GEMM_X6_US16 : 1.024;
+struct TilePlan { int bm, bn, bk; double us16; };     // block tile and the cost of 16 k of it for one workgroup (microseconds)
+inline TilePlan f32_plan() { return {BM, BN, BK, 1.024}; }
+// bf16x6 tile configuration (X6Cfg) of an M x N output: 256-wide tiles where they waste under 10 % of the rows / columns they cover.
+inline int x6_choose_cfg(int M, int N) {
+    if (tuning().x6cfg >= 0 && tuning().x6cfg <= 3) return tuning().x6cfg;
+    const bool m256 = (double)ceil_div(M, 256) * 256 <= 1.10 * M, n256 = (double)ceil_div(N, 256) * 256 <= 1.10 * N;
+    return m256 && n256 ? 1 : m256 ? 2 : n256 ? 3 : 0;
+}
+inline TilePlan x6_plan(int cfg) {
+    static const double us16[4] = {AMS_GEMM_X6_US16, AMS_GEMM_X6_US16_1, AMS_GEMM_X6_US16_2, AMS_GEMM_X6_US16_2};
+    return {x6_bm(cfg), x6_bn(cfg), X6_BK, us16[cfg]};
+}
+inline int choose_splits(int M, int N, int K, int nbatch, const TilePlan& tp) {
+    const int tiles = ceil_div(M, tp.bm) * ceil_div(N, tp.bn) * nbatch;
     int best = 1;
     double best_t = 1e30;
     for (int s = 1; s <= 32; ++s) {
         if (s > 1 && K / s < 128) break;
-        const int kps = ceil_div(ceil_div(K, s), bk) * bk;
+        const int kps = ceil_div(ceil_div(K, s), tp.bk) * tp.bk;
         const int s2 = ceil_div(K, kps);
         const int n = ceil_div((long)tiles * s2, 256);
         const double occ = n <= 1 ? 0.62 : (n == 2 ? 0.80 : (n == 3 ? 0.92 : 1.0));
-        double t = n * ((kps / 16.0) * us16 + 5.0) / occ;
+        double t = n * ((kps / 16.0) * tp.us16 + 5.0) / occ;
         if (s2 > 1) t += (double)(s2 + 1) * M * N * nbatch * 4.0 / 2.5e6;
         if (t < best_t - 1e-9) { best_t = t; best = s2; }
     }
     return best;
+}
+// what a workspace query assumes: the process-wide arithmetic (a launch whose operands are not 16-byte addressable falls back to
+// the f32 kernel and re-plans within the workspace it is given)
+inline int choose_splits(int M, int N, int K, int nbatch = 1) {
+    return choose_splits(M, N, K, nbatch, use_x6() ? x6_plan(x6_choose_cfg(M, N)) : f32_plan());
 }
 
 // Band height of the tile order: the patch of tiles one XCD works on at a time (its share of the grid, at most ~64 in
@@ -1165,14 +999,6 @@ inline int choose_group_m(int tiles_m, int tiles_n) {
 template <int AMODE, int BMODE>
 ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nbatch = 1, float* bsum_out = nullptr,
                   int bsum_accumulate = 0, float* bsum_ws = nullptr) {
-    const int tiles = ceil_div(g.M, BM) * ceil_div(g.N, BN);
-    g.group_m = choose_group_m(ceil_div(g.M, BM), ceil_div(g.N, BN));
-    int splits = 1;
-    if (ws) {
-        splits = choose_splits(g.M, g.N, g.K, nbatch);
-        if (tuning().splits > 0) splits = tuning().splits;
-        while (splits > 1 && (size_t)nbatch * splits * g.M * g.N * sizeof(float) > ws_bytes) --splits;
-    }
     constexpr bool AKc = (AMODE == A_ROW), BKcc = (BMODE == B_COL);
     const bool vec_off = tuning().novec;
     const bool vec = g.a_vec && g.b_vec && !vec_off &&
@@ -1180,9 +1006,18 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
                       AKc ? (g.K % 4 == 0 && g.K >= 4) : (g.M % 4 == 0 && g.M >= 4)) &&
                      (BKcc ? (g.K % 4 == 0 && g.K >= 4) : (g.N % 4 == 0 && g.N >= 4));
     const bool x6 = vec && use_x6();
-    const int bk = x6 ? X6_BK : BK;
+    const int cfg = x6 ? x6_choose_cfg(g.M, g.N) : 0;
+    const TilePlan tp = x6 ? x6_plan(cfg) : f32_plan();
+    const int tiles = ceil_div(g.M, tp.bm) * ceil_div(g.N, tp.bn);
+    g.group_m = choose_group_m(ceil_div(g.M, tp.bm), ceil_div(g.N, tp.bn));
+    int splits = 1;
+    if (ws) {
+        splits = choose_splits(g.M, g.N, g.K, nbatch, tp);
+        if (tuning().splits > 0) splits = tuning().splits;
+        while (splits > 1 && (size_t)nbatch * splits * g.M * g.N * sizeof(float) > ws_bytes) --splits;
+    }
     int kps = ceil_div(g.K, splits);
-    kps = ceil_div(kps, bk) * bk;
+    kps = ceil_div(kps, tp.bk) * tp.bk;
     splits = ceil_div(g.K, kps);
     g.splits = splits;
     g.k_per_split = kps;
@@ -1204,25 +1039,28 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
         }
     }
     if (x6) {
-        // same residency (workgroups per CU) as the pad asks of the 16.8 KB f32 kernel, restated for 48.75 KB of static LDS
-        int pad = 0;
-        if (t_gemm_lds_pad > 0) {
-            int wg = 163840 / (17152 + t_gemm_lds_pad);
-            if (wg < 1) wg = 1;
-            pad = 163840 / wg - X6_LDS - 1024;
-            if (pad < 0) pad = 0;
-        }
-        if (X6_LDS + pad > 64 * 1024) {
-            static thread_local int raised_x = 0;
-            if (raised_x < pad) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<AMODE, BMODE>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, pad);
-                raised_x = pad;
+        // residency: the 128 x 128 configuration holds 48.75 KB of LDS (3 workgroups per CU by LDS, 2 by registers); a pad asks for
+        // what it asks of the 16.8 KB f32 kernel (workgroups per CU), restated.  The 8-wave configurations are alone on a CU anyway.
+        if (cfg == 0) {
+            int pad = 0;
+            if (t_gemm_lds_pad > 0) {
+                int wg = 163840 / (17152 + t_gemm_lds_pad);
+                if (wg < 1) wg = 1;
+                pad = 163840 / wg - x6_lds(0) - 1024;
+                if (pad < 0) pad = 0;
             }
-        }
-        if (tuning().x6mode == 2) hipLaunchKernelGGL((gemm_x6fs_kernel<AMODE, BMODE>), grid, dim3(256), 0, st, g);   // one workgroup per CU by its own LDS
-        else if (tuning().x6mode == 1) hipLaunchKernelGGL((gemm_x6ws_kernel<AMODE, BMODE>), grid, dim3(512), 0, st, g);
-        else hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE>), grid, dim3(256), (size_t)pad, st, g);
+            if (x6_lds(0) + pad > 64 * 1024) {
+                static thread_local int raised_x = 0;
+                if (raised_x < pad) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<AMODE, BMODE, 0>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, pad);
+                    raised_x = pad;
+                }
+            }
+            hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 0>), grid, dim3(256), (size_t)pad, st, g);
+        } else if (cfg == 1) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 1>), grid, dim3(512), 0, st, g);
+        else if (cfg == 2) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 2>), grid, dim3(512), 0, st, g);
+        else hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 3>), grid, dim3(512), 0, st, g);
     } else if (vec) {
         if (t_gemm_lds_pad > 40 * 1024) {
             static thread_local int raised_v = 0;
@@ -1271,9 +1109,6 @@ extern "C" {
 void ams_gemm_set_lds_pad(int bytes) { t_gemm_lds_pad = bytes < 0 ? 0 : bytes; }
 void ams_gemm_set_arith(int mode) { g_gemm_arith.store(mode ? 1 : 0, std::memory_order_relaxed); }
 int ams_gemm_get_arith(void) { return use_x6() ? 1 : 0; }
-#if AMS_X6_TRACE
-int ams_gemm_x6_trace_read(unsigned long long* out) { return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_x6_trace), sizeof(g_x6_trace)); }
-#endif
 
 size_t ams_gemm_workspace_bytes(int M, int N, int K) {
     if (M <= 0 || N <= 0 || K <= 0) return 0;

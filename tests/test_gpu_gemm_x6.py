@@ -78,6 +78,10 @@ def check_pair(e0, e1):
     (4, 4, 4, 0, 0), (4, 8, 12, 1, 1), (128, 128, 32, 0, 0), (128, 128, 36, 1, 0), (256, 384, 64, 0, 1),
     (260, 132, 2052, 1, 0), (600, 520, 5120, 1, 0), (512, 256, 1024, 0, 1), (64, 10240, 600, 0, 0), (300, 1200, 2048, 1, 0),
     (5120, 2400, 600, 0, 0), (5120, 600, 2400, 0, 1), (600, 2400, 5120, 1, 0),
+    # the 8-wave tile configurations (256 x 256, 256 x 128, 128 x 256: csrc/gemm.hip X6Cfg) on every loader, ragged edges included
+    (516, 772, 100, 0, 0), (516, 772, 100, 0, 1), (516, 772, 100, 1, 0), (516, 772, 100, 1, 1),
+    (516, 132, 292, 0, 0), (516, 132, 292, 0, 1), (516, 132, 292, 1, 0), (516, 132, 292, 1, 1),
+    (132, 516, 292, 0, 0), (132, 516, 292, 0, 1), (132, 516, 292, 1, 0), (132, 516, 292, 1, 1),
 ])
 def test_x6_matches_float64_like_native_f32(ops, arith, M, N, K, tA, tB):
     rng = np.random.RandomState(M + 3 * N + 7 * K + tA + 2 * tB)
@@ -107,8 +111,8 @@ def test_x6_small_integers_are_exact(ops, arith):
     """Products of small integers are exact in every term of the split and in f32: any layout / k-order / transposition mistake in
     the bf16 images shows as a whole-number error.  Asymmetric operands (guide rule: symmetric inputs hide transposes)."""
     rng = np.random.RandomState(5)
-    for tA, tB in ((0, 0), (0, 1), (1, 0), (1, 1)):
-        M, N, K = 196, 324, 100
+    for M, N, K, tA, tB in [(m, n, 100, ta, tb) for (m, n) in ((196, 324), (520, 776), (520, 196), (196, 520))
+                            for ta in (0, 1) for tb in (0, 1)]:
         A = rng.randint(-7, 8, size=(K, M) if tA else (M, K)).astype(np.float64)
         B = rng.randint(-7, 8, size=(N, K) if tB else (K, N)).astype(np.float64)
         ref = (A.T if tA else A) @ (B.T if tB else B)

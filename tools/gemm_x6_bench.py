@@ -34,7 +34,8 @@ SHAPES = [
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--reps', type=int, default=20)
+    ap.add_argument('--reps', type=int, default=200)
+    ap.add_argument('--warm', type=int, default=100, help='untimed launches first (the clock ramps up from idle over milliseconds)')
     ap.add_argument('--only', default='', help='comma-separated substrings of the product labels to run')
     ap.add_argument('--modes', default='0,1', help='arithmetics to time: 0 native f32, 1 bf16x6')
     a = ap.parse_args()
@@ -54,7 +55,7 @@ def main():
         scale = (np.linalg.norm(A64, axis=1)[:, None] * np.linalg.norm(B64, axis=0)[None, :]).max()
         for mode in [int(m) for m in a.modes.split(',')]:
             lib.ams_gemm_set_arith(mode)
-            for _ in range(3):
+            for _ in range(a.warm):
                 ops.gemm(A, B, transA=bool(tA), transB=bool(tB), out=out)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
