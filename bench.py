@@ -26,6 +26,11 @@ for _p in (ROOT, PKG):
         sys.path.insert(0, _p)
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0    # same guide: v_mfma_f32_32x32x16_bf16 dense peak
+# The products run as "bf16x6" by default (csrc/gemm.hip): every f32 operand is split EXACTLY into three bf16 terms and six bf16 MFMA
+# products are accumulated in f32 per f32 product -- f32-level error (tests/test_gpu_gemm_x6.py) on the bf16 matrix pipe.  The
+# roofline prices the ALGORITHMIC f32 flops (2 M N K) against what that pipe can deliver for them: bf16 peak / 6.
+X6_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
 HBM_PEAK_GBS = 8000.0
 
 
@@ -40,6 +45,7 @@ def parse():
                          "(SURVEY 8d: global batch 64)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-secondary', action='store_true', help='skip the cfg3(ii) fine-tuning step timing (N=1 only)')
+    ap.add_argument('--no-native-f32', action='store_true', help='skip the second timing with native f32 MFMA products (N=1 only)')
     ap.add_argument('--cpu-batch', type=int, default=16)
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--roofline-steps', type=int, default=5)
@@ -209,26 +215,37 @@ def main():
 
     # ---- roofline of the dominant kernel: the fp32 MFMA GEMM family (dense 600->F*E, its two gradients, LSTM projections)
     prof = ops.PROFILE.summary(prefix='gemm')
+    from ams_hip._lib import load as _load
+    x6 = bool(_load().ams_gemm_get_arith())
+    peak = X6_PEAK_TFLOPS if x6 else MFMA_F32_PEAK_TFLOPS
+    kname = 'gemm_x6_kernel' if x6 else 'gemm_f32_kernel'
     roof = None
     tj = None
     if prof['launches']:
         avg_ms = prof['ms'] / prof['launches']
         flops_per_launch = prof['flops'] / prof['launches']
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        roof = {'bound': 'mfma', 'kernel': 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32)', 'achieved': round(achieved, 2),
-                'peak': MFMA_F32_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / MFMA_F32_PEAK_TFLOPS, 4),
+        roof = {'bound': 'mfma', 'kernel': (kname + ' (6 x v_mfma_f32_32x32x16_bf16 per f32 product: exact 3-way bf16 operand split, f32 accumulate)')
+                if x6 else 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32)', 'achieved': round(achieved, 2),
+                'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                 'traffic': None, 'launches_per_step': prof['launches'] / prof_steps,
                 'avg_launch_ms': round(avg_ms, 4), 'share_of_step': round(prof['ms'] / prof_steps / (elapsed / args.steps * 1e3), 3),
                 'measured': ('HIP events around each launch, %d eager steps after the graph-replayed timed region' % prof_steps)
                 if args.graph else 'HIP events around each launch inside the timed region',
                 'by_variant': {}}
+        if x6:
+            roof['achieved_unit_note'] = 'f32-equivalent TFLOP/s = algorithmic 2*M*N*K per launch / duration'
+            roof['peak_note'] = ('bf16 MFMA dense peak %.0f TFLOP/s / 6 bf16 products per f32 product; the same launches reach %.2f of '
+                                 'the NATIVE f32 MFMA peak (%.1f TFLOP/s), which this arithmetic is not bound by'
+                                 % (MFMA_BF16_PEAK_TFLOPS, achieved / MFMA_F32_PEAK_TFLOPS, MFMA_F32_PEAK_TFLOPS))
+            roof['bf16_mfma_flops_issued_TFLOP/s'] = round(6 * achieved, 1)
         # HBM traffic of the same kernels: rocprofv3 PMC passes cannot run inside this process, so the per-launch figure is CITED
         # from the newest committed summary of `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this very workload
         # (tools/pmc_traffic.sh -> tools/pmc_summary.py; gfx950 x2 read correction applied there), tagged with the commit the
         # counters were collected at.  null for any other shape or when no summary is committed.
         tj, tfile = _newest_profile('_c_hbm_traffic.json')
         if tj is not None and (B, L, N) == (64, 20480, 256):
-            gk = [v for k, v in tj.items() if k.startswith('gemm_f32_kernel') and isinstance(v, dict)]
+            gk = [v for k, v in tj.items() if k.startswith(kname) and isinstance(v, dict)]
             calls = sum(v['calls'] for v in gk)
             if calls:
                 mb = sum(v['calls'] * (v['read_MB_per_launch'] + v['write_MB_per_launch']) for v in gk) / calls
@@ -246,21 +263,23 @@ def main():
             fa = alone['family']
             ach = fa['flops'] / (fa['ms'] * 1e-3) / 1e12
             roof['standalone'] = {
-                'achieved': round(ach, 2), 'frac': round(ach / MFMA_F32_PEAK_TFLOPS, 4), 'unit': 'TFLOP/s',
+                'achieved': round(ach, 2), 'frac': round(ach / peak, 4), 'unit': 'TFLOP/s',
                 'measured': 'HIP events around each launch, %d eager steps with the side stream off (no co-resident kernel, no residency '
                             'cap): the kernel alone at the step\'s own shapes' % alone['steps'],
-                'by_variant': {'gemm_f32_kernel' + t[4:]: {'avg_launch_us': round(v['ms'] / v['launches'] * 1e3, 2),
+                'by_variant': {kname + t[4:]: {'avg_launch_us': round(v['ms'] / v['launches'] * 1e3, 2),
                                                             'TFLOP/s': round(v['flops'] / (v['ms'] * 1e-3) / 1e12, 2)}
                                for t, v in alone['by_tag'].items() if v['launches']},
-                'sustained_mfma_ceiling_TFLOP/s': 125.0,
-                'ceiling_note': 'tools/mfma_peak.hip on the same boxes: dependent-free v_mfma_f32_32x32x2_f32 streams reach 152-156 TFLOP/s '
-                                'for ~100 us and settle at ~125 TFLOP/s when sustained (power management), DESIGN.md 4'}
+                'ceiling_note': ('the MFMA-only instruction stream of this kernel (split, LDS and fetch compiled out) runs the 4096^3 product in '
+                                 '379 us = 362 TFLOP/s f32-equivalent at 2400 MHz / 1050 W; the whole kernel draws 1385-1393 W, i.e. the board '
+                                 'power limit, at 2135 MHz (tools/clock_probe.sh, DESIGN.md 4)') if x6 else
+                                ('tools/mfma_peak.hip on the same boxes: dependent-free v_mfma_f32_32x32x2_f32 streams reach 152-156 TFLOP/s '
+                                 'for ~100 us and settle at ~125 TFLOP/s when sustained (power management), DESIGN.md 4')}
         for tag in ops.PROFILE.tags():
             if not tag.startswith('gemm'):
                 continue
             pv = ops.PROFILE.summary(tag)
             if pv['launches']:
-                roof['by_variant']['gemm_f32_kernel' + tag[4:]] = {
+                roof['by_variant'][kname + tag[4:]] = {
                     'launches_per_step': pv['launches'] / prof_steps, 'avg_launch_us': round(pv['ms'] / pv['launches'] * 1e3, 2),
                     'TFLOP/s': round(pv['flops'] / (pv['ms'] * 1e-3) / 1e12, 2)}
 
@@ -290,23 +309,29 @@ def main():
     if pf['launches']:
         t = pf['ms'] * 1e-3
         targets['front_conv'] = {
-            'kernel': 'gemm_f32_kernel<A_FRAMES> (+ split-K reduce)', 'avg_launch_us': round(pf['ms'] / pf['launches'] * 1e3, 2),
-            'TFLOP/s': round(pf['flops'] / t / 1e12, 2), 'mfma_frac': round(pf['flops'] / t / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
+            'kernel': kname + '<A_FRAMES> (+ split-K reduce)', 'avg_launch_us': round(pf['ms'] / pf['launches'] * 1e3, 2),
+            'TFLOP/s': round(pf['flops'] / t / 1e12, 2), 'mfma_frac': round(pf['flops'] / t / 1e12 / peak, 4),
+            'vs_native_f32_mfma_peak': round(pf['flops'] / t / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
             'algorithmic_GB/s': round(pf['bytes'] / t / 1e9, 1), 'hbm_frac': round(pf['bytes'] / t / 8e12, 4),
             'note': 'strided analysis conv = dense contraction, AI ~ 250 flop/B: MFMA-bound, not HBM-bound (DESIGN.md 4)'}
     pi = ops.PROFILE.summary(label='blstm_input_gemm')
     if pi['launches']:
         t = pi['ms'] * 1e-3
         targets['blstm_input_gemm'] = {
-            'kernel': 'gemm_f32_kernel<A_ROW,B_ROW>, both directions in one [B*T, D] x [D, 8H] product',
+            'kernel': kname + '<A_ROW,B_ROW>, both directions in one [B*T, D] x [D, 8H] product',
             'avg_launch_us': round(pi['ms'] / pi['launches'] * 1e3, 2), 'TFLOP/s': round(pi['flops'] / t / 1e12, 2),
-            'mfma_frac': round(pi['flops'] / t / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
+            'mfma_frac': round(pi['flops'] / t / 1e12 / peak, 4),
+            'vs_native_f32_mfma_peak': round(pi['flops'] / t / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
 
     out = {
         'metric': 'mixtures/sec training throughput (2-spk, 256-filter adapt+BLSTM-DPCL)',
         'value': round(value, 2), 'unit': 'mixtures/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': args.scaling,
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+        'arith': ('f32 throughout; dense products as bf16x6 on the bf16 matrix pipe: exact 3-way bf16 split of both f32 operands, 6 of 9 partial '
+                  'products (dropped: <= 2^-26 |a.b|), f32 accumulation -- error vs float64 at or below the native f32 MFMA kernel\'s '
+                  '(tests/test_gpu_gemm_x6.py); `secondary.native_f32_mfma` is the same step with v_mfma_f32_32x32x2_f32 products')
+        if x6 else 'f32 throughout, products on v_mfma_f32_32x32x2_f32',
         'config': {'workload': 'front_DPCL training step (SURVEY 8d cfg3(i)): frozen adaptive front W=1024 hop=256 N=%d -> '
                                '3xBLSTM(600) -> dense 600->%d -> l2norm -> DPCL loss, fwd+bwd+AMSGrad' % (N, N * E),
                    'batch_per_gpu': B, 'global_batch': B * world, 'nb_speakers': S, 'chunk_size': L, 'frames': T,
@@ -329,6 +354,20 @@ def main():
                                                                    'workload': r['workload']}}
             except Exception as e:                       # the headline line must still be printed
                 out['secondary'] = {'error': '%s: %s' % (type(e).__name__, e)}
+        if world == 1 and x6 and not args.no_native_f32:
+            # the same timed region with the native f32 MFMA products (AMS_GEMM_X6=0), in a fresh process (the hipGraph is captured per arithmetic)
+            import subprocess
+            try:
+                env = dict(os.environ, AMS_GEMM_X6='0')
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), '--steps', str(args.steps), '--warmup', str(args.warmup),
+                                    '--batch', str(args.batch), '--chunk', str(args.chunk), '--filters', str(args.filters),
+                                    '--graph', str(int(bool(args.graph))), '--roofline-steps', '0', '--no-secondary', '--no-cpu-baseline',
+                                    '--quiet'], env=env, capture_output=True, text=True, timeout=600)
+                j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+                out.setdefault('secondary', {})['native_f32_mfma'] = {'mixtures_per_s': j['value'], 'ms_per_step': j['ms_per_step'],
+                                                                      'note': 'same step, same run, products on v_mfma_f32_32x32x2_f32'}
+            except Exception as e:
+                out.setdefault('secondary', {})['native_f32_mfma'] = {'error': '%s: %s' % (type(e).__name__, e)}
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(args)
         print(json.dumps(out))

@@ -233,6 +233,7 @@ def test_ring_recurrence_is_bit_stable_under_uneven_load(ops):
                 ops.gemm(a, bmat)
         got = layer()
         torch.cuda.synchronize()
-        for g, r in zip(got, ref):
-            assert torch.equal(g, r), 'repetition %d differs from the idle run' % rep
+        for i, (g, r) in enumerate(zip(got, ref)):
+            assert torch.equal(g, r), ('repetition %d: tensor %d differs from the idle run (max |diff| %.3e, ring error word %d)'
+                                       % (rep, i, float((g - r).abs().max()), ops.persist_errors()))
     assert ops.persist_errors() == 0
