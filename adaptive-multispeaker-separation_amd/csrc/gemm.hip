@@ -26,15 +26,16 @@ thread_local int t_gemm_lds_pad = 0;
 std::atomic<int> g_gemm_arith{-1};        // -1: not chosen yet (AMS_GEMM_X6, default 1), 0: native f32 MFMA, 1: bf16x6
 
 // Tuning overrides (A/B runs only): read from the environment ONCE per process, never on the launch path.
-struct GemmTuning { int group_m, splits, x6cfg; bool noprio, novec; };
+struct GemmTuning { int group_m, splits, x6cfg, x6rule; bool noprio, novec; };
 inline const GemmTuning& tuning() {
     static const GemmTuning t = [] {
-        GemmTuning v{0, 0, -1, false, false};
+        GemmTuning v{0, 0, -1, 1, false, false};
         if (const char* f = getenv("AMS_GEMM_GROUP_M")) v.group_m = atoi(f);
         if (const char* f = getenv("AMS_GEMM_SPLITS")) v.splits = atoi(f);
         v.noprio = getenv("AMS_GEMM_NOPRIO") != nullptr;
         v.novec = getenv("AMS_GEMM_NOVEC") != nullptr;
         if (const char* f = getenv("AMS_GEMM_X6CFG")) v.x6cfg = atoi(f);       // force one bf16x6 tile configuration (0..3, X6Cfg)
+        if (const char* f = getenv("AMS_GEMM_X6RULE")) v.x6rule = atoi(f);
         return v;
     }();
     return t;
@@ -64,11 +65,11 @@ constexpr int X6_BK = 32;           // k-tile of the bf16x6 kernel
 #ifndef AMS_GEMM_X6_US16
 #define AMS_GEMM_X6_US16 0.84
 #endif
-#ifndef AMS_GEMM_X6_US16_1
-#define AMS_GEMM_X6_US16_1 2.35
-#endif
 #ifndef AMS_GEMM_X6_US16_2
 #define AMS_GEMM_X6_US16_2 1.35
+#endif
+#ifndef AMS_GEMM_X6_US16_1
+#define AMS_GEMM_X6_US16_1 2.35
 #endif
 constexpr int PAD_T = 2;   // k-contiguous source, transposed scalar LDS writes: stride 130 -> conflict-free
 constexpr int PAD_V = 4;   // m/n-contiguous source, float4 LDS writes: stride 132 keeps 16B alignment
@@ -585,11 +586,9 @@ template <> struct X6Cfg<2> { static constexpr int BMX = 256, BNX = 128, WMC = 4
 template <> struct X6Cfg<3> { static constexpr int BMX = 128, BNX = 256, WMC = 2, WNC = 4, TM = 2, TN = 2; };   // 8 waves, 72.75 KB
 constexpr int x6_plane(int rows) { return rows * 16 + 32; }     // bytes; +32: the four planes start 8 banks apart (16-byte row writes of one wave hit all four)
 constexpr int x6_oper(int rows) { return 3 * 4 * x6_plane(rows); }
-constexpr int x6_lds(int cfg) {
-    return cfg == 0 ? x6_oper(128) + x6_oper(128) : cfg == 1 ? x6_oper(256) + x6_oper(256) : x6_oper(256) + x6_oper(128);
-}
 constexpr int x6_bm(int cfg) { return (cfg == 1 || cfg == 2) ? 256 : 128; }
 constexpr int x6_bn(int cfg) { return (cfg == 1 || cfg == 3) ? 256 : 128; }
+constexpr int x6_lds(int cfg) { return x6_oper(x6_bm(cfg)) + x6_oper(x6_bn(cfg)); }
 
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {           // v_cvt_pk_bf16_f32: a -> bits 0..15, b -> bits 16..31
     const f32x2_t v = {a, b};
@@ -950,15 +949,21 @@ __global__ void bsum_finish_kernel(const float* __restrict__ part, float* __rest
 // barrier stalls are not covered by a neighbour's MFMAs; the last term is the fp32 partial-slab round trip.
 struct TilePlan { int bm, bn, bk; double us16; };     // block tile and the cost of 16 k of it for one workgroup (microseconds)
 inline TilePlan f32_plan() { return {BM, BN, BK, 1.024}; }
-// bf16x6 tile configuration (X6Cfg) of an M x N output: 256-wide tiles where they waste under 10 % of the rows / columns they cover.
-inline int x6_choose_cfg(int M, int N) {
+// bf16x6 tile configuration (X6Cfg) of an M x N output: 256-wide tiles where they waste under 10 % of the rows / columns they
+// cover.  A residency-capped launch (one meant to run beside a recurrence ring) never takes the 256 x 256 tile: its 8 waves x 256
+// VGPRs leave no room for a ring workgroup on the CU.  AMS_GEMM_X6RULE (A/B runs): 0 = {256x256, 128x128} only, 1 = + 128x256,
+// 2 = + 256x128.
+inline int x6_choose_cfg(int M, int N, bool capped) {
     if (tuning().x6cfg >= 0 && tuning().x6cfg <= 3) return tuning().x6cfg;
     const bool m256 = (double)ceil_div(M, 256) * 256 <= 1.10 * M, n256 = (double)ceil_div(N, 256) * 256 <= 1.10 * N;
-    return m256 && n256 ? 1 : m256 ? 2 : n256 ? 3 : 0;
+    const int rule = tuning().x6rule;
+    if (m256 && n256 && !capped) return 1;
+    if (n256 && rule >= 1) return 3;
+    if (m256 && rule >= 2) return 2;
+    return 0;
 }
 inline TilePlan x6_plan(int cfg) {
-    static const double us16[4] = {AMS_GEMM_X6_US16, AMS_GEMM_X6_US16_1, AMS_GEMM_X6_US16_2, AMS_GEMM_X6_US16_2};
-    return {x6_bm(cfg), x6_bn(cfg), X6_BK, us16[cfg]};
+    return {x6_bm(cfg), x6_bn(cfg), X6_BK, cfg == 1 ? AMS_GEMM_X6_US16_1 : cfg == 0 ? AMS_GEMM_X6_US16 : AMS_GEMM_X6_US16_2};
 }
 inline int choose_splits(int M, int N, int K, int nbatch, const TilePlan& tp) {
     const int tiles = ceil_div(M, tp.bm) * ceil_div(N, tp.bn) * nbatch;
@@ -979,7 +984,7 @@ inline int choose_splits(int M, int N, int K, int nbatch, const TilePlan& tp) {
 // what a workspace query assumes: the process-wide arithmetic (a launch whose operands are not 16-byte addressable falls back to
 // the f32 kernel and re-plans within the workspace it is given)
 inline int choose_splits(int M, int N, int K, int nbatch = 1) {
-    return choose_splits(M, N, K, nbatch, use_x6() ? x6_plan(x6_choose_cfg(M, N)) : f32_plan());
+    return choose_splits(M, N, K, nbatch, use_x6() ? x6_plan(x6_choose_cfg(M, N, t_gemm_lds_pad > 0)) : f32_plan());
 }
 
 // Band height of the tile order: the patch of tiles one XCD works on at a time (its share of the grid, at most ~64 in
@@ -1006,7 +1011,7 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
                       AKc ? (g.K % 4 == 0 && g.K >= 4) : (g.M % 4 == 0 && g.M >= 4)) &&
                      (BKcc ? (g.K % 4 == 0 && g.K >= 4) : (g.N % 4 == 0 && g.N >= 4));
     const bool x6 = vec && use_x6();
-    const int cfg = x6 ? x6_choose_cfg(g.M, g.N) : 0;
+    const int cfg = x6 ? x6_choose_cfg(g.M, g.N, t_gemm_lds_pad > 0) : 0;
     const TilePlan tp = x6 ? x6_plan(cfg) : f32_plan();
     const int tiles = ceil_div(g.M, tp.bm) * ceil_div(g.N, tp.bn);
     g.group_m = choose_group_m(ceil_div(g.M, tp.bm), ceil_div(g.N, tp.bn));

@@ -78,7 +78,8 @@ def check_pair(e0, e1):
     (4, 4, 4, 0, 0), (4, 8, 12, 1, 1), (128, 128, 32, 0, 0), (128, 128, 36, 1, 0), (256, 384, 64, 0, 1),
     (260, 132, 2052, 1, 0), (600, 520, 5120, 1, 0), (512, 256, 1024, 0, 1), (64, 10240, 600, 0, 0), (300, 1200, 2048, 1, 0),
     (5120, 2400, 600, 0, 0), (5120, 600, 2400, 0, 1), (600, 2400, 5120, 1, 0),
-    # the 8-wave tile configurations (256 x 256, 256 x 128, 128 x 256: csrc/gemm.hip X6Cfg) on every loader, ragged edges included
+    # the 8-wave 256 x 256 tile configuration (csrc/gemm.hip X6Cfg<1>) on every loader, ragged edges included; shapes with one
+    # narrow side stay on 128 x 128
     (516, 772, 100, 0, 0), (516, 772, 100, 0, 1), (516, 772, 100, 1, 0), (516, 772, 100, 1, 1),
     (516, 132, 292, 0, 0), (516, 132, 292, 0, 1), (516, 132, 292, 1, 0), (516, 132, 292, 1, 1),
     (132, 516, 292, 0, 0), (132, 516, 292, 0, 1), (132, 516, 292, 1, 0), (132, 516, 292, 1, 1),
