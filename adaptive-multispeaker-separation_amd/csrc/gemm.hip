@@ -76,6 +76,7 @@ constexpr int PAD_V = 4;   // m/n-contiguous source, float4 LDS writes: stride 1
 
 enum { A_ROW = 0, A_COL = 1, A_FRAMES = 2, A_FRAMES_T = 3 };
 enum { B_ROW = 0, B_COL = 1 };
+enum { EPI_STORE = 0, EPI_MAXPOOL = 1 };
 
 struct GemmArgs {
     const float* A; const float* B; float* C; const float* bias;
@@ -200,10 +201,45 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16 (&acc
         }
 }
 
+// Fused max-pool partial, shared by the f32 and the bf16x6 kernel (2 x 2 waves of 64 x 64):
+__device__ __forceinline__ void maxpool_epilogue(const GemmArgs& g, const f32x16 (&acc)[2][2], float* smem, int tile_m, int m0, int n0,
+                                                 int wm, int wn, int l31, int lk) {
+        // Fused max-pool partial (reference models/adapt.py:115-117: stride-1 conv + max_pool_with_argmax): the [Bt,L,N]
+        // conv output is never written; each 128-row tile emits, per column, its maximum and the row that holds it
+        // (first maximum wins ties).  A second small kernel combines tiles into pooling windows.
+        float* sred = smem;                                     // [2 wn][2 j][32] values then rows
+        int* srow = reinterpret_cast<int*>(smem + 128);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            float best = -3.4e38f;
+            int brow = 0x7fffffff;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    const float v = acc[i][j][r];
+                    if (row < g.M && (v > best || (v == best && row < brow))) { best = v; brow = row; }
+                }
+            const float ob = __shfl_xor(best, 32, 64);
+            const int orow = __shfl_xor(brow, 32, 64);
+            if (ob > best || (ob == best && orow < brow)) { best = ob; brow = orow; }
+            if (wm == 1 && lk == 0) { sred[(wn * 2 + j) * 32 + l31] = best; srow[(wn * 2 + j) * 32 + l31] = brow; }
+            __syncthreads();
+            if (wm == 0 && lk == 0) {
+                const float ob2 = sred[(wn * 2 + j) * 32 + l31];
+                const int or2 = srow[(wn * 2 + j) * 32 + l31];
+                if (ob2 > best || (ob2 == best && or2 < brow)) { best = ob2; brow = or2; }
+                const int col = n0 + wn * 64 + j * 32 + l31;
+                if (col < g.N) { g.C[(long)tile_m * g.N + col] = best; g.pidx[(long)tile_m * g.N + col] = brow; }
+            }
+            __syncthreads();
+        }
+}
+
 // Is operand A contiguous along k (-> transposed LDS writes) ?
 template <int AMODE> struct AKContig { static constexpr bool v = (AMODE == A_ROW || AMODE == A_FRAMES); };
 
-enum { EPI_STORE = 0, EPI_MAXPOOL = 1 };
 
 #ifndef AMS_GEMM_WPE
 #define AMS_GEMM_WPE 2
@@ -506,37 +542,7 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
         __syncthreads();
     }
     if (EPI == EPI_MAXPOOL) {
-        // Fused max-pool partial (reference models/adapt.py:115-117: stride-1 conv + max_pool_with_argmax): the [Bt,L,N]
-        // conv output is never written; each 128-row tile emits, per column, its maximum and the row that holds it
-        // (first maximum wins ties).  A second small kernel combines tiles into pooling windows.
-        float* sred = smem;                                     // [2 wn][2 j][32] values then rows
-        int* srow = reinterpret_cast<int*>(smem + 128);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            float best = -3.4e38f;
-            int brow = 0x7fffffff;
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    const float v = acc[i][j][r];
-                    if (row < g.M && (v > best || (v == best && row < brow))) { best = v; brow = row; }
-                }
-            const float ob = __shfl_xor(best, 32, 64);
-            const int orow = __shfl_xor(brow, 32, 64);
-            if (ob > best || (ob == best && orow < brow)) { best = ob; brow = orow; }
-            if (wm == 1 && lk == 0) { sred[(wn * 2 + j) * 32 + l31] = best; srow[(wn * 2 + j) * 32 + l31] = brow; }
-            __syncthreads();
-            if (wm == 0 && lk == 0) {
-                const float ob2 = sred[(wn * 2 + j) * 32 + l31];
-                const int or2 = srow[(wn * 2 + j) * 32 + l31];
-                if (ob2 > best || (ob2 == best && or2 < brow)) { best = ob2; brow = or2; }
-                const int col = n0 + wn * 64 + j * 32 + l31;
-                if (col < g.N) { g.C[(long)tile_m * g.N + col] = best; g.pidx[(long)tile_m * g.N + col] = brow; }
-            }
-            __syncthreads();
-        }
+        maxpool_epilogue(g, acc, smem, tile_m, m0, n0, wm, wn, l31, lk);
         return;
     }
     store_tile(g, acc, split, m0, n0, wm, wn, l31, lk);
@@ -610,7 +616,7 @@ template <int R>
 __device__ __forceinline__ int x6_slot(int n) { return (n & 3) * (R / 4) + (((n >> 2) + 4 * (n & 3)) & (R / 4 - 1)); }
 __device__ __forceinline__ float comp4(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
-template <int AMODE, int BMODE, int CFG>
+template <int AMODE, int BMODE, int CFG, int EPI>
 __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) {
     using C = X6Cfg<CFG>;
     constexpr int BK = X6_BK, BMX = C::BMX, BNX = C::BNX, TM = C::TM, TN = C::TN;
@@ -857,6 +863,12 @@ __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) 
             if (n < g.N) *reinterpret_cast<float4*>(g.bsum_part + (long)split * g.N + n) = t;
         }
     }
+    if constexpr (EPI == EPI_MAXPOOL) {             // stride-1 conv + max_pool_with_argmax (models/adapt.py:115-117), 128 x 128 tile only
+        static_assert(CFG == 0, "the max-pool epilogue is written for 2 x 2 waves of 64 x 64");
+        __syncthreads();                            // every wave is done with the LDS images
+        maxpool_epilogue(g, acc, reinterpret_cast<float*>(smem), tile_m, m0, n0, wm, wn, l31, lk);
+        return;
+    }
     // Epilogue.  C/D layout of a 32x32 MFMA (any input type): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
     float* out = g.splits > 1 ? g.partial + (long)split * g.M * g.N : g.C;
     const long ldo = g.splits > 1 ? g.N : g.ldc;
@@ -880,10 +892,10 @@ __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) 
         }
 }
 
-template <int AMODE, int BMODE, int CFG>
+template <int AMODE, int BMODE, int CFG, int EPI = EPI_STORE>
 __global__ __launch_bounds__(X6Cfg<CFG>::WMC * X6Cfg<CFG>::WNC * 64, CFG == 0 ? 2 : 1) void gemm_x6_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[x6_lds(CFG)];
-    x6_body<AMODE, BMODE, CFG>(g, smem);
+    x6_body<AMODE, BMODE, CFG, EPI>(g, smem);
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, const float* __restrict__ bias,
@@ -1483,6 +1495,10 @@ ams_status ams_front_maxpool_fwd(const float* x, const float* f, float* y, long 
             if (pb > 4096) pb = 4096;
             hipLaunchKernelGGL(pad_rows_kernel, dim3(pb), dim3(256), 0, st, x, xp, Bt, L, Lp, pl);
             g.A = xp; g.fr_L = Lp; g.fr_pl = 0; g.a_vec = 1;
+            if (use_x6()) {
+                g.k_per_split = ceil_div(W, X6_BK) * X6_BK;
+                hipLaunchKernelGGL((gemm_x6_kernel<A_FRAMES, B_ROW, 0, EPI_MAXPOOL>), grid, dim3(256), 0, st, g);
+            } else
             hipLaunchKernelGGL((gemm_f32_kernel<A_FRAMES, B_ROW, EPI_MAXPOOL, AMS_GEMM_BK, true>), grid, dim3(256), 0, st, g);
         } else
         hipLaunchKernelGGL((gemm_f32_kernel<A_FRAMES, B_ROW, EPI_MAXPOOL>), grid, dim3(256), 0, st, g);
