@@ -267,6 +267,19 @@ def persist_errors():
     return sum(int(t[:1].view(torch.int32).item() != 0) for t in LAST_SYNC)
 
 
+def raise_on_ring_errors():
+    """Fail loudly when a ring-recurrence launch gave up a bounded in-launch wait (csrc/lstm_ring.hip: its workgroups must all be
+    resident at once; a co-running kernel that fills every CU's registers can keep some of them out past the wait limit).  The
+    step that launch belonged to is invalid.  One host sync; the trainer calls it where it fetches the cost anyway."""
+    if not LAST_SYNC:
+        return
+    flags = torch.stack([t[:1].view(torch.int32).reshape(()) for t in LAST_SYNC])
+    if bool((flags != 0).any().item()):
+        raise AmsError('a BLSTM ring recurrence launch abandoned a bounded wait: its workgroups were not all resident in time '
+                       '(another kernel filled the CUs); the results of that step are invalid.  AMS_LSTM_RING=0 selects the '
+                       'per-step recurrence kernels, which need no co-residency.')
+
+
 def blstm_fwd(x, Kf, bf, Kb, bb, consumer=None):
     """One BLSTM layer (utils/ops.py:358-383).  x [B,T,D]; K* [D+H,4H]; b* [4H].
     Returns out [B,T,2H] and the tensors the backward needs (G = activated gates, cst = cell states).

@@ -29,7 +29,7 @@ std::atomic<int> g_gemm_arith{-1};        // -1: not chosen yet (AMS_GEMM_X6, de
 struct GemmTuning { int group_m, splits, x6cfg, x6rule; bool noprio, novec; };
 inline const GemmTuning& tuning() {
     static const GemmTuning t = [] {
-        GemmTuning v{0, 0, -1, 1, false, false};
+        GemmTuning v{0, 0, -1, 2, false, false};
         if (const char* f = getenv("AMS_GEMM_GROUP_M")) v.group_m = atoi(f);
         if (const char* f = getenv("AMS_GEMM_SPLITS")) v.splits = atoi(f);
         v.noprio = getenv("AMS_GEMM_NOPRIO") != nullptr;
@@ -616,7 +616,7 @@ template <int R>
 __device__ __forceinline__ int x6_slot(int n) { return (n & 3) * (R / 4) + (((n >> 2) + 4 * (n & 3)) & (R / 4 - 1)); }
 __device__ __forceinline__ float comp4(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
-template <int AMODE, int BMODE, int CFG, int EPI>
+template <int AMODE, int BMODE, int CFG, int EPI, bool SEP>
 __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) {
     using C = X6Cfg<CFG>;
     constexpr int BK = X6_BK, BMX = C::BMX, BNX = C::BNX, TM = C::TM, TN = C::TN;
@@ -640,13 +640,19 @@ __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) 
     const int k_end = min(g.K, k_begin + g.k_per_split);
     const int nk = (k_end - k_begin + BK - 1) / BK;
 
-    f32x16 acc[TM][TN];
+    // SEP: two accumulator sets (64 x 64 waves, launches that are not residency-capped -- with 64 more VGPRs a workgroup no longer
+    // shares a CU with a recurrence ring): hi.hi goes to `acc`, the five small partial products to `accs`, added once in the epilogue.  The bf16 MFMA adds its 16 products to the accumulator with the bits below its internal
+    // guard bits TRUNCATED (two's complement, i.e. toward -inf) at a level set by the largest addend: a bias of ~1e-3 ulp of the
+    // accumulator per MFMA, -0.3 .. -1 ulp per output when all six products go into one accumulator (measured, K = 600 .. 5120;
+    // the f32 MFMA rounds to nearest: 0.00).  Small products into their own accumulator are truncated 2^-8 lower: 6x less bias.
+    static_assert(!SEP || TM * TN <= 4, "no registers for a second accumulator set on 128 x 64 waves");
+    f32x16 acc[TM][TN], accs[SEP ? TM : 1][SEP ? TN : 1];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; if (SEP) accs[i][j][r] = 0.f; }
 
     // Operand of R rows, NT threads.  k-contiguous source: slot = (row, k-group of 8), R * 4 slots, thread -> rows (tid >> 2) + (NT / 4) h,
     // k-group tid & 3, two float4 per slot.  m/n-contiguous source: 4 (k) x 4 (m) blocks, R / 4 x 8 of them, thread -> block
@@ -829,7 +835,10 @@ __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) 
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {
                             if (AMS_X6_DBG & 4) { asm volatile("" :: "v"(a[i][PA[t]]), "v"(b[j][PB[t]])); continue; }
-                            acc[ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[ip + i][j], 0, 0, 0);
+                            if (SEP && t < 5)
+                                accs[ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], accs[ip + i][j], 0, 0, 0);
+                            else
+                                acc[ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[ip + i][j], 0, 0, 0);
                         }
             }
         }
@@ -863,6 +872,12 @@ __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) 
             if (n < g.N) *reinterpret_cast<float4*>(g.bsum_part + (long)split * g.N + n) = t;
         }
     }
+    if (SEP) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] += accs[i][j];
+    }
     if constexpr (EPI == EPI_MAXPOOL) {             // stride-1 conv + max_pool_with_argmax (models/adapt.py:115-117), 128 x 128 tile only
         static_assert(CFG == 0, "the max-pool epilogue is written for 2 x 2 waves of 64 x 64");
         __syncthreads();                            // every wave is done with the LDS images
@@ -892,10 +907,10 @@ __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) 
         }
 }
 
-template <int AMODE, int BMODE, int CFG, int EPI = EPI_STORE>
+template <int AMODE, int BMODE, int CFG, int EPI = EPI_STORE, bool SEP = false>
 __global__ __launch_bounds__(X6Cfg<CFG>::WMC * X6Cfg<CFG>::WNC * 64, CFG == 0 ? 2 : 1) void gemm_x6_kernel(GemmArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[x6_lds(CFG)];
-    x6_body<AMODE, BMODE, CFG, EPI>(g, smem);
+    x6_body<AMODE, BMODE, CFG, EPI, SEP>(g, smem);
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, const float* __restrict__ bias,
@@ -961,17 +976,20 @@ __global__ void bsum_finish_kernel(const float* __restrict__ part, float* __rest
 // barrier stalls are not covered by a neighbour's MFMAs; the last term is the fp32 partial-slab round trip.
 struct TilePlan { int bm, bn, bk; double us16; };     // block tile and the cost of 16 k of it for one workgroup (microseconds)
 inline TilePlan f32_plan() { return {BM, BN, BK, 1.024}; }
-// bf16x6 tile configuration (X6Cfg) of an M x N output: 256-wide tiles where they waste under 10 % of the rows / columns they
-// cover.  A residency-capped launch (one meant to run beside a recurrence ring) never takes the 256 x 256 tile: its 8 waves x 256
-// VGPRs leave no room for a ring workgroup on the CU.  AMS_GEMM_X6RULE (A/B runs): 0 = {256x256, 128x128} only, 1 = + 128x256,
-// 2 = + 256x128.
+// bf16x6 tile configuration (X6Cfg) of an M x N output.  Default (rule 2): 128 x 256 (8 waves of 64 x 64) where it wastes under
+// 10 % of the columns it covers, 128 x 128 otherwise -- both carry the second accumulator set (SEP) when they are not
+// residency-capped.  Rule 1 (AMS_GEMM_X6RULE=1) adds the 256 x 256 tile (8 waves of 128 x 64) where both sides fit: +0.7 % on the
+// step (projections 107 vs 121 us), but no registers for SEP -- its outputs carry the bf16 MFMA's truncation bias (-0.3 .. -1 ulp
+// each, coherent: the LSTM bias gradients, sums over 5120 rows downstream of it, were 1.2e-5 off the oracle instead of < 1e-6), so
+// it is not the default.  A residency-capped launch never takes it (8 waves x 256 VGPRs leave no room for a ring workgroup).
+// Rule 0: {256 x 256, 128 x 128} only.  (256 x 128 was measured too -- profiles/r02_i_gemm_x6_tile_configs.txt -- and lost to
+// 128 x 128 on every shape it suits.)
 inline int x6_choose_cfg(int M, int N, bool capped) {
-    if (tuning().x6cfg >= 0 && tuning().x6cfg <= 3) return tuning().x6cfg;
+    if (tuning().x6cfg == 0 || tuning().x6cfg == 1 || tuning().x6cfg == 3) return tuning().x6cfg;
     const bool m256 = (double)ceil_div(M, 256) * 256 <= 1.10 * M, n256 = (double)ceil_div(N, 256) * 256 <= 1.10 * N;
     const int rule = tuning().x6rule;
-    if (m256 && n256 && !capped) return 1;
+    if (m256 && n256 && !capped && rule <= 1) return 1;
     if (n256 && rule >= 1) return 3;
-    if (m256 && rule >= 2) return 2;
     return 0;
 }
 inline TilePlan x6_plan(int cfg) {
@@ -1074,10 +1092,11 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
                     raised_x = pad;
                 }
             }
-            hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 0>), grid, dim3(256), (size_t)pad, st, g);
+            if (t_gemm_lds_pad > 0) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 0>), grid, dim3(256), (size_t)pad, st, g);
+            else hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 0, EPI_STORE, true>), grid, dim3(256), 0, st, g);
         } else if (cfg == 1) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 1>), grid, dim3(512), 0, st, g);
-        else if (cfg == 2) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 2>), grid, dim3(512), 0, st, g);
-        else hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 3>), grid, dim3(512), 0, st, g);
+        else if (t_gemm_lds_pad > 0) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 3>), grid, dim3(512), 0, st, g);
+        else hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 3, EPI_STORE, true>), grid, dim3(512), 0, st, g);
     } else if (vec) {
         if (t_gemm_lds_pad > 40 * 1024) {
             static thread_local int raised_v = 0;
@@ -1497,7 +1516,7 @@ ams_status ams_front_maxpool_fwd(const float* x, const float* f, float* y, long 
             g.A = xp; g.fr_L = Lp; g.fr_pl = 0; g.a_vec = 1;
             if (use_x6()) {
                 g.k_per_split = ceil_div(W, X6_BK) * X6_BK;
-                hipLaunchKernelGGL((gemm_x6_kernel<A_FRAMES, B_ROW, 0, EPI_MAXPOOL>), grid, dim3(256), 0, st, g);
+                hipLaunchKernelGGL((gemm_x6_kernel<A_FRAMES, B_ROW, 0, EPI_MAXPOOL, true>), grid, dim3(256), 0, st, g);
             } else
             hipLaunchKernelGGL((gemm_f32_kernel<A_FRAMES, B_ROW, EPI_MAXPOOL, AMS_GEMM_BK, true>), grid, dim3(256), 0, st, g);
         } else

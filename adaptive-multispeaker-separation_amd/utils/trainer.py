@@ -16,6 +16,7 @@ import time
 import numpy as np
 import torch
 
+from ams_hip import ops
 from ams_hip.dist import Dist
 from ams_hip.graph import Graph
 from data.dataset import TFDataset
@@ -266,6 +267,7 @@ class Trainer(object):
                         self._say('Validation set tested in ', time.time() - t, ' seconds')
                         self._say('Validation set: ', mean)
                     c = float(c)                   # host sync, as sess.run returning the cost does
+                    ops.raise_on_ring_errors()     # a ring launch that timed out must not train on silently
                     window = window[1:] + [time.time() - mark]
                     avg = sum(window) / len(window)
                     self._say('Epoch #', epoch + 1, '/', epochs, ' Batch #', b + 1, '/', n_train, 'in', avg, 'sec loss=', c,

@@ -70,6 +70,7 @@ def test_blstm_layer_at_benchmark_shape(ops, monkeypatch, D, ring):
     assert e_fwd < FWD_TOL, errs
     assert max(v for k, v in errs.items() if k != 'out') < BWD_TOL, errs
     assert ops.persist_errors() == 0
+    ops.raise_on_ring_errors()
 
 
 def test_dense_l2norm_dpcl_at_benchmark_shape(ops):
@@ -150,11 +151,23 @@ def test_kmeans_hard_at_benchmark_shape(ops):
     assert np.array_equal(lab.cpu().numpy(), lab_ref)
 
 
-@pytest.mark.parametrize('hip_graph', [False, True])
-def test_front_dpcl_step_at_benchmark_shape(hip_graph):
+@pytest.fixture()
+def gemm_arith():
+    """Switch the arithmetic of the dense products for one test (csrc/gemm.hip: 1 = bf16x6, the default; 0 = native f32 MFMA)."""
+    from ams_hip._lib import load
+    lib = load()
+    before = lib.ams_gemm_get_arith()
+    yield lib.ams_gemm_set_arith
+    lib.ams_gemm_set_arith(before)
+
+
+@pytest.mark.parametrize('hip_graph,arith', [(False, 1), (True, 1), (False, 0)])
+def test_front_dpcl_step_at_benchmark_shape(hip_graph, arith, gemm_arith):
     """The step bench.py times -- front_DPCL, B=64, full geometry -- against the float64 oracle: cost, every gradient, every
-    updated weight after AMSGrad; eager and as the replayed hipGraph (3rd call = first replay)."""
+    updated weight after AMSGrad; eager and as the replayed hipGraph (3rd call = first replay), with the default bf16x6 products
+    and, eager, with the native f32 MFMA products: the SAME tolerances hold for both arithmetics."""
     from tests.smoke_step import build_front_dpcl
+    gemm_arith(arith)
     tmp = tempfile.mkdtemp(prefix='ams_benchshape_')
     trainer, tfds = build_front_dpcl(tmp, B=B, L=L, W=W, N=N, hop=HOP, layer_size=LS, nb_layers=NL, E=E, no_summaries=True,
                                      hip_graph=hip_graph)
@@ -192,7 +205,7 @@ def test_front_dpcl_step_at_benchmark_shape(hip_graph):
     for n, p in zip(names, plist):
         errs['update ' + n] = rel(P_new[n], p)
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
-    print('front_DPCL B=64 step (hip_graph=%s): cost %.6f oracle %.6f; worst' % (hip_graph, cost, c_ref), worst)
+    print('front_DPCL B=64 step (hip_graph=%s, arith=%d): cost %.6f oracle %.6f; worst' % (hip_graph, arith, cost, c_ref), worst)
     assert errs['cost'] < FWD_TOL, worst
     assert max(v for k, v in errs.items() if k.startswith('grad ')) < BWD_TOL, worst
     assert max(v for k, v in errs.items() if k.startswith('update ')) < 1e-5, worst
@@ -202,7 +215,11 @@ def test_ring_recurrence_is_bit_stable_under_uneven_load(ops):
     """The in-launch hand-off of csrc/lstm_ring.hip (plain stores through the chain's L2 + L1-bypassing loads, tags / flags) must
     not depend on what else the chip is doing: a stale or torn read would change bits.  One BLSTM layer at the benchmark shape,
     forward + BPTT, 12 times while a second stream keeps the CUs busy with large products (uneven: the load starts and stops at
-    random points of the recurrence) -- every repetition must reproduce the idle run bit for bit, and no bounded wait may time out."""
+    random points of the recurrence) -- every repetition must reproduce the idle run bit for bit, and no bounded wait may time out.
+    The side products are launched the way the product launches EVERYTHING that runs beside a ring (ams_hip/functional.py: side
+    stream, residency cap): a ring needs all its workgroups resident at once, and an uncapped bf16x6 product (8 waves x ~230
+    VGPRs, one workgroup per CU) admits no ring workgroup on a CU it occupies -- with several of those queued the ring's bounded
+    wait CAN run out (observed: error word set, garbage output; ops.raise_on_ring_errors() is what the trainer calls)."""
     D = 256
     rng = np.random.RandomState(11)
     lim = np.sqrt(6.0 / (D + 5 * H))
@@ -211,6 +228,8 @@ def test_ring_recurrence_is_bit_stable_under_uneven_load(ops):
     bf, bb = dev(rng.randn(4 * H) * 0.1), dev(rng.randn(4 * H) * 0.1)
     dout = dev(rng.randn(B, T, 2 * H) * 0.1)
     assert ops.LSTM_RING == '1'
+    from ams_hip._lib import load
+    lib = load()
 
     def layer():
         out, G, cst = ops.blstm_fwd(x, Kf, bf, Kb, bb)
@@ -224,16 +243,17 @@ def test_ring_recurrence_is_bit_stable_under_uneven_load(ops):
     gen = np.random.RandomState(3)
     for rep in range(12):
         n_before, n_during = int(gen.randint(0, 3)), int(gen.randint(1, 6))
-        with torch.cuda.stream(side):
-            for _ in range(n_before):
-                ops.gemm(a, bmat)
-        got = None
-        with torch.cuda.stream(side):
-            for _ in range(n_during):
-                ops.gemm(a, bmat)
+        lib.ams_gemm_set_lds_pad(50000)                 # the product's residency cap for launches beside a ring
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(n_before + n_during):
+                    ops.gemm(a, bmat)
+        finally:
+            lib.ams_gemm_set_lds_pad(0)
         got = layer()
         torch.cuda.synchronize()
         for i, (g, r) in enumerate(zip(got, ref)):
             assert torch.equal(g, r), ('repetition %d: tensor %d differs from the idle run (max |diff| %.3e, ring error word %d)'
                                        % (rep, i, float((g - r).abs().max()), ops.persist_errors()))
     assert ops.persist_errors() == 0
+    ops.raise_on_ring_errors()
