@@ -1395,10 +1395,22 @@ __global__ __launch_bounds__(256) void gather_filter_grad_kernel(const float* __
         const float* xr = x + (long)r * L;
         const int32_t* pr = pos + ((long)(r / rdiv) * T) * N + n;
         const float* vr = v + ((long)r * T) * N + n;
-        for (int t = 0; t < T; ++t) {
-            const int p = pr[(long)t * N] + k - pl;
-            const float val = vr[(long)t * N];
-            if (p >= 0 && p < L) s += xr[p] * val;
+        // eight (position, value) pairs and their eight window samples in flight per round: the loop was one dependent chain of
+        // scalar load -> vector load -> FMA per iteration (~1.5 us each, 3.1 ms per launch at the path-B shape); same summation order
+        for (int t = 0; t < T; t += 8) {
+            int p[8];
+            float val[8], xv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int tt = min(t + u, T - 1);
+                p[u] = pr[(long)tt * N] + k - pl;
+                val[u] = vr[(long)tt * N];
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) xv[u] = xr[min(max(p[u], 0), L - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (t + u < T && p[u] >= 0 && p[u] < L) s += xv[u] * val[u];
         }
     }
     if (k < W) part[((long)blockIdx.z * W + k) * N + n] = s;
@@ -1429,7 +1441,7 @@ __global__ __launch_bounds__(256) void synth_unpool_kernel(const float* __restri
         for (int n = 0; n < N; ++n) {
             const int k = l - am[(long)t * N + n] + pl;                 // uniform offset: consecutive l -> consecutive k
             if (k >= 0 && k < W) s += vr[(long)t * N + n] * f2t[(long)n * W + k];
-        }
+        }                                                               // (eight filters per round, unconditional loads: 1.68 -> 2.17 ms)
     if (l < L) out[(long)r * L + l] = s;
 }
 
@@ -1447,9 +1459,11 @@ __global__ __launch_bounds__(256) void synth_unpool_bwd_vals_kernel(const float*
         const float* dr = dout + (long)r * L;
         const float* fr = f2t + (long)n * W;
         float s = 0.f;
+#pragma unroll 4
         for (int k = lane; k < W; k += 64) {
             const int p = p0 + k;
-            if (p >= 0 && p < L) s += dr[p] * fr[k];
+            const float dv = dr[min(max(p, 0), L - 1)], fv = fr[k];     // unconditional loads: four rounds in flight
+            if (p >= 0 && p < L) s += dv * fv;
         }
         s = wave_sum(s);
         if (lane == 0) dvals[i] = s;
