@@ -573,9 +573,10 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
 // wave-specialised form (4 MFMA waves + 4 split waves, two LDS buffers) was slower: a split wave progresses ~2 VALU instructions
 // per MFMA of its SIMD partner (phase trace: 1.6 us per tile for ~220 instructions); (c) a fused stream (one wave = MFMA + one
 // slice of the next tile's split per MFMA, hand-laid behind sched_barrier fences, 1 wave per SIMD) measured the same as the plain
-// form (873 us; its MFMA-only stream 426 us, its split-only stream 567 us).  Both forms are in the history (commits "wave-
-// specialised" / "fused-stream").  What does help is LESS split work per MFMA: a 256 x 256 tile splits each element once for
-// twice as many MFMAs -- hence the tile configurations below.
+// form (873 us; its MFMA-only stream 426 us, its split-only stream 567 us).  Both forms are in the history (commits 810b95b,
+// 232c519).  The kernel draws the board's power limit (1385-1393 W at 2135 MHz; its MFMA-only stream 1050 W at 2400 MHz) and gains
+// 0-4 % with the split arithmetic compiled out: at that limit its run time is the energy of a product, not its instruction schedule
+// (DESIGN.md 4.0).
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
