@@ -65,6 +65,9 @@ constexpr int X6_BK = 32;           // k-tile of the bf16x6 kernel
 #ifndef AMS_GEMM_X6_US16
 #define AMS_GEMM_X6_US16 0.84
 #endif
+#ifndef AMS_X6_OCC1
+#define AMS_X6_OCC1 1
+#endif
 #ifndef AMS_GEMM_X6_US16_2
 #define AMS_GEMM_X6_US16_2 1.35
 #endif
@@ -589,11 +592,10 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 template <int CFG> struct X6Cfg;
 template <> struct X6Cfg<0> { static constexpr int BMX = 128, BNX = 128, WMC = 2, WNC = 2, TM = 2, TN = 2; };   // 4 waves, 48.75 KB
 template <> struct X6Cfg<1> { static constexpr int BMX = 256, BNX = 256, WMC = 2, WNC = 4, TM = 4, TN = 2; };   // 8 waves, 96.75 KB
-template <> struct X6Cfg<2> { static constexpr int BMX = 256, BNX = 128, WMC = 4, WNC = 2, TM = 2, TN = 2; };   // 8 waves, 72.75 KB
 template <> struct X6Cfg<3> { static constexpr int BMX = 128, BNX = 256, WMC = 2, WNC = 4, TM = 2, TN = 2; };   // 8 waves, 72.75 KB
 constexpr int x6_plane(int rows) { return rows * 16 + 32; }     // bytes; +32: the four planes start 8 banks apart (16-byte row writes of one wave hit all four)
 constexpr int x6_oper(int rows) { return 3 * 4 * x6_plane(rows); }
-constexpr int x6_bm(int cfg) { return (cfg == 1 || cfg == 2) ? 256 : 128; }
+constexpr int x6_bm(int cfg) { return cfg == 1 ? 256 : 128; }
 constexpr int x6_bn(int cfg) { return (cfg == 1 || cfg == 3) ? 256 : 128; }
 constexpr int x6_lds(int cfg) { return x6_oper(x6_bm(cfg)) + x6_oper(x6_bn(cfg)); }
 
@@ -975,8 +977,8 @@ __global__ void bsum_finish_kernel(const float* __restrict__ part, float* __rest
 // n = ceil(tiles*s/256) workgroups end up on the busiest CU (equal-work workgroups time-share a CU's four
 // SIMDs, so the launch ends when that CU drains); occ(n) discounts CUs holding only 1-3 workgroups, whose
 // barrier stalls are not covered by a neighbour's MFMAs; the last term is the fp32 partial-slab round trip.
-struct TilePlan { int bm, bn, bk; double us16; };     // block tile and the cost of 16 k of it for one workgroup (microseconds)
-inline TilePlan f32_plan() { return {BM, BN, BK, 1.024}; }
+struct TilePlan { int bm, bn, bk; double us16; bool alone; };   // block tile, the cost of 16 k of it for one workgroup (microseconds), one workgroup per CU by construction
+inline TilePlan f32_plan() { return {BM, BN, BK, 1.024, false}; }
 // bf16x6 tile configuration (X6Cfg) of an M x N output.  Default (rule 2): 128 x 256 (8 waves of 64 x 64) where it wastes under
 // 10 % of the columns it covers, 128 x 128 otherwise -- both carry the second accumulator set (SEP) when they are not
 // residency-capped.  Rule 1 (AMS_GEMM_X6RULE=1) adds the 256 x 256 tile (8 waves of 128 x 64) where both sides fit: +0.7 % on the
@@ -994,7 +996,7 @@ inline int x6_choose_cfg(int M, int N, bool capped) {
     return 0;
 }
 inline TilePlan x6_plan(int cfg) {
-    return {x6_bm(cfg), x6_bn(cfg), X6_BK, cfg == 1 ? AMS_GEMM_X6_US16_1 : cfg == 0 ? AMS_GEMM_X6_US16 : AMS_GEMM_X6_US16_2};
+    return {x6_bm(cfg), x6_bn(cfg), X6_BK, cfg == 1 ? AMS_GEMM_X6_US16_1 : cfg == 0 ? AMS_GEMM_X6_US16 : AMS_GEMM_X6_US16_2, cfg != 0 && AMS_X6_OCC1};
 }
 inline int choose_splits(int M, int N, int K, int nbatch, const TilePlan& tp) {
     const int tiles = ceil_div(M, tp.bm) * ceil_div(N, tp.bn) * nbatch;
@@ -1005,7 +1007,8 @@ inline int choose_splits(int M, int N, int K, int nbatch, const TilePlan& tp) {
         const int kps = ceil_div(ceil_div(K, s), tp.bk) * tp.bk;
         const int s2 = ceil_div(K, kps);
         const int n = ceil_div((long)tiles * s2, 256);
-        const double occ = n <= 1 ? 0.62 : (n == 2 ? 0.80 : (n == 3 ? 0.92 : 1.0));
+        // an 8-wave configuration is alone on its CU whatever the grid: no discount for few workgroups per CU
+        const double occ = tp.alone ? 1.0 : n <= 1 ? 0.62 : (n == 2 ? 0.80 : (n == 3 ? 0.92 : 1.0));
         double t = n * ((kps / 16.0) * tp.us16 + 5.0) / occ;
         if (s2 > 1) t += (double)(s2 + 1) * M * N * nbatch * 4.0 / 2.5e6;
         if (t < best_t - 1e-9) { best_t = t; best = s2; }
