@@ -165,6 +165,7 @@ def main():
         torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
         ops.PROFILE.enabled = False
+        ops.raise_on_ring_errors()                       # a ring launch that gave up a bounded wait would make this number meaningless
         last_cost = float(c)
         prof_steps = args.steps
         if args.graph:
