@@ -30,6 +30,22 @@ def test_ops_refuse_cpu_tensors():
         ops.front_filter(torch.zeros(4), torch.zeros(4, 2))
 
 
+def test_ring_timeout_is_loud(monkeypatch):
+    """A ring-recurrence launch that gave up a bounded wait leaves a non-zero word 0 in its sync buffer (csrc/lstm_ring.hip); the
+    trainer and bench.py call ops.raise_on_ring_errors() at their host sync, so such a step cannot be trained on or timed silently."""
+    torch = pytest.importorskip('torch')
+    from ams_hip import ops, AmsError
+    ok, bad = torch.zeros(8), torch.zeros(8)
+    bad.view(torch.int32)[0] = 1
+    monkeypatch.setattr(ops, 'LAST_SYNC', [ok, ok])
+    ops.raise_on_ring_errors()
+    assert ops.persist_errors() == 0
+    monkeypatch.setattr(ops, 'LAST_SYNC', [ok, bad])
+    assert ops.persist_errors() == 1
+    with pytest.raises(AmsError):
+        ops.raise_on_ring_errors()
+
+
 def test_bss_library_exports_declared_symbols():
     """include/ams_bss.h: every declared entry point is exported (no compute call without a GPU)."""
     import re
