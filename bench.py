@@ -129,8 +129,31 @@ def cpu_baseline(args):
                       % (B, args.cpu_steps, t)}
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher in the environment: re-exec this very command line under
+    torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1).  Rank 0's single JSON line is the only thing on stdout."""
+    import subprocess
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        raise SystemExit(spawn_ranks(args))
     import torch
     from ams_hip import ops
     tmp = tempfile.mkdtemp(prefix='ams_bench_')
@@ -139,8 +162,9 @@ def main():
         trainer, tfds, dist = build(args, tmp)
     model, g = trainer.model, trainer.graph
     rank, world = dist.rank, dist.world_size
-    if args.gpus != world and rank == 0 and not args.quiet:
-        print('note: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N>1)' % (args.gpus, world), file=sys.stderr)
+    if args.gpus != world:
+        raise SystemExit('bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks -- the reported n_gpus would not be '
+                         'the requested one' % (args.gpus, world))
 
     with g.as_default():
         feed = {tfds.handle: tfds.get_handle(tfds.TRAIN), tfds.chunk_size: args.chunk}

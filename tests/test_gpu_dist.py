@@ -89,3 +89,30 @@ def test_two_ranks_on_one_gpu_match_single_process(hip_graph):
     for n in p_one:
         d = np.abs(p0[n] - p_one[n]).max()
         assert d <= 1e-5 * max(1.0, np.abs(p_one[n]).max()), (n, d)
+
+
+def test_bench_spawns_the_ranks_it_is_asked_for():
+    """`python bench.py --gpus 2` with no launcher in the environment must START two ranks (self re-exec under
+    torch.distributed.run) and report n_gpus == 2 -- on the one-GPU box both ranks share cuda:0 over gloo.  A reduced geometry of the
+    same step (batch 4 per rank, 4096-sample chunks): this checks the plumbing the driver's scaling run depends on, not a number."""
+    import json
+    import subprocess
+    env = dict(os.environ, AMS_DIST_BACKEND='gloo', HSA_ENABLE_IPC_MODE_LEGACY='0')
+    for k in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '4',
+                        '--chunk', '4096', '--no-cpu-baseline', '--no-secondary', '--no-native-f32', '--roofline-steps', '0', '--quiet'],
+                       env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, r.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert j['n_gpus'] == 2 and j['steps'] == 3 and j['warmup'] == 1
+    assert j['config']['global_batch'] == 8 and j['config']['parallelism'] == 'dp2'
+    assert j['value'] > 0 and np.isfinite(j['final_cost'])
+    # a launcher that started a different number of ranks than --gpus is an error, not a silently wrong n_gpus
+    env1 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--batch', '4',
+                        '--chunk', '4096', '--no-cpu-baseline', '--no-secondary', '--no-native-f32', '--roofline-steps', '0', '--quiet'],
+                       env=env1, capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in (r.stderr + r.stdout)
