@@ -614,44 +614,69 @@ def pretrain_separator(y, B, S, separation):
     return PretrainSeparator.apply(_c(y), B, S, separation)
 
 
+class SumSq(Function):
+    """sum x^2 -> [1]  (tf.nn.l2_loss = sum x^2 / 2, adapt.py:312); backward 2 x g on the device (ams_sumsq_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        ctx.save_for_backward(x)
+        return ops.sumsq(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.sumsq_bwd(x, _c(g).reshape(1), 1.0, 0)
+
+
 def sumsq(x):
-    return ops.sumsq(_c(x)) if not x.requires_grad else (x * x).sum().reshape(1)
+    return SumSq.apply(x) if x.requires_grad else ops.sumsq(_c(x))
+
+
+class NegativeEnergy(Function):
+    """mean_b sum_{t,n} min(y, 0)^2 -> [1]  (tf.square(tf.where(front < 0, front, 0)), adapt.py:314-316)."""
+
+    @staticmethod
+    def forward(ctx, y):
+        y = _c(y)
+        ctx.save_for_backward(y)
+        return ops.negative_energy_fwd(y.reshape(y.shape[0], -1))
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return ops.sumsq_bwd(y, _c(g).reshape(1), 1.0 / y.shape[0], 1)
 
 
 def negative_energy(y):
-    neg = torch.where(y < 0, y, torch.zeros_like(y)) ** 2
-    return neg.reshape(neg.shape[0], -1).sum(dim=1).mean()
+    return NegativeEnergy.apply(y).reshape(())
 
 
-def abs_colsum(y2):
-    return y2.abs().sum(dim=0)
+class SparseKL(Function):
+    """sum kl_div(p, p_hat), p_hat = sum_b |y|  (adapt.py:130-132, utils/ops.py:46-54).  Under data parallelism p_hat is a batch
+    SUM that enters a non-linear term: it is all-reduced before the KL, and the backward carries `world` because the gradient
+    exchange averages per-rank gradients (tests/test_dist_gloo.py::test_sparsity_term_gradient_matches_single_process)."""
+
+    @staticmethod
+    def forward(ctx, y2, p, dist):
+        y2 = _c(y2)
+        p_hat = ops.abs_colsum(y2)
+        world = 1.0
+        if dist is not None and getattr(dist, 'enabled', False):
+            dist.all_reduce_sum(p_hat)
+            world = float(dist.world_size)
+        ctx.save_for_backward(y2, p_hat)
+        ctx.p, ctx.world = float(p), world
+        return ops.kl_sparsity_fwd(p_hat, p)
+
+    @staticmethod
+    def backward(ctx, g):
+        y2, p_hat = ctx.saved_tensors
+        return ops.kl_sparsity_bwd(y2, p_hat, _c(g).reshape(1), ctx.p, ctx.world), None, None
 
 
-def kl_sparsity(p_hat, p):
-    def logfunc(a, b):
-        return a * torch.log(torch.clamp(a, 1e-10, 1.0) / torch.clamp(b, 1e-10, 1.0))
-    pt = torch.full((), float(p), dtype=p_hat.dtype, device=p_hat.device)      # fill kernel, capturable
-    return (logfunc(pt, p_hat) + logfunc(1 - pt, 1 - p_hat)).sum()
-
-
-def all_reduce_sum_autograd(t, dist):
-    """SUM over ranks of a batch statistic that feeds a NON-mean loss term (p_hat -> KL, adapt.py:130-132).  Every rank
-    holds the same global term; rank r's backward carries d term / d (its own shard), and FlatOptimizer.exchange then averages
-    the per-rank gradients (sum x 1/world) -- right for the batch-MEAN terms, world x too small for this one -- so the incoming
-    gradient is scaled by world here (tests/test_dist_gloo.py::test_sparsity_term_gradient_matches_single_process)."""
-    world = float(getattr(dist, 'world_size', 1)) if getattr(dist, 'enabled', False) else 1.0
-
-    class _AR(Function):
-        @staticmethod
-        def forward(ctx, x):
-            y = x.clone()
-            dist.all_reduce_sum(y)
-            return y
-
-        @staticmethod
-        def backward(ctx, g):
-            return g * world if world != 1.0 else g
-    return _AR.apply(t)
+def sparse_kl(y2, p, dist=None):
+    return SparseKL.apply(y2, p, dist).reshape(())
 
 
 class ApplyMasks(Function):

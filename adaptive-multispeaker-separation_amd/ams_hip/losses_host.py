@@ -11,12 +11,10 @@ from .graph import Node, get_default_graph, get_scope_variable
 
 def sparse_constraint(y, p, dist=None):
     """adapt.py:130-132 + utils/ops.py:46-54.  p_hat is a batch SUM fed to a non-linear KL, so under data
-    parallelism it is all-reduced before the KL."""
+    parallelism it is all-reduced before the KL.  |.| column sum, KL and their backward are HIP kernels
+    (csrc/preproc.hip: ams_abs_colsum_fwd, ams_kl_sparsity_*)."""
     Bt = y.shape[0]
-    p_hat = F.abs_colsum(y.reshape(Bt, -1))
-    if dist is not None and dist.enabled:
-        p_hat = F.all_reduce_sum_autograd(p_hat, dist)
-    return F.kl_sparsity(p_hat, p)
+    return F.sparse_kl(y.reshape(Bt, -1), p, dist)
 
 
 def build_adapt_separator(m):

@@ -866,6 +866,53 @@ def sumsq(x):
     return out
 
 
+# ------------------------------------------------------------------ pre-training regularisers (adapt.py:127-132, 310-316)
+def abs_colsum(y2):
+    """p_hat[M] = sum over rows of |y2[Bt, M]|."""
+    _chk(y2)
+    Bt, M = y2.shape
+    lib = load()
+    nb = lib.ams_abs_colsum_workspace_bytes(Bt, M)
+    ws = _ws(nb, y2)
+    out = torch.empty(M, dtype=torch.float32, device=y2.device)
+    check(lib.ams_abs_colsum_fwd(_p(y2), _p(out), Bt, M, _p(ws), nb, _s()), 'ams_abs_colsum_fwd')
+    return out
+
+
+def kl_sparsity_fwd(p_hat, p):
+    _chk(p_hat)
+    out = torch.empty(1, dtype=torch.float32, device=p_hat.device)
+    ws = _ws(4096, p_hat)
+    check(load().ams_kl_sparsity_fwd(_p(p_hat), _p(out), p_hat.numel(), float(p), _p(ws), 4096, _s()), 'ams_kl_sparsity_fwd')
+    return out
+
+
+def kl_sparsity_bwd(y2, p_hat, upstream, p, gscale=1.0):
+    """d (sum kl_div(p, p_hat)) / d y2 through p_hat = sum_b |y2|, times the device scalar `upstream` and the host scalar gscale."""
+    _chk(y2, p_hat, upstream)
+    Bt, M = y2.shape
+    dy = torch.empty_like(y2)
+    check(load().ams_kl_sparsity_bwd(_p(y2), _p(p_hat), _p(upstream), float(gscale), _p(dy), Bt, M, float(p), 0, _s()), 'ams_kl_sparsity_bwd')
+    return dy
+
+
+def negative_energy_fwd(y2):
+    _chk(y2)
+    Bt, M = y2.shape
+    out = torch.empty(1, dtype=torch.float32, device=y2.device)
+    ws = _ws(4096, y2)
+    check(load().ams_negative_energy_fwd(_p(y2), _p(out), Bt, M, _p(ws), 4096, _s()), 'ams_negative_energy_fwd')
+    return out
+
+
+def sumsq_bwd(x, upstream, scale=1.0, mode=0):
+    """upstream[0] * scale * 2x (mode 0) or * 2 min(x, 0) (mode 1)."""
+    _chk(x, upstream)
+    dx = torch.empty_like(x)
+    check(load().ams_sumsq_bwd(_p(x), _p(upstream), float(scale), _p(dx), x.numel(), int(mode), 0, _s()), 'ams_sumsq_bwd')
+    return dx
+
+
 # ------------------------------------------------------------------ framed products / overlap-add (STFT, synthesis)
 def frames_matmul(x, Bm, hop, T, pad_left):
     """out[(r,t), n] = sum_k xpad[r, t*hop + k - pad_left] * Bm[k, n];  x [R,L], Bm [W,N] -> [R*T, N]."""

@@ -132,9 +132,165 @@ __global__ __launch_bounds__(256) void pretrain_sep_bwd_kernel(const float* __re
     }
 }
 
+
+// ---- default-on terms of the pre-training objective (reference models/adapt.py:127-132, 310-316, 377-384; CLI defaults
+// utils/trainer.py:151-161: beta = 1e-2, regularization = 1e-4) ------------------------------------------------------------------
+//
+// p_hat[m] = sum_b |y[b, m]|  (adapt.py:130-131), rows split over grid.y, partials added in row-slab order (deterministic).
+__global__ __launch_bounds__(256) void abs_colsum_part_kernel(const float* __restrict__ y, float* __restrict__ part, int Bt, long M,
+                                                              int rows_per) {
+    const long m = ((long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (m >= M) return;
+    const int r0 = blockIdx.y * rows_per, r1 = min(Bt, r0 + rows_per);
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (m + 3 < M && (M & 3) == 0) {
+        for (int r = r0; r < r1; ++r) {
+            const float4 v = *reinterpret_cast<const float4*>(y + (long)r * M + m);
+            s.x += fabsf(v.x); s.y += fabsf(v.y); s.z += fabsf(v.z); s.w += fabsf(v.w);
+        }
+        *reinterpret_cast<float4*>(part + (long)blockIdx.y * M + m) = s;
+    } else {
+        for (int j = 0; j < 4 && m + j < M; ++j) {
+            float t = 0.f;
+            for (int r = r0; r < r1; ++r) t += fabsf(y[(long)r * M + m + j]);
+            part[(long)blockIdx.y * M + m + j] = t;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, long M, int nslab) {
+    const long m = (long)blockIdx.x * 256 + threadIdx.x;
+    if (m >= M) return;
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += part[(long)k * M + m];
+    out[m] = s;
+}
+
+// kl_div(p, p_hat) = logfunc(p, p_hat) + logfunc(1 - p, 1 - p_hat), logfunc(a, b) = a * log(clip(a) / clip(b)), clip to [1e-10, 1]
+// (utils/ops.py:46-54).  tf.clip_by_value passes the gradient where 1e-10 <= b <= 1.
+__device__ __forceinline__ float clip01(float v) { return fminf(fmaxf(v, 1e-10f), 1.0f); }
+__device__ __forceinline__ float kl_term(float p, float ph) {
+    const float q = 1.0f - p, qh = 1.0f - ph;
+    return p * logf(clip01(p) / clip01(ph)) + q * logf(clip01(q) / clip01(qh));
+}
+__device__ __forceinline__ float kl_dph(float p, float ph) {       // d kl_term / d p_hat
+    const float q = 1.0f - p, qh = 1.0f - ph;
+    float g = 0.f;
+    if (ph >= 1e-10f && ph <= 1.0f) g -= p / ph;
+    if (qh >= 1e-10f && qh <= 1.0f) g += q / qh;
+    return g;
+}
+__global__ __launch_bounds__(256) void kl_part_kernel(const float* __restrict__ p_hat, float* __restrict__ part, long M, float p) {
+    __shared__ float sm[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < M; i += (long)gridDim.x * 256) s += kl_term(p, p_hat[i]);
+    s = blk_reduce(s, sm, 0);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void small_sum_kernel(const float* __restrict__ part, float* __restrict__ out, int n, float scale) {
+    __shared__ float sm[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+    s = blk_reduce(s, sm, 0);
+    if (threadIdx.x == 0) out[0] = s * scale;
+}
+// dy[b, m] (+)= up * gscale * sign(y[b, m]) * d kl / d p_hat[m]     (tf.abs' = sign, 0 at 0)
+__global__ __launch_bounds__(256) void kl_bwd_kernel(const float* __restrict__ y, const float* __restrict__ p_hat,
+                                                     const float* __restrict__ up, float gscale, float* __restrict__ dy, int Bt, long M,
+                                                     float p, int accumulate) {
+    const float g0 = up[0] * gscale;
+    for (long m = (long)blockIdx.x * 256 + threadIdx.x; m < M; m += (long)gridDim.x * 256) {
+        const float g = g0 * kl_dph(p, p_hat[m]);
+        for (int r = blockIdx.y; r < Bt; r += gridDim.y) {
+            const float v = y[(long)r * M + m];
+            const float d = v > 0.f ? g : (v < 0.f ? -g : 0.f);
+            float* o = dy + (long)r * M + m;
+            *o = accumulate ? *o + d : d;
+        }
+    }
+}
+
+// non-negativity term: mean_b sum_{t,n} min(y, 0)^2   (adapt.py:314-316)
+__global__ __launch_bounds__(256) void negsq_part_kernel(const float* __restrict__ y, float* __restrict__ part, long n) {
+    __shared__ float sm[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { const float v = fminf(y[i], 0.f); s += v * v; }
+    s = blk_reduce(s, sm, 0);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+// dx (+)= up * scale * f(x):  mode 0  f = 2 x  (sum of squares),  mode 1  f = 2 min(x, 0)  (negative energy)
+__global__ __launch_bounds__(256) void sq_bwd_kernel(const float* __restrict__ x, const float* __restrict__ up, float scale,
+                                                     float* __restrict__ dx, long n, int mode, int accumulate) {
+    const float g = 2.0f * up[0] * scale;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = mode ? fminf(x[i], 0.f) : x[i];
+        dx[i] = accumulate ? dx[i] + g * v : g * v;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+// p_hat[M] = sum over the Bt rows of |y|  (adapt.py:130-131).  ws: ams_abs_colsum_workspace_bytes(Bt, M).
+size_t ams_abs_colsum_workspace_bytes(int Bt, long M) {
+    if (Bt <= 0 || M <= 0) return 0;
+    int nslab = (Bt + 11) / 12;
+    if (nslab > 32) nslab = 32;
+    return (size_t)nslab * M * sizeof(float);
+}
+ams_status ams_abs_colsum_fwd(const float* y, float* p_hat, int Bt, long M, void* ws, size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(y && p_hat && ws && Bt > 0 && M > 0);
+    if (ws_bytes < ams_abs_colsum_workspace_bytes(Bt, M)) return AMS_E_WORKSPACE_TOO_SMALL;
+    int nslab = (Bt + 11) / 12;
+    if (nslab > 32) nslab = 32;
+    const int rows_per = (Bt + nslab - 1) / nslab;
+    nslab = (Bt + rows_per - 1) / rows_per;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(abs_colsum_part_kernel, dim3((unsigned)((M + 1023) / 1024), nslab), dim3(256), 0, st, y, (float*)ws, Bt, M, rows_per);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)((M + 255) / 256)), dim3(256), 0, st, (const float*)ws, p_hat, M, nslab);
+    return ams_check_launch();
+}
+// out[0] = sum_m kl_div(p, p_hat[m])  (utils/ops.py:46-54).  ws: 1024 floats.
+ams_status ams_kl_sparsity_fwd(const float* p_hat, float* out, long M, float p, void* ws, size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(p_hat && out && ws && M > 0);
+    if (ws_bytes < 1024 * sizeof(float)) return AMS_E_WORKSPACE_TOO_SMALL;
+    int blocks = (int)((M + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(kl_part_kernel, dim3(blocks), dim3(256), 0, st, p_hat, (float*)ws, M, p);
+    hipLaunchKernelGGL(small_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, out, blocks, 1.0f);
+    return ams_check_launch();
+}
+// dy[Bt, M] (+)= upstream[0] * gscale * sign(y) * d kl / d p_hat   (the |.| column sum and the KL in one pass)
+ams_status ams_kl_sparsity_bwd(const float* y, const float* p_hat, const float* upstream, float gscale, float* dy, int Bt, long M,
+                               float p, int accumulate, void* stream) {
+    AMS_REQUIRE(y && p_hat && upstream && dy && Bt > 0 && M > 0);
+    int bx = (int)((M + 255) / 256);
+    if (bx > 1024) bx = 1024;
+    int by = Bt < 8 ? Bt : 8;
+    hipLaunchKernelGGL(kl_bwd_kernel, dim3(bx, by), dim3(256), 0, (hipStream_t)stream, y, p_hat, upstream, gscale, dy, Bt, M, p, accumulate);
+    return ams_check_launch();
+}
+// out[0] = (1 / Bt) * sum min(y, 0)^2 over all Bt * M entries  (adapt.py:314-316).  ws: 1024 floats.
+ams_status ams_negative_energy_fwd(const float* y, float* out, int Bt, long M, void* ws, size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(y && out && ws && Bt > 0 && M > 0);
+    if (ws_bytes < 1024 * sizeof(float)) return AMS_E_WORKSPACE_TOO_SMALL;
+    const long n = (long)Bt * M;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 1024) blocks = 1024;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(negsq_part_kernel, dim3(blocks), dim3(256), 0, st, y, (float*)ws, n);
+    hipLaunchKernelGGL(small_sum_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, out, blocks, 1.0f / (float)Bt);
+    return ams_check_launch();
+}
+// dx[n] (+)= upstream[0] * scale * 2 x  (mode 0: gradient of sum x^2)  /  * 2 min(x, 0)  (mode 1: of sum min(x, 0)^2)
+ams_status ams_sumsq_bwd(const float* x, const float* upstream, float scale, float* dx, long n, int mode, int accumulate, void* stream) {
+    AMS_REQUIRE(x && upstream && dx && n > 0 && (mode == 0 || mode == 1));
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sq_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, upstream, scale, dx, n, mode, accumulate);
+    return ams_check_launch();
+}
 
 // y [B(1+S), TN] -> out [B*S, TN];  mode 0 mask, 1 perfect
 ams_status ams_pretrain_separator_fwd(const float* y, float* out, int B, int S, long TN, int mode, void* stream) {

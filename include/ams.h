@@ -220,6 +220,23 @@ ams_status ams_silence_weights(const float* lat, float* w, int rows, long n, flo
 ams_status ams_pretrain_separator_fwd(const float* y, float* out, int B, int S, long TN, int mode, void* stream);
 ams_status ams_pretrain_separator_bwd(const float* dout, float* dy, int B, int S, long TN, int mode, void* stream);
 
+/* ---- default-on terms of the pre-training objective   models/adapt.py:127-132 (p_hat, sparse_constraint), 310-316 and 377-384
+ * (regularization, non-negativity), utils/ops.py:46-54 (kl_div / logfunc); CLI defaults utils/trainer.py:151-161 ----
+ * ams_abs_colsum_fwd:       p_hat[M] = sum_b |y[b, m]| over the Bt rows (tf.reduce_sum(tf.abs(y), 0)); fixed slab order.
+ * ams_kl_sparsity_fwd:      out[0] = sum_m p log(clip(p)/clip(p_hat)) + (1-p) log(clip(1-p)/clip(1-p_hat)), clip to [1e-10, 1].
+ * ams_kl_sparsity_bwd:      dy[Bt, M] (+)= upstream[0] * gscale * sign(y) * d kl / d p_hat (clip_by_value passes the gradient
+ *                           inside [1e-10, 1] only); gscale carries the data-parallel world size (p_hat is a batch SUM).
+ * ams_negative_energy_fwd:  out[0] = mean_b sum_{t,n} min(y, 0)^2.
+ * ams_sumsq_bwd:            dx (+)= upstream[0] * scale * 2 x (mode 0: of ams_sumsq) / * 2 min(x, 0) (mode 1: of the above, with
+ *                           scale = 1 / Bt).   upstream is a DEVICE scalar: nothing here synchronises. */
+size_t ams_abs_colsum_workspace_bytes(int Bt, long M);
+ams_status ams_abs_colsum_fwd(const float* y, float* p_hat, int Bt, long M, void* ws, size_t ws_bytes, void* stream);
+ams_status ams_kl_sparsity_fwd(const float* p_hat, float* out, long M, float p, void* ws, size_t ws_bytes, void* stream);
+ams_status ams_kl_sparsity_bwd(const float* y, const float* p_hat, const float* upstream, float gscale, float* dy, int Bt, long M,
+                               float p, int accumulate, void* stream);
+ams_status ams_negative_energy_fwd(const float* y, float* out, int Bt, long M, void* ws, size_t ws_bytes, void* stream);
+ams_status ams_sumsq_bwd(const float* x, const float* upstream, float scale, float* dx, long n, int mode, int accumulate, void* stream);
+
 /* ---- K24  optimizers     models/network.py:181-194, utils/ops.py:686-703 ---- */
 ams_status ams_opt_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, long n, float lr_t, float beta1,
                            float beta2, float eps, float grad_scale, void* stream);

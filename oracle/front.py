@@ -126,6 +126,21 @@ def sparsity_terms(y, p):
     return p_hat, kl.sum()
 
 
+def sparsity_terms_bwd(y, p, p_hat=None):
+    """d [sum kl_div(p, p_hat)] / d y with p_hat = sum_b |y| (adapt.py:130-132): tf.abs' = sign; tf.clip_by_value passes the
+    gradient where 1e-10 <= value <= 1 and blocks it outside (utils/ops.py:46-49)."""
+    Bt = y.shape[0]
+    if p_hat is None:
+        p_hat = np.abs(y.reshape(Bt, -1)).sum(axis=0)
+    q, qh = 1.0 - p, 1.0 - p_hat
+    g = np.zeros_like(p_hat)
+    inside = (p_hat >= 1e-10) & (p_hat <= 1.0)
+    g[inside] -= p / p_hat[inside]
+    inside_q = (qh >= 1e-10) & (qh <= 1.0)
+    g[inside_q] += q / qh[inside_q]
+    return (np.sign(y.reshape(Bt, -1)) * g[None, :]).reshape(y.shape)
+
+
 # ----------------------------------------------------------------------------------------
 # Synthesis (reference Adapt.back, adapt.py:205-252)
 # ----------------------------------------------------------------------------------------

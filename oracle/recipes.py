@@ -6,8 +6,11 @@ import numpy as np
 from . import front, stft, separate, losses, kmeans, step
 
 
-def pretrain_loss(x_mix, x_non_mix, P, hop, loss_kind, separation, overlap_coef=0.0, want_grads=True):
-    """experiments.training.pretraining step, path A (adapt.py:16-56, 95-252, 307-402) with beta=0, regularization=0."""
+def pretrain_loss(x_mix, x_non_mix, P, hop, loss_kind, separation, overlap_coef=0.0, want_grads=True, beta=0.0, sparsity=0.01,
+                  regularization=0.0, non_negativity=0.0):
+    """experiments.training.pretraining step, path A (adapt.py:16-56, 95-252, 307-402), with the default-on terms of the CLI
+    (utils/trainer.py:151-161: beta 1e-2 x sum kl_div(sparsity, p_hat), regularization 1e-4 applied twice to the two filter
+    l2_losses, non_negativity applied twice to mean_b sum min(front, 0)^2 -- adapt.py:130-132, 312-316, 377-384)."""
     B, S, L = x_non_mix.shape
     x = np.concatenate([x_mix, x_non_mix.reshape(B * S, L)], axis=0)
     w1, b1, w2, b2 = P['front/window/w'], P['front/bases/bases'], P['back/window/value'], P['back/bases/value']
@@ -18,6 +21,16 @@ def pretrain_loss(x_mix, x_non_mix, P, hop, loss_kind, separation, overlap_coef=
     loss, l2, sdr = losses.pretrain_cost(x_mix, x_non_mix, back, loss_kind)
     ov = front.overlap_metric(y, B, S)
     cost = loss + (overlap_coef * ov if overlap_coef != 0.0 else 0.0)
+    Bt = y.shape[0]
+    p_hat = None
+    if beta != 0.0:
+        p_hat, kl = front.sparsity_terms(y, sparsity)
+        cost = cost + beta * kl
+    reg, nn = losses.adapt_regularizers(f, f2, y, regularization, non_negativity)
+    if regularization != 0.0:
+        cost = cost + regularization * reg
+    if non_negativity is not None and non_negativity != 0.0:
+        cost = cost + non_negativity * nn
     if not want_grads:
         return cost, back
     dback = losses.pretrain_cost_bwd(x_non_mix, back, loss_kind).reshape(B * S, L)
@@ -25,7 +38,14 @@ def pretrain_loss(x_mix, x_non_mix, P, hop, loss_kind, separation, overlap_coef=
     dy = front.pretrain_separator_bwd(y, B, S, separation, dz)
     if overlap_coef != 0.0:
         dy = dy + overlap_coef * front.overlap_metric_bwd(y, B, S)
+    if beta != 0.0:
+        dy = dy + beta * front.sparsity_terms_bwd(y, sparsity, p_hat)
+    if non_negativity is not None and non_negativity != 0.0:
+        dy = dy + non_negativity * non_negativity * 2.0 * np.minimum(y, 0.0) / Bt
     df = front.conv_strided_bwd_filter(x, dy, f.shape[0], hop)
+    if regularization != 0.0:                            # d/df [lam * lam * 0.5 * sum f^2] = lam^2 f
+        df = df + regularization * regularization * f
+        df2 = df2 + regularization * regularization * f2
     dw1, db1 = front.front_filter_bwd(w1, b1, df)
     dw2, db2 = front.front_filter_bwd(w2, b2, df2)
     grads = {'front/window/w': dw1, 'front/bases/bases': db1, 'back/window/value': dw2, 'back/bases/value': db2}

@@ -59,15 +59,31 @@ def _worker(rank, world, port, tmp, q):
     same_id = all(i == ids[0] for i in ids)
     # 6. sparsity term (adapt.py:130-132): p_hat is a batch SUM through a non-linear KL.  Per-rank gradient of
     #    [mean-type term + KL(all-reduced p_hat)] averaged over ranks must equal the single-process gradient on the whole batch.
-    from ams_hip import functional as F
+    #    The product's autograd node (ams_hip/functional.py::SparseKL: all-reduce of p_hat in the forward, x world in the backward)
+    #    is driven here with CPU stand-ins for its three HIP kernels (test doubles of ams_abs_colsum_fwd / ams_kl_sparsity_*;
+    #    the kernels themselves are checked against the oracle in tests/test_gpu_recipes.py).
+    from ams_hip import functional as F, ops as O
+
+    def kl_ref(p_hat, p):
+        def logfunc(a, b):
+            return a * torch.log(torch.clamp(a, 1e-10, 1.0) / torch.clamp(b, 1e-10, 1.0))
+        pt = torch.full((), float(p), dtype=p_hat.dtype)
+        return (logfunc(pt, p_hat) + logfunc(1 - pt, 1 - p_hat)).sum()
+
+    def kl_bwd_ref(y2, p_hat, up, p, gscale):
+        with torch.enable_grad():
+            ph = p_hat.detach().clone().requires_grad_(True)
+            kl_ref(ph, p).backward()
+        return up * gscale * torch.sign(y2) * ph.grad[None, :]
+    O.abs_colsum = lambda y2: y2.abs().sum(0)
+    O.kl_sparsity_fwd = lambda p_hat, p: kl_ref(p_hat, p).reshape(1)
+    O.kl_sparsity_bwd = kl_bwd_ref
     gen = torch.Generator().manual_seed(5)
     y_all = (torch.rand(2 * world, 6, generator=gen) * 0.1).double()
-    def loss_of(y, p_hat):
-        return (y ** 2).sum(1).mean() + F.kl_sparsity(p_hat, 0.05)
     ya = y_all.clone().requires_grad_(True)
-    loss_of(ya, ya.abs().sum(0)).backward()
+    ((ya ** 2).sum(1).mean() + kl_ref(ya.abs().sum(0), 0.05)).backward()
     mine = y_all[2 * rank:2 * rank + 2].clone().requires_grad_(True)
-    loss_of(mine, F.all_reduce_sum_autograd(mine.abs().sum(0), dist)).backward()
+    ((mine ** 2).sum(1).mean() + F.sparse_kl(mine, 0.05, dist)).backward()
     # what FlatOptimizer.exchange does to a parameter gradient: sum over ranks x 1/world.  Here the "parameter" is the input
     # shard itself, so compare d/d(shard) x (1/world) with the matching rows of the full-batch gradient: the mean term carries
     # 1/(2*world) vs 1/2 locally (-> x 1/world), the KL term must come out unscaled.

@@ -230,3 +230,71 @@ def test_x6_accumulation_is_unbiased(ops, arith, K, kind):
     d0, d1 = (c0 - ref) / scale, (c1 - ref) / scale
     assert abs(d1.mean()) < 5e-9, (d0.mean(), d1.mean())
     assert np.sqrt((d1 ** 2).mean()) <= 1.05 * np.sqrt((d0 ** 2).mean()), (np.sqrt((d0 ** 2).mean()), np.sqrt((d1 ** 2).mean()))
+
+
+@pytest.fixture()
+def capped():
+    """Launch products the way every weight-gradient product of a training step is launched (ams_hip/functional.py::_Overlap:
+    side stream, residency cap of 2 workgroups per CU beside a recurrence ring)."""
+    from ams_hip._lib import load
+    lib = load()
+    lib.ams_gemm_set_lds_pad(50000)
+    yield
+    lib.ams_gemm_set_lds_pad(0)
+
+
+def _bias_stats(c, ref, scale):
+    d = (np.asarray(c, np.float64) - ref) / scale
+    return float(d.mean()), float(np.sqrt((d ** 2).mean()))
+
+
+@pytest.mark.parametrize('M,N,K', [(600, 10240, 5120), (600, 2400, 5120), (256, 2400, 5120)])
+def test_x6_capped_weight_gradient_products_are_unbiased(ops, arith, capped, M, N, K):
+    """The products bench.py's weight gradients run: dW = x^T dY (A_COL x B_ROW) at the step's own shapes -- dense 600 x 10240,
+    projections 600 x 2400 and 256 x 2400, all K = B*T = 5120 -- under the residency cap.  Same bound as the uncapped default
+    path: |mean signed error| < 5e-9 of the term scale, rms at or below the native f32 kernel's.  (The one-accumulator form of
+    round 2 sat at -4e-6 here: a coherent error that AMSGrad's first moment integrates over steps.)"""
+    rng = np.random.RandomState(M + N)
+    A, B = rng.randn(K, M), rng.randn(K, N)
+    ref = f32(A).T @ f32(B)
+    a, b = dev(A), dev(B)
+    c0, c1 = both(arith, lambda: host(ops.gemm(a, b, transA=True)))
+    m0, r0 = _bias_stats(c0, ref, np.sqrt(K))
+    m1, r1 = _bias_stats(c1, ref, np.sqrt(K))
+    print('capped %dx%dx%d: native mean %.2e rms %.2e | bf16x6 mean %.2e rms %.2e' % (M, N, K, m0, r0, m1, r1))
+    assert abs(m1) < 5e-9, (m0, m1)
+    assert r1 <= 1.05 * r0, (r0, r1)
+    # sign-coherent inputs (activations after a sigmoid-like squashing): the worst case for a truncating adder
+    A, B = rng.uniform(0.5, 1.0, (K, M)), rng.uniform(0.5, 1.0, (K, N))
+    ref = f32(A).T @ f32(B)
+    a, b = dev(A), dev(B)
+    c0, c1 = both(arith, lambda: host(ops.gemm(a, b, transA=True)))
+    m0, r0 = _bias_stats(c0, ref, np.abs(ref).mean())
+    m1, r1 = _bias_stats(c1, ref, np.abs(ref).mean())
+    print('capped %dx%dx%d positive: native mean %.2e rms %.2e | bf16x6 mean %.2e rms %.2e' % (M, N, K, m0, r0, m1, r1))
+    assert abs(m1) < 5e-9, (m0, m1)
+    assert r1 <= 1.05 * r0, (r0, r1)
+
+
+def test_x6_capped_recurrent_kernel_gradient_is_unbiased(ops, arith, capped):
+    """The batched, time-shifted, masked form of the recurrent-kernel gradients at the step's shape (2 x [300 x 1200], K = 5120 rows
+    of which every T-th is masked), capped like in the step."""
+    rng = np.random.RandomState(77)
+    T, Bq, H = 80, 64, 300
+    M = Bq * T
+    out, dZ = rng.randn(M, 2 * H), rng.randn(M, 8 * H)
+    o3, z3 = f32(out).reshape(Bq, T, 2 * H), f32(dZ).reshape(Bq, T, 8 * H)
+    ref = np.stack([np.einsum('btj,btg->jg', o3[:, :-1, :H], z3[:, 1:, :4 * H]),
+                    np.einsum('btj,btg->jg', o3[:, :-1, H:], z3[:, 1:, 4 * H:])])
+    o, z = dev(out), dev(dZ)
+
+    def run():
+        res = torch.zeros((2, H, 4 * H), device='cuda', dtype=torch.float32)
+        ops.gemm_batched2(o.view(-1), o.view(-1)[H:], z.view(-1)[8 * H:], z.view(-1)[8 * H + 4 * H:], res[0], res[1], True, False,
+                          H, 4 * H, M - 1, 2 * H, 8 * H, 4 * H, mask=(T, T - 1))
+        return host(res)
+    c0, c1 = both(arith, run)
+    m0, r0 = _bias_stats(c0, ref, np.sqrt(M))
+    m1, r1 = _bias_stats(c1, ref, np.sqrt(M))
+    print('capped batched dU: native mean %.2e rms %.2e | bf16x6 mean %.2e rms %.2e' % (m0, r0, m1, r1))
+    assert abs(m1) < 5e-9 and r1 <= 1.05 * r0, (m0, r0, m1, r1)

@@ -392,3 +392,39 @@ def test_blstm_banded_and_tail_overlap_match_plain(ops, monkeypatch, B, T, D, H)
     u2 = ops.dense_fwd(out3, W2, bd)
     torch.cuda.synchronize()
     assert rel(host(u2), out_ref.reshape(B * T, 2 * H).dot(2.0 * W).reshape(B, T, 50) + b) < TOL
+
+
+@pytest.mark.parametrize('Bt,T,N,scale', [(9, 64, 16, 0.02), (192, 80, 256, 0.004), (5, 7, 3, 0.3)])
+def test_sparsity_kl_and_regulariser_kernels(F, ops, Bt, T, N, scale):
+    """p_hat = sum_b |y|, sum kl_div(p, p_hat) with both clip_by_value gates (models/adapt.py:130-132, utils/ops.py:46-54), the
+    non-negativity energy (adapt.py:314-316) and sum-of-squares (tf.nn.l2_loss), forward and backward, against the oracle --
+    including p_hat values exactly on and on either side of the clip bounds, and the benchmark's [192, 80 * 256] shape."""
+    rng = np.random.RandomState(Bt * T)
+    y = rng.randn(Bt, T, N) * scale
+    y[:, 0, 0] = 0.0                                          # p_hat = 0 < 1e-10: clipped below, no gradient; sign(0) = 0
+    y[:, 0, 1] = 0.0
+    y[0, 0, 1] = 1.0                                          # p_hat == 1 exactly: inside both gates' closed ends
+    y[:, 0, 2] = 2.0 / Bt * np.sign(rng.randn(Bt))            # p_hat = 2 > 1: clipped above
+    p = 0.01
+    y32 = y.astype(np.float32).astype(np.float64)
+    p_hat_ref, kl_ref = ofront.sparsity_terms(y32, p)
+    yt = dev(y).requires_grad_()
+    ph = ops.abs_colsum(yt.detach().reshape(Bt, -1))
+    assert rel(host(ph), p_hat_ref) < 1e-6
+    kl = F.sparse_kl(yt.reshape(Bt, -1), p)
+    assert abs(float(kl) - kl_ref) < 2e-5 * abs(kl_ref)
+    (3.0 * kl).backward()
+    g_ref = 3.0 * ofront.sparsity_terms_bwd(y32, p, np.asarray(host(ph), np.float64))
+    assert rel(host(yt.grad), g_ref) < 2e-5
+    # non-negativity and l2 terms
+    yt2 = dev(y).requires_grad_()
+    ne = F.negative_energy(yt2)
+    ne_ref = (np.minimum(y32, 0.0) ** 2).reshape(Bt, -1).sum(1).mean()
+    assert abs(float(ne) - ne_ref) < 2e-5 * ne_ref
+    (0.5 * ne).backward()
+    assert rel(host(yt2.grad), 0.5 * 2.0 * np.minimum(y32, 0.0) / Bt) < 1e-6
+    yt3 = dev(y).requires_grad_()
+    ss = F.sumsq(yt3)
+    assert abs(float(ss) - (y32 ** 2).sum()) < 2e-5 * (y32 ** 2).sum()
+    (0.25 * ss).sum().backward()
+    assert rel(host(yt3.grad), 0.5 * y32) < 1e-6

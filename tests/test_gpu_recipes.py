@@ -86,6 +86,34 @@ def test_pretraining_step(loss, separation, overlap, optimizer):
     check_step(cost, c_ref, grads, g_ref, P, P_new, opt)
 
 
+@pytest.mark.parametrize('beta,lam,nn,gain', [(1e-2, 1e-4, 0.1, 1.0), (1e-2, 1e-4, 0.0, 25.0), (0.5, 0.3, 0.7, 6.0)])
+def test_pretraining_step_at_cli_default_regularisers(beta, lam, nn, gain):
+    """experiments.training.pretraining with the terms the CLI turns ON by default (utils/trainer.py:151-161: --beta 1e-2,
+    --regularization 1e-4; --non_negativity exercised too): beta * sum kl_div(sparsity, p_hat), lam * (lam * (l2_loss(f2) +
+    l2_loss(f))), nn * (nn * mean_b sum min(front, 0)^2)  (models/adapt.py:130-132, 312-316, 377-384).  Cost, all four gradients
+    and the AMSGrad update against the oracle.  `gain` scales the front filter so that p_hat = sum_b |y| sits below 1 (gradient
+    through the clip), straddles 1, or mostly above (clipped: no gradient) -- the three regimes of utils/ops.py:46-49; the third
+    row uses large coefficients so that every term is visible next to the loss."""
+    from utils.trainer import Adapt_Pretrainer
+    B, S, L, W, N, hop = 3, 2, 1024, 64, 16, 16
+    a = base_args(batch_size=B, nb_speakers=S, chunk_size=L, window_size=W, filters=N, hop_size=hop, loss='sdr+l2', separation='perfect',
+                  overlap_coef=0.001, optimizer='Adam', learning_rate=1e-3, pretraining=True, beta=beta, regularization=lam,
+                  non_negativity=nn, sparsity=0.01)
+    a.pop('type')
+    tr = Adapt_Pretrainer(**a)
+    dist, tfds = tr.prepare()
+    g = tr.graph
+    g.variables['front/bases/bases'].data.mul_(gain)
+    P, cost, xm, xn, I, grads, P_new = one_train_step(tr, tfds, L)
+    c_ref, g_ref, back = orec.pretrain_loss(xm, xn, P, hop, 'sdr+l2', 'perfect', 0.001, beta=beta, sparsity=0.01, regularization=lam,
+                                            non_negativity=nn)
+    c_plain, g_plain, _ = orec.pretrain_loss(xm, xn, P, hop, 'sdr+l2', 'perfect', 0.001)
+    # the terms are really in the objective and in the gradient (otherwise this test would pass with them dropped)
+    assert abs(c_ref - c_plain) > 1e-6 * abs(c_plain)
+    assert max(rel(g_ref[n], g_plain[n]) for n in g_ref) > 1e-5
+    check_step(cost, c_ref, grads, g_ref, P, P_new, ooptim.AMSGrad(1e-3))
+
+
 def test_stft_dpcl_step():
     """experiments.training.STFT_DPCL (cfg1) at reduced size."""
     from models.dpcl import DPCL

@@ -353,6 +353,56 @@ def test_overlap_metric_grad():
     assert rel(front.overlap_metric_bwd(y, B, S), yt.grad.numpy()) < 1e-11
 
 
+def test_default_on_pretraining_terms_vs_autograd():
+    """The terms the reference's CLI turns on by default (utils/trainer.py:151-161) -- sum kl_div(p, p_hat) with p_hat = sum_b |y|
+    and both clip_by_value gates (models/adapt.py:130-132, utils/ops.py:46-54), the twice-applied filter l2 and non-negativity
+    terms (adapt.py:312-316, 377-384) -- inside the whole pretraining objective: oracle cost and gradients vs torch autograd of an
+    independently written graph (torch.clamp has TensorFlow's clip_by_value gradient: 1 inside the closed interval, 0 outside)."""
+    from oracle import recipes
+    rng = np.random.RandomState(12)
+    B, S, L, W, N, hop = 2, 2, 256, 32, 6, 8
+    P = {'front/window/w': rng.randn(W) * 0.4, 'front/bases/bases': rng.randn(W, N) * 0.9,
+         'back/window/value': rng.randn(W) * 0.4, 'back/bases/value': rng.randn(W, N) * 0.5}
+    xn = rng.randn(B, S, L) * 0.2
+    xm = xn.sum(1)
+    beta, p, lam, nn, ov = 0.3, 0.01, 0.2, 0.6, 0.05
+    c, g, _ = recipes.pretrain_loss(xm, xn, P, hop, 'sdr+l2', 'perfect', ov, beta=beta, sparsity=p, regularization=lam, non_negativity=nn)
+    T, pl, _ = front.same_pads(L, W, hop)
+    Pt = {k: t(v).requires_grad_() for k, v in P.items()}
+    x = torch.cat([t(xm), t(xn).reshape(B * S, L)], 0)
+    f = Pt['front/window/w'].abs()[:, None] * Pt['front/bases/bases']
+    f2 = Pt['back/window/value'].abs()[:, None] * Pt['back/bases/value']
+    pad_total = max((T - 1) * hop + W - L, 0)
+    y = F.conv1d(F.pad(x[:, None, :], (pl, pad_total - pl)), f.t()[:, None, :], stride=hop).transpose(1, 2)      # [Bt, T, N]
+    Bt = y.shape[0]
+    mix, nm = y[:B][:, None], y[B:].reshape(B, S, T, N)
+    z = (mix - (nm.sum(1, keepdim=True) - nm)).reshape(B * S, T, N)
+    full = F.conv_transpose1d(z.transpose(1, 2), f2.t()[:, None, :], stride=hop)                                  # [R, 1, (T-1)hop+W]
+    back = full[:, 0, pl:pl + L].reshape(B, S, L)
+    tgt = t(xn)
+    l2 = ((tgt - back) ** 2).sum(-1).sum(-1).mean()
+    sdr = (((tgt ** 2).sum(-1) * (back ** 2).sum(-1)) / ((tgt * back).sum(-1) ** 2 + 1e-12)).mean()
+    p_hat = y.reshape(Bt, -1).abs().sum(0)
+    pt = torch.tensor(p, dtype=torch.float64)
+
+    def logfunc(a, b):
+        return a * torch.log(torch.clamp(a, 1e-10, 1.0) / torch.clamp(b, 1e-10, 1.0))
+    kl = (logfunc(pt, p_hat) + logfunc(1 - pt, 1 - p_hat)).sum()
+    reg = lam * (0.5 * (f2 ** 2).sum() + 0.5 * (f ** 2).sum())
+    neg = torch.where(y < 0, y, torch.zeros_like(y)) ** 2
+    nnv = nn * neg.reshape(Bt, -1).sum(1).mean()
+    from itertools import combinations
+    a = y[B:].reshape(B, S, -1).abs()
+    ovv = torch.stack([(1.0 - (a[:, i] - a[:, j]).abs() / (torch.maximum(a[:, i], a[:, j]) + 1e-8)).mean(-1)
+                       for i, j in combinations(range(S), 2)], 1).mean(1).mean()
+    cost = l2 + sdr + beta * kl + lam * reg + ov * ovv + nn * nnv
+    cost.backward()
+    assert float((p_hat > 1).sum()) > 0 and float((p_hat < 1).sum()) > 0          # both sides of the upper clip bound are exercised
+    assert abs(c - cost.item()) < 1e-10 * abs(cost.item())
+    for k in P:
+        assert rel(g[k], Pt[k].grad.numpy()) < 1e-9, k
+
+
 def test_kmeans_oracle_matches_sklearn_lloyd():
     """Independent cross-check of the hard k-means restatement (Kmeans_2.py:86-188): without silence weights and with one try it
     is plain Lloyd's algorithm for a fixed number of iterations from given seeds -- compare labels/centroids with scikit-learn."""
