@@ -64,6 +64,7 @@ class _Overlap(object):
             pad = tab[min(self.n_cap, len(tab) - 1)]
             self.n_cap += 1
         load().ams_gemm_set_lds_pad(pad if on else 0)
+        load().ams_x3_set_capped(1 if on else 0)
 
     def join(self):
         self.n_cap = 0
@@ -110,6 +111,11 @@ _ORDER = int(_os.environ.get('AMS_OVERLAP_ORDER', '2'))
 # 2 = dW alone, then dX (8.97 k) -- measured on the B=64 step, kept as a tuning aid
 _DENSE_MODE = int(_os.environ.get('AMS_DENSE_MODE', '0'))
 _L1_TAIL = int(_os.environ.get('AMS_L1_TAIL', '0'))
+# AMS_X3_SIDE=1: the side-stream (residency-capped) weight-gradient products run from pre-split x3 images (csrc/gemm_x3.hip, two
+# accumulator sets: no truncation bias) instead of the capped one-accumulator form of the in-loop-split kernel.  Measured on the B=64
+# step: 16.68-16.70 k against 17.20-17.30 k mixtures/s (-3.2 %: the 525 MB split pass of dU beside the top BPTT ring, which it slows
+# from 344 to 390 us) -- parity-tested (tests/test_gpu_benchshape.py passes with either setting), off by default; DESIGN.md 4.0b.
+X3_SIDE = _os.environ.get('AMS_X3_SIDE', '0') != '0'
 
 
 _NEXT = []
@@ -179,12 +185,13 @@ class BLSTMLayer(Function):
                     ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart)
                 return None, None, None, None, None, None
             with torch.cuda.stream(s):
+                x3 = {} if X3_SIDE else None             # products beside the ring from pre-split images (csrc/gemm_x3.hip)
                 OVERLAP.cap(True, 'lstm')
-                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart)
+                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart, x3_side=x3)
                 # the LAST capped product of the backward pass (recurrent-kernel gradient of the layer above the first one) ends
                 # after the BPTT it hides behind: 2 workgroups per CU there (+0.6 %)
                 OVERLAP.cap(True, 'lstm_last' if ctx.last_capped else 'lstm')
-                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u')
+                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u', x3_side=x3)
                 OVERLAP.cap(False)
             if dx is None and need_dx:
                 dx = ops.blstm_bwd_dx(G, Kf, Kb, B, T, D)
@@ -210,15 +217,24 @@ class Dense(Function):
         b = ctx.bias
         if OVERLAP.usable(W, b) and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
             dx = None
+            x3 = X3_SIDE and _DENSE_MODE == 0 and W.grad.is_contiguous()
             if _DENSE_MODE == 0 and _ORDER >= 1 and ctx.needs_input_grad[0]:
                 dx = ops.gemm(du2, W, transB=True).view(x.shape)
             s = OVERLAP.fork(x2, du2)
             with torch.cuda.stream(s):
                 OVERLAP.cap(_DENSE_MODE == 0)
-                # dW = x^T dU and db = colsum(dU) from ONE pass over dU (210 MB at the benchmark shape)
-                fused = ops.gemm_at_b_colsum(x2, du2, W.grad, b.grad, accumulate=True)
-                if not fused:
-                    ops.gemm(x2, du2, transA=True, out=W.grad, accumulate=True)
+                if x3:
+                    # beside the top layer's BPTT ring: pre-split images, two accumulator sets (csrc/gemm_x3.hip); db = colsum(dU)
+                    # comes out of the pass that splits dU.  (Writing the images on the side stream WHILE dX runs was measured too:
+                    # the HBM-bound split beside the MFMA-bound dX took 213 instead of 97 us and slowed dX by 40 us -- 16.1 k.)
+                    ops.gemm_x3(ops.x3_split(x2), 1, ops.x3_split_colsum(du2, b.grad, True), 1, W.shape[0], W.shape[1], x2.shape[0],
+                                out=W.grad, accumulate=True)
+                    fused = True
+                else:
+                    # dW = x^T dU and db = colsum(dU) from ONE pass over dU (210 MB at the benchmark shape)
+                    fused = ops.gemm_at_b_colsum(x2, du2, W.grad, b.grad, accumulate=True)
+                    if not fused:
+                        ops.gemm(x2, du2, transA=True, out=W.grad, accumulate=True)
                 OVERLAP.cap(False)
                 if not fused:
                     ops.colsum_into(du2, b.grad, True)

@@ -239,6 +239,75 @@ def gemm_batched(A, B, C, nbatch, a_zs, b_zs, c_zs, transA, transB, M, N, K, lda
         PROFILE.end(ev, nbatch * 2.0 * M * N * K, nbatch * 4.0 * (M * K + K * N + M * N), 'gemm<%d,%d>' % (int(bool(transA)), int(bool(transB))))
 
 
+# ------------------------------------------------------------------ products from pre-split operands (csrc/gemm_x3.hip)
+class X3(object):
+    """x3 image of a logical row-major f32 matrix [R, C]: each element split exactly into three bf16 terms, stored in the layout the
+    MFMA fragments are read from (include/ams.h).  `buf` is a uint8 device tensor of ams_x3_image_bytes(R, C)."""
+    __slots__ = ('buf', 'R', 'C')
+
+    def __init__(self, R, C, device, buf=None):
+        self.R, self.C = int(R), int(C)
+        nb = load().ams_x3_image_bytes(self.R, self.C)
+        self.buf = buf if buf is not None else torch.empty(nb, dtype=torch.uint8, device=device)
+        if self.buf.numel() < nb:
+            raise AmsError('x3 image buffer too small')
+
+
+def x3_split(X, out=None, R=None, C=None, ld=None):
+    """x3 image of a 2-D fp32 tensor (rows may be strided by ld floats)."""
+    if R is None:
+        _chk_rows(X)
+        R, C = X.shape
+        ld = X.stride(0)
+    img = out if out is not None else X3(R, C, X.device)
+    if img.R != R or img.C != C:
+        raise AmsError('x3_split: image is [%d, %d], source is [%d, %d]' % (img.R, img.C, R, C))
+    check(load().ams_x3_split(_p(X), ld, R, C, _p(img.buf), _s()), 'ams_x3_split')
+    return img
+
+
+def x3_split_colsum(X, csum, accumulate=True):
+    """x3 image of X [R, C] and csum[C] (+)= column sums of X, one pass over X."""
+    _chk_rows(X)
+    _chk(csum)
+    R, C = X.shape
+    img = X3(R, C, X.device)
+    lib = load()
+    nb = lib.ams_x3_split_colsum_workspace_bytes(R, C)
+    ws = _ws(nb, X)
+    check(lib.ams_x3_split_colsum(_p(X), X.stride(0), R, C, _p(img.buf), _p(csum), int(bool(accumulate)), _p(ws), nb, _s()),
+          'ams_x3_split_colsum')
+    return img
+
+
+def x3_split_shifted(out2, T, H, out=None):
+    """Shifted image of a BLSTM layer output [B*T, 2H] for the recurrent-kernel gradients (include/ams.h)."""
+    _chk(out2)
+    BT = out2.shape[0]
+    Hp = (H + 7) // 8 * 8
+    img = out if out is not None else X3(BT, 2 * Hp, out2.device)
+    check(load().ams_x3_split_shifted(_p(out2), out2.stride(0), BT, T, H, _p(img.buf), _s()), 'ams_x3_split_shifted')
+    return img
+
+
+def gemm_x3(A, roleA, B, roleB, M, N, K, out=None, ldc=None, bias=None, accumulate=False, a_off=(0, 0), b_off=(0, 0), nbatch=1,
+            a_m_zs=0, b_n_zs=0, c_zs=0, label=''):
+    """out[M, N] (+)= op(A) op(B) (+ bias) from x3 images.  role 0: k along the image's columns, 1: k along its rows."""
+    lib = load()
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=A.buf.device)
+    if ldc is None:
+        ldc = out.stride(0) if out.dim() == 2 else N
+    nb = lib.ams_gemm_x3_workspace_bytes(M, N, K, nbatch)
+    ws = _ws(nb, out) if nb else None
+    ev = PROFILE.begin() if PROFILE.enabled else None
+    check(lib.ams_gemm_x3(int(roleA), int(roleB), M, N, K, _p(A.buf), A.R, A.C, a_off[0], a_off[1], _p(B.buf), B.R, B.C, b_off[0], b_off[1],
+                          _p(out), ldc, c_zs, _p(bias), int(accumulate), nbatch, a_m_zs, b_n_zs, _p(ws), nb, _s()), 'ams_gemm_x3')
+    if ev is not None:
+        PROFILE.end(ev, nbatch * 2.0 * M * N * K, nbatch * (6.0 * (M * K + K * N) + 4.0 * M * N), 'gemm<%d,%d>' % (int(roleA), 1 - int(roleB)), label)
+    return out
+
+
 # ------------------------------------------------------------------ masks
 def make_masks(rep_non_mix, B, S, a, b, take_abs, want_argmax=False):
     """rep_non_mix: [B*S, ...] rows (b,s) row-major.  Returns Y [B, TF, S] (and int32 argmax [B, TF])."""
@@ -569,7 +638,7 @@ def blstm_bwd_dx(G, Kf, Kb, B, T, D):
     return dx
 
 
-def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate, part='all', dbpart=None):
+def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate, part='all', dbpart=None, x3_side=None):
     """Weight gradients of one BLSTM layer from dZ (= G after blstm_bwd_recurrent), written (or accumulated) into the given
     buffers: dWx = x^T dZ, dU = h_prev^T dZ (time-shifted, masked at sequence boundaries), db = column sums.
     part: 'all' | 'wx' (input kernels + biases) | 'u' (recurrent kernels) -- the two halves are independent and may be
@@ -583,6 +652,23 @@ def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate, part='all', dbp
     dZb = G.view(-1)[4 * H:]
     acc = bool(accumulate)
     _chk_rows(dKf, dKb)
+    if x3_side is not None and _twin(dKf, dKb) and dKf.stride(0) == 8 * H and M > 1:
+        # residency-capped launch beside a recurrence ring: products from pre-split images (csrc/gemm_x3.hip) -- no split arithmetic
+        # on the CUs the ring shares, and the second accumulator set in every configuration (tests/test_gpu_gemm_x3.py).
+        # x3_side: dict cache for this layer's dZ image (shared by the 'wx' and 'u' halves).
+        zi = x3_side.get('dZ')
+        if zi is None:
+            zi = x3_side['dZ'] = x3_split(G.view(M, 8 * H))
+        if part in ('all', 'wx'):
+            xi = x3_split(x2)
+            gemm_x3(xi, 1, zi, 1, D, 8 * H, M, out=torch.as_strided(dKf, (D, 8 * H), (8 * H, 1)), ldc=8 * H, accumulate=acc)
+        if part in ('all', 'u'):
+            hs = x3_split_shifted(out.view(M, 2 * H), T, H)
+            Hp = (H + 7) // 8 * 8
+            # dU_fw = h[t-1, :H]^T dZ[:, :4H] -> dKf[D:], dU_bw = h[t+1, H:]^T dZ[:, 4H:] -> dKb[D:]  (one batched launch)
+            gemm_x3(hs, 1, zi, 1, H, 4 * H, M, out=dKf[D:], ldc=8 * H, accumulate=acc, nbatch=2, a_m_zs=Hp, b_n_zs=4 * H,
+                    c_zs=(dKb.data_ptr() - dKf.data_ptr()) // 4)
+        part = {'all': 'bias', 'wx': 'bias', 'u': 'none'}[part]
     if part in ('all', 'wx'):
         if _twin(dKf, dKb):
             # twin-interleaved gradient block: [dWx_f | dWx_b] IS a row-major [D, 8H] matrix -> written in place
@@ -597,6 +683,7 @@ def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate, part='all', dbp
             else:
                 dKf[:D].copy_(dWcat[:, :4 * H])
                 dKb[:D].copy_(dWcat[:, 4 * H:])
+    if part in ('all', 'wx', 'bias'):
         if dbpart is not None and _twin(dbf, dbb):      # ring BPTT already summed dZ over time: column sum over B rows only
             nb = lib.ams_colsum_workspace_bytes(B, 8 * H)
             ws = _ws(nb, x)

@@ -220,6 +220,34 @@ ams_status ams_silence_weights(const float* lat, float* w, int rows, long n, flo
 ams_status ams_pretrain_separator_fwd(const float* y, float* out, int B, int S, long TN, int mode, void* stream);
 ams_status ams_pretrain_separator_bwd(const float* dout, float* dy, int B, int S, long TN, int mode, void* stream);
 
+/* ---- f32 products from PRE-SPLIT operands ("x3 images", csrc/gemm_x3.hip) -- same call sites as ams_gemm_f32 (tf.matmul / conv1d
+ * k=1 / dynamic_rnn projections and their gradients, utils/ops.py:366-383, 501-503) ----
+ * x3 image of a logical row-major f32 matrix X[R, C]: every element split EXACTLY into three bf16 terms (hi + mid + lo == x), stored
+ * in 8-row x 16-column units of 768 bytes, [plane][column group of 8][row % 8][column % 8]; rows and columns zero-padded to multiples
+ * of 256.  The layout is the LDS image the MFMA operand fragments are read from, so the product's main loop is LDS-DMA -> ds_read ->
+ * v_mfma_f32_32x32x16_bf16 with no split arithmetic; arithmetic and error class are those of the bf16x6 form of ams_gemm_f32 (six
+ * partial products, two accumulator sets), in EVERY launch configuration.
+ * ams_x3_split            img <- X[R, C] (row stride ld floats); writes the whole padded image.
+ * ams_x3_split_colsum     the same, and csum[C] (+)= column sums of X in the same pass (fixed order).
+ * ams_x3_split_shifted    img <- time-shifted BLSTM output for the recurrent-kernel gradients: logical [B*T, 2 * Hp], Hp = H rounded
+ *                         up to 8; columns [0, H) = out[b, t-1, 0:H] (0 at t = 0), [Hp, Hp + H) = out[b, t+1, H:2H] (0 at t = T-1).
+ * ams_gemm_x3             C[M, N] (+)= op(A) op(B) (+ bias).  role 0: the contraction index runs along the image's COLUMNS
+ *                         (A[m, k] = X[r0 + m, c0 + k]); role 1: along its ROWS (A[m, k] = X[r0 + k, c0 + m]); same for B with n.
+ *                         Offsets: multiples of 8 along m / n, of 32 along k.  nbatch products share one launch (z-th: m offset
+ *                         + z * a_m_zs, n offset + z * b_n_zs, C + z * c_zs).  ws from ams_gemm_x3_workspace_bytes (split-K slabs).
+ * ams_x3_set_capped       thread-local: launches that follow run one 4-wave workgroup per CU (beside a recurrence ring). */
+size_t ams_x3_image_bytes(int R, int C);
+ams_status ams_x3_split(const float* X, long ld, int R, int C, void* img, void* stream);
+size_t ams_x3_split_colsum_workspace_bytes(int R, int C);
+ams_status ams_x3_split_colsum(const float* X, long ld, int R, int C, void* img, float* csum, int accumulate, void* ws, size_t ws_bytes,
+                               void* stream);
+ams_status ams_x3_split_shifted(const float* out, long ld, int BT, int T, int H, void* img, void* stream);
+void ams_x3_set_capped(int on);
+size_t ams_gemm_x3_workspace_bytes(int M, int N, int K, int nbatch);
+ams_status ams_gemm_x3(int roleA, int roleB, int M, int N, int K, const void* A, int a_R, int a_C, int a_r0, int a_c0, const void* B,
+                       int b_R, int b_C, int b_r0, int b_c0, float* C, long ldc, long c_zs, const float* bias, int accumulate, int nbatch,
+                       int a_m_zs, int b_n_zs, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- default-on terms of the pre-training objective   models/adapt.py:127-132 (p_hat, sparse_constraint), 310-316 and 377-384
  * (regularization, non-negativity), utils/ops.py:46-54 (kl_div / logfunc); CLI defaults utils/trainer.py:151-161 ----
  * ams_abs_colsum_fwd:       p_hat[M] = sum_b |y[b, m]| over the Bt rows (tf.reduce_sum(tf.abs(y), 0)); fixed slab order.

@@ -161,12 +161,14 @@ def gemm_arith():
     lib.ams_gemm_set_arith(before)
 
 
-@pytest.mark.parametrize('hip_graph,arith', [(False, 1), (True, 1), (False, 0)])
-def test_front_dpcl_step_at_benchmark_shape(hip_graph, arith, gemm_arith):
+@pytest.mark.parametrize('hip_graph,arith,x3_side', [(False, 1, False), (True, 1, False), (False, 0, False), (True, 1, True)])
+def test_front_dpcl_step_at_benchmark_shape(hip_graph, arith, x3_side, gemm_arith, monkeypatch):
     """The step bench.py times -- front_DPCL, B=64, full geometry -- against the float64 oracle: cost, every gradient, every
     updated weight after AMSGrad; eager and as the replayed hipGraph (3rd call = first replay), with the default bf16x6 products
     and, eager, with the native f32 MFMA products: the SAME tolerances hold for both arithmetics."""
     from tests.smoke_step import build_front_dpcl
+    from ams_hip import functional as Fn
+    monkeypatch.setattr(Fn, 'X3_SIDE', x3_side)          # side-stream weight gradients from pre-split images (AMS_X3_SIDE=1)
     gemm_arith(arith)
     tmp = tempfile.mkdtemp(prefix='ams_benchshape_')
     trainer, tfds = build_front_dpcl(tmp, B=B, L=L, W=W, N=N, hop=HOP, layer_size=LS, nb_layers=NL, E=E, no_summaries=True,

@@ -99,7 +99,7 @@ def _dense_l41(Fq, Tq, S, seed):
     V = F.l2norm(u.reshape(Bq, -1), E)
     e_v = rel(host(V), V_ref)
     c = F.l41_loss(V.reshape(Bq, Tq, Fq, E), dev(y), st, dev(I, np.int32), True)
-    e_c = abs(float(c) - c_ref) / abs(c_ref)
+    e_c = abs(float(c.detach()) - c_ref) / abs(c_ref)
     c.backward()
     F.OVERLAP.join()
     errs = {'u': e_u, 'V': e_v, 'cost': e_c, 'dh': rel(host(ht.grad), dh_ref), 'dW': rel(host(Wt.grad), dW_ref),
