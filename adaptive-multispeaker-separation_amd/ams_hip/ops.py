@@ -328,22 +328,49 @@ LSTM_RING = _os.environ.get('AMS_LSTM_RING', '1')
 # 1 = the forward ring computes the layer's own input projection with four extra waves per workgroup (ams_blstm_ring_fwd_proj).
 # Parity-tested, measured SLOWER than the separate product, so off by default.
 LSTM_RING_PROJ = _os.environ.get('AMS_LSTM_RING_PROJ', '0') != '0'
-LAST_SYNC = []                                                      # most recent sync buffers (word 0 = timeout flag)
+LAST_SYNC = []                                                      # most recent sync buffers of the PERSISTENT-kernel form (word 0 = timeout flag)
+_RING_ERR = {}                                                      # device index -> int32[1]: the sticky error word of every ring launch
+
+
+def ring_error_word(device=None):
+    """The sticky error word handed to every ring-recurrence launch on this device (include/ams.h: sticky_err): the kernels set it
+    when a bounded in-launch wait gives up, nothing but ring_errors_clear() zeroes it.  One persistent buffer per device, so a
+    replayed hipGraph keeps writing to the word the host reads; the fused optimizers take it as their skip guard."""
+    dev = torch.cuda.current_device() if device is None else (device.index if hasattr(device, 'index') and device.index is not None
+                                                               else torch.cuda.current_device())
+    t = _RING_ERR.get(dev)
+    if t is None:
+        t = _RING_ERR[dev] = torch.zeros(1, dtype=torch.int32, device='cuda:%d' % dev)
+    return t
+
+
+def ring_error_pending():
+    """True when a ring launch since the last ring_errors_clear() abandoned a bounded wait (one host sync)."""
+    return any(bool(t.item() != 0) for t in _RING_ERR.values())
+
+
+def ring_errors_clear():
+    for t in _RING_ERR.values():
+        t.zero_()
 
 
 def persist_errors():
-    """Number of recent persistent-recurrence launches whose bounded in-launch wait timed out (host sync)."""
-    return sum(int(t[:1].view(torch.int32).item() != 0) for t in LAST_SYNC)
+    """Number of recent recurrence launches whose bounded in-launch wait timed out (host sync): the ring launches through their
+    sticky word, the persistent-kernel form through its per-launch sync buffers."""
+    return sum(int(t[:1].view(torch.int32).item() != 0) for t in LAST_SYNC) + int(ring_error_pending())
 
 
 def raise_on_ring_errors():
     """Fail loudly when a ring-recurrence launch gave up a bounded in-launch wait (csrc/lstm_ring.hip: its workgroups must all be
     resident at once; a co-running kernel that fills every CU's registers can keep some of them out past the wait limit).  The
-    step that launch belonged to is invalid.  One host sync; the trainer calls it where it fetches the cost anyway."""
-    if not LAST_SYNC:
-        return
-    flags = torch.stack([t[:1].view(torch.int32).reshape(()) for t in LAST_SYNC])
-    if bool((flags != 0).any().item()):
+    step that launch belonged to is invalid.  One host sync.  The trainer does not call this any more: it REPEATS such a step on
+    the per-step kernels (utils/trainer.py::Trainer._guarded); benches and tests do, where a repeat would hide what they measure."""
+    bad = ring_error_pending()
+    if LAST_SYNC:
+        flags = torch.stack([t[:1].view(torch.int32).reshape(()) for t in LAST_SYNC])
+        bad = bad or bool((flags != 0).any().item())
+    if bad:
+        ring_errors_clear()
         raise AmsError('a BLSTM ring recurrence launch abandoned a bounded wait: its workgroups were not all resident in time '
                        '(another kernel filled the CUs); the results of that step are invalid.  AMS_LSTM_RING=0 selects the '
                        'per-step recurrence kernels, which need no co-residency.')
@@ -384,12 +411,11 @@ def blstm_fwd(x, Kf, bf, Kb, bb, consumer=None):
         sync = _ws(nring, x)
         ev = PROFILE.begin() if PROFILE.enabled else None
         check(lib.ams_blstm_ring_fwd_proj(_p(x), D, _p(Kf), _p(Kb), ldu, _p(bf), _p(bb), _p(G), _p(out), _p(cst[0]), _p(cst[1]),
-                                          _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring, B, T, H, int(LSTM_RING == 'safe'), _s()),
+                                          _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring, _p(ring_error_word(x.device)), B, T, H,
+                                          int(LSTM_RING == 'safe'), _s()),
               'ams_blstm_ring_fwd_proj')
         if ev is not None:      # the projection's flops, attributed to the ring launch that now contains them
             PROFILE.end(ev, 2 * 2.0 * B * T * 4 * H * (D + H), 4.0 * (B * T * (D + 8 * H + 2 * H)), 'ring_fwd_proj', 'blstm_input_gemm_in_ring')
-        LAST_SYNC.append(sync)
-        del LAST_SYNC[:-8]
         return out, G, cst
     bands = _fwd_bands(T) if not (LSTM_PERSIST or nring or pre is not None or consumer is not None) else None
     if bands:
@@ -406,10 +432,8 @@ def blstm_fwd(x, Kf, bf, Kb, bb, consumer=None):
         return out, G, cst
     if nring:
         sync = _ws(nring, x)
-        check(lib.ams_blstm_ring_fwd(_p(G), _p(out), _p(cst[0]), _p(cst[1]), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring, B, T, H,
-                                     int(LSTM_RING == 'safe'), _s()), 'ams_blstm_ring_fwd')
-        LAST_SYNC.append(sync)
-        del LAST_SYNC[:-8]
+        check(lib.ams_blstm_ring_fwd(_p(G), _p(out), _p(cst[0]), _p(cst[1]), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring,
+                                     _p(ring_error_word(x.device)), B, T, H, int(LSTM_RING == 'safe'), _s()), 'ams_blstm_ring_fwd')
         return out, G, cst
     nsync = lib.ams_blstm_persist_sync_bytes(B, H, 0) if LSTM_PERSIST else 0
     if nsync:
@@ -610,9 +634,7 @@ def blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout):
         sync = _ws(nring, x)
         dbpart = torch.empty((B, 2, 4 * H), dtype=torch.float32, device=x.device)
         check(lib.ams_blstm_ring_bwd(_p(G), _p(cst[0]), _p(cst[1]), _p(dout), _p(dbpart), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring,
-                                     B, T, H, int(LSTM_RING == 'safe'), _s()), 'ams_blstm_ring_bwd')
-        LAST_SYNC.append(sync)
-        del LAST_SYNC[:-8]
+                                     _p(ring_error_word(x.device)), B, T, H, int(LSTM_RING == 'safe'), _s()), 'ams_blstm_ring_bwd')
         return dbpart
     pack = torch.empty(lib.ams_blstm_pack_floats(H, 1), dtype=torch.float32, device=x.device)
     nsync = lib.ams_blstm_persist_sync_bytes(B, H, 1) if LSTM_PERSIST else 0
@@ -929,20 +951,29 @@ def l41_speaker_bwd(table, I, d_vs, normalize):
 
 
 # ------------------------------------------------------------------ optimizers
-def opt_amsgrad(p, g, m, v, vhat, lr_t, beta1, beta2, eps, grad_scale=1.0):
+def _guard(p, guard):
+    """The optimizers' skip word: the device's sticky ring-error word unless the caller passes its own (or False for none)."""
+    if guard is False:
+        return None
+    return ring_error_word(p.device) if guard is None else guard
+
+
+def opt_amsgrad(p, g, m, v, vhat, lr_t, beta1, beta2, eps, grad_scale=1.0, guard=None):
     _chk(p, g, m, v, vhat)
-    check(load().ams_opt_amsgrad(_p(p), _p(g), _p(m), _p(v), _p(vhat), p.numel(), lr_t, beta1, beta2, eps, grad_scale, _s()),
-          'ams_opt_amsgrad')
+    check(load().ams_opt_amsgrad(_p(p), _p(g), _p(m), _p(v), _p(vhat), p.numel(), lr_t, beta1, beta2, eps, grad_scale,
+                                 _p(_guard(p, guard)), _s()), 'ams_opt_amsgrad')
 
 
-def opt_rmsprop(p, g, ms, lr, decay=0.9, eps=1e-10, grad_scale=1.0):
+def opt_rmsprop(p, g, ms, lr, decay=0.9, eps=1e-10, grad_scale=1.0, guard=None):
     _chk(p, g, ms)
-    check(load().ams_opt_rmsprop(_p(p), _p(g), _p(ms), p.numel(), lr, decay, eps, grad_scale, _s()), 'ams_opt_rmsprop')
+    check(load().ams_opt_rmsprop(_p(p), _p(g), _p(ms), p.numel(), lr, decay, eps, grad_scale, _p(_guard(p, guard)), _s()),
+          'ams_opt_rmsprop')
 
 
-def opt_momentum(p, g, acc, lr, momentum=0.9, grad_scale=1.0):
+def opt_momentum(p, g, acc, lr, momentum=0.9, grad_scale=1.0, guard=None):
     _chk(p, g, acc)
-    check(load().ams_opt_momentum(_p(p), _p(g), _p(acc), p.numel(), lr, momentum, grad_scale, _s()), 'ams_opt_momentum')
+    check(load().ams_opt_momentum(_p(p), _p(g), _p(acc), p.numel(), lr, momentum, grad_scale, _p(_guard(p, guard)), _s()),
+          'ams_opt_momentum')
 
 
 def sumsq(x):

@@ -92,6 +92,13 @@ class FlatOptimizer(object):
             scale *= self.clip / max(gn, self.clip)                           # tf.clip_by_global_norm
         return scale
 
+    def undo_counters(self):
+        """Host-side step counters back to before the last step() (whose device update the guard word skipped)."""
+        b1p, b2p, t = getattr(self, '_before', (None, None, self.t))
+        if b1p is not None:
+            self.b1p, self.b2p = b1p, b2p
+        self.t = t
+
     def _sumsq(self, t):
         return ops.sumsq(t).item() if t.is_cuda else float((t.double() ** 2).sum())
 
@@ -99,6 +106,11 @@ class FlatOptimizer(object):
         """Gradient exchange + clip + fused update.  Gradients must already be in flat_grad."""
         if self.flat.numel() == 0:
             return
+        self._before = (getattr(self, 'b1p', None), getattr(self, 'b2p', None), self.t)
+        if self.dist is not None and self.dist.world_size > 1 and self.flat.is_cuda and ops.LSTM_RING != '0':
+            # a rank whose recurrence ring gave up makes EVERY rank skip this update (the word is the optimizers' guard) and
+            # repeat the step: the gradients it would contribute to the all-reduce are garbage
+            self.dist.all_reduce_max(ops.ring_error_word(self.flat.device))
         scale = self.exchange()
         if self.kind == 'Adam':
             lr_t = self.base_lr * math.sqrt(1.0 - self.b2p) / (1.0 - self.b1p)

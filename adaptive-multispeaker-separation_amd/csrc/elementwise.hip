@@ -253,7 +253,11 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, float* __res
 
 // ---- optimizers (reference utils/ops.py:686-703; TF RMSProp/Momentum) ----
 __global__ void amsgrad_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
-                               float* __restrict__ vh, long n, float lr_t, float b1, float b2, float eps, float gscale) {
+                               float* __restrict__ vh, long n, float lr_t, float b1, float b2, float eps, float gscale,
+                               const unsigned* __restrict__ skip) {
+    // skip: a recurrence launch of this step gave up a bounded wait (csrc/lstm_ring.hip, sticky error word): its gradients are
+    // garbage -- leave parameters and slots untouched so that the caller can repeat the step on the per-step kernels
+    if (skip && *skip != 0u) return;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
@@ -264,7 +268,8 @@ __global__ void amsgrad_kernel(float* __restrict__ p, const float* __restrict__ 
     }
 }
 __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ ms, long n, float lr,
-                               float decay, float eps, float gscale) {
+                               float decay, float eps, float gscale, const unsigned* __restrict__ skip) {
+    if (skip && *skip != 0u) return;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
         const float s = decay * ms[i] + (1.0f - decay) * gi * gi;
@@ -273,7 +278,8 @@ __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ 
     }
 }
 __global__ void momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ acc, long n, float lr,
-                                float mom, float gscale) {
+                                float mom, float gscale, const unsigned* __restrict__ skip) {
+    if (skip && *skip != 0u) return;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float a = mom * acc[i] + g[i] * gscale;
         acc[i] = a;
@@ -377,24 +383,26 @@ ams_status ams_colsum(const float* x, float* out, long rows, int cols, long ld, 
 }
 
 ams_status ams_opt_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, long n, float lr_t, float beta1,
-                           float beta2, float eps, float grad_scale, void* stream) {
+                           float beta2, float eps, float grad_scale, const void* skip_if_set, void* stream) {
     AMS_REQUIRE(p && g && m && v && vhat && n > 0);
     hipLaunchKernelGGL(amsgrad_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vhat, n, lr_t, beta1,
-                       beta2, eps, grad_scale);
+                       beta2, eps, grad_scale, (const unsigned*)skip_if_set);
     return ams_check_launch();
 }
 
 ams_status ams_opt_rmsprop(float* p, const float* g, float* ms, long n, float lr, float decay, float eps, float grad_scale,
-                           void* stream) {
+                           const void* skip_if_set, void* stream) {
     AMS_REQUIRE(p && g && ms && n > 0);
-    hipLaunchKernelGGL(rmsprop_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, ms, n, lr, decay, eps, grad_scale);
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, ms, n, lr, decay, eps, grad_scale,
+                       (const unsigned*)skip_if_set);
     return ams_check_launch();
 }
 
 ams_status ams_opt_momentum(float* p, const float* g, float* accum, long n, float lr, float momentum, float grad_scale,
-                            void* stream) {
+                            const void* skip_if_set, void* stream) {
     AMS_REQUIRE(p && g && accum && n > 0);
-    hipLaunchKernelGGL(momentum_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, accum, n, lr, momentum, grad_scale);
+    hipLaunchKernelGGL(momentum_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, accum, n, lr, momentum, grad_scale,
+                       (const unsigned*)skip_if_set);
     return ams_check_launch();
 }
 

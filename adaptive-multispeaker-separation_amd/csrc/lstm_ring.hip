@@ -79,6 +79,8 @@ struct RingArgs {
     float* dbpart;              // backward, optional: [B,2,4H] = sum over t of da[b,t,dir,:] (bias-gradient partials)
     const float* Uf; const float* Ub; long ldu;
     unsigned* err;              // word 0 of the sync buffer
+    unsigned* sticky;           // optional: a word the CALLER owns and never zeroes per launch -- set whenever err is set, so that one
+                                // check at the caller's next host sync covers every ring launch since its last check
     unsigned* ids;              // [n_chains][IDS_STRIDE]   XCC id + 1 of every workgroup (placement agreement)
     unsigned* flags;            // [n_chains][IDS_STRIDE]   backward: last published step + 1
     float* xbuf;                // forward: granules [n_chains][2][TB][NW*4] float4; backward: partial tiles [n_chains][2][NW][NW][UW*TB]
@@ -134,11 +136,15 @@ __device__ __forceinline__ float ring_tanh(float x) {
 }
 
 // returns true when the wait must be abandoned (timeout here, or another ring already gave up)
-__device__ __forceinline__ bool spin_check(unsigned& spins, unsigned* err) {
+__device__ __forceinline__ bool spin_check(unsigned& spins, unsigned* err, unsigned* sticky) {
     ++spins;
     if ((spins & 255u) == 0u) {
         if (__hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return true;
-        if (spins >= SPIN_LIMIT) { __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }
+        if (spins >= SPIN_LIMIT) {
+            __hip_atomic_store(err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (sticky) __hip_atomic_store(sticky, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return true;
+        }
     }
     return false;
 }
@@ -186,7 +192,7 @@ __device__ __forceinline__ bool chain_shares_l2(const RingArgs& a, int chain, in
         for (;;) {
             v = (tid < a.NW) ? __hip_atomic_load(a.ids + chain * IDS_STRIDE + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 1u;
             if (__all(v != 0u)) break;
-            if (spin_check(spins, a.err)) { dead = true; break; }
+            if (spin_check(spins, a.err, a.sticky)) { dead = true; break; }
         }
         const unsigned first = __shfl(v, 0, 64);
         const bool same = __all(tid >= a.NW || v == first);
@@ -297,7 +303,7 @@ __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
 #pragma unroll
                     for (int i = 0; i < NR; ++i) ok &= (__float_as_uint(hv[i].w) == want);
                     if (__all(ok)) break;
-                    if (spin_check(spins, a.err)) { abort = true; break; }
+                    if (spin_check(spins, a.err, a.sticky)) { abort = true; break; }
                 }
             }
             tr.stamp(0);                                        // wait for h_{s-1}
@@ -533,7 +539,7 @@ __global__ __launch_bounds__(512) void lstm_ring_fwdp_kernel(RingArgs a) {
 #pragma unroll
                     for (int i = 0; i < NR; ++i) ok &= (__float_as_uint(hv[i].w) == want);
                     if (__all(ok)) break;
-                    if (spin_check(spins, a.err)) { abort = true; break; }
+                    if (spin_check(spins, a.err, a.sticky)) { abort = true; break; }
                 }
             }
             tr.stamp(0);                                        // wait for h_{s-1}
@@ -682,7 +688,7 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
             for (;;) {                                          // every wave watches its chain's flags itself: no extra barrier
                 const unsigned v = (lane < NW) ? (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rf, lane * 4, 0, 16) : 0xffffffffu;
                 if (__all(v >= (unsigned)s)) break;
-                if (spin_check(spins, a.err)) { abort = true; break; }
+                if (spin_check(spins, a.err, a.sticky)) { abort = true; break; }
             }
         }
         tr.stamp(0);                                            // flag wait
@@ -785,10 +791,25 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
     tr.end();
 }
 
+// Workgroups of the ring kernels this device can hold AT ONCE: CUs x 2 (what their registers admit), read from the device once.
+// MI355X in SPX mode: 256 x 2 = 512.  A CPX / DPX partition, a CU-masked process or a smaller part has fewer, and a ring that
+// is not fully resident would only ever time out.
+inline long ring_capacity() {
+    static const long cap = [] {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            return 512L;                                        // no device visible (build / CPU-side symbol tests): MI355X geometry
+        if (const char* f = getenv("AMS_LSTM_RING_CUS")) cus = atoi(f);      // testing aid: pretend a smaller partition
+        return 2L * cus;
+    }();
+    return cap;
+}
 inline bool ring_shape(int B, int H, int& NW, int& n_chains) {
     NW = ceil_div(H, UW);
     n_chains = 2 * ceil_div(B, TB);
-    return NW <= 4 * MAXR && ceil_div(NW * UW, 16) <= 4 * MAXT && (long)n_chains * NW <= 512;
+    // the grid is padded to whole groups of 8 chains (one chain per XCD id): count those workgroups, not only the live ones
+    const long grid = 8L * NW * ceil_div(n_chains, 8);
+    return NW <= 4 * MAXR && ceil_div(NW * UW, 16) <= 4 * MAXT && (long)n_chains * NW <= 512 && grid <= ring_capacity();
 }
 
 struct RingLayout { size_t ids, flags, x, total, head; };
@@ -858,7 +879,7 @@ size_t ams_blstm_ring_sync_bytes(int B, int H, int backward) {
 // (ams_blstm_ring_sync_bytes(B, H, 0) bytes, word 0 = timeout flag) and `tch` [B,T,2,H] = tanh(c_t), which the backward ring reads
 // instead of calling tanhf again.  safe bit 0 forces the placement-independent hand-off, bit 1 turns the phase trace on.
 ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, const float* Uf, const float* Ub, long ldu, void* sync,
-                              size_t sync_bytes, int B, int T, int H, int safe, void* stream) {
+                              size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream) {
     AMS_REQUIRE(G && out && cst && tch && Uf && Ub && sync && B > 0 && T > 0 && H > 0);
     int NW, n_chains;
     AMS_REQUIRE(ring_shape(B, H, NW, n_chains));
@@ -868,7 +889,7 @@ ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, cons
     if (hipMemsetAsync(sync, 0, L.head, st) != hipSuccess) return AMS_E_LAUNCH_FAILED;
     RingArgs a{};
     a.G = G; a.out = out; a.cst = cst; a.tch = tch; a.Uf = Uf; a.Ub = Ub; a.ldu = ldu;
-    a.err = (unsigned*)sync; a.ids = (unsigned*)((char*)sync + L.ids); a.flags = (unsigned*)((char*)sync + L.flags);
+    a.err = (unsigned*)sync; a.sticky = (unsigned*)sticky_err; a.ids = (unsigned*)((char*)sync + L.ids); a.flags = (unsigned*)((char*)sync + L.flags);
     a.xbuf = (float*)((char*)sync + L.x);
     a.B = B; a.T = T; a.H = H; a.NW = NW; a.n_chains = n_chains; a.force_safe = ((safe & 1) || ring_force_safe()) ? 1 : 0; a.trace = (safe & 2) ? 1 : 0;
     const dim3 grid(8 * NW * ceil_div(n_chains, 8));
@@ -888,7 +909,7 @@ ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, cons
 // each direction's [D+H,4H] kernel (row stride ldw), bf/bb the biases.  Requires ams_blstm_ring_proj_ok(D) (D % 4 == 0, D <= 640).
 ams_status ams_blstm_ring_fwd_proj(const float* x, int D, const float* Wxf, const float* Wxb, long ldw, const float* bf, const float* bb,
                                    float* G, float* out, float* cst, float* tch, const float* Uf, const float* Ub, long ldu, void* sync,
-                                   size_t sync_bytes, int B, int T, int H, int safe, void* stream) {
+                                   size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream) {
     AMS_REQUIRE(x && Wxf && Wxb && bf && bb && G && out && cst && tch && Uf && Ub && sync && B > 0 && T > 0 && H > 0);
     const int ngw = ring_proj_ngw(D);
     AMS_REQUIRE(ngw != 0 && (((uintptr_t)x) & 15) == 0);
@@ -901,7 +922,7 @@ ams_status ams_blstm_ring_fwd_proj(const float* x, int D, const float* Wxf, cons
     RingArgs a{};
     a.G = G; a.out = out; a.cst = cst; a.tch = tch; a.Uf = Uf; a.Ub = Ub; a.ldu = ldu;
     a.x = x; a.Wxf = Wxf; a.Wxb = Wxb; a.ldw = ldw; a.bf = bf; a.bb = bb; a.D = D;
-    a.err = (unsigned*)sync; a.ids = (unsigned*)((char*)sync + L.ids); a.flags = (unsigned*)((char*)sync + L.flags);
+    a.err = (unsigned*)sync; a.sticky = (unsigned*)sticky_err; a.ids = (unsigned*)((char*)sync + L.ids); a.flags = (unsigned*)((char*)sync + L.flags);
     a.xbuf = (float*)((char*)sync + L.x);
     a.B = B; a.T = T; a.H = H; a.NW = NW; a.n_chains = n_chains;
     a.force_safe = ((safe & 1) || ring_force_safe()) ? 1 : 0; a.trace = (safe & 2) ? 1 : 0;
@@ -915,7 +936,7 @@ ams_status ams_blstm_ring_fwd_proj(const float* x, int D, const float* Wxf, cons
 // Same contract as ams_blstm_recurrent_bwd (on return G holds da), without the dc workspace (the running dc lives in registers).
 // dbpart (optional, [B,2,4H]): receives sum_t da[b,t,dir,:] -- the bias gradient is then a column sum over B rows instead of B*T.
 ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* tch, const float* dout, float* dbpart, const float* Uf, const float* Ub,
-                              long ldu, void* sync, size_t sync_bytes, int B, int T, int H, int safe, void* stream) {
+                              long ldu, void* sync, size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream) {
     AMS_REQUIRE(G && cst && tch && dout && Uf && Ub && sync && B > 0 && T > 0 && H > 0);
     int NW, n_chains;
     AMS_REQUIRE(ring_shape(B, H, NW, n_chains));
@@ -925,7 +946,7 @@ ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* tch, cons
     if (hipMemsetAsync(sync, 0, L.head, st) != hipSuccess) return AMS_E_LAUNCH_FAILED;
     RingArgs a{};
     a.G = G; a.cst = const_cast<float*>(cst); a.tch = const_cast<float*>(tch); a.dout = dout; a.dbpart = dbpart; a.Uf = Uf; a.Ub = Ub; a.ldu = ldu;
-    a.err = (unsigned*)sync; a.ids = (unsigned*)((char*)sync + L.ids); a.flags = (unsigned*)((char*)sync + L.flags);
+    a.err = (unsigned*)sync; a.sticky = (unsigned*)sticky_err; a.ids = (unsigned*)((char*)sync + L.ids); a.flags = (unsigned*)((char*)sync + L.flags);
     a.xbuf = (float*)((char*)sync + L.x);
     a.B = B; a.T = T; a.H = H; a.NW = NW; a.n_chains = n_chains; a.force_safe = ((safe & 1) || ring_force_safe()) ? 1 : 0; a.trace = (safe & 2) ? 1 : 0;
     const dim3 grid(8 * NW * ceil_div(n_chains, 8));

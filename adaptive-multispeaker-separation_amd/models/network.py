@@ -322,33 +322,81 @@ class Network(object):
         self.last_run = run
         return cost.detach().reshape(-1)[0]
 
-    def infer(self, feed_dict, step):
-        run = self._feeds(feed_dict, False)
+    # ---- a recurrence ring that could not get all its workgroups resident gives up a bounded wait and flags it in the device's
+    # sticky error word (csrc/lstm_ring.hip, K.ring_error_word): the batch is then REPEATED on the per-step recurrence kernels,
+    # which need no co-residency -- safe rather than loud.  `ring_fallbacks` counts how often that happened.
+    ring_fallbacks = 0
+
+    def _inputs_of(self, run):
+        return [(n, n.value(run)) for n in (self.x_mix, self.x_non_mix, self.I)]
+
+    def _eval_guarded(self, feed_dict, fn, training=False):
+        """fn(run) without gradients; the same batch again on the per-step kernels when a ring launch gave up (one host sync: every
+        caller reads its results on the host anyway)."""
+        run = self._feeds(feed_dict, training)
         with torch.no_grad():
-            return [self.x_mix.value(run), self.x_non_mix.value(run), self.output.value(run)]
+            out = fn(run)
+        if K.LSTM_RING != '0' and K.ring_error_pending():
+            ins = self._inputs_of(run)
+            K.ring_errors_clear()
+            old, K.LSTM_RING = K.LSTM_RING, '0'
+            try:
+                run = self._feeds(feed_dict, training)
+                for n, t in ins:
+                    run.cache[id(n)] = t
+                with torch.no_grad():
+                    out = fn(run)
+            finally:
+                K.LSTM_RING = old
+            Network.ring_fallbacks += 1
+        return out
+
+    def retrain_last(self, step):
+        """Repeat the LAST training step on the per-step recurrence kernels.  Call when K.ring_error_pending() after train():
+        the fused optimizer has skipped that step's update (the error word is its guard), so weights and slots are those of before
+        the step; this runs the same batch eagerly with the ring off and applies the update.  Returns the cost."""
+        run0 = self.last_run
+        ins = self._inputs_of(run0)
+        opt = self.optimize
+        K.ring_errors_clear()
+        opt.undo_counters()
+        old, K.LSTM_RING = K.LSTM_RING, '0'
+        try:
+            run = Run(dict(run0.feeds), True)
+            for n, t in ins:
+                run.cache[id(n)] = t
+            opt.zero_grad()
+            cost = self.cost_model.value(run)
+            self._backward(cost)
+            F.OVERLAP.join()
+            opt.step()
+        finally:
+            K.LSTM_RING = old
+        Network.ring_fallbacks += 1
+        self.last_run = run
+        return cost.detach().reshape(-1)[0]
+
+    def infer(self, feed_dict, step):
+        return self._eval_guarded(feed_dict, lambda run: [self.x_mix.value(run), self.x_non_mix.value(run), self.output.value(run)])
 
     def improvement(self, feed_dict, step):
-        run = self._feeds(feed_dict, False)
-        with torch.no_grad():
-            return [self.x_mix.value(run), self.x_non_mix.value(run), self.sdr_imp.value(run)]
+        return self._eval_guarded(feed_dict, lambda run: [self.x_mix.value(run), self.x_non_mix.value(run), self.sdr_imp.value(run)])
 
     def valid_batch(self, feed_dict, step):
-        run = self._feeds(feed_dict, False)
-        with torch.no_grad():
+        def fn(run):
             cost = self.cost_model.value(run)
-            if getattr(self, 'merged_valid', None) and self.summaries_enabled:
+            return run, float(cost.reshape(-1)[0].item())
+        run, c = self._eval_guarded(feed_dict, fn)
+        if getattr(self, 'merged_valid', None) and self.summaries_enabled:
+            with torch.no_grad():
                 self.valid_writer.add(step, self._summaries(run, self.merged_valid))
-        return float(cost.reshape(-1)[0].item())
+        return c
 
     def get_embeddings(self, feed_dict):
-        run = self._feeds(feed_dict, False)
-        with torch.no_grad():
-            return self.prediction.value(run)
+        return self._eval_guarded(feed_dict, lambda run: self.prediction.value(run))
 
     def test_batch(self, feed_dict):
-        run = self._feeds(feed_dict, False)
-        with torch.no_grad():
-            return float(self.cost_model.value(run).reshape(-1)[0].item())
+        return self._eval_guarded(feed_dict, lambda run: float(self.cost_model.value(run).reshape(-1)[0].item()))
 
     def test(self, feed_dict):
         run = self._feeds(feed_dict, True)

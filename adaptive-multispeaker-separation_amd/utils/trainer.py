@@ -267,7 +267,11 @@ class Trainer(object):
                         self._say('Validation set tested in ', time.time() - t, ' seconds')
                         self._say('Validation set: ', mean)
                     c = float(c)                   # host sync, as sess.run returning the cost does
-                    ops.raise_on_ring_errors()     # a ring launch that timed out must not train on silently
+                    if ops.ring_error_pending():
+                        # a ring recurrence of this step could not get its workgroups resident in time: the optimizer skipped
+                        # the update (the sticky error word is its guard); the same batch again on the per-step kernels
+                        c = float(self.model.retrain_last(step))
+                        self._say('recurrence ring gave up a bounded wait: step repeated on the per-step kernels')
                     window = window[1:] + [time.time() - mark]
                     avg = sum(window) / len(window)
                     self._say('Epoch #', epoch + 1, '/', epochs, ' Batch #', b + 1, '/', n_train, 'in', avg, 'sec loss=', c,

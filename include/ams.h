@@ -143,14 +143,19 @@ ams_status ams_blstm_persist_bwd(float* G, const float* cst, const float* dout, 
  * whose members do not share an L2, or safe != 0, use write-through stores instead of plain ones).  Forward: h_t travels as
  * 16-byte {3 values, step tag} granules; backward: partial dh tiles (reduce-scatter) + one flag per producer.
  * ams_blstm_ring_sync_bytes returns 0 when the shape cannot use it (H > 336, or more than 512 workgroups): callers then use
- * ams_blstm_recurrent_fwd/bwd.  sync word 0 (uint32) is non-zero after the launch if a bounded in-launch wait timed out.
+ * ams_blstm_recurrent_fwd/bwd; so does a device whose CUs cannot hold the whole grid at once (occupancy query, cached).  sync word 0
+ * (uint32) is non-zero after the launch if a bounded in-launch wait timed out; sticky_err (may be NULL) is a uint32 the CALLER owns
+ * and clears: it is set whenever word 0 is, so ONE read at the caller's next host sync covers every ring launch since its last
+ * check -- also the launches inside a replayed hipGraph, whose per-launch sync buffers nobody looks at again.  The optimizers take
+ * the same word as `skip_if_set` and leave parameters and slots untouched when it is non-zero, so a step whose recurrence gave up
+ * can be repeated on the per-step kernels instead of being trained on.
  * tch [B,T,2,H]: tanh(c_t), written by the forward ring and read by the backward one (cst keeps c_t).  safe: bit 0 forces the
  * write-through hand-off, bit 1 records a per-phase cycle trace in the sync header (tools/ring_anatomy.py).
  * dbpart (backward, may be NULL): [B,2,4H] receives sum_t d pre-activation[b,t,dir,:]; the bias gradients are its column sums.
  * Replaces the same dynamic_rnn while_loop (utils/ops.py:358-383). */
 size_t ams_blstm_ring_sync_bytes(int B, int H, int backward);
 ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, const float* Uf, const float* Ub, long ldu, void* sync,
-                              size_t sync_bytes, int B, int T, int H, int safe, void* stream);
+                              size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream);
 /* Forward ring with the layer's input projection z_t = x_t.Wx + b computed INSIDE it by four extra waves per workgroup that work one step
  * ahead of the ring (the ring's MFMA pipes idle ~55 % of a step otherwise): replaces ams_gemm_f32 (projection) + ams_blstm_ring_fwd.  G is output only (activated gates).
  * x [B,T,D]; Wxf / Wxb: the input rows of the two direction kernels, row stride ldw; ams_blstm_ring_proj_ok(B, H, D): D % 4 == 0,
@@ -158,9 +163,9 @@ ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, cons
 int ams_blstm_ring_proj_ok(int B, int H, int D);
 ams_status ams_blstm_ring_fwd_proj(const float* x, int D, const float* Wxf, const float* Wxb, long ldw, const float* bf, const float* bb,
                                    float* G, float* out, float* cst, float* tch, const float* Uf, const float* Ub, long ldu, void* sync,
-                                   size_t sync_bytes, int B, int T, int H, int safe, void* stream);
+                                   size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream);
 ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* tch, const float* dout, float* dbpart, const float* Uf, const float* Ub,
-                              long ldu, void* sync, size_t sync_bytes, int B, int T, int H, int safe, void* stream);
+                              long ldu, void* sync, size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream);
 
 /* ---- K13  tf.nn.l2_normalize over groups of E       utils/ops.py:323-324 ---- */
 ams_status ams_l2norm_fwd(const float* u, float* v, float* inv, long rows, int E, void* stream);
@@ -267,11 +272,11 @@ ams_status ams_sumsq_bwd(const float* x, const float* upstream, float scale, flo
 
 /* ---- K24  optimizers     models/network.py:181-194, utils/ops.py:686-703 ---- */
 ams_status ams_opt_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, long n, float lr_t, float beta1,
-                           float beta2, float eps, float grad_scale, void* stream);
+                           float beta2, float eps, float grad_scale, const void* skip_if_set, void* stream);
 ams_status ams_opt_rmsprop(float* p, const float* g, float* ms, long n, float lr, float decay, float eps, float grad_scale,
-                           void* stream);
+                           const void* skip_if_set, void* stream);
 ams_status ams_opt_momentum(float* p, const float* g, float* accum, long n, float lr, float momentum, float grad_scale,
-                            void* stream);
+                            const void* skip_if_set, void* stream);
 ams_status ams_sumsq(const float* x, float* out, long n, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- framed products: out[(r,t), n] = sum_k xpad[r, t*hop + k - pad_left] * Bm[k, n]   (K6 STFT as a DFT product,

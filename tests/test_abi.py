@@ -31,8 +31,10 @@ def test_ops_refuse_cpu_tensors():
 
 
 def test_ring_timeout_is_loud(monkeypatch):
-    """A ring-recurrence launch that gave up a bounded wait leaves a non-zero word 0 in its sync buffer (csrc/lstm_ring.hip); the
-    trainer and bench.py call ops.raise_on_ring_errors() at their host sync, so such a step cannot be trained on or timed silently."""
+    """A persistent-recurrence launch that gave up a bounded wait leaves a non-zero word 0 in its sync buffer; ring launches set the
+    device's sticky error word (csrc/lstm_ring.hip, ops.ring_error_word).  bench.py and the tests call ops.raise_on_ring_errors()
+    at their host sync, so such a step cannot be timed silently; the trainer repeats it on the per-step kernels instead
+    (tests/test_gpu_ring_guard.py)."""
     torch = pytest.importorskip('torch')
     from ams_hip import ops, AmsError
     ok, bad = torch.zeros(8), torch.zeros(8)

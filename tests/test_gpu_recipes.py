@@ -569,3 +569,36 @@ def test_restore_from_tensorflow_bundle_matches_npz():
         tr = Front_Separator_Inference(DPCL, 'front_DPCL_inference', **a)
         outs.append(_infer(tr, L)[2])
     assert np.array_equal(outs[0], outs[1])
+
+
+def test_tf_eval_cli_on_a_pretrained_checkpoint():
+    """python -m experiments.evaluation.tf_eval --model pretraining (reference experiments/evaluation/tf_eval.py:1-38): the CLI's
+    running mean equals the batch-size-weighted mean of the ORACLE's SDR improvement (models/network.py:196-221) of the oracle's
+    own reconstruction, batch by batch over the test split."""
+    from ams_hip import testing
+    from experiments.evaluation import tf_eval
+    from oracle import losses as olosses
+    from utils.trainer import Pretrained_Inference
+    tmp = tempfile.mkdtemp(prefix='ams_tfeval_')
+    B, S, L, W, N, hop = 3, 2, 2048, 64, 16, 16
+    folder, params = testing.make_pretrained_adapt(os.path.join(tmp, 'pre'), window_size=W, filters=N, hop_size=hop, chunk_size=L,
+                                                   batch_size=B, nb_speakers=S, separation='perfect')
+    argv = ['--model_folder', folder, '--model', 'pretraining', '--dataset', 'synthetic', '--batch_size', str(B), '--chunk_size', str(L),
+            '--nb_speakers', str(S), '--window_size', str(W), '--filters', str(N), '--hop_size', str(hop), '--separation', 'perfect',
+            '--men', '--women']
+    sdr, n = tf_eval.main(argv)
+    assert n >= 1 and np.isfinite(sdr)
+    # the same split again (same command line), through the oracle
+    tr, _ = tf_eval.build(argv)
+    assert isinstance(tr, Pretrained_Inference)
+    tot, cnt = 0.0, 0
+    for xm, xn, imp in tr.sdr_improvement():
+        xm, xn = xm.cpu().numpy().astype(np.float64), xn.cpu().numpy().astype(np.float64)
+        P = {k: v.detach().cpu().numpy().astype(np.float64) for k, v in tr.graph.variables.items()}
+        back = orec.pretrained_infer(xm, xn, P, hop, 'perfect')
+        val, _ = olosses.sdr_improvement(xm, xn, back)
+        val = float(np.mean(val))
+        assert abs(float(imp) - val) < 1e-3 * max(1.0, abs(val)), (float(imp), val)
+        tot += val * B
+        cnt += 1
+    assert cnt == n and abs(sdr - tot / (cnt * B)) < 1e-3 * max(1.0, abs(sdr)), (sdr, tot / (cnt * B))

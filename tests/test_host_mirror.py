@@ -147,3 +147,20 @@ def test_kmeans_reference_seeding():
     assert got.dtype == np.int32 and np.array_equal(got, ref) and after_got == after_ref
     fast = KMeans._draw(types.SimpleNamespace(nb_clusters=C, seeding='fast'), 200, 50).numpy()
     assert fast.shape == (200, C) and all(len(set(r)) == C for r in fast.tolist()) and fast.min() >= 0 and fast.max() < 50
+
+
+def test_tf_eval_running_mean_and_model_choices():
+    """experiments/evaluation/tf_eval.py:27-38: batch-size-weighted running mean of the per-batch in-graph SDR improvement, NaN
+    batches skipped; --model choices the reference leaves without an inferencer exit instead of crashing with a NameError."""
+    import numpy as np
+    import pytest
+    from experiments.evaluation import tf_eval
+    batches = [(None, None, np.float32(3.0)), (None, None, np.float32('nan')), (None, None, np.array([5.0], np.float32))]
+    sdr, n = tf_eval.running_sdr(batches, batch_size=4, verbose=False)
+    assert n == 2 and abs(sdr - 4.0) < 1e-6
+    assert np.isnan(tf_eval.running_sdr([], 4, verbose=False)[0])
+    assert set(tf_eval.INFERENCERS) == {'front_L41', 'STFT_L41', 'front_L41_enhance', 'pretraining'}
+    with pytest.raises(SystemExit):
+        tf_eval.main(['--model_folder', '/nonexistent', '--model', 'front_L41_finetuned'])
+    with pytest.raises(SystemExit):                                       # --model is required (utils/trainer.py:112-117)
+        tf_eval.main(['--model_folder', '/nonexistent'])

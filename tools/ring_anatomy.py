@@ -37,11 +37,11 @@ for mode, safe in (('plain stores (same L2)', 2), ('write-through', 3)):
         torch.cuda.synchronize()
         if kind == 'fwdp':
             ops.check(lib.ams_blstm_ring_fwd_proj(p(x), D, p(Kf), p(Kb), ldu, p(bf), p(bb), p(G), p(out), p(cst[0]), p(cst[1]), p(Kf[D:]), p(Kb[D:]),
-                                                  ldu, p(sync), n, B, T, H, safe, st), 'fp')
+                                                  ldu, p(sync), n, None, B, T, H, safe, st), 'fp')
         elif kind == 'fwd':
-            ops.check(lib.ams_blstm_ring_fwd(p(G), p(out), p(cst[0]), p(cst[1]), p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, B, T, H, safe, st), 'f')
+            ops.check(lib.ams_blstm_ring_fwd(p(G), p(out), p(cst[0]), p(cst[1]), p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, None, B, T, H, safe, st), 'f')
         else:
-            ops.check(lib.ams_blstm_ring_bwd(p(G), p(cst[0]), p(cst[1]), p(dout), None, p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, B, T, H, safe, st), 'b')
+            ops.check(lib.ams_blstm_ring_bwd(p(G), p(cst[0]), p(cst[1]), p(dout), None, p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, None, B, T, H, safe, st), 'b')
         torch.cuda.synchronize()
         w = sync[:64].view(torch.int64).cpu().numpy()
         ph = w[8:8 + len(names[kind])] / float(T)
@@ -70,9 +70,9 @@ if '--beside' in sys.argv:
             torch.cuda._sleep(200000)                         # let the product fill the chip first (~100 us)
             e0.record()
             if kind == 'bwd':
-                ops.check(lib.ams_blstm_ring_bwd(p(G), p(cst[0]), p(cst[1]), p(dout), None, p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, B, T, H, 2, st), 'b')
+                ops.check(lib.ams_blstm_ring_bwd(p(G), p(cst[0]), p(cst[1]), p(dout), None, p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, None, B, T, H, 2, st), 'b')
             else:
-                ops.check(lib.ams_blstm_ring_fwd(p(G), p(out), p(cst[0]), p(cst[1]), p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, B, T, H, 2, st), 'f')
+                ops.check(lib.ams_blstm_ring_fwd(p(G), p(out), p(cst[0]), p(cst[1]), p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, None, B, T, H, 2, st), 'f')
             e1.record()
             torch.cuda.synchronize()
             w = sync[:64].view(torch.int64).cpu().numpy()
