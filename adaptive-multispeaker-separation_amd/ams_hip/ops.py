@@ -52,22 +52,38 @@ def _twin(a, b):
 
 
 class _Profile(object):
-    """HIP-event timing of individual launches on the launching stream (bench.py `roofline`).  Events are
-    recorded around a launch only when enabled; elapsed times are read after the timed region."""
+    """Timing of individual launches on the launching stream (bench.py `roofline`).  Two modes: HIP events around a launch (eager
+    launches), or device-clock STAMPS (ams_stamp: one-thread kernels writing the constant-rate wall clock) -- the only form that
+    survives hipGraph capture: stamps recorded while a graph is being captured are replayed with it, so the durations read back
+    are those of the launches INSIDE the replayed graph (each includes its two ~1.5 us kernel boundaries to the stamp kernels)."""
 
     def __init__(self):
         self.reset(False)
 
-    def reset(self, enabled=False):
+    def reset(self, enabled=False, stamps=False):
         self.enabled = enabled
-        self.records = []            # (start_event, stop_event, flops, bytes, tag, label)
+        self.stamps = bool(stamps)
+        self.records = []            # (start, stop, flops, bytes, tag, label): events, or stamp slots
+        self.buf = torch.zeros(8192, dtype=torch.int64, device='cuda') if (enabled and stamps) else None
+        self.nslots = 0
 
     def begin(self):
+        if self.stamps:
+            slot = self.nslots
+            self.nslots += 2
+            if self.nslots > self.buf.numel():
+                raise AmsError('profile: more than %d stamped launches' % (self.buf.numel() // 2))
+            check(load().ams_stamp(_p(self.buf), slot, _s()), 'ams_stamp')
+            return slot
         e = torch.cuda.Event(enable_timing=True)
         e.record(torch.cuda.current_stream())
         return e
 
     def end(self, start, flops=0.0, nbytes=0.0, tag='', label=''):
+        if self.stamps:
+            check(load().ams_stamp(_p(self.buf), start + 1, _s()), 'ams_stamp')
+            self.records.append((start, start + 1, flops, nbytes, tag, label))
+            return
         e = torch.cuda.Event(enable_timing=True)
         e.record(torch.cuda.current_stream())
         self.records.append((start, e, flops, nbytes, tag, label))
@@ -79,6 +95,8 @@ class _Profile(object):
         torch.cuda.synchronize()
         ms = fl = by = 0.0
         n = 0
+        ticks = self.buf.cpu().numpy() if self.stamps and self.buf is not None else None
+        rate = float(load().ams_stamp_rate()) if self.stamps else 1.0
         for s, e, f, b, t, lab in self.records:
             if tag is not None and t != tag:
                 continue
@@ -86,7 +104,7 @@ class _Profile(object):
                 continue
             if prefix is not None and not t.startswith(prefix):
                 continue
-            ms += s.elapsed_time(e)
+            ms += (float(ticks[e] - ticks[s]) / rate * 1e3) if self.stamps else s.elapsed_time(e)
             fl += f
             by += b
             n += 1

@@ -307,9 +307,24 @@ __global__ void sum_final_kernel(const float* __restrict__ part, float* __restri
     if (threadIdx.x == 0) out[0] = sm[0] + sm[1] + sm[2] + sm[3];
 }
 
+// one device-clock stamp (constant 100 MHz counter): brackets a launch INSIDE a captured hipGraph, where HIP events cannot be read back
+__global__ void stamp_kernel(unsigned long long* __restrict__ buf, int slot) { buf[slot] = wall_clock64(); }
+
 }  // namespace
 
 extern "C" {
+
+ams_status ams_stamp(void* buf, int slot, void* stream) {
+    AMS_REQUIRE(buf && slot >= 0);
+    hipLaunchKernelGGL(stamp_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (unsigned long long*)buf, slot);
+    return ams_check_launch();
+}
+/* ticks per second of the ams_stamp counter */
+long ams_stamp_rate(void) {
+    int dev = 0, khz = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev) != hipSuccess || khz <= 0) return 100000000L;
+    return (long)khz * 1000L;
+}
 
 int ams_last_error(void) { return g_ams_last_hip_error; }
 int ams_abi_version(void) { return AMS_ABI_VERSION; }

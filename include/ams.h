@@ -278,6 +278,10 @@ ams_status ams_opt_rmsprop(float* p, const float* g, float* ms, long n, float lr
 ams_status ams_opt_momentum(float* p, const float* g, float* accum, long n, float lr, float momentum, float grad_scale,
                             const void* skip_if_set, void* stream);
 ams_status ams_sumsq(const float* x, float* out, long n, void* ws, size_t ws_bytes, void* stream);
+/* measurement aid: buf[slot] (uint64) = the device's constant-rate wall clock when the stream reaches this point; ams_stamp_rate() =
+ * its ticks per second.  Stamps bracket launches INSIDE a replayed hipGraph (HIP events recorded during capture cannot be read back). */
+ams_status ams_stamp(void* buf, int slot, void* stream);
+long ams_stamp_rate(void);
 
 /* ---- framed products: out[(r,t), n] = sum_k xpad[r, t*hop + k - pad_left] * Bm[k, n]   (K6 STFT as a DFT product,
  * tf.contrib.signal.stft models/network.py:482-492; also the generic form of K2) ---- */

@@ -420,3 +420,27 @@ def test_kmeans_oracle_matches_sklearn_lloyd():
         km = sk.KMeans(n_clusters=C, init=Xn[i][init[i]], n_init=1, max_iter=iters, tol=0.0, algorithm='lloyd').fit(Xn[i])
         assert np.allclose(km.cluster_centers_, cent[i], atol=1e-10)
         assert np.array_equal(km.labels_, labels[i])
+
+
+def test_torch_cpu_step_matches_the_numpy_oracle():
+    """oracle/torch_step.py (the timed CPU baseline of bench.py: torch-CPU / oneDNN formulation, fused nn.LSTM kernel with the TF cell
+    re-laid out) against oracle/step.py::front_dpcl_loss in float64: cost, every gradient, and one AMSGrad update."""
+    from oracle import torch_step
+    rng = np.random.RandomState(1)
+    B, S, L, W, N, hop, LS, NL, E = 3, 2, 1024, 64, 16, 16, 16, 2, 8
+    P = step.init_params(rng, np.float64, front_W=W, N=N, D_in=N, layer_size=LS, nb_layers=NL, E=E, F=N, conv1d_scale=0.05)
+    xn = rng.randn(B, S, L) * 0.1
+    xm = xn.sum(1)
+    c_ref, g_ref, _, _ = step.front_dpcl_loss(xm, xn, P, hop, NL, E)
+    ts = torch_step.FrontDPCLStep(P, hop, NL, E, lr=1e-3, dtype=torch.float64)
+    c = ts.step(torch.tensor(xm), torch.tensor(xn))
+    assert abs(c - c_ref) < 1e-12 * abs(c_ref)
+    names = sorted(g_ref)
+    assert names == ts.names
+    for n in names:
+        assert rel(ts.P[n].grad.numpy(), g_ref[n]) < 1e-11, n
+    opt = optim.AMSGrad(1e-3)
+    plist = [P[n].copy() for n in names]
+    opt.apply(plist, [g_ref[n] for n in names])
+    for n, p in zip(names, plist):
+        assert rel(ts.P[n].detach().numpy(), p) < 1e-11, n
