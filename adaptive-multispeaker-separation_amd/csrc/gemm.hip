@@ -1419,6 +1419,91 @@ __global__ __launch_bounds__(256) void gather_filter_grad_kernel(const float* __
     }
     if (k < W) part[((long)blockIdx.z * W + k) * N + n] = s;
 }
+// LDS-staged form of the same sum (the default).  For one (row r, frame t) the windows of ALL filters start inside one pooling
+// window, so they lie inside one short segment of the row: [min_n pos, max_n pos + W).  The kernel above re-reads that segment
+// from L2 once per filter (4 KB x R*T*N = 16 GB per launch at the path-B shape, 2.2 ms); here a workgroup = 256 taps x 64 filters
+// x a slice of the (r, t) pairs stages the part of the segment its taps need ONCE in LDS and every thread accumulates 4 taps x 16
+// filters in registers from it (8-byte LDS reads; a second copy of the segment shifted by one sample serves the odd shifts).
+constexpr int GF_TAPS = 256, GF_FILT = 64, GF_SEG = 1536;      // segment capacity: spread of the positions + 256 taps + 1
+__global__ __launch_bounds__(256) void gather_filter_grad_lds_kernel(const float* __restrict__ x, const float* __restrict__ v,
+                                                                     const int32_t* __restrict__ pos, float* __restrict__ part, int R,
+                                                                     int L, int W, int N, int T, int pl, int rdiv, long pairs_per_z) {
+    __shared__ __attribute__((aligned(16))) float seg0[GF_SEG + 8], seg1[GF_SEG + 8];
+    __shared__ float sv[GF_FILT];
+    __shared__ int ss[GF_FILT], smm[2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int k0 = blockIdx.x * GF_TAPS, n0 = blockIdx.y * GF_FILT;
+    const long q_lo = (long)blockIdx.z * pairs_per_z, q_hi = min((long)R * T, q_lo + pairs_per_z);
+    float acc[16][4];
+#pragma unroll
+    for (int a = 0; a < 16; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
+    for (long q = q_lo; q < q_hi; ++q) {
+        const int r = (int)(q / T), t = (int)(q - (long)r * T);
+        if (tid < 64) {
+            const int n = n0 + tid;
+            const bool live = n < N;
+            const int p = live ? pos[((long)(r / rdiv) * T + t) * N + n] : 0;
+            sv[tid] = live ? v[((long)r * T + t) * N + n] : 0.f;
+            int mn = live ? p : 0x7fffffff, mx = live ? p : -0x7fffffff;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { mn = min(mn, __shfl_xor(mn, o, 64)); mx = max(mx, __shfl_xor(mx, o, 64)); }
+            ss[tid] = live ? p - mn : 0;
+            if (tid == 0) { smm[0] = mn; smm[1] = mx; }
+        }
+        __syncthreads();
+        const int mn = smm[0], span = smm[1] - mn;                 // workgroup-uniform
+        const float* xr = x + (long)r * L;
+        if (span + GF_TAPS + 1 <= GF_SEG) {
+            const int base = mn - pl + k0, len = span + GF_TAPS + 1;
+            for (int i = tid; i < len; i += 256) {
+                const int pp = base + i;
+                const float val = (pp >= 0 && pp < L) ? xr[pp] : 0.f;
+                seg0[i] = val;
+                if (i > 0) seg1[i - 1] = val;                      // seg1[i] = seg0[i + 1]
+            }
+            __syncthreads();
+#pragma unroll
+            for (int nn = 0; nn < 16; ++nn) {
+                const int f = wave * 16 + nn;
+                const int sh = ss[f];
+                const float vv = sv[f];
+                // taps 2 lane, 2 lane + 1 and + 128: seg[sh + kk], seg[sh + kk + 1] as ONE 8-byte read (even index into seg0, or seg1 shifted)
+                const float* sb = (sh & 1) ? (seg1 + (sh - 1)) : (seg0 + sh);
+                const float2 a = *reinterpret_cast<const float2*>(sb + 2 * lane);
+                const float2 b = *reinterpret_cast<const float2*>(sb + 2 * lane + 128);
+                acc[nn][0] = fmaf(vv, a.x, acc[nn][0]);
+                acc[nn][1] = fmaf(vv, a.y, acc[nn][1]);
+                acc[nn][2] = fmaf(vv, b.x, acc[nn][2]);
+                acc[nn][3] = fmaf(vv, b.y, acc[nn][3]);
+            }
+        } else {                                                  // positions spread wider than the staging buffer: direct reads
+#pragma unroll
+            for (int nn = 0; nn < 16; ++nn) {
+                const int f = wave * 16 + nn;
+                const int p0 = mn + ss[f] - pl + k0;
+                const float vv = sv[f];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int pp = p0 + 2 * lane + (j & 1) + 128 * (j >> 1);
+                    acc[nn][j] = fmaf(vv, (pp >= 0 && pp < L) ? xr[pp] : 0.f, acc[nn][j]);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int k = k0 + 2 * lane + (j & 1) + 128 * (j >> 1);
+        if (k >= W) continue;
+#pragma unroll
+        for (int nn = 0; nn < 16; ++nn) {
+            const int n = n0 + wave * 16 + nn;
+            if (n < N) part[((long)blockIdx.z * W + k) * N + n] = acc[nn][j];
+        }
+    }
+}
 __global__ void gather_filter_reduce_kernel(const float* __restrict__ part, float* __restrict__ df, long WN, int nz) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= WN) return;
@@ -1565,7 +1650,21 @@ ams_status ams_transpose_f32(const float* in, float* out, int rows, int cols, vo
 }
 
 static int gather_nz(int R) { int nz = R / 16; if (nz < 1) nz = 1; if (nz > 16) nz = 16; return nz; }
-size_t ams_gather_filter_grad_workspace_bytes(int R, int W, int N) { return (size_t)gather_nz(R) * W * N * sizeof(float); }
+// slices of the (r, t) pairs of the LDS-staged form: ~1024 workgroups in all
+static int gather_nz_lds(int R, int W, int N, int T) {
+    const long tiles = (long)ceil_div(W, GF_TAPS) * ceil_div(N, GF_FILT);
+    long nz = 1024 / tiles;
+    if (nz < 1) nz = 1;
+    if (nz > 128) nz = 128;
+    if (nz > (long)R * T) nz = (long)R * T;
+    return (int)nz;
+}
+static bool gather_use_lds() { static const bool v = getenv("AMS_GATHER_LDS") == nullptr || atoi(getenv("AMS_GATHER_LDS")) != 0; return v; }
+size_t ams_gather_filter_grad_workspace_bytes(int R, int W, int N) {
+    // the caller does not pass T: size for the larger of the two forms (<= 128 slices)
+    const size_t a = (size_t)gather_nz(R) * W * N * sizeof(float), b = (size_t)128 * W * N * sizeof(float);
+    return gather_use_lds() ? (a > b ? a : b) : a;
+}
 
 // df[k,n] = sum_{r,t} xpad[r, pos[r/rdiv,t,n] + k - pl] * v[r,t,n]   (max-pool front: x = waveforms, v = dy, rdiv = 1;
 // sparse synthesis: x = d out, v = pooled values, rdiv = S because the mixture's positions are tiled over speakers)
@@ -1573,8 +1672,16 @@ ams_status ams_gather_filter_grad(const float* x, const float* v, const int32_t*
                                   int rdiv, void* ws, size_t ws_bytes, void* stream) {
     AMS_REQUIRE(x && v && pos && df && ws && R > 0 && L > 0 && W > 0 && N > 0 && T > 0 && rdiv > 0);
     if (ws_bytes < ams_gather_filter_grad_workspace_bytes(R, W, N)) return AMS_E_WORKSPACE_TOO_SMALL;
-    const int nz = gather_nz(R), rpz = ceil_div(R, nz);
     hipStream_t st = (hipStream_t)stream;
+    if (gather_use_lds()) {
+        const int nz = gather_nz_lds(R, W, N, T);
+        const long ppz = ((long)R * T + nz - 1) / nz;
+        hipLaunchKernelGGL(gather_filter_grad_lds_kernel, dim3(ceil_div(W, GF_TAPS), ceil_div(N, GF_FILT), nz), dim3(256), 0, st, x, v, pos,
+                           (float*)ws, R, L, W, N, T, (W - 1) / 2, rdiv, ppz);
+        hipLaunchKernelGGL(gather_filter_reduce_kernel, dim3(ceil_div((long)W * N, 256)), dim3(256), 0, st, (const float*)ws, df, (long)W * N, nz);
+        return ams_check_launch();
+    }
+    const int nz = gather_nz(R), rpz = ceil_div(R, nz);
     hipLaunchKernelGGL(gather_filter_grad_kernel, dim3(ceil_div(W, 256), N, nz), dim3(256), 0, st, x, v, pos, (float*)ws, R, L, W, N, T,
                        (W - 1) / 2, rdiv, rpz);
     hipLaunchKernelGGL(gather_filter_reduce_kernel, dim3(ceil_div((long)W * N, 256)), dim3(256), 0, st, (const float*)ws, df, (long)W * N, nz);

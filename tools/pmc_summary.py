@@ -12,15 +12,31 @@ import sqlite3
 import sys
 
 
+# launch grid (workgroups) -> what that launch is in the B=64 front_DPCL step (bench.py): the product family runs many shapes under
+# one kernel name, and traffic only means something per shape
+STEP_SHAPES = {
+    ('<2, 0', 240): 'front conv 15360x256x1024 (3-way split-K)', ('<0, 0', 400): 'projection 5120x2400xD', ('<0, 0', 1600): 'dense fwd 5120x10240x600',
+    ('<0, 1', 1000): 'dX 5120x600xK (dense: K=10240 5-way split-K / LSTM: K=2400)', ('<1, 0', 1000): 'dense dW 600x10240x5120',
+    ('<1, 0', 250): 'LSTM dWx 600x2400x5120', ('<1, 0', 240): 'LSTM dU 2x300x1200x5120 / L0 dWx 256x2400x5120',
+}
+
+
 def per_kernel(path, counter):
     db = sqlite3.connect(path)
-    rows = db.execute("select kernel_name, grid_size_x, grid_size_y, value from counters_collection where counter_name=?",
+    cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
+    wg = 'workgroup_size_x' if 'workgroup_size_x' in cols else '256'
+    rows = db.execute("select kernel_name, grid_size_x, %s, value from counters_collection where counter_name=?" % wg,
                       (counter,)).fetchall()
     out = {}
-    for name, gx, gy, v in rows:
-        # the fp32 product family runs many shapes under one name: keep them apart by launch grid
-        m = re.search(r'gemm_f32_kernel<[^>]*>', name)
-        key = name if m is None else '%s grid=%d' % (m.group(0), int(gx) // 256)
+    for name, gx, wx, v in rows:
+        # the product family runs many shapes under one name: keep them apart by launch grid (= by shape)
+        m = re.search(r'gemm_(f32|x6|x3)_kernel<[^>]*>', name)
+        if m is None:
+            key = name
+        else:
+            nwg = int(gx) // max(1, int(wx))
+            what = next((v2 for (pre, g), v2 in STEP_SHAPES.items() if g == nwg and m.group(0).split('kernel')[1].startswith(pre)), '')
+            key = '%s grid=%d%s' % (m.group(0), nwg, (' [' + what + ']') if what else '')
         out.setdefault(key, []).append(float(v))
     return out
 
@@ -28,7 +44,7 @@ def per_kernel(path, counter):
 def short(n):
     n = n.replace('(anonymous namespace)::', '').replace('void ', '')
     if ' grid=' in n:
-        return n[:70]
+        return n[:120]
     return n.split('(')[0][:70]
 
 
@@ -39,14 +55,14 @@ def main():
     names = sorted(set(f) | set(w), key=lambda n: -(2 * sum(f.get(n, [0])) + sum(w.get(n, [0]))))
     lines = ['# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only); MB per launch',
              '# read = 2 x FETCH_SIZE (gfx950 correction), write = WRITE_SIZE as reported; ' + desc,
-             '%-72s %7s %12s %12s %12s' % ('kernel', 'calls', 'read_MB', 'write_MB', 'total_MB')]
+             '%-120s %7s %12s %12s %12s' % ('kernel', 'calls', 'read_MB', 'write_MB', 'total_MB')]
     js = {}
     for n in names:
         fv, wv = f.get(n, []), w.get(n, [])
         calls = max(len(fv), len(wv))
         rd = 2.0 * sum(fv) / max(1, len(fv)) * 1024 / 1e6
         wr = sum(wv) / max(1, len(wv)) * 1024 / 1e6
-        lines.append('%-72s %7d %12.3f %12.3f %12.3f' % (short(n), calls, rd, wr, rd + wr))
+        lines.append('%-120s %7d %12.3f %12.3f %12.3f' % (short(n), calls, rd, wr, rd + wr))
         js[short(n)] = {'calls': calls, 'read_MB_per_launch': round(rd, 4), 'write_MB_per_launch': round(wr, 4)}
     open(sys.argv[3], 'w').write('\n'.join(lines) + '\n')
     if len(sys.argv) > 4 and sys.argv[4]:
