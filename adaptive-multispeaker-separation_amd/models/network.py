@@ -151,7 +151,10 @@ class Network(object):
             bundle = tf_checkpoint.read_bundle(prefix, names=set(self.saver))
             for name in self.saver:
                 if name not in bundle:
-                    raise KeyError('variable %s not found in TensorFlow checkpoint %s' % (name, prefix))
+                    # the BLSTM / dense / speaker-vector names are inferred from the reference's scopes, never
+                    # observed in a TensorFlow-written file: say what the bundle does hold, so a renamed variable is one edit away
+                    have = sorted(tf_checkpoint.list_bundle(prefix)[1])
+                    raise KeyError('variable %s not found in TensorFlow checkpoint %s; the bundle holds: %s' % (name, prefix, ', '.join(have)))
                 v = g.variables[name]
                 arr = bundle[name]
                 if tuple(arr.shape) != tuple(v.shape):

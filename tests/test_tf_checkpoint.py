@@ -219,3 +219,24 @@ def test_reader_on_snappy_compressed_blocks(tmp_path):
     assert sorted(got) == sorted(arrays)
     for k in arrays:
         assert np.array_equal(got[k], arrays[k]) and got[k].dtype == arrays[k].dtype
+
+
+def test_missing_variable_error_lists_what_the_bundle_holds(tmp_path):
+    """The BLSTM / dense variable names of a reference checkpoint are inferred: when one is not in the bundle the
+    error must name what IS there, so that a renamed variable is one edit away instead of a silent zero-fill."""
+    import types
+    import torch
+    from models.network import Network
+    folder = str(tmp_path)
+    tfc.write_bundle(os.path.join(folder, 'model-3'), {'front/window/w': np.ones(4, np.float32), 'prediction/weights_typo': np.zeros((2, 2), np.float32)})
+    open(os.path.join(folder, 'checkpoint'), 'w').write('model_checkpoint_path: "model-3"\n')
+    fake = types.SimpleNamespace(saver=['front/window/w', 'prediction/W'])
+    from ams_hip.graph import Graph
+    g = Graph()
+    with g.as_default():
+        from ams_hip.graph import get_scope_variable  # noqa: F401
+        g.variables['front/window/w'] = torch.zeros(4)
+        g.variables['prediction/W'] = torch.zeros(2, 2)
+        with pytest.raises(KeyError) as e:
+            Network.restore_model(fake, folder)
+    assert 'prediction/W' in str(e.value) and 'prediction/weights_typo' in str(e.value) and 'front/window/w' in str(e.value)
