@@ -79,8 +79,11 @@ void ams_gemm_set_lds_pad(int bytes);
  * split EXACTLY into three bf16 terms (hi + mid + lo, round-to-nearest) and six of the nine bf16 x bf16 partial products (all but
  * mid.lo, lo.mid, lo.lo <= 2^-26 |a.b|) are accumulated in f32 on v_mfma_f32_32x32x16_bf16, which gfx950 issues at 16x the rate
  * of its f32 MFMA; results carry f32-level error (tests/test_gpu_gemm_x6.py: against float64, next to mode 0).  0 = native
- * v_mfma_f32_32x32x2_f32.  Launches whose operands are not 16-byte addressable use mode 0 whatever the setting.  The workspace
- * size of a product depends on the mode: size and launch under the same one. */
+ * v_mfma_f32_32x32x2_f32.  Launches whose operands are not 16-byte addressable use mode 0 whatever the setting.  Inf / NaN
+ * operands give NaN in mode 1 (inf - inf in the split) where mode 0 propagates Inf.  The workspace size a query returns depends
+ * on the mode and on the lds pad (they select the tile configuration, hence the split-K count), but a workspace sized under
+ * another setting is NEVER an error: a launch uses as many split-K slabs as the workspace it is given holds (down to none) --
+ * a mismatch costs speed, not correctness; the results differ only in summation order (both inside the tested tolerances). */
 void ams_gemm_set_arith(int mode);
 int ams_gemm_get_arith(void);
 ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C,

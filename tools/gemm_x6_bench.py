@@ -38,8 +38,10 @@ def main():
     ap.add_argument('--warm', type=int, default=100, help='untimed launches first (the clock ramps up from idle over milliseconds)')
     ap.add_argument('--only', default='', help='comma-separated substrings of the product labels to run')
     ap.add_argument('--modes', default='0,1', help='arithmetics to time: 0 native f32, 1 bf16x6')
+    ap.add_argument('--pad', type=int, default=0, help='dynamic-LDS pad = residency cap of the launches (the step uses 50000 beside a ring)')
     a = ap.parse_args()
     lib = load()
+    lib.ams_gemm_set_lds_pad(a.pad)
     rng = np.random.RandomState(0)
     only = [w for w in a.only.split(',') if w]
     for label, M, N, K, tA, tB in SHAPES:
