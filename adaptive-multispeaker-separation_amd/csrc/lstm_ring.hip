@@ -58,6 +58,9 @@
 // s_sleep units (64 cycles) the P waves wait behind each step barrier: the R waves' gate epilogue is VALU work, and VALU issue of
 // one wave all but stops while its SIMD partner streams MFMAs (measured: epilogue 1300 -> 5000 cycles beside the projection,
 // whatever the two priorities); delays of 0 / 770 / 1800 / 2560 cycles all measured the same 452-475 us per layer (D = 600)
+#ifndef AMS_RING_X6_DEFAULT
+#define AMS_RING_X6_DEFAULT 1
+#endif
 #ifndef AMS_RING_P_DELAY
 #define AMS_RING_P_DELAY 0
 #endif
@@ -208,7 +211,27 @@ __device__ __forceinline__ bool chain_shares_l2(const RingArgs& a, int chain, in
 // NR = ceil(NW / 4) producer rounds per wave, a COMPILE-TIME bound: the MFMA chain is then straight-line code (rounds past a wave's
 // last producer multiply clamped granules with zero weights); a run-time `wave + 4 i < NW` test per round costs a branch and
 // accumulator copies per MFMA.
-template <int NR>
+// X6 (round 3): the recurrent product h_{t-1} . U on the bf16 pipe as f32 arithmetic -- exact three-way bf16 split of both operands, six
+// partial products, the five small ones in their own accumulator (csrc/gemm.hip, SEP) -- on v_mfma_f32_16x16x32_bf16: 54 MFMAs of
+// ~17 cycles instead of 63 of 32 per wave and step.  U's slice lives in registers as three bf16 images (108 VGPRs instead of 63);
+// h_{t-1} is split on arrival: every lane already holds exactly the 8 k-slots per MFMA its A fragment needs, because an MFMA's k
+// order is free as long as A and B agree (slot e = 3 i + j of lane group q <-> k = 12 r_i + 3 q + j on both sides).
+typedef __bf16 rbf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 rbf16x2_t __attribute__((ext_vector_type(2)));
+typedef float rf32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned ring_pk_bf16(float a, float b) {
+    const rf32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, rbf16x2_t));
+}
+__device__ __forceinline__ void ring_split3(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
+    hi = ring_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(hi << 16), rb = b - __uint_as_float(hi & 0xffff0000u);
+    mid = ring_pk_bf16(ra, rb);
+    const float sa = ra - __uint_as_float(mid << 16), sb = rb - __uint_as_float(mid & 0xffff0000u);
+    lo = ring_pk_bf16(sa, sb);
+}
+
+template <int NR, bool X6 = false>
 __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
     __shared__ __attribute__((aligned(16))) float red[2][4][3][64][4];     // [step parity][wave][column tile][lane][reg]
     __shared__ int lds_flag;
@@ -240,6 +263,28 @@ __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
                 bw[i][j][t] = (r < NW && k < H && unit < H) ? U[(long)k * a.ldu + gate * H + unit] : 0.f;
             }
         }
+    }
+
+    // X6: the same weights as three bf16 images, 8 k-slots per lane and MFMA: slot e = 3 i + j, MFMA m = e / 8 (zero beyond 3 NR)
+    constexpr int NM = X6 ? (3 * NR + 7) / 8 : 1;
+    rbf16x8_t bq[NM][3][3];                                        // [MFMA][column tile][plane hi / mid / lo]
+    if constexpr (X6) {
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                unsigned hi[4], mid[4], lo[4];
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    const int e0 = 8 * m + 2 * pr, e1 = e0 + 1;
+                    const float v0 = e0 < 3 * NR ? bw[e0 / 3][e0 % 3][t] : 0.f, v1 = e1 < 3 * NR ? bw[e1 / 3][e1 % 3][t] : 0.f;
+                    ring_split3(v0, v1, hi[pr], mid[pr], lo[pr]);
+                }
+                const uint4 h4 = {hi[0], hi[1], hi[2], hi[3]}, m4 = {mid[0], mid[1], mid[2], mid[3]}, l4 = {lo[0], lo[1], lo[2], lo[3]};
+                bq[m][t][0] = __builtin_bit_cast(rbf16x8_t, h4);
+                bq[m][t][1] = __builtin_bit_cast(rbf16x8_t, m4);
+                bq[m][t][2] = __builtin_bit_cast(rbf16x8_t, l4);
+            }
     }
 
     // epilogue element of this thread: (row, local unit); 16 threads per row, 12 of them live
@@ -315,14 +360,47 @@ __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
             }
 #endif
             if (s > 0) {
+                if constexpr (X6) {
+                    f32x4 accs[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                    rbf16x8_t aq[NM][3];
 #pragma unroll
-                for (int i = 0; i < NR; ++i) {
+                    for (int m = 0; m < NM; ++m) {
+                        unsigned hi[4], mid[4], lo[4];
 #pragma unroll
-                    for (int t3 = 0; t3 < 3; ++t3) acc[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i].x, bw[i][0][t3], acc[t3], 0, 0, 0);
+                        for (int pr = 0; pr < 4; ++pr) {
+                            const int e0 = 8 * m + 2 * pr, e1 = e0 + 1;
+                            const float v0 = e0 < 3 * NR ? (e0 % 3 == 0 ? hv[e0 / 3].x : e0 % 3 == 1 ? hv[e0 / 3].y : hv[e0 / 3].z) : 0.f;
+                            const float v1 = e1 < 3 * NR ? (e1 % 3 == 0 ? hv[e1 / 3].x : e1 % 3 == 1 ? hv[e1 / 3].y : hv[e1 / 3].z) : 0.f;
+                            ring_split3(v0, v1, hi[pr], mid[pr], lo[pr]);
+                        }
+                        const uint4 h4 = {hi[0], hi[1], hi[2], hi[3]}, m4 = {mid[0], mid[1], mid[2], mid[3]}, l4 = {lo[0], lo[1], lo[2], lo[3]};
+                        aq[m][0] = __builtin_bit_cast(rbf16x8_t, h4);
+                        aq[m][1] = __builtin_bit_cast(rbf16x8_t, m4);
+                        aq[m][2] = __builtin_bit_cast(rbf16x8_t, l4);
+                    }
+                    constexpr int PA[6] = {2, 0, 1, 1, 0, 0};           // lo.hi, hi.lo, mid.mid, mid.hi, hi.mid | hi.hi: smallest first
+                    constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
 #pragma unroll
-                    for (int t3 = 0; t3 < 3; ++t3) acc[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i].y, bw[i][1][t3], acc[t3], 0, 0, 0);
+                    for (int pp = 0; pp < 6; ++pp)
 #pragma unroll
-                    for (int t3 = 0; t3 < 3; ++t3) acc[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i].z, bw[i][2][t3], acc[t3], 0, 0, 0);
+                        for (int m = 0; m < NM; ++m)
+#pragma unroll
+                            for (int t3 = 0; t3 < 3; ++t3) {
+                                if (pp < 5) accs[t3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[m][PA[pp]], bq[m][t3][PB[pp]], accs[t3], 0, 0, 0);
+                                else acc[t3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq[m][PA[pp]], bq[m][t3][PB[pp]], acc[t3], 0, 0, 0);
+                            }
+#pragma unroll
+                    for (int t3 = 0; t3 < 3; ++t3) acc[t3] += accs[t3];
+                } else {
+#pragma unroll
+                    for (int i = 0; i < NR; ++i) {
+#pragma unroll
+                        for (int t3 = 0; t3 < 3; ++t3) acc[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i].x, bw[i][0][t3], acc[t3], 0, 0, 0);
+#pragma unroll
+                        for (int t3 = 0; t3 < 3; ++t3) acc[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i].y, bw[i][1][t3], acc[t3], 0, 0, 0);
+#pragma unroll
+                        for (int t3 = 0; t3 < 3; ++t3) acc[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i].z, bw[i][2][t3], acc[t3], 0, 0, 0);
+                    }
                 }
             }
         }
@@ -826,6 +904,12 @@ inline RingLayout ring_layout(int NW, int n_chains, int backward) {
     return L;
 }
 
+// AMS_LSTM_RING_X6 (read once): 1 = the forward ring's recurrent product on the bf16 pipe (bf16x6), 0 = v_mfma_f32_16x16x4_f32
+inline bool ring_fwd_x6() {
+    static const bool v = getenv("AMS_LSTM_RING_X6") ? atoi(getenv("AMS_LSTM_RING_X6")) != 0 : AMS_RING_X6_DEFAULT;
+    return v;
+}
+
 inline int ring_force_safe() {
     static const int v = getenv("AMS_LSTM_RING_SAFE") ? atoi(getenv("AMS_LSTM_RING_SAFE")) : 0;     // read once; testing aid
     return v;
@@ -893,6 +977,18 @@ ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, cons
     a.xbuf = (float*)((char*)sync + L.x);
     a.B = B; a.T = T; a.H = H; a.NW = NW; a.n_chains = n_chains; a.force_safe = ((safe & 1) || ring_force_safe()) ? 1 : 0; a.trace = (safe & 2) ? 1 : 0;
     const dim3 grid(8 * NW * ceil_div(n_chains, 8));
+    if (ring_fwd_x6()) {
+        switch (ceil_div(NW, 4)) {
+            case 1: hipLaunchKernelGGL((lstm_ring_fwd_kernel<1, true>), grid, dim3(256), 0, st, a); break;
+            case 2: hipLaunchKernelGGL((lstm_ring_fwd_kernel<2, true>), grid, dim3(256), 0, st, a); break;
+            case 3: hipLaunchKernelGGL((lstm_ring_fwd_kernel<3, true>), grid, dim3(256), 0, st, a); break;
+            case 4: hipLaunchKernelGGL((lstm_ring_fwd_kernel<4, true>), grid, dim3(256), 0, st, a); break;
+            case 5: hipLaunchKernelGGL((lstm_ring_fwd_kernel<5, true>), grid, dim3(256), 0, st, a); break;
+            case 6: hipLaunchKernelGGL((lstm_ring_fwd_kernel<6, true>), grid, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((lstm_ring_fwd_kernel<7, true>), grid, dim3(256), 0, st, a); break;
+        }
+        return ams_check_launch();
+    }
     switch (ceil_div(NW, 4)) {
         case 1: hipLaunchKernelGGL(lstm_ring_fwd_kernel<1>, grid, dim3(256), 0, st, a); break;
         case 2: hipLaunchKernelGGL(lstm_ring_fwd_kernel<2>, grid, dim3(256), 0, st, a); break;

@@ -259,3 +259,17 @@ def test_ring_recurrence_is_bit_stable_under_uneven_load(ops):
                                        % (rep, i, float((g - r).abs().max()), ops.persist_errors()))
     assert ops.persist_errors() == 0
     ops.raise_on_ring_errors()
+
+
+def test_forward_ring_on_the_f32_pipe_still_matches():
+    """The forward ring's recurrent product runs as bf16x6 on v_mfma_f32_16x16x32_bf16 by default (csrc/lstm_ring.hip, X6; every test
+    above ran that).  AMS_LSTM_RING_X6=0 selects the round-2 form on v_mfma_f32_16x16x4_f32 (read once per process): the same
+    benchmark-shape layer test in a child process."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, '-m', 'pytest', os.path.join(root, 'tests', 'test_gpu_benchshape.py'), '-q', '-x', '-k',
+                        'test_blstm_layer_at_benchmark_shape and (600-1 or 256-1)'], env=dict(os.environ, AMS_LSTM_RING_X6='0'),
+                       capture_output=True, text=True, timeout=900, cwd=root)
+    assert r.returncode == 0 and '2 passed' in r.stdout, r.stdout[-1500:]
