@@ -57,6 +57,10 @@ class Network(object):
         if kwargs is not None and len(kwargs):
             self.folder = kwargs['type']
             self.S = kwargs['nb_speakers']
+            if self.S > 4:
+                # the permutation-invariant cost kernels (ams_pair_stats_*, ams_pair_combine_*: csrc/synth.hip) hold the S x S pair
+                # table and the S! permutations of at most four speakers; say so at construction, not as AMS_E_INVALID_ARG in a step
+                raise ValueError('--nb_speakers %d: the PIT / SDR cost kernels support at most 4 speakers' % self.S)
             self.args = kwargs
             self.learning_rate = kwargs['learning_rate']
             self.my_opt = kwargs['optimizer']

@@ -3,7 +3,7 @@
 
 ``MyArgs`` keeps the reference's flag names and defaults; ``Trainer.train`` keeps its
 loop (train -> every validation_step validate -> save-if-best -> epoch-end lr decay -> final validation,
-restore best, test); the 15 recipe classes (same names and constructor signatures) are generated from the ``WIRING`` table
+restore best, test); the 13 recipe classes (same names and constructor signatures; the reference's two `Adapt_Enhance` / `MultiChannel_Pretrainer` classes are not on the path) are generated from the ``WIRING`` table
 below, which states what each one builds, restores, freezes and optimises.  Additions (all optional): ``--synthetic_batches``,
 ``--synthetic_pool`` (synthetic data source size), ``--no_summaries``, ``--hip_graph``; data parallelism is picked up from
 torchrun's environment (WORLD_SIZE/RANK/LOCAL_RANK), one process per GPU, RCCL all-reduce of gradients.

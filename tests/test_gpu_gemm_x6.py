@@ -298,3 +298,29 @@ def test_x6_capped_recurrent_kernel_gradient_bias_is_bounded(ops, arith, capped)
     m1, r1 = _bias_stats(c1, ref, np.sqrt(M))
     print('capped batched dU: native mean %.2e rms %.2e | bf16x6 (one accumulator) mean %.2e rms %.2e' % (m0, r0, m1, r1))
     assert abs(m1) < CAPPED_BIAS_BOUND and r1 <= 1.5 * r0, (m0, r0, m1, r1)
+
+
+def test_mask_separator_nan_rows_agree_under_both_arithmetics(ops, arith):
+    """Pre-training with --separation mask computes mix * (non_mix / mix) (models/adapt.py:179-184): NaN wherever the mixture
+    representation is exactly zero (0 * inf), by the reference's design.  Those NaNs then enter the synthesis product z . f2^T
+    (adapt.py:236-243).  The bf16x6 arithmetic turns Inf operands into NaN (inf - inf in its split) where the f32 MFMA propagates
+    Inf -- but what reaches the product here is already NaN, so both arithmetics must mark exactly the same outputs as NaN and
+    agree on every finite one."""
+    rng = np.random.RandomState(8)
+    B, S, T, N, W = 2, 2, 12, 16, 64
+    y = rng.randn(B * (S + 1), T, N)
+    y[0, 3, 5] = 0.0                       # mixture bin exactly zero, sources non-zero: nm / 0 = +-inf, 0 * inf = NaN
+    y[1, 7, :] = 0.0                       # a whole silent mixture frame
+    y[1 + B + 2, 7, 2] = 0.0               # with a zero source bin too: 0 / 0 = NaN
+    z = ops.pretrain_separator_fwd(dev(y), B, S, 'mask')
+    zh = host(z)
+    assert np.isnan(zh).sum() >= 1 + N and not np.isinf(zh).any()
+    f2 = rng.randn(W, N)
+    zr = z.reshape(B * S * T, N)
+    c0, c1 = both(arith, lambda: host(ops.gemm(zr, dev(f2), transB=True)))
+    assert np.array_equal(np.isnan(c0), np.isnan(c1))
+    assert not np.isinf(c0).any() and not np.isinf(c1).any()
+    nan_rows = np.isnan(zh).reshape(B * S * T, N).any(axis=1)
+    assert np.isnan(c1[nan_rows]).all() and np.isfinite(c1[~nan_rows]).all()
+    fin = ~np.isnan(c0)
+    assert np.abs(c0[fin] - c1[fin]).max() < 1e-5 * np.abs(c0[fin]).max()
