@@ -1,10 +1,80 @@
 """Host side of the batched k-means (reference models/Kmeans_2.py:12-195): same constructor and `.network` /
 `.fit` surface; the Lloyd iterations, restarts, inertia selection and final assignment run in csrc/kmeans.hip."""
+import os
+import threading
+
 import numpy as np
 import torch
 
 from . import functional as F
 from .graph import Node, Placeholder, get_default_graph
+
+
+class _ReferenceSeeds(object):
+    """np.random.choice(range(l), size=C, replace=False) for R rows from numpy's GLOBAL generator (Kmeans_2.py:61-66), through
+    libams_host.so::ams_mt_choice_rows (csrc/host/mt_choice.c): the same values and the same stream position afterwards, ~15x
+    faster than the per-row numpy calls (which shuffle all l bins to keep C of them).
+
+    One batch ahead: after serving a draw the worker thread computes the NEXT draw of the same shape from the state this one left
+    (ctypes releases the GIL, so it runs beside the GPU launches of the current batch).  The speculation is used only if, at the
+    next call, numpy's global state is still exactly the state it started from (nobody else drew in between) and the shape is
+    the same; otherwise it is dropped and the draw is made on the spot -- the stream numpy users see never depends on it."""
+
+    def __init__(self):
+        self._fn = None
+        self._spec = None               # (thread, key0, pos0, (R, L, C), box)
+        self.ahead = os.environ.get('AMS_KMEANS_SEED_AHEAD', '1') != '0'
+        self.hits = 0
+
+    def _native(self):
+        if self._fn is None:
+            import ctypes
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'libams_host.so')
+            try:
+                fn = ctypes.CDLL(path).ams_mt_choice_rows
+                fn.restype = ctypes.c_int
+                fn.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+                self._fn = fn
+            except (OSError, AttributeError):
+                self._fn = False
+        return self._fn
+
+    def _run(self, key, pos, shape, box):
+        R, L, C = shape
+        out = np.empty((R, C), np.int32)
+        p = np.array([pos], np.int32)
+        rc = self._fn(key.ctypes.data, p.ctypes.data, R, L, C, out.ctypes.data)
+        box.append((rc, out, key, int(p[0])))
+
+    def draw(self, R, L, C):
+        fn = self._native()
+        st = np.random.get_state()
+        if not fn or st[0] != 'MT19937' or C > L or R == 0:          # numpy's own path (and its own error for C > L)
+            return np.array([np.random.choice(L, size=C, replace=False) for _ in range(R)]).astype(np.int32).reshape(R, C)
+        key0, pos0, shape = np.ascontiguousarray(st[1], dtype=np.uint32), int(st[2]), (R, L, C)
+        box, spec, self._spec = None, self._spec, None
+        if spec is not None:
+            th, k, p, sh, b = spec
+            th.join()
+            if sh == shape and p == pos0 and np.array_equal(k, key0):
+                box = b
+                self.hits += 1
+        if box is None:
+            box = []
+            self._run(key0.copy(), pos0, shape, box)
+        rc, out, key1, pos1 = box[0]
+        if rc != 0:
+            raise RuntimeError('ams_mt_choice_rows failed (%d)' % rc)
+        np.random.set_state((st[0], key1, pos1, st[3], st[4]))
+        if self.ahead:
+            nb = []
+            th = threading.Thread(target=self._run, args=(key1.copy(), pos1, shape, nb), daemon=True)
+            th.start()
+            self._spec = (th, key1.copy(), pos1, shape, nb)
+        return out
+
+
+_REFERENCE_SEEDS = _ReferenceSeeds()
 
 
 class KMeans(object):
@@ -40,14 +110,14 @@ class KMeans(object):
         models/network.py:17-18) -- index work is bit-exact with the reference given the same stream position
         (tests/test_host_mirror.py::test_kmeans_reference_seeding).  `choice(l, ...)` consumes exactly the stream of
         `choice(range(l), ...)` (both are permutation(l)[:C]) without building a list per row.  The draw is inherently serial
-        (a full Fisher-Yates shuffle of l bins per row: ~0.15 ms x 640 rows at the benchmark shape, far above the 6 ms the GPU
-        needs for the batch), so throughput runs may opt into `seeding='fast'` (--kmeans_seeding fast): the same distribution
+        (every row consumes a data-dependent number of MT19937 words: ~27 k for l = 20480); _ReferenceSeeds makes it through the
+        C helper, one batch ahead on a worker thread, which still costs ~20-40 us x 640 rows at the benchmark shape -- above the
+        6 ms the GPU needs for the batch -- so throughput runs may opt into `seeding='fast'` (--kmeans_seeding fast): the same distribution
         (C distinct bins, uniform) in one vectorised call from the same global RNG, rows with a repeated index redrawn -- a
         DIFFERENT stream, hence different (equally valid) restarts."""
         C = self.nb_clusters
         if self.seeding == 'reference':
-            a = np.array([np.random.choice(L, size=C, replace=False) for _ in range(R)])
-            return torch.from_numpy(a.astype(np.int32))
+            return torch.from_numpy(_REFERENCE_SEEDS.draw(R, L, C))
         a = np.random.randint(0, L, size=(R, C))
         if C > 1:
             while True:

@@ -26,13 +26,14 @@ thread_local int t_gemm_lds_pad = 0;
 std::atomic<int> g_gemm_arith{-1};        // -1: not chosen yet (AMS_GEMM_X6, default 1), 0: native f32 MFMA, 1: bf16x6
 
 // Tuning overrides (A/B runs only): read from the environment ONCE per process, never on the launch path.
-struct GemmTuning { int group_m, splits, x6cfg, x6rule; bool noprio, novec; };
+struct GemmTuning { int group_m, splits, x6cfg, x6rule, x6persist; bool noprio, novec; };
 inline const GemmTuning& tuning() {
     static const GemmTuning t = [] {
         GemmTuning v{0, 0, -1, 2, false, false};
         if (const char* f = getenv("AMS_GEMM_GROUP_M")) v.group_m = atoi(f);
         if (const char* f = getenv("AMS_GEMM_SPLITS")) v.splits = atoi(f);
         v.noprio = getenv("AMS_GEMM_NOPRIO") != nullptr;
+        { const char* e = getenv("AMS_X6_PERSIST"); v.x6persist = e ? atoi(e) : 1; }
         v.novec = getenv("AMS_GEMM_NOVEC") != nullptr;
         if (const char* f = getenv("AMS_GEMM_X6CFG")) v.x6cfg = atoi(f);       // force one bf16x6 tile configuration (0, 1 or 3: X6Cfg)
         if (const char* f = getenv("AMS_GEMM_X6RULE")) v.x6rule = atoi(f);
@@ -140,14 +141,14 @@ __device__ __forceinline__ float loadB1(const GemmArgs& g, int k, int n) {
 }
 
 // Work item of this workgroup: (batch z, k-split, output tile).  Shifts the operand pointers of a batched launch.
-__device__ __forceinline__ void locate_tile(GemmArgs& g, int& split, int& tile_m, int& tile_n, int bm = BM, int bn = BN) {
+__device__ __forceinline__ void locate_tile(GemmArgs& g, int& split, int& tile_m, int& tile_n, int bm = BM, int bn = BN, int vbid = -1) {
     const int tiles_m = (g.M + bm - 1) / bm, tiles_n = (g.N + bn - 1) / bn;
     const int ntiles = tiles_m * tiles_n;
     int bid, zb;
     {
         const int nz = g.nbatch > 1 ? g.nbatch : 1;
         const int items = ntiles * g.splits * nz;               // == gridDim.x
-        int item = blockIdx.x;
+        int item = vbid >= 0 ? vbid : (int)blockIdx.x;
 #if AMS_GEMM_XCD_FLAT
         const int q = items / 8, r = items % 8, xcd = item % 8, idx = item / 8;
         item = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
@@ -620,7 +621,14 @@ __device__ __forceinline__ int x6_slot(int n) { return (n & 3) * (R / 4) + (((n 
 __device__ __forceinline__ float comp4(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
 template <int AMODE, int BMODE, int CFG, int EPI, bool SEP>
-__device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) {
+// PERSISTENT over work items (round 3): the grid is at most one resident set of workgroups (ams_gemm launch: 256 CUs x the
+// configuration's workgroups per CU) and a workgroup walks items blockIdx.x, + gridDim.x, ... .  The operands of the NEXT item's first
+// k-tile are requested BEFORE the epilogue stores of the finished one, so the stores (210 MB for the dense forward product: ~10 us per
+// round of 256 tiles with every workgroup storing at once, and nothing else resident on the CU to hide them) drain under the next
+// item's main loop instead of in front of the next workgroup's launch.  gridDim.x is a multiple of 8 (or the whole item count), so
+// an item stays on the XCD the flat order meant it for.
+__device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const smem) {
+    GemmArgs g = g0;
     using C = X6Cfg<CFG>;
     constexpr int BK = X6_BK, BMX = C::BMX, BNX = C::BNX, TM = C::TM, TN = C::TN;
     constexpr int NT = C::WMC * C::WNC * 64;
@@ -636,12 +644,12 @@ __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) 
     const int wm = wave / C::WNC, wn = wave % C::WNC;
     const int l31 = lane & 31, lk = lane >> 5;
 
-    int split, tile_m, tile_n;
-    locate_tile(g, split, tile_m, tile_n, BMX, BNX);
-    const int m0 = tile_m * BMX, n0 = tile_n * BNX;
-    const int k_begin = split * g.k_per_split;
-    const int k_end = min(g.K, k_begin + g.k_per_split);
-    const int nk = (k_end - k_begin + BK - 1) / BK;
+    // only the two-accumulator (uncapped, alone-on-the-CU) variants walk items: the capped single-accumulator ones are sized to sit
+    // beside a recurrence ring and the walk costs them 20-40 VGPRs (next item's staging registers live over the epilogue)
+    constexpr bool PERSIST = SEP && EPI == EPI_STORE;
+    const int n_items = (int)((long)((g0.M + BMX - 1) / BMX) * ((g0.N + BNX - 1) / BNX) * g0.splits * (g0.nbatch > 1 ? g0.nbatch : 1));
+    int vbid = blockIdx.x;
+    int split, tile_m, tile_n, m0, n0, k_begin, k_end, nk;
 
     // SEP: two accumulator sets (64 x 64 waves, launches that are not residency-capped -- with 64 more VGPRs a workgroup no longer
     // shares a CU with a recurrence ring): hi.hi goes to `acc`, the five small partial products to `accs`, added once in the epilogue.  The bf16 MFMA adds its 16 products to the accumulator with the bits below its internal
@@ -650,12 +658,6 @@ __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) 
     // the f32 MFMA rounds to nearest: 0.00).  Small products into their own accumulator are truncated 2^-8 lower: 6x less bias.
     static_assert(!SEP || TM * TN <= 4, "no registers for a second accumulator set on 128 x 64 waves");
     f32x16 acc[TM][TN], accs[SEP ? TM : 1][SEP ? TN : 1];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; if (SEP) accs[i][j][r] = 0.f; }
 
     // Operand of R rows, NT threads.  k-contiguous source: slot = (row, k-group of 8), R * 4 slots, thread -> rows (tid >> 2) + (NT / 4) h,
     // k-group tid & 3, two float4 per slot.  m/n-contiguous source: 4 (k) x 4 (m) blocks, R / 4 x 8 of them, thread -> block
@@ -667,24 +669,34 @@ __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) 
     const bool actA = AK || tid < BMX * 2, actB = BKc || tid < BNX * 2;     // wave-uniform (multiples of 64)
     long arow[2] = {0, 0};
     int fp0[2] = {0, 0};
-    if (AMODE == A_ROW) {
-#pragma unroll
-        for (int h = 0; h < NSA; ++h) arow[h] = rowmap(g, min(m0 + krow + (NT / 4) * h, g.M - 1)) * g.lda;
-    }
-    if (AMODE == A_FRAMES) {
-#pragma unroll
-        for (int h = 0; h < NSA; ++h) {
-            const int m = min(m0 + krow + (NT / 4) * h, g.M - 1);
-            const int b = m / g.fr_T, t = m - b * g.fr_T;
-            arow[h] = (long)b * g.fr_L;
-            fp0[h] = t * g.fr_hop - g.fr_pl;
-        }
-    }
     long brow[2] = {0, 0};
-    if (BKc) {
+    // per-item state: (batch, split, tile) of virtual block `id`, operand row pointers
+    auto setup = [&](int id) {
+        g = g0;
+        locate_tile(g, split, tile_m, tile_n, BMX, BNX, id);
+        m0 = tile_m * BMX; n0 = tile_n * BNX;
+        k_begin = split * g.k_per_split;
+        k_end = min(g.K, k_begin + g.k_per_split);
+        nk = (k_end - k_begin + BK - 1) / BK;
+        if (AMODE == A_ROW) {
 #pragma unroll
-        for (int h = 0; h < NSB; ++h) brow[h] = (long)min(n0 + krow + (NT / 4) * h, g.N - 1) * g.ldb;
-    }
+            for (int h = 0; h < NSA; ++h) arow[h] = rowmap(g, min(m0 + krow + (NT / 4) * h, g.M - 1)) * g.lda;
+        }
+        if (AMODE == A_FRAMES) {
+#pragma unroll
+            for (int h = 0; h < NSA; ++h) {
+                const int m = min(m0 + krow + (NT / 4) * h, g.M - 1);
+                const int b = m / g.fr_T, t = m - b * g.fr_T;
+                arow[h] = (long)b * g.fr_L;
+                fp0[h] = t * g.fr_hop - g.fr_pl;
+            }
+        }
+        if (BKc) {
+#pragma unroll
+            for (int h = 0; h < NSB; ++h) brow[h] = (long)min(n0 + krow + (NT / 4) * h, g.N - 1) * g.ldb;
+        }
+    };
+    setup(vbid);
 
     float4 ra[4], rb[4];
     bool va[4], vb[4];
@@ -740,7 +752,7 @@ __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) 
         }
     };
 
-    const bool do_bsum = !BKc && g.bsum_part != nullptr && tile_m == 0;      // workgroup-uniform
+    bool do_bsum = !BKc && g.bsum_part != nullptr && tile_m == 0;            // workgroup-uniform, per item
     float4 bsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // split the staged f32 values and write the three bf16 images of one operand (R rows; plane / part strides PL / PT)
@@ -848,70 +860,94 @@ __device__ __forceinline__ void x6_body(GemmArgs& g, unsigned char* const smem) 
     };
 
     fetch(0);
-    stash();
-    fetch(1);                                       // tiles past the split's end: clamped addresses, staged as zeros if ever used
-    __syncthreads();
-    for (int kt = 0;; ++kt) {                       // every branch below is workgroup-uniform
-        mfma_tile();                                // tile kt
-        if (kt + 1 >= nk) break;
-        __syncthreads();
-        stash();                                    // tile kt + 1 (fetched one iteration ago)
-        if (!(AMS_X6_DBG & 16)) fetch(kt + 2);
-        __syncthreads();
-    }
-
-    if (!BKc && do_bsum) {
-        // thread (kb, mb) summed rows 4 kb .. 4 kb + 3 of every k-tile, columns 4 mb .. + 3: the 8 threads of a column group meet
-        // in LDS in a fixed order (deterministic)
-        float4* sbuf = reinterpret_cast<float4*>(smem);
-        __syncthreads();
-        if (actB) sbuf[tid] = bsum4;
-        __syncthreads();
-        if (tid < BNX / 4) {
-            float4 t = sbuf[tid];
-#pragma unroll
-            for (int j = 1; j < 8; ++j) { const float4 v = sbuf[tid + (BNX / 4) * j]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
-            const int n = n0 + tid * 4;
-            if (n < g.N) *reinterpret_cast<float4*>(g.bsum_part + (long)split * g.N + n) = t;
-        }
-    }
-    if (SEP) {
+    for (;;) {                                      // one work item per trip; every branch below is workgroup-uniform
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] += accs[i][j];
-    }
-    if constexpr (EPI == EPI_MAXPOOL) {             // stride-1 conv + max_pool_with_argmax (models/adapt.py:115-117), 128 x 128 tile only
-        static_assert(CFG == 0, "the max-pool epilogue is written for 2 x 2 waves of 64 x 64");
-        __syncthreads();                            // every wave is done with the LDS images
-        maxpool_epilogue(g, acc, reinterpret_cast<float*>(smem), tile_m, m0, n0, wm, wn, l31, lk);
-        return;
-    }
-    // Epilogue.  C/D layout of a 32x32 MFMA (any input type): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-    float* out = g.splits > 1 ? g.partial + (long)split * g.M * g.N : g.C;
-    const long ldo = g.splits > 1 ? g.N : g.ldc;
+            for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+                for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; if (SEP) accs[i][j][r] = 0.f; }
+        do_bsum = !BKc && g.bsum_part != nullptr && tile_m == 0;
+        bsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        stash();
+        fetch(1);                                   // tiles past the split's end: clamped addresses, staged as zeros if ever used
+        __syncthreads();
+        for (int kt = 0;; ++kt) {
+            mfma_tile();                            // tile kt
+            if (kt + 1 >= nk) break;
+            __syncthreads();
+            stash();                                // tile kt + 1 (fetched one iteration ago)
+            if (!(AMS_X6_DBG & 16)) fetch(kt + 2);
+            __syncthreads();
+        }
+
+        if (!BKc && do_bsum) {
+            // thread (kb, mb) summed rows 4 kb .. 4 kb + 3 of every k-tile, columns 4 mb .. + 3: the 8 threads of a column group meet
+            // in LDS in a fixed order (deterministic)
+            float4* sbuf = reinterpret_cast<float4*>(smem);
+            __syncthreads();
+            if (actB) sbuf[tid] = bsum4;
+            __syncthreads();
+            if (tid < BNX / 4) {
+                float4 t = sbuf[tid];
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + (wn * TN + j) * 32 + l31;
-            if (col >= g.N) continue;
-            const float bv = (g.splits == 1 && g.bias) ? g.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                if (row < g.M) {
-                    float v = acc[i][j][r] + bv;
-                    float* p = out + ((g.splits == 1 && g.seg_len) ? rowmap(g, row) : (long)row) * ldo + col;
-                    if (g.splits == 1 && g.accumulate) v += *p;
-                    *p = v;
-                }
+                for (int j = 1; j < 8; ++j) { const float4 v = sbuf[tid + (BNX / 4) * j]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+                const int n = n0 + tid * 4;
+                if (n < g.N) *reinterpret_cast<float4*>(g.bsum_part + (long)split * g.N + n) = t;
             }
         }
+        if (SEP) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] += accs[i][j];
+        }
+        if constexpr (EPI == EPI_MAXPOOL) {             // stride-1 conv + max_pool_with_argmax (models/adapt.py:115-117), 128 x 128 tile only
+            static_assert(CFG == 0, "the max-pool epilogue is written for 2 x 2 waves of 64 x 64");
+            __syncthreads();                            // every wave is done with the LDS images
+            maxpool_epilogue(g, acc, reinterpret_cast<float*>(smem), tile_m, m0, n0, wm, wn, l31, lk);
+            return;                                     // (launched with one workgroup per item)
+        }
+        // what the epilogue of THIS item needs, saved before the per-item state moves on
+        float* const out = g.splits > 1 ? g.partial + (long)split * g.M * g.N : g.C;
+        const long ldo = g.splits > 1 ? g.N : g.ldc;
+        const float* const ebias = g.bias;
+        const long eseg = g.seg_off;
+        const int em0 = m0, en0 = n0;
+        const int nxt = vbid + (int)gridDim.x;
+        const bool more = PERSIST && nxt < n_items;
+        if (more) {
+            __syncthreads();                            // every wave has read its last fragments: the staging registers and LDS are free
+            setup(nxt);
+            fetch(0);                                   // the next item's first k-tile is in flight BEFORE this item's stores
+        }
+        // Epilogue.  C/D layout of a 32x32 MFMA (any input type): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int col = en0 + (wn * TN + j) * 32 + l31;
+                if (col >= g.N) continue;
+                const float bv = (g.splits == 1 && ebias) ? ebias[col] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = em0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                    if (row < g.M) {
+                        float v = acc[i][j][r] + bv;
+                        const long orow = (g.splits == 1 && g.seg_len) ? (long)(row / g.seg_len) * g.seg_stride + eseg + (row % g.seg_len) : (long)row;
+                        float* p = out + orow * ldo + col;
+                        if (g.splits == 1 && g.accumulate) v += *p;
+                        *p = v;
+                    }
+                }
+            }
+        if (!more) break;
+        vbid = nxt;
+    }
 }
 
 template <int AMODE, int BMODE, int CFG, int EPI = EPI_STORE, bool SEP = false>
-__global__ __launch_bounds__(X6Cfg<CFG>::WMC * X6Cfg<CFG>::WNC * 64, CFG == 0 ? 2 : 1) void gemm_x6_kernel(GemmArgs g) {
+__global__ __launch_bounds__(X6Cfg<CFG>::WMC * X6Cfg<CFG>::WNC * 64, CFG == 0 ? 2 : 1) void gemm_x6_kernel(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[x6_lds(CFG)];
     x6_body<AMODE, BMODE, CFG, EPI, SEP>(g, smem);
 }
@@ -1078,6 +1114,14 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
         }
     }
     if (x6) {
+        // persistent grid (x6_body, uncapped two-accumulator variants): one resident set of workgroups -- 256 CUs x (2 for the 4-wave configuration, 1 for the 8-wave
+        // ones) x AMS_X6_PERSIST (default 1; 0 = one workgroup per item as before) -- walks the items.
+        if (tuning().x6persist > 0 && t_gemm_lds_pad == 0 && cfg != 1) {      // the variants launched with SEP = true below
+            int ncu = 256;
+            { static int cus = 0; if (!cus) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); if (cus <= 0) cus = 256; } ncu = cus; }
+            const long cap = (long)((ncu + 7) / 8 * 8) * (cfg == 0 ? 2 : 1) * tuning().x6persist;
+            if ((long)grid.x > cap) grid.x = (unsigned)cap;
+        }
         // residency: the 128 x 128 configuration holds 48.75 KB of LDS (3 workgroups per CU by LDS, 2 by registers); a pad asks for
         // what it asks of the 16.8 KB f32 kernel (workgroups per CU), restated.  The 8-wave configurations are alone on a CU anyway.
         if (cfg == 0) {

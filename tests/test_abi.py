@@ -64,3 +64,27 @@ def test_bss_library_exports_declared_symbols():
     for n in names:
         assert hasattr(lib, n), n
     assert lib.ams_bss_abi_version() == 1
+
+
+def test_host_library_exports_declared_symbols():
+    """include/ams_host.h: both helpers are exported and answer their known-answer checks (plain C: runs without a GPU)."""
+    import re
+    import numpy as np
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, 'include', 'ams_host.h')).read()
+    src = re.sub(r'/\*.*?\*/', ' ', src, flags=re.S)
+    names = set(re.findall(r'\b(ams_\w+)\s*\(', src))
+    assert names == {'ams_crc32c', 'ams_mt_choice_rows'}
+    lib = ctypes.CDLL(os.path.join(root, 'adaptive-multispeaker-separation_amd', 'ams_hip', 'libams_host.so'))
+    for n in names:
+        assert hasattr(lib, n), n
+    lib.ams_crc32c.restype = ctypes.c_uint32
+    lib.ams_crc32c.argtypes = [ctypes.c_char_p, ctypes.c_size_t]
+    assert lib.ams_crc32c(b'123456789', 9) == 0xE3069283
+    f = lib.ams_mt_choice_rows
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
+    key, pos, out = np.zeros(624, np.uint32), np.array([0], np.int32), np.zeros((2, 3), np.int32)
+    assert f(key.ctypes.data, pos.ctypes.data, 2, 2, 3, out.ctypes.data) == -1            # C > l
+    pos[0] = 625
+    assert f(key.ctypes.data, pos.ctypes.data, 2, 5, 3, out.ctypes.data) == -1            # not a numpy stream position

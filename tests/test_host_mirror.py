@@ -149,6 +149,44 @@ def test_kmeans_reference_seeding():
     assert fast.shape == (200, C) and all(len(set(r)) == C for r in fast.tolist()) and fast.min() >= 0 and fast.max() < 50
 
 
+def test_kmeans_reference_seeding_shapes_and_stream_sharing():
+    """The C draw (csrc/host/mt_choice.c) against numpy itself over the shapes the recipes use and the edge ones (l = 1, C = l,
+    powers of two either side, l > 65536), from odd stream positions; and the one-batch-ahead speculation: used when nobody
+    else touched the global generator, dropped -- without changing what anyone sees -- when somebody did."""
+    import types
+    import numpy as np
+    from ams_hip import kmeans_host as kh
+    assert kh._REFERENCE_SEEDS._native(), 'libams_host.so must be built (make -C adaptive-multispeaker-separation_amd/csrc)'
+    for (R, L, C) in [(5, 1, 1), (7, 2, 2), (9, 3, 3), (20, 4, 3), (20, 5, 2), (20, 8, 8), (20, 9, 1), (50, 17, 17), (6, 1024, 2),
+                      (6, 1025, 5), (4, 20480, 2), (2, 40960, 3), (2, 20303, 2), (3, 65537, 4)]:
+        ns = types.SimpleNamespace(nb_clusters=C, seeding='reference')
+        for seed in (42, 7):
+            np.random.seed(seed)
+            np.random.randint(0, 10, size=seed)
+            ref = np.array([np.random.choice(range(L), size=C, replace=False) for _ in range(R)]).astype(np.int32)
+            after_ref = np.random.randint(0, 1 << 30)
+            np.random.seed(seed)
+            np.random.randint(0, 10, size=seed)
+            got = kh.KMeans._draw(ns, R, L).numpy()
+            assert np.array_equal(ref, got) and np.random.randint(0, 1 << 30) == after_ref, (R, L, C, seed)
+    ns = types.SimpleNamespace(nb_clusters=3, seeding='reference')
+    np.random.seed(1)
+    r = [np.array([np.random.choice(range(300), size=3, replace=False) for _ in range(5)]) for _ in range(3)]
+    x = np.random.normal()                                  # leaves a cached gaussian in the state as well
+    r.append(np.array([np.random.choice(range(300), size=3, replace=False) for _ in range(5)]))
+    x2 = np.random.normal()
+    np.random.seed(1)
+    hits = kh._REFERENCE_SEEDS.hits
+    g = [kh.KMeans._draw(ns, 5, 300).numpy() for _ in range(3)]
+    assert kh._REFERENCE_SEEDS.hits - hits == 2             # batches 2 and 3 came from the worker thread
+    y = np.random.normal()
+    g.append(kh.KMeans._draw(ns, 5, 300).numpy())           # the speculation started before the foreign draw: dropped
+    assert kh._REFERENCE_SEEDS.hits - hits == 2
+    assert all(np.array_equal(a, b) for a, b in zip(r, g)) and x == y and np.random.normal() == x2
+    with pytest.raises(ValueError):                         # numpy's own error for C > l
+        kh.KMeans._draw(types.SimpleNamespace(nb_clusters=4, seeding='reference'), 2, 3)
+
+
 def test_tf_eval_running_mean_and_model_choices():
     """experiments/evaluation/tf_eval.py:27-38: batch-size-weighted running mean of the per-batch in-graph SDR improvement, NaN
     batches skipped; --model choices the reference leaves without an inferencer exit instead of crashing with a NameError."""
