@@ -13,6 +13,13 @@
 // global traffic stays float4-coalesced.
 #include "common.h"
 
+// timing anatomy builds (WRONG results): 1 = no MFMAs, 2 = no norm / no epilogue arithmetic, 4 = no global loads, 8 = no global stores
+#ifndef AMS_DPCL_PTS
+#define AMS_DPCL_PTS 256
+#endif
+#ifndef AMS_DPCL_DBG
+#define AMS_DPCL_DBG 0
+#endif
 namespace {
 
 constexpr int CHUNK = 2048;            // points per workgroup in the Gram pass
@@ -98,8 +105,10 @@ __global__ __launch_bounds__(256) void dpcl_gram_kernel(const float* __restrict_
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-                for (int tj = ti; tj < NT; ++tj)
-                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], bb[tj], acc[ti][tj], 0, 0, 0);
+                for (int tj = ti; tj < NT; ++tj) {
+                    if (AMS_DPCL_DBG & 1) acc[ti][tj][0] += a[ti] * bb[tj];
+                    else acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], bb[tj], acc[ti][tj], 0, 0, 0);
+                }
         }
     }
     __syncthreads();
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(256) void dpcl_gram_u_kernel(const float* __restric
     const int S = SC ? SC : S_rt;
     constexpr int Z = NT * 16;
     constexpr int ZP = Z + 4;                       // row pitch: 16-byte aligned rows, 16 lanes x 16 B cover all banks
-    constexpr int PTS = NT <= 3 ? 256 : 128;        // points staged per iteration
+    constexpr int PTS = NT <= 3 ? AMS_DPCL_PTS : 128;        // points staged per iteration
     constexpr int NV = PTS * Z / 4 / 256;           // 16-byte loads per thread and slab (upper bound, E <= Z)
     __shared__ __attribute__((aligned(16))) float zt[PTS * ZP];   // raw points [u | y | 0]; reused for the final reduce
     __shared__ float dsh[PTS], ivs[PTS];
@@ -271,8 +280,8 @@ __global__ __launch_bounds__(256) void dpcl_gram_u_kernel(const float* __restric
             dsh[tid] = (tid < npts && diag > 0.f) ? 1.0f / sqrtf(diag) : 0.f;    // all-zero Y row: reference has D = inf
         }
         __syncthreads();
-        if (p0 + PTS < p_end) fetch(p0 + PTS);      // in flight during everything below
-        if (tid < PTS) {
+        if (p0 + PTS < p_end && !(AMS_DPCL_DBG & 4)) fetch(p0 + PTS);      // in flight during everything below
+        if (tid < PTS && !(AMS_DPCL_DBG & 2)) {
             float ss = 0.f;
             const float* row = &zt[tid * ZP];
             for (int e = 0; e < E; ++e) ss += row[e] * row[e];
@@ -302,8 +311,10 @@ __global__ __launch_bounds__(256) void dpcl_gram_u_kernel(const float* __restric
 #pragma unroll
             for (int ti = 0; ti < NT; ++ti)
 #pragma unroll
-                for (int tj = ti; tj < NT; ++tj)
-                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], bb[tj], acc[ti][tj], 0, 0, 0);
+                for (int tj = ti; tj < NT; ++tj) {
+                    if (AMS_DPCL_DBG & 1) acc[ti][tj][0] += a[ti] * bb[tj];
+                    else acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ti], bb[tj], acc[ti][tj], 0, 0, 0);
+                }
         }
     }
     __syncthreads();
@@ -476,7 +487,7 @@ __global__ __launch_bounds__(256, 2) void dpcl_bwd_u_kernel(const float* __restr
     const int E = EC ? EC : E_rt;
     const int S = SC ? SC : S_rt;
     constexpr int Z = NT * 16, ZP = Z + 4, KT = Z / 4;
-    constexpr int PTS = NT <= 3 ? 256 : 128;
+    constexpr int PTS = NT <= 3 ? AMS_DPCL_PTS : 128;
     constexpr int NV = PTS * Z / 4 / 256;
     __shared__ __attribute__((aligned(16))) float zt[PTS * ZP];
     __shared__ float dsh[PTS], ivs[PTS];
@@ -584,7 +595,7 @@ __global__ __launch_bounds__(256, 2) void dpcl_bwd_u_kernel(const float* __restr
             ivs[tid] = tid < npts ? ivp : 0.f;
         }
         __syncthreads();
-        if (p0 + PTS < p_end) fetch(p0 + PTS);
+        if (p0 + PTS < p_end && !(AMS_DPCL_DBG & 4)) fetch(p0 + PTS);
 
 #pragma unroll 1
         for (int gi = 0; gi < PTS / 64; ++gi) {
@@ -599,12 +610,20 @@ __global__ __launch_bounds__(256, 2) void dpcl_bwd_u_kernel(const float* __restr
                 float a = arow[kt * 4];
                 a = (kt * 4 + slot < E) ? a * iv_a : a;
 #pragma unroll
-                for (int ft = 0; ft < NT; ++ft) acc[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bm[kt][ft], acc[ft], 0, 0, 0);
+                for (int ft = 0; ft < NT; ++ft) {
+                    if (AMS_DPCL_DBG & 1) acc[ft][kt & 3] += a * bm[kt][ft];
+                    else acc[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bm[kt][ft], acc[ft], 0, 0, 0);
+                }
             }
             // accumulator layout: point = pb + slot*4 + r, column f = ft*16 + e_lo
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int pnt = pb + slot * 4 + r;
+                if (AMS_DPCL_DBG & 2) {
+#pragma unroll
+                    for (int ft = 0; ft < NT; ++ft) if (ft * 16 + e_lo < E) zt[pnt * ZP + ft * 16 + e_lo] = acc[ft][r];
+                    continue;
+                }
                 const float d = dsh[pnt], iv = ivs[pnt];
                 float vv[NT], dd[NT], dot = 0.f;
 #pragma unroll
@@ -630,7 +649,7 @@ __global__ __launch_bounds__(256, 2) void dpcl_bwd_u_kernel(const float* __restr
 #pragma unroll
             for (int j = 0; j < NV; ++j) {
                 const int i4 = tid + 256 * j;
-                if (i4 < nvec && i4 * 4 < npts * E) {
+                if (i4 < nvec && i4 * 4 < npts * E && (!(AMS_DPCL_DBG & 8) || zt[0] == 12345.f)) {
                     const int pnt = (i4 * 4) / E, e = i4 * 4 - pnt * E;
                     dst[i4] = *reinterpret_cast<const float4*>(&zt[pnt * ZP + e]);
                 }
@@ -640,6 +659,157 @@ __global__ __launch_bounds__(256, 2) void dpcl_bwd_u_kernel(const float* __restr
             for (int i = tid; i < npts * E; i += 256) dst[i] = zt[(i / E) * ZP + (i % E)];
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Round 3: the fused BACKWARD pass without the LDS transposes (E % 4 == 0, E + S <= 48, S <= 4: the recipes' E = 40).
+// The anatomy of the staged kernels (AMS_DPCL_DBG builds, cold caches, 64 x 20480 x 40): backward 137 us, without its MFMAs 129,
+// without its epilogue 119, without ANY global traffic 107, with nothing but the staging and its four barriers per slab 37 --
+// neither HBM nor the matrix pipe but the chain load -> LDS -> barrier -> MFMA -> LDS -> barrier -> store, two workgroups per CU.
+// The backward product can take its operands straight from global memory in the layout the MFMA wants, because an MFMA's k
+// order is free as long as A and B agree:
+//   dV^T = M^T . Z^T  (features x points): B operand lane (slot, e) = point e, k = 16 j + 4 slot + i for MFMA (j, i) -- exactly
+//   the three float4 a lane loads from its point's row; the D registers of feature tile ft are features 16 ft + 4 slot + r of
+//   point e: the SAME float4 positions, so the l2-normalise Jacobian needs the lane's own loads and two cross-slot shuffles,
+//   and dU leaves as float4.  No LDS, no barrier, waves independent.
+// (The Gram pass was tried the same way -- A lane (slot, e) = feature e of point slot from 4-byte loads, |u|^2 as a 16-lane
+// reduction -- and was slower, 163 vs 110 us: 1/|u| and D are then computed once per FOUR points per instruction instead of once
+// per 64, and that VALU work outweighs the barriers it removes.  It keeps the staged form.)
+constexpr int BCH2 = 1024;             // points per 256-thread workgroup, backward (16 groups of 16 points per wave)
+
+template <int EC, int SC>
+__global__ __launch_bounds__(256) void dpcl_bwd_u2_kernel(const float* __restrict__ U, const float* __restrict__ Y,
+                                                          const float* __restrict__ cntp, const float* __restrict__ mats,
+                                                          const float* __restrict__ inv, const float* __restrict__ upstream,
+                                                          float* __restrict__ dU, long TF) {
+    constexpr int E = EC, S = SC, NT = 3, NJ = 3;
+    static_assert(E % 4 == 0 && E + S <= 48 && S <= 4 && E > 32, "layout of dpcl_bwd_u2_kernel");
+    const int b = blockIdx.y, c = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e_lo = lane & 15, slot = lane >> 4;
+    float cn[8];
+    load_counts(cntp, b, S, cn);
+    const float up = upstream ? upstream[0] : 1.0f;
+    // A fragments: MFMA (j, i) of feature tile ft: M[k = 16 j + 4 slot + i][f = 16 ft + e_lo],  M = [Gn ; -An^T]
+    float am[NJ][4][NT];
+    {
+        const float* G = mats + (long)b * (E * E + E * S);
+        const float* A = G + E * E;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ft = 0; ft < NT; ++ft) {
+                    const int k = 16 * j + 4 * slot + i, f = ft * 16 + e_lo;
+                    float v = 0.f;
+                    if (f < E) {
+                        if (k < E) v = G[k * E + f];
+                        else if (k < E + S) v = -A[f * S + (k - E)];
+                    }
+                    am[j][i][ft] = v;
+                }
+    }
+    const long p_begin = (long)c * BCH2, p_end = min(TF, p_begin + BCH2);
+    const float* Ub = U + (long)b * TF * E;
+    const float* Yb = Y + (long)b * TF * S;
+    const float* ib = inv + (long)b * TF;
+    float* dUb = dU + (long)b * TF * E;
+    constexpr int NG = BCH2 / 16 / 4;               // groups per wave
+    // which of the lane's three float4 are embedding values, which one is the label vector
+    const bool uval[NJ] = {true, true, 32 + 4 * slot < E};
+    const bool ylane = (32 + 4 * slot == E);
+
+    struct Grp { float4 q[NJ]; float y[4]; float iv; };
+    auto fetch = [&](long p, Grp& g) {
+        const long pc = min(p, p_end - 1);          // clamped: lanes past the end redo the last point and are discarded
+        const float4* row = reinterpret_cast<const float4*>(Ub + pc * E);
+        g.q[0] = row[slot];
+        g.q[1] = row[4 + slot];
+        g.q[2] = row[min(8 + slot, E / 4 - 1)];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) g.y[s] = (s < S) ? Yb[pc * S + s] : 0.f;
+        g.iv = ib[pc];
+    };
+    auto compute = [&](long g0, const Grp& g) {
+        const long p = g0 + e_lo;
+        const bool live = p < p_end;
+        float diag = 0.f;
+#pragma unroll
+        for (int s = 0; s < S; ++s) diag += g.y[s] * cn[s];
+        const float d = (live && diag > 0.f) ? up / sqrtf(diag) : 0.f;          // all-zero Y row contributes nothing
+        const float iv = g.iv;
+        float z[NJ][4];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float t[4] = {g.q[j].x, g.q[j].y, g.q[j].z, g.q[j].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[j][i] = uval[j] ? t[i] * iv : 0.f;
+        }
+        if (ylane) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) z[NJ - 1][i] = g.y[i];
+        }
+        f32x4 acc[NT];
+#pragma unroll
+        for (int ft = 0; ft < NT; ++ft) acc[ft] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ft = 0; ft < NT; ++ft) {
+                    if (AMS_DPCL_DBG & 1) acc[ft][i] += am[j][i][ft] * z[j][i];
+                    else acc[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[j][i][ft], z[j][i], acc[ft], 0, 0, 0);
+                }
+        // acc[ft][r]: feature 16 ft + 4 slot + r of point e_lo -- the positions of the lane's own float4 number ft
+        float dd[NT][4], dot = 0.f;
+#pragma unroll
+        for (int ft = 0; ft < NT; ++ft)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dd[ft][r] = acc[ft][r] * d;
+                if (uval[ft]) dot += z[ft][r] * dd[ft][r];
+            }
+        dot += __shfl_xor(dot, 16);
+        dot += __shfl_xor(dot, 32);
+        const bool active = iv < 0.999999e6f;       // |u|^2 was clamped to 1e-12: the norm's gradient is zero there
+#pragma unroll
+        for (int ft = 0; ft < NT; ++ft) {
+            if (uval[ft] && live && !(AMS_DPCL_DBG & 8)) {
+                float4 o;
+                o.x = active ? (dd[ft][0] - z[ft][0] * dot) * iv : dd[ft][0] * iv;
+                o.y = active ? (dd[ft][1] - z[ft][1] * dot) * iv : dd[ft][1] * iv;
+                o.z = active ? (dd[ft][2] - z[ft][2] * dot) * iv : dd[ft][2] * iv;
+                o.w = active ? (dd[ft][3] - z[ft][3] * dot) * iv : dd[ft][3] * iv;
+                reinterpret_cast<float4*>(dUb + p * E)[4 * ft + slot] = o;
+            }
+        }
+    };
+    // three register buffers in rotation: while group n is in the MFMAs, groups n + 1 and n + 2 are in flight (one wave keeps
+    // 5 KB outstanding, a CU's 16 waves 80 KB -- what 6 TB/s x 3 us of loaded latency asks of each of the 256 CUs)
+    Grp g0b, g1b, g2b;
+    const long w0 = p_begin + (long)wave * (NG * 16);
+    const long w_end = min(p_end, w0 + (long)NG * 16);
+    if (w0 < w_end) fetch(w0 + e_lo, g0b);
+    if (w0 + 16 < w_end) fetch(w0 + 16 + e_lo, g1b);
+#pragma unroll 1
+    for (long g = w0; g < w_end; g += 48) {
+        if (g + 32 < w_end) fetch(g + 32 + e_lo, g2b);
+        compute(g, g0b);
+        if (g + 16 >= w_end) break;
+        if (g + 48 < w_end) fetch(g + 48 + e_lo, g0b);
+        compute(g + 16, g1b);
+        if (g + 32 >= w_end) break;
+        if (g + 64 < w_end) fetch(g + 64 + e_lo, g1b);
+        compute(g + 32, g2b);
+    }
+}
+
+// AMS_DPCL_LDS=1 (read once): the LDS-staged passes of round 2 also where the direct ones apply (A/B runs, tests hold both)
+inline bool dpcl_direct() {
+    static const bool v = !(getenv("AMS_DPCL_LDS") && atoi(getenv("AMS_DPCL_LDS")) != 0);
+    return v;
 }
 
 }  // namespace
@@ -756,7 +926,10 @@ ams_status ams_dpcl_loss_bwd_u(const float* U, const float* Y, const float* inv,
         case 2: hipLaunchKernelGGL((dpcl_bwd_u_kernel<2, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S); break;
         case 3: {
             const bool al = (((uintptr_t)U & 15) == 0) && (((uintptr_t)dU & 15) == 0);
-            if (E == 40 && S == 2 && al) hipLaunchKernelGGL((dpcl_bwd_u_kernel<3, 40, 2>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S);
+            const dim3 grid2(ceil_div(TF, BCH2), B);
+            if (E == 40 && S == 2 && al && dpcl_direct()) hipLaunchKernelGGL((dpcl_bwd_u2_kernel<40, 2>), grid2, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF);
+            else if (E == 40 && S == 3 && al && dpcl_direct()) hipLaunchKernelGGL((dpcl_bwd_u2_kernel<40, 3>), grid2, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF);
+            else if (E == 40 && S == 2 && al) hipLaunchKernelGGL((dpcl_bwd_u_kernel<3, 40, 2>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S);
             else if (E == 40 && S == 3 && al) hipLaunchKernelGGL((dpcl_bwd_u_kernel<3, 40, 3>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S);
             else hipLaunchKernelGGL((dpcl_bwd_u_kernel<3, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S);
             break;

@@ -1,6 +1,8 @@
 """GPU parity: every HIP kernel, called through the C ABI (ctypes), against the float64 numpy oracle on
 the same seeded inputs.  Spec tolerance (BASELINE.json north_star): 1e-3 relative fp32; the asserts below
 use the much tighter bound an exact-f32 MFMA path should meet (`TOL`), so a layout bug cannot hide."""
+import os
+
 import numpy as np
 import pytest
 
@@ -178,6 +180,16 @@ def test_l2norm_dpcl(ops, B, TF, E, S):
     up = dev(np.array([0.5]))
     du_h = ops.dpcl_loss_bwd_u(Ud, Yd, inv_u, ws_u, upstream=up)
     assert rel(host(du_h).reshape(du_ref.shape), 0.5 * du_ref) < 5 * TOL
+
+
+def test_dpcl_backward_staged_form_still_agrees():
+    """E = 40 takes the direct (LDS-free) backward kernel by default; AMS_DPCL_LDS=1 (read once per process) selects the staged
+    one of round 2 for the same shapes.  Both are held to the oracle."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, '-m', 'pytest', '-q', '-x', os.path.abspath(__file__), '-k', 'test_l2norm_dpcl'],
+                       env=dict(os.environ, AMS_DPCL_LDS='1'), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 def test_optimizers(ops):
