@@ -153,7 +153,16 @@ class BLSTMLayer(Function):
 
     @staticmethod
     def forward(ctx, x, Kf, bf, Kb, bb, last_capped=False):
-        out, G, cst = ops.blstm_fwd(x, Kf, bf, Kb, bb, consumer=_take_hint(Kf.shape[1] // 2))
+        # fp16x3 products (ops.set_amax): bounds of the input and of the kernels (one bound over the optimizer's flat buffer; two
+        # kernels measured separately have no common bound at hand and keep bf16x6)
+        aw = ops.param_amax(Kf) if ops.F16X3 and x.is_cuda else None
+        if aw is not None and aw is not ops.param_amax(Kb):
+            aw = None
+        ax = ops.amax_of(x) if aw is not None else None
+        ctx.amax = (ax, aw) if aw is not None else None
+        out, G, cst = ops.blstm_fwd(x, Kf, bf, Kb, bb, consumer=_take_hint(Kf.shape[1] // 2), amax=ctx.amax)
+        if x.is_cuda:
+            ops.tag_amax(out, ops.amax_one(out.device))          # |tanh(c) sigmoid(o)| < 1
         ctx.last_capped = bool(last_capped)
         ctx.save_for_backward(x, Kf, Kb, out, G, cst)
         ctx.biases = (bf, bb)
@@ -167,34 +176,39 @@ class BLSTMLayer(Function):
         if OVERLAP.usable(Kf, Kb, bf, bb) and all(ctx.needs_input_grad[1:5]):
             B, T, D = x.shape
             dbpart = ops.blstm_bwd_recurrent(x, Kf, Kb, G, cst, _c(dout))
+            am_dx = am_w = None
+            if ctx.amax is not None:
+                az = ops.absmax(G)                               # G now holds dZ
+                am_dx = (az, ctx.amax[1])
+                am_w = (ctx.amax[0], ops.amax_one(G.device), az)
             dx = None
             if _ORDER >= 2 and need_dx:
-                dx = ops.blstm_bwd_dx(G, Kf, Kb, B, T, D)
+                dx = ops.blstm_bwd_dx(G, Kf, Kb, B, T, D, amax=am_dx)
             s = OVERLAP.fork(x, out, G, *([dbpart] if dbpart is not None else []))
             if not need_dx:
                 # first layer: no recurrence follows -- both streams work on the weight gradients, uncapped
                 if _L1_TAIL == 0:
                     with torch.cuda.stream(s):
-                        ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u')
-                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart)
+                        ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u', amax=am_w)
+                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart, amax=am_w)
                 elif _L1_TAIL == 1:
-                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart)
-                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u')
+                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart, amax=am_w)
+                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u', amax=am_w)
                 else:
-                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u')
-                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart)
+                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u', amax=am_w)
+                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart, amax=am_w)
                 return None, None, None, None, None, None
             with torch.cuda.stream(s):
                 x3 = {} if X3_SIDE else None             # products beside the ring from pre-split images (csrc/gemm_x3.hip)
                 OVERLAP.cap(True, 'lstm')
-                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart, x3_side=x3)
+                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart, x3_side=x3, amax=am_w)
                 # the LAST capped product of the backward pass (recurrent-kernel gradient of the layer above the first one) ends
                 # after the BPTT it hides behind: 2 workgroups per CU there (+0.6 %)
                 OVERLAP.cap(True, 'lstm_last' if ctx.last_capped else 'lstm')
-                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u', x3_side=x3)
+                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u', x3_side=x3, amax=am_w)
                 OVERLAP.cap(False)
             if dx is None and need_dx:
-                dx = ops.blstm_bwd_dx(G, Kf, Kb, B, T, D)
+                dx = ops.blstm_bwd_dx(G, Kf, Kb, B, T, D, amax=am_dx)
             return dx, None, None, None, None, None
         dx, dKf, dbf, dKb, dbb = ops.blstm_bwd(x, Kf, Kb, out, G, cst, _c(dout), need_dx=need_dx)
         return dx, dKf, dbf, dKb, dbb, None
@@ -207,7 +221,9 @@ class Dense(Function):
     def forward(ctx, x, W, b):
         ctx.save_for_backward(x, W)
         ctx.bias = b
-        return ops.dense_fwd(x, W, b)
+        aw = ops.param_amax(W) if ops.F16X3 and x.is_cuda else None
+        ctx.amax = (ops.amax_of(x), aw) if aw is not None else None         # fp16x3 products (ops.set_amax)
+        return ops.dense_fwd(x, W, b, amax=ctx.amax)
 
     @staticmethod
     def backward(ctx, du):
@@ -215,11 +231,15 @@ class Dense(Function):
         du2 = _c(du).view(-1, W.shape[1])
         x2 = x.reshape(-1, x.shape[-1])
         b = ctx.bias
+        am_dx = am_dw = None
+        if ctx.amax is not None:
+            adu = ops.amax_of(du)                                # the loss kernel that wrote dU left its bound (ops.dpcl_loss_bwd_u)
+            am_dx, am_dw = (adu, ctx.amax[1]), (ctx.amax[0], adu)
         if OVERLAP.usable(W, b) and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
             dx = None
             x3 = X3_SIDE and _DENSE_MODE == 0 and W.grad.is_contiguous()
             if _DENSE_MODE == 0 and _ORDER >= 1 and ctx.needs_input_grad[0]:
-                dx = ops.gemm(du2, W, transB=True).view(x.shape)
+                dx = ops.gemm(du2, W, transB=True, amax=am_dx).view(x.shape)
             s = OVERLAP.fork(x2, du2)
             with torch.cuda.stream(s):
                 OVERLAP.cap(_DENSE_MODE == 0)
@@ -232,9 +252,9 @@ class Dense(Function):
                     fused = True
                 else:
                     # dW = x^T dU and db = colsum(dU) from ONE pass over dU (210 MB at the benchmark shape)
-                    fused = ops.gemm_at_b_colsum(x2, du2, W.grad, b.grad, accumulate=True)
+                    fused = ops.gemm_at_b_colsum(x2, du2, W.grad, b.grad, accumulate=True, amax=am_dw)
                     if not fused:
-                        ops.gemm(x2, du2, transA=True, out=W.grad, accumulate=True)
+                        ops.gemm(x2, du2, transA=True, out=W.grad, accumulate=True, amax=am_dw)
                 OVERLAP.cap(False)
                 if not fused:
                     ops.colsum_into(du2, b.grad, True)
@@ -243,10 +263,10 @@ class Dense(Function):
                 # on the side stream when the recurrence below starts
                 torch.cuda.current_stream().wait_stream(s)
             if dx is None and ctx.needs_input_grad[0]:
-                dx = ops.gemm(du2, W, transB=True).view(x.shape)
+                dx = ops.gemm(du2, W, transB=True, amax=am_dx).view(x.shape)
             return dx, None, None
-        dx = ops.gemm(du2, W, transB=True).view(x.shape) if ctx.needs_input_grad[0] else None
-        dW = ops.gemm(x2, du2, transA=True) if ctx.needs_input_grad[1] else None
+        dx = ops.gemm(du2, W, transB=True, amax=am_dx).view(x.shape) if ctx.needs_input_grad[0] else None
+        dW = ops.gemm(x2, du2, transA=True, amax=am_dw) if ctx.needs_input_grad[1] else None
         db = ops.colsum(du2) if ctx.needs_input_grad[2] else None
         return dx, dW, db
 

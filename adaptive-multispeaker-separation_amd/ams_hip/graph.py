@@ -98,6 +98,8 @@ class Run(object):
         self.cache = {}
         self.feeds = feeds or {}
         self.training = training
+        from . import ops
+        ops.PASS[0] += 1                # weight bounds of the fp16x3 products are measured once per pass (ops.param_amax)
 
 
 class Node(object):

@@ -4,6 +4,7 @@ Every function enqueues hand-written HIP kernels from libams_hip.so on torch's c
 All tensors must be contiguous fp32 CUDA(HIP) tensors unless stated.  There is no CPU path.
 """
 import ctypes
+import os as _os
 
 import torch
 
@@ -164,11 +165,90 @@ def front_conv_bwd_filter(x, dy, W, hop):
     return df
 
 
+# ------------------------------------------------------------------ operand bounds of the fp16x3 products (include/ams.h: ams_gemm_set_amax)
+F16X3 = _os.environ.get('AMS_GEMM_F16X3', '1') != '0'           # 0: nobody computes or passes bounds; every product stays bf16x6
+_ONE = {}
+
+
+def absmax(t, out=None):
+    """1-element tensor holding max |t| (NaN if t has one): two small launches.  `out`: refresh an existing bound in place (so that
+    captured graphs, which hold its address, see the new value)."""
+    if out is None:
+        out = torch.empty(1, dtype=torch.float32, device=t.device)
+    _chk(t)
+    check(load().ams_absmax_f32(_p(t), t.numel(), _p(out), _s()), 'ams_absmax_f32')
+    return out
+
+
+def amax_one(device):
+    """The bound of everything a BLSTM layer emits: |tanh(c) * sigmoid(o)| < 1."""
+    k = str(device)
+    if k not in _ONE:
+        _ONE[k] = torch.ones(1, dtype=torch.float32, device=device)
+    return _ONE[k]
+
+
+def tag_amax(t, a):
+    """Producers that know a bound of their output attach it; consumers find it with amax_of()."""
+    if F16X3 and a is not None:
+        t._ams_amax = a
+    return t
+
+
+def amax_of(t):
+    """The bound a producer attached to `t`, else max |t| computed now (None when fp16x3 is switched off)."""
+    if not F16X3:
+        return None
+    b = t
+    while b is not None:                                         # a view of a tagged tensor is bounded by the tag of its base
+        a = getattr(b, '_ams_amax', None)
+        if a is not None:
+            return a
+        b = b._base
+    return absmax(t)
+
+
+PASS = [0]                                                       # bumped by graph.Run: one evaluation pass = one measurement
+
+
+def param_amax(W):
+    """Bound of a weight tensor, measured at its first use in every evaluation pass (graph.Run) -- inside a captured step the
+    measurement is part of the graph and is repeated by every replay, so no writer of weights (optimizer kernels, restore,
+    `.data.copy_`) has to remember anything.  Variables owned by an optimizer share ONE bound over its whole flat buffer (a bound up
+    to 2^10 above a tensor's own maximum costs that tensor no precision); anything else is measured by itself."""
+    if not F16X3:
+        return None
+    src = getattr(W, '_ams_amax_src', None)
+    if src is not None:
+        flat, bound, seen = src
+        if seen[0] != PASS[0]:
+            absmax(flat, out=bound)
+            seen[0] = PASS[0]
+        return bound
+    c = getattr(W, '_ams_amax_cache', None)
+    if c is None or c[0] != PASS[0]:
+        W._ams_amax_cache = c = (PASS[0], absmax(W.detach(), out=c[1] if c is not None else None))
+    return c[1]
+
+
+def register_param_source(variables, flat):
+    """FlatOptimizer: every variable it owns takes its bound from one measurement of the flat buffer."""
+    src = (flat, torch.zeros(1, dtype=torch.float32, device=flat.device), [-1])
+    for v in variables:
+        v._ams_amax_src = src
+
+
+def set_amax(a, b):
+    """Bounds for the NEXT product launch of this thread (one-shot).  Either None: that launch stays bf16x6."""
+    if F16X3 and a is not None and b is not None:
+        load().ams_gemm_set_amax(_p(a), _p(b))
+
+
 # ------------------------------------------------------------------ GEMM
 def gemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False, M=None, N=None, K=None,
-         lda=None, ldb=None, ldc=None, mask=(0, 0), label=''):
+         lda=None, ldb=None, ldc=None, mask=(0, 0), label='', amax=None):
     """out[M,N] (+)= op(A) op(B) (+ bias).  A/B may be 2-D tensors (dims inferred) or raw views with explicit
-    M,N,K and leading dimensions (for column slices of wider buffers)."""
+    M,N,K and leading dimensions (for column slices of wider buffers).  amax = (bound of A, bound of B): fp16x3 arithmetic."""
     lib = load()
     if M is None:
         _chk(A, B, bias)
@@ -195,6 +275,8 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False
     nb = lib.ams_gemm_workspace_bytes(M, N, K)
     ws = _ws(nb, A) if nb else None
     ev = PROFILE.begin() if PROFILE.enabled else None
+    if amax is not None:
+        set_amax(amax[0], amax[1])
     check(lib.ams_gemm_f32(int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc, _p(bias), int(accumulate),
                            mask[0], mask[1], _p(ws), nb, _s()), 'ams_gemm_f32')
     if ev is not None:
@@ -202,7 +284,7 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False
     return out
 
 
-def gemm_at_b_colsum(A, B, out, bsum, accumulate=True):
+def gemm_at_b_colsum(A, B, out, bsum, accumulate=True, amax=None):
     """out[M,N] (+)= A^T B and bsum[N] (+)= column sums of B in ONE pass over B (A [K,M], B [K,N] row-major).  Returns False when
     the shapes / alignments do not allow the fused form (the caller then uses gemm + colsum)."""
     K, M = A.shape
@@ -217,6 +299,8 @@ def gemm_at_b_colsum(A, B, out, bsum, accumulate=True):
     ws = _ws(nb, A) if nb else None
     bws = _ws(32 * N * 4, A)
     ev = PROFILE.begin() if PROFILE.enabled else None
+    if amax is not None:
+        set_amax(amax[0], amax[1])
     check(lib.ams_gemm_f32_at_b_colsum(M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), int(accumulate),
                                        _p(bsum), int(accumulate), _p(bws), _p(ws), nb, _s()), 'ams_gemm_f32_at_b_colsum')
     if ev is not None:
@@ -224,7 +308,7 @@ def gemm_at_b_colsum(A, B, out, bsum, accumulate=True):
     return True
 
 
-def gemm_batched2(A0, A1, B0, B1, C0, C1, transA, transB, M, N, K, lda, ldb, ldc, accumulate=False, mask=(0, 0)):
+def gemm_batched2(A0, A1, B0, B1, C0, C1, transA, transB, M, N, K, lda, ldb, ldc, accumulate=False, mask=(0, 0), amax=None):
     """Two products of one shape in ONE launch (operand pairs given as tensors/views; offsets taken from their addresses)."""
     lib = load()
     for t_ in (A0, A1, B0, B1, C0, C1):
@@ -236,13 +320,15 @@ def gemm_batched2(A0, A1, B0, B1, C0, C1, transA, transB, M, N, K, lda, ldb, ldc
     nb = lib.ams_gemm_batched_workspace_bytes(M, N, K, 2)
     ws = _ws(nb, A0) if nb else None
     ev = PROFILE.begin() if PROFILE.enabled else None
+    if amax is not None:
+        set_amax(amax[0], amax[1])
     check(lib.ams_gemm_f32_batched(int(transA), int(transB), M, N, K, _p(A0), lda, da // 4, _p(B0), ldb, db_ // 4, _p(C0), ldc, dc // 4, 2,
                                    int(accumulate), mask[0], mask[1], _p(ws), nb, _s()), 'ams_gemm_f32_batched')
     if ev is not None:
         PROFILE.end(ev, 2 * 2.0 * M * N * K, 2 * 4.0 * (M * K + K * N + M * N), 'gemm<%d,%d>' % (int(bool(transA)), int(bool(transB))))
 
 
-def gemm_batched(A, B, C, nbatch, a_zs, b_zs, c_zs, transA, transB, M, N, K, lda, ldb, ldc, accumulate=False):
+def gemm_batched(A, B, C, nbatch, a_zs, b_zs, c_zs, transA, transB, M, N, K, lda, ldb, ldc, accumulate=False, amax=None):
     """nbatch products of one shape in ONE launch: batch z reads A + z*a_zs, B + z*b_zs and writes C + z*c_zs (element strides)."""
     lib = load()
     for t_ in (A, B, C):
@@ -251,6 +337,8 @@ def gemm_batched(A, B, C, nbatch, a_zs, b_zs, c_zs, transA, transB, M, N, K, lda
     nb = lib.ams_gemm_batched_workspace_bytes(M, N, K, nbatch)
     ws = _ws(nb, A) if nb else None
     ev = PROFILE.begin() if PROFILE.enabled else None
+    if amax is not None:
+        set_amax(amax[0], amax[1])
     check(lib.ams_gemm_f32_batched(int(transA), int(transB), M, N, K, _p(A), lda, a_zs, _p(B), ldb, b_zs, _p(C), ldc, c_zs, nbatch,
                                    int(accumulate), 0, 0, _p(ws), nb, _s()), 'ams_gemm_f32_batched')
     if ev is not None:
@@ -394,11 +482,12 @@ def raise_on_ring_errors():
                        'per-step recurrence kernels, which need no co-residency.')
 
 
-def blstm_fwd(x, Kf, bf, Kb, bb, consumer=None):
+def blstm_fwd(x, Kf, bf, Kb, bb, consumer=None, amax=None):
     """One BLSTM layer (utils/ops.py:358-383).  x [B,T,D]; K* [D+H,4H]; b* [4H].
     Returns out [B,T,2H] and the tensors the backward needs (G = activated gates, cst = cell states).
     consumer: optional (kind, W [2H, Dout] row-major view, bias [Dout]) of the row-wise product that will read `out` next
-    (the next layer's input projection or the dense layer) -- see the TAIL_* note below."""
+    (the next layer's input projection or the dense layer) -- see the TAIL_* note below.
+    amax: (bound of x, bound of the kernels) -> the input projection runs as fp16x3."""
     _chk(x, bf, bb)
     _chk_rows(Kf, Kb)
     lib = load()
@@ -442,7 +531,7 @@ def blstm_fwd(x, Kf, bf, Kb, bb, consumer=None):
     if pre is not None:
         _finish_precomputed(lib, pre, x2, Wcat, 8 * H, bias, B, T, D, 'blstm_input_gemm')
     else:
-        gemm(x2, Wcat, bias=bias, out=G, M=B * T, N=8 * H, K=D, lda=D, ldb=8 * H, ldc=8 * H, label='blstm_input_gemm')
+        gemm(x2, Wcat, bias=bias, out=G, M=B * T, N=8 * H, K=D, lda=D, ldb=8 * H, ldc=8 * H, label='blstm_input_gemm', amax=amax)
     cuts = _tail_cuts(consumer[0], T) if (consumer is not None and not LSTM_PERSIST and not nring) else None
     if cuts:
         check(lib.ams_blstm_pack(_p(Kf[D:]), _p(Kb[D:]), ldu, _p(pack), H, 0, _s()), 'ams_blstm_pack')
@@ -612,13 +701,13 @@ def _finish_precomputed(lib, e, x2, W, Dout, bias, B, T, K, label):
     torch.cuda.current_stream().wait_event(e['event'])
 
 
-def dense_fwd(x, W, b):
+def dense_fwd(x, W, b, amax=None):
     """u = x.W + b over the last axis (utils/ops.py:486-503), picking up rows a preceding blstm_fwd(consumer=...) already
     produced."""
     x2 = x.reshape(-1, x.shape[-1])
     e = _take_precomputed(x, W, W.shape[1]) if x.dim() == 3 else None
     if e is None:
-        return gemm(x2, W, bias=b).view(x.shape[:-1] + (W.shape[1],))
+        return gemm(x2, W, bias=b, amax=amax).view(x.shape[:-1] + (W.shape[1],))
     B, T, K = x.shape
     _finish_precomputed(load(), e, x2, W, W.shape[1], b, B, T, K, 'dense')
     return e['Y']
@@ -668,22 +757,24 @@ def blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout):
               'ams_blstm_recurrent_bwd')
 
 
-def blstm_bwd_dx(G, Kf, Kb, B, T, D):
+def blstm_bwd_dx(G, Kf, Kb, B, T, D, amax=None):
     """dx = dZ . [Wx_f | Wx_b]^T  (the only hoisted product on the backward critical path), one GEMM with K = 8H."""
     H = Kf.shape[1] // 4
     M = B * T
     Wcat = blstm_wcat(Kf, Kb, D)
     dx = torch.empty((B, T, D), dtype=torch.float32, device=G.device)
-    gemm(G.view(-1), Wcat, transB=True, out=dx, M=M, N=D, K=8 * H, lda=8 * H, ldb=8 * H, ldc=D)
+    gemm(G.view(-1), Wcat, transB=True, out=dx, M=M, N=D, K=8 * H, lda=8 * H, ldb=8 * H, ldc=D, amax=amax)
     return dx
 
 
-def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate, part='all', dbpart=None, x3_side=None):
+def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate, part='all', dbpart=None, x3_side=None, amax=None):
     """Weight gradients of one BLSTM layer from dZ (= G after blstm_bwd_recurrent), written (or accumulated) into the given
     buffers: dWx = x^T dZ, dU = h_prev^T dZ (time-shifted, masked at sequence boundaries), db = column sums.
     part: 'all' | 'wx' (input kernels + biases) | 'u' (recurrent kernels) -- the two halves are independent and may be
-    issued on different streams."""
+    issued on different streams.  amax: (bound of x, bound of out, bound of dZ) -> fp16x3 products."""
     lib = load()
+    am_wx = (amax[0], amax[2]) if amax is not None else None
+    am_u = (amax[1], amax[2]) if amax is not None else None
     B, T, D = x.shape
     H = dKf.shape[1] // 4
     M = B * T
@@ -713,7 +804,7 @@ def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate, part='all', dbp
         if _twin(dKf, dKb):
             # twin-interleaved gradient block: [dWx_f | dWx_b] IS a row-major [D, 8H] matrix -> written in place
             gemm(x2, dZf, transA=True, M=D, N=8 * H, K=M, lda=D, ldb=8 * H, ldc=8 * H, accumulate=acc,
-                 out=torch.as_strided(dKf, (D, 8 * H), (8 * H, 1)))
+                 out=torch.as_strided(dKf, (D, 8 * H), (8 * H, 1)), amax=am_wx)
         else:
             dWcat = gemm(x2, dZf, transA=True, M=D, N=8 * H, K=M, lda=D, ldb=8 * H, ldc=8 * H,
                          out=torch.empty((D, 8 * H), dtype=torch.float32, device=x.device))
@@ -754,7 +845,7 @@ def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate, part='all', dbp
         elif dKf.stride(0) == dKb.stride(0):
             # both directions in ONE launch: 2 x (3 x 10) tiles share the chip instead of queueing behind each other
             gemm_batched2(of, of[2 * H + H:], dZf[8 * H:], dZb, dKf[D:], dKb[D:], True, False, H, 4 * H, M - 1, 2 * H, 8 * H,
-                          dKf.stride(0), accumulate=acc, mask=(T, T - 1))
+                          dKf.stride(0), accumulate=acc, mask=(T, T - 1), amax=am_u)
         else:
             gemm(of, dZf[8 * H:], transA=True, out=dKf[D:], accumulate=acc, M=H, N=4 * H, K=M - 1, lda=2 * H, ldb=8 * H,
                  ldc=dKf.stride(0), mask=(T, T - 1))
@@ -856,6 +947,10 @@ def dpcl_loss_bwd_u(U, Y, inv, ws, upstream=None):
           'ams_dpcl_loss_bwd_u')
     if ev is not None:      # read U, Y, 1/|u|; write dU
         PROFILE.end(ev, 2.0 * B * TF * (E + S) * E, 4.0 * B * TF * (2 * E + S + 1), 'dpcl_bwd_u', 'dpcl')
+    if F16X3:
+        # max |dU| came out of the same pass (include/ams.h: ams_dpcl_u_amax_offset): the bound of the two dense-layer products
+        off = load().ams_dpcl_u_amax_offset(B, TF, E, S) // 4
+        tag_amax(d, ws.view(-1)[off:off + 1])
     return d
 
 

@@ -69,6 +69,10 @@ class FlatOptimizer(object):
             self.acc = z()
         else:
             raise ValueError('unknown optimizer %r' % kind)
+        # fp16x3 products (ops.set_amax) scale their weight operand by ONE bound over everything this optimizer owns, measured
+        # at its first use in every pass (ops.param_amax)
+        if ops.F16X3 and dev.type == 'cuda' and n > 0:
+            ops.register_param_source(self.vars, self.flat)
 
     # tf.train.exponential_decay(lr, global_epoch, decay_epoch, 0.5, staircase=True)  (network.py:175-177)
     def learning_rate(self):

@@ -390,9 +390,10 @@ __global__ __launch_bounds__(1024) void dpcl_finish_kernel(const float* __restri
     for (int i = tid; i < E * S; i += blockDim.x) m[E * E + i] = gram[(i / S) * Z + E + (i % S)] * ka;
 }
 
-__global__ void dpcl_mean_kernel(const float* __restrict__ per_utt, float* __restrict__ out, int B) {
+__global__ void dpcl_mean_kernel(const float* __restrict__ per_utt, float* __restrict__ out, int B, unsigned* __restrict__ clear = nullptr) {
     // out[0] = cost, out[1..3] = the three summary terms (dpcl.py:82-85)
     const int k = threadIdx.x;
+    if (k == 4 && clear) clear[0] = 0u;             // the backward's max |dU| slot
     if (k < 4) {
         float s = 0.f;
         for (int b = 0; b < B; ++b) s += per_utt[b * 4 + k];
@@ -483,8 +484,9 @@ template <int NT, int EC, int SC>                  // EC / SC: compile-time E / 
 __global__ __launch_bounds__(256, 2) void dpcl_bwd_u_kernel(const float* __restrict__ U, const float* __restrict__ Y,
                                                          const float* __restrict__ cntp, const float* __restrict__ mats,
                                                          const float* __restrict__ inv, const float* __restrict__ upstream,
-                                                         float* __restrict__ dU, long TF, int E_rt, int S_rt) {
+                                                         float* __restrict__ dU, long TF, int E_rt, int S_rt, unsigned* __restrict__ amax_out) {
     const int E = EC ? EC : E_rt;
+    unsigned amax_bits = 0;
     const int S = SC ? SC : S_rt;
     constexpr int Z = NT * 16, ZP = Z + 4, KT = Z / 4;
     constexpr int PTS = NT <= 3 ? AMS_DPCL_PTS : 128;
@@ -651,13 +653,20 @@ __global__ __launch_bounds__(256, 2) void dpcl_bwd_u_kernel(const float* __restr
                 const int i4 = tid + 256 * j;
                 if (i4 < nvec && i4 * 4 < npts * E && (!(AMS_DPCL_DBG & 8) || zt[0] == 12345.f)) {
                     const int pnt = (i4 * 4) / E, e = i4 * 4 - pnt * E;
-                    dst[i4] = *reinterpret_cast<const float4*>(&zt[pnt * ZP + e]);
+                    const float4 o = *reinterpret_cast<const float4*>(&zt[pnt * ZP + e]);
+                    dst[i4] = o;
+                    amax_bits = max(max(amax_bits, __float_as_uint(o.x) & 0x7fffffffu), max(max(__float_as_uint(o.y) & 0x7fffffffu, __float_as_uint(o.z) & 0x7fffffffu), __float_as_uint(o.w) & 0x7fffffffu));
                 }
             }
         } else {
             float* dst = dUb + p0 * E;
-            for (int i = tid; i < npts * E; i += 256) dst[i] = zt[(i / E) * ZP + (i % E)];
+            for (int i = tid; i < npts * E; i += 256) { const float o = zt[(i / E) * ZP + (i % E)]; dst[i] = o; amax_bits = max(amax_bits, __float_as_uint(o) & 0x7fffffffu); }
         }
+    }
+    if (amax_out) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax_bits = max(amax_bits, (unsigned)__shfl_xor((int)amax_bits, o));
+        if (lane == 0) atomicMax(amax_out, amax_bits);
     }
 }
 
@@ -681,8 +690,9 @@ template <int EC, int SC>
 __global__ __launch_bounds__(256) void dpcl_bwd_u2_kernel(const float* __restrict__ U, const float* __restrict__ Y,
                                                           const float* __restrict__ cntp, const float* __restrict__ mats,
                                                           const float* __restrict__ inv, const float* __restrict__ upstream,
-                                                          float* __restrict__ dU, long TF) {
+                                                          float* __restrict__ dU, long TF, unsigned* __restrict__ amax_out) {
     constexpr int E = EC, S = SC, NT = 3, NJ = 3;
+    unsigned amax_bits = 0;
     static_assert(E % 4 == 0 && E + S <= 48 && S <= 4 && E > 32, "layout of dpcl_bwd_u2_kernel");
     const int b = blockIdx.y, c = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -783,6 +793,7 @@ __global__ __launch_bounds__(256) void dpcl_bwd_u2_kernel(const float* __restric
                 o.z = active ? (dd[ft][2] - z[ft][2] * dot) * iv : dd[ft][2] * iv;
                 o.w = active ? (dd[ft][3] - z[ft][3] * dot) * iv : dd[ft][3] * iv;
                 reinterpret_cast<float4*>(dUb + p * E)[4 * ft + slot] = o;
+                amax_bits = max(max(amax_bits, __float_as_uint(o.x) & 0x7fffffffu), max(max(__float_as_uint(o.y) & 0x7fffffffu, __float_as_uint(o.z) & 0x7fffffffu), __float_as_uint(o.w) & 0x7fffffffu));
             }
         }
     };
@@ -803,6 +814,11 @@ __global__ __launch_bounds__(256) void dpcl_bwd_u2_kernel(const float* __restric
         if (g + 32 >= w_end) break;
         if (g + 64 < w_end) fetch(g + 64 + e_lo, g1b);
         compute(g + 32, g2b);
+    }
+    if (amax_out) {                                 // max |dU| of this wave: the operand bound of the products that read dU
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) amax_bits = max(amax_bits, (unsigned)__shfl_xor((int)amax_bits, o));
+        if (lane == 0) atomicMax(amax_out, amax_bits);
     }
 }
 
@@ -873,11 +889,18 @@ ams_status ams_dpcl_loss_bwd(const float* V, const float* Y, const float* inv, c
     return ams_check_launch();
 }
 
-size_t ams_dpcl_u_workspace_bytes(int B, long TF, int E, int S) {
+// byte offset, inside the ams_dpcl_loss_fwd_u workspace, of max |dU| (as a float): cleared by the forward, filled by ams_dpcl_loss_bwd_u --
+// the operand bound ams_gemm_set_amax wants for the two dense-layer products that read dU
+size_t ams_dpcl_u_amax_offset(int B, long TF, int E, int S) {
     const int NT = ceil_div(E + S, 16), Z = NT * 16;
     const int nchunk = ceil_div(TF, UCHUNK);
-    // cntp [B,CP,S] | per_utt [B,4] | mats [B, E*E+E*S] | partials [B, nchunk, Z*Z]
-    return sizeof(float) * ((size_t)B * CP * S + (size_t)B * 4 + (size_t)B * (E * E + E * S) + (size_t)B * nchunk * Z * Z);
+    const size_t n = sizeof(float) * ((size_t)B * CP * S + (size_t)B * 4 + (size_t)B * (E * E + E * S) + (size_t)B * nchunk * Z * Z);
+    return (n + 15) / 16 * 16;
+}
+
+size_t ams_dpcl_u_workspace_bytes(int B, long TF, int E, int S) {
+    // cntp [B,CP,S] | per_utt [B,4] | mats [B, E*E+E*S] | partials [B, nchunk, Z*Z] | bound of dU (1 float, 16-byte slot)
+    return ams_dpcl_u_amax_offset(B, TF, E, S) + 16;
 }
 
 // Fused l2-normalise + loss forward on the dense output U [B,TF,E].  inv [B,TF] receives 1/|u| (needed by the
@@ -907,7 +930,7 @@ ams_status ams_dpcl_loss_fwd_u(const float* U, const float* Y, float* inv, float
         default: hipLaunchKernelGGL((dpcl_gram_u_kernel<4, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
     }
     hipLaunchKernelGGL(dpcl_finish_kernel, dim3(B), dim3(1024), Z * Z * sizeof(float), st, part, per_utt, mats, E, S, Z, nchunk, B);
-    hipLaunchKernelGGL(dpcl_mean_kernel, dim3(1), dim3(64), 0, st, per_utt, out, B);
+    hipLaunchKernelGGL(dpcl_mean_kernel, dim3(1), dim3(64), 0, st, per_utt, out, B, (unsigned*)((char*)ws + ams_dpcl_u_amax_offset(B, TF, E, S)));
     return ams_check_launch();
 }
 
@@ -919,22 +942,23 @@ ams_status ams_dpcl_loss_bwd_u(const float* U, const float* Y, const float* inv,
     const float* cntp = (const float*)ws;
     const float* mats = cntp + (size_t)B * CP * S + (size_t)B * 4;
     const int NT = ceil_div(E + S, 16);
+    unsigned* const amax_out = (unsigned*)((char*)const_cast<void*>(ws) + ams_dpcl_u_amax_offset(B, TF, E, S));     // cleared by ams_dpcl_loss_fwd_u
     if (E + S > 64) return AMS_E_INVALID_ARG;
     dim3 grid(ceil_div(TF, BCHUNK), B);
     switch (NT) {
-        case 1: hipLaunchKernelGGL((dpcl_bwd_u_kernel<1, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S); break;
-        case 2: hipLaunchKernelGGL((dpcl_bwd_u_kernel<2, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S); break;
+        case 1: hipLaunchKernelGGL((dpcl_bwd_u_kernel<1, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S, amax_out); break;
+        case 2: hipLaunchKernelGGL((dpcl_bwd_u_kernel<2, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S, amax_out); break;
         case 3: {
             const bool al = (((uintptr_t)U & 15) == 0) && (((uintptr_t)dU & 15) == 0);
             const dim3 grid2(ceil_div(TF, BCH2), B);
-            if (E == 40 && S == 2 && al && dpcl_direct()) hipLaunchKernelGGL((dpcl_bwd_u2_kernel<40, 2>), grid2, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF);
-            else if (E == 40 && S == 3 && al && dpcl_direct()) hipLaunchKernelGGL((dpcl_bwd_u2_kernel<40, 3>), grid2, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF);
-            else if (E == 40 && S == 2 && al) hipLaunchKernelGGL((dpcl_bwd_u_kernel<3, 40, 2>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S);
-            else if (E == 40 && S == 3 && al) hipLaunchKernelGGL((dpcl_bwd_u_kernel<3, 40, 3>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S);
-            else hipLaunchKernelGGL((dpcl_bwd_u_kernel<3, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S);
+            if (E == 40 && S == 2 && al && dpcl_direct()) hipLaunchKernelGGL((dpcl_bwd_u2_kernel<40, 2>), grid2, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, amax_out);
+            else if (E == 40 && S == 3 && al && dpcl_direct()) hipLaunchKernelGGL((dpcl_bwd_u2_kernel<40, 3>), grid2, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, amax_out);
+            else if (E == 40 && S == 2 && al) hipLaunchKernelGGL((dpcl_bwd_u_kernel<3, 40, 2>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S, amax_out);
+            else if (E == 40 && S == 3 && al) hipLaunchKernelGGL((dpcl_bwd_u_kernel<3, 40, 3>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S, amax_out);
+            else hipLaunchKernelGGL((dpcl_bwd_u_kernel<3, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S, amax_out);
             break;
         }
-        default: hipLaunchKernelGGL((dpcl_bwd_u_kernel<4, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S); break;
+        default: hipLaunchKernelGGL((dpcl_bwd_u_kernel<4, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, mats, inv, upstream, dU, TF, E, S, amax_out); break;
     }
     return ams_check_launch();
 }

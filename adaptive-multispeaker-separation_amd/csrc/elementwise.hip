@@ -307,12 +307,47 @@ __global__ void sum_final_kernel(const float* __restrict__ part, float* __restri
     if (threadIdx.x == 0) out[0] = sm[0] + sm[1] + sm[2] + sm[3];
 }
 
+// max |x| as float bits (non-negative floats order like unsigned integers; a NaN anywhere wins and comes out as NaN): operand bound
+// of the fp16x3 products (csrc/gemm.hip).  out[0] must be zero on entry (the entry point clears it).
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long n, unsigned* __restrict__ out) {
+    __shared__ unsigned sm[4];
+    unsigned m = 0;
+    const long n4 = n / 4;
+    const bool al = ((uintptr_t)x & 15) == 0;
+    if (al) {
+        const uint4* x4 = reinterpret_cast<const uint4*>(x);
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+            const uint4 v = x4[i];
+            m = max(max(m, v.x & 0x7fffffffu), max(max(v.y & 0x7fffffffu, v.z & 0x7fffffffu), v.w & 0x7fffffffu));
+        }
+        for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+    } else {
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicMax(out, max(max(sm[0], sm[1]), max(sm[2], sm[3])));
+}
+
 // one device-clock stamp (constant 100 MHz counter): brackets a launch INSIDE a captured hipGraph, where HIP events cannot be read back
 __global__ void stamp_kernel(unsigned long long* __restrict__ buf, int slot) { buf[slot] = wall_clock64(); }
 
 }  // namespace
 
 extern "C" {
+
+ams_status ams_absmax_f32(const float* x, long n, float* out, void* stream) {
+    AMS_REQUIRE(x && out && n > 0);
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) return ams_check_launch();
+    long blocks = (n / 4 + 255) / 256 / 8;          // ~8 float4 per thread
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, (unsigned*)out);
+    return ams_check_launch();
+}
 
 ams_status ams_stamp(void* buf, int slot, void* stream) {
     AMS_REQUIRE(buf && slot >= 0);

@@ -23,10 +23,13 @@
 namespace {
 
 thread_local int t_gemm_lds_pad = 0;
+// one-shot: operand bounds for the NEXT product launched from this thread (ams_gemm_set_amax); consumed and cleared by launch()
+thread_local const float* t_amax_a = nullptr;
+thread_local const float* t_amax_b = nullptr;
 std::atomic<int> g_gemm_arith{-1};        // -1: not chosen yet (AMS_GEMM_X6, default 1), 0: native f32 MFMA, 1: bf16x6
 
 // Tuning overrides (A/B runs only): read from the environment ONCE per process, never on the launch path.
-struct GemmTuning { int group_m, splits, x6cfg, x6rule, x6persist; bool noprio, novec; };
+struct GemmTuning { int group_m, splits, x6cfg, x6rule, x6persist; bool noprio, novec, f16x3; };
 inline const GemmTuning& tuning() {
     static const GemmTuning t = [] {
         GemmTuning v{0, 0, -1, 2, false, false};
@@ -34,6 +37,7 @@ inline const GemmTuning& tuning() {
         if (const char* f = getenv("AMS_GEMM_SPLITS")) v.splits = atoi(f);
         v.noprio = getenv("AMS_GEMM_NOPRIO") != nullptr;
         { const char* e = getenv("AMS_X6_PERSIST"); v.x6persist = e ? atoi(e) : 1; }
+        { const char* e = getenv("AMS_GEMM_F16X3"); v.f16x3 = !(e && atoi(e) == 0); }
         v.novec = getenv("AMS_GEMM_NOVEC") != nullptr;
         if (const char* f = getenv("AMS_GEMM_X6CFG")) v.x6cfg = atoi(f);       // force one bf16x6 tile configuration (0, 1 or 3: X6Cfg)
         if (const char* f = getenv("AMS_GEMM_X6RULE")) v.x6rule = atoi(f);
@@ -108,6 +112,9 @@ struct GemmArgs {
     // column sums of B (B_ROW, VEC path): the tile_m == 0 workgroups add up the B rows they stage anyway and write one partial
     // row per split to bsum_part [splits, N]; a finishing kernel adds the splits into bsum_out (bias gradient = colsum(dY))
     float* bsum_part;
+    // fp16x3 arithmetic: device pointers to an upper bound of max|A|, max|B| over the WHOLE operand tensors (all batches); the kernel
+    // derives the power-of-two operand scales from them
+    const float* amax_a; const float* amax_b;
 };
 
 __device__ __forceinline__ long rowmap(const GemmArgs& g, int m) {
@@ -604,6 +611,30 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {           // v_c
     const f32x2_t v = {a, b};
     return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
+// fp16x3 (round 3): two fp16 planes per operand instead of three bf16 planes, three products instead of six.
+//   a * s = h0 + h1 + e,  h0 = fp16(a s),  h1 = fp16(a s - h0),  |e| <= 2^-22 |a s|   (both conversions round to nearest; h0 * h0' is exact in f32)
+//   a.b ~ [h0.h0' + (h0.h1' + h1.h0')] / (s s')   -- dropped: h1.h1' (2^-22) and e: the same 2^-22 level as the f32 accumulation itself
+// s = 2^(13 - floor(log2(amax))): the largest operand entry lands in [2^13, 2^14) (fp16 overflows at 65504), entries down to amax * 2^-17
+// keep all 22 bits, smaller ones an absolute error of amax * 2^-39.  bf16x6 needs no scale (bf16 has the f32 exponent) and stays the
+// arithmetic of every launch that does not supply the bounds.
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_f16(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2_t));
+}
+__device__ __forceinline__ void split2h(float a, float b, unsigned& hi, unsigned& mid) {
+    hi = pk_f16(a, b);
+    const f16x2_t h = __builtin_bit_cast(f16x2_t, hi);
+    mid = pk_f16(a - (float)h[0], b - (float)h[1]);
+}
+// 2^(13 - floor(log2(amax))) for a finite positive amax; 1 for 0, denormals, Inf and NaN (which then propagate as they would in f32)
+__device__ __forceinline__ float f16_scale(float amax) {
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+    if (e == 0 || e == 255) return 1.0f;
+    const int se = 127 + 13 - (e - 127);            // biased exponent of the scale
+    return (se >= 1 && se <= 254) ? __uint_as_float((unsigned)se << 23) : 1.0f;
+}
 __device__ __forceinline__ void split3(float a, float b, unsigned& hi, unsigned& mid, unsigned& lo) {
 #if AMS_X6_DBG & 1
     hi = __builtin_amdgcn_perm(__float_as_uint(b), __float_as_uint(a), 0x07060302u); mid = hi; lo = hi; return;
@@ -620,7 +651,7 @@ template <int R>
 __device__ __forceinline__ int x6_slot(int n) { return (n & 3) * (R / 4) + (((n >> 2) + 4 * (n & 3)) & (R / 4 - 1)); }
 __device__ __forceinline__ float comp4(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
-template <int AMODE, int BMODE, int CFG, int EPI, bool SEP>
+template <int AMODE, int BMODE, int CFG, int EPI, bool SEP, bool F16>
 // PERSISTENT over work items (round 3): the grid is at most one resident set of workgroups (ams_gemm launch: 256 CUs x the
 // configuration's workgroups per CU) and a workgroup walks items blockIdx.x, + gridDim.x, ... .  The operands of the NEXT item's first
 // k-tile are requested BEFORE the epilogue stores of the finished one, so the stores (210 MB for the dense forward product: ~10 us per
@@ -756,7 +787,14 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
     float4 bsum4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // split the staged f32 values and write the three bf16 images of one operand (R rows; plane / part strides PL / PT)
-    auto stash_k = [&](unsigned char* base, int PL, int PT, int NS, float4 (&rv)[4], bool (&vv)[4]) {      // k-contiguous source
+    // fp16x3: the power-of-two operand scales (workgroup-uniform) and the factor that undoes both on the accumulators
+    float sc_a = 1.0f, sc_b = 1.0f, sc_inv = 1.0f;
+    if constexpr (F16) {
+        sc_a = f16_scale(g0.amax_a[0]);
+        sc_b = f16_scale(g0.amax_b[0]);
+        sc_inv = (1.0f / sc_a) * (1.0f / sc_b);     // exact: powers of two, |exponent| <= 140 each way -- may leave the f32 range only where the f32 result would
+    }
+    auto stash_k = [&](unsigned char* base, int PL, int PT, int NS, float4 (&rv)[4], bool (&vv)[4], float sc) {      // k-contiguous source
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
@@ -764,43 +802,57 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
             if (!vv[2 * h]) rv[2 * h] = z;
             if (!vv[2 * h + 1]) rv[2 * h + 1] = z;
             uint4 hi, mid, lo;
+            if constexpr (F16) {
+                split2h(rv[2 * h].x * sc, rv[2 * h].y * sc, hi.x, mid.x);
+                split2h(rv[2 * h].z * sc, rv[2 * h].w * sc, hi.y, mid.y);
+                split2h(rv[2 * h + 1].x * sc, rv[2 * h + 1].y * sc, hi.z, mid.z);
+                split2h(rv[2 * h + 1].z * sc, rv[2 * h + 1].w * sc, hi.w, mid.w);
+                lo = hi;
+            } else {
             split3(rv[2 * h].x, rv[2 * h].y, hi.x, mid.x, lo.x);
             split3(rv[2 * h].z, rv[2 * h].w, hi.y, mid.y, lo.y);
             split3(rv[2 * h + 1].x, rv[2 * h + 1].y, hi.z, mid.z, lo.z);
             split3(rv[2 * h + 1].z, rv[2 * h + 1].w, hi.w, mid.w, lo.w);
+            }
             unsigned char* p = base + kgrp * PL + (krow + (NT / 4) * h) * 16;
             if (AMS_X6_DBG & 2) { asm volatile("" :: "v"(hi.x ^ hi.y ^ hi.z ^ hi.w ^ mid.x ^ mid.y ^ mid.z ^ mid.w ^ lo.x ^ lo.y ^ lo.z ^ lo.w)); continue; }
             *reinterpret_cast<uint4*>(p) = hi;
             *reinterpret_cast<uint4*>(p + PT) = mid;
-            *reinterpret_cast<uint4*>(p + 2 * PT) = lo;
+            if (!F16) *reinterpret_cast<uint4*>(p + 2 * PT) = lo;
         }
     };
     auto stash_m = [&](unsigned char* base, int PL, int PT, int kb, int slot0, int slot1, int slot2, int slot3, float4 (&rv)[4],
-                       bool (&vv)[4]) {                                                                     // m/n-contiguous source
+                       bool (&vv)[4], float sc) {                                                           // m/n-contiguous source
         const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int q = 0; q < 4; ++q) if (!vv[q]) rv[q] = z;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             uint2 hi, mid, lo;
+            if constexpr (F16) {
+                split2h(comp4(rv[0], j) * sc, comp4(rv[1], j) * sc, hi.x, mid.x);
+                split2h(comp4(rv[2], j) * sc, comp4(rv[3], j) * sc, hi.y, mid.y);
+                lo = hi;
+            } else {
             split3(comp4(rv[0], j), comp4(rv[1], j), hi.x, mid.x, lo.x);
             split3(comp4(rv[2], j), comp4(rv[3], j), hi.y, mid.y, lo.y);
+            }
             const int slot = j == 0 ? slot0 : j == 1 ? slot1 : j == 2 ? slot2 : slot3;
             unsigned char* p = base + (kb >> 1) * PL + slot * 16 + (kb & 1) * 8;
             if (AMS_X6_DBG & 2) { asm volatile("" :: "v"(hi.x ^ hi.y ^ mid.x ^ mid.y ^ lo.x ^ lo.y)); continue; }
             *reinterpret_cast<uint2*>(p) = hi;
             *reinterpret_cast<uint2*>(p + PT) = mid;
-            *reinterpret_cast<uint2*>(p + 2 * PT) = lo;
+            if (!F16) *reinterpret_cast<uint2*>(p + 2 * PT) = lo;
         }
     };
     const int sa0 = x6_slot<BMX>(4 * mbA), sa1 = x6_slot<BMX>(4 * mbA + 1), sa2 = x6_slot<BMX>(4 * mbA + 2), sa3 = x6_slot<BMX>(4 * mbA + 3);
     const int sb0 = x6_slot<BNX>(4 * mbB), sb1 = x6_slot<BNX>(4 * mbB + 1), sb2 = x6_slot<BNX>(4 * mbB + 2), sb3 = x6_slot<BNX>(4 * mbB + 3);
     auto stash = [&]() {
-        if (AK) stash_k(As, A_PLANE, A_PART, NSA, ra, va);
-        else if (actA) stash_m(As, A_PLANE, A_PART, kbA, sa0, sa1, sa2, sa3, ra, va);
-        if (BKc) stash_k(Bs, B_PLANE, B_PART, NSB, rb, vb);
+        if (AK) stash_k(As, A_PLANE, A_PART, NSA, ra, va, sc_a);
+        else if (actA) stash_m(As, A_PLANE, A_PART, kbA, sa0, sa1, sa2, sa3, ra, va, sc_a);
+        if (BKc) stash_k(Bs, B_PLANE, B_PART, NSB, rb, vb, sc_b);
         else if (actB) {
-            stash_m(Bs, B_PLANE, B_PART, kbB, sb0, sb1, sb2, sb3, rb, vb);
+            stash_m(Bs, B_PLANE, B_PART, kbB, sb0, sb1, sb2, sb3, rb, vb, sc_b);
             if (do_bsum) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { bsum4.x += rb[r].x; bsum4.y += rb[r].y; bsum4.z += rb[r].z; bsum4.w += rb[r].w; }
@@ -828,29 +880,35 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
     auto mfma_tile = [&]() {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8_t b[TN][3];
+            constexpr int NP = F16 ? 2 : 3;
+            bf16x8_t b[TN][NP];
 #pragma unroll
             for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int p = 0; p < 3; ++p) b[j][p] = frag(bp[j] + p * B_PART + ks * 2 * B_PLANE);
+                for (int p = 0; p < NP; ++p) b[j][p] = frag(bp[j] + p * B_PART + ks * 2 * B_PLANE);
 #pragma unroll
             for (int ip = 0; ip < TM; ip += 2) {        // two m-tiles at a time: 24 MFMAs on four alternating accumulators
-                bf16x8_t a[2][3];
+                bf16x8_t a[2][NP];
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int p = 0; p < 3; ++p) a[i][p] = frag(ap[ip + i] + p * A_PART + ks * 2 * A_PLANE);
+                    for (int p = 0; p < NP; ++p) a[i][p] = frag(ap[ip + i] + p * A_PART + ks * 2 * A_PLANE);
                 // smallest partial products first
-                constexpr int PA[6] = {2, 0, 1, 1, 0, 0};
-                constexpr int PB[6] = {0, 2, 1, 0, 1, 0};
+                constexpr int NPROD = F16 ? 3 : 6;
+                constexpr int PA[6] = {F16 ? 1 : 2, 0, F16 ? 0 : 1, 1, 0, 0};
+                constexpr int PB[6] = {0, F16 ? 1 : 2, F16 ? 0 : 1, 0, 1, 0};
 #pragma unroll
-                for (int t = 0; t < 6; ++t)
+                for (int t = 0; t < NPROD; ++t)
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j) {
                             if (AMS_X6_DBG & 4) { asm volatile("" :: "v"(a[i][PA[t]]), "v"(b[j][PB[t]])); continue; }
-                            if (SEP && t < 5)
+                            if constexpr (F16) {
+                                const f16x8_t fa = __builtin_bit_cast(f16x8_t, a[i][PA[t]]), fb = __builtin_bit_cast(f16x8_t, b[j][PB[t]]);
+                                if (SEP && t < NPROD - 1) accs[ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, accs[ip + i][j], 0, 0, 0);
+                                else acc[ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa, fb, acc[ip + i][j], 0, 0, 0);
+                            } else if (SEP && t < 5)
                                 accs[ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], accs[ip + i][j], 0, 0, 0);
                             else
                                 acc[ip + i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA[t]], b[j][PB[t]], acc[ip + i][j], 0, 0, 0);
@@ -902,6 +960,12 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] += accs[i][j];
         }
+        if constexpr (F16) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] *= sc_inv;
+        }
         if constexpr (EPI == EPI_MAXPOOL) {             // stride-1 conv + max_pool_with_argmax (models/adapt.py:115-117), 128 x 128 tile only
             static_assert(CFG == 0, "the max-pool epilogue is written for 2 x 2 waves of 64 x 64");
             __syncthreads();                            // every wave is done with the LDS images
@@ -946,10 +1010,10 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
     }
 }
 
-template <int AMODE, int BMODE, int CFG, int EPI = EPI_STORE, bool SEP = false>
+template <int AMODE, int BMODE, int CFG, int EPI = EPI_STORE, bool SEP = false, bool F16 = false>
 __global__ __launch_bounds__(X6Cfg<CFG>::WMC * X6Cfg<CFG>::WNC * 64, CFG == 0 ? 2 : 1) void gemm_x6_kernel(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[x6_lds(CFG)];
-    x6_body<AMODE, BMODE, CFG, EPI, SEP>(g, smem);
+    x6_body<AMODE, BMODE, CFG, EPI, SEP, F16>(g, smem);
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, const float* __restrict__ bias,
@@ -1082,6 +1146,13 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
                      (BKcc ? (g.K % 4 == 0 && g.K >= 4) : (g.N % 4 == 0 && g.N >= 4));
     const bool x6 = vec && use_x6();
     const int cfg = x6 ? x6_choose_cfg(g.M, g.N, t_gemm_lds_pad > 0) : 0;
+    // fp16x3 when the caller supplied bounds for both operands (one-shot: consumed here whatever kernel ends up running)
+    const float* const amax_a = t_amax_a;
+    const float* const amax_b = t_amax_b;
+    t_amax_a = t_amax_b = nullptr;
+    const bool f16 = x6 && cfg != 1 && amax_a && amax_b && tuning().f16x3;
+    g.amax_a = f16 ? amax_a : nullptr;
+    g.amax_b = f16 ? amax_b : nullptr;
     const TilePlan tp = x6 ? x6_plan(cfg) : f32_plan();
     const int tiles = ceil_div(g.M, tp.bm) * ceil_div(g.N, tp.bn);
     g.group_m = choose_group_m(ceil_div(g.M, tp.bm), ceil_div(g.N, tp.bn));
@@ -1137,13 +1208,21 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
                 if (raised_x < pad) {
                     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<AMODE, BMODE, 0>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, pad);
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<AMODE, BMODE, 0, EPI_STORE, false, true>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, pad);
                     raised_x = pad;
                 }
             }
-            if (t_gemm_lds_pad > 0) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 0>), grid, dim3(256), (size_t)pad, st, g);
+            if (f16) {
+                if (t_gemm_lds_pad > 0) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 0, EPI_STORE, false, true>), grid, dim3(256), (size_t)pad, st, g);
+                else hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 0, EPI_STORE, true, true>), grid, dim3(256), 0, st, g);
+            } else if (t_gemm_lds_pad > 0) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 0>), grid, dim3(256), (size_t)pad, st, g);
             else hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 0, EPI_STORE, true>), grid, dim3(256), 0, st, g);
         } else if (cfg == 1) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 1>), grid, dim3(512), 0, st, g);
-        else if (t_gemm_lds_pad > 0) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 3>), grid, dim3(512), 0, st, g);
+        else if (f16) {
+            if (t_gemm_lds_pad > 0) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 3, EPI_STORE, false, true>), grid, dim3(512), 0, st, g);
+            else hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 3, EPI_STORE, true, true>), grid, dim3(512), 0, st, g);
+        } else if (t_gemm_lds_pad > 0) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 3>), grid, dim3(512), 0, st, g);
         else hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 3, EPI_STORE, true>), grid, dim3(512), 0, st, g);
     } else if (vec) {
         if (t_gemm_lds_pad > 40 * 1024) {
@@ -1191,6 +1270,7 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 extern "C" {
 
 void ams_gemm_set_lds_pad(int bytes) { t_gemm_lds_pad = bytes < 0 ? 0 : bytes; }
+void ams_gemm_set_amax(const float* amax_a, const float* amax_b) { t_amax_a = amax_a; t_amax_b = amax_b; }
 void ams_gemm_set_arith(int mode) { g_gemm_arith.store(mode ? 1 : 0, std::memory_order_relaxed); }
 int ams_gemm_get_arith(void) { return use_x6() ? 1 : 0; }
 
@@ -1633,6 +1713,9 @@ ams_status ams_front_maxpool_fwd(const float* x, const float* f, float* y, long 
                                  void* ws, size_t ws_bytes, void* stream) {
     AMS_REQUIRE(x && f && y && argmax && Bt > 0 && L >= P && W > 0 && N > 0 && P > 0 && hop > 0);
     hipStream_t st = (hipStream_t)stream;
+    const float* const mp_aa = t_amax_a;                         // one-shot operand bounds (ams_gemm_set_amax): consumed here
+    const float* const mp_ab = t_amax_b;
+    t_amax_a = t_amax_b = nullptr;
     const int T = (L - P) / hop + 1;
     const int pl = (W - 1) / 2;                                  // stride-1 SAME: pad_total = W-1, left = floor
     const long total = (long)Bt * T * N;
@@ -1663,6 +1746,10 @@ ams_status ams_front_maxpool_fwd(const float* x, const float* f, float* y, long 
             g.A = xp; g.fr_L = Lp; g.fr_pl = 0; g.a_vec = 1;
             if (use_x6()) {
                 g.k_per_split = ceil_div(W, X6_BK) * X6_BK;
+                if (mp_aa && mp_ab && tuning().f16x3) {
+                    g.amax_a = mp_aa; g.amax_b = mp_ab;
+                    hipLaunchKernelGGL((gemm_x6_kernel<A_FRAMES, B_ROW, 0, EPI_MAXPOOL, true, true>), grid, dim3(256), 0, st, g);
+                } else
                 hipLaunchKernelGGL((gemm_x6_kernel<A_FRAMES, B_ROW, 0, EPI_MAXPOOL, true>), grid, dim3(256), 0, st, g);
             } else
             hipLaunchKernelGGL((gemm_f32_kernel<A_FRAMES, B_ROW, EPI_MAXPOOL, AMS_GEMM_BK, true>), grid, dim3(256), 0, st, g);

@@ -75,6 +75,22 @@ size_t ams_gemm_workspace_bytes(int M, int N, int K);
  * by the thread until the next set uses it.  Environment overrides of tile order / split count (AMS_GEMM_*) are read once
  * per process, not per launch. */
 void ams_gemm_set_lds_pad(int bytes);
+
+/* fp16x3 product arithmetic (round 3).  ONE-SHOT, thread-local: the next product launched from this thread through any ams_gemm_* /
+   ams_front_conv_* / ams_front_maxpool_fwd entry point that takes the 16-byte-fetch path runs as fp16x3 instead of bf16x6, and the
+   setting is cleared whether or not it was used.  amax_a / amax_b: device pointers to ONE float each, an upper bound of max |value|
+   over the WHOLE A / B operand as the entry point sees it (all batches; for A_FRAMES the waveform).  The kernel scales each operand
+   by 2^(13 - floor(log2(bound))), splits it exactly into two fp16 terms (22 significant bits for entries within 2^17 of the bound,
+   an absolute error of bound * 2^-39 below), issues three fp16 MFMA products per f32 product and unscales the accumulators: f32
+   results at the error level of bf16x6 and of the f32 MFMA themselves (tests/test_gpu_gemm_f16.py holds all three against
+   float64), at half the matrix-pipe work.  A bound below the true maximum by more than 4x overflows fp16 and yields Inf/NaN (loud);
+   a bound too high by up to 2^10 costs nothing; a bound of 0, Inf or NaN selects scale 1.  Passing NULL for either pointer, a
+   launch that does not take the 16-byte-fetch path, AMS_GEMM_X6=0 or AMS_GEMM_F16X3=0 leave the arithmetic as it was.
+   Replaces nothing in the reference (tf.matmul / conv2d in f32): it is how those f32 products are issued. */
+void ams_gemm_set_amax(const float* amax_a, const float* amax_b);
+/* out[0] = max |x[i]|, i < n, as a float (NaN if any x is NaN): the bound ams_gemm_set_amax wants, for operands whose producer does
+   not supply one.  Two stream-ordered launches (a 4-byte clear, the reduction); out is a device pointer. */
+ams_status ams_absmax_f32(const float* x, long n, float* out, void* stream);
 /* Arithmetic of the products below (process-wide; default 1, or AMS_GEMM_X6 read once): 1 = "bf16x6" -- both f32 operands are
  * split EXACTLY into three bf16 terms (hi + mid + lo, round-to-nearest) and six of the nine bf16 x bf16 partial products (all but
  * mid.lo, lo.mid, lo.lo <= 2^-26 |a.b|) are accumulated in f32 on v_mfma_f32_32x32x16_bf16, which gfx950 issues at 16x the rate
@@ -192,6 +208,11 @@ ams_status ams_dpcl_loss_bwd(const float* V, const float* Y, const float* inv, c
 /* Fused training form of K13+K14: U [B,TF,E] is the dense output BEFORE tf.nn.l2_normalize (utils/ops.py:323-324);
  * one pass computes inv[B,TF] = 1/max(|u|,1e-6), the loss terms and (V_out != NULL) the normalised embeddings.
  * The backward recomputes v = u*inv and applies d loss/dV and the l2-normalise Jacobian in one pass. */
+/* Byte offset, inside the ams_dpcl_loss_fwd_u workspace, of ONE float: max |dU| of the latest ams_dpcl_loss_bwd_u on that workspace
+   (cleared by ams_dpcl_loss_fwd_u, raised by every backward since: always an upper bound of the latest dU).  It is the operand
+   bound ams_gemm_set_amax wants for the dense layer's dX and dW products, produced without another pass over the 210 MB of dU.
+   (ams_dpcl_loss_bwd_u takes the workspace as const: this slot is the one thing it writes there.) */
+size_t ams_dpcl_u_amax_offset(int B, long TF, int E, int S);
 size_t ams_dpcl_u_workspace_bytes(int B, long TF, int E, int S);
 ams_status ams_dpcl_loss_fwd_u(const float* U, const float* Y, float* inv, float* V_out, float* out, int B, long TF, int E, int S,
                                void* ws, size_t ws_bytes, void* stream);

@@ -1,0 +1,110 @@
+"""GPU: fp16x3 product arithmetic (csrc/gemm.hip, include/ams.h::ams_gemm_set_amax) against float64, next to bf16x6 and the f32 MFMA.
+
+The reference's products are f32 tf.matmul / conv2d.  fp16x3 issues each of them as three fp16 MFMA products of
+operands scaled by a power of two taken from a per-tensor bound and split exactly into two fp16 terms.  What must hold:
+  * error at the level of bf16x6 / the f32 MFMA on well-scaled data, every operand layout and tile configuration;
+  * independence of the data's magnitude (1e-30 .. 1e+30: the scale is part of the arithmetic, fp16 has 5 exponent bits);
+  * a loose bound (too high by 2^10) costs nothing, a wide dynamic range inside one operand costs what the header says;
+  * the one-shot setting does not leak into the next launch; without bounds the launch is bit-identical to bf16x6."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    from ams_hip import ops as o
+    return o
+
+
+def _err(out, A64, B64):
+    ref = A64 @ B64
+    scale = (np.linalg.norm(A64, axis=1)[:, None] * np.linalg.norm(B64, axis=0)[None, :]).max()
+    return np.abs(out.double().cpu().numpy() - ref).max() / scale
+
+
+def _ops_pair(rng, M, N, K, tA, tB, sa=1.0, sb=1.0):
+    A = torch.from_numpy((rng.randn(*((K, M) if tA else (M, K))) * sa).astype(np.float32)).cuda()
+    B = torch.from_numpy((rng.randn(*((N, K) if tB else (K, N))) * sb).astype(np.float32)).cuda()
+    A64 = (A.T if tA else A).double().cpu().numpy()
+    B64 = (B.T if tB else B).double().cpu().numpy()
+    return A, B, A64, B64
+
+
+@pytest.mark.parametrize('M,N,K,tA,tB', [(512, 384, 600, 0, 0), (640, 600, 1024, 0, 1), (600, 1024, 640, 1, 0), (300, 1200, 512, 1, 1),
+                                         (5120, 2400, 256, 0, 0), (132, 260, 68, 0, 0), (128, 128, 32, 1, 0), (4, 8, 4, 0, 0)])
+def test_fp16x3_matches_float64_like_the_other_arithmetics(ops, M, N, K, tA, tB):
+    from ams_hip._lib import load
+    lib = load()
+    rng = np.random.RandomState(M + 3 * N + 7 * K + tA + 2 * tB)
+    A, B, A64, B64 = _ops_pair(rng, M, N, K, tA, tB)
+    bounds = (ops.absmax(A), ops.absmax(B))
+    assert abs(float(bounds[0]) - float(A.abs().max())) == 0.0
+    e16 = _err(ops.gemm(A, B, transA=bool(tA), transB=bool(tB), amax=bounds), A64, B64)
+    out6 = ops.gemm(A, B, transA=bool(tA), transB=bool(tB))
+    e6 = _err(out6, A64, B64)
+    lib.ams_gemm_set_arith(0)
+    try:
+        e32 = _err(ops.gemm(A, B, transA=bool(tA), transB=bool(tB)), A64, B64)
+    finally:
+        lib.ams_gemm_set_arith(1)
+    assert e16 <= max(1.5 * max(e6, e32), 3e-8), (e16, e6, e32)
+    # the setting was one-shot: the next launch without bounds is bf16x6 again, bit for bit
+    assert torch.equal(ops.gemm(A, B, transA=bool(tA), transB=bool(tB)), out6)
+
+
+@pytest.mark.parametrize('sa,sb', [(1e-30, 1.0), (1e+30, 1e-12), (3e-8, 2e-7), (7e4, 9e4), (1.0, 1e+25)])
+def test_fp16x3_is_independent_of_the_operands_magnitude(ops, sa, sb):
+    rng = np.random.RandomState(11)
+    A, B, A64, B64 = _ops_pair(rng, 384, 512, 640, 0, 0, sa, sb)
+    out = ops.gemm(A, B, amax=(ops.absmax(A), ops.absmax(B)))
+    assert torch.isfinite(out).all()
+    assert _err(out, A64, B64) < 1.5e-7
+
+
+def test_a_loose_bound_costs_nothing_and_a_wide_range_costs_what_the_header_says(ops):
+    rng = np.random.RandomState(12)
+    A, B, A64, B64 = _ops_pair(rng, 256, 256, 512, 0, 0)
+    tight = (ops.absmax(A), ops.absmax(B))
+    loose = (tight[0] * 1024.0, tight[1] * 1024.0)
+    e_t = _err(ops.gemm(A, B, amax=tight), A64, B64)
+    e_l = _err(ops.gemm(A, B, amax=loose), A64, B64)
+    assert e_l < 1.5 * e_t + 1e-9, (e_t, e_l)
+    # one row of A at 2^-20 of the rest: that row's results are exact to bound * 2^-39 absolutely, i.e. ~2^-19 relatively
+    A2 = A.clone()
+    A2[7] *= 2.0 ** -20
+    out = ops.gemm(A2, B, amax=(ops.absmax(A2), tight[1]))
+    ref = A2.double().cpu().numpy() @ B64
+    row_rel = np.abs(out[7].double().cpu().numpy() - ref[7]).max() / np.abs(ref[7]).max()
+    rest = np.abs(np.delete(out.double().cpu().numpy(), 7, 0) - np.delete(ref, 7, 0)).max() / np.abs(ref).max()
+    assert row_rel < 2.0 ** -15 and rest < 1e-6, (row_rel, rest)
+
+
+def test_fp16x3_under_the_residency_cap_and_with_split_k(ops):
+    """The capped (single-accumulator) variants and the split-K partial slabs take the same scaling."""
+    from ams_hip._lib import load
+    lib = load()
+    rng = np.random.RandomState(13)
+    for (M, N, K, tA, tB) in [(600, 2400, 5120, 1, 0), (600, 10240, 2560, 1, 0), (5120, 600, 2400, 0, 1)]:
+        A, B, A64, B64 = _ops_pair(rng, M, N, K, tA, tB, 1e-4, 3.0)
+        bounds = (ops.absmax(A), ops.absmax(B))
+        lib.ams_gemm_set_lds_pad(50000)
+        try:
+            capped = ops.gemm(A, B, transA=bool(tA), transB=bool(tB), amax=bounds)
+            capped6 = ops.gemm(A, B, transA=bool(tA), transB=bool(tB))
+        finally:
+            lib.ams_gemm_set_lds_pad(0)
+        free = ops.gemm(A, B, transA=bool(tA), transB=bool(tB), amax=bounds)
+        # the capped variants run one accumulator (tests/test_gpu_gemm_x6.py pins what that costs bf16x6): same ceiling here
+        e_c, e_c6, e_f = _err(capped, A64, B64), _err(capped6, A64, B64), _err(free, A64, B64)
+        assert e_f < 1e-7 and e_c < max(2.0 * e_c6, 2e-7), (M, N, K, e_c, e_c6, e_f)
+
+
+def test_nan_and_inf_propagate(ops):
+    rng = np.random.RandomState(14)
+    A, B, _, _ = _ops_pair(rng, 128, 128, 64, 0, 0)
+    A[3, 5] = float('nan')
+    out = ops.gemm(A, B, amax=(ops.absmax(A), ops.absmax(B)))
+    assert torch.isnan(ops.absmax(A)).all() and torch.isnan(out[3]).all() and torch.isfinite(out[4]).all()

@@ -37,7 +37,7 @@ def main():
     ap.add_argument('--reps', type=int, default=200)
     ap.add_argument('--warm', type=int, default=100, help='untimed launches first (the clock ramps up from idle over milliseconds)')
     ap.add_argument('--only', default='', help='comma-separated substrings of the product labels to run')
-    ap.add_argument('--modes', default='0,1', help='arithmetics to time: 0 native f32, 1 bf16x6')
+    ap.add_argument('--modes', default='0,1,2', help='arithmetics to time: 0 native f32, 1 bf16x6, 2 fp16x3 (bounds measured once, outside the timing)')
     ap.add_argument('--pad', type=int, default=0, help='dynamic-LDS pad = residency cap of the launches (the step uses 50000 beside a ring)')
     a = ap.parse_args()
     lib = load()
@@ -55,23 +55,25 @@ def main():
         B64 = (B.T if tB else B).cpu().numpy().astype(np.float64)
         ref = A64 @ B64
         scale = (np.linalg.norm(A64, axis=1)[:, None] * np.linalg.norm(B64, axis=0)[None, :]).max()
+        bounds = (ops.absmax(A), ops.absmax(B))
         for mode in [int(m) for m in a.modes.split(',')]:
-            lib.ams_gemm_set_arith(mode)
+            lib.ams_gemm_set_arith(1 if mode else 0)
+            am = bounds if mode == 2 else None
             for _ in range(a.warm):
-                ops.gemm(A, B, transA=bool(tA), transB=bool(tB), out=out)
+                ops.gemm(A, B, transA=bool(tA), transB=bool(tB), out=out, amax=am)
             torch.cuda.synchronize()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(a.reps):
-                ops.gemm(A, B, transA=bool(tA), transB=bool(tB), out=out)
+                ops.gemm(A, B, transA=bool(tA), transB=bool(tB), out=out, amax=am)
             e1.record()
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / a.reps
             tf = 2.0 * M * N * K / us * 1e-6
             err = np.abs(out.cpu().numpy().astype(np.float64)[rows] - ref).max() / scale
-            extra = '  bf16 issue frac %.3f' % (6 * tf / 2500.0) if mode else ''
+            extra = '  16-bit MFMA issue frac %.3f' % ((6 if mode == 1 else 3) * tf / 2500.0) if mode else ''
             print('%-20s M=%5d N=%5d K=%5d  %s  %8.1f us  %6.1f TFLOP/s(f32-eq)  err %.2e%s'
-                  % (label, M, N, K, 'bf16x6' if mode else 'f32   ', us, tf, err, extra), flush=True)
+                  % (label, M, N, K, ('f32   ', 'bf16x6', 'fp16x3')[mode], us, tf, err, extra), flush=True)
     lib.ams_gemm_set_arith(1)
 
 
