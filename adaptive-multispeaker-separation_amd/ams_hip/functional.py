@@ -178,7 +178,7 @@ class BLSTMLayer(Function):
             dbpart = ops.blstm_bwd_recurrent(x, Kf, Kb, G, cst, _c(dout))
             am_dx = am_w = None
             if ctx.amax is not None:
-                az = ops.absmax(G)                               # G now holds dZ
+                az = ops.amax_of(G)                              # G now holds dZ; the ring left its bound, the step kernels do not
                 am_dx = (az, ctx.amax[1])
                 am_w = (ctx.amax[0], ops.amax_one(G.device), az)
             dx = None

@@ -742,6 +742,7 @@ def blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout):
         dbpart = torch.empty((B, 2, 4 * H), dtype=torch.float32, device=x.device)
         check(lib.ams_blstm_ring_bwd(_p(G), _p(cst[0]), _p(cst[1]), _p(dout), _p(dbpart), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring,
                                      _p(ring_error_word(x.device)), B, T, H, int(LSTM_RING == 'safe'), _s()), 'ams_blstm_ring_bwd')
+        tag_amax(G, sync.view(-1)[2:3])                          # max |dZ| came out of the same launch (float word 2 of the sync head)
         return dbpart
     pack = torch.empty(lib.ams_blstm_pack_floats(H, 1), dtype=torch.float32, device=x.device)
     nsync = lib.ams_blstm_persist_sync_bytes(B, H, 1) if LSTM_PERSIST else 0

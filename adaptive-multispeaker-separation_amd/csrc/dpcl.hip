@@ -14,6 +14,9 @@
 #include "common.h"
 
 // timing anatomy builds (WRONG results): 1 = no MFMAs, 2 = no norm / no epilogue arithmetic, 4 = no global loads, 8 = no global stores
+#ifndef AMS_DPCL_AMAX
+#define AMS_DPCL_AMAX 2
+#endif
 #ifndef AMS_DPCL_PTS
 #define AMS_DPCL_PTS 256
 #endif
@@ -486,7 +489,7 @@ __global__ __launch_bounds__(256, 2) void dpcl_bwd_u_kernel(const float* __restr
                                                          const float* __restrict__ inv, const float* __restrict__ upstream,
                                                          float* __restrict__ dU, long TF, int E_rt, int S_rt, unsigned* __restrict__ amax_out) {
     const int E = EC ? EC : E_rt;
-    unsigned amax_bits = 0;
+    float amax_f = 0.f;                             // max |dU| seen by this lane (v_max3_f32 with |.| modifiers)
     const int S = SC ? SC : S_rt;
     constexpr int Z = NT * 16, ZP = Z + 4, KT = Z / 4;
     constexpr int PTS = NT <= 3 ? AMS_DPCL_PTS : 128;
@@ -655,18 +658,18 @@ __global__ __launch_bounds__(256, 2) void dpcl_bwd_u_kernel(const float* __restr
                     const int pnt = (i4 * 4) / E, e = i4 * 4 - pnt * E;
                     const float4 o = *reinterpret_cast<const float4*>(&zt[pnt * ZP + e]);
                     dst[i4] = o;
-                    amax_bits = max(max(amax_bits, __float_as_uint(o.x) & 0x7fffffffu), max(max(__float_as_uint(o.y) & 0x7fffffffu, __float_as_uint(o.z) & 0x7fffffffu), __float_as_uint(o.w) & 0x7fffffffu));
+                    amax_f = fmaxf(fmaxf(amax_f, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
                 }
             }
         } else {
             float* dst = dUb + p0 * E;
-            for (int i = tid; i < npts * E; i += 256) { const float o = zt[(i / E) * ZP + (i % E)]; dst[i] = o; amax_bits = max(amax_bits, __float_as_uint(o) & 0x7fffffffu); }
+            for (int i = tid; i < npts * E; i += 256) { const float o = zt[(i / E) * ZP + (i % E)]; dst[i] = o; amax_f = fmaxf(amax_f, fabsf(o)); }
         }
     }
     if (amax_out) {
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) amax_bits = max(amax_bits, (unsigned)__shfl_xor((int)amax_bits, o));
-        if (lane == 0) atomicMax(amax_out, amax_bits);
+        for (int o = 32; o > 0; o >>= 1) amax_f = fmaxf(amax_f, __shfl_xor(amax_f, o));
+        if (lane == 0) atomicMax(amax_out, __float_as_uint(amax_f));    // a NaN in dU is dropped here and reaches the products through dU itself
     }
 }
 
@@ -692,7 +695,7 @@ __global__ __launch_bounds__(256) void dpcl_bwd_u2_kernel(const float* __restric
                                                           const float* __restrict__ inv, const float* __restrict__ upstream,
                                                           float* __restrict__ dU, long TF, unsigned* __restrict__ amax_out) {
     constexpr int E = EC, S = SC, NT = 3, NJ = 3;
-    unsigned amax_bits = 0;
+    float amax_f = 0.f;                             // max |dU| seen by this lane (v_max3_f32 with |.| modifiers)
     static_assert(E % 4 == 0 && E + S <= 48 && S <= 4 && E > 32, "layout of dpcl_bwd_u2_kernel");
     const int b = blockIdx.y, c = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -793,7 +796,7 @@ __global__ __launch_bounds__(256) void dpcl_bwd_u2_kernel(const float* __restric
                 o.z = active ? (dd[ft][2] - z[ft][2] * dot) * iv : dd[ft][2] * iv;
                 o.w = active ? (dd[ft][3] - z[ft][3] * dot) * iv : dd[ft][3] * iv;
                 reinterpret_cast<float4*>(dUb + p * E)[4 * ft + slot] = o;
-                amax_bits = max(max(amax_bits, __float_as_uint(o.x) & 0x7fffffffu), max(max(__float_as_uint(o.y) & 0x7fffffffu, __float_as_uint(o.z) & 0x7fffffffu), __float_as_uint(o.w) & 0x7fffffffu));
+                amax_f = fmaxf(fmaxf(amax_f, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
             }
         }
     };
@@ -815,10 +818,15 @@ __global__ __launch_bounds__(256) void dpcl_bwd_u2_kernel(const float* __restric
         if (g + 64 < w_end) fetch(g + 64 + e_lo, g1b);
         compute(g + 32, g2b);
     }
-    if (amax_out) {                                 // max |dU| of this wave: the operand bound of the products that read dU
+    if (amax_out && AMS_DPCL_AMAX) {                // max |dU|: the operand bound of the products that read dU
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) amax_bits = max(amax_bits, (unsigned)__shfl_xor((int)amax_bits, o));
-        if (lane == 0) atomicMax(amax_out, amax_bits);
+        for (int o = 32; o > 0; o >>= 1) amax_f = fmaxf(amax_f, __shfl_xor(amax_f, o));
+        if (AMS_DPCL_AMAX == 2) {                   // one atomic per workgroup
+            __shared__ float wm[4];
+            if (lane == 0) wm[wave] = amax_f;
+            __syncthreads();
+            if (tid == 0) atomicMax(amax_out, __float_as_uint(fmaxf(fmaxf(wm[0], wm[1]), fmaxf(wm[2], wm[3]))));
+        } else if (lane == 0) atomicMax(amax_out, __float_as_uint(amax_f));    // a NaN in dU is dropped here and reaches the products through dU itself
     }
 }
 

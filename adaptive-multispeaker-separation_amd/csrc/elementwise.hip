@@ -314,15 +314,21 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     unsigned m = 0;
     const long n4 = n / 4;
     const bool al = ((uintptr_t)x & 15) == 0;
+    const long stride = (long)gridDim.x * 256;
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    auto fold = [&](const uint4& v) {
+        m = max(max(m, v.x & 0x7fffffffu), max(max(v.y & 0x7fffffffu, v.z & 0x7fffffffu), v.w & 0x7fffffffu));
+    };
     if (al) {
         const uint4* x4 = reinterpret_cast<const uint4*>(x);
-        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-            const uint4 v = x4[i];
-            m = max(max(m, v.x & 0x7fffffffu), max(max(v.y & 0x7fffffffu, v.z & 0x7fffffffu), v.w & 0x7fffffffu));
+        for (; i + 3 * stride < n4; i += 4 * stride) {          // four independent 16-byte loads in flight per thread
+            const uint4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
+            fold(a); fold(b); fold(c); fold(d);
         }
-        for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+        for (; i < n4; i += stride) fold(x4[i]);
+        for (long j = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) m = max(m, __float_as_uint(x[j]) & 0x7fffffffu);
     } else {
-        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
+        for (; i < n; i += stride) m = max(m, __float_as_uint(x[i]) & 0x7fffffffu);
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
@@ -342,9 +348,9 @@ ams_status ams_absmax_f32(const float* x, long n, float* out, void* stream) {
     AMS_REQUIRE(x && out && n > 0);
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) return ams_check_launch();
-    long blocks = (n / 4 + 255) / 256 / 8;          // ~8 float4 per thread
+    long blocks = (n / 4 + 255) / 256 / 8;          // >= 8 float4 per thread, at most 4 workgroups per CU
     if (blocks < 1) blocks = 1;
-    if (blocks > 2048) blocks = 2048;
+    if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, (unsigned*)out);
     return ams_check_launch();
 }

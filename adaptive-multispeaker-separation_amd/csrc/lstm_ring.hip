@@ -77,6 +77,7 @@ constexpr int MAXT = 6;         // backward: 16-unit output tiles per wave: ceil
 constexpr int IDS_STRIDE = 32;  // per-chain slots in the id / flag tables (NW <= 28)
 constexpr unsigned SPIN_LIMIT = 1u << 20;
 
+constexpr int RING_AMAX_WORD = 2;     // sync head: word 0 = error word, word 2 = max |da| of a backward launch, bytes 64.. = trace
 struct RingArgs {
     float* G; float* out; float* cst; float* tch; const float* dout;   // tch [B,T,2,H] = tanh(c_t), written by the forward ring
     float* dbpart;              // backward, optional: [B,2,4H] = sum over t of da[b,t,dir,:] (bias-gradient partials)
@@ -730,6 +731,7 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
     const rsrc_t rf = make_rsrc(fl, IDS_STRIDE * 4);
     float dc_state = 0.f;
     float dbs[4] = {0.f, 0.f, 0.f, 0.f};                       // running sum over t of this element's four da (bias gradient)
+    float amax_f = 0.f;                                         // max |da| of this element over t: operand bound of the products that read dZ
 
     // per-thread base pointers (time 0) and per-time-step strides; dead threads alias element (0, 0)
     const long bl_ = live ? b : 0, ul_ = live ? u : 0;
@@ -808,6 +810,7 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
         const float da3 = live ? d_o * og * (1.0f - og) : 0.f;
         dc_state = dcv * fg;
         dbs[0] += da0; dbs[1] += da1; dbs[2] += da2; dbs[3] += da3;
+        amax_f = fmaxf(fmaxf(amax_f, fmaxf(fabsf(da0), fabsf(da1))), fmaxf(fabsf(da2), fabsf(da3)));
         if (nl < UW) {
             lds_a[r][0 * UW + nl] = da0;
             lds_a[r][1 * UW + nl] = da1;
@@ -866,6 +869,11 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) o[g * H] = dbs[g];
     }
+    // word RING_AMAX_WORD of the sync head (zeroed before the launch): max |da| over the whole launch, as float bits
+    amax_f = live ? amax_f : 0.f;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax_f = fmaxf(amax_f, __shfl_xor(amax_f, o));
+    if (lane == 0) atomicMax(a.err + RING_AMAX_WORD, __float_as_uint(amax_f));
     tr.end();
 }
 
@@ -1031,6 +1039,7 @@ ams_status ams_blstm_ring_fwd_proj(const float* x, int D, const float* Wxf, cons
 
 // Same contract as ams_blstm_recurrent_bwd (on return G holds da), without the dc workspace (the running dc lives in registers).
 // dbpart (optional, [B,2,4H]): receives sum_t da[b,t,dir,:] -- the bias gradient is then a column sum over B rows instead of B*T.
+// On return float word 2 of `sync` holds max |da| (the operand bound ams_gemm_set_amax wants for the three products that read dZ).
 ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* tch, const float* dout, float* dbpart, const float* Uf, const float* Ub,
                               long ldu, void* sync, size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream) {
     AMS_REQUIRE(G && cst && tch && dout && Uf && Ub && sync && B > 0 && T > 0 && H > 0);
