@@ -239,9 +239,15 @@ def register_param_source(variables, flat):
 
 
 def set_amax(a, b):
-    """Bounds for the NEXT product launch of this thread (one-shot).  Either None: that launch stays bf16x6."""
+    """Bounds for the NEXT product launch of this thread (one-shot).  Either None: that launch stays bf16x6.  Returns the profile
+    tag prefix of the arithmetic asked for ('gemm16' = fp16x3, 'gemm' = bf16x6 / native f32)."""
     if F16X3 and a is not None and b is not None:
+        cur = torch.cuda.current_stream()
+        a.record_stream(cur)            # the launch may be on the side stream (functional.OVERLAP): the caching allocator must not
+        b.record_stream(cur)            # hand a bound's 4 bytes to a main-stream tensor while that product has yet to read them
         load().ams_gemm_set_amax(_p(a), _p(b))
+        return 'gemm16'
+    return 'gemm'
 
 
 # ------------------------------------------------------------------ GEMM
@@ -275,12 +281,11 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False
     nb = lib.ams_gemm_workspace_bytes(M, N, K)
     ws = _ws(nb, A) if nb else None
     ev = PROFILE.begin() if PROFILE.enabled else None
-    if amax is not None:
-        set_amax(amax[0], amax[1])
+    gt = set_amax(amax[0], amax[1]) if amax is not None else 'gemm'
     check(lib.ams_gemm_f32(int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc, _p(bias), int(accumulate),
                            mask[0], mask[1], _p(ws), nb, _s()), 'ams_gemm_f32')
     if ev is not None:
-        PROFILE.end(ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N), 'gemm<%d,%d>' % (int(bool(transA)), int(bool(transB))), label)
+        PROFILE.end(ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N), gt + '<%d,%d>' % (int(bool(transA)), int(bool(transB))), label)
     return out
 
 
@@ -299,12 +304,11 @@ def gemm_at_b_colsum(A, B, out, bsum, accumulate=True, amax=None):
     ws = _ws(nb, A) if nb else None
     bws = _ws(32 * N * 4, A)
     ev = PROFILE.begin() if PROFILE.enabled else None
-    if amax is not None:
-        set_amax(amax[0], amax[1])
+    gt = set_amax(amax[0], amax[1]) if amax is not None else 'gemm'
     check(lib.ams_gemm_f32_at_b_colsum(M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), int(accumulate),
                                        _p(bsum), int(accumulate), _p(bws), _p(ws), nb, _s()), 'ams_gemm_f32_at_b_colsum')
     if ev is not None:
-        PROFILE.end(ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N), 'gemm<1,0>', '')
+        PROFILE.end(ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N), gt + '<1,0>', '')
     return True
 
 
@@ -320,12 +324,11 @@ def gemm_batched2(A0, A1, B0, B1, C0, C1, transA, transB, M, N, K, lda, ldb, ldc
     nb = lib.ams_gemm_batched_workspace_bytes(M, N, K, 2)
     ws = _ws(nb, A0) if nb else None
     ev = PROFILE.begin() if PROFILE.enabled else None
-    if amax is not None:
-        set_amax(amax[0], amax[1])
+    gt = set_amax(amax[0], amax[1]) if amax is not None else 'gemm'
     check(lib.ams_gemm_f32_batched(int(transA), int(transB), M, N, K, _p(A0), lda, da // 4, _p(B0), ldb, db_ // 4, _p(C0), ldc, dc // 4, 2,
                                    int(accumulate), mask[0], mask[1], _p(ws), nb, _s()), 'ams_gemm_f32_batched')
     if ev is not None:
-        PROFILE.end(ev, 2 * 2.0 * M * N * K, 2 * 4.0 * (M * K + K * N + M * N), 'gemm<%d,%d>' % (int(bool(transA)), int(bool(transB))))
+        PROFILE.end(ev, 2 * 2.0 * M * N * K, 2 * 4.0 * (M * K + K * N + M * N), gt + '<%d,%d>' % (int(bool(transA)), int(bool(transB))))
 
 
 def gemm_batched(A, B, C, nbatch, a_zs, b_zs, c_zs, transA, transB, M, N, K, lda, ldb, ldc, accumulate=False, amax=None):
@@ -337,12 +340,11 @@ def gemm_batched(A, B, C, nbatch, a_zs, b_zs, c_zs, transA, transB, M, N, K, lda
     nb = lib.ams_gemm_batched_workspace_bytes(M, N, K, nbatch)
     ws = _ws(nb, A) if nb else None
     ev = PROFILE.begin() if PROFILE.enabled else None
-    if amax is not None:
-        set_amax(amax[0], amax[1])
+    gt = set_amax(amax[0], amax[1]) if amax is not None else 'gemm'
     check(lib.ams_gemm_f32_batched(int(transA), int(transB), M, N, K, _p(A), lda, a_zs, _p(B), ldb, b_zs, _p(C), ldc, c_zs, nbatch,
                                    int(accumulate), 0, 0, _p(ws), nb, _s()), 'ams_gemm_f32_batched')
     if ev is not None:
-        PROFILE.end(ev, nbatch * 2.0 * M * N * K, nbatch * 4.0 * (M * K + K * N + M * N), 'gemm<%d,%d>' % (int(bool(transA)), int(bool(transB))))
+        PROFILE.end(ev, nbatch * 2.0 * M * N * K, nbatch * 4.0 * (M * K + K * N + M * N), gt + '<%d,%d>' % (int(bool(transA)), int(bool(transB))))
 
 
 # ------------------------------------------------------------------ products from pre-split operands (csrc/gemm_x3.hip)
@@ -498,6 +500,12 @@ def blstm_fwd(x, Kf, bf, Kb, bb, consumer=None, amax=None):
         raise AmsError('blstm: the two direction kernels must share one row stride')
     x2 = x.view(B * T, D)
     Wcat = blstm_wcat(Kf, Kb, D)
+    if amax is None and F16X3 and x.is_cuda:
+        # no optimizer, hence no common bound of the two kernels (inference): the gathered [D, 8H] matrix is measured once per pass
+        c = getattr(Kf, '_ams_wcat_amax', None)
+        if c is None or c[0] != PASS[0]:
+            Kf._ams_wcat_amax = c = (PASS[0], absmax(Wcat, out=c[1] if c is not None else None))
+        amax = (amax_of(x), c[1])
     bias = torch.as_strided(bf, (8 * H,), (1,)) if _twin(bf, bb) else torch.cat([bf, bb])
     pre = _take_precomputed(x, Wcat, 8 * H)
     if pre is not None:

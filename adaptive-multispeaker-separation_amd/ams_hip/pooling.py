@@ -23,10 +23,13 @@ def front_maxpool_fwd(x, f, P, hop):
     am = _ll((Bt, T, N), x.device)
     nb = lib.ams_front_maxpool_workspace_bytes_w(Bt, L, N, W)
     ws = ops._ws(nb, x)
+    # 2 TFLOP of brute-force stride-1 conv: worth two small passes for the operand bounds that let it run as fp16x3
+    bounds = (ops.absmax(x), ops.absmax(f)) if ops.F16X3 else None
     ev = ops.PROFILE.begin() if ops.PROFILE.enabled else None
+    gt = ops.set_amax(*bounds) if bounds is not None else 'gemm'
     check(lib.ams_front_maxpool_fwd(_p(x), _p(f), _p(y), _p(am), Bt, L, W, N, P, hop, _p(ws), nb, _s()), 'ams_front_maxpool_fwd')
     if ev is not None:
-        ops.PROFILE.end(ev, 2.0 * Bt * L * N * W, 4.0 * (Bt * L + W * N + Bt * T * N), 'gemm')
+        ops.PROFILE.end(ev, 2.0 * Bt * L * N * W, 4.0 * (Bt * L + W * N + Bt * T * N), gt)
     return y, am
 
 

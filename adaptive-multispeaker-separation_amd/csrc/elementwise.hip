@@ -321,9 +321,12 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     };
     if (al) {
         const uint4* x4 = reinterpret_cast<const uint4*>(x);
-        for (; i + 3 * stride < n4; i += 4 * stride) {          // four independent 16-byte loads in flight per thread
-            const uint4 a = x4[i], b = x4[i + stride], c = x4[i + 2 * stride], d = x4[i + 3 * stride];
-            fold(a); fold(b); fold(c); fold(d);
+        for (; i + 7 * stride < n4; i += 8 * stride) {          // eight independent 16-byte loads in flight per thread
+            uint4 v[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) v[k] = x4[i + k * stride];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) fold(v[k]);
         }
         for (; i < n4; i += stride) fold(x4[i]);
         for (long j = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) m = max(m, __float_as_uint(x[j]) & 0x7fffffffu);
@@ -348,9 +351,9 @@ ams_status ams_absmax_f32(const float* x, long n, float* out, void* stream) {
     AMS_REQUIRE(x && out && n > 0);
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) return ams_check_launch();
-    long blocks = (n / 4 + 255) / 256 / 8;          // >= 8 float4 per thread, at most 4 workgroups per CU
+    long blocks = (n / 4 + 255) / 256 / 8;          // >= 8 float4 per thread, at most 8 workgroups per CU
     if (blocks < 1) blocks = 1;
-    if (blocks > 1024) blocks = 1024;
+    if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, (unsigned*)out);
     return ams_check_launch();
 }

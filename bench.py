@@ -27,9 +27,11 @@ for _p in (ROOT, PKG):
 
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # same guide: v_mfma_f32_32x32x16_bf16 dense peak
-# The products run as "bf16x6" by default (csrc/gemm.hip): every f32 operand is split EXACTLY into three bf16 terms and six bf16 MFMA
-# products are accumulated in f32 per f32 product -- f32-level error (tests/test_gpu_gemm_x6.py) on the bf16 matrix pipe.  The
-# roofline prices the ALGORITHMIC f32 flops (2 M N K) against what that pipe can deliver for them: bf16 peak / 6.
+# The products run on the 16-bit matrix pipe as f32 arithmetic (csrc/gemm.hip): "fp16x3" where the caller has a bound of each operand
+# (every product of this step but the front conv: both f32 operands scaled by a power of two and split EXACTLY into two fp16 terms,
+# three fp16 MFMA products per f32 product), "bf16x6" otherwise (three bf16 terms, six products) -- f32-level error either way
+# (tests/test_gpu_gemm_f16.py, test_gpu_gemm_x6.py).  The roofline prices the ALGORITHMIC f32 flops (2 M N K) against what that
+# pipe can deliver for them: 16-bit MFMA peak / (MFMA products issued per f32 product, flop-weighted over the launches).
 X6_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
 HBM_PEAK_GBS = 8000.0
 
@@ -294,16 +296,28 @@ def main():
     prof = ops.PROFILE.summary(prefix='gemm')
     from ams_hip._lib import load as _load
     x6 = bool(_load().ams_gemm_get_arith())
-    peak = X6_PEAK_TFLOPS if x6 else MFMA_F32_PEAK_TFLOPS
     kname = 'gemm_x6_kernel' if x6 else 'gemm_f32_kernel'
+    # MFMA products issued per f32 product: 3 (fp16x3, profile tag gemm16<..>), 6 (bf16x6), 1 (native f32 MFMA)
+    issue = lambda tag: (3.0 if tag.startswith('gemm16') else 6.0) if x6 else 1.0     # noqa: E731
+    fl16 = sum(ops.PROFILE.summary(t)['flops'] for t in ops.PROFILE.tags() if t.startswith('gemm16'))
+    issued = sum(issue(t) * ops.PROFILE.summary(t)['flops'] for t in ops.PROFILE.tags() if t.startswith('gemm'))
+    factor = issued / prof['flops'] if prof['flops'] else 1.0
+    peak = (MFMA_BF16_PEAK_TFLOPS if x6 else MFMA_F32_PEAK_TFLOPS) / factor
     roof = None
     tj = None
     if prof['launches']:
         avg_ms = prof['ms'] / prof['launches']
         flops_per_launch = prof['flops'] / prof['launches']
         achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-        roof = {'bound': 'mfma', 'kernel': (kname + ' (6 x v_mfma_f32_32x32x16_bf16 per f32 product: exact 3-way bf16 operand split, f32 accumulate)')
-                if x6 else 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32)', 'achieved': round(achieved, 2),
+        if not x6:
+            kdesc = 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32)'
+        elif fl16 > 0.5 * prof['flops']:
+            kdesc = ('gemm_x6_kernel<.., F16=true> (fp16x3: 3 x v_mfma_f32_32x32x16_f16 per f32 product -- both operands scaled by a power of '
+                     'two from a per-tensor bound and split exactly into two fp16 terms, f32 accumulate; %.1f %% of the family\'s flops, the '
+                     'rest bf16x6)' % (100.0 * fl16 / prof['flops']))
+        else:
+            kdesc = kname + ' (6 x v_mfma_f32_32x32x16_bf16 per f32 product: exact 3-way bf16 operand split, f32 accumulate)'
+        roof = {'bound': 'mfma', 'kernel': kdesc, 'achieved': round(achieved, 2),
                 'peak': round(peak, 1), 'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4),
                 'traffic': None, 'launches_per_step': prof['launches'] / prof_steps,
                 'avg_launch_ms': round(avg_ms, 4), 'share_of_step': round(prof['ms'] / prof_steps / (elapsed / args.steps * 1e3), 3),
@@ -314,10 +328,10 @@ def main():
                 'by_variant': {}}
         if x6:
             roof['achieved_unit_note'] = 'f32-equivalent TFLOP/s = algorithmic 2*M*N*K per launch / duration'
-            roof['peak_note'] = ('bf16 MFMA dense peak %.0f TFLOP/s / 6 bf16 products per f32 product; the same launches reach %.2f of '
-                                 'the NATIVE f32 MFMA peak (%.1f TFLOP/s), which this arithmetic is not bound by'
-                                 % (MFMA_BF16_PEAK_TFLOPS, achieved / MFMA_F32_PEAK_TFLOPS, MFMA_F32_PEAK_TFLOPS))
-            roof['bf16_mfma_flops_issued_TFLOP/s'] = round(6 * achieved, 1)
+            roof['peak_note'] = ('16-bit MFMA dense peak %.0f TFLOP/s / %.2f MFMA products issued per f32 product (3 for fp16x3 launches, 6 for '
+                                 'bf16x6, flop-weighted); the same launches reach %.2f of the NATIVE f32 MFMA peak (%.1f TFLOP/s), which this '
+                                 'arithmetic is not bound by' % (MFMA_BF16_PEAK_TFLOPS, factor, achieved / MFMA_F32_PEAK_TFLOPS, MFMA_F32_PEAK_TFLOPS))
+            roof['mfma_16bit_flops_issued_TFLOP/s'] = round(factor * achieved, 1)
         # HBM traffic of the same kernels: rocprofv3 PMC passes cannot run inside this process, so the per-launch figure is CITED
         # from the newest committed summary of `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this very workload
         # (tools/pmc_traffic.sh -> tools/pmc_summary.py; gfx950 x2 read correction applied there), tagged with the commit the
@@ -342,7 +356,7 @@ def main():
             fa = alone['family']
             ach = fa['flops'] / (fa['ms'] * 1e-3) / 1e12
             roof['standalone'] = {
-                'achieved': round(ach, 2), 'frac': round(ach / peak, 4), 'unit': 'TFLOP/s',
+                'achieved': round(ach, 2), 'frac': round(ach / peak, 4), 'unit': 'TFLOP/s',   # same arithmetic mix, hence the same peak
                 'measured': 'HIP events around each launch, %d eager steps with the side stream off (no co-resident kernel, no residency '
                             'cap): the kernel alone at the step\'s own shapes' % alone['steps'],
                 'by_variant': {kname + t[4:]: {'avg_launch_us': round(v['ms'] / v['launches'] * 1e3, 2),
@@ -389,7 +403,9 @@ def main():
         t = pf['ms'] * 1e-3
         targets['front_conv'] = {
             'kernel': kname + '<A_FRAMES> (+ split-K reduce)', 'avg_launch_us': round(pf['ms'] / pf['launches'] * 1e3, 2),
-            'TFLOP/s': round(pf['flops'] / t / 1e12, 2), 'mfma_frac': round(pf['flops'] / t / 1e12 / peak, 4),
+            'TFLOP/s': round(pf['flops'] / t / 1e12, 2),
+            'mfma_frac': round(pf['flops'] / t / 1e12 / ((MFMA_BF16_PEAK_TFLOPS / 6.0) if x6 else MFMA_F32_PEAK_TFLOPS), 4),
+            'arithmetic': 'bf16x6 (6 MFMA products per f32 product: this launch has no operand bounds at hand)' if x6 else 'native f32 MFMA',
             'vs_native_f32_mfma_peak': round(pf['flops'] / t / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
             'algorithmic_GB/s': round(pf['bytes'] / t / 1e9, 1), 'hbm_frac': round(pf['bytes'] / t / 8e12, 4),
             'note': 'strided analysis conv = dense contraction, AI ~ 250 flop/B: MFMA-bound, not HBM-bound (DESIGN.md 4)'}
@@ -399,7 +415,8 @@ def main():
         targets['blstm_input_gemm'] = {
             'kernel': kname + '<A_ROW,B_ROW>, both directions in one [B*T, D] x [D, 8H] product',
             'avg_launch_us': round(pi['ms'] / pi['launches'] * 1e3, 2), 'TFLOP/s': round(pi['flops'] / t / 1e12, 2),
-            'mfma_frac': round(pi['flops'] / t / 1e12 / peak, 4),
+            'mfma_frac': round(pi['flops'] / t / 1e12 / ((MFMA_BF16_PEAK_TFLOPS / (3.0 if fl16 > 0 else 6.0)) if x6 else MFMA_F32_PEAK_TFLOPS), 4),
+            'arithmetic': ('fp16x3 (3 MFMA products per f32 product)' if fl16 > 0 else 'bf16x6') if x6 else 'native f32 MFMA',
             'vs_native_f32_mfma_peak': round(pi['flops'] / t / 1e12 / MFMA_F32_PEAK_TFLOPS, 4)}
 
     out = {
@@ -407,7 +424,7 @@ def main():
         'value': round(value, 2), 'unit': 'mixtures/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(elapsed / args.steps * 1e3, 3), 'higher_is_better': True, 'scaling': args.scaling,
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-        'arith': ('f32 throughout; dense products as bf16x6 on the bf16 matrix pipe: exact 3-way bf16 split of both f32 operands, 6 of 9 partial '
+        'arith': ('f32 throughout; dense products on the 16-bit matrix pipe as f32 arithmetic -- fp16x3 (operands scaled by a power of two and split exactly in two fp16 terms, 3 products) where operand bounds are at hand, else bf16x6: exact 3-way bf16 split of both f32 operands, 6 of 9 partial '
                   'products (dropped: <= 2^-26 |a.b|), f32 accumulation -- error vs float64 at or below the native f32 MFMA kernel\'s '
                   '(tests/test_gpu_gemm_x6.py); `secondary.native_f32_mfma` is the same step with v_mfma_f32_32x32x2_f32 products')
         if x6 else 'f32 throughout, products on v_mfma_f32_32x32x2_f32',
