@@ -108,3 +108,38 @@ def test_nan_and_inf_propagate(ops):
     A[3, 5] = float('nan')
     out = ops.gemm(A, B, amax=(ops.absmax(A), ops.absmax(B)))
     assert torch.isnan(ops.absmax(A)).all() and torch.isnan(out[3]).all() and torch.isfinite(out[4]).all()
+
+
+def test_the_training_step_takes_fp16x3_wherever_bounds_are_at_hand(ops):
+    """A front_DPCL step at a shape whose products all take the 16-byte-fetch path: every product but the front conv (which has no
+    bounds) is launched with bounds -- a regression to bf16x6 would be silent otherwise -- and the only bounds MEASURED
+    by a pass of their own are the front output's and the weights' (dZ and dU bring theirs from the kernels that wrote them)."""
+    import tempfile
+    from tests.smoke_step import build_front_dpcl
+    tmp = tempfile.mkdtemp(prefix='ams_f16_step_')
+    trainer, tfds = build_front_dpcl(tmp, B=16, L=4096, W=64, N=64, hop=64, layer_size=600, nb_layers=2, E=40, no_summaries=True)
+    g, model = trainer.graph, trainer.model
+    calls = []
+    orig = ops.absmax
+
+    def counting(t, out=None):
+        calls.append(tuple(t.shape))
+        return orig(t, out=out)
+    ops.absmax = counting
+    try:
+        with g.as_default():
+            feed = {tfds.handle: tfds.get_handle(tfds.TRAIN), tfds.chunk_size: 4096}
+            tfds.initialize(tfds.TRAIN)
+            model.train(feed, 0)
+            del calls[:]
+            ops.PROFILE.reset(enabled=True)
+            c = float(model.train(feed, 1))
+            ops.PROFILE.enabled = False
+        tags = [r[4] for r in ops.PROFILE.records if r[4].startswith('gemm')]
+    finally:
+        ops.absmax = orig
+        ops.PROFILE.reset(False)
+    assert np.isfinite(c)
+    n16 = sum(t.startswith('gemm16') for t in tags)
+    assert n16 >= 10 and len(tags) - n16 <= 1, tags              # 2 projections, dense fwd/dX/dW, 1 LSTM dX, 2 dWx, 2 dU; front conv
+    assert len(calls) <= 2, calls                                 # the front output X and the optimizer's flat weight buffer
