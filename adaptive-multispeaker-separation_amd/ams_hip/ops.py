@@ -500,6 +500,7 @@ def blstm_fwd(x, Kf, bf, Kb, bb, consumer=None, amax=None):
         raise AmsError('blstm: the two direction kernels must share one row stride')
     x2 = x.view(B * T, D)
     Wcat = blstm_wcat(Kf, Kb, D)
+    u_amax = amax[1] if amax is not None else None               # the caller's weight bound covers the recurrent kernels too
     if amax is None and F16X3 and x.is_cuda:
         # no optimizer, hence no common bound of the two kernels (inference): the gathered [D, 8H] matrix is measured once per pass
         c = getattr(Kf, '_ams_wcat_amax', None)
@@ -547,6 +548,8 @@ def blstm_fwd(x, Kf, bf, Kb, bb, consumer=None, amax=None):
         return out, G, cst
     if nring:
         sync = _ws(nring, x)
+        if u_amax is not None and F16X3:
+            lib.ams_blstm_ring_set_amax(_p(u_amax))              # one-shot: the recurrent product of this launch runs as fp16x3
         check(lib.ams_blstm_ring_fwd(_p(G), _p(out), _p(cst[0]), _p(cst[1]), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring,
                                      _p(ring_error_word(x.device)), B, T, H, int(LSTM_RING == 'safe'), _s()), 'ams_blstm_ring_fwd')
         return out, G, cst

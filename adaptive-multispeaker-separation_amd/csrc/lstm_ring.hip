@@ -91,6 +91,7 @@ struct RingArgs {
     int B, T, H, NW, n_chains, force_safe, trace;
     // fused input projection (lstm_ring_fwdp_kernel): x [B,T,D], input parts of the two direction kernels [D, 4H] (row stride ldw), biases
     const float* x; const float* Wxf; const float* Wxb; long ldw; const float* bf; const float* bb; int D;
+    const float* amax_u;        // forward, fp16x3: device pointer to an upper bound of max |U| over both recurrent kernels
 };
 
 __device__ __forceinline__ rsrc_t make_rsrc(const void* p, unsigned bytes) {
@@ -232,8 +233,26 @@ __device__ __forceinline__ void ring_split3(float a, float b, unsigned& hi, unsi
     lo = ring_pk_bf16(sa, sb);
 }
 
-template <int NR, bool X6 = false>
+typedef _Float16 rf16x8_t __attribute__((ext_vector_type(8)));
+typedef _Float16 rf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void ring_split2h(float a, float b, unsigned& hi, unsigned& mid) {
+    const rf32x2_t v = {a, b};
+    hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, rf16x2_t));
+    const rf16x2_t h = __builtin_bit_cast(rf16x2_t, hi);
+    const rf32x2_t r = {a - (float)h[0], b - (float)h[1]};
+    mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r, rf16x2_t));
+}
+// 2^(13 - floor(log2(amax))); 1 for 0, denormals, Inf, NaN (csrc/gemm.hip::f16_scale)
+__device__ __forceinline__ float ring_f16_scale(float amax) {
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+    if (e == 0 || e == 255) return 1.0f;
+    const int se = 127 + 13 - (e - 127);
+    return (se >= 1 && se <= 254) ? __uint_as_float((unsigned)se << 23) : 1.0f;
+}
+
+template <int NR, int ARITH = 0>      // 0: v_mfma_f32_16x16x4_f32, 1: bf16x6, 2: fp16x3 (a.amax_u = bound of the recurrent kernels)
 __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
+    constexpr bool X6 = (ARITH == 1), F16 = (ARITH == 2);
     __shared__ __attribute__((aligned(16))) float red[2][4][3][64][4];     // [step parity][wave][column tile][lane][reg]
     __shared__ int lds_flag;
     int chain, w;
@@ -267,8 +286,29 @@ __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
     }
 
     // X6: the same weights as three bf16 images, 8 k-slots per lane and MFMA: slot e = 3 i + j, MFMA m = e / 8 (zero beyond 3 NR)
-    constexpr int NM = X6 ? (3 * NR + 7) / 8 : 1;
-    rbf16x8_t bq[NM][3][3];                                        // [MFMA][column tile][plane hi / mid / lo]
+    constexpr int NM = (X6 || F16) ? (3 * NR + 7) / 8 : 1;
+    rbf16x8_t bq[NM][3][F16 ? 2 : 3];                              // [MFMA][column tile][plane hi / mid / lo]
+    // fp16x3 (csrc/gemm.hip): U scaled by a power of two from its bound and split in two fp16 terms; h_{t-1} (|h| < 1) scaled by 2^13
+    float sc_u = 1.0f, sc_inv = 1.0f;
+    if constexpr (F16) {
+        sc_u = ring_f16_scale(a.amax_u[0]);
+        sc_inv = (1.0f / sc_u) * (1.0f / 8192.0f);
+#pragma unroll
+        for (int m = 0; m < NM; ++m)
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                unsigned hi[4], mid[4];
+#pragma unroll
+                for (int pr = 0; pr < 4; ++pr) {
+                    const int e0 = 8 * m + 2 * pr, e1 = e0 + 1;
+                    const float v0 = e0 < 3 * NR ? bw[e0 / 3][e0 % 3][t] : 0.f, v1 = e1 < 3 * NR ? bw[e1 / 3][e1 % 3][t] : 0.f;
+                    ring_split2h(v0 * sc_u, v1 * sc_u, hi[pr], mid[pr]);
+                }
+                const uint4 h4 = {hi[0], hi[1], hi[2], hi[3]}, m4 = {mid[0], mid[1], mid[2], mid[3]};
+                bq[m][t][0] = __builtin_bit_cast(rbf16x8_t, h4);
+                bq[m][t][1] = __builtin_bit_cast(rbf16x8_t, m4);
+            }
+    }
     if constexpr (X6) {
 #pragma unroll
         for (int m = 0; m < NM; ++m)
@@ -361,7 +401,38 @@ __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
             }
 #endif
             if (s > 0) {
-                if constexpr (X6) {
+                if constexpr (F16) {
+                    f32x4 accs[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+                    rf16x8_t aq[NM][2];
+#pragma unroll
+                    for (int m = 0; m < NM; ++m) {
+                        unsigned hi[4], mid[4];
+#pragma unroll
+                        for (int pr = 0; pr < 4; ++pr) {
+                            const int e0 = 8 * m + 2 * pr, e1 = e0 + 1;
+                            const float v0 = e0 < 3 * NR ? (e0 % 3 == 0 ? hv[e0 / 3].x : e0 % 3 == 1 ? hv[e0 / 3].y : hv[e0 / 3].z) : 0.f;
+                            const float v1 = e1 < 3 * NR ? (e1 % 3 == 0 ? hv[e1 / 3].x : e1 % 3 == 1 ? hv[e1 / 3].y : hv[e1 / 3].z) : 0.f;
+                            ring_split2h(v0 * 8192.0f, v1 * 8192.0f, hi[pr], mid[pr]);
+                        }
+                        const uint4 h4 = {hi[0], hi[1], hi[2], hi[3]}, m4 = {mid[0], mid[1], mid[2], mid[3]};
+                        aq[m][0] = __builtin_bit_cast(rf16x8_t, h4);
+                        aq[m][1] = __builtin_bit_cast(rf16x8_t, m4);
+                    }
+                    constexpr int PA[3] = {1, 0, 0};                    // lo.hi, hi.lo | hi.hi: the cross terms in their own accumulator
+                    constexpr int PB[3] = {0, 1, 0};
+#pragma unroll
+                    for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                        for (int m = 0; m < NM; ++m)
+#pragma unroll
+                            for (int t3 = 0; t3 < 3; ++t3) {
+                                const rf16x8_t fb = __builtin_bit_cast(rf16x8_t, bq[m][t3][PB[pp]]);
+                                if (pp < 2) accs[t3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aq[m][PA[pp]], fb, accs[t3], 0, 0, 0);
+                                else acc[t3] = __builtin_amdgcn_mfma_f32_16x16x32_f16(aq[m][PA[pp]], fb, acc[t3], 0, 0, 0);
+                            }
+#pragma unroll
+                    for (int t3 = 0; t3 < 3; ++t3) acc[t3] = (acc[t3] + accs[t3]) * sc_inv;
+                } else if constexpr (X6) {
                     f32x4 accs[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
                     rbf16x8_t aq[NM][3];
 #pragma unroll
@@ -918,6 +989,13 @@ inline bool ring_fwd_x6() {
     return v;
 }
 
+// AMS_LSTM_RING_F16 (read once): 0 = the forward ring never takes the fp16x3 form, whatever bound it is given
+inline bool ring_fwd_f16() {
+    static const bool v = !(getenv("AMS_LSTM_RING_F16") && atoi(getenv("AMS_LSTM_RING_F16")) == 0);
+    return v;
+}
+thread_local const float* t_ring_amax_u = nullptr;
+
 inline int ring_force_safe() {
     static const int v = getenv("AMS_LSTM_RING_SAFE") ? atoi(getenv("AMS_LSTM_RING_SAFE")) : 0;     // read once; testing aid
     return v;
@@ -970,6 +1048,8 @@ size_t ams_blstm_ring_sync_bytes(int B, int H, int backward) {
 // Same contract as ams_blstm_recurrent_fwd (G: pre-activations in, activated gates out; out; cst), plus `sync`
 // (ams_blstm_ring_sync_bytes(B, H, 0) bytes, word 0 = timeout flag) and `tch` [B,T,2,H] = tanh(c_t), which the backward ring reads
 // instead of calling tanhf again.  safe bit 0 forces the placement-independent hand-off, bit 1 turns the phase trace on.
+void ams_blstm_ring_set_amax(const float* amax_u) { t_ring_amax_u = amax_u; }
+
 ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, const float* Uf, const float* Ub, long ldu, void* sync,
                               size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream) {
     AMS_REQUIRE(G && out && cst && tch && Uf && Ub && sync && B > 0 && T > 0 && H > 0);
@@ -985,15 +1065,30 @@ ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, cons
     a.xbuf = (float*)((char*)sync + L.x);
     a.B = B; a.T = T; a.H = H; a.NW = NW; a.n_chains = n_chains; a.force_safe = ((safe & 1) || ring_force_safe()) ? 1 : 0; a.trace = (safe & 2) ? 1 : 0;
     const dim3 grid(8 * NW * ceil_div(n_chains, 8));
+    const float* const amax_u = t_ring_amax_u;      // one-shot (ams_blstm_ring_set_amax): consumed here
+    t_ring_amax_u = nullptr;
+    if (ring_fwd_x6() && amax_u && ring_fwd_f16()) {
+        a.amax_u = amax_u;
+        switch (ceil_div(NW, 4)) {
+            case 1: hipLaunchKernelGGL((lstm_ring_fwd_kernel<1, 2>), grid, dim3(256), 0, st, a); break;
+            case 2: hipLaunchKernelGGL((lstm_ring_fwd_kernel<2, 2>), grid, dim3(256), 0, st, a); break;
+            case 3: hipLaunchKernelGGL((lstm_ring_fwd_kernel<3, 2>), grid, dim3(256), 0, st, a); break;
+            case 4: hipLaunchKernelGGL((lstm_ring_fwd_kernel<4, 2>), grid, dim3(256), 0, st, a); break;
+            case 5: hipLaunchKernelGGL((lstm_ring_fwd_kernel<5, 2>), grid, dim3(256), 0, st, a); break;
+            case 6: hipLaunchKernelGGL((lstm_ring_fwd_kernel<6, 2>), grid, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((lstm_ring_fwd_kernel<7, 2>), grid, dim3(256), 0, st, a); break;
+        }
+        return ams_check_launch();
+    }
     if (ring_fwd_x6()) {
         switch (ceil_div(NW, 4)) {
-            case 1: hipLaunchKernelGGL((lstm_ring_fwd_kernel<1, true>), grid, dim3(256), 0, st, a); break;
-            case 2: hipLaunchKernelGGL((lstm_ring_fwd_kernel<2, true>), grid, dim3(256), 0, st, a); break;
-            case 3: hipLaunchKernelGGL((lstm_ring_fwd_kernel<3, true>), grid, dim3(256), 0, st, a); break;
-            case 4: hipLaunchKernelGGL((lstm_ring_fwd_kernel<4, true>), grid, dim3(256), 0, st, a); break;
-            case 5: hipLaunchKernelGGL((lstm_ring_fwd_kernel<5, true>), grid, dim3(256), 0, st, a); break;
-            case 6: hipLaunchKernelGGL((lstm_ring_fwd_kernel<6, true>), grid, dim3(256), 0, st, a); break;
-            default: hipLaunchKernelGGL((lstm_ring_fwd_kernel<7, true>), grid, dim3(256), 0, st, a); break;
+            case 1: hipLaunchKernelGGL((lstm_ring_fwd_kernel<1, 1>), grid, dim3(256), 0, st, a); break;
+            case 2: hipLaunchKernelGGL((lstm_ring_fwd_kernel<2, 1>), grid, dim3(256), 0, st, a); break;
+            case 3: hipLaunchKernelGGL((lstm_ring_fwd_kernel<3, 1>), grid, dim3(256), 0, st, a); break;
+            case 4: hipLaunchKernelGGL((lstm_ring_fwd_kernel<4, 1>), grid, dim3(256), 0, st, a); break;
+            case 5: hipLaunchKernelGGL((lstm_ring_fwd_kernel<5, 1>), grid, dim3(256), 0, st, a); break;
+            case 6: hipLaunchKernelGGL((lstm_ring_fwd_kernel<6, 1>), grid, dim3(256), 0, st, a); break;
+            default: hipLaunchKernelGGL((lstm_ring_fwd_kernel<7, 1>), grid, dim3(256), 0, st, a); break;
         }
         return ams_check_launch();
     }

@@ -173,6 +173,12 @@ ams_status ams_blstm_persist_bwd(float* G, const float* cst, const float* dout, 
  * dbpart (backward, may be NULL): [B,2,4H] receives sum_t d pre-activation[b,t,dir,:]; the bias gradients are its column sums.
  * Replaces the same dynamic_rnn while_loop (utils/ops.py:358-383). */
 size_t ams_blstm_ring_sync_bytes(int B, int H, int backward);
+/* ONE-SHOT, thread-local (like ams_gemm_set_amax): the next ams_blstm_ring_fwd launched from this thread runs its recurrent product
+   h_{t-1} . U as fp16x3 instead of bf16x6 -- U scaled by a power of two from *amax_u (device pointer: an upper bound of max |U| over
+   both recurrent kernels) and split exactly into two fp16 terms, h_{t-1} (|h| < 1) scaled by 2^13, three fp16 MFMA products, the two
+   cross terms in their own accumulator.  27 instead of 54 MFMAs per wave and step, 149 instead of 196 VGPRs.  AMS_LSTM_RING_F16=0
+   or a NULL pointer: bf16x6 as before. */
+void ams_blstm_ring_set_amax(const float* amax_u);
 ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, const float* Uf, const float* Ub, long ldu, void* sync,
                               size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream);
 /* Forward ring with the layer's input projection z_t = x_t.Wx + b computed INSIDE it by four extra waves per workgroup that work one step

@@ -73,6 +73,30 @@ def test_blstm_layer_at_benchmark_shape(ops, monkeypatch, D, ring):
     ops.raise_on_ring_errors()
 
 
+@pytest.mark.parametrize('D', [600, 256])
+def test_forward_ring_as_fp16x3_at_benchmark_shape(ops, D):
+    """The same layer with the bounds a training step supplies (functional.BLSTMLayer: input bound, ONE bound over all kernels):
+    input projection AND the ring's recurrent product run as fp16x3 (ams_gemm_set_amax / ams_blstm_ring_set_amax).  Same forward
+    tolerance as the bf16x6 form; the two forms differ (the arithmetic did change) by less than that tolerance."""
+    rng = np.random.RandomState(D)
+    lim = np.sqrt(6.0 / (D + 5 * H))
+    x = rng.randn(B, T, D) * 0.5
+    Kf, Kb = rng.uniform(-lim, lim, (D + H, 4 * H)) * 2, rng.uniform(-lim, lim, (D + H, 4 * H)) * 2
+    bf, bb = rng.randn(4 * H) * 0.1, rng.randn(4 * H) * 0.1
+    out_ref, _ = oblstm.blstm_fwd(x, Kf, bf, Kb, bb)
+    xd, Kfd, Kbd, bfd, bbd = dev(x), dev(Kf), dev(Kb), dev(bf), dev(bb)
+    bound_w = torch.maximum(ops.absmax(Kfd), ops.absmax(Kbd))
+    out16, _, _ = ops.blstm_fwd(xd, Kfd, bfd, Kbd, bbd, amax=(ops.absmax(xd), bound_w))
+    out6, _, _ = ops.blstm_fwd(xd, Kfd, bfd, Kbd, bbd)
+    e16, e6 = rel(host(out16), out_ref), rel(host(out6), out_ref)
+    d = float((out16 - out6).abs().max())
+    print('forward ring D=%d: fp16x3 %.2e, bf16x6 %.2e, difference %.2e' % (D, e16, e6, d))
+    assert e16 < FWD_TOL and e6 < FWD_TOL, (e16, e6)
+    assert 0.0 < d < FWD_TOL, d
+    assert ops.persist_errors() == 0
+    ops.raise_on_ring_errors()
+
+
 def test_dense_l2norm_dpcl_at_benchmark_shape(ops):
     """Conv1D 600 -> E*F = 10240 (utils/ops.py:486-503) + fused l2-normalise + DPCL loss (models/dpcl.py:41-87) at TF=20480, E=40,
     for B=2 utterances (160 rows of the 5120-row product: same tiles, same N and K), forward and backward down to dW, db, dh."""
