@@ -5,6 +5,9 @@
 
 thread_local int g_ams_last_hip_error = 0;
 
+#ifndef AMS_ABSMAX_BLOCKS
+#define AMS_ABSMAX_BLOCKS 256
+#endif
 namespace {
 
 inline int stream_blocks(long n, int per_block = 256) {
@@ -351,9 +354,9 @@ ams_status ams_absmax_f32(const float* x, long n, float* out, void* stream) {
     AMS_REQUIRE(x && out && n > 0);
     hipStream_t st = (hipStream_t)stream;
     if (hipMemsetAsync(out, 0, sizeof(float), st) != hipSuccess) return ams_check_launch();
-    long blocks = (n / 4 + 255) / 256 / 8;          // >= 8 float4 per thread, at most 8 workgroups per CU
-    if (blocks < 1) blocks = 1;
-    if (blocks > 2048) blocks = 2048;
+    long blocks = (n / 4 + 255) / 256 / 8;          // >= 8 float4 per thread; at most two workgroups per CU: their final atomics all
+    if (blocks < 1) blocks = 1;                     // arrive at one address at about the same time and are served one after another
+    if (blocks > AMS_ABSMAX_BLOCKS) blocks = AMS_ABSMAX_BLOCKS;
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, (unsigned*)out);
     return ams_check_launch();
 }
