@@ -92,7 +92,7 @@ class BLSTM:
         self.drop_val = drop_val
         if drop_val not in (0, 0.0):
             raise NotImplementedError('recurrent_dropout != 0 is not on the HIP path (reference default is 0.0; which part of the LSTM '
-                                      'state DropoutWrapper masks differs between the TF 1.4 and 1.5 the reference pins -- DESIGN.md 6)')
+                                      'state DropoutWrapper masks depends on the TensorFlow release -- DESIGN.md 6)')
         H = hid_dim // 2
         g = get_default_graph()
 
