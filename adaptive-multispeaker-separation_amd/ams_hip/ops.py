@@ -238,16 +238,25 @@ def register_param_source(variables, flat):
         v._ams_amax_src = src
 
 
-def set_amax(a, b):
-    """Bounds for the NEXT product launch of this thread (one-shot).  Either None: that launch stays bf16x6.  Returns the profile
-    tag prefix of the arithmetic asked for ('gemm16' = fp16x3, 'gemm' = bf16x6 / native f32)."""
-    if F16X3 and a is not None and b is not None:
+def _bounds(amax):
+    """(pointer of A's bound, pointer of B's bound, profile tag prefix) for the *_bounded product entry points: fp16x3 ('gemm16')
+    when both bounds are there, else NULLs = bf16x6 / native f32 ('gemm')."""
+    if F16X3 and amax is not None and amax[0] is not None and amax[1] is not None:
         cur = torch.cuda.current_stream()
-        a.record_stream(cur)            # the launch may be on the side stream (functional.OVERLAP): the caching allocator must not
-        b.record_stream(cur)            # hand a bound's 4 bytes to a main-stream tensor while that product has yet to read them
-        load().ams_gemm_set_amax(_p(a), _p(b))
-        return 'gemm16'
-    return 'gemm'
+        amax[0].record_stream(cur)      # the launch may be on the side stream (functional.OVERLAP): the caching allocator must not
+        amax[1].record_stream(cur)      # hand a bound's 4 bytes to a main-stream tensor while that product has yet to read them
+        return _p(amax[0]), _p(amax[1]), 'gemm16'
+    return _vp(0), _vp(0), 'gemm'
+
+
+def set_amax(a, b):
+    """Bounds for the NEXT product launch of this thread (one-shot, include/ams.h: ams_gemm_set_amax) -- for the entry points that
+    have no *_bounded form (ams_front_maxpool_fwd).  Returns the profile tag prefix of the arithmetic asked for."""
+    pa, pb, tag = _bounds((a, b))
+    if tag == 'gemm16':
+        load().ams_gemm_set_amax(pa, pb)
+    return tag
+
 
 
 # ------------------------------------------------------------------ GEMM
@@ -281,9 +290,9 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False
     nb = lib.ams_gemm_workspace_bytes(M, N, K)
     ws = _ws(nb, A) if nb else None
     ev = PROFILE.begin() if PROFILE.enabled else None
-    gt = set_amax(amax[0], amax[1]) if amax is not None else 'gemm'
-    check(lib.ams_gemm_f32(int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc, _p(bias), int(accumulate),
-                           mask[0], mask[1], _p(ws), nb, _s()), 'ams_gemm_f32')
+    pa, pb, gt = _bounds(amax)
+    check(lib.ams_gemm_f32_bounded(int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc, _p(bias), int(accumulate),
+                                   mask[0], mask[1], pa, pb, _p(ws), nb, _s()), 'ams_gemm_f32')
     if ev is not None:
         PROFILE.end(ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N), gt + '<%d,%d>' % (int(bool(transA)), int(bool(transB))), label)
     return out
@@ -304,9 +313,9 @@ def gemm_at_b_colsum(A, B, out, bsum, accumulate=True, amax=None):
     ws = _ws(nb, A) if nb else None
     bws = _ws(32 * N * 4, A)
     ev = PROFILE.begin() if PROFILE.enabled else None
-    gt = set_amax(amax[0], amax[1]) if amax is not None else 'gemm'
-    check(lib.ams_gemm_f32_at_b_colsum(M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), int(accumulate),
-                                       _p(bsum), int(accumulate), _p(bws), _p(ws), nb, _s()), 'ams_gemm_f32_at_b_colsum')
+    pa, pb, gt = _bounds(amax)
+    check(lib.ams_gemm_f32_at_b_colsum_bounded(M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), int(accumulate),
+                                               _p(bsum), int(accumulate), _p(bws), pa, pb, _p(ws), nb, _s()), 'ams_gemm_f32_at_b_colsum')
     if ev is not None:
         PROFILE.end(ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N), gt + '<1,0>', '')
     return True
@@ -324,9 +333,9 @@ def gemm_batched2(A0, A1, B0, B1, C0, C1, transA, transB, M, N, K, lda, ldb, ldc
     nb = lib.ams_gemm_batched_workspace_bytes(M, N, K, 2)
     ws = _ws(nb, A0) if nb else None
     ev = PROFILE.begin() if PROFILE.enabled else None
-    gt = set_amax(amax[0], amax[1]) if amax is not None else 'gemm'
-    check(lib.ams_gemm_f32_batched(int(transA), int(transB), M, N, K, _p(A0), lda, da // 4, _p(B0), ldb, db_ // 4, _p(C0), ldc, dc // 4, 2,
-                                   int(accumulate), mask[0], mask[1], _p(ws), nb, _s()), 'ams_gemm_f32_batched')
+    pa, pb, gt = _bounds(amax)
+    check(lib.ams_gemm_f32_batched_bounded(int(transA), int(transB), M, N, K, _p(A0), lda, da // 4, _p(B0), ldb, db_ // 4, _p(C0), ldc,
+                                           dc // 4, 2, int(accumulate), mask[0], mask[1], pa, pb, _p(ws), nb, _s()), 'ams_gemm_f32_batched')
     if ev is not None:
         PROFILE.end(ev, 2 * 2.0 * M * N * K, 2 * 4.0 * (M * K + K * N + M * N), gt + '<%d,%d>' % (int(bool(transA)), int(bool(transB))))
 
@@ -340,9 +349,9 @@ def gemm_batched(A, B, C, nbatch, a_zs, b_zs, c_zs, transA, transB, M, N, K, lda
     nb = lib.ams_gemm_batched_workspace_bytes(M, N, K, nbatch)
     ws = _ws(nb, A) if nb else None
     ev = PROFILE.begin() if PROFILE.enabled else None
-    gt = set_amax(amax[0], amax[1]) if amax is not None else 'gemm'
-    check(lib.ams_gemm_f32_batched(int(transA), int(transB), M, N, K, _p(A), lda, a_zs, _p(B), ldb, b_zs, _p(C), ldc, c_zs, nbatch,
-                                   int(accumulate), 0, 0, _p(ws), nb, _s()), 'ams_gemm_f32_batched')
+    pa, pb, gt = _bounds(amax)
+    check(lib.ams_gemm_f32_batched_bounded(int(transA), int(transB), M, N, K, _p(A), lda, a_zs, _p(B), ldb, b_zs, _p(C), ldc, c_zs, nbatch,
+                                           int(accumulate), 0, 0, pa, pb, _p(ws), nb, _s()), 'ams_gemm_f32_batched')
     if ev is not None:
         PROFILE.end(ev, nbatch * 2.0 * M * N * K, nbatch * 4.0 * (M * K + K * N + M * N), gt + '<%d,%d>' % (int(bool(transA)), int(bool(transB))))
 

@@ -26,6 +26,8 @@ thread_local int t_gemm_lds_pad = 0;
 // one-shot: operand bounds for the NEXT product launched from this thread (ams_gemm_set_amax); consumed and cleared by launch()
 thread_local const float* t_amax_a = nullptr;
 thread_local const float* t_amax_b = nullptr;
+// every product entry point holds one of these: the one-shot bounds never outlive the call they were set for, whichever way it returns
+struct AmaxOneShot { ~AmaxOneShot() { t_amax_a = nullptr; t_amax_b = nullptr; } };
 std::atomic<int> g_gemm_arith{-1};        // -1: not chosen yet (AMS_GEMM_X6, default 1), 0: native f32 MFMA, 1: bf16x6
 
 // Tuning overrides (A/B runs only): read from the environment ONCE per process, never on the launch path.
@@ -1271,6 +1273,27 @@ extern "C" {
 
 void ams_gemm_set_lds_pad(int bytes) { t_gemm_lds_pad = bytes < 0 ? 0 : bytes; }
 void ams_gemm_set_amax(const float* amax_a, const float* amax_b) { t_amax_a = amax_a; t_amax_b = amax_b; }
+
+// the same products with the operand bounds as ARGUMENTS (no state survives the call)
+ams_status ams_gemm_f32_bounded(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                                float* C, long ldc, const float* bias, int accumulate, int mask_period, int mask_skip,
+                                const float* amax_a, const float* amax_b, void* ws, size_t ws_bytes, void* stream) {
+    t_amax_a = amax_a; t_amax_b = amax_b;
+    return ams_gemm_f32(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, mask_period, mask_skip, ws, ws_bytes, stream);
+}
+ams_status ams_gemm_f32_batched_bounded(int transA, int transB, int M, int N, int K, const float* A, long lda, long a_zs, const float* B,
+                                        long ldb, long b_zs, float* C, long ldc, long c_zs, int nbatch, int accumulate, int mask_period,
+                                        int mask_skip, const float* amax_a, const float* amax_b, void* ws, size_t ws_bytes, void* stream) {
+    t_amax_a = amax_a; t_amax_b = amax_b;
+    return ams_gemm_f32_batched(transA, transB, M, N, K, A, lda, a_zs, B, ldb, b_zs, C, ldc, c_zs, nbatch, accumulate, mask_period, mask_skip,
+                                ws, ws_bytes, stream);
+}
+ams_status ams_gemm_f32_at_b_colsum_bounded(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                                            int accumulate, float* bsum_out, int bsum_accumulate, float* bsum_ws, const float* amax_a,
+                                            const float* amax_b, void* ws, size_t ws_bytes, void* stream) {
+    t_amax_a = amax_a; t_amax_b = amax_b;
+    return ams_gemm_f32_at_b_colsum(M, N, K, A, lda, B, ldb, C, ldc, accumulate, bsum_out, bsum_accumulate, bsum_ws, ws, ws_bytes, stream);
+}
 void ams_gemm_set_arith(int mode) { g_gemm_arith.store(mode ? 1 : 0, std::memory_order_relaxed); }
 int ams_gemm_get_arith(void) { return use_x6() ? 1 : 0; }
 
@@ -1287,6 +1310,7 @@ size_t ams_gemm_workspace_bytes(int M, int N, int K) {
 ams_status ams_gemm_f32_at_b_colsum(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                                     int accumulate, float* bsum_out, int bsum_accumulate, float* bsum_ws, void* ws, size_t ws_bytes,
                                     void* stream) {
+    AmaxOneShot amax_scope;
     AMS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C && bsum_out && bsum_ws);
     GemmArgs g{};
     g.A = A; g.B = B; g.C = C;
@@ -1301,6 +1325,7 @@ ams_status ams_gemm_f32_at_b_colsum(int M, int N, int K, const float* A, long ld
 ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                         float* C, long ldc, const float* bias, int accumulate, int mask_period, int mask_skip, void* ws,
                         size_t ws_bytes, void* stream) {
+    AmaxOneShot amax_scope;
     AMS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C);
     GemmArgs g{};
     g.A = A; g.B = B; g.C = C; g.bias = bias;
@@ -1328,6 +1353,7 @@ size_t ams_gemm_batched_workspace_bytes(int M, int N, int K, int nbatch) {
 ams_status ams_gemm_f32_batched(int transA, int transB, int M, int N, int K, const float* A, long lda, long a_zs, const float* B,
                                 long ldb, long b_zs, float* C, long ldc, long c_zs, int nbatch, int accumulate, int mask_period,
                                 int mask_skip, void* ws, size_t ws_bytes, void* stream) {
+    AmaxOneShot amax_scope;
     AMS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C && nbatch >= 1 && nbatch <= 64);
     GemmArgs g{};
     g.A = A; g.B = B; g.C = C; g.bias = nullptr;
@@ -1354,6 +1380,7 @@ ams_status ams_gemm_f32_batched(int transA, int transB, int M, int N, int K, con
 ams_status ams_gemm_f32_rowseg(int M, int N, int K, const float* A, long lda, const float* B, long ldb, long b_zs, float* C,
                                long ldc, long c_zs, const float* bias, long bias_zs, int seg_len, long seg_stride, long seg_off,
                                long seg_off_zs, int nbatch, void* ws, size_t ws_bytes, void* stream) {
+    AmaxOneShot amax_scope;
     AMS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C && nbatch >= 1 && nbatch <= 64 && seg_len >= 0);
     GemmArgs g{};
     g.A = A; g.B = B; g.C = C; g.bias = bias;
@@ -1374,6 +1401,7 @@ size_t ams_front_conv_fwd_workspace_bytes(int Bt, int L, int W, int N, int hop) 
 // ws (may be NULL: no split-K) lets the few-tile benchmark shape (5120 x 256 output = 80 tiles) fill 256 CUs.
 ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, void* ws,
                               size_t ws_bytes, void* stream) {
+    AmaxOneShot amax_scope;
     AMS_REQUIRE(x && f && y && Bt > 0 && L > 0 && W > 0 && N > 0 && hop > 0);
     const int T = (L + hop - 1) / hop;
     int pad_total = (T - 1) * hop + W - L;
@@ -1390,6 +1418,7 @@ ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, 
 // Generic framed product: out[(r,t), n] = sum_k xpad[r, t*hop + k - pad_left] * Bm[k, n]   (STFT as a DFT product)
 ams_status ams_frames_matmul(const float* x, const float* Bm, float* out, int R, int L, int W, int N, int hop, int T, int pad_left,
                              void* stream) {
+    AmaxOneShot amax_scope;
     AMS_REQUIRE(x && Bm && out && R > 0 && L > 0 && W > 0 && N > 0 && hop > 0 && T > 0 && pad_left >= 0);
     GemmArgs g{};
     g.A = x; g.B = Bm; g.C = out; g.bias = nullptr;
@@ -1405,6 +1434,7 @@ size_t ams_frames_matmul_bwd_filter_workspace_bytes(int R, int W, int N, int T) 
 
 ams_status ams_frames_matmul_bwd_filter(const float* x, const float* dy, float* dB, int R, int L, int W, int N, int hop, int T,
                                         int pad_left, void* ws, size_t ws_bytes, void* stream) {
+    AmaxOneShot amax_scope;
     AMS_REQUIRE(x && dy && dB && R > 0 && L > 0 && W > 0 && N > 0 && hop > 0 && T > 0 && pad_left >= 0);
     GemmArgs g{};
     g.A = x; g.B = dy; g.C = dB; g.bias = nullptr;
@@ -1423,6 +1453,7 @@ size_t ams_front_conv_bwd_filter_workspace_bytes(int Bt, int L, int W, int N, in
 // df[k,n] = sum_{b,t} xpad[b,t*hop+k-pl] * dy[b,t,n]   
 ams_status ams_front_conv_bwd_filter(const float* x, const float* dy, float* df, int Bt, int L, int W, int N, int hop,
                                      void* ws, size_t ws_bytes, void* stream) {
+    AmaxOneShot amax_scope;
     AMS_REQUIRE(x && dy && df && Bt > 0 && L > 0 && W > 0 && N > 0 && hop > 0);
     const int T = (L + hop - 1) / hop;
     int pad_total = (T - 1) * hop + W - L;

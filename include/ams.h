@@ -88,6 +88,18 @@ void ams_gemm_set_lds_pad(int bytes);
    launch that does not take the 16-byte-fetch path, AMS_GEMM_X6=0 or AMS_GEMM_F16X3=0 leave the arithmetic as it was.
    Replaces nothing in the reference (tf.matmul / conv2d in f32): it is how those f32 products are issued. */
 void ams_gemm_set_amax(const float* amax_a, const float* amax_b);
+/* The three product entry points with the bounds as ARGUMENTS: same contract as ams_gemm_f32 / _batched / _at_b_colsum below, fp16x3
+   arithmetic when both bounds are non-NULL and the launch takes the 16-byte-fetch path, bf16x6 otherwise; no state survives the
+   call (and none set earlier through ams_gemm_set_amax is used). */
+ams_status ams_gemm_f32_bounded(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
+                                float* C, long ldc, const float* bias, int accumulate, int mask_period, int mask_skip,
+                                const float* amax_a, const float* amax_b, void* ws, size_t ws_bytes, void* stream);
+ams_status ams_gemm_f32_batched_bounded(int transA, int transB, int M, int N, int K, const float* A, long lda, long a_zs, const float* B,
+                                        long ldb, long b_zs, float* C, long ldc, long c_zs, int nbatch, int accumulate, int mask_period,
+                                        int mask_skip, const float* amax_a, const float* amax_b, void* ws, size_t ws_bytes, void* stream);
+ams_status ams_gemm_f32_at_b_colsum_bounded(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
+                                            int accumulate, float* bsum_out, int bsum_accumulate, float* bsum_ws, const float* amax_a,
+                                            const float* amax_b, void* ws, size_t ws_bytes, void* stream);
 /* out[0] = max |x[i]|, i < n, as a float (NaN if any x is NaN): the bound ams_gemm_set_amax wants, for operands whose producer does
    not supply one.  Two stream-ordered launches (a 4-byte clear, the reduction); out is a device pointer. */
 ams_status ams_absmax_f32(const float* x, long n, float* out, void* stream);
