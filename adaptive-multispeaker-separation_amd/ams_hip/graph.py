@@ -100,6 +100,7 @@ class Run(object):
         self.training = training
         from . import ops
         ops.PASS[0] += 1                # weight bounds of the fp16x3 products are measured once per pass (ops.param_amax)
+        self.begun = False
 
 
 class Node(object):
@@ -113,6 +114,11 @@ class Node(object):
     def value(self, run):
         k = id(self)
         if k not in run.cache:
+            if not run.begun:
+                run.begun = True
+                if torch.cuda.is_available():
+                    from . import ops, functional
+                    ops.pass_begin(functional.OVERLAP.side())
             run.cache[k] = self.fn(run)
         return run.cache[k]
 

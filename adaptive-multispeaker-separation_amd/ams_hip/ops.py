@@ -211,31 +211,74 @@ def amax_of(t):
 PASS = [0]                                                       # bumped by graph.Run: one evaluation pass = one measurement
 
 
+class _ParamSource(object):
+    """One optimizer's flat parameter buffer and the bound measured over it (shared by every variable the optimizer owns)."""
+    __slots__ = ('flat', 'bound', 'seen', 'event', '__weakref__')
+
+    def __init__(self, flat):
+        self.flat = flat
+        self.bound = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        self.seen = -1                  # the pass (PASS[0]) it was last measured in
+        self.event = None               # measured on the side stream: recorded there, awaited by the first consumer
+
+
+_SOURCES = []                                                    # weak references: a source lives as long as its variables do
+
+
 def param_amax(W):
-    """Bound of a weight tensor, measured at its first use in every evaluation pass (graph.Run) -- inside a captured step the
-    measurement is part of the graph and is repeated by every replay, so no writer of weights (optimizer kernels, restore,
-    `.data.copy_`) has to remember anything.  Variables owned by an optimizer share ONE bound over its whole flat buffer (a bound up
-    to 2^10 above a tensor's own maximum costs that tensor no precision); anything else is measured by itself."""
+    """Bound of a weight tensor, measured once in every evaluation pass (graph.Run) -- inside a captured step the measurement is
+    part of the graph and is repeated by every replay, so no writer of weights (optimizer kernels, restore, `.data.copy_`) has to
+    remember anything.  Variables owned by an optimizer share ONE bound over its whole flat buffer (a bound up to 2^10 above a
+    tensor's own maximum costs that tensor no precision), measured by pass_begin() on the side stream while the front end runs;
+    anything else is measured by itself at its first use."""
     if not F16X3:
         return None
     src = getattr(W, '_ams_amax_src', None)
     if src is not None:
-        flat, bound, seen = src
-        if seen[0] != PASS[0]:
-            absmax(flat, out=bound)
-            seen[0] = PASS[0]
-        return bound
+        if src.seen != PASS[0]:                                  # pass_begin() did not run (no graph.Node evaluation): measure here
+            absmax(src.flat, out=src.bound)
+            src.seen, src.event = PASS[0], None
+        elif src.event is not None:                              # measured on the side stream: the first consumer waits for it
+            torch.cuda.current_stream().wait_event(src.event)
+            src.event = None
+        return src.bound
     c = getattr(W, '_ams_amax_cache', None)
     if c is None or c[0] != PASS[0]:
         W._ams_amax_cache = c = (PASS[0], absmax(W.detach(), out=c[1] if c is not None else None))
     return c[1]
 
 
+def pass_begin(side_stream):
+    """First node evaluation of a pass (graph.Node.value): the live optimizers' flat buffers are measured on the side stream, beside
+    whatever the pass starts with (input staging, the front conv) instead of in front of the first product that needs the bound
+    (47 MB: ~25 us).  Inside a captured step this is part of the graph."""
+    if not F16X3:
+        return
+    cur = torch.cuda.current_stream()
+    live = []
+    for ref in _SOURCES:
+        src = ref()
+        if src is None:
+            continue
+        live.append(ref)
+        if not src.flat.is_cuda or src.seen == PASS[0] or src.flat.device != cur.device:
+            continue
+        side_stream.wait_stream(cur)
+        with torch.cuda.stream(side_stream):
+            absmax(src.flat, out=src.bound)
+            ev = torch.cuda.Event()
+            ev.record(side_stream)
+        src.seen, src.event = PASS[0], ev
+    _SOURCES[:] = live
+
+
 def register_param_source(variables, flat):
     """FlatOptimizer: every variable it owns takes its bound from one measurement of the flat buffer."""
-    src = (flat, torch.zeros(1, dtype=torch.float32, device=flat.device), [-1])
+    import weakref
+    src = _ParamSource(flat)
     for v in variables:
         v._ams_amax_src = src
+    _SOURCES.append(weakref.ref(src))
 
 
 def _bounds(amax):
