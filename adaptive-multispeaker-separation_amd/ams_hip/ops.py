@@ -213,13 +213,14 @@ PASS = [0]                                                       # bumped by gra
 
 class _ParamSource(object):
     """One optimizer's flat parameter buffer and the bound measured over it (shared by every variable the optimizer owns)."""
-    __slots__ = ('flat', 'bound', 'seen', 'event', '__weakref__')
+    __slots__ = ('flat', 'bound', 'seen', 'event', 'used', '__weakref__')
 
     def __init__(self, flat):
         self.flat = flat
         self.bound = torch.zeros(1, dtype=torch.float32, device=flat.device)
         self.seen = -1                  # the pass (PASS[0]) it was last measured in
         self.event = None               # measured on the side stream: recorded there, awaited by the first consumer
+        self.used = -1                  # the last pass a product asked for this bound
 
 
 _SOURCES = []                                                    # weak references: a source lives as long as its variables do
@@ -235,7 +236,8 @@ def param_amax(W):
         return None
     src = getattr(W, '_ams_amax_src', None)
     if src is not None:
-        if src.seen != PASS[0]:                                  # pass_begin() did not run (no graph.Node evaluation): measure here
+        src.used = PASS[0]
+        if src.seen != PASS[0]:                                  # not measured by pass_begin() (first use of this model): measure here
             absmax(src.flat, out=src.bound)
             src.seen, src.event = PASS[0], None
         elif src.event is not None:                              # measured on the side stream: the first consumer waits for it
@@ -261,8 +263,8 @@ def pass_begin(side_stream):
         if src is None:
             continue
         live.append(ref)
-        if not src.flat.is_cuda or src.seen == PASS[0] or src.flat.device != cur.device:
-            continue
+        if not src.flat.is_cuda or src.seen == PASS[0] or src.flat.device != cur.device or src.used < PASS[0] - 2:
+            continue                                            # (only models whose bound a recent pass asked for)
         side_stream.wait_stream(cur)
         with torch.cuda.stream(side_stream):
             absmax(src.flat, out=src.bound)

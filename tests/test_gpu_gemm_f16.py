@@ -117,6 +117,7 @@ def test_the_training_step_takes_fp16x3_wherever_bounds_are_at_hand(ops):
     import tempfile
     from tests.smoke_step import build_front_dpcl
     tmp = tempfile.mkdtemp(prefix='ams_f16_step_')
+    ops.PASS[0] += 10                                             # models other tests left alive are no longer 'recently used' (ops.pass_begin)
     trainer, tfds = build_front_dpcl(tmp, B=16, L=4096, W=64, N=64, hop=64, layer_size=600, nb_layers=2, E=40, no_summaries=True)
     g, model = trainer.graph, trainer.model
     calls = []
