@@ -240,9 +240,8 @@ def param_amax(W):
         if src.seen != PASS[0]:                                  # not measured by pass_begin() (first use of this model): measure here
             absmax(src.flat, out=src.bound)
             src.seen, src.event = PASS[0], None
-        elif src.event is not None:                              # measured on the side stream: the first consumer waits for it
-            torch.cuda.current_stream().wait_event(src.event)
-            src.event = None
+        elif src.event is not None:                              # measured on the side stream: every consuming stream waits once
+            _await_pass_side()
         return src.bound
     c = getattr(W, '_ams_amax_cache', None)
     if c is None or c[0] != PASS[0]:
@@ -250,28 +249,160 @@ def param_amax(W):
     return c[1]
 
 
-def pass_begin(side_stream):
-    """First node evaluation of a pass (graph.Node.value): the live optimizers' flat buffers are measured on the side stream, beside
-    whatever the pass starts with (input staging, the front conv) instead of in front of the first product that needs the bound
-    (47 MB: ~25 us).  Inside a captured step this is part of the graph."""
-    if not F16X3:
+class _PassSide(object):
+    """What pass_begin() put on the side stream for the current pass, and which streams have already waited for it."""
+    __slots__ = ('event', 'n', 'waited')
+
+    def __init__(self):
+        self.event, self.n, self.waited = None, -1, set()
+
+
+_PASS_SIDE = _PassSide()
+
+
+def _await_pass_side():
+    """The current stream waits (once per pass and stream) for the side-stream work of pass_begin(): weight bounds, cleared ring
+    sync buffers.  One cross-stream edge per pass, taken by whichever consumer comes first."""
+    ps = _PASS_SIDE
+    if ps.event is None or ps.n != PASS[0]:
         return
     cur = torch.cuda.current_stream()
+    if cur.cuda_stream in ps.waited:
+        return
+    cur.wait_event(ps.event)
+    ps.waited.add(cur.cuda_stream)
+
+
+RING_ARENA = _os.environ.get('AMS_RING_ARENA', '1') != '0'
+
+
+class _RingArena(object):
+    """Sync buffers of the ring-recurrence launches of one pass, cleared TOGETHER: every ring launch needs its sync head zeroed, and a
+    memset node in front of each of the six launches of a training step sat on the step's critical path (~5 us each).  Launch i of
+    a pass takes slot i of one flat buffer that pass_begin() zeroes with ONE memset on the side stream, beside the input staging;
+    the launch itself is told so (`safe` bit 2, include/ams.h) and is not preceded by anything.  A launch that finds no slot (first
+    pass of a model, a larger shape, ops called outside a graph.Run) takes a private buffer and the per-launch memset as before, and
+    leaves its size for the next pass.  A replaced flat buffer is kept alive: a captured hipGraph may hold its address."""
+
+    def __init__(self):
+        self.want = []              # bytes asked of slot i so far (maximum over passes)
+        self.slots = []             # float32 views into self.flat
+        self.flat = None
+        self.retired = []
+        self.next = 0               # slot the next ring launch of this pass takes
+        self.cleared = -1           # the pass whose pass_begin() zeroed the slots
+        self.used = -1              # the last pass a ring launch asked for a slot
+
+    def begin(self, side_stream, device):
+        """Called by pass_begin() inside `with torch.cuda.stream(side_stream)`.  True when it enqueued the memset."""
+        self.next = 0
+        if not self.want or self.used < PASS[0] - 2:
+            return False
+        have = [v.numel() * 4 for v in self.slots]
+        if len(have) < len(self.want) or any(h < w for h, w in zip(have, self.want)):
+            sizes = [(w + 255) // 256 * 256 for w in self.want]
+            if self.flat is not None:
+                self.retired.append(self.flat)
+            self.flat = torch.empty(sum(sizes) // 4, dtype=torch.float32, device=device)
+            self.slots, off = [], 0
+            for n in sizes:
+                self.slots.append(self.flat[off // 4:(off + n) // 4])
+                off += n
+        self.flat.zero_()
+        self.cleared = PASS[0]
+        return True
+
+    def take(self, nbytes, like):
+        """(sync buffer, `safe` bit) for the next ring launch."""
+        i = self.next
+        self.next += 1
+        self.used = PASS[0]
+        while len(self.want) <= i:
+            self.want.append(0)
+        self.want[i] = max(self.want[i], int(nbytes))
+        if (self.cleared == PASS[0] and i < len(self.slots) and self.slots[i].numel() * 4 >= nbytes
+                and self.slots[i].device == like.device):
+            _await_pass_side()
+            return self.slots[i], 4
+        return _ws(nbytes, like), 0
+
+
+_ARENAS = {}
+
+
+def _ring_sync(nbytes, like):
+    if not RING_ARENA or not like.is_cuda:
+        return _ws(nbytes, like), 0
+    k = like.device.index if like.device.index is not None else torch.cuda.current_device()
+    ar = _ARENAS.get(k)
+    if ar is None:
+        ar = _ARENAS[k] = _RingArena()
+    return ar.take(nbytes, like)
+
+
+_DEFER_ZERO = []
+
+
+def zero_deferred(t):
+    """Zero `t` (an optimizer's flat gradient buffer) in the side-stream block of the NEXT pass_begin() instead of now: zeroing 47 MB
+    in front of the forward pass cost the B = 64 step ~14 us of its critical path, and nothing writes a gradient before the backward
+    pass.  The caller must call flush_deferred_zero() + await_pass_side() before its backward pass (models/network.py::_backward)."""
+    if not t.is_cuda:
+        t.zero_()
+        return
+    _DEFER_ZERO.append(t)
+
+
+def flush_deferred_zero():
+    """Zero, on the current stream, whatever no pass_begin() took since zero_deferred()."""
+    while _DEFER_ZERO:
+        _DEFER_ZERO.pop().zero_()
+
+
+def await_pass_side():
+    _await_pass_side()
+
+
+def pass_begin(side_stream):
+    """First node evaluation of a pass (graph.Node.value): work that depends on nothing the pass computes goes on the side stream,
+    beside whatever the pass starts with (input staging, the front conv) -- the live optimizers' flat buffers are measured there
+    instead of in front of the first product that needs the bound (47 MB: ~25 us), and the sync buffers of the pass's ring launches
+    are zeroed there in one memset (_RingArena).  ONE event covers both; its first consumer waits for it (_await_pass_side).
+    Inside a captured step this is part of the graph."""
+    cur = torch.cuda.current_stream()
+    dev = cur.device.index if cur.device.index is not None else torch.cuda.current_device()
+    todo = []
     live = []
-    for ref in _SOURCES:
+    for ref in _SOURCES if F16X3 else []:
         src = ref()
         if src is None:
             continue
         live.append(ref)
         if not src.flat.is_cuda or src.seen == PASS[0] or src.flat.device != cur.device or src.used < PASS[0] - 2:
             continue                                            # (only models whose bound a recent pass asked for)
-        side_stream.wait_stream(cur)
-        with torch.cuda.stream(side_stream):
+        todo.append(src)
+    if F16X3:
+        _SOURCES[:] = live
+    ar = _ARENAS.get(dev) if RING_ARENA else None
+    if ar is not None:
+        ar.next = 0
+    zeros = [t for t in _DEFER_ZERO if t.device == cur.device]
+    if not todo and not zeros and (ar is None or not ar.want or ar.used < PASS[0] - 2):
+        return
+    side_stream.wait_stream(cur)
+    with torch.cuda.stream(side_stream):
+        for t in zeros:
+            t.zero_()
+        _DEFER_ZERO[:] = [t for t in _DEFER_ZERO if t.device != cur.device]
+        for src in todo:
             absmax(src.flat, out=src.bound)
-            ev = torch.cuda.Event()
-            ev.record(side_stream)
+        if ar is not None:
+            ar.begin(side_stream, cur.device)
+        ev = torch.cuda.Event()
+        ev.record(side_stream)
+    for src in todo:
         src.seen, src.event = PASS[0], ev
-    _SOURCES[:] = live
+    _PASS_SIDE.event, _PASS_SIDE.n, _PASS_SIDE.waited = ev, PASS[0], set()
 
 
 def register_param_source(variables, flat):
@@ -578,11 +709,11 @@ def blstm_fwd(x, Kf, bf, Kb, bb, consumer=None, amax=None):
     pack = torch.empty(lib.ams_blstm_pack_floats(H, 0), dtype=torch.float32, device=x.device)
     if (nring and LSTM_RING_PROJ and pre is None and lib.ams_blstm_ring_proj_ok(B, H, D) and x.is_contiguous() and x.data_ptr() % 16 == 0
             and bf.is_contiguous() and bb.is_contiguous()):
-        sync = _ws(nring, x)
+        sync, pre0 = _ring_sync(nring, x)
         ev = PROFILE.begin() if PROFILE.enabled else None
         check(lib.ams_blstm_ring_fwd_proj(_p(x), D, _p(Kf), _p(Kb), ldu, _p(bf), _p(bb), _p(G), _p(out), _p(cst[0]), _p(cst[1]),
                                           _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring, _p(ring_error_word(x.device)), B, T, H,
-                                          int(LSTM_RING == 'safe'), _s()),
+                                          int(LSTM_RING == 'safe') | pre0, _s()),
               'ams_blstm_ring_fwd_proj')
         if ev is not None:      # the projection's flops, attributed to the ring launch that now contains them
             PROFILE.end(ev, 2 * 2.0 * B * T * 4 * H * (D + H), 4.0 * (B * T * (D + 8 * H + 2 * H)), 'ring_fwd_proj', 'blstm_input_gemm_in_ring')
@@ -601,11 +732,11 @@ def blstm_fwd(x, Kf, bf, Kb, bb, consumer=None, amax=None):
         _fwd_steps_feeding(lib, G, out, cst, pack, B, T, H, consumer, cuts)
         return out, G, cst
     if nring:
-        sync = _ws(nring, x)
+        sync, pre0 = _ring_sync(nring, x)
         if u_amax is not None and F16X3:
             lib.ams_blstm_ring_set_amax(_p(u_amax))              # one-shot: the recurrent product of this launch runs as fp16x3
         check(lib.ams_blstm_ring_fwd(_p(G), _p(out), _p(cst[0]), _p(cst[1]), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring,
-                                     _p(ring_error_word(x.device)), B, T, H, int(LSTM_RING == 'safe'), _s()), 'ams_blstm_ring_fwd')
+                                     _p(ring_error_word(x.device)), B, T, H, int(LSTM_RING == 'safe') | pre0, _s()), 'ams_blstm_ring_fwd')
         return out, G, cst
     nsync = lib.ams_blstm_persist_sync_bytes(B, H, 0) if LSTM_PERSIST else 0
     if nsync:
@@ -803,10 +934,10 @@ def blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout):
     # cst with a leading plane axis = written by the forward ring (plane 1 = tanh(c_t)); a 4-D cst came from the step kernels
     nring = lib.ams_blstm_ring_sync_bytes(B, H, 1) if (LSTM_RING != '0' and not LSTM_PERSIST and cst.dim() == 5) else 0
     if nring:
-        sync = _ws(nring, x)
+        sync, pre0 = _ring_sync(nring, x)
         dbpart = torch.empty((B, 2, 4 * H), dtype=torch.float32, device=x.device)
         check(lib.ams_blstm_ring_bwd(_p(G), _p(cst[0]), _p(cst[1]), _p(dout), _p(dbpart), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring,
-                                     _p(ring_error_word(x.device)), B, T, H, int(LSTM_RING == 'safe'), _s()), 'ams_blstm_ring_bwd')
+                                     _p(ring_error_word(x.device)), B, T, H, int(LSTM_RING == 'safe') | pre0, _s()), 'ams_blstm_ring_bwd')
         tag_amax(G, sync.view(-1)[2:3])                          # max |dZ| came out of the same launch (float word 2 of the sync head)
         return dbpart
     pack = torch.empty(lib.ams_blstm_pack_floats(H, 1), dtype=torch.float32, device=x.device)

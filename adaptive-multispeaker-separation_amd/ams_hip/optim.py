@@ -81,8 +81,13 @@ class FlatOptimizer(object):
     def increment_epoch(self):
         self.global_epoch += 1
 
-    def zero_grad(self):
-        self.flat_grad.zero_()
+    def zero_grad(self, defer=False):
+        """defer: zeroed on the side stream when the next evaluation pass begins (ops.zero_deferred) -- for callers whose backward
+        pass starts with ops.flush_deferred_zero() + ops.await_pass_side() (Network._backward)."""
+        if defer:
+            ops.zero_deferred(self.flat_grad)
+        else:
+            self.flat_grad.zero_()
 
     def exchange(self):
         """Data-parallel gradient exchange: ONE all-reduce (sum) of the flat gradient buffer; returns the scale that

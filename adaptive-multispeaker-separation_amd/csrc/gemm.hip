@@ -31,10 +31,12 @@ struct AmaxOneShot { ~AmaxOneShot() { t_amax_a = nullptr; t_amax_b = nullptr; } 
 std::atomic<int> g_gemm_arith{-1};        // -1: not chosen yet (AMS_GEMM_X6, default 1), 0: native f32 MFMA, 1: bf16x6
 
 // Tuning overrides (A/B runs only): read from the environment ONCE per process, never on the launch path.
-struct GemmTuning { int group_m, splits, x6cfg, x6rule, x6persist; bool noprio, novec, f16x3; };
+struct GemmTuning { int group_m, splits, x6cfg, x6rule, x6persist; bool noprio, novec, f16x3; double x6waste; };
 inline const GemmTuning& tuning() {
     static const GemmTuning t = [] {
         GemmTuning v{0, 0, -1, 2, false, false};
+        v.x6waste = 1.30;
+        if (const char* f = getenv("AMS_GEMM_X6WASTE")) v.x6waste = atof(f);
         if (const char* f = getenv("AMS_GEMM_GROUP_M")) v.group_m = atoi(f);
         if (const char* f = getenv("AMS_GEMM_SPLITS")) v.splits = atoi(f);
         v.noprio = getenv("AMS_GEMM_NOPRIO") != nullptr;
@@ -1082,7 +1084,9 @@ __global__ void bsum_finish_kernel(const float* __restrict__ part, float* __rest
 struct TilePlan { int bm, bn, bk; double us16; bool alone; };   // block tile, the cost of 16 k of it for one workgroup (microseconds), one workgroup per CU by construction
 inline TilePlan f32_plan() { return {BM, BN, BK, 1.024, false}; }
 // bf16x6 tile configuration (X6Cfg) of an M x N output.  Default (rule 2): 128 x 256 (8 waves of 64 x 64) where it wastes under
-// 10 % of the columns it covers, 128 x 128 otherwise -- both carry the second accumulator set (SEP) when they are not
+// 30 % of the columns it covers (AMS_GEMM_X6WASTE = 1.30; 1.10 until the fp16x3 products: with half the MFMAs per k-tile the
+// 8-wave tile wins even at N = 600 -> 768 -- LSTM dX 98 -> 87 us, dense dX 289 -> 277 us alone, the B = 64 step 3.14 -> 3.09 ms,
+// tools/cfg_sweep.sh + tools/ab_bench.sh), 128 x 128 otherwise -- both carry the second accumulator set (SEP) when they are not
 // residency-capped.  Rule 1 (AMS_GEMM_X6RULE=1) adds the 256 x 256 tile (8 waves of 128 x 64) where both sides fit: +0.7 % on the
 // step (projections 107 vs 121 us), but no registers for SEP -- its outputs carry the bf16 MFMA's truncation bias (-0.3 .. -1 ulp
 // each, coherent: the LSTM bias gradients, sums over 5120 rows downstream of it, were 1.2e-5 off the oracle instead of < 1e-6), so
@@ -1091,7 +1095,7 @@ inline TilePlan f32_plan() { return {BM, BN, BK, 1.024, false}; }
 // 128 x 128 on every shape it suits.)
 inline int x6_choose_cfg(int M, int N, bool capped) {
     if (tuning().x6cfg == 0 || tuning().x6cfg == 1 || tuning().x6cfg == 3) return tuning().x6cfg;
-    const bool m256 = (double)ceil_div(M, 256) * 256 <= 1.10 * M, n256 = (double)ceil_div(N, 256) * 256 <= 1.10 * N;
+    const bool m256 = (double)ceil_div(M, 256) * 256 <= 1.10 * M, n256 = (double)ceil_div(N, 256) * 256 <= tuning().x6waste * N;
     const int rule = tuning().x6rule;
     if (m256 && n256 && !capped && rule <= 1) return 1;
     if (n256 && rule >= 1) return 3;

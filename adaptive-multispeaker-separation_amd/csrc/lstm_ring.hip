@@ -1045,9 +1045,19 @@ size_t ams_blstm_ring_sync_bytes(int B, int H, int backward) {
     return ring_layout(NW, n_chains, backward).total;
 }
 
+// bytes at the start of the sync buffer that must be zero when a ring launch starts (forward: the whole buffer, granule tags included)
+size_t ams_blstm_ring_sync_head_bytes(int B, int H, int backward) {
+    int NW, n_chains;
+    if (B <= 0 || H <= 0 || !ring_shape(B, H, NW, n_chains)) return 0;
+    return ring_layout(NW, n_chains, backward).head;
+}
+
 // Same contract as ams_blstm_recurrent_fwd (G: pre-activations in, activated gates out; out; cst), plus `sync`
 // (ams_blstm_ring_sync_bytes(B, H, 0) bytes, word 0 = timeout flag) and `tch` [B,T,2,H] = tanh(c_t), which the backward ring reads
 // instead of calling tanhf again.  safe bit 0 forces the placement-independent hand-off, bit 1 turns the phase trace on.
+// Bit 2: the caller has ALREADY zeroed the sync buffer (all of it for the forward ring, its first ams_blstm_ring_sync_head_bytes()
+// for the backward ring) in stream order before this launch -- no memset node in front of the ring (ops.py clears the buffers of a
+// whole pass with one memset on the side stream while the pass starts).
 void ams_blstm_ring_set_amax(const float* amax_u) { t_ring_amax_u = amax_u; }
 
 ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, const float* Uf, const float* Ub, long ldu, void* sync,
@@ -1058,7 +1068,7 @@ ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, cons
     const RingLayout L = ring_layout(NW, n_chains, 0);
     if (sync_bytes < L.total) return AMS_E_WORKSPACE_TOO_SMALL;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sync, 0, L.head, st) != hipSuccess) return AMS_E_LAUNCH_FAILED;
+    if (!(safe & 4) && hipMemsetAsync(sync, 0, L.head, st) != hipSuccess) return AMS_E_LAUNCH_FAILED;      // bit 2: the caller cleared [0, head)
     RingArgs a{};
     a.G = G; a.out = out; a.cst = cst; a.tch = tch; a.Uf = Uf; a.Ub = Ub; a.ldu = ldu;
     a.err = (unsigned*)sync; a.sticky = (unsigned*)sticky_err; a.ids = (unsigned*)((char*)sync + L.ids); a.flags = (unsigned*)((char*)sync + L.flags);
@@ -1117,7 +1127,7 @@ ams_status ams_blstm_ring_fwd_proj(const float* x, int D, const float* Wxf, cons
     const RingLayout L = ring_layout(NW, n_chains, 0);
     if (sync_bytes < L.total) return AMS_E_WORKSPACE_TOO_SMALL;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sync, 0, L.head, st) != hipSuccess) return AMS_E_LAUNCH_FAILED;
+    if (!(safe & 4) && hipMemsetAsync(sync, 0, L.head, st) != hipSuccess) return AMS_E_LAUNCH_FAILED;      // bit 2: the caller cleared [0, head)
     RingArgs a{};
     a.G = G; a.out = out; a.cst = cst; a.tch = tch; a.Uf = Uf; a.Ub = Ub; a.ldu = ldu;
     a.x = x; a.Wxf = Wxf; a.Wxb = Wxb; a.ldw = ldw; a.bf = bf; a.bb = bb; a.D = D;
@@ -1143,7 +1153,7 @@ ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* tch, cons
     const RingLayout L = ring_layout(NW, n_chains, 1);
     if (sync_bytes < L.total) return AMS_E_WORKSPACE_TOO_SMALL;
     hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(sync, 0, L.head, st) != hipSuccess) return AMS_E_LAUNCH_FAILED;
+    if (!(safe & 4) && hipMemsetAsync(sync, 0, L.head, st) != hipSuccess) return AMS_E_LAUNCH_FAILED;      // bit 2: the caller cleared [0, head)
     RingArgs a{};
     a.G = G; a.cst = const_cast<float*>(cst); a.tch = const_cast<float*>(tch); a.dout = dout; a.dbpart = dbpart; a.Uf = Uf; a.Ub = Ub; a.ldu = ldu;
     a.err = (unsigned*)sync; a.sticky = (unsigned*)sticky_err; a.ids = (unsigned*)((char*)sync + L.ids); a.flags = (unsigned*)((char*)sync + L.flags);

@@ -261,7 +261,7 @@ class Network(object):
                     run = self._feeds(feed_dict, True)
                     for node, t in zip((self.x_mix, self.x_non_mix, self.I), ins):
                         run.cache[id(node)] = t
-                    opt.zero_grad()
+                    opt.zero_grad(defer=True)
                     cost = self.cost_model.value(run)
                     self._backward(cost)
                     F.OVERLAP.join()
@@ -286,7 +286,7 @@ class Network(object):
             torch.cuda.synchronize()
             # thread_local: a collective library's watchdog thread (RCCL at N > 1) must not be able to invalidate this capture
             with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
-                opt.zero_grad()
+                opt.zero_grad(defer=True)
                 cost = self.cost_model.value(run)
                 self._backward(cost)
                 F.OVERLAP.join()
@@ -302,6 +302,9 @@ class Network(object):
 
     def _backward(self, cost):
         """d cost[0]: a 1-element cost is seeded with a cached ones tensor (no select / fill launches on the way back)."""
+        K.flush_deferred_zero()          # zero_grad(defer=True): zeroed by pass_begin() on the side stream, or here if no pass began
+        if cost.is_cuda:
+            K.await_pass_side()          # gradients written on this stream come after that memset
         c = cost.reshape(-1)
         if c.numel() != 1:
             c[0].backward()
@@ -318,7 +321,7 @@ class Network(object):
                 return c
         run = self._feeds(feed_dict, True)
         opt = self.optimize
-        opt.zero_grad()
+        opt.zero_grad(defer=True)
         cost = self.cost_model.value(run)
         self._backward(cost)
         F.OVERLAP.join()

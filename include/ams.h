@@ -181,10 +181,15 @@ ams_status ams_blstm_persist_bwd(float* G, const float* cst, const float* dout, 
  * the same word as `skip_if_set` and leave parameters and slots untouched when it is non-zero, so a step whose recurrence gave up
  * can be repeated on the per-step kernels instead of being trained on.
  * tch [B,T,2,H]: tanh(c_t), written by the forward ring and read by the backward one (cst keeps c_t).  safe: bit 0 forces the
- * write-through hand-off, bit 1 records a per-phase cycle trace in the sync header (tools/ring_anatomy.py).
+ * write-through hand-off, bit 1 records a per-phase cycle trace in the sync header (tools/ring_anatomy.py), bit 2 says the CALLER has
+ * already zeroed the first ams_blstm_ring_sync_head_bytes() of `sync` in stream order (forward ring: the whole buffer, the granule
+ * tags start at 0; backward ring: the error word, ids and flags) -- without it every launch is preceded by its own memset node,
+ * ~5 us on the critical path of each of the six ring launches of a training step; the host side (ops.py::_RingArena) clears the
+ * buffers of a whole pass with ONE memset on the side stream while the pass starts.
  * dbpart (backward, may be NULL): [B,2,4H] receives sum_t d pre-activation[b,t,dir,:]; the bias gradients are its column sums.
  * Replaces the same dynamic_rnn while_loop (utils/ops.py:358-383). */
 size_t ams_blstm_ring_sync_bytes(int B, int H, int backward);
+size_t ams_blstm_ring_sync_head_bytes(int B, int H, int backward);
 /* ONE-SHOT, thread-local (like ams_gemm_set_amax): the next ams_blstm_ring_fwd launched from this thread runs its recurrent product
    h_{t-1} . U as fp16x3 instead of bf16x6 -- U scaled by a power of two from *amax_u (device pointer: an upper bound of max |U| over
    both recurrent kernels) and split exactly into two fp16 terms, h_{t-1} (|h| < 1) scaled by 2^13, three fp16 MFMA products, the two

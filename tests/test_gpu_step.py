@@ -41,6 +41,43 @@ def test_hip_graph_replay_matches_eager():
         assert np.array_equal(p_e[n], p_g[n]) or np.abs(p_e[n] - p_g[n]).max() <= 1e-7 * max(1.0, np.abs(p_e[n]).max()), n
 
 
+def test_ring_sync_arena_matches_private_buffers():
+    """The sync buffers of a pass's ring launches come from one arena that pass_begin() zeroes on the side stream (ops._RingArena,
+    `safe` bit 2 of ams_blstm_ring_fwd/bwd: no memset node in front of a ring), and the flat gradient buffer is zeroed there too
+    (zero_grad(defer=True)): 5 eager steps end bit-identical to the same steps with a private buffer + memset per launch."""
+    import tempfile
+    from ams_hip import ops
+    from tests.smoke_step import build_front_dpcl
+
+    def run(arena):
+        old, ops.RING_ARENA = ops.RING_ARENA, arena
+        try:
+            tmp = tempfile.mkdtemp(prefix='ams_ar_')
+            trainer, tfds = build_front_dpcl(tmp, B=4, L=1024, W=64, N=16, hop=16, layer_size=16, nb_layers=2, E=8, no_summaries=True)
+            g, model = trainer.graph, trainer.model
+            costs = []
+            with g.as_default():
+                feed = {tfds.handle: tfds.get_handle(tfds.TRAIN), tfds.chunk_size: 1024}
+                tfds.initialize(tfds.TRAIN)
+                for i in range(5):
+                    costs.append(float(model.train(feed, i)))
+            torch.cuda.synchronize()
+            ops.raise_on_ring_errors()
+            return costs, {v.ams_name: v.detach().cpu().numpy().copy() for v in model.trainable_variables}
+        finally:
+            ops.RING_ARENA = old
+
+    c_p, p_p = run(False)
+    ops._ARENAS.clear()
+    c_a, p_a = run(True)
+    if ops.LSTM_RING != '0':
+        ar = ops._ARENAS[torch.cuda.current_device()]
+        assert len(ar.slots) == 4 and ar.next == 4 and ar.cleared == ops.PASS[0], (len(ar.slots), ar.next, ar.cleared, ops.PASS[0])
+    assert c_p == c_a, (c_p, c_a)
+    for n in p_p:
+        assert np.array_equal(p_p[n], p_a[n]), n
+
+
 def test_hip_graph_finetuning_step_refreshes_kmeans_seeds():
     """--hip_graph on a recipe whose k-means seeds come from the host RNG (front_*_finetuning): the captured kernels read a
     persistent index buffer that a pre-replay hook re-fills, so replayed steps see fresh seeds and the run equals the eager one
