@@ -102,6 +102,43 @@ def test_fp16x3_under_the_residency_cap_and_with_split_k(ops):
         assert e_f < 1e-7 and e_c < max(2.0 * e_c6, 2e-7), (M, N, K, e_c, e_c6, e_f)
 
 
+@pytest.mark.parametrize('M,N,K', [(600, 10240, 5120), (600, 2400, 5120), (256, 2400, 5120)])
+def test_fp16x3_weight_gradient_bias_capped_and_free(ops, M, N, K):
+    """The weight-gradient products of the training step run as fp16x3 UNDER THE RESIDENCY CAP (side stream, one accumulator set:
+    gemm_x6_kernel<.., SEP = false, F16 = true>).  Signed mean error against float64 at the step's own shapes, zero-mean and
+    all-positive data: the capped form is held to the bound tests/test_gpu_gemm_x6.py pins for capped bf16x6 (3e-7 of the term
+    scale), the uncapped two-accumulator form to the 5e-9 of the default kernels; rms at the native f32 kernel's level."""
+    from ams_hip._lib import load
+    lib = load()
+    rng = np.random.RandomState(M + N + 1)
+    for kind in ('randn', 'pos'):
+        if kind == 'randn':
+            A, B = rng.randn(K, M), rng.randn(K, N)
+        else:
+            A, B = rng.uniform(0.5, 1.0, (K, M)), rng.uniform(0.5, 1.0, (K, N))
+        A32, B32 = A.astype(np.float32), B.astype(np.float32)
+        ref = A32.astype(np.float64).T @ B32.astype(np.float64)
+        scale = np.sqrt(K) if kind == 'randn' else np.abs(ref).mean()
+        a, b = torch.from_numpy(A32).cuda(), torch.from_numpy(B32).cuda()
+        bounds = (ops.absmax(a), ops.absmax(b))
+        lib.ams_gemm_set_arith(0)
+        try:
+            d0 = (ops.gemm(a, b, transA=True).double().cpu().numpy() - ref) / scale
+        finally:
+            lib.ams_gemm_set_arith(1)
+        free = (ops.gemm(a, b, transA=True, amax=bounds).double().cpu().numpy() - ref) / scale
+        lib.ams_gemm_set_lds_pad(50000)
+        try:
+            cap = (ops.gemm(a, b, transA=True, amax=bounds).double().cpu().numpy() - ref) / scale
+        finally:
+            lib.ams_gemm_set_lds_pad(0)
+        r0 = np.sqrt((d0 ** 2).mean())
+        print('fp16x3 %s %dx%dx%d: native mean %.2e rms %.2e | free mean %.2e rms %.2e | capped mean %.2e rms %.2e'
+              % (kind, M, N, K, d0.mean(), r0, free.mean(), np.sqrt((free ** 2).mean()), cap.mean(), np.sqrt((cap ** 2).mean())))
+        assert abs(free.mean()) < 5e-9 and np.sqrt((free ** 2).mean()) <= 1.05 * r0, (kind, free.mean(), d0.mean())
+        assert abs(cap.mean()) < 3e-7 and np.sqrt((cap ** 2).mean()) <= 1.5 * r0, (kind, cap.mean(), d0.mean())
+
+
 def test_nan_and_inf_propagate(ops):
     rng = np.random.RandomState(14)
     A, B, _, _ = _ops_pair(rng, 128, 128, 64, 0, 0)
