@@ -156,9 +156,11 @@ constexpr int UCHUNK = AMS_DPCL_UCHUNK;           // points per workgroup in the
 #endif
 constexpr int BCHUNK = AMS_DPCL_BCHUNK;           // ... in the backward pass (no per-workgroup partials there: may be smaller)
 
-__global__ __launch_bounds__(256) void dpcl_count_part_kernel(const float* __restrict__ Y, float* __restrict__ cntp, long TF, int S) {
+__global__ __launch_bounds__(256) void dpcl_count_part_kernel(const float* __restrict__ Y, float* __restrict__ cntp, long TF, int S,
+                                                              unsigned* __restrict__ ticket = nullptr) {
     __shared__ float sm[4][8];
     const int b = blockIdx.y, c = blockIdx.x;
+    if (ticket && b == 0 && c == 0 && threadIdx.x == 0) *ticket = 0u;      // arrival counter of dpcl_finish_kernel (two launches later)
     const long per = (TF + CP - 1) / CP;
     const long lo = (long)c * per, hi = min(TF, lo + per);
     float acc[8];
@@ -344,10 +346,16 @@ __global__ __launch_bounds__(256) void dpcl_gram_u_kernel(const float* __restric
 }
 
 // Per utterance: reduce chunk partials (fixed order), Frobenius norms, cost_b, normalised matrices for bwd.
+// out / ticket / clear (optional, together): the LAST workgroup to arrive also writes the batch means out[0..3] (what dpcl_mean_kernel
+// does in a launch of its own: 8 us on the critical path of a training step) and clears the backward's max |dU| slot; utterances
+// are summed in index order whoever arrives last, so the result does not depend on the arrival order.
 __global__ __launch_bounds__(1024) void dpcl_finish_kernel(const float* __restrict__ part, float* __restrict__ per_utt,
-                                                           float* __restrict__ mats, int E, int S, int Z, int nchunk, int B) {
+                                                           float* __restrict__ mats, int E, int S, int Z, int nchunk, int B,
+                                                           float* __restrict__ out = nullptr, unsigned* __restrict__ ticket = nullptr,
+                                                           unsigned* __restrict__ clear = nullptr) {
     extern __shared__ float gram[];
     __shared__ float sm[3][16];
+    __shared__ int last_sh;
     const int b = blockIdx.x, tid = threadIdx.x, nw = blockDim.x >> 6;
     for (int i = tid; i < Z * Z; i += blockDim.x) {
         // chunk partials summed in chunk order; loads issued 8 at a time (a serial chain of ~1 us round trips made this
@@ -391,6 +399,22 @@ __global__ __launch_bounds__(1024) void dpcl_finish_kernel(const float* __restri
     const float kg = 2.0f / (nG * B), ka = 2.0f / (nA * B);
     for (int i = tid; i < E * E; i += blockDim.x) m[i] = gram[(i / E) * Z + (i % E)] * kg;
     for (int i = tid; i < E * S; i += blockDim.x) m[E * E + i] = gram[(i / S) * Z + E + (i % S)] * ka;
+    if (ticket) {
+        if (tid == 0) {
+            __threadfence();                                    // per_utt[b] is out before the arrival is counted
+            last_sh = (atomicAdd(ticket, 1u) == (unsigned)gridDim.x - 1u) ? 1 : 0;
+        }
+        __syncthreads();
+        if (last_sh) {
+            __threadfence();
+            if (tid < 4) {
+                float t = 0.f;
+                for (int u = 0; u < B; ++u) t += __hip_atomic_load(&per_utt[u * 4 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                out[tid] = t / B;
+            }
+            if (tid == 4 && clear) clear[0] = 0u;
+        }
+    }
 }
 
 __global__ void dpcl_mean_kernel(const float* __restrict__ per_utt, float* __restrict__ out, int B, unsigned* __restrict__ clear = nullptr) {
@@ -923,7 +947,8 @@ ams_status ams_dpcl_loss_fwd_u(const float* U, const float* Y, float* inv, float
     float* per_utt = cntp + (size_t)B * CP * S;
     float* mats = per_utt + (size_t)B * 4;
     float* part = mats + (size_t)B * (E * E + E * S);
-    hipLaunchKernelGGL(dpcl_count_part_kernel, dim3(CP, B), dim3(256), 0, st, Y, cntp, TF, S);
+    unsigned* const slot = (unsigned*)((char*)ws + ams_dpcl_u_amax_offset(B, TF, E, S));      // word 0: max |dU|, word 1: arrival counter
+    hipLaunchKernelGGL(dpcl_count_part_kernel, dim3(CP, B), dim3(256), 0, st, Y, cntp, TF, S, slot + 1);
     dim3 grid(nchunk, B);
     switch (NT) {
         case 1: hipLaunchKernelGGL((dpcl_gram_u_kernel<1, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
@@ -937,8 +962,8 @@ ams_status ams_dpcl_loss_fwd_u(const float* U, const float* Y, float* inv, float
         }
         default: hipLaunchKernelGGL((dpcl_gram_u_kernel<4, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
     }
-    hipLaunchKernelGGL(dpcl_finish_kernel, dim3(B), dim3(1024), Z * Z * sizeof(float), st, part, per_utt, mats, E, S, Z, nchunk, B);
-    hipLaunchKernelGGL(dpcl_mean_kernel, dim3(1), dim3(64), 0, st, per_utt, out, B, (unsigned*)((char*)ws + ams_dpcl_u_amax_offset(B, TF, E, S)));
+    hipLaunchKernelGGL(dpcl_finish_kernel, dim3(B), dim3(1024), Z * Z * sizeof(float), st, part, per_utt, mats, E, S, Z, nchunk, B, out,
+                       slot + 1, slot);
     return ams_check_launch();
 }
 
