@@ -214,6 +214,35 @@ class BLSTMLayer(Function):
         return dx, dKf, dbf, dKb, dbb, None
 
 
+class BLSTMLayerDropout(Function):
+    """utils/ops.py:358-383 with --recurrent_dropout != 0 while training: each direction's BasicLSTMCell sits in a
+    DropoutWrapper(cell, keep, keep, keep) -- independent masks per time step on the cell input, on the carried state (TF 1.4: both c
+    and h) and on the cell output.  Per-step recurrence kernels (csrc/lstm.hip); the masks come in as tensors (ops.blstm_dropout_masks)."""
+
+    @staticmethod
+    def forward(ctx, x, Kf, bf, Kb, bb, m_in, m_h, m_c, m_out):
+        masks = {'in': m_in, 'h': m_h, 'c': m_c, 'out': m_out}
+        y, saved = ops.blstm_fwd_dropout(x, Kf, bf, Kb, bb, masks)
+        ctx.save_for_backward(x, Kf, Kb, m_in, m_h, m_c, m_out, *saved)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, Kf, Kb, m_in, m_h, m_c, m_out = ctx.saved_tensors[:7]
+        saved = ctx.saved_tensors[7:]
+        masks = {'in': m_in, 'h': m_h, 'c': m_c, 'out': m_out}
+        dx, dKf, dbf, dKb, dbb = ops.blstm_bwd_dropout(_c(dy), x, Kf, Kb, saved, masks, need_dx=ctx.needs_input_grad[0])
+        return dx, dKf, dbf, dKb, dbb, None, None, None, None
+
+
+def blstm_dropout(x, Kf, bf, Kb, bb, keep, masks=None):
+    """One BLSTM layer under the reference's dropout wrappers; masks default to a fresh draw (ops.blstm_dropout_masks)."""
+    if masks is None:
+        B, T, D = x.shape
+        masks = ops.blstm_dropout_masks(B, T, D, Kf.shape[1] // 4, keep, x.device)
+    return BLSTMLayerDropout.apply(_c(x), Kf, bf, Kb, bb, masks['in'], masks['h'], masks['c'], masks['out'])
+
+
 class Dense(Function):
     """Conv1D with kernel width 1: u = x.W + b  (utils/ops.py:486-503).  x [..., Din], W [Din, Dout]."""
 

@@ -103,6 +103,15 @@ class Run(object):
         self.begun = False
 
 
+_RUNNING = []                           # the Runs whose nodes are being evaluated (innermost last)
+
+
+def current_run():
+    """The evaluation pass a node function is running in (None outside one): layers built without access to the run -- the
+    reference reads `inputs/is_training:0` from the graph instead (utils/ops.py:362-363) -- ask it whether this is a training pass."""
+    return _RUNNING[-1] if _RUNNING else None
+
+
 class Node(object):
     def __init__(self, name, fn, graph=None, register=True):
         g = graph or get_default_graph()
@@ -119,7 +128,11 @@ class Node(object):
                 if torch.cuda.is_available():
                     from . import ops, functional
                     ops.pass_begin(functional.OVERLAP.side())
-            run.cache[k] = self.fn(run)
+            _RUNNING.append(run)
+            try:
+                run.cache[k] = self.fn(run)
+            finally:
+                _RUNNING.pop()
         return run.cache[k]
 
     def __repr__(self):

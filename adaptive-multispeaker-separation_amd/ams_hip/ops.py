@@ -954,6 +954,77 @@ def blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout):
               'ams_blstm_recurrent_bwd')
 
 
+# ---- DropoutWrapper(cell, keep, keep, keep) around each direction (utils/ops.py:363,373,379; --recurrent_dropout != 0, training)
+def blstm_dropout_masks(B, T, D, H, keep, device, generator=None):
+    """The eight keep-masks of one BLSTM layer, scaled by 1/keep (tf.nn.dropout): 'in' [2,B,T,D] (one per direction wrapper),
+    'h', 'c' [B,T,2,H] on the two parts of the carried state (TF 1.4 maps the state dropout over the whole LSTMStateTuple),
+    'out' [B,T,2H] on the cell outputs.  Drawn on the device: TensorFlow's stream is not reproducible, the distribution is."""
+    def m(*shape):
+        return (torch.rand(*shape, device=device, generator=generator) < keep).to(torch.float32) / keep
+    return {'in': m(2, B, T, D), 'h': m(B, T, 2, H), 'c': m(B, T, 2, H), 'out': m(B, T, 2 * H)}
+
+
+def blstm_fwd_dropout(x, Kf, bf, Kb, bb, masks):
+    """One BLSTM layer under the reference's dropout wrappers.  Returns the layer output [B,T,2H] and what the backward needs."""
+    _chk(x, bf, bb, masks['in'], masks['h'], masks['c'], masks['out'])
+    _chk_rows(Kf, Kb)
+    lib = load()
+    B, T, D = x.shape
+    H = Kf.shape[1] // 4
+    ldu = Kf.stride(0)
+    if Kb.stride(0) != ldu:
+        raise AmsError('blstm: the two direction kernels must share one row stride')
+    M = B * T
+    xd = x.unsqueeze(0) * masks['in']                            # [2,B,T,D]: elementwise glue of a default-off flag
+    G = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=x.device)
+    Gv = G.view(-1)
+    # the two wrappers see different inputs: one projection per direction, written into its half of the [B*T, 8H] rows
+    gemm(xd[0].reshape(M, D), Kf, bias=bf, out=Gv, M=M, N=4 * H, K=D, lda=D, ldb=ldu, ldc=8 * H)
+    gemm(xd[1].reshape(M, D), Kb, bias=bb, out=Gv[4 * H:], M=M, N=4 * H, K=D, lda=D, ldb=ldu, ldc=8 * H)
+    out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
+    hs = torch.empty_like(out)
+    cst = torch.empty((B, T, 2, H), dtype=torch.float32, device=x.device)
+    cs = torch.empty_like(cst)
+    pack = torch.empty(lib.ams_blstm_pack_floats(H, 0), dtype=torch.float32, device=x.device)
+    check(lib.ams_blstm_recurrent_fwd_dropout(_p(G), _p(out), _p(cst), _p(hs), _p(cs), _p(masks['h']), _p(masks['c']), _p(Kf[D:]),
+                                              _p(Kb[D:]), ldu, _p(pack), B, T, H, _s()), 'ams_blstm_recurrent_fwd_dropout')
+    return out * masks['out'], (xd, G, cst, cs, hs)
+
+
+def blstm_bwd_dropout(dy, x, Kf, Kb, saved, masks, need_dx=True):
+    """BPTT of blstm_fwd_dropout.  DESTROYS G.  Returns dx, dKf, dbf, dKb, dbb."""
+    xd, G, cst, cs, hs = saved
+    _chk(dy, G, cst, cs, hs)
+    lib = load()
+    B, T, D = x.shape
+    H = Kf.shape[1] // 4
+    ldu = Kf.stride(0)
+    M = B * T
+    dout = (dy * masks['out']).contiguous()
+    pack = torch.empty(lib.ams_blstm_pack_floats(H, 1), dtype=torch.float32, device=x.device)
+    dc = torch.empty((B, 2, H), dtype=torch.float32, device=x.device)
+    check(lib.ams_blstm_recurrent_bwd_dropout(_p(G), _p(cst), _p(cs), _p(dout), _p(dc), _p(masks['h']), _p(masks['c']), _p(Kf[D:]),
+                                              _p(Kb[D:]), ldu, _p(pack), B, T, H, _s()), 'ams_blstm_recurrent_bwd_dropout')
+    dKf = torch.empty((D + H, 4 * H), dtype=torch.float32, device=x.device)
+    dKb = torch.empty((D + H, 4 * H), dtype=torch.float32, device=x.device)
+    dbf = torch.empty(4 * H, dtype=torch.float32, device=x.device)
+    dbb = torch.empty(4 * H, dtype=torch.float32, device=x.device)
+    dZ = G.view(-1)
+    gemm(xd[0].reshape(M, D), dZ, transA=True, out=dKf, M=D, N=4 * H, K=M, lda=D, ldb=8 * H, ldc=4 * H)
+    gemm(xd[1].reshape(M, D), dZ[4 * H:], transA=True, out=dKb, M=D, N=4 * H, K=M, lda=D, ldb=8 * H, ldc=4 * H)
+    # recurrent kernels: the MASKED states paired with dZ one step on; biases: column sums of dZ
+    blstm_bwd_weights(x, hs, G, dKf, dbf, dKb, dbb, False, part='u')
+    blstm_bwd_weights(x, hs, G, dKf, dbf, dKb, dbb, False, part='bias')
+    dx = None
+    if need_dx:
+        dxf = gemm(dZ, Kf, transB=True, M=M, N=D, K=4 * H, lda=8 * H, ldb=ldu, ldc=D,
+                   out=torch.empty((M, D), dtype=torch.float32, device=x.device))
+        dxb = gemm(dZ[4 * H:], Kb, transB=True, M=M, N=D, K=4 * H, lda=8 * H, ldb=ldu, ldc=D,
+                   out=torch.empty((M, D), dtype=torch.float32, device=x.device))
+        dx = dxf.view(B, T, D) * masks['in'][0] + dxb.view(B, T, D) * masks['in'][1]
+    return dx, dKf, dbf, dKb, dbb
+
+
 def blstm_bwd_dx(G, Kf, Kb, B, T, D, amax=None):
     """dx = dZ . [Wx_f | Wx_b]^T  (the only hoisted product on the backward critical path), one GEMM with K = 8H."""
     H = Kf.shape[1] // 4

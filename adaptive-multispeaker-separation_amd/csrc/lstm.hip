@@ -81,6 +81,11 @@ struct StepArgs {
     // backward only
     const float* dout;             // [B,T,2H] gradient w.r.t. layer output
     float* dc;                     // [B,2,H] running dc
+    // state dropout (DropoutWrapper(state_keep_prob), utils/ops.py:373,379): the state handed to the NEXT step is (c.mc, h.mh) while
+    // the cell output stays h.  mh / mc [B,T,2,H]: masks already scaled by 1/keep; hs [B,T,2H] / cs [B,T,2,H]: the masked states
+    // (written by the forward kernel, read by it one step later, by the backward kernel and by the recurrent-kernel gradients).
+    const float* mh; const float* mc;
+    float* hs; float* cs;
 };
 
 // Workgroup -> (unit tile, batch tile, direction).  The n_bt batch tiles of one (direction, unit tile) read the SAME 76 KB slice
@@ -149,11 +154,11 @@ __global__ __launch_bounds__(NWF * 64) void lstm_step_fwd_kernel(StepArgs a) {
     if (live) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) zq[q] = grow[q * H + u];
-        if (has_prev) c_prev = a.cst[(((long)b * T + tp) * 2 + dir) * H + u];
+        if (has_prev) c_prev = (a.cs ? a.cs : a.cst)[(((long)b * T + tp) * 2 + dir) * H + u];
     }
 
     if (has_prev) {
-        const float* hrow = a.out + ((long)b_row * T + tp) * (2 * H) + dir * H;
+        const float* hrow = (a.hs ? a.hs : a.out) + ((long)b_row * T + tp) * (2 * H) + dir * H;
         const float* pk = a.pk + (((long)dir * a.n_ut + ut) * a.n_g) * (4 * 64 * 4) + lane * 4;
         // Issue EVERY operand load of a chunk before the first MFMA: the h/U fetches are L2 round trips
         // (~1 us) and a load->MFMA->load loop would pay that latency once per k-group.
@@ -211,6 +216,11 @@ __global__ __launch_bounds__(NWF * 64) void lstm_step_fwd_kernel(StepArgs a) {
     grow[3 * H + u] = og;
     a.cst[(((long)b * T + t) * 2 + dir) * H + u] = c;
     a.out[((long)b * T + t) * (2 * H) + dir * H + u] = h;
+    if (a.hs) {
+        const long si = (((long)b * T + t) * 2 + dir) * H + u;
+        a.cs[si] = c * a.mc[si];
+        a.hs[((long)b * T + t) * (2 * H) + dir * H + u] = h * a.mh[si];
+    }
 }
 
 // Pipelined-fetch form of the forward step (H % 4 == 0 and NWF < n_g <= 3 * NWF, i.e. 132 <= H <= 384).
@@ -346,8 +356,14 @@ __global__ __launch_bounds__(NWB * 64) void lstm_step_bwd_kernel(StepArgs a) {
         dh = a.dout[((long)b * T + t) * (2 * H) + dir * H + u];
         ig = grow[0 * H + u]; gg = grow[1 * H + u]; fg = grow[2 * H + u]; og = grow[3 * H + u];
         c = a.cst[(((long)b * T + t) * 2 + dir) * H + u];
-        if (has_prev) c_prev = a.cst[(((long)b * T + tp) * 2 + dir) * H + u];
+        if (has_prev) c_prev = (a.cs ? a.cs : a.cst)[(((long)b * T + tp) * 2 + dir) * H + u];
         if (has_next) dc_next = *dcp;
+    }
+    float mh = 1.f;
+    if (live && a.mh) {                                  // the state that left step t was (c_t.mc_t, h_t.mh_t)
+        const long si = (((long)b * T + t) * 2 + dir) * H + u;
+        mh = a.mh[si];
+        dc_next *= a.mc[si];
     }
 
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -387,8 +403,10 @@ __global__ __launch_bounds__(NWB * 64) void lstm_step_bwd_kernel(StepArgs a) {
 
     if (!live) return;
     const int src_lane = (bl >> 2) * 16 + ul, src_reg = bl & 3;
+    float dh_rec = 0.f;
 #pragma unroll
-    for (int w = 0; w < NWB; ++w) dh += red[w][src_lane][src_reg];
+    for (int w = 0; w < NWB; ++w) dh_rec += red[w][src_lane][src_reg];
+    dh += dh_rec * mh;
     const float tc = tanhf(c);
     const float d_o = dh * tc;
     const float dcv = dc_next + dh * og * (1.0f - tc * tc);
@@ -471,6 +489,57 @@ ams_status ams_blstm_recurrent_fwd(float* G, float* out, float* cst, const float
         a.s = s;
         if (use_pipe) hipLaunchKernelGGL(lstm_step_fwd_pipe_kernel, grid, dim3(NWF * 64), 0, st, a);
         else hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(NWF * 64), 0, st, a);
+    }
+    return ams_check_launch();
+}
+
+// The same recurrence with DropoutWrapper's STATE dropout (utils/ops.py:373,379 at --recurrent_dropout != 0; TF 1.4 masks both parts
+// of the LSTMStateTuple): out / cst keep the cell's own h_t / c_t, hs [B,T,2H] / cs [B,T,2,H] receive the masked states h_t.mh_t /
+// c_t.mc_t that step t+1 (t-1 for the backward direction) starts from.  mh, mc [B,T,2,H]: keep-masks scaled by 1/keep, drawn by the
+// caller.  Input and output dropout are elementwise on x and on out and stay with the caller.  Per-step kernels only.
+ams_status ams_blstm_recurrent_fwd_dropout(float* G, float* out, float* cst, float* hs, float* cs, const float* mh, const float* mc,
+                                           const float* Uf, const float* Ub, long ldu, float* pack, int B, int T, int H, void* stream) {
+    AMS_REQUIRE(G && out && cst && hs && cs && mh && mc && Uf && Ub && pack && B > 0 && T > 0 && H > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int n_ut = ceil_div(H, TU), n_g = ceil_div(H, 16);
+    {
+        const long total = (long)2 * n_ut * n_g * 4 * 64 * 4;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(pack_u_fwd_kernel, dim3(blocks), dim3(256), 0, st, Uf, Ub, ldu, pack, H, n_ut, n_g);
+    }
+    StepArgs a{};
+    a.G = G; a.out = out; a.cst = cst; a.pk = pack; a.hs = hs; a.cs = cs; a.mh = mh; a.mc = mc;
+    a.B = B; a.T = T; a.H = H; a.n_ut = n_ut; a.n_g = n_g;
+    dim3 grid = step_grid(a);
+    for (int s = 0; s < T; ++s) {
+        a.s = s;
+        hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(NWF * 64), 0, st, a);
+    }
+    return ams_check_launch();
+}
+
+// BPTT of the recurrence above: dh_t = dout_t + mh_t . (da_{t+1} U^T), dc_t = mc_t . (dc_{t+1} f_{t+1}) + ..., c_prev = the MASKED state.
+ams_status ams_blstm_recurrent_bwd_dropout(float* G, const float* cst, const float* cs, const float* dout, float* dc, const float* mh,
+                                           const float* mc, const float* Uf, const float* Ub, long ldu, float* pack, int B, int T, int H,
+                                           void* stream) {
+    AMS_REQUIRE(G && cst && cs && dout && dc && mh && mc && Uf && Ub && pack && B > 0 && T > 0 && H > 0);
+    hipStream_t st = (hipStream_t)stream;
+    const int n_ut = ceil_div(H, TU), n_g = ceil_div(4 * H, 16);
+    {
+        const long total = (long)2 * n_ut * n_g * 64 * 4;
+        int blocks = (int)((total + 255) / 256);
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(pack_u_bwd_kernel, dim3(blocks), dim3(256), 0, st, Uf, Ub, ldu, pack, H, n_ut, n_g);
+    }
+    StepArgs a{};
+    a.G = G; a.cst = const_cast<float*>(cst); a.cs = const_cast<float*>(cs); a.pk = pack; a.dout = dout; a.dc = dc; a.mh = mh; a.mc = mc;
+    a.B = B; a.T = T; a.H = H; a.n_ut = n_ut; a.n_g = n_g;
+    dim3 grid = step_grid(a);
+    for (int s = 0; s < T; ++s) {
+        a.s = s;
+        if (H % 4 == 0) hipLaunchKernelGGL(lstm_step_bwd_kernel<true>, grid, dim3(NWB * 64), 0, st, a);
+        else hipLaunchKernelGGL(lstm_step_bwd_kernel<false>, grid, dim3(NWB * 64), 0, st, a);
     }
     return ams_check_launch();
 }

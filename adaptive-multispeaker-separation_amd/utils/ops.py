@@ -89,10 +89,9 @@ class BLSTM:
     def __init__(self, hid_dim, name, drop_val=0.0, in_dim=None):
         self.hid_dim = hid_dim
         self.name = name
-        self.drop_val = drop_val
-        if drop_val not in (0, 0.0):
-            raise NotImplementedError('recurrent_dropout != 0 is not on the HIP path (reference default is 0.0; which part of the LSTM '
-                                      'state DropoutWrapper masks depends on the TensorFlow release -- DESIGN.md 6)')
+        self.drop_val = float(drop_val or 0.0)
+        if not 0.0 <= self.drop_val < 1.0:
+            raise ValueError('recurrent_dropout must be in [0, 1), got %r' % (drop_val,))
         H = hid_dim // 2
         g = get_default_graph()
 
@@ -109,6 +108,14 @@ class BLSTM:
         self.Kf._ams_twin, self.bf._ams_twin = self.Kb, self.bb      # storage hint for FlatOptimizer (interleaved rows)
 
     def f_prop(self, x):
+        # utils/ops.py:362-363: keep = cond(is_training, 1 - drop_val, 1.0); with keep = 1 tf.nn.dropout is the identity, so only a
+        # training pass with drop_val != 0 takes the wrapper form (per-step kernels, masks drawn on the device)
+        if self.drop_val != 0.0:
+            from ams_hip.graph import current_run
+            run = current_run()
+            if run is not None and run.training and torch.is_grad_enabled():
+                F.hint_next(None)
+                return F.blstm_dropout(x, self.Kf, self.bf, self.Kb, self.bb, 1.0 - self.drop_val)
         return F.blstm(x, self.Kf, self.bf, self.Kb, self.bb, getattr(self, '_last_capped', False))
 
 

@@ -163,6 +163,17 @@ ams_status ams_blstm_recurrent_fwd_steps(float* G, float* out, float* cst, const
  * cannot use it (not all workgroups resident, or H > 320): callers then use ams_blstm_recurrent_fwd/bwd.
  * sync word 0 (uint32) is non-zero after the launch if a bounded in-launch wait timed out. */
 ams_status ams_blstm_pack(const float* Uf, const float* Ub, long ldu, float* pack, int H, int backward, void* stream);
+/* The per-step recurrence with DropoutWrapper's STATE dropout (utils/ops.py:363,373,379, --recurrent_dropout / --recurrent_dropout_enhance
+ * != 0, training only; TensorFlow 1.4 masks BOTH parts of the LSTMStateTuple): out / cst keep the cell's own h_t / c_t, hs [B,T,2H] and
+ * cs [B,T,2,H] receive the masked states h_t.mh_t / c_t.mc_t the next step starts from; mh, mc [B,T,2,H] are keep-masks scaled by 1/keep,
+ * drawn by the caller (TensorFlow's mask stream is not reproducible; the distribution is).  The wrapper's input and output dropout are
+ * elementwise on x (one mask per direction) and on the layer output and stay with the caller.  The recurrent-kernel gradients are
+ * products of hs (not out) with da.  dc: [B,2,H] workspace as for ams_blstm_recurrent_bwd. */
+ams_status ams_blstm_recurrent_fwd_dropout(float* G, float* out, float* cst, float* hs, float* cs, const float* mh, const float* mc,
+                                           const float* Uf, const float* Ub, long ldu, float* pack, int B, int T, int H, void* stream);
+ams_status ams_blstm_recurrent_bwd_dropout(float* G, const float* cst, const float* cs, const float* dout, float* dc, const float* mh,
+                                           const float* mc, const float* Uf, const float* Ub, long ldu, float* pack, int B, int T, int H,
+                                           void* stream);
 size_t ams_blstm_persist_sync_bytes(int B, int H, int backward);
 ams_status ams_blstm_persist_fwd(float* G, float* out, float* cst, const float* Uf, const float* Ub, long ldu, float* pack, void* sync,
                                  size_t sync_bytes, int B, int T, int H, void* stream);

@@ -239,3 +239,37 @@ def test_gemm_at_b_colsum(ops, M, N, K):
     assert rel(host(out2), A.T.dot(Bm)) < TOL and rel(host(bsum2), Bm.sum(0)) < TOL
     # a shape the fused form does not take (N not a multiple of 4): the wrapper says so instead of guessing
     assert not ops.gemm_at_b_colsum(dev(A), dev(Bm[:, :N - 1].copy()), torch.empty(M, N - 1, device='cuda'), torch.empty(N - 1, device='cuda'))
+
+
+@pytest.mark.parametrize('B,T,D,H,twin', [(5, 7, 12, 10, False), (20, 9, 16, 24, False), (33, 6, 8, 12, True)])
+def test_blstm_under_dropout_wrappers(B, T, D, H, twin):
+    """--recurrent_dropout != 0 (utils/ops.py:363,373,379): the per-step recurrence with state dropout on c and h
+    (ams_blstm_recurrent_fwd/bwd_dropout) plus the input / output masks, against the oracle with the SAME masks: output, dx and all
+    four parameter gradients.  twin: the two direction kernels row-interleaved as FlatOptimizer stores them."""
+    from ams_hip import ops
+    rng = np.random.RandomState(B + H)
+    keep = 0.75
+    x = rng.randn(B, T, D)
+    Kf, Kb = rng.randn(D + H, 4 * H) * 0.4, rng.randn(D + H, 4 * H) * 0.4
+    bf, bb = rng.randn(4 * H) * 0.1, rng.randn(4 * H) * 0.1
+    g = torch.Generator(device='cuda').manual_seed(B)
+    masks = ops.blstm_dropout_masks(B, T, D, H, keep, 'cuda', generator=g)
+    mh = {k: host(v) for k, v in masks.items()}
+    assert set(np.unique(mh['h']).round(6)) <= {0.0, round(1.0 / keep, 6)} and 0.6 < (mh['in'] > 0).mean() < 0.9
+    om = tuple({'in': mh['in'][d], 'h': mh['h'][:, :, d], 'c': mh['c'][:, :, d], 'out': mh['out'][:, :, d * H:(d + 1) * H]} for d in (0, 1))
+    out_ref, cache = oblstm.blstm_fwd(x, Kf, bf, Kb, bb, om)
+    dout = rng.randn(B, T, 2 * H)
+    dx_ref, (dKf_ref, dbf_ref, dKb_ref, dbb_ref) = oblstm.blstm_bwd(dout, cache)
+    if twin:
+        blk = torch.empty(D + H, 2, 4 * H, device='cuda')
+        blk[:, 0].copy_(dev(Kf))
+        blk[:, 1].copy_(dev(Kb))
+        kf, kb = blk[:, 0], blk[:, 1]
+    else:
+        kf, kb = dev(Kf), dev(Kb)
+    xd = dev(x)
+    y, saved = ops.blstm_fwd_dropout(xd, kf, dev(bf), kb, dev(bb), masks)
+    assert rel(host(y), out_ref) < TOL
+    dx, dKf, dbf, dKb, dbb = ops.blstm_bwd_dropout(dev(dout), xd, kf, kb, saved, masks)
+    for mine, ref in ((dx, dx_ref), (dKf, dKf_ref), (dbf, dbf_ref), (dKb, dKb_ref), (dbb, dbb_ref)):
+        assert rel(host(mine), ref) < 5 * TOL

@@ -78,6 +78,41 @@ def test_ring_sync_arena_matches_private_buffers():
         assert np.array_equal(p_p[n], p_a[n]), n
 
 
+def test_training_with_recurrent_dropout():
+    """--recurrent_dropout 0.3 through the trainer: training passes take the DropoutWrapper form (fresh masks every step, so the same
+    batch gives different costs), evaluation passes are the plain network (tf.cond(training, 1 - drop, 1.0): identical costs, equal to
+    a model without the flag), gradients reach every variable and the step stays finite; the same under --hip_graph."""
+    import tempfile
+    from tests.smoke_step import build_front_dpcl
+
+    def build(drop, graph=False):
+        tmp = tempfile.mkdtemp(prefix='ams_rd_')
+        tr, tfds = build_front_dpcl(tmp, B=4, L=1024, W=64, N=16, hop=16, layer_size=16, nb_layers=2, E=8, recurrent_dropout=drop,
+                                    hip_graph=graph, no_summaries=True)
+        return tr, tfds
+
+    tr0, tfds0 = build(0.0)
+    with tr0.graph.as_default():
+        feed0 = {tfds0.handle: tfds0.get_handle(tfds0.TRAIN), tfds0.chunk_size: 1024}
+        tfds0.initialize(tfds0.TRAIN)
+        v_plain = tr0.model.valid_batch(feed0, 0)
+        c_plain = float(tr0.model.train(feed0, 0))
+    for graph in (False, True):
+        tr, tfds = build(0.3, graph)
+        g, model = tr.graph, tr.model
+        with g.as_default():
+            feed = {tfds.handle: tfds.get_handle(tfds.TRAIN), tfds.chunk_size: 1024}
+            tfds.initialize(tfds.TRAIN)
+            v1 = model.valid_batch(feed, 0)
+            assert v1 == v_plain, (v1, v_plain)                       # same seeds, same init, same batch: evaluation ignores the flag
+            before = {v.ams_name: v.detach().clone() for v in model.trainable_variables}
+            costs = [float(model.train(feed, i)) for i in range(5)]
+        torch.cuda.synchronize()
+        assert np.all(np.isfinite(costs)) and costs[0] != c_plain and len(set(costs)) == 5, (costs, c_plain)
+        for v in model.trainable_variables:
+            assert torch.isfinite(v).all() and not torch.equal(v, before[v.ams_name]), v.ams_name
+
+
 def test_hip_graph_finetuning_step_refreshes_kmeans_seeds():
     """--hip_graph on a recipe whose k-means seeds come from the host RNG (front_*_finetuning): the captured kernels read a
     persistent index buffer that a pre-replay hook re-fills, so replayed steps see fresh seeds and the run equals the eager one

@@ -187,6 +187,49 @@ def test_blstm_vs_torch_lstm_and_grads():
         assert rel(db[perm], l.bias_ih_l0.grad.numpy()) < 1e-11
 
 
+def _dropout_masks(rng, B, T, D, H, keep):
+    def m(*s):
+        return (rng.rand(*s) < keep) / keep
+    return {'in': m(B, T, D), 'h': m(B, T, H), 'c': m(B, T, H), 'out': m(B, T, H)}
+
+
+def test_blstm_with_dropout_wrappers_vs_autograd():
+    """--recurrent_dropout != 0 (utils/ops.py:363,373,379): DropoutWrapper(cell, keep, keep, keep) per direction, restated step by
+    step in torch (input mask -> cell -> state mask on c AND h as TF 1.4 does -> output mask) and differentiated by autograd, against
+    the oracle's forward and hand-written BPTT with the same masks."""
+    B, T, D, H, keep = 3, 6, 5, 4, 0.7
+    rng = np.random.RandomState(5)
+    x = rng.randn(B, T, D)
+    Kf, Kb = rng.randn(D + H, 4 * H) * 0.5, rng.randn(D + H, 4 * H) * 0.5
+    bf, bb = rng.randn(4 * H) * 0.1, rng.randn(4 * H) * 0.1
+    masks = (_dropout_masks(rng, B, T, D, H, keep), _dropout_masks(rng, B, T, D, H, keep))
+    out, cache = blstm.blstm_fwd(x, Kf, bf, Kb, bb, masks)
+    dout = rng.randn(B, T, 2 * H)
+    dx, (dKf, dbf, dKb, dbb) = blstm.blstm_bwd(dout, cache)
+    tx, tKf, tbf, tKb, tbb = [t(a).requires_grad_() for a in (x, Kf, bf, Kb, bb)]
+
+    def run_dir(K, b, m, rev):
+        h = torch.zeros(B, H, dtype=torch.float64)
+        c = torch.zeros(B, H, dtype=torch.float64)
+        outs = [None] * T
+        for tt in (range(T - 1, -1, -1) if rev else range(T)):
+            a = torch.cat([tx[:, tt] * t(m['in'][:, tt]), h], 1) @ K + b
+            i, j, f, o = a[:, :H], a[:, H:2 * H], a[:, 2 * H:3 * H], a[:, 3 * H:]
+            cn = c * torch.sigmoid(f + 1.0) + torch.sigmoid(i) * torch.tanh(j)
+            hn = torch.tanh(cn) * torch.sigmoid(o)
+            outs[tt] = hn * t(m['out'][:, tt])
+            h, c = hn * t(m['h'][:, tt]), cn * t(m['c'][:, tt])
+        return torch.stack(outs, 1)
+    ot = torch.cat([run_dir(tKf, tbf, masks[0], False), run_dir(tKb, tbb, masks[1], True)], 2)
+    assert rel(out, ot.detach().numpy()) < 1e-12
+    (ot * t(dout)).sum().backward()
+    for mine, ref in ((dx, tx), (dKf, tKf), (dbf, tbf), (dKb, tKb), (dbb, tbb)):
+        assert rel(mine, ref.grad.numpy()) < 1e-11
+    # keep = 1: the wrapper is the identity
+    ones = tuple({k: np.ones_like(v) for k, v in m.items()} for m in masks)
+    assert rel(blstm.blstm_fwd(x, Kf, bf, Kb, bb, ones)[0], blstm.blstm_fwd(x, Kf, bf, Kb, bb)[0]) < 1e-14
+
+
 # ---------------------------------------------------------------- dense + l2norm + DPCL + L41
 def test_dense_l2norm_dpcl_grads():
     B, T, Fq, E, S, Din = 2, 3, 4, 5, 2, 6
