@@ -961,7 +961,10 @@ def blstm_dropout_masks(B, T, D, H, keep, device, generator=None):
     'out' [B,T,2H] on the cell outputs.  Drawn on the device: TensorFlow's stream is not reproducible, the distribution is."""
     def m(*shape):
         return (torch.rand(*shape, device=device, generator=generator) < keep).to(torch.float32) / keep
-    return {'in': m(2, B, T, D), 'h': m(B, T, 2, H), 'c': m(B, T, 2, H), 'out': m(B, T, 2 * H)}
+    # AMS_RDROPOUT_MASK_C=0: leave the cell state unmasked -- what DropoutWrapper does in the TensorFlow releases that have
+    # `dropout_state_filter_visitor` (default: h only); 1.4.0, the release of the reference's containers, masks both parts
+    mc = m(B, T, 2, H) if _os.environ.get('AMS_RDROPOUT_MASK_C', '1') != '0' else torch.ones(B, T, 2, H, device=device)
+    return {'in': m(2, B, T, D), 'h': m(B, T, 2, H), 'c': mc, 'out': m(B, T, 2 * H)}
 
 
 def blstm_fwd_dropout(x, Kf, bf, Kb, bb, masks):
