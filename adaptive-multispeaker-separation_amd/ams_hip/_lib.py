@@ -12,6 +12,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('AMS_HIP_LIB') or os.path.join(_HERE, 'libams_hip.so')   # env: kernel-variant A/B runs
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'include', 'ams.h'))
 
+ABI_VERSION = 2            # include/ams.h: AMS_ABI_VERSION
+
 _CT = {
     'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float, 'size_t': ctypes.c_size_t,
     'int32_t': ctypes.c_int32, 'ams_status': ctypes.c_int32, 'void': None,
@@ -23,7 +25,7 @@ def parse_header(path=HEADER_PATH):
     src = open(path).read()
     src = re.sub(r'/\*.*?\*/', ' ', src, flags=re.S)
     protos = {}
-    for m in re.finditer(r'\b(ams_status|size_t|int|void)\s+(ams_\w+)\s*\(([^)]*)\)\s*;', src):  # noqa: E501
+    for m in re.finditer(r'\b(ams_status|size_t|int|long|void)\s+(ams_\w+)\s*\(([^)]*)\)\s*;', src):  # noqa: E501
         ret, name, args = m.group(1), m.group(2), m.group(3).strip()
         argtypes = []
         if args and args != 'void':
@@ -63,8 +65,9 @@ def load():
             raise AmsError('libams_hip.so does not export %s (declared in include/ams.h)' % name)
         fn.restype = ret
         fn.argtypes = argtypes
-    if lib.ams_abi_version() != 1:
-        raise AmsError('libams_hip.so ABI version mismatch')
+    if lib.ams_abi_version() != ABI_VERSION:
+        raise AmsError('libams_hip.so ABI version mismatch: the library is %d, this binding is %d -- rebuild (make -C csrc)'
+                       % (lib.ams_abi_version(), ABI_VERSION))
     _lib = lib
     return lib
 

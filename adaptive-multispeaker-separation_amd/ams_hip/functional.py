@@ -42,7 +42,6 @@ class _Overlap(object):
 
     def cap(self, on, kind='dense'):
         import os
-        from ._lib import load
         # residency cap of side-stream products via a dynamic-LDS pad: 1 workgroup per CU for all of them, with the step kernels
         # at s_setprio 3.  (Measured history: before the GEMM's operand fetch was made branch-free a capped product was
         # latency-bound at 54 TFLOP/s and the dense dW product paid off at 2 per CU, 9.62 k vs 9.32 k mixtures/s; with the
@@ -63,8 +62,7 @@ class _Overlap(object):
             tab = [int(v) for v in tab.split(',')]
             pad = tab[min(self.n_cap, len(tab) - 1)]
             self.n_cap += 1
-        load().ams_gemm_set_lds_pad(pad if on else 0)
-        load().ams_x3_set_capped(1 if on else 0)
+        ops.LDS_PAD[0] = pad if on else 0               # handed to every product launched until the next cap() (include/ams.h: lds_pad)
 
     def join(self):
         self.n_cap = 0
@@ -111,56 +109,20 @@ _ORDER = int(_os.environ.get('AMS_OVERLAP_ORDER', '2'))
 # 2 = dW alone, then dX (8.97 k) -- measured on the B=64 step, kept as a tuning aid
 _DENSE_MODE = int(_os.environ.get('AMS_DENSE_MODE', '0'))
 _L1_TAIL = int(_os.environ.get('AMS_L1_TAIL', '0'))
-# AMS_X3_SIDE=1: the side-stream (residency-capped) weight-gradient products run from pre-split x3 images (csrc/gemm_x3.hip, two
-# accumulator sets: no truncation bias) instead of the capped one-accumulator form of the in-loop-split kernel.  Measured on the B=64
-# step: 16.68-16.70 k against 17.20-17.30 k mixtures/s (-3.2 %: the 525 MB split pass of dU beside the top BPTT ring, which it slows
-# from 344 to 390 us) -- parity-tested (tests/test_gpu_benchshape.py passes with either setting), off by default; DESIGN.md 4.0b.
-X3_SIDE = _os.environ.get('AMS_X3_SIDE', '0') != '0'
-
-
-_NEXT = []
-
-
-def hint_next(kind=None, *params):
-    """Tell the next blstm() call which row-wise product consumes its output: ('proj', Kf, bf, Kb, bb) = another BLSTM layer,
-    ('dense', W, b) = the width-1 Conv1D.  One-shot; see ops.TAIL_CUTS."""
-    del _NEXT[:]
-    if kind is not None:
-        _NEXT.append((kind,) + tuple(params))
-
-
-def _take_hint(in_dim):
-    if not _NEXT:
-        return None
-    h = _NEXT.pop()
-    if h[0] == 'proj':
-        Kf, bf, Kb, bb = h[1:]
-        H4 = Kf.shape[1]
-        D = Kf.shape[0] - H4 // 4
-        if D != in_dim or not Kf.is_cuda or not ops._twin(Kf, Kb):     # zero-copy [D, 8H] view only (FlatOptimizer layout)
-            return None
-        W = ops.blstm_wcat(Kf, Kb, D)
-        bias = torch.as_strided(bf, (2 * H4,), (1,)) if ops._twin(bf, bb) else torch.cat([bf, bb])
-        return ('proj', W.detach(), bias.detach())
-    W, b = h[1:]
-    if W.shape[0] != in_dim or not W.is_cuda or W.stride(1) != 1:
-        return None
-    return ('dense', W.detach(), b.detach())
-
 
 class BLSTMLayer(Function):
     """utils/ops.py:358-383 (BasicLSTMCell x 2 directions, concat)."""
 
     @staticmethod
     def forward(ctx, x, Kf, bf, Kb, bb, last_capped=False):
-        # fp16x3 products (ops.set_amax): bounds of the input and of the kernels (one bound over the optimizer's flat buffer; two
+        # fp16x3 products (amax_a / amax_b of the product entry points): bounds of the input and of the kernels (one bound over the optimizer's flat buffer; two
         # kernels measured separately have no common bound at hand and keep bf16x6)
         aw = ops.param_amax(Kf) if ops.F16X3 and x.is_cuda else None
         if aw is not None and aw is not ops.param_amax(Kb):
             aw = None
         ax = ops.amax_of(x) if aw is not None else None
         ctx.amax = (ax, aw) if aw is not None else None
-        out, G, cst = ops.blstm_fwd(x, Kf, bf, Kb, bb, consumer=_take_hint(Kf.shape[1] // 2), amax=ctx.amax)
+        out, G, cst = ops.blstm_fwd(x, Kf, bf, Kb, bb, amax=ctx.amax)
         if x.is_cuda:
             ops.tag_amax(out, ops.amax_one(out.device))          # |tanh(c) sigmoid(o)| < 1
         ctx.last_capped = bool(last_capped)
@@ -199,13 +161,12 @@ class BLSTMLayer(Function):
                     ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart, amax=am_w)
                 return None, None, None, None, None, None
             with torch.cuda.stream(s):
-                x3 = {} if X3_SIDE else None             # products beside the ring from pre-split images (csrc/gemm_x3.hip)
                 OVERLAP.cap(True, 'lstm')
-                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart, x3_side=x3, amax=am_w)
+                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart, amax=am_w)
                 # the LAST capped product of the backward pass (recurrent-kernel gradient of the layer above the first one) ends
                 # after the BPTT it hides behind: 2 workgroups per CU there (+0.6 %)
                 OVERLAP.cap(True, 'lstm_last' if ctx.last_capped else 'lstm')
-                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u', x3_side=x3, amax=am_w)
+                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u', amax=am_w)
                 OVERLAP.cap(False)
             if dx is None and need_dx:
                 dx = ops.blstm_bwd_dx(G, Kf, Kb, B, T, D, amax=am_dx)
@@ -251,7 +212,7 @@ class Dense(Function):
         ctx.save_for_backward(x, W)
         ctx.bias = b
         aw = ops.param_amax(W) if ops.F16X3 and x.is_cuda else None
-        ctx.amax = (ops.amax_of(x), aw) if aw is not None else None         # fp16x3 products (ops.set_amax)
+        ctx.amax = (ops.amax_of(x), aw) if aw is not None else None         # fp16x3 products (amax_a / amax_b of the product entry points)
         return ops.dense_fwd(x, W, b, amax=ctx.amax)
 
     @staticmethod
@@ -262,28 +223,19 @@ class Dense(Function):
         b = ctx.bias
         am_dx = am_dw = None
         if ctx.amax is not None:
-            adu = ops.amax_of(du)                                # the loss kernel that wrote dU left its bound (ops.dpcl_loss_bwd_u)
+            adu = ops.amax_of(du2)                               # the loss kernel that wrote dU left its bound (ops.dpcl_loss_bwd_u)
             am_dx, am_dw = (adu, ctx.amax[1]), (ctx.amax[0], adu)
         if OVERLAP.usable(W, b) and ctx.needs_input_grad[1] and ctx.needs_input_grad[2]:
             dx = None
-            x3 = X3_SIDE and _DENSE_MODE == 0 and W.grad.is_contiguous()
             if _DENSE_MODE == 0 and _ORDER >= 1 and ctx.needs_input_grad[0]:
                 dx = ops.gemm(du2, W, transB=True, amax=am_dx).view(x.shape)
             s = OVERLAP.fork(x2, du2)
             with torch.cuda.stream(s):
                 OVERLAP.cap(_DENSE_MODE == 0)
-                if x3:
-                    # beside the top layer's BPTT ring: pre-split images, two accumulator sets (csrc/gemm_x3.hip); db = colsum(dU)
-                    # comes out of the pass that splits dU.  (Writing the images on the side stream WHILE dX runs was measured too:
-                    # the HBM-bound split beside the MFMA-bound dX took 213 instead of 97 us and slowed dX by 40 us -- 16.1 k.)
-                    ops.gemm_x3(ops.x3_split(x2), 1, ops.x3_split_colsum(du2, b.grad, True), 1, W.shape[0], W.shape[1], x2.shape[0],
-                                out=W.grad, accumulate=True)
-                    fused = True
-                else:
-                    # dW = x^T dU and db = colsum(dU) from ONE pass over dU (210 MB at the benchmark shape)
-                    fused = ops.gemm_at_b_colsum(x2, du2, W.grad, b.grad, accumulate=True, amax=am_dw)
-                    if not fused:
-                        ops.gemm(x2, du2, transA=True, out=W.grad, accumulate=True, amax=am_dw)
+                # dW = x^T dU and db = colsum(dU) from ONE pass over dU (210 MB at the benchmark shape)
+                fused = ops.gemm_at_b_colsum(x2, du2, W.grad, b.grad, accumulate=True, amax=am_dw)
+                if not fused:
+                    ops.gemm(x2, du2, transA=True, out=W.grad, accumulate=True, amax=am_dw)
                 OVERLAP.cap(False)
                 if not fused:
                     ops.colsum_into(du2, b.grad, True)

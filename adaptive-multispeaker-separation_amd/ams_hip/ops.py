@@ -147,7 +147,9 @@ def front_conv(x, f, hop):
     nb = lib.ams_front_conv_fwd_workspace_bytes(Bt, L, W, N, hop)
     ws = _ws(nb, x) if nb else None
     ev = PROFILE.begin() if PROFILE.enabled else None
-    check(lib.ams_front_conv_fwd(_p(x), _p(f), _p(y), Bt, L, W, N, hop, _p(ws), nb, _s()), 'ams_front_conv_fwd')
+    cnt = _counters(x) if nb else None
+    check(lib.ams_front_conv_fwd(_p(x), _p(f), _p(y), Bt, L, W, N, hop, _p(ws), nb, _p(cnt), (N_COUNTERS if cnt is not None else 0), _s()),
+          'ams_front_conv_fwd')
     if ev is not None:      # algorithmic bytes: waveform in, frames out, filter once
         PROFILE.end(ev, 2.0 * Bt * T * N * W, 4.0 * (Bt * L + Bt * T * N + W * N), 'gemm<2,0>', 'front_conv')
     return y
@@ -161,11 +163,13 @@ def front_conv_bwd_filter(x, dy, W, hop):
     nb = lib.ams_front_conv_bwd_filter_workspace_bytes(Bt, L, W, N, hop)
     ws = _ws(nb, x)
     df = torch.empty((W, N), dtype=torch.float32, device=x.device)
-    check(lib.ams_front_conv_bwd_filter(_p(x), _p(dy), _p(df), Bt, L, W, N, hop, _p(ws), nb, _s()), 'ams_front_conv_bwd_filter')
+    cnt = _counters(x) if nb else None
+    check(lib.ams_front_conv_bwd_filter(_p(x), _p(dy), _p(df), Bt, L, W, N, hop, _p(ws), nb, _p(cnt), (N_COUNTERS if cnt is not None else 0),
+                                        _s()), 'ams_front_conv_bwd_filter')
     return df
 
 
-# ------------------------------------------------------------------ operand bounds of the fp16x3 products (include/ams.h: ams_gemm_set_amax)
+# ------------------------------------------------------------------ operand bounds of the fp16x3 products (include/ams.h: amax_a / amax_b)
 F16X3 = _os.environ.get('AMS_GEMM_F16X3', '1') != '0'           # 0: nobody computes or passes bounds; every product stays bf16x6
 _ONE = {}
 
@@ -191,7 +195,7 @@ def amax_one(device):
 def tag_amax(t, a):
     """Producers that know a bound of their output attach it; consumers find it with amax_of()."""
     if F16X3 and a is not None:
-        t._ams_amax = a
+        t._ams_amax = (a, t._version)                            # the tag dies with the first in-place write (autograd accumulation)
     return t
 
 
@@ -202,8 +206,8 @@ def amax_of(t):
     b = t
     while b is not None:                                         # a view of a tagged tensor is bounded by the tag of its base
         a = getattr(b, '_ams_amax', None)
-        if a is not None:
-            return a
+        if a is not None and a[1] == b._version:
+            return a[0]
         b = b._base
     return absmax(t)
 
@@ -415,7 +419,7 @@ def register_param_source(variables, flat):
 
 
 def _bounds(amax):
-    """(pointer of A's bound, pointer of B's bound, profile tag prefix) for the *_bounded product entry points: fp16x3 ('gemm16')
+    """(pointer of A's bound, pointer of B's bound, profile tag prefix) for the product entry points: fp16x3 ('gemm16')
     when both bounds are there, else NULLs = bf16x6 / native f32 ('gemm')."""
     if F16X3 and amax is not None and amax[0] is not None and amax[1] is not None:
         cur = torch.cuda.current_stream()
@@ -425,13 +429,38 @@ def _bounds(amax):
     return _vp(0), _vp(0), 'gemm'
 
 
-def set_amax(a, b):
-    """Bounds for the NEXT product launch of this thread (one-shot, include/ams.h: ams_gemm_set_amax) -- for the entry points that
-    have no *_bounded form (ams_front_maxpool_fwd).  Returns the profile tag prefix of the arithmetic asked for."""
-    pa, pb, tag = _bounds((a, b))
-    if tag == 'gemm16':
-        load().ams_gemm_set_amax(pa, pb)
-    return tag
+# Residency cap of the products launched next (functional.OVERLAP.cap): a launch ATTRIBUTE handed to every product entry point as
+# its `lds_pad` argument (include/ams.h) -- Python-side state of the overlap scheduler, nothing behind the C ABI.
+LDS_PAD = [0]
+
+
+class lds_pad(object):
+    """with ops.lds_pad(50000): ...  -- the products inside are launched residency-capped (beside a recurrence ring)."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __enter__(self):
+        self.old, LDS_PAD[0] = LDS_PAD[0], self.n
+
+    def __exit__(self, *exc):
+        LDS_PAD[0] = self.old
+
+
+# Arrival counters of the in-launch split-K reduce (include/ams.h: `counters`): zero on entry, left zero by the kernel.  Launches on
+# ONE stream are serialised, so they share one block; launches on streams that may run concurrently (main / side) get their own.
+_COUNTERS = {}
+N_COUNTERS = 16384
+
+
+def _counters(like):
+    key = (like.device.index, torch.cuda.current_stream().cuda_stream)
+    c = _COUNTERS.get(key)
+    if c is None:
+        if torch.cuda.is_current_stream_capturing():
+            return None         # a block allocated during capture would live in the graph's private pool: this launch takes the two-pass form
+        c = _COUNTERS[key] = torch.zeros(N_COUNTERS, dtype=torch.int32, device=like.device)
+    return c
 
 
 
@@ -463,35 +492,41 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False
     for t_ in (A, B, out, bias):
         if t_ is not None and (t_.dtype != torch.float32 or not t_.is_cuda):
             raise AmsError('gemm: operands must be fp32 device tensors')
-    nb = lib.ams_gemm_workspace_bytes(M, N, K)
+    pad = LDS_PAD[0]
+    nb = lib.ams_gemm_workspace_bytes(M, N, K, 1, pad)
     ws = _ws(nb, A) if nb else None
+    cnt = _counters(A) if nb else None
     ev = PROFILE.begin() if PROFILE.enabled else None
     pa, pb, gt = _bounds(amax)
-    check(lib.ams_gemm_f32_bounded(int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc, _p(bias), int(accumulate),
-                                   mask[0], mask[1], pa, pb, _p(ws), nb, _s()), 'ams_gemm_f32')
+    check(lib.ams_gemm_f32(int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc, _p(bias), int(accumulate),
+                           mask[0], mask[1], pa, pb, pad, _p(ws), nb, _p(cnt), (N_COUNTERS if cnt is not None else 0), _s()), 'ams_gemm_f32')
     if ev is not None:
         PROFILE.end(ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N), gt + '<%d,%d>' % (int(bool(transA)), int(bool(transB))), label)
     return out
 
 
-def gemm_at_b_colsum(A, B, out, bsum, accumulate=True, amax=None):
+def gemm_at_b_colsum(A, B, out, bsum, accumulate=True, amax=None, ldc=None):
     """out[M,N] (+)= A^T B and bsum[N] (+)= column sums of B in ONE pass over B (A [K,M], B [K,N] row-major).  Returns False when
     the shapes / alignments do not allow the fused form (the caller then uses gemm + colsum)."""
     K, M = A.shape
     N = B.shape[1]
+    ldc = out.stride(0) if ldc is None else ldc
     ok = (M % 4 == 0 and N % 4 == 0 and A.stride(0) % 4 == 0 and B.stride(0) % 4 == 0 and A.stride(1) == 1 and B.stride(1) == 1
-          and out.stride(-1) == 1 and bsum.is_contiguous()
+          and out.stride(-1) == 1 and bsum.stride(-1) == 1 and bsum.data_ptr() % 16 == 0
           and all(t.data_ptr() % 16 == 0 for t in (A, B)) and _os.environ.get('AMS_GEMM_NOVEC') is None)
     if not ok:
         return False
     lib = load()
-    nb = lib.ams_gemm_workspace_bytes(M, N, K)
+    pad = LDS_PAD[0]
+    nb = lib.ams_gemm_workspace_bytes(M, N, K, 1, pad)
     ws = _ws(nb, A) if nb else None
+    cnt = _counters(A) if nb else None
     bws = _ws(32 * N * 4, A)
     ev = PROFILE.begin() if PROFILE.enabled else None
     pa, pb, gt = _bounds(amax)
-    check(lib.ams_gemm_f32_at_b_colsum_bounded(M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(out), out.stride(0), int(accumulate),
-                                               _p(bsum), int(accumulate), _p(bws), pa, pb, _p(ws), nb, _s()), 'ams_gemm_f32_at_b_colsum')
+    check(lib.ams_gemm_f32_at_b_colsum(M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(out), ldc, int(accumulate),
+                                       _p(bsum), int(accumulate), _p(bws), pa, pb, pad, _p(ws), nb, _p(cnt), (N_COUNTERS if cnt is not None else 0), _s()),
+          'ams_gemm_f32_at_b_colsum')
     if ev is not None:
         PROFILE.end(ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N), gt + '<1,0>', '')
     return True
@@ -499,106 +534,32 @@ def gemm_at_b_colsum(A, B, out, bsum, accumulate=True, amax=None):
 
 def gemm_batched2(A0, A1, B0, B1, C0, C1, transA, transB, M, N, K, lda, ldb, ldc, accumulate=False, mask=(0, 0), amax=None):
     """Two products of one shape in ONE launch (operand pairs given as tensors/views; offsets taken from their addresses)."""
-    lib = load()
     for t_ in (A0, A1, B0, B1, C0, C1):
         if t_.dtype != torch.float32 or not t_.is_cuda:
             raise AmsError('gemm_batched2: operands must be fp32 device tensors')
     da, db_, dc = (A1.data_ptr() - A0.data_ptr()), (B1.data_ptr() - B0.data_ptr()), (C1.data_ptr() - C0.data_ptr())
     if da % 4 or db_ % 4 or dc % 4:
         raise AmsError('gemm_batched2: operand offsets must be whole floats')
-    nb = lib.ams_gemm_batched_workspace_bytes(M, N, K, 2)
-    ws = _ws(nb, A0) if nb else None
-    ev = PROFILE.begin() if PROFILE.enabled else None
-    pa, pb, gt = _bounds(amax)
-    check(lib.ams_gemm_f32_batched_bounded(int(transA), int(transB), M, N, K, _p(A0), lda, da // 4, _p(B0), ldb, db_ // 4, _p(C0), ldc,
-                                           dc // 4, 2, int(accumulate), mask[0], mask[1], pa, pb, _p(ws), nb, _s()), 'ams_gemm_f32_batched')
-    if ev is not None:
-        PROFILE.end(ev, 2 * 2.0 * M * N * K, 2 * 4.0 * (M * K + K * N + M * N), gt + '<%d,%d>' % (int(bool(transA)), int(bool(transB))))
+    gemm_batched(A0, B0, C0, 2, da // 4, db_ // 4, dc // 4, transA, transB, M, N, K, lda, ldb, ldc, accumulate, amax, mask)
 
 
-def gemm_batched(A, B, C, nbatch, a_zs, b_zs, c_zs, transA, transB, M, N, K, lda, ldb, ldc, accumulate=False, amax=None):
+def gemm_batched(A, B, C, nbatch, a_zs, b_zs, c_zs, transA, transB, M, N, K, lda, ldb, ldc, accumulate=False, amax=None, mask=(0, 0)):
     """nbatch products of one shape in ONE launch: batch z reads A + z*a_zs, B + z*b_zs and writes C + z*c_zs (element strides)."""
     lib = load()
     for t_ in (A, B, C):
         if t_.dtype != torch.float32 or not t_.is_cuda:
             raise AmsError('gemm_batched: operands must be fp32 device tensors')
-    nb = lib.ams_gemm_batched_workspace_bytes(M, N, K, nbatch)
+    pad = LDS_PAD[0]
+    nb = lib.ams_gemm_workspace_bytes(M, N, K, nbatch, pad)
     ws = _ws(nb, A) if nb else None
+    cnt = _counters(A) if nb else None
     ev = PROFILE.begin() if PROFILE.enabled else None
     pa, pb, gt = _bounds(amax)
-    check(lib.ams_gemm_f32_batched_bounded(int(transA), int(transB), M, N, K, _p(A), lda, a_zs, _p(B), ldb, b_zs, _p(C), ldc, c_zs, nbatch,
-                                           int(accumulate), 0, 0, pa, pb, _p(ws), nb, _s()), 'ams_gemm_f32_batched')
+    check(lib.ams_gemm_f32_batched(int(transA), int(transB), M, N, K, _p(A), lda, a_zs, _p(B), ldb, b_zs, _p(C), ldc, c_zs, nbatch,
+                                   int(accumulate), mask[0], mask[1], pa, pb, pad, _p(ws), nb, _p(cnt), (N_COUNTERS if cnt is not None else 0), _s()),
+          'ams_gemm_f32_batched')
     if ev is not None:
         PROFILE.end(ev, nbatch * 2.0 * M * N * K, nbatch * 4.0 * (M * K + K * N + M * N), gt + '<%d,%d>' % (int(bool(transA)), int(bool(transB))))
-
-
-# ------------------------------------------------------------------ products from pre-split operands (csrc/gemm_x3.hip)
-class X3(object):
-    """x3 image of a logical row-major f32 matrix [R, C]: each element split exactly into three bf16 terms, stored in the layout the
-    MFMA fragments are read from (include/ams.h).  `buf` is a uint8 device tensor of ams_x3_image_bytes(R, C)."""
-    __slots__ = ('buf', 'R', 'C')
-
-    def __init__(self, R, C, device, buf=None):
-        self.R, self.C = int(R), int(C)
-        nb = load().ams_x3_image_bytes(self.R, self.C)
-        self.buf = buf if buf is not None else torch.empty(nb, dtype=torch.uint8, device=device)
-        if self.buf.numel() < nb:
-            raise AmsError('x3 image buffer too small')
-
-
-def x3_split(X, out=None, R=None, C=None, ld=None):
-    """x3 image of a 2-D fp32 tensor (rows may be strided by ld floats)."""
-    if R is None:
-        _chk_rows(X)
-        R, C = X.shape
-        ld = X.stride(0)
-    img = out if out is not None else X3(R, C, X.device)
-    if img.R != R or img.C != C:
-        raise AmsError('x3_split: image is [%d, %d], source is [%d, %d]' % (img.R, img.C, R, C))
-    check(load().ams_x3_split(_p(X), ld, R, C, _p(img.buf), _s()), 'ams_x3_split')
-    return img
-
-
-def x3_split_colsum(X, csum, accumulate=True):
-    """x3 image of X [R, C] and csum[C] (+)= column sums of X, one pass over X."""
-    _chk_rows(X)
-    _chk(csum)
-    R, C = X.shape
-    img = X3(R, C, X.device)
-    lib = load()
-    nb = lib.ams_x3_split_colsum_workspace_bytes(R, C)
-    ws = _ws(nb, X)
-    check(lib.ams_x3_split_colsum(_p(X), X.stride(0), R, C, _p(img.buf), _p(csum), int(bool(accumulate)), _p(ws), nb, _s()),
-          'ams_x3_split_colsum')
-    return img
-
-
-def x3_split_shifted(out2, T, H, out=None):
-    """Shifted image of a BLSTM layer output [B*T, 2H] for the recurrent-kernel gradients (include/ams.h)."""
-    _chk(out2)
-    BT = out2.shape[0]
-    Hp = (H + 7) // 8 * 8
-    img = out if out is not None else X3(BT, 2 * Hp, out2.device)
-    check(load().ams_x3_split_shifted(_p(out2), out2.stride(0), BT, T, H, _p(img.buf), _s()), 'ams_x3_split_shifted')
-    return img
-
-
-def gemm_x3(A, roleA, B, roleB, M, N, K, out=None, ldc=None, bias=None, accumulate=False, a_off=(0, 0), b_off=(0, 0), nbatch=1,
-            a_m_zs=0, b_n_zs=0, c_zs=0, label=''):
-    """out[M, N] (+)= op(A) op(B) (+ bias) from x3 images.  role 0: k along the image's columns, 1: k along its rows."""
-    lib = load()
-    if out is None:
-        out = torch.empty((M, N), dtype=torch.float32, device=A.buf.device)
-    if ldc is None:
-        ldc = out.stride(0) if out.dim() == 2 else N
-    nb = lib.ams_gemm_x3_workspace_bytes(M, N, K, nbatch)
-    ws = _ws(nb, out) if nb else None
-    ev = PROFILE.begin() if PROFILE.enabled else None
-    check(lib.ams_gemm_x3(int(roleA), int(roleB), M, N, K, _p(A.buf), A.R, A.C, a_off[0], a_off[1], _p(B.buf), B.R, B.C, b_off[0], b_off[1],
-                          _p(out), ldc, c_zs, _p(bias), int(accumulate), nbatch, a_m_zs, b_n_zs, _p(ws), nb, _s()), 'ams_gemm_x3')
-    if ev is not None:
-        PROFILE.end(ev, nbatch * 2.0 * M * N * K, nbatch * (6.0 * (M * K + K * N) + 4.0 * M * N), 'gemm<%d,%d>' % (int(roleA), 1 - int(roleB)), label)
-    return out
 
 
 # ------------------------------------------------------------------ masks
@@ -614,14 +575,9 @@ def make_masks(rep_non_mix, B, S, a, b, take_abs, want_argmax=False):
 
 # ------------------------------------------------------------------ BLSTM
 import os as _os
-LSTM_PERSIST = _os.environ.get('AMS_LSTM_PERSIST', '0') != '0'     # persistent in-launch recurrence (csrc/lstm_persist.hip)
 # chain-per-XCD ring recurrence (csrc/lstm_ring.hip), the default: 1 = on, 0 = per-step kernels, 'safe' = on with the
 # placement-independent (write-through) hand-off forced
 LSTM_RING = _os.environ.get('AMS_LSTM_RING', '1')
-# 1 = the forward ring computes the layer's own input projection with four extra waves per workgroup (ams_blstm_ring_fwd_proj).
-# Parity-tested, measured SLOWER than the separate product, so off by default.
-LSTM_RING_PROJ = _os.environ.get('AMS_LSTM_RING_PROJ', '0') != '0'
-LAST_SYNC = []                                                      # most recent sync buffers of the PERSISTENT-kernel form (word 0 = timeout flag)
 _RING_ERR = {}                                                      # device index -> int32[1]: the sticky error word of every ring launch
 
 
@@ -648,33 +604,26 @@ def ring_errors_clear():
 
 
 def persist_errors():
-    """Number of recent recurrence launches whose bounded in-launch wait timed out (host sync): the ring launches through their
-    sticky word, the persistent-kernel form through its per-launch sync buffers."""
-    return sum(int(t[:1].view(torch.int32).item() != 0) for t in LAST_SYNC) + int(ring_error_pending())
+    """Number of devices whose sticky ring error word is raised (host sync)."""
+    return int(ring_error_pending())
 
 
 def raise_on_ring_errors():
     """Fail loudly when a ring-recurrence launch gave up a bounded in-launch wait (csrc/lstm_ring.hip: its workgroups must all be
     resident at once; a co-running kernel that fills every CU's registers can keep some of them out past the wait limit).  The
-    step that launch belonged to is invalid.  One host sync.  The trainer does not call this any more: it REPEATS such a step on
-    the per-step kernels (utils/trainer.py::Trainer._guarded); benches and tests do, where a repeat would hide what they measure."""
-    bad = ring_error_pending()
-    if LAST_SYNC:
-        flags = torch.stack([t[:1].view(torch.int32).reshape(()) for t in LAST_SYNC])
-        bad = bad or bool((flags != 0).any().item())
-    if bad:
+    step that launch belonged to is invalid.  One host sync.  The trainer does not call this: it REPEATS such a step on
+    the per-step kernels (utils/trainer.py::Trainer.train); benches and tests do, where a repeat would hide what they measure."""
+    if ring_error_pending():
         ring_errors_clear()
         raise AmsError('a BLSTM ring recurrence launch abandoned a bounded wait: its workgroups were not all resident in time '
                        '(another kernel filled the CUs); the results of that step are invalid.  AMS_LSTM_RING=0 selects the '
                        'per-step recurrence kernels, which need no co-residency.')
 
 
-def blstm_fwd(x, Kf, bf, Kb, bb, consumer=None, amax=None):
+def blstm_fwd(x, Kf, bf, Kb, bb, amax=None):
     """One BLSTM layer (utils/ops.py:358-383).  x [B,T,D]; K* [D+H,4H]; b* [4H].
     Returns out [B,T,2H] and the tensors the backward needs (G = activated gates, cst = cell states).
-    consumer: optional (kind, W [2H, Dout] row-major view, bias [Dout]) of the row-wise product that will read `out` next
-    (the next layer's input projection or the dense layer) -- see the TAIL_* note below.
-    amax: (bound of x, bound of the kernels) -> the input projection runs as fp16x3."""
+    amax: (bound of x, bound of the kernels) -> the input projection and the ring's recurrent product run as fp16x3."""
     _chk(x, bf, bb)
     _chk_rows(Kf, Kb)
     lib = load()
@@ -693,220 +642,31 @@ def blstm_fwd(x, Kf, bf, Kb, bb, consumer=None, amax=None):
             Kf._ams_wcat_amax = c = (PASS[0], absmax(Wcat, out=c[1] if c is not None else None))
         amax = (amax_of(x), c[1])
     bias = torch.as_strided(bf, (8 * H,), (1,)) if _twin(bf, bb) else torch.cat([bf, bb])
-    pre = _take_precomputed(x, Wcat, 8 * H)
-    if pre is not None:
-        G = pre['Y'].view(B, T, 2, 4 * H)
-    else:
-        G = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=x.device)
+    G = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=x.device)
     # hoisted input projection of BOTH directions as ONE MFMA GEMM [B*T, D] x [D, 8H]: the two [D,4H] halves of the TF
     # kernels are gathered side by side (a 2 x D x 4H copy) so N = 8H gives 19 x 40 = 760 tiles = 2.97 per CU instead of
     # two launches of 400 (1.56 per CU, i.e. 22 % of the CU-time idle).
-    ring = LSTM_RING != '0' and not LSTM_PERSIST
-    nring = lib.ams_blstm_ring_sync_bytes(B, H, 0) if ring else 0
+    nring = lib.ams_blstm_ring_sync_bytes(B, H, 0) if LSTM_RING != '0' else 0
     out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
     # ring recurrence: plane 0 = c_t (what every backward reads as `cst`), plane 1 = tanh(c_t) for the backward ring
     cst = torch.empty(((2, B, T, 2, H) if nring else (B, T, 2, H)), dtype=torch.float32, device=x.device)
-    pack = torch.empty(lib.ams_blstm_pack_floats(H, 0), dtype=torch.float32, device=x.device)
-    if (nring and LSTM_RING_PROJ and pre is None and lib.ams_blstm_ring_proj_ok(B, H, D) and x.is_contiguous() and x.data_ptr() % 16 == 0
-            and bf.is_contiguous() and bb.is_contiguous()):
-        sync, pre0 = _ring_sync(nring, x)
-        ev = PROFILE.begin() if PROFILE.enabled else None
-        check(lib.ams_blstm_ring_fwd_proj(_p(x), D, _p(Kf), _p(Kb), ldu, _p(bf), _p(bb), _p(G), _p(out), _p(cst[0]), _p(cst[1]),
-                                          _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring, _p(ring_error_word(x.device)), B, T, H,
-                                          int(LSTM_RING == 'safe') | pre0, _s()),
-              'ams_blstm_ring_fwd_proj')
-        if ev is not None:      # the projection's flops, attributed to the ring launch that now contains them
-            PROFILE.end(ev, 2 * 2.0 * B * T * 4 * H * (D + H), 4.0 * (B * T * (D + 8 * H + 2 * H)), 'ring_fwd_proj', 'blstm_input_gemm_in_ring')
-        return out, G, cst
-    bands = _fwd_bands(T) if not (LSTM_PERSIST or nring or pre is not None or consumer is not None) else None
-    if bands:
-        _blstm_fwd_banded(lib, x2, Wcat, bias, G, out, cst, pack, Kf[D:], Kb[D:], ldu, B, T, D, H, bands)
-        return out, G, cst
-    if pre is not None:
-        _finish_precomputed(lib, pre, x2, Wcat, 8 * H, bias, B, T, D, 'blstm_input_gemm')
-    else:
-        gemm(x2, Wcat, bias=bias, out=G, M=B * T, N=8 * H, K=D, lda=D, ldb=8 * H, ldc=8 * H, label='blstm_input_gemm', amax=amax)
-    cuts = _tail_cuts(consumer[0], T) if (consumer is not None and not LSTM_PERSIST and not nring) else None
-    if cuts:
-        check(lib.ams_blstm_pack(_p(Kf[D:]), _p(Kb[D:]), ldu, _p(pack), H, 0, _s()), 'ams_blstm_pack')
-        _fwd_steps_feeding(lib, G, out, cst, pack, B, T, H, consumer, cuts)
-        return out, G, cst
+    gemm(x2, Wcat, bias=bias, out=G, M=B * T, N=8 * H, K=D, lda=D, ldb=8 * H, ldc=8 * H, label='blstm_input_gemm', amax=amax)
     if nring:
         sync, pre0 = _ring_sync(nring, x)
-        if u_amax is not None and F16X3:
-            lib.ams_blstm_ring_set_amax(_p(u_amax))              # one-shot: the recurrent product of this launch runs as fp16x3
-        check(lib.ams_blstm_ring_fwd(_p(G), _p(out), _p(cst[0]), _p(cst[1]), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring,
-                                     _p(ring_error_word(x.device)), B, T, H, int(LSTM_RING == 'safe') | pre0, _s()), 'ams_blstm_ring_fwd')
+        check(lib.ams_blstm_ring_fwd(_p(G), _p(out), _p(cst[0]), _p(cst[1]), _p(Kf[D:]), _p(Kb[D:]), ldu,
+                                     _p(u_amax if F16X3 else None), _p(sync), nring, _p(ring_error_word(x.device)), B, T, H,
+                                     int(LSTM_RING == 'safe') | pre0, _s()), 'ams_blstm_ring_fwd')
         return out, G, cst
-    nsync = lib.ams_blstm_persist_sync_bytes(B, H, 0) if LSTM_PERSIST else 0
-    if nsync:
-        sync = _ws(nsync, x)
-        check(lib.ams_blstm_persist_fwd(_p(G), _p(out), _p(cst), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(pack), _p(sync), nsync, B, T, H, _s()),
-              'ams_blstm_persist_fwd')
-        LAST_SYNC.append(sync)
-        del LAST_SYNC[:-8]
-    else:
-        check(lib.ams_blstm_recurrent_fwd(_p(G), _p(out), _p(cst), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(pack), B, T, H, _s()),
-              'ams_blstm_recurrent_fwd')
+    pack = torch.empty(lib.ams_blstm_pack_floats(H, 0), dtype=torch.float32, device=x.device)
+    check(lib.ams_blstm_recurrent_fwd(_p(G), _p(out), _p(cst), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(pack), B, T, H, _s()),
+          'ams_blstm_recurrent_fwd')
     return out, G, cst
 
 
-# Time-banded input projection: the recurrence of a layer is a chain of T dependent launches that leaves ~100 CUs idle, and
-# step s only needs the projected rows of time s (forward direction) / T-1-s (backward direction).  So only the first band of
-# steps is projected before the recurrence starts; the remaining bands run on a side stream (residency-capped, like the
-# weight-gradient products of the backward pass) while the recurrence works through the earlier ones, each band guarded by an
-# event.  AMS_FWD_BANDS = comma-separated step boundaries (e.g. "8,26,52"); default "0" = one product up front: measured
-# 9.38-9.54 k vs 9.59 k mixtures/s -- the first band is a latency-bound 50-70 us launch whatever its size, and the side bands
-# slow ~70 steps by 0.7 us each.  Kept as a tuning aid; the cross-layer form below (TAIL_*) is the one that pays.
-FWD_BANDS = _os.environ.get('AMS_FWD_BANDS', '0')
-_BAND_STREAM = []
-
-
-def _fwd_bands(T):
-    if FWD_BANDS in ('', '0'):
-        return None
-    cuts = sorted(set(int(v) for v in FWD_BANDS.split(',') if 0 < int(v) < T))
-    if not cuts or T < 16:
-        return None
-    edges = [0] + cuts + [T]
-    return list(zip(edges[:-1], edges[1:]))
-
-
-def _band_gemm(lib, x2, Wcat, bias, G, B, T, D, H, s0, s1):
-    """Project steps [s0, s1) of both directions: rows (b, s0..s1) for z = 0 and (b, T-s1..T-s0) for z = 1."""
-    n = s1 - s0
-    M = B * n
-    nb = lib.ams_gemm_batched_workspace_bytes(M, 4 * H, D, 2)
-    ws = _ws(nb, x2) if nb else None
-    ev = PROFILE.begin() if PROFILE.enabled else None
-    check(lib.ams_gemm_f32_rowseg(M, 4 * H, D, _p(x2), D, _p(Wcat), 8 * H, 4 * H, _p(G), 8 * H, 4 * H, _p(bias), 4 * H,
-                                  n, T, s0, T - s1 - s0, 2, _p(ws), nb, _s()), 'ams_gemm_f32_rowseg')
-    if ev is not None:
-        PROFILE.end(ev, 2 * 2.0 * M * 4 * H * D, 2 * 4.0 * (M * D + D * 4 * H + M * 4 * H), 'gemm<0,0>', 'blstm_input_gemm')
-
-
-def _blstm_fwd_banded(lib, x2, Wcat, bias, G, out, cst, pack, Uf, Ub, ldu, B, T, D, H, bands):
-    main = torch.cuda.current_stream()
-    if not _BAND_STREAM:
-        _BAND_STREAM.append(torch.cuda.Stream())
-    side = _BAND_STREAM[0]
-    side.wait_stream(main)                               # x is ready
-    for t_ in (x2, Wcat, bias, G):
-        t_.record_stream(side)
-    events = []
-    with torch.cuda.stream(side):
-        lib.ams_gemm_set_lds_pad(int(_os.environ.get('AMS_BAND_LDS_PAD', '70000')))
-        for s0, s1 in bands[1:]:
-            _band_gemm(lib, x2, Wcat, bias, G, B, T, D, H, s0, s1)
-            events.append(side.record_event())
-        lib.ams_gemm_set_lds_pad(0)
-    _band_gemm(lib, x2, Wcat, bias, G, B, T, D, H, bands[0][0], bands[0][1])
-    check(lib.ams_blstm_pack(_p(Uf), _p(Ub), ldu, _p(pack), H, 0, _s()), 'ams_blstm_pack')
-    for i, (s0, s1) in enumerate(bands):
-        if i > 0:
-            main.wait_event(events[i - 1])
-        check(lib.ams_blstm_recurrent_fwd_steps(_p(G), _p(out), _p(cst), _p(pack), B, T, H, s0, s1, _s()),
-              'ams_blstm_recurrent_fwd_steps')
-
-
-# Cross-layer tail overlap.  Row (b, t) of a BLSTM layer's output is complete once BOTH directions have passed time t, i.e.
-# after s recurrence steps the rows with T-s <= t < s are final -- the middle of the sequence first, the two ends last.  Whatever
-# reads `out` row by row next (the next layer's input projection [2H -> 8H], or the dense layer [2H -> F*E]) can therefore start
-# on those rows while the recurrence is still working through its last steps with ~100 CUs idle: at each cut the host records
-# an event behind the step launches and a side stream runs the consumer product for the newly completed rows (row-segmented
-# GEMM, residency-capped like the weight-gradient products).  The consumer later finds the partly filled result, computes only
-# the two end bands and joins the side stream.  (The reference runs each layer's while_loop to completion first,
-# utils/ops.py:358-383, then the next matmul.)
-# MEASURED, default OFF ("0"; e.g. AMS_TAIL_CUTS_PROJ=48,64 AMS_TAIL_CUTS_DENSE=48 turns it on): 9.33-9.43 k (projections) /
-# 9.58-9.60 k (dense only) vs 9.60 k mixtures/s without.  A 128x128x8-tile GEMM needs ~3+ workgroups per CU to cover its fetch
-# latency, so the 40 % end-band product takes 66 % of the full product's time, its split-K reduce another 45 us, the steps
-# that share CUs with a band run 0.7-1.7 us slower, and a stream join inside a replayed hipGraph showed up as a 40-55 us
-# bubble on the main chain.  Kept as a tuning aid for other shapes (longer T, larger B).
-TAIL_CUTS = {'proj': _os.environ.get('AMS_TAIL_CUTS_PROJ', '0'), 'dense': _os.environ.get('AMS_TAIL_CUTS_DENSE', '0')}
-TAIL_PAD = {'proj': int(_os.environ.get('AMS_TAIL_PAD_PROJ', '70000')), 'dense': int(_os.environ.get('AMS_TAIL_PAD_DENSE', '40000'))}
-_TAIL_READY = {}
-
-
-def _tail_cuts(kind, T):
-    spec = TAIL_CUTS.get(kind, '0')
-    if spec in ('', '0') or T < 16:
-        return None
-    ref_T = 80                                        # cuts are quoted for the benchmark's 80 steps and scaled to T
-    cuts = sorted(set(int(round(int(v) * T / float(ref_T))) for v in spec.split(',')))
-    cuts = [c for c in cuts if T - c < c < T]
-    return cuts or None
-
-
-def _rows_gemm(lib, x2, W, ldw, Dout, bias, Y, B, T, K, segs, label):
-    """Y[(b,t), :] = x2[(b,t), :] . W + bias for t in the given equal-length segment(s) [(t0, t1)] or [(t0, t1), (u0, u1)]."""
-    n = segs[0][1] - segs[0][0]
-    nz = len(segs)
-    M = B * n
-    nb = lib.ams_gemm_batched_workspace_bytes(M, Dout, K, nz)
-    ws = _ws(nb, x2) if nb else None
-    ev = PROFILE.begin() if PROFILE.enabled else None
-    check(lib.ams_gemm_f32_rowseg(M, Dout, K, _p(x2), K, _p(W), ldw, 0, _p(Y), Dout, 0, _p(bias), 0, n, T, segs[0][0],
-                                  (segs[1][0] - segs[0][0]) if nz > 1 else 0, nz, _p(ws), nb, _s()), 'ams_gemm_f32_rowseg')
-    if ev is not None:
-        PROFILE.end(ev, nz * 2.0 * M * Dout * K, nz * 4.0 * (M * K + K * Dout + M * Dout), 'gemm<0,0>', label)
-
-
-def _fwd_steps_feeding(lib, G, out, cst, pack, B, T, H, consumer, cuts):
-    kind, W, bias = consumer
-    Dout = W.shape[1]
-    Y = torch.empty((B, T, Dout), dtype=torch.float32, device=out.device)
-    out2 = out.view(B * T, 2 * H)
-    main = torch.cuda.current_stream()
-    if not _BAND_STREAM:
-        _BAND_STREAM.append(torch.cuda.Stream())
-    side = _BAND_STREAM[0]
-    for t_ in (out, W, bias, Y):
-        t_.record_stream(side)
-    lo = hi = None
-    s_prev = 0
-    for s in cuts:
-        check(lib.ams_blstm_recurrent_fwd_steps(_p(G), _p(out), _p(cst), _p(pack), B, T, H, s_prev, s, _s()),
-              'ams_blstm_recurrent_fwd_steps')
-        side.wait_event(main.record_event())
-        with torch.cuda.stream(side):
-            lib.ams_gemm_set_lds_pad(TAIL_PAD[kind])
-            segs = [(T - s, s)] if lo is None else [(T - s, lo), (hi, s)]
-            _rows_gemm(lib, out2, W, W.stride(0), Dout, bias, Y, B, T, 2 * H, segs, 'tail_' + kind)
-            lib.ams_gemm_set_lds_pad(0)
-        lo, hi, s_prev = T - s, s, s
-    check(lib.ams_blstm_recurrent_fwd_steps(_p(G), _p(out), _p(cst), _p(pack), B, T, H, s_prev, T, _s()),
-          'ams_blstm_recurrent_fwd_steps')
-    _TAIL_READY.clear()
-    _TAIL_READY[out.data_ptr()] = {'Y': Y, 'lo': lo, 'hi': hi, 'event': side.record_event(), 'W': W.data_ptr(), 'Dout': Dout,
-                            'shape': (B, T, 2 * H)}
-
-
-def _take_precomputed(x, W, Dout):
-    e = _TAIL_READY.pop(x.data_ptr(), None) if _TAIL_READY else None
-    if e is None:
-        return None
-    if e['W'] != W.data_ptr() or e['Dout'] != Dout or tuple(x.shape) != e['shape']:
-        torch.cuda.current_stream().wait_event(e['event'])     # not ours: drop the partial result, but stay ordered behind it
-        return None
-    return e
-
-
-def _finish_precomputed(lib, e, x2, W, Dout, bias, B, T, K, label):
-    """The two end bands [0, lo) and [hi, T) on the current stream, then join the side stream that filled the middle."""
-    _rows_gemm(lib, x2, W, W.stride(0), Dout, bias, e['Y'], B, T, K, [(0, e['lo']), (e['hi'], T)], label)
-    torch.cuda.current_stream().wait_event(e['event'])
-
-
 def dense_fwd(x, W, b, amax=None):
-    """u = x.W + b over the last axis (utils/ops.py:486-503), picking up rows a preceding blstm_fwd(consumer=...) already
-    produced."""
+    """u = x.W + b over the last axis (utils/ops.py:486-503)."""
     x2 = x.reshape(-1, x.shape[-1])
-    e = _take_precomputed(x, W, W.shape[1]) if x.dim() == 3 else None
-    if e is None:
-        return gemm(x2, W, bias=b, amax=amax).view(x.shape[:-1] + (W.shape[1],))
-    B, T, K = x.shape
-    _finish_precomputed(load(), e, x2, W, W.shape[1], b, B, T, K, 'dense')
-    return e['Y']
+    return gemm(x2, W, bias=b, amax=amax).view(x.shape[:-1] + (W.shape[1],))
 
 
 def blstm_wcat(Kf, Kb, D):
@@ -932,7 +692,7 @@ def blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout):
     H = Kf.shape[1] // 4
     ldu = Kf.stride(0)
     # cst with a leading plane axis = written by the forward ring (plane 1 = tanh(c_t)); a 4-D cst came from the step kernels
-    nring = lib.ams_blstm_ring_sync_bytes(B, H, 1) if (LSTM_RING != '0' and not LSTM_PERSIST and cst.dim() == 5) else 0
+    nring = lib.ams_blstm_ring_sync_bytes(B, H, 1) if (LSTM_RING != '0' and cst.dim() == 5) else 0
     if nring:
         sync, pre0 = _ring_sync(nring, x)
         dbpart = torch.empty((B, 2, 4 * H), dtype=torch.float32, device=x.device)
@@ -941,17 +701,9 @@ def blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout):
         tag_amax(G, sync.view(-1)[2:3])                          # max |dZ| came out of the same launch (float word 2 of the sync head)
         return dbpart
     pack = torch.empty(lib.ams_blstm_pack_floats(H, 1), dtype=torch.float32, device=x.device)
-    nsync = lib.ams_blstm_persist_sync_bytes(B, H, 1) if LSTM_PERSIST else 0
-    if nsync:
-        sync = _ws(nsync, x)
-        check(lib.ams_blstm_persist_bwd(_p(G), _p(cst), _p(dout), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(pack), _p(sync), nsync, B, T, H, _s()),
-              'ams_blstm_persist_bwd')
-        LAST_SYNC.append(sync)
-        del LAST_SYNC[:-8]
-    else:
-        dc = torch.empty((B, 2, H), dtype=torch.float32, device=x.device)
-        check(lib.ams_blstm_recurrent_bwd(_p(G), _p(cst), _p(dout), _p(dc), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(pack), B, T, H, _s()),
-              'ams_blstm_recurrent_bwd')
+    dc = torch.empty((B, 2, H), dtype=torch.float32, device=x.device)
+    check(lib.ams_blstm_recurrent_bwd(_p(G), _p(cst), _p(dout), _p(dc), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(pack), B, T, H, _s()),
+          'ams_blstm_recurrent_bwd')
 
 
 # ---- DropoutWrapper(cell, keep, keep, keep) around each direction (utils/ops.py:363,373,379; --recurrent_dropout != 0, training)
@@ -1038,7 +790,7 @@ def blstm_bwd_dx(G, Kf, Kb, B, T, D, amax=None):
     return dx
 
 
-def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate, part='all', dbpart=None, x3_side=None, amax=None):
+def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate, part='all', dbpart=None, amax=None):
     """Weight gradients of one BLSTM layer from dZ (= G after blstm_bwd_recurrent), written (or accumulated) into the given
     buffers: dWx = x^T dZ, dU = h_prev^T dZ (time-shifted, masked at sequence boundaries), db = column sums.
     part: 'all' | 'wx' (input kernels + biases) | 'u' (recurrent kernels) -- the two halves are independent and may be
@@ -1054,28 +806,18 @@ def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate, part='all', dbp
     dZb = G.view(-1)[4 * H:]
     acc = bool(accumulate)
     _chk_rows(dKf, dKb)
-    if x3_side is not None and _twin(dKf, dKb) and dKf.stride(0) == 8 * H and M > 1:
-        # residency-capped launch beside a recurrence ring: products from pre-split images (csrc/gemm_x3.hip) -- no split arithmetic
-        # on the CUs the ring shares, and the second accumulator set in every configuration (tests/test_gpu_gemm_x3.py).
-        # x3_side: dict cache for this layer's dZ image (shared by the 'wx' and 'u' halves).
-        zi = x3_side.get('dZ')
-        if zi is None:
-            zi = x3_side['dZ'] = x3_split(G.view(M, 8 * H))
-        if part in ('all', 'wx'):
-            xi = x3_split(x2)
-            gemm_x3(xi, 1, zi, 1, D, 8 * H, M, out=torch.as_strided(dKf, (D, 8 * H), (8 * H, 1)), ldc=8 * H, accumulate=acc)
-        if part in ('all', 'u'):
-            hs = x3_split_shifted(out.view(M, 2 * H), T, H)
-            Hp = (H + 7) // 8 * 8
-            # dU_fw = h[t-1, :H]^T dZ[:, :4H] -> dKf[D:], dU_bw = h[t+1, H:]^T dZ[:, 4H:] -> dKb[D:]  (one batched launch)
-            gemm_x3(hs, 1, zi, 1, H, 4 * H, M, out=dKf[D:], ldc=8 * H, accumulate=acc, nbatch=2, a_m_zs=Hp, b_n_zs=4 * H,
-                    c_zs=(dKb.data_ptr() - dKf.data_ptr()) // 4)
-        part = {'all': 'bias', 'wx': 'bias', 'u': 'none'}[part]
     if part in ('all', 'wx'):
         if _twin(dKf, dKb):
-            # twin-interleaved gradient block: [dWx_f | dWx_b] IS a row-major [D, 8H] matrix -> written in place
-            gemm(x2, dZf, transA=True, M=D, N=8 * H, K=M, lda=D, ldb=8 * H, ldc=8 * H, accumulate=acc,
-                 out=torch.as_strided(dKf, (D, 8 * H), (8 * H, 1)), amax=am_wx)
+            # twin-interleaved gradient block: [dWx_f | dWx_b] IS a row-major [D, 8H] matrix -> written in place; when the two bias
+            # gradients are adjacent too, db = column sums of dZ come out of the SAME pass over dZ (the product's tile_m == 0
+            # workgroups add up the rows they stage anyway, finished inside the launch): no column-sum launches at all
+            dWcat = torch.as_strided(dKf, (D, 8 * H), (8 * H, 1))
+            fused = (_twin(dbf, dbb) and x2.is_cuda and
+                     gemm_at_b_colsum(x2, G.view(M, 8 * H), dWcat, torch.as_strided(dbf, (8 * H,), (1,)), accumulate=acc, amax=am_wx, ldc=8 * H))
+            if fused:
+                part = {'all': 'u', 'wx': 'none'}[part]
+            else:
+                gemm(x2, dZf, transA=True, M=D, N=8 * H, K=M, lda=D, ldb=8 * H, ldc=8 * H, accumulate=acc, out=dWcat, amax=am_wx)
         else:
             dWcat = gemm(x2, dZf, transA=True, M=D, N=8 * H, K=M, lda=D, ldb=8 * H, ldc=8 * H,
                          out=torch.empty((D, 8 * H), dtype=torch.float32, device=x.device))

@@ -26,8 +26,8 @@ def front_maxpool_fwd(x, f, P, hop):
     # 2 TFLOP of brute-force stride-1 conv: worth two small passes for the operand bounds that let it run as fp16x3
     bounds = (ops.absmax(x), ops.absmax(f)) if ops.F16X3 else None
     ev = ops.PROFILE.begin() if ops.PROFILE.enabled else None
-    gt = ops.set_amax(*bounds) if bounds is not None else 'gemm'
-    check(lib.ams_front_maxpool_fwd(_p(x), _p(f), _p(y), _p(am), Bt, L, W, N, P, hop, _p(ws), nb, _s()), 'ams_front_maxpool_fwd')
+    pa, pb, gt = ops._bounds(bounds)
+    check(lib.ams_front_maxpool_fwd(_p(x), _p(f), _p(y), _p(am), Bt, L, W, N, P, hop, pa, pb, _p(ws), nb, _s()), 'ams_front_maxpool_fwd')
     if ev is not None:
         ops.PROFILE.end(ev, 2.0 * Bt * L * N * W, 4.0 * (Bt * L + W * N + Bt * T * N), gt)
     return y, am
@@ -149,7 +149,9 @@ class FramesConv(Function):
         nb = lib.ams_frames_matmul_bwd_filter_workspace_bytes(R, Wg, N, T)
         ws = ops._ws(nb, x)
         dB = torch.empty((Wg, N), dtype=torch.float32, device=x.device)
-        check(lib.ams_frames_matmul_bwd_filter(_p(x), _p(dy), _p(dB), R, L, Wg, N, hop, T, pl, _p(ws), nb, _s()), 'ams_frames_matmul_bwd_filter')
+        cnt = ops._counters(x) if nb else None
+        check(lib.ams_frames_matmul_bwd_filter(_p(x), _p(dy), _p(dB), R, L, Wg, N, hop, T, pl, _p(ws), nb, _p(cnt),
+                                               (ops.N_COUNTERS if cnt is not None else 0), _s()), 'ams_frames_matmul_bwd_filter')
         return None, dB, None, None, None
 
 
@@ -181,8 +183,9 @@ class SynthFrames(Function):
             nb = lib.ams_frames_matmul_bwd_filter_workspace_bytes(R, Wg, N, T)
             ws = ops._ws(nb, z)
             dB = torch.empty((Wg, N), dtype=torch.float32, device=z.device)
-            check(lib.ams_frames_matmul_bwd_filter(_p(dout), _p(z), _p(dB), R, L, Wg, N, hop, T, pl, _p(ws), nb, _s()),
-                  'ams_frames_matmul_bwd_filter')
+            cnt = ops._counters(z) if nb else None
+            check(lib.ams_frames_matmul_bwd_filter(_p(dout), _p(z), _p(dB), R, L, Wg, N, hop, T, pl, _p(ws), nb, _p(cnt),
+                                                   (ops.N_COUNTERS if cnt is not None else 0), _s()), 'ams_frames_matmul_bwd_filter')
         return dz, dB, None, None, None
 
 

@@ -922,7 +922,7 @@ ams_status ams_dpcl_loss_bwd(const float* V, const float* Y, const float* inv, c
 }
 
 // byte offset, inside the ams_dpcl_loss_fwd_u workspace, of max |dU| (as a float): cleared by the forward, filled by ams_dpcl_loss_bwd_u --
-// the operand bound ams_gemm_set_amax wants for the two dense-layer products that read dU
+// the operand bound of the two dense-layer products that read dU
 size_t ams_dpcl_u_amax_offset(int B, long TF, int E, int S) {
     const int NT = ceil_div(E + S, 16), Z = NT * 16;
     const int nchunk = ceil_div(TF, UCHUNK);

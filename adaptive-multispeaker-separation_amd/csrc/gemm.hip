@@ -22,16 +22,15 @@
 
 namespace {
 
-thread_local int t_gemm_lds_pad = 0;
-// one-shot: operand bounds for the NEXT product launched from this thread (ams_gemm_set_amax); consumed and cleared by launch()
-thread_local const float* t_amax_a = nullptr;
-thread_local const float* t_amax_b = nullptr;
-// every product entry point holds one of these: the one-shot bounds never outlive the call they were set for, whichever way it returns
-struct AmaxOneShot { ~AmaxOneShot() { t_amax_a = nullptr; t_amax_b = nullptr; } };
+// per-launch options of the product entry points (arguments of the C ABI, no state survives a call):
+//   amax_a / amax_b: device pointers to upper bounds of max|A|, max|B| (both set -> fp16x3 arithmetic)
+//   lds_pad: residency cap of a launch that is meant to run BESIDE a latency-critical kernel (unused dynamic LDS limits how many
+//            of these workgroups a CU admits); 0 = uncapped, critical-path launch
+struct LaunchOpt { const float* amax_a = nullptr; const float* amax_b = nullptr; int lds_pad = 0; };
 std::atomic<int> g_gemm_arith{-1};        // -1: not chosen yet (AMS_GEMM_X6, default 1), 0: native f32 MFMA, 1: bf16x6
 
 // Tuning overrides (A/B runs only): read from the environment ONCE per process, never on the launch path.
-struct GemmTuning { int group_m, splits, x6cfg, x6rule, x6persist; bool noprio, novec, f16x3; double x6waste; };
+struct GemmTuning { int group_m, splits, x6cfg, x6rule, x6persist; bool noprio, novec, f16x3, inred; double x6waste; };
 inline const GemmTuning& tuning() {
     static const GemmTuning t = [] {
         GemmTuning v{0, 0, -1, 2, false, false};
@@ -42,6 +41,7 @@ inline const GemmTuning& tuning() {
         v.noprio = getenv("AMS_GEMM_NOPRIO") != nullptr;
         { const char* e = getenv("AMS_X6_PERSIST"); v.x6persist = e ? atoi(e) : 1; }
         { const char* e = getenv("AMS_GEMM_F16X3"); v.f16x3 = !(e && atoi(e) == 0); }
+        { const char* e = getenv("AMS_GEMM_INRED"); v.inred = !(e && atoi(e) == 0); }      // 0: split-K always as two passes (A/B runs)
         v.novec = getenv("AMS_GEMM_NOVEC") != nullptr;
         if (const char* f = getenv("AMS_GEMM_X6CFG")) v.x6cfg = atoi(f);       // force one bf16x6 tile configuration (0, 1 or 3: X6Cfg)
         if (const char* f = getenv("AMS_GEMM_X6RULE")) v.x6rule = atoi(f);
@@ -108,27 +108,27 @@ struct GemmArgs {
     int32_t* pidx;             // EPI_MAXPOOL: per (row-tile, column) arg-max row
     // batch (grid.z): element offsets added per batch index to A, B, C (any sign); partial slabs are z-major
     long a_zs, b_zs, c_zs;
-    // row segments (A_ROW only): logical row m of A and C lives at row (m / seg_len) * seg_stride + seg_off + m % seg_len;
-    // seg_len 0 = identity.  Batch index z shifts seg_off by z * seg_off_zs and bias by z * bias_zs.
-    int seg_len;
-    long seg_stride, seg_off, seg_off_zs, bias_zs;
+    long bias_zs;              // batch index z shifts bias by z * bias_zs
     int hiprio;                // 1: launch is on the critical path (not residency-capped) -> waves raise their issue priority
     // column sums of B (B_ROW, VEC path): the tile_m == 0 workgroups add up the B rows they stage anyway and write one partial
     // row per split to bsum_part [splits, N]; a finishing kernel adds the splits into bsum_out (bias gradient = colsum(dY))
     float* bsum_part;
+    // split-K reduced INSIDE the producing launch (16-bit-pipe kernels): `counters` = one arrival counter per (batch, output tile),
+    // zero on entry and zero again on completion; the slabs of `partial` are then in FRAGMENT order (x6_body).  NULL = the two-pass
+    // form (row-major slabs + splitk_reduce_*_kernel).  bsum_out / bsum_accumulate: where the column sums of B end up when the
+    // launch finishes them itself (splits == 1, or the last-arriving workgroup of a column tile)
+    unsigned* counters;
+    float* bsum_out; int bsum_accumulate;
+    int zb;                    // batch index of the current item (set by locate_tile)
     // fp16x3 arithmetic: device pointers to an upper bound of max|A|, max|B| over the WHOLE operand tensors (all batches); the kernel
     // derives the power-of-two operand scales from them
     const float* amax_a; const float* amax_b;
 };
 
-__device__ __forceinline__ long rowmap(const GemmArgs& g, int m) {
-    return g.seg_len ? (long)(m / g.seg_len) * g.seg_stride + g.seg_off + (m % g.seg_len) : (long)m;
-}
-
 template <int AMODE>
 __device__ __forceinline__ float loadA1(const GemmArgs& g, int m, int k) {
     if (m >= g.M || k >= g.K) return 0.f;
-    if (AMODE == A_ROW) return g.A[rowmap(g, m) * g.lda + k];
+    if (AMODE == A_ROW) return g.A[(long)m * g.lda + k];
     if (AMODE == A_COL) {
         if (g.mask_period && (k % g.mask_period) == g.mask_skip) return 0.f;
         return g.A[(long)k * g.lda + m];
@@ -167,11 +167,13 @@ __device__ __forceinline__ void locate_tile(GemmArgs& g, int& split, int& tile_m
         item -= zb * (ntiles * g.splits);
         split = item / ntiles;
         bid = item - split * ntiles;
+        g.zb = zb;
 #else
         zb = item / (ntiles * g.splits);                       // round-1 order: per-(z, split) plane, tiles dealt by x % 8
         item -= zb * (ntiles * g.splits);
         split = item / ntiles;
         bid = item - split * ntiles;
+        g.zb = zb;
         const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 #endif
@@ -179,9 +181,8 @@ __device__ __forceinline__ void locate_tile(GemmArgs& g, int& split, int& tile_m
     if (g.nbatch > 1) {                             // batched launch: same shape, shifted operands
         const long z = zb;
         g.A += z * g.a_zs; g.B += z * g.b_zs; g.C += z * g.c_zs;
-        g.seg_off += z * g.seg_off_zs;
         if (g.bias) g.bias += z * g.bias_zs;
-        if (g.partial) g.partial += z * (long)g.splits * g.M * g.N;
+        if (g.partial && !g.counters) g.partial += z * (long)g.splits * g.M * g.N;
     }
     const int GROUP_M = g.group_m > 0 ? g.group_m : 1;        // chosen per launch (choose_group_m)
     const int band = bid / (GROUP_M * tiles_n), within = bid - band * (GROUP_M * tiles_n);
@@ -208,7 +209,7 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16 (&acc
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                 if (row < g.M) {
                     float v = acc[i][j][r] + bv;
-                    float* p = out + ((g.splits == 1 && g.seg_len) ? rowmap(g, row) : (long)row) * ldo + col;
+                    float* p = out + (long)row * ldo + col;
                     if (g.splits == 1 && g.accumulate) v += *p;
                     *p = v;
                 }
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
     float4 ra[NLD], rb[NLD], ra2[NLD], rb2[NLD];
     long arow[NLD];                                 // A_ROW: element offset of this thread's operand row(s), mapped once
 #pragma unroll
-    for (int h = 0; h < NLD; ++h) arow[h] = (AMODE == A_ROW) ? rowmap(g, min(m0 + (tid + h * 256) / KQ, g.M - 1)) * g.lda : 0;
+    for (int h = 0; h < NLD; ++h) arow[h] = (AMODE == A_ROW) ? (long)min(m0 + (tid + h * 256) / KQ, g.M - 1) * g.lda : 0;
     int fp0[NLD];                                   // A_FRAMES (VEC): first sample of this thread's frame, relative to its row
     if (AMODE == A_FRAMES) {
 #pragma unroll
@@ -592,6 +593,18 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
 // 232c519).  The kernel draws the board's power limit (1385-1393 W at 2135 MHz; its MFMA-only stream 1050 W at 2400 MHz) and gains
 // 0-4 % with the split arithmetic compiled out: at that limit its run time is the energy of a product, not its instruction schedule
 // (DESIGN.md 4.0).
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+// Raw buffer accesses with aux bit 16 = sc1: stores write through to the memory side, loads bypass this CU's L1 -- the publish form of
+// MI355X_MICROARCH.md ("publish-large" / "splitk-seam": sc1 payload -> s_waitcnt vmcnt(0) -> agent-scope arrival, sc1 loads on the reader)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t x6_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 ld16_sc1(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
+}
+__device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t rs, unsigned off, float4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), rs, off, 0, 16);
+}
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -715,7 +728,7 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
         nk = (k_end - k_begin + BK - 1) / BK;
         if (AMODE == A_ROW) {
 #pragma unroll
-            for (int h = 0; h < NSA; ++h) arow[h] = rowmap(g, min(m0 + krow + (NT / 4) * h, g.M - 1)) * g.lda;
+            for (int h = 0; h < NSA; ++h) arow[h] = (long)min(m0 + krow + (NT / 4) * h, g.M - 1) * g.lda;
         }
         if (AMODE == A_FRAMES) {
 #pragma unroll
@@ -943,6 +956,14 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
             __syncthreads();
         }
 
+        // Split-K reduced in THIS launch (g.counters): every workgroup of an output tile leaves its accumulators in its slab, in FRAGMENT
+        // order (lane l's float4 q of MFMA tile (i, j) of wave w at ((w TM TN + i TN + j) 4 + q) * 1 KB + 16 l: 64 lanes store 1 KB
+        // contiguous, write-through), counts itself in, and the LAST one to arrive adds the slabs 0 .. splits-1 in index order -- the
+        // order of the two-pass reduce kernel, so the sums are bit-identical to it and do not depend on who arrives last -- and runs the
+        // normal epilogue (bias, accumulate).  No second launch, no row-major slab re-read by another grid.
+        const bool inred = g.splits > 1 && g.counters != nullptr;
+        const int tile_lin = (g.nbatch > 1 ? g.zb : 0) * (((g0.M + BMX - 1) / BMX) * ((g0.N + BNX - 1) / BNX)) + tile_m * ((g0.N + BNX - 1) / BNX) + tile_n;
+        float4 bs_t = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!BKc && do_bsum) {
             // thread (kb, mb) summed rows 4 kb .. 4 kb + 3 of every k-tile, columns 4 mb .. + 3: the 8 threads of a column group meet
             // in LDS in a fixed order (deterministic)
@@ -954,8 +975,12 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
                 float4 t = sbuf[tid];
 #pragma unroll
                 for (int j = 1; j < 8; ++j) { const float4 v = sbuf[tid + (BNX / 4) * j]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+                bs_t = t;
                 const int n = n0 + tid * 4;
-                if (n < g.N) *reinterpret_cast<float4*>(g.bsum_part + (long)split * g.N + n) = t;
+                if (n < g.N && g.splits > 1) {
+                    if (inred) st16_sc1(x6_rsrc(g.bsum_part, (unsigned)((size_t)g.splits * g.N * 4)), (unsigned)(((long)split * g.N + n) * 4), t);
+                    else *reinterpret_cast<float4*>(g.bsum_part + (long)split * g.N + n) = t;
+                }
             }
         }
         if (SEP) {
@@ -976,11 +1001,71 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
             maxpool_epilogue(g, acc, reinterpret_cast<float*>(smem), tile_m, m0, n0, wm, wn, l31, lk);
             return;                                     // (launched with one workgroup per item)
         }
+        bool fin = g.splits == 1;                       // this workgroup writes C (and the column sums) of its tile
+        if (inred) {
+            constexpr unsigned TILE_B = (unsigned)BMX * BNX * 4;
+            const __amdgpu_buffer_rsrc_t rs = x6_rsrc(g0.partial + (long)tile_lin * g.splits * (BMX * BNX), (unsigned)g.splits * TILE_B);
+            const unsigned loff = (unsigned)(wave * TM * TN * 4) * 1024u + (unsigned)lane * 16u;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        st16_sc1(rs, (unsigned)split * TILE_B + loff + (unsigned)((i * TN + j) * 4 + q) * 1024u,
+                                 make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]));
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the write-through stores have left before the arrival is counted
+            __syncthreads();                                            // (and every wave is done with the LDS images)
+            int* const s_last = reinterpret_cast<int*>(smem);
+            if (tid == 0) {
+                unsigned* const cnt = g0.counters + tile_lin;
+                const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int last = old == (unsigned)g.splits - 1u;
+                if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next launch
+                *s_last = last;
+            }
+            __syncthreads();
+            fin = *s_last != 0;
+            if (fin) {
+                for (int k = 0; k < g.splits; ++k) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) {              // TN x 4 16-byte loads in flight per lane
+                        float4 v[TN][4];
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) v[j][q] = ld16_sc1(rs, (unsigned)k * TILE_B + loff + (unsigned)((i * TN + j) * 4 + q) * 1024u);
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                if (k == 0) { acc[i][j][4 * q] = v[j][q].x; acc[i][j][4 * q + 1] = v[j][q].y; acc[i][j][4 * q + 2] = v[j][q].z; acc[i][j][4 * q + 3] = v[j][q].w; }
+                                else { acc[i][j][4 * q] += v[j][q].x; acc[i][j][4 * q + 1] += v[j][q].y; acc[i][j][4 * q + 2] += v[j][q].z; acc[i][j][4 * q + 3] += v[j][q].w; }
+                            }
+                    }
+                }
+                if (!BKc && do_bsum && tid < BNX / 4 && n0 + tid * 4 < g.N) {
+                    const __amdgpu_buffer_rsrc_t rb_ = x6_rsrc(g.bsum_part, (unsigned)((size_t)g.splits * g.N * 4));
+                    float4 t = ld16_sc1(rb_, (unsigned)((n0 + tid * 4) * 4));
+                    for (int k = 1; k < g.splits; ++k) {
+                        const float4 v = ld16_sc1(rb_, (unsigned)(((long)k * g.N + n0 + tid * 4) * 4));
+                        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
+                    }
+                    bs_t = t;
+                }
+            }
+            __syncthreads();                            // s_last is read: the LDS is free for the next item's images
+        }
+        if (!BKc && do_bsum && g.bsum_out && fin && tid < BNX / 4 && n0 + tid * 4 < g.N) {
+            float4* const po = reinterpret_cast<float4*>(g.bsum_out + n0 + tid * 4);
+            if (g.bsum_accumulate) { const float4 o = *po; bs_t.x += o.x; bs_t.y += o.y; bs_t.z += o.z; bs_t.w += o.w; }
+            *po = bs_t;
+        }
         // what the epilogue of THIS item needs, saved before the per-item state moves on
-        float* const out = g.splits > 1 ? g.partial + (long)split * g.M * g.N : g.C;
-        const long ldo = g.splits > 1 ? g.N : g.ldc;
+        const bool two_pass = g.splits > 1 && !inred;
+        float* const out = two_pass ? g.partial + (long)split * g.M * g.N : g.C;
+        const long ldo = two_pass ? g.N : g.ldc;
         const float* const ebias = g.bias;
-        const long eseg = g.seg_off;
         const int em0 = m0, en0 = n0;
         const int nxt = vbid + (int)gridDim.x;
         const bool more = PERSIST && nxt < n_items;
@@ -990,25 +1075,26 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
             fetch(0);                                   // the next item's first k-tile is in flight BEFORE this item's stores
         }
         // Epilogue.  C/D layout of a 32x32 MFMA (any input type): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+        if (fin || two_pass) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = en0 + (wn * TN + j) * 32 + l31;
                 if (col >= g.N) continue;
-                const float bv = (g.splits == 1 && ebias) ? ebias[col] : 0.f;
+                const float bv = (fin && ebias) ? ebias[col] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = em0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                     if (row < g.M) {
                         float v = acc[i][j][r] + bv;
-                        const long orow = (g.splits == 1 && g.seg_len) ? (long)(row / g.seg_len) * g.seg_stride + eseg + (row % g.seg_len) : (long)row;
-                        float* p = out + orow * ldo + col;
-                        if (g.splits == 1 && g.accumulate) v += *p;
+                        float* p = out + (long)row * ldo + col;
+                        if (fin && g.accumulate) v += *p;
                         *p = v;
                     }
                 }
             }
+        }
         if (!more) break;
         vbid = nxt;
     }
@@ -1021,25 +1107,23 @@ __global__ __launch_bounds__(X6Cfg<CFG>::WMC * X6Cfg<CFG>::WNC * 64, CFG == 0 ? 
 }
 
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ C, const float* __restrict__ bias,
-                                     int M, int N, long ldc, int splits, int accumulate, long c_zs, int seg_len, long seg_stride,
-                                     long seg_off, long seg_off_zs, long bias_zs) {
+                                     int M, int N, long ldc, int splits, int accumulate, long c_zs, long bias_zs) {
     const long total = (long)M * N;
     partial += (long)blockIdx.y * splits * total;
     C += (long)blockIdx.y * c_zs;
-    seg_off += (long)blockIdx.y * seg_off_zs;
     if (bias) bias += (long)blockIdx.y * bias_zs;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int m = (int)(i / N), n = (int)(i - (long)m * N);
         float s = 0.f;
         for (int k = 0; k < splits; ++k) s += partial[(long)k * total + i];
         if (bias) s += bias[n];
-        float* p = C + (seg_len ? (long)(m / seg_len) * seg_stride + seg_off + (m % seg_len) : (long)m) * ldc + n;
+        float* p = C + (long)m * ldc + n;
         if (accumulate) s += *p;
         *p = s;
     }
 }
 
-// 16-byte form of the same reduction (N, ldc multiples of 4, 16-byte aligned C / bias, no row segments, M*N < 2^31): one float4
+// 16-byte form of the same reduction (N, ldc multiples of 4, 16-byte aligned C / bias, M*N < 2^31): one float4
 // per thread and slab, 32-bit index arithmetic.  The scalar kernel above ran at 1.8 TB/s (55 us for the 3-slab dense weight
 // gradient); the slabs are summed in the same order, so the result is bit-identical.
 __global__ __launch_bounds__(256) void splitk_reduce_vec_kernel(const float* __restrict__ partial, float* __restrict__ C,
@@ -1123,8 +1207,20 @@ inline int choose_splits(int M, int N, int K, int nbatch, const TilePlan& tp) {
 }
 // what a workspace query assumes: the process-wide arithmetic (a launch whose operands are not 16-byte addressable falls back to
 // the f32 kernel and re-plans within the workspace it is given)
-inline int choose_splits(int M, int N, int K, int nbatch = 1) {
-    return choose_splits(M, N, K, nbatch, use_x6() ? x6_plan(x6_choose_cfg(M, N, t_gemm_lds_pad > 0)) : f32_plan());
+inline int choose_splits(int M, int N, int K, int nbatch, bool capped) {
+    return choose_splits(M, N, K, nbatch, use_x6() ? x6_plan(x6_choose_cfg(M, N, capped)) : f32_plan());
+}
+// bytes of `splits` partial slabs: row-major [M, N] slabs for the two-pass form, whole (padded) tiles in fragment order for the
+// in-launch reduce of the 16-bit-pipe kernels -- a workspace sized for the larger serves either
+inline size_t slab_bytes(int M, int N, int nbatch, int splits, bool capped) {
+    if (splits <= 1) return 0;
+    size_t b = (size_t)nbatch * splits * M * N * sizeof(float);
+    if (use_x6()) {
+        const int cfg = x6_choose_cfg(M, N, capped);
+        const size_t f = (size_t)nbatch * splits * ceil_div(M, x6_bm(cfg)) * ceil_div(N, x6_bn(cfg)) * x6_bm(cfg) * x6_bn(cfg) * sizeof(float);
+        if (f > b) b = f;
+    }
+    return b;
 }
 
 // Band height of the tile order: the patch of tiles one XCD works on at a time (its share of the grid, at most ~64 in
@@ -1141,32 +1237,48 @@ inline int choose_group_m(int tiles_m, int tiles_n) {
     return gm;
 }
 
+// raise a kernel's dynamic-LDS limit once per (kernel, size) and thread
+template <typename KernelT>
+inline void raise_dyn_lds(KernelT* kernel, int bytes) {
+    static thread_local int raised = 0;
+    if (raised < bytes) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        raised = bytes;
+    }
+}
+
+// counters / n_counters: arrival counters of the in-launch split-K reduce (zero on entry, left zero); NULL or too few = two-pass
+struct Counters { unsigned* p = nullptr; int n = 0; };
+
 template <int AMODE, int BMODE>
-ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nbatch = 1, float* bsum_out = nullptr,
-                  int bsum_accumulate = 0, float* bsum_ws = nullptr) {
+ams_status launch(GemmArgs& g, const LaunchOpt& opt, void* ws, size_t ws_bytes, Counters cnt, hipStream_t st, int nbatch = 1,
+                  float* bsum_out = nullptr, int bsum_accumulate = 0, float* bsum_ws = nullptr) {
     constexpr bool AKc = (AMODE == A_ROW), BKcc = (BMODE == B_COL);
+    const int lds_pad = opt.lds_pad < 0 ? 0 : opt.lds_pad;
+    const bool capped = lds_pad > 0;
     const bool vec_off = tuning().novec;
     const bool vec = g.a_vec && g.b_vec && !vec_off &&
                      (AMODE == A_FRAMES ? (g.K % 4 == 0 && g.fr_L >= 4) : AMODE == A_FRAMES_T ? (g.M % 4 == 0 && g.fr_L >= 4) :
                       AKc ? (g.K % 4 == 0 && g.K >= 4) : (g.M % 4 == 0 && g.M >= 4)) &&
                      (BKcc ? (g.K % 4 == 0 && g.K >= 4) : (g.N % 4 == 0 && g.N >= 4));
     const bool x6 = vec && use_x6();
-    const int cfg = x6 ? x6_choose_cfg(g.M, g.N, t_gemm_lds_pad > 0) : 0;
-    // fp16x3 when the caller supplied bounds for both operands (one-shot: consumed here whatever kernel ends up running)
-    const float* const amax_a = t_amax_a;
-    const float* const amax_b = t_amax_b;
-    t_amax_a = t_amax_b = nullptr;
-    const bool f16 = x6 && cfg != 1 && amax_a && amax_b && tuning().f16x3;
-    g.amax_a = f16 ? amax_a : nullptr;
-    g.amax_b = f16 ? amax_b : nullptr;
+    const int cfg = x6 ? x6_choose_cfg(g.M, g.N, capped) : 0;
+    // fp16x3 when the caller supplied bounds for both operands
+    const bool f16 = x6 && cfg != 1 && opt.amax_a && opt.amax_b && tuning().f16x3;
+    g.amax_a = f16 ? opt.amax_a : nullptr;
+    g.amax_b = f16 ? opt.amax_b : nullptr;
     const TilePlan tp = x6 ? x6_plan(cfg) : f32_plan();
     const int tiles = ceil_div(g.M, tp.bm) * ceil_div(g.N, tp.bn);
     g.group_m = choose_group_m(ceil_div(g.M, tp.bm), ceil_div(g.N, tp.bn));
+    // the in-launch reduce: 16-bit-pipe kernels, a counter per (batch, tile), column sums (if any) addressable as float4
+    const bool inred_ok = x6 && cnt.p != nullptr && (long)tiles * nbatch <= (long)cnt.n && tuning().inred &&
+                          (!bsum_out || (((uintptr_t)bsum_out | (uintptr_t)bsum_ws) & 15) == 0);
     int splits = 1;
     if (ws) {
         splits = choose_splits(g.M, g.N, g.K, nbatch, tp);
         if (tuning().splits > 0) splits = tuning().splits;
-        while (splits > 1 && (size_t)nbatch * splits * g.M * g.N * sizeof(float) > ws_bytes) --splits;
+        const size_t per = inred_ok ? (size_t)nbatch * tiles * tp.bm * tp.bn * sizeof(float) : (size_t)nbatch * g.M * g.N * sizeof(float);
+        while (splits > 1 && (size_t)splits * per > ws_bytes) --splits;
     }
     int kps = ceil_div(g.K, splits);
     kps = ceil_div(kps, tp.bk) * tp.bk;
@@ -1174,26 +1286,23 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
     g.splits = splits;
     g.k_per_split = kps;
     g.partial = (float*)ws;
+    const bool inred = inred_ok && splits > 1;
+    g.counters = inred ? cnt.p : nullptr;
     g.bsum_part = bsum_out ? bsum_ws : nullptr;
+    const bool bsum_in_launch = x6 && bsum_out && (splits == 1 || inred) && (((uintptr_t)bsum_out) & 15) == 0;
+    g.bsum_out = bsum_in_launch ? bsum_out : nullptr;
+    g.bsum_accumulate = bsum_accumulate;
     g.nbatch = nbatch;
     dim3 grid((unsigned)((long)tiles * splits * nbatch));
     const bool prio_off = tuning().noprio;
-    g.hiprio = (t_gemm_lds_pad == 0 && !prio_off) ? 1 : 0;
+    g.hiprio = (!capped && !prio_off) ? 1 : 0;
     // Occupancy cap for launches that are meant to run BESIDE latency-critical kernels (weight-gradient products on
     // the side stream): unused dynamic LDS limits how many of these workgroups a CU admits, leaving registers/slots
-    // for the recurrent step kernels.  Thread-local, set through ams_gemm_set_lds_pad().
-    if (t_gemm_lds_pad > 40 * 1024) {               // beyond the default 64 KB static+dynamic limit
-        static thread_local int raised = 0;
-        if (raised < t_gemm_lds_pad) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<AMODE, BMODE, 0>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, t_gemm_lds_pad);
-            raised = t_gemm_lds_pad;
-        }
-    }
+    // for the recurrence.  An explicit argument of the entry points (LaunchOpt::lds_pad).
     if (x6) {
         // persistent grid (x6_body, uncapped two-accumulator variants): one resident set of workgroups -- 256 CUs x (2 for the 4-wave configuration, 1 for the 8-wave
         // ones) x AMS_X6_PERSIST (default 1; 0 = one workgroup per item as before) -- walks the items.
-        if (tuning().x6persist > 0 && t_gemm_lds_pad == 0 && cfg != 1) {      // the variants launched with SEP = true below
+        if (tuning().x6persist > 0 && !capped && cfg != 1) {      // the variants launched with SEP = true below
             int ncu = 256;
             { static int cus = 0; if (!cus) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); if (cus <= 0) cus = 256; } ncu = cus; }
             const long cap = (long)((ncu + 7) / 8 * 8) * (cfg == 0 ? 2 : 1) * tuning().x6persist;
@@ -1203,52 +1312,41 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
         // what it asks of the 16.8 KB f32 kernel (workgroups per CU), restated.  The 8-wave configurations are alone on a CU anyway.
         if (cfg == 0) {
             int pad = 0;
-            if (t_gemm_lds_pad > 0) {
-                int wg = 163840 / (17152 + t_gemm_lds_pad);
+            if (capped) {
+                int wg = 163840 / (17152 + lds_pad);
                 if (wg < 1) wg = 1;
                 pad = 163840 / wg - x6_lds(0) - 1024;
                 if (pad < 0) pad = 0;
             }
             if (x6_lds(0) + pad > 64 * 1024) {
-                static thread_local int raised_x = 0;
-                if (raised_x < pad) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<AMODE, BMODE, 0>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, pad);
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_x6_kernel<AMODE, BMODE, 0, EPI_STORE, false, true>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, pad);
-                    raised_x = pad;
-                }
+                raise_dyn_lds(&gemm_x6_kernel<AMODE, BMODE, 0>, pad);
+                raise_dyn_lds(&gemm_x6_kernel<AMODE, BMODE, 0, EPI_STORE, false, true>, pad);
             }
             if (f16) {
-                if (t_gemm_lds_pad > 0) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 0, EPI_STORE, false, true>), grid, dim3(256), (size_t)pad, st, g);
+                if (capped) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 0, EPI_STORE, false, true>), grid, dim3(256), (size_t)pad, st, g);
                 else hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 0, EPI_STORE, true, true>), grid, dim3(256), 0, st, g);
-            } else if (t_gemm_lds_pad > 0) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 0>), grid, dim3(256), (size_t)pad, st, g);
+            } else if (capped) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 0>), grid, dim3(256), (size_t)pad, st, g);
             else hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 0, EPI_STORE, true>), grid, dim3(256), 0, st, g);
         } else if (cfg == 1) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 1>), grid, dim3(512), 0, st, g);
         else if (f16) {
-            if (t_gemm_lds_pad > 0) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 3, EPI_STORE, false, true>), grid, dim3(512), 0, st, g);
+            if (capped) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 3, EPI_STORE, false, true>), grid, dim3(512), 0, st, g);
             else hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 3, EPI_STORE, true, true>), grid, dim3(512), 0, st, g);
-        } else if (t_gemm_lds_pad > 0) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 3>), grid, dim3(512), 0, st, g);
+        } else if (capped) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 3>), grid, dim3(512), 0, st, g);
         else hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 3, EPI_STORE, true>), grid, dim3(512), 0, st, g);
     } else if (vec) {
-        if (t_gemm_lds_pad > 40 * 1024) {
-            static thread_local int raised_v = 0;
-            if (raised_v < t_gemm_lds_pad) {
-                (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_f32_kernel<AMODE, BMODE, 0, AMS_GEMM_BK, true, AMS_GEMM_PF>),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, t_gemm_lds_pad);
-                raised_v = t_gemm_lds_pad;
-            }
-        }
-        hipLaunchKernelGGL((gemm_f32_kernel<AMODE, BMODE, 0, AMS_GEMM_BK, true, AMS_GEMM_PF>), grid, dim3(256), (size_t)t_gemm_lds_pad, st, g);
-    } else
-    hipLaunchKernelGGL((gemm_f32_kernel<AMODE, BMODE>), grid, dim3(256), (size_t)t_gemm_lds_pad, st, g);
+        if (lds_pad > 40 * 1024) raise_dyn_lds(&gemm_f32_kernel<AMODE, BMODE, 0, AMS_GEMM_BK, true, AMS_GEMM_PF>, lds_pad);      // beyond the default 64 KB static + dynamic limit
+        hipLaunchKernelGGL((gemm_f32_kernel<AMODE, BMODE, 0, AMS_GEMM_BK, true, AMS_GEMM_PF>), grid, dim3(256), (size_t)lds_pad, st, g);
+    } else {
+        if (lds_pad > 40 * 1024) raise_dyn_lds(&gemm_f32_kernel<AMODE, BMODE, 0>, lds_pad);
+        hipLaunchKernelGGL((gemm_f32_kernel<AMODE, BMODE>), grid, dim3(256), (size_t)lds_pad, st, g);
+    }
     ams_status s = ams_check_launch();
     if (s != AMS_OK) return s;
-    if (splits > 1) {
+    if (splits > 1 && !inred) {
         const long total = (long)g.M * g.N;
-        const bool vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (g.c_zs % 4 == 0) && (g.bias_zs % 4 == 0) && !g.seg_len &&
-                         (((uintptr_t)g.C | (uintptr_t)g.partial | (uintptr_t)g.bias) & 15) == 0 && total < (1L << 31);
-        if (vec) {
+        const bool rvec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (g.c_zs % 4 == 0) && (g.bias_zs % 4 == 0) &&
+                          (((uintptr_t)g.C | (uintptr_t)g.partial | (uintptr_t)g.bias) & 15) == 0 && total < (1L << 31);
+        if (rvec) {
             int blocks = (int)((total / 4 + 255) / 256);
             if (blocks > 4096) blocks = 4096;
             hipLaunchKernelGGL(splitk_reduce_vec_kernel, dim3(blocks, nbatch), dim3(256), 0, st, g.partial, g.C, g.bias, g.M, g.N, g.ldc,
@@ -1257,11 +1355,11 @@ ams_status launch(GemmArgs& g, void* ws, size_t ws_bytes, hipStream_t st, int nb
             int blocks = (int)((total + 255) / 256);
             if (blocks > 2048) blocks = 2048;
             hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks, nbatch), dim3(256), 0, st, g.partial, g.C, g.bias, g.M, g.N, g.ldc,
-                               splits, g.accumulate, g.c_zs, g.seg_len, g.seg_stride, g.seg_off, g.seg_off_zs, g.bias_zs);
+                               splits, g.accumulate, g.c_zs, g.bias_zs);
         }
         s = ams_check_launch();
     }
-    if (s == AMS_OK && bsum_out) {
+    if (s == AMS_OK && bsum_out && !bsum_in_launch) {
         if (!vec || BMODE != B_ROW) return AMS_E_INVALID_ARG;          // only the 16-byte B_ROW fetch path accumulates the sums
         hipLaunchKernelGGL(bsum_finish_kernel, dim3(ceil_div(g.N, 256)), dim3(256), 0, st, bsum_ws, bsum_out, g.N, splits, bsum_accumulate);
         s = ams_check_launch();
@@ -1275,46 +1373,28 @@ inline bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
 extern "C" {
 
-void ams_gemm_set_lds_pad(int bytes) { t_gemm_lds_pad = bytes < 0 ? 0 : bytes; }
-void ams_gemm_set_amax(const float* amax_a, const float* amax_b) { t_amax_a = amax_a; t_amax_b = amax_b; }
-
-// the same products with the operand bounds as ARGUMENTS (no state survives the call)
-ams_status ams_gemm_f32_bounded(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
-                                float* C, long ldc, const float* bias, int accumulate, int mask_period, int mask_skip,
-                                const float* amax_a, const float* amax_b, void* ws, size_t ws_bytes, void* stream) {
-    t_amax_a = amax_a; t_amax_b = amax_b;
-    return ams_gemm_f32(transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, accumulate, mask_period, mask_skip, ws, ws_bytes, stream);
-}
-ams_status ams_gemm_f32_batched_bounded(int transA, int transB, int M, int N, int K, const float* A, long lda, long a_zs, const float* B,
-                                        long ldb, long b_zs, float* C, long ldc, long c_zs, int nbatch, int accumulate, int mask_period,
-                                        int mask_skip, const float* amax_a, const float* amax_b, void* ws, size_t ws_bytes, void* stream) {
-    t_amax_a = amax_a; t_amax_b = amax_b;
-    return ams_gemm_f32_batched(transA, transB, M, N, K, A, lda, a_zs, B, ldb, b_zs, C, ldc, c_zs, nbatch, accumulate, mask_period, mask_skip,
-                                ws, ws_bytes, stream);
-}
-ams_status ams_gemm_f32_at_b_colsum_bounded(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
-                                            int accumulate, float* bsum_out, int bsum_accumulate, float* bsum_ws, const float* amax_a,
-                                            const float* amax_b, void* ws, size_t ws_bytes, void* stream) {
-    t_amax_a = amax_a; t_amax_b = amax_b;
-    return ams_gemm_f32_at_b_colsum(M, N, K, A, lda, B, ldb, C, ldc, accumulate, bsum_out, bsum_accumulate, bsum_ws, ws, ws_bytes, stream);
-}
 void ams_gemm_set_arith(int mode) { g_gemm_arith.store(mode ? 1 : 0, std::memory_order_relaxed); }
 int ams_gemm_get_arith(void) { return use_x6() ? 1 : 0; }
 
-size_t ams_gemm_workspace_bytes(int M, int N, int K) {
-    if (M <= 0 || N <= 0 || K <= 0) return 0;
-    int splits = choose_splits(M, N, K);
+size_t ams_gemm_workspace_bytes(int M, int N, int K, int nbatch, int lds_pad) {
+    if (M <= 0 || N <= 0 || K <= 0 || nbatch <= 0) return 0;
+    int splits = choose_splits(M, N, K, nbatch, lds_pad > 0);
     if (tuning().splits > 0) splits = tuning().splits;
-    if (splits <= 1) return 0;
-    return (size_t)splits * M * N * sizeof(float);
+    return slab_bytes(M, N, nbatch, splits, lds_pad > 0);
+}
+
+// arrival counters the in-launch reduce of such a product would use: one per (batch, output tile) of the SMALLEST tile configuration
+int ams_gemm_counter_count(int M, int N, int nbatch) {
+    if (M <= 0 || N <= 0 || nbatch <= 0) return 0;
+    return ceil_div(M, 128) * ceil_div(N, 128) * nbatch;
 }
 
 // C (+)= A^T . B  AND  bsum_out[N] (+)= column sums of B, in one pass over B (reference: the weight and bias gradients of a
 // width-1 Conv1D, utils/ops.py:501-503 under tf.gradients).  bsum_ws: 32 * N floats (one row per possible split).
 ams_status ams_gemm_f32_at_b_colsum(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
-                                    int accumulate, float* bsum_out, int bsum_accumulate, float* bsum_ws, void* ws, size_t ws_bytes,
+                                    int accumulate, float* bsum_out, int bsum_accumulate, float* bsum_ws, const float* amax_a,
+                                    const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* counters, int n_counters,
                                     void* stream) {
-    AmaxOneShot amax_scope;
     AMS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C && bsum_out && bsum_ws);
     GemmArgs g{};
     g.A = A; g.B = B; g.C = C;
@@ -1323,13 +1403,13 @@ ams_status ams_gemm_f32_at_b_colsum(int M, int N, int K, const float* A, long ld
     g.a_vec = aligned16(A) && (lda % 4 == 0);
     g.b_vec = aligned16(B) && (ldb % 4 == 0);
     AMS_REQUIRE(g.a_vec && g.b_vec && M % 4 == 0 && N % 4 == 0 && aligned16(bsum_ws) && !tuning().novec);
-    return launch<A_COL, B_ROW>(g, ws, ws_bytes, (hipStream_t)stream, 1, bsum_out, bsum_accumulate, bsum_ws);
+    LaunchOpt o; o.amax_a = amax_a; o.amax_b = amax_b; o.lds_pad = lds_pad;
+    return launch<A_COL, B_ROW>(g, o, ws, ws_bytes, Counters{(unsigned*)counters, n_counters}, (hipStream_t)stream, 1, bsum_out, bsum_accumulate, bsum_ws);
 }
 
 ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
-                        float* C, long ldc, const float* bias, int accumulate, int mask_period, int mask_skip, void* ws,
-                        size_t ws_bytes, void* stream) {
-    AmaxOneShot amax_scope;
+                        float* C, long ldc, const float* bias, int accumulate, int mask_period, int mask_skip, const float* amax_a,
+                        const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* counters, int n_counters, void* stream) {
     AMS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C);
     GemmArgs g{};
     g.A = A; g.B = B; g.C = C; g.bias = bias;
@@ -1339,25 +1419,20 @@ ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float
     g.a_vec = aligned16(A) && (lda % 4 == 0);
     g.b_vec = aligned16(B) && (ldb % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
-    if (!transA && !transB) return launch<A_ROW, B_ROW>(g, ws, ws_bytes, st);
-    if (!transA && transB) return launch<A_ROW, B_COL>(g, ws, ws_bytes, st);
-    if (transA && !transB) return launch<A_COL, B_ROW>(g, ws, ws_bytes, st);
-    return launch<A_COL, B_COL>(g, ws, ws_bytes, st);
+    LaunchOpt o; o.amax_a = amax_a; o.amax_b = amax_b; o.lds_pad = lds_pad;
+    const Counters c{(unsigned*)counters, n_counters};
+    if (!transA && !transB) return launch<A_ROW, B_ROW>(g, o, ws, ws_bytes, c, st);
+    if (!transA && transB) return launch<A_ROW, B_COL>(g, o, ws, ws_bytes, c, st);
+    if (transA && !transB) return launch<A_COL, B_ROW>(g, o, ws, ws_bytes, c, st);
+    return launch<A_COL, B_COL>(g, o, ws, ws_bytes, c, st);
 }
 
-// nbatch products of one shape in ONE launch (grid.z): operand z is at A + z*a_zs etc. (element offsets, any sign).
+// nbatch products of one shape in ONE launch: operand z is at A + z*a_zs etc. (element offsets, any sign).
 // Used for the two directions' recurrent-kernel gradients: 2 x 30 tiles fill the chip better than 30 twice.
-size_t ams_gemm_batched_workspace_bytes(int M, int N, int K, int nbatch) {
-    if (M <= 0 || N <= 0 || K <= 0 || nbatch <= 0) return 0;
-    int splits = choose_splits(M, N, K, nbatch);
-    if (tuning().splits > 0) splits = tuning().splits;
-    if (splits <= 1) return 0;
-    return (size_t)nbatch * splits * M * N * sizeof(float);
-}
 ams_status ams_gemm_f32_batched(int transA, int transB, int M, int N, int K, const float* A, long lda, long a_zs, const float* B,
                                 long ldb, long b_zs, float* C, long ldc, long c_zs, int nbatch, int accumulate, int mask_period,
-                                int mask_skip, void* ws, size_t ws_bytes, void* stream) {
-    AmaxOneShot amax_scope;
+                                int mask_skip, const float* amax_a, const float* amax_b, int lds_pad, void* ws, size_t ws_bytes,
+                                void* counters, int n_counters, void* stream) {
     AMS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C && nbatch >= 1 && nbatch <= 64);
     GemmArgs g{};
     g.A = A; g.B = B; g.C = C; g.bias = nullptr;
@@ -1368,44 +1443,23 @@ ams_status ams_gemm_f32_batched(int transA, int transB, int M, int N, int K, con
     g.a_vec = aligned16(A) && (lda % 4 == 0) && (a_zs % 4 == 0);
     g.b_vec = aligned16(B) && (ldb % 4 == 0) && (b_zs % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
-    if (!transA && !transB) return launch<A_ROW, B_ROW>(g, ws, ws_bytes, st, nbatch);
-    if (!transA && transB) return launch<A_ROW, B_COL>(g, ws, ws_bytes, st, nbatch);
-    if (transA && !transB) return launch<A_COL, B_ROW>(g, ws, ws_bytes, st, nbatch);
-    return launch<A_COL, B_COL>(g, ws, ws_bytes, st, nbatch);
-}
-
-// Row-segmented batched product (A_ROW x B_ROW): for z < nbatch and logical row r < M,
-//   row(z, r) = (r / seg_len) * seg_stride + seg_off + z * seg_off_zs + r % seg_len
-//   C[row * ldc + z * c_zs + n] = sum_k A[row * lda + k] * B[k * ldb + z * b_zs + n] + bias[z * bias_zs + n]
-// A and C share the row map.  This is the BLSTM input projection restricted to a band of time steps of every utterance
-// (rows (b, t0..t0+len) of a [B, T, .] buffer: seg_len = len, seg_stride = T, seg_off = t0), with the two directions as
-// z = 0, 1 taking their bands from opposite ends of the sequence (reference utils/ops.py:366-383 computes the same
-// product inside dynamic_rnn, step by step).
-ams_status ams_gemm_f32_rowseg(int M, int N, int K, const float* A, long lda, const float* B, long ldb, long b_zs, float* C,
-                               long ldc, long c_zs, const float* bias, long bias_zs, int seg_len, long seg_stride, long seg_off,
-                               long seg_off_zs, int nbatch, void* ws, size_t ws_bytes, void* stream) {
-    AmaxOneShot amax_scope;
-    AMS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C && nbatch >= 1 && nbatch <= 64 && seg_len >= 0);
-    GemmArgs g{};
-    g.A = A; g.B = B; g.C = C; g.bias = bias;
-    g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc;
-    g.b_zs = b_zs; g.c_zs = c_zs; g.bias_zs = bias_zs;
-    g.seg_len = seg_len; g.seg_stride = seg_stride; g.seg_off = seg_off; g.seg_off_zs = seg_off_zs;
-    g.a_vec = aligned16(A) && (lda % 4 == 0);
-    g.b_vec = aligned16(B) && (ldb % 4 == 0) && (b_zs % 4 == 0);
-    return launch<A_ROW, B_ROW>(g, ws, ws_bytes, (hipStream_t)stream, nbatch);
+    LaunchOpt o; o.amax_a = amax_a; o.amax_b = amax_b; o.lds_pad = lds_pad;
+    const Counters c{(unsigned*)counters, n_counters};
+    if (!transA && !transB) return launch<A_ROW, B_ROW>(g, o, ws, ws_bytes, c, st, nbatch);
+    if (!transA && transB) return launch<A_ROW, B_COL>(g, o, ws, ws_bytes, c, st, nbatch);
+    if (transA && !transB) return launch<A_COL, B_ROW>(g, o, ws, ws_bytes, c, st, nbatch);
+    return launch<A_COL, B_COL>(g, o, ws, ws_bytes, c, st, nbatch);
 }
 
 // Adaptive analysis filterbank, path A (reference models/adapt.py:122): y[b,t,n] = sum_k xpad[b,t*hop+k-pl] f[k,n]
 size_t ams_front_conv_fwd_workspace_bytes(int Bt, int L, int W, int N, int hop) {
     if (Bt <= 0 || L <= 0 || W <= 0 || N <= 0 || hop <= 0) return 0;
-    return ams_gemm_workspace_bytes(Bt * ((L + hop - 1) / hop), N, W);
+    return ams_gemm_workspace_bytes(Bt * ((L + hop - 1) / hop), N, W, 1, 0);
 }
 
 // ws (may be NULL: no split-K) lets the few-tile benchmark shape (5120 x 256 output = 80 tiles) fill 256 CUs.
 ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, void* ws,
-                              size_t ws_bytes, void* stream) {
-    AmaxOneShot amax_scope;
+                              size_t ws_bytes, void* counters, int n_counters, void* stream) {
     AMS_REQUIRE(x && f && y && Bt > 0 && L > 0 && W > 0 && N > 0 && hop > 0);
     const int T = (L + hop - 1) / hop;
     int pad_total = (T - 1) * hop + W - L;
@@ -1416,13 +1470,12 @@ ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, 
     g.fr_L = L; g.fr_T = T; g.fr_hop = hop; g.fr_pl = pad_total / 2; g.fr_W = W;
     g.a_vec = aligned16(x) && (L % 4 == 0) && (hop % 4 == 0) && (g.fr_pl % 4 == 0);
     g.b_vec = aligned16(f) && (N % 4 == 0);
-    return launch<A_FRAMES, B_ROW>(g, ws, ws_bytes, (hipStream_t)stream);
+    return launch<A_FRAMES, B_ROW>(g, LaunchOpt{}, ws, ws_bytes, Counters{(unsigned*)counters, n_counters}, (hipStream_t)stream);
 }
 
 // Generic framed product: out[(r,t), n] = sum_k xpad[r, t*hop + k - pad_left] * Bm[k, n]   (STFT as a DFT product)
 ams_status ams_frames_matmul(const float* x, const float* Bm, float* out, int R, int L, int W, int N, int hop, int T, int pad_left,
                              void* stream) {
-    AmaxOneShot amax_scope;
     AMS_REQUIRE(x && Bm && out && R > 0 && L > 0 && W > 0 && N > 0 && hop > 0 && T > 0 && pad_left >= 0);
     GemmArgs g{};
     g.A = x; g.B = Bm; g.C = out; g.bias = nullptr;
@@ -1430,15 +1483,14 @@ ams_status ams_frames_matmul(const float* x, const float* Bm, float* out, int R,
     g.fr_L = L; g.fr_T = T; g.fr_hop = hop; g.fr_pl = pad_left; g.fr_W = W;
     g.a_vec = aligned16(x) && (L % 4 == 0) && (hop % 4 == 0) && (pad_left % 4 == 0);
     g.b_vec = aligned16(Bm) && (N % 4 == 0);
-    return launch<A_FRAMES, B_ROW>(g, nullptr, 0, (hipStream_t)stream);
+    return launch<A_FRAMES, B_ROW>(g, LaunchOpt{}, nullptr, 0, Counters{}, (hipStream_t)stream);
 }
 
 // Filter gradient of a framed product with explicit geometry: dB[k,n] = sum_{r,t} xpad[r, t*hop + k - pad_left] * dy[(r,t), n]
-size_t ams_frames_matmul_bwd_filter_workspace_bytes(int R, int W, int N, int T) { return ams_gemm_workspace_bytes(W, N, R * T); }
+size_t ams_frames_matmul_bwd_filter_workspace_bytes(int R, int W, int N, int T) { return ams_gemm_workspace_bytes(W, N, R * T, 1, 0); }
 
 ams_status ams_frames_matmul_bwd_filter(const float* x, const float* dy, float* dB, int R, int L, int W, int N, int hop, int T,
-                                        int pad_left, void* ws, size_t ws_bytes, void* stream) {
-    AmaxOneShot amax_scope;
+                                        int pad_left, void* ws, size_t ws_bytes, void* counters, int n_counters, void* stream) {
     AMS_REQUIRE(x && dy && dB && R > 0 && L > 0 && W > 0 && N > 0 && hop > 0 && T > 0 && pad_left >= 0);
     GemmArgs g{};
     g.A = x; g.B = dy; g.C = dB; g.bias = nullptr;
@@ -1446,18 +1498,17 @@ ams_status ams_frames_matmul_bwd_filter(const float* x, const float* dy, float* 
     g.fr_L = L; g.fr_T = T; g.fr_hop = hop; g.fr_pl = pad_left; g.fr_W = W;
     g.a_vec = aligned16(x) && (L % 4 == 0) && (hop % 4 == 0) && (pad_left % 4 == 0);
     g.b_vec = aligned16(dy) && (N % 4 == 0);
-    return launch<A_FRAMES_T, B_ROW>(g, ws, ws_bytes, (hipStream_t)stream);
+    return launch<A_FRAMES_T, B_ROW>(g, LaunchOpt{}, ws, ws_bytes, Counters{(unsigned*)counters, n_counters}, (hipStream_t)stream);
 }
 
 size_t ams_front_conv_bwd_filter_workspace_bytes(int Bt, int L, int W, int N, int hop) {
     const int T = (L + hop - 1) / hop;
-    return ams_gemm_workspace_bytes(W, N, Bt * T);
+    return ams_gemm_workspace_bytes(W, N, Bt * T, 1, 0);
 }
 
 // df[k,n] = sum_{b,t} xpad[b,t*hop+k-pl] * dy[b,t,n]   
 ams_status ams_front_conv_bwd_filter(const float* x, const float* dy, float* df, int Bt, int L, int W, int N, int hop,
-                                     void* ws, size_t ws_bytes, void* stream) {
-    AmaxOneShot amax_scope;
+                                     void* ws, size_t ws_bytes, void* counters, int n_counters, void* stream) {
     AMS_REQUIRE(x && dy && df && Bt > 0 && L > 0 && W > 0 && N > 0 && hop > 0);
     const int T = (L + hop - 1) / hop;
     int pad_total = (T - 1) * hop + W - L;
@@ -1468,7 +1519,7 @@ ams_status ams_front_conv_bwd_filter(const float* x, const float* dy, float* df,
     g.fr_L = L; g.fr_T = T; g.fr_hop = hop; g.fr_pl = pad_total / 2; g.fr_W = W;
     g.a_vec = aligned16(x) && (L % 4 == 0) && (hop % 4 == 0) && (g.fr_pl % 4 == 0);
     g.b_vec = aligned16(dy) && (N % 4 == 0);
-    return launch<A_FRAMES_T, B_ROW>(g, ws, ws_bytes, (hipStream_t)stream);
+    return launch<A_FRAMES_T, B_ROW>(g, LaunchOpt{}, ws, ws_bytes, Counters{(unsigned*)counters, n_counters}, (hipStream_t)stream);
 }
 
 }  // extern "C"
@@ -1745,12 +1796,11 @@ size_t ams_front_maxpool_workspace_bytes_w(int Bt, int L, int N, int W) {
 
 // Path B front: y [Bt,T,N], argmax int64 [Bt,T,N], T = (L-P)/hop + 1   (reference models/adapt.py:115-117)
 ams_status ams_front_maxpool_fwd(const float* x, const float* f, float* y, long long* argmax, int Bt, int L, int W, int N, int P, int hop,
-                                 void* ws, size_t ws_bytes, void* stream) {
+                                 const float* amax_x, const float* amax_f, void* ws, size_t ws_bytes, void* stream) {
     AMS_REQUIRE(x && f && y && argmax && Bt > 0 && L >= P && W > 0 && N > 0 && P > 0 && hop > 0);
     hipStream_t st = (hipStream_t)stream;
-    const float* const mp_aa = t_amax_a;                         // one-shot operand bounds (ams_gemm_set_amax): consumed here
-    const float* const mp_ab = t_amax_b;
-    t_amax_a = t_amax_b = nullptr;
+    const float* const mp_aa = amax_x;                           // operand bounds (both set: fp16x3)
+    const float* const mp_ab = amax_f;
     const int T = (L - P) / hop + 1;
     const int pl = (W - 1) / 2;                                  // stride-1 SAME: pad_total = W-1, left = floor
     const long total = (long)Bt * T * N;

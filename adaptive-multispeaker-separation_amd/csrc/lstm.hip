@@ -544,25 +544,6 @@ ams_status ams_blstm_recurrent_bwd_dropout(float* G, const float* cst, const flo
     return ams_check_launch();
 }
 
-// Steps [s_begin, s_end) of the forward recurrence on an already packed recurrent matrix (ams_blstm_pack): lets the host
-// interleave the step launches with events of a time-banded input projection running on another stream.
-ams_status ams_blstm_recurrent_fwd_steps(float* G, float* out, float* cst, const float* pack, int B, int T, int H, int s_begin,
-                                         int s_end, void* stream) {
-    AMS_REQUIRE(G && out && cst && pack && B > 0 && T > 0 && H > 0 && s_begin >= 0 && s_begin <= s_end && s_end <= T);
-    hipStream_t st = (hipStream_t)stream;
-    StepArgs a{};
-    a.G = G; a.out = out; a.cst = cst; a.pk = const_cast<float*>(pack);
-    a.B = B; a.T = T; a.H = H; a.n_ut = ceil_div(H, TU); a.n_g = ceil_div(H, 16);
-    dim3 grid = step_grid(a);
-    const bool use_pipe = fwd_pipe_ok(H, a.n_g);
-    for (int s = s_begin; s < s_end; ++s) {
-        a.s = s;
-        if (use_pipe) hipLaunchKernelGGL(lstm_step_fwd_pipe_kernel, grid, dim3(NWF * 64), 0, st, a);
-        else hipLaunchKernelGGL(lstm_step_fwd_kernel, grid, dim3(NWF * 64), 0, st, a);
-    }
-    return ams_check_launch();
-}
-
 // Recurrence, backward (BPTT).  On return G holds da (gradient w.r.t. the pre-activations).
 ams_status ams_blstm_recurrent_bwd(float* G, const float* cst, const float* dout, float* dc, const float* Uf, const float* Ub,
                                    long ldu, float* pack, int B, int T, int H, void* stream) {

@@ -48,21 +48,8 @@
 #ifndef AMS_RING_BWD_SLEEP
 #define AMS_RING_BWD_SLEEP 0
 #endif
-// experiments on the fused-projection kernel: P-wave priority; 1 = P waves skip their MFMAs (wrong results, timing only)
-#ifndef AMS_RING_P_PRIO
-#define AMS_RING_P_PRIO 1
-#endif
-#ifndef AMS_RING_P_IDLE
-#define AMS_RING_P_IDLE 0
-#endif
-// s_sleep units (64 cycles) the P waves wait behind each step barrier: the R waves' gate epilogue is VALU work, and VALU issue of
-// one wave all but stops while its SIMD partner streams MFMAs (measured: epilogue 1300 -> 5000 cycles beside the projection,
-// whatever the two priorities); delays of 0 / 770 / 1800 / 2560 cycles all measured the same 452-475 us per layer (D = 600)
 #ifndef AMS_RING_X6_DEFAULT
 #define AMS_RING_X6_DEFAULT 1
-#endif
-#ifndef AMS_RING_P_DELAY
-#define AMS_RING_P_DELAY 0
 #endif
 
 namespace {
@@ -89,8 +76,6 @@ struct RingArgs {
     unsigned* flags;            // [n_chains][IDS_STRIDE]   backward: last published step + 1
     float* xbuf;                // forward: granules [n_chains][2][TB][NW*4] float4; backward: partial tiles [n_chains][2][NW][NW][UW*TB]
     int B, T, H, NW, n_chains, force_safe, trace;
-    // fused input projection (lstm_ring_fwdp_kernel): x [B,T,D], input parts of the two direction kernels [D, 4H] (row stride ldw), biases
-    const float* x; const float* Wxf; const float* Wxb; long ldw; const float* bf; const float* bb; int D;
     const float* amax_u;        // forward, fp16x3: device pointer to an upper bound of max |U| over both recurrent kernels
 };
 
@@ -530,224 +515,6 @@ __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
     tr.end();
 }
 
-// ------------------------------------------------------------------------------------- forward, input projection fused
-// The forward ring leaves the MFMA pipes idle ~55 % of every step (the wait for h_{t-1} and the gate epilogue) and nothing else can
-// run beside it: the next layer needs all of this one.  So the layer's OWN input projection z_t = x_t . Wx + b (14.7 GFLOP per layer
-// at the benchmark shape, 135 us as a stand-alone launch) moves into those idle slots.  The workgroup grows to 8 waves, two per SIMD:
-//   * waves 0-3, the R waves, are the ring exactly as in lstm_ring_fwd_kernel (s_setprio 3);
-//   * waves 4-7, the P waves (s_setprio 1), keep the [D x 48] slice of Wx in REGISTERS as B fragments (NGW * 12 VGPRs), take the
-//     16-feature k-groups p, p + 4, ... of x_{t+1} -- the same K split as the recurrent part -- and leave their partial
-//     accumulators in LDS, one step AHEAD of the ring, in a 3-slot rotation (slot (s+1) % 3 is written during step s while the
-//     epilogue of step s reads slot s % 3 and slot (s+2) % 3 is still untouched).
-// Every wave executes exactly ONE s_barrier per step, so the two roles stay in step without any other handshake; the P waves'
-// 3840 cycles of MFMA per step (D = 600) fit under the ring's ~5400-cycle step, the SIMD arbitrates by priority.
-// (A first form ran the projection inside the R waves between their poll rounds: the wait hides only ~50 MFMAs of the 120, the rest
-// lengthened the step -- 459 us per layer vs 393 with a separate product at D = 600, a gain only for D <= 256.)
-// MEASURED SLOWER than projection-as-a-separate-product (452 vs 393 us per layer at D = 600): opt-in (AMS_LSTM_RING_PROJ=1), kept
-// parity-tested as the record of the experiment.
-// NR: producer rounds per R wave; NGW: k-groups per P wave (compile-time), D <= 64 * NGW.
-template <int NR, int NGW>
-__global__ __launch_bounds__(512) void lstm_ring_fwdp_kernel(RingArgs a) {
-    __shared__ __attribute__((aligned(16))) float red[2][4][3][64][4];     // R partials [step parity][wave][column tile][lane][reg]
-    __shared__ __attribute__((aligned(16))) float zp[3][4][3][64][4];      // P partials [slot][wave][column tile][lane][reg]
-    __shared__ int lds_flag;
-    int chain, w;
-    if (!ring_coords(a, chain, w)) return;
-    const int tid = threadIdx.x, lane = tid & 63, wave8 = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const bool is_p = wave8 >= 4;                               // uniform per wave
-    const int wave = wave8 & 3;
-    const int dir = chain & 1, bt = chain >> 1;
-    const int H = a.H, T = a.T, NW = a.NW, NG = NW * 4, D = a.D;
-    bool abort = false;
-    const bool fast = chain_shares_l2(a, chain, w, &lds_flag, abort);        // one __syncthreads inside, all 8 waves
-    const int n16 = lane & 15, q = lane >> 4;
-    const int rowl = lane & 15;
-
-    if (is_p) {
-        // ------------------------------------------------------------------------------------------------ P waves
-        __builtin_amdgcn_s_setprio(AMS_RING_P_PRIO);
-        const float* Wx = dir ? a.Wxb : a.Wxf;
-        float wf[NGW][12];                                      // [k-group][j * 3 + tile]: Wx[16 (wave + 4 g) + 4 q + j][tile * 16 + n16]
-#pragma unroll
-        for (int g = 0; g < NGW; ++g)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int k = 16 * (wave + 4 * g) + 4 * q + j;
-#pragma unroll
-                for (int t3 = 0; t3 < 3; ++t3) {
-                    const int c = t3 * 16 + n16, gate = c / UW, unit = w * UW + c % UW;
-                    wf[g][j * 3 + t3] = (k < D && unit < H) ? Wx[(long)k * a.ldw + gate * H + unit] : 0.f;
-                }
-            }
-        // A fragments: lane (row = lane & 15, q) reads x[row][16 gg + 4 q .. + 3], gg = wave + 4 g (clamped: k-groups past D meet
-        // zero weights; rows past B are never stored)
-        const float* xrow = a.x + (long)min(bt * TB + rowl, a.B - 1) * T * D;
-        int xoff[NGW];
-#pragma unroll
-        for (int g = 0; g < NGW; ++g) xoff[g] = min(16 * (wave + 4 * g) + 4 * q, D - 4);
-        float4 xa[NGW];
-        auto load_x = [&](int sidx) {                           // x rows of ring step sidx (clamped)
-            const int sc = min(max(sidx, 0), T - 1);
-            const float* xr = xrow + (long)(dir ? (T - 1 - sc) : sc) * D;
-#pragma unroll
-            for (int g = 0; g < NGW; ++g) xa[g] = *reinterpret_cast<const float4*>(xr + xoff[g]);
-        };
-        auto project = [&](int slot) {
-            f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-#pragma unroll
-            for (int g = 0; g < (AMS_RING_P_IDLE ? 0 : NGW); ++g) {
-#pragma unroll
-                for (int t3 = 0; t3 < 3; ++t3) acc[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[g].x, wf[g][0 * 3 + t3], acc[t3], 0, 0, 0);
-#pragma unroll
-                for (int t3 = 0; t3 < 3; ++t3) acc[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[g].y, wf[g][1 * 3 + t3], acc[t3], 0, 0, 0);
-#pragma unroll
-                for (int t3 = 0; t3 < 3; ++t3) acc[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[g].z, wf[g][2 * 3 + t3], acc[t3], 0, 0, 0);
-#pragma unroll
-                for (int t3 = 0; t3 < 3; ++t3) acc[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(xa[g].w, wf[g][3 * 3 + t3], acc[t3], 0, 0, 0);
-            }
-#pragma unroll
-            for (int t3 = 0; t3 < 3; ++t3) *reinterpret_cast<f32x4*>(&zp[slot][wave][t3][lane][0]) = acc[t3];
-        };
-        load_x(0);
-        project(0);                                             // step 0's projection, before the ring starts
-        load_x(1);
-        __syncthreads();                                        // barrier "-1": slot 0 is visible
-        for (int s = 0; s < T; ++s) {
-            if (AMS_RING_P_DELAY) __builtin_amdgcn_s_sleep(AMS_RING_P_DELAY);
-            project((s + 1) % 3);                               // step s + 1 (a clamped repeat at the end; nobody reads it)
-            load_x(s + 2);
-            __syncthreads();                                    // barrier of step s
-        }
-        return;
-    }
-
-    // ---------------------------------------------------------------------------------------------------- R waves
-    __builtin_amdgcn_s_setprio(3);
-    const float* U = dir ? a.Ub : a.Uf;
-    float bw[NR][3][3];
-#pragma unroll
-    for (int i = 0; i < NR; ++i) {
-        const int r = wave + 4 * i;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int k = 12 * r + 3 * q + j;
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const int c = t * 16 + n16, gate = c / UW, unit = w * UW + c % UW;
-                bw[i][j][t] = (r < NW && k < H && unit < H) ? U[(long)k * a.ldu + gate * H + unit] : 0.f;
-            }
-        }
-    }
-    const int row = tid >> 4, ul = tid & 15;                    // tid < 256 here
-    const int b = bt * TB + row, u = w * UW + ul;
-    const bool live = (ul < UW && b < a.B && u < H);
-    int src_off[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        const int c = g * UW + (ul < UW ? ul : 0);
-        src_off[g] = ((c >> 4) * 64 + (row >> 2) * 16 + (c & 15)) * 4 + (row & 3);
-    }
-    float* xb = a.xbuf + (size_t)chain * 2 * TB * NG * 4;
-    const rsrc_t rs = make_rsrc(xb, (unsigned)((size_t)2 * TB * NG * 16));
-    float c_state = 0.f;
-    const long bl_ = live ? b : 0, ul_ = live ? u : 0;
-    float* const gp = a.G + ((bl_ * T) * 2 + dir) * (4 * H) + ul_;
-    float* const cp = a.cst + ((bl_ * T) * 2 + dir) * H + ul_;
-    float* const tp_ = a.tch + ((bl_ * T) * 2 + dir) * H + ul_;
-    float* const op = a.out + (bl_ * T) * (2 * H) + dir * H + ul_;
-    const int gst = 8 * H, cst_st = 2 * H;
-    float bias[4];
-    {
-        const float* bp = (dir ? a.bb : a.bf) + ul_;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) bias[g] = bp[g * H];
-    }
-    __syncthreads();                                            // barrier "-1" (pairs with the P waves')
-
-    Trace tr;
-    tr.begin(reinterpret_cast<unsigned long long*>(a.err) + 8, a.trace && chain == 0 && w == 0 && tid == 0);
-    for (int s = 0; s < T; ++s) {
-        const int t = dir ? (T - 1 - s) : s;
-        const int par = s & 1;
-        f32x4 acc[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-        if (s > 0) {
-            float4 hv[NR];
-#pragma unroll
-            for (int i = 0; i < NR; ++i) hv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (!abort) {
-                unsigned spins = 0;
-                const unsigned want = (unsigned)s;              // h_{s-1} carries tag s
-                const unsigned rbase = (unsigned)(((par ^ 1) * TB + rowl) * NG) * 16u;
-                for (;;) {
-#pragma unroll
-                    for (int i = 0; i < NR; ++i) {
-                        const int r = min(wave + 4 * i, NW - 1);
-                        hv[i] = ld16_l2(rs, rbase + (unsigned)(r * 4 + q) * 16u);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);          // all requests in flight before the first tag is looked at
-                    bool ok = true;
-#pragma unroll
-                    for (int i = 0; i < NR; ++i) ok &= (__float_as_uint(hv[i].w) == want);
-                    if (__all(ok)) break;
-                    if (spin_check(spins, a.err, a.sticky)) { abort = true; break; }
-                }
-            }
-            tr.stamp(0);                                        // wait for h_{s-1}
-#pragma unroll
-            for (int i = 0; i < NR; ++i) {
-#pragma unroll
-                for (int t3 = 0; t3 < 3; ++t3) acc[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i].x, bw[i][0][t3], acc[t3], 0, 0, 0);
-#pragma unroll
-                for (int t3 = 0; t3 < 3; ++t3) acc[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i].y, bw[i][1][t3], acc[t3], 0, 0, 0);
-#pragma unroll
-                for (int t3 = 0; t3 < 3; ++t3) acc[t3] = __builtin_amdgcn_mfma_f32_16x16x4f32(hv[i].z, bw[i][2][t3], acc[t3], 0, 0, 0);
-            }
-        }
-#pragma unroll
-        for (int t3 = 0; t3 < 3; ++t3) *reinterpret_cast<f32x4*>(&red[par][wave][t3][lane][0]) = acc[t3];
-        tr.stamp(1);                                            // MFMA chain + accumulators to LDS
-        __syncthreads();                                        // barrier of step s: red[par] complete, zp[s % 3] long complete
-        tr.stamp(2);
-
-        float pre[4];
-        const float* rp = &red[par][0][0][0][0];
-        const float* zpp = &zp[s % 3][0][0][0][0];
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            float v = bias[g];
-#pragma unroll
-            for (int wv = 0; wv < 4; ++wv) v += zpp[wv * (3 * 64 * 4) + src_off[g]];       // input projection, k-split order
-#pragma unroll
-            for (int wv = 0; wv < 4; ++wv) v += rp[wv * (3 * 64 * 4) + src_off[g]];        // recurrent part
-            pre[g] = v;
-        }
-        const float ig = ring_sigmoid(pre[0]);
-        const float gg = ring_tanh(pre[1]);
-        const float fg = ring_sigmoid(pre[2] + 1.0f);                 // forget_bias = 1.0
-        const float og = ring_sigmoid(pre[3]);
-        const float c = c_state * fg + ig * gg;
-        const float tc = ring_tanh(c);
-        const float h = live ? tc * og : 0.f;
-        c_state = c;
-        const float h1 = __shfl_down(h, 1, 64), h2 = __shfl_down(h, 2, 64);
-        if (ul < UW && ul % 3 == 0)
-            st16(rs, xb, (unsigned)(((par * TB + row) * NG) + w * 4 + ul / 3) * 16u, make_float4(h, h1, h2, __uint_as_float((unsigned)(s + 1))), fast);
-        tr.stamp(3);                                            // gate epilogue up to the granule store
-        if (live) {
-            float* gr = gp + t * gst;
-            gr[0 * H] = ig;
-            gr[1 * H] = gg;
-            gr[2 * H] = fg;
-            gr[3 * H] = og;
-            cp[t * cst_st] = c;
-            tp_[t * cst_st] = tc;
-            op[t * cst_st] = h;
-        }
-        tr.stamp(4);                                            // G / cst / tanh(c) / out stores
-    }
-    tr.end();
-}
-
 // ----------------------------------------------------------------------------------------------------- backward
 // NI = ceil(NT / 4) output-tile rounds per wave (compile-time, as NR above); NP = 4 * ceil(NW / 4) partial tiles summed per element.
 // Partial tiles are read with 16-byte loads: a dword load costs the CU's address unit the same 16 cycles per wave-instruction as
@@ -994,49 +761,15 @@ inline bool ring_fwd_f16() {
     static const bool v = !(getenv("AMS_LSTM_RING_F16") && atoi(getenv("AMS_LSTM_RING_F16")) == 0);
     return v;
 }
-thread_local const float* t_ring_amax_u = nullptr;
 
 inline int ring_force_safe() {
     static const int v = getenv("AMS_LSTM_RING_SAFE") ? atoi(getenv("AMS_LSTM_RING_SAFE")) : 0;     // read once; testing aid
     return v;
 }
 
-// k-groups per wave the fused-projection kernel is instantiated for; 0 = D not supported (caller projects with ams_gemm_f32)
-static inline int ring_proj_ngw(int D) {
-    if (D < 4 || D % 4 != 0) return 0;
-    const int need = ceil_div(ceil_div(D, 16), 4);
-    const int opts[] = {1, 2, 4, 5, 8, 10};
-    for (int o : opts) if (need <= o) return o;
-    return 0;
-}
-
-template <int NR, int NGW>
-static ams_status launch_fwdp(const RingArgs& a, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((lstm_ring_fwdp_kernel<NR, NGW>), grid, dim3(512), 0, st, a);
-    return ams_check_launch();
-}
-template <int NR>
-static ams_status launch_fwdp_ngw(const RingArgs& a, int ngw, dim3 grid, hipStream_t st) {
-    switch (ngw) {
-        case 1: return launch_fwdp<NR, 1>(a, grid, st);
-        case 2: return launch_fwdp<NR, 2>(a, grid, st);
-        case 4: return launch_fwdp<NR, 4>(a, grid, st);
-        case 5: return launch_fwdp<NR, 5>(a, grid, st);
-        case 8: return launch_fwdp<NR, 8>(a, grid, st);
-        default: return launch_fwdp<NR, 10>(a, grid, st);
-    }
-}
-
 }  // namespace
 
 extern "C" {
-
-// 8-wave workgroups at ~200 VGPRs: ONE per CU, so the whole grid must fit 256 CUs (the plain ring admits two per CU)
-int ams_blstm_ring_proj_ok(int B, int H, int D) {
-    int NW, n_chains;
-    return ring_proj_ngw(D) != 0 && B > 0 && H > 0 && ring_shape(B, H, NW, n_chains) && (long)n_chains * NW <= 256;
-}
-
 
 // 0 when the ring path cannot be used for this shape (caller falls back to the per-step kernels of lstm.hip).
 size_t ams_blstm_ring_sync_bytes(int B, int H, int backward) {
@@ -1058,10 +791,9 @@ size_t ams_blstm_ring_sync_head_bytes(int B, int H, int backward) {
 // Bit 2: the caller has ALREADY zeroed the sync buffer (all of it for the forward ring, its first ams_blstm_ring_sync_head_bytes()
 // for the backward ring) in stream order before this launch -- no memset node in front of the ring (ops.py clears the buffers of a
 // whole pass with one memset on the side stream while the pass starts).
-void ams_blstm_ring_set_amax(const float* amax_u) { t_ring_amax_u = amax_u; }
-
-ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, const float* Uf, const float* Ub, long ldu, void* sync,
-                              size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream) {
+// amax_u (optional): device pointer to an upper bound of max |U| over both recurrent kernels -> the recurrent product runs as fp16x3.
+ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, const float* Uf, const float* Ub, long ldu, const float* amax_u,
+                              void* sync, size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream) {
     AMS_REQUIRE(G && out && cst && tch && Uf && Ub && sync && B > 0 && T > 0 && H > 0);
     int NW, n_chains;
     AMS_REQUIRE(ring_shape(B, H, NW, n_chains));
@@ -1075,8 +807,6 @@ ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, cons
     a.xbuf = (float*)((char*)sync + L.x);
     a.B = B; a.T = T; a.H = H; a.NW = NW; a.n_chains = n_chains; a.force_safe = ((safe & 1) || ring_force_safe()) ? 1 : 0; a.trace = (safe & 2) ? 1 : 0;
     const dim3 grid(8 * NW * ceil_div(n_chains, 8));
-    const float* const amax_u = t_ring_amax_u;      // one-shot (ams_blstm_ring_set_amax): consumed here
-    t_ring_amax_u = nullptr;
     if (ring_fwd_x6() && amax_u && ring_fwd_f16()) {
         a.amax_u = amax_u;
         switch (ceil_div(NW, 4)) {
@@ -1114,37 +844,9 @@ ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, cons
     return ams_check_launch();
 }
 
-// Forward ring WITH the layer's input projection inside it: G is written only (activated gates); x [B,T,D]; Wxf/Wxb = rows 0..D-1 of
-// each direction's [D+H,4H] kernel (row stride ldw), bf/bb the biases.  Requires ams_blstm_ring_proj_ok(D) (D % 4 == 0, D <= 640).
-ams_status ams_blstm_ring_fwd_proj(const float* x, int D, const float* Wxf, const float* Wxb, long ldw, const float* bf, const float* bb,
-                                   float* G, float* out, float* cst, float* tch, const float* Uf, const float* Ub, long ldu, void* sync,
-                                   size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream) {
-    AMS_REQUIRE(x && Wxf && Wxb && bf && bb && G && out && cst && tch && Uf && Ub && sync && B > 0 && T > 0 && H > 0);
-    const int ngw = ring_proj_ngw(D);
-    AMS_REQUIRE(ngw != 0 && (((uintptr_t)x) & 15) == 0);
-    int NW, n_chains;
-    AMS_REQUIRE(ring_shape(B, H, NW, n_chains) && (long)n_chains * NW <= 256);
-    const RingLayout L = ring_layout(NW, n_chains, 0);
-    if (sync_bytes < L.total) return AMS_E_WORKSPACE_TOO_SMALL;
-    hipStream_t st = (hipStream_t)stream;
-    if (!(safe & 4) && hipMemsetAsync(sync, 0, L.head, st) != hipSuccess) return AMS_E_LAUNCH_FAILED;      // bit 2: the caller cleared [0, head)
-    RingArgs a{};
-    a.G = G; a.out = out; a.cst = cst; a.tch = tch; a.Uf = Uf; a.Ub = Ub; a.ldu = ldu;
-    a.x = x; a.Wxf = Wxf; a.Wxb = Wxb; a.ldw = ldw; a.bf = bf; a.bb = bb; a.D = D;
-    a.err = (unsigned*)sync; a.sticky = (unsigned*)sticky_err; a.ids = (unsigned*)((char*)sync + L.ids); a.flags = (unsigned*)((char*)sync + L.flags);
-    a.xbuf = (float*)((char*)sync + L.x);
-    a.B = B; a.T = T; a.H = H; a.NW = NW; a.n_chains = n_chains;
-    a.force_safe = ((safe & 1) || ring_force_safe()) ? 1 : 0; a.trace = (safe & 2) ? 1 : 0;
-    const dim3 grid(8 * NW * ceil_div(n_chains, 8));
-    const int nr = ceil_div(NW, 4);
-    if (nr <= 2) return launch_fwdp_ngw<2>(a, ngw, grid, st);
-    if (nr <= 4) return launch_fwdp_ngw<4>(a, ngw, grid, st);
-    return launch_fwdp_ngw<7>(a, ngw, grid, st);
-}
-
 // Same contract as ams_blstm_recurrent_bwd (on return G holds da), without the dc workspace (the running dc lives in registers).
 // dbpart (optional, [B,2,4H]): receives sum_t da[b,t,dir,:] -- the bias gradient is then a column sum over B rows instead of B*T.
-// On return float word 2 of `sync` holds max |da| (the operand bound ams_gemm_set_amax wants for the three products that read dZ).
+// On return float word 2 of `sync` holds max |da| (the operand bound of the three products that read dZ).
 ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* tch, const float* dout, float* dbpart, const float* Uf, const float* Ub,
                               long ldu, void* sync, size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream) {
     AMS_REQUIRE(G && cst && tch && dout && Uf && Ub && sync && B > 0 && T > 0 && H > 0);

@@ -249,6 +249,9 @@ class Network(object):
         st = self.__dict__.setdefault('_cg_state', {'n': 0, 'graph': None,
                                                     'stream': torch.cuda.Stream(priority=int(os.environ.get('AMS_MAIN_PRIORITY', '0')))})
         probe = self._feeds(feed_dict, True)
+        # the probe only fetches the input nodes: it must NOT begin a pass (ops.pass_begin clears the ring arena and rewrites the shared
+        # weight bound on the side stream, un-joined, while the replayed graph owns both addresses)
+        probe.begun = True
         ins = [n.value(probe) for n in (self.x_mix, self.x_non_mix, self.I)]
         opt = self.optimize
         side = st['stream']
@@ -343,12 +346,17 @@ class Network(object):
     def _eval_guarded(self, feed_dict, fn, training=False):
         """fn(run) without gradients; the same batch again on the per-step kernels when a ring launch gave up (one host sync: every
         caller reads its results on the host anyway)."""
+        # a word that is ALREADY set belongs to an earlier (training) launch whose owner has yet to handle it (Trainer.train checks
+        # right after the step): it is not this evaluation's to clear -- the batch is evaluated on the per-step kernels and the word
+        # stays up
+        pre = K.LSTM_RING != '0' and self._ring_error_any()
         run = self._feeds(feed_dict, training)
         with torch.no_grad():
             out = fn(run)
-        if K.LSTM_RING != '0' and K.ring_error_pending():
+        if K.LSTM_RING != '0' and (pre or self._ring_error_any()):
             ins = self._inputs_of(run)
-            K.ring_errors_clear()
+            if not pre:
+                K.ring_errors_clear()
             old, K.LSTM_RING = K.LSTM_RING, '0'
             try:
                 run = self._feeds(feed_dict, training)
@@ -360,6 +368,14 @@ class Network(object):
                 K.LSTM_RING = old
             Network.ring_fallbacks += 1
         return out
+
+    def _ring_error_any(self):
+        """Did a ring launch of the evaluation just run give up -- on ANY rank?  The decision to repeat a batch must be the same on
+        every rank: the repeat may issue collectives (SparseKL all-reduces p_hat) its peers would otherwise not match."""
+        d = self.dist
+        if d is not None and getattr(d, 'enabled', False) and torch.cuda.is_available():
+            d.all_reduce_max(K.ring_error_word())
+        return K.ring_error_pending()
 
     def retrain_last(self, step):
         """Repeat the LAST training step on the per-step recurrence kernels.  Call when K.ring_error_pending() after train():

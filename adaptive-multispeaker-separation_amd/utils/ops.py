@@ -16,20 +16,11 @@ rng = np.random.RandomState(42)          # reference utils/ops.py:5 (module-leve
 
 
 def f_props(layers, x, then=None):
-    """utils/ops.py:82-85.  `then` (an addition) names the layer that will be applied to the result, so that the last BLSTM of
-    the list can start feeding it while its own recurrence finishes (ams_hip/ops.py TAIL_CUTS)."""
+    """utils/ops.py:82-85."""
     for i, layer in enumerate(layers):
-        nxt = layers[i + 1] if i + 1 < len(layers) else then
         if isinstance(layer, BLSTM):                 # the layer whose backward runs just before the first layer's (functional.py)
             layer._last_capped = (i == 1 and isinstance(layers[0], BLSTM))
-        if isinstance(layer, BLSTM) and isinstance(nxt, BLSTM):
-            F.hint_next('proj', nxt.Kf, nxt.bf, nxt.Kb, nxt.bb)
-        elif isinstance(layer, BLSTM) and isinstance(nxt, Conv1D):
-            F.hint_next('dense', nxt.W, nxt.b)
-        else:
-            F.hint_next(None)
         x = layer.f_prop(x)
-    F.hint_next(None)
     return x
 
 
@@ -114,7 +105,6 @@ class BLSTM:
             from ams_hip.graph import current_run
             run = current_run()
             if run is not None and run.training and torch.is_grad_enabled():
-                F.hint_next(None)
                 return F.blstm_dropout(x, self.Kf, self.bf, self.Kb, self.bb, 1.0 - self.drop_val)
         return F.blstm(x, self.Kf, self.bf, self.Kb, self.bb, getattr(self, '_last_capped', False))
 

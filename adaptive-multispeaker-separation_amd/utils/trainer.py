@@ -261,17 +261,19 @@ class Trainer(object):
                 tfds.initialize(tfds.TRAIN)
                 for b in range(n_train):
                     c = self.model.train(feeds[tfds.TRAIN], step)
+                    c = float(c)                   # host sync, as sess.run returning the cost does
+                    if ops.ring_error_pending():
+                        # a ring recurrence of this step could not get its workgroups resident in time: the optimizer skipped
+                        # the update (the sticky error word is its guard); the same batch again on the per-step kernels.  Checked
+                        # BEFORE any validation pass: an evaluation batch would see the word, clear it, and this step would be lost
+                        # with the optimizer's host counters already advanced.
+                        c = float(self.model.retrain_last(step))
+                        self._say('recurrence ring gave up a bounded wait: step repeated on the per-step kernels')
                     if (step + 1) % every == 0:
                         t = time.time()
                         costs, mean = self._validate(tfds, feeds, step)
                         self._say('Validation set tested in ', time.time() - t, ' seconds')
                         self._say('Validation set: ', mean)
-                    c = float(c)                   # host sync, as sess.run returning the cost does
-                    if ops.ring_error_pending():
-                        # a ring recurrence of this step could not get its workgroups resident in time: the optimizer skipped
-                        # the update (the sticky error word is its guard); the same batch again on the per-step kernels
-                        c = float(self.model.retrain_last(step))
-                        self._say('recurrence ring gave up a bounded wait: step repeated on the per-step kernels')
                     window = window[1:] + [time.time() - mark]
                     avg = sum(window) / len(window)
                     self._say('Epoch #', epoch + 1, '/', epochs, ' Batch #', b + 1, '/', n_train, 'in', avg, 'sec loss=', c,

@@ -10,7 +10,10 @@
  *   - `stream` is a hipStream_t; work is only enqueued, never synchronised; nothing is allocated;
  *   - the caller owns inputs, outputs and workspaces (sizes from the *_workspace_bytes / *_floats helpers);
  *   - return value: AMS_OK or a negative ams_status; on AMS_E_LAUNCH_FAILED the hipError_t is in ams_last_error();
- *   - re-entrant across streams/threads (no global mutable state besides the thread-local last error).
+ *   - re-entrant across streams/threads.  State behind this ABI, all of it: the thread-local last error; ONE process-wide selector of
+ *     the product arithmetic (ams_gemm_set_arith, a test / A-B switch; default from AMS_GEMM_X6, read once); a once-per-process cache of
+ *     device properties and of the AMS_* tuning environment.  Operand bounds (fp16x3) and the residency cap of a product are ARGUMENTS
+ *     of the entry points, not state (ABI 2; ABI 1 had thread-local one-shot setters for both).
  */
 #ifndef AMS_H
 #define AMS_H
@@ -21,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AMS_ABI_VERSION 1
+#define AMS_ABI_VERSION 2
 
 typedef int32_t ams_status;
 #define AMS_OK 0
@@ -41,18 +44,19 @@ ams_status ams_front_filter_bwd(const float* w, const float* bases, const float*
  * x [Bt,L], f [W,N] -> y [Bt,T',N], T' = ceil(L/hop), pad_left = ((T'-1)hop+W-L)/2. */
 size_t ams_front_conv_fwd_workspace_bytes(int Bt, int L, int W, int N, int hop);
 ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, void* ws,
-                              size_t ws_bytes, void* stream);
+                              size_t ws_bytes, void* counters, int n_counters, void* stream);      /* counters: see ams_gemm_f32 */
 size_t ams_front_conv_bwd_filter_workspace_bytes(int Bt, int L, int W, int N, int hop);
 ams_status ams_front_conv_bwd_filter(const float* x, const float* dy, float* df, int Bt, int L, int W, int N, int hop, void* ws,
-                                     size_t ws_bytes, void* stream);
+                                     size_t ws_bytes, void* counters, int n_counters, void* stream);
 
 /* ---- K3/K4/K5 path B (--with_max_pool): stride-1 conv + tf.nn.max_pool_with_argmax fused (models/adapt.py:115-117);
  * argmax int64 = l*N + n (no batch term).  Sparse (unpool-free) synthesis and gather-form filter
  * gradients (models/adapt.py:210-243, utils/ops.py:94-120). ---- */
 size_t ams_front_maxpool_workspace_bytes(int Bt, int L, int N);
 size_t ams_front_maxpool_workspace_bytes_w(int Bt, int L, int N, int W);   /* + room for the zero-padded signal copy (faster product) */
+/* amax_x / amax_f (optional, both or neither): device pointers to upper bounds of max |x|, max |f| -> the product runs as fp16x3 */
 ams_status ams_front_maxpool_fwd(const float* x, const float* f, float* y, long long* argmax, int Bt, int L, int W, int N, int P, int hop,
-                                 void* ws, size_t ws_bytes, void* stream);
+                                 const float* amax_x, const float* amax_f, void* ws, size_t ws_bytes, void* stream);
 /* the sparse kernels take int32 sample positions (argmax / N, converted once) and the synthesis filter TRANSPOSED, f2t [N, W] */
 ams_status ams_argmax_to_pos(const long long* argmax, int32_t* pos, long count, int N, void* stream);
 ams_status ams_transpose_f32(const float* in, float* out, int rows, int cols, void* stream);
@@ -68,76 +72,57 @@ ams_status ams_synth_unpool_bwd_vals(const float* dout, const int32_t* pos, cons
  * C[M,N] (+)= op(A) . op(B) (+ bias[N]);  transX = 0: row-major [rows,cols] as written, 1: stored transposed.
  * mask_period/mask_skip (transA only): reduction rows k with k % period == skip are treated as zero
  * (used for the time-shifted h_{t-1}^T . da product).  utils/ops.py:366-383, :501-503. */
-size_t ams_gemm_workspace_bytes(int M, int N, int K);
-/* The ONE piece of state behind this ABI (per host thread, default 0): a launch attribute of the GEMM entry points below --
- * extra (unused) dynamic LDS bytes per workgroup, which caps the product's CU occupancy when it is launched beside the
- * latency-bound recurrence on another stream (0 = off).  It changes scheduling only, never results; every GEMM call made
- * by the thread until the next set uses it.  Environment overrides of tile order / split count (AMS_GEMM_*) are read once
- * per process, not per launch. */
-void ams_gemm_set_lds_pad(int bytes);
-
-/* fp16x3 product arithmetic (round 3).  ONE-SHOT, thread-local: the next product launched from this thread through any ams_gemm_* /
-   ams_front_conv_* / ams_front_maxpool_fwd entry point that takes the 16-byte-fetch path runs as fp16x3 instead of bf16x6, and the
-   setting is cleared whether or not it was used.  amax_a / amax_b: device pointers to ONE float each, an upper bound of max |value|
-   over the WHOLE A / B operand as the entry point sees it (all batches; for A_FRAMES the waveform).  The kernel scales each operand
-   by 2^(13 - floor(log2(bound))), splits it exactly into two fp16 terms (22 significant bits for entries within 2^17 of the bound,
-   an absolute error of bound * 2^-39 below), issues three fp16 MFMA products per f32 product and unscales the accumulators: f32
-   results at the error level of bf16x6 and of the f32 MFMA themselves (tests/test_gpu_gemm_f16.py holds all three against
-   float64), at half the matrix-pipe work.  A bound below the true maximum by more than 4x overflows fp16 and yields Inf/NaN (loud);
-   a bound too high by up to 2^10 costs nothing; a bound of 0, Inf or NaN selects scale 1.  Passing NULL for either pointer, a
-   launch that does not take the 16-byte-fetch path, AMS_GEMM_X6=0 or AMS_GEMM_F16X3=0 leave the arithmetic as it was.
-   Replaces nothing in the reference (tf.matmul / conv2d in f32): it is how those f32 products are issued. */
-void ams_gemm_set_amax(const float* amax_a, const float* amax_b);
-/* The three product entry points with the bounds as ARGUMENTS: same contract as ams_gemm_f32 / _batched / _at_b_colsum below, fp16x3
-   arithmetic when both bounds are non-NULL and the launch takes the 16-byte-fetch path, bf16x6 otherwise; no state survives the
-   call (and none set earlier through ams_gemm_set_amax is used). */
-ams_status ams_gemm_f32_bounded(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
-                                float* C, long ldc, const float* bias, int accumulate, int mask_period, int mask_skip,
-                                const float* amax_a, const float* amax_b, void* ws, size_t ws_bytes, void* stream);
-ams_status ams_gemm_f32_batched_bounded(int transA, int transB, int M, int N, int K, const float* A, long lda, long a_zs, const float* B,
-                                        long ldb, long b_zs, float* C, long ldc, long c_zs, int nbatch, int accumulate, int mask_period,
-                                        int mask_skip, const float* amax_a, const float* amax_b, void* ws, size_t ws_bytes, void* stream);
-ams_status ams_gemm_f32_at_b_colsum_bounded(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
-                                            int accumulate, float* bsum_out, int bsum_accumulate, float* bsum_ws, const float* amax_a,
-                                            const float* amax_b, void* ws, size_t ws_bytes, void* stream);
-/* out[0] = max |x[i]|, i < n, as a float (NaN if any x is NaN): the bound ams_gemm_set_amax wants, for operands whose producer does
-   not supply one.  Two stream-ordered launches (a 4-byte clear, the reduction); out is a device pointer. */
-ams_status ams_absmax_f32(const float* x, long n, float* out, void* stream);
-/* Arithmetic of the products below (process-wide; default 1, or AMS_GEMM_X6 read once): 1 = "bf16x6" -- both f32 operands are
- * split EXACTLY into three bf16 terms (hi + mid + lo, round-to-nearest) and six of the nine bf16 x bf16 partial products (all but
- * mid.lo, lo.mid, lo.lo <= 2^-26 |a.b|) are accumulated in f32 on v_mfma_f32_32x32x16_bf16, which gfx950 issues at 16x the rate
- * of its f32 MFMA; results carry f32-level error (tests/test_gpu_gemm_x6.py: against float64, next to mode 0).  0 = native
- * v_mfma_f32_32x32x2_f32.  Launches whose operands are not 16-byte addressable use mode 0 whatever the setting.  Inf / NaN
- * operands give NaN in mode 1 (inf - inf in the split) where mode 0 propagates Inf.  The workspace size a query returns depends
- * on the mode and on the lds pad (they select the tile configuration, hence the split-K count), but a workspace sized under
- * another setting is NEVER an error: a launch uses as many split-K slabs as the workspace it is given holds (down to none) --
- * a mismatch costs speed, not correctness; the results differ only in summation order (both inside the tested tolerances). */
+/* Every product entry point takes, besides its operands:
+ *   amax_a / amax_b  (optional, both or neither) device pointers to ONE float each, an upper bound of max |value| over the WHOLE A / B
+ *                    operand as the entry point sees it (all batches).  Both non-NULL and a launch on the 16-byte-fetch path: "fp16x3"
+ *                    arithmetic -- each operand is scaled by 2^(13 - floor(log2(bound))), split exactly into two fp16 terms (22
+ *                    significant bits for entries within 2^17 of the bound, an absolute error of bound * 2^-39 below), three fp16 MFMA
+ *                    products per f32 product, accumulators unscaled: f32 results at the error level of bf16x6 and of the f32 MFMA
+ *                    (tests/test_gpu_gemm_f16.py holds all three against float64; tests/test_gpu_rowwise.py row by row on the operands
+ *                    of a real training step), at half the matrix-pipe work.  A bound below the true maximum by more than 4x overflows
+ *                    fp16 and yields Inf/NaN (loud); a bound too high by up to 2^10 costs nothing; 0, Inf or NaN select scale 1.
+ *                    NULL: bf16x6 (below), which needs no bounds.
+ *   lds_pad          0 for a product on the critical path.  > 0: the product is meant to run BESIDE the latency-bound recurrence on
+ *                    another stream: that many bytes of unused dynamic LDS per workgroup cap its CU occupancy, and it takes the
+ *                    single-accumulator kernel variant (register budget of a CU shared with a ring workgroup); results of the two
+ *                    variants differ at the 1e-7 level (tests/test_gpu_gemm_f16.py::test_fp16x3_weight_gradient_bias_capped_and_free).
+ *   ws, ws_bytes     split-K partial slabs, ams_gemm_workspace_bytes(M, N, K, nbatch, lds_pad); NULL = no split-K.  A workspace sized
+ *                    under another setting is never an error: a launch uses as many slabs as it holds (down to none).
+ *   counters, n_counters  (optional) uint32 arrival counters, at least ams_gemm_counter_count(M, N, nbatch) of them, ZERO on entry and
+ *                    left zero: the 16-bit-pipe kernels then reduce split-K INSIDE the producing launch -- every workgroup of an output
+ *                    tile publishes its partial tile (write-through), the last one to arrive adds the slabs in index order (bit-
+ *                    identical to the two-pass form, independent of the arrival order) and applies bias / accumulate.  Two launches on
+ *                    streams that may run concurrently need disjoint counters.  NULL: partial slabs + a second reduce launch.
+ * Arithmetic without bounds (process-wide; default 1, or AMS_GEMM_X6 read once; ams_gemm_set_arith for tests and A/B runs): 1 =
+ * "bf16x6" -- both f32 operands are split EXACTLY into three bf16 terms (hi + mid + lo, round-to-nearest) and six of the nine bf16 x
+ * bf16 partial products (all but mid.lo, lo.mid, lo.lo <= 2^-26 |a.b|) are accumulated in f32 on v_mfma_f32_32x32x16_bf16, which gfx950
+ * issues at 16x the rate of its f32 MFMA; f32-level error (tests/test_gpu_gemm_x6.py: against float64, next to mode 0).  0 = native
+ * v_mfma_f32_32x32x2_f32 everywhere (bounds are then ignored).  Launches whose operands are not 16-byte addressable use mode 0 whatever
+ * the setting.  Inf / NaN operands give NaN in mode 1 (inf - inf in the split) where mode 0 propagates Inf.
+ * Replaces nothing in the reference beyond tf.matmul / conv1d / conv2d in f32: it is how those products are issued. */
+size_t ams_gemm_workspace_bytes(int M, int N, int K, int nbatch, int lds_pad);
+int ams_gemm_counter_count(int M, int N, int nbatch);
 void ams_gemm_set_arith(int mode);
 int ams_gemm_get_arith(void);
 ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C,
-                        long ldc, const float* bias, int accumulate, int mask_period, int mask_skip, void* ws, size_t ws_bytes,
-                        void* stream);
+                        long ldc, const float* bias, int accumulate, int mask_period, int mask_skip, const float* amax_a,
+                        const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* counters, int n_counters, void* stream);
 /* C[M,N] (+)= A^T . B with A stored [K, M] and B [K, N], AND bsum_out[N] (+)= column sums of B in the same pass over B: the
- * weight and bias gradients of Conv1D (utils/ops.py:501-503) from one read of dY.  M, N, lda, ldb multiples of 4, 16-byte
- * aligned operands; bsum_ws = 32 * N floats of scratch. */
+ * weight and bias gradients of Conv1D (utils/ops.py:501-503) and of a BLSTM layer's input kernels from one read of dY / dZ.  M, N, lda,
+ * ldb multiples of 4, 16-byte aligned operands; bsum_ws = 32 * N floats of scratch (16-byte aligned). */
 ams_status ams_gemm_f32_at_b_colsum(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
-                                    int accumulate, float* bsum_out, int bsum_accumulate, float* bsum_ws, void* ws, size_t ws_bytes,
+                                    int accumulate, float* bsum_out, int bsum_accumulate, float* bsum_ws, const float* amax_a,
+                                    const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* counters, int n_counters,
                                     void* stream);
 /* nbatch products of ONE shape in one launch; operand z lives at A + z*a_zs, B + z*b_zs, C + z*c_zs (element offsets, any
  * sign).  No bias.  Used for the two BLSTM directions' recurrent-kernel gradients (h_prev^T . dZ). */
-size_t ams_gemm_batched_workspace_bytes(int M, int N, int K, int nbatch);
 ams_status ams_gemm_f32_batched(int transA, int transB, int M, int N, int K, const float* A, long lda, long a_zs, const float* B,
                                 long ldb, long b_zs, float* C, long ldc, long c_zs, int nbatch, int accumulate, int mask_period,
-                                int mask_skip, void* ws, size_t ws_bytes, void* stream);
-
-/* Row-segmented batched product (no transposes): for z < nbatch and logical row r < M,
- *   row(z,r) = (r / seg_len) * seg_stride + seg_off + z * seg_off_zs + r % seg_len      (seg_len 0: row = r)
- *   C[row*ldc + z*c_zs + n] = sum_k A[row*lda + k] * B[k*ldb + z*b_zs + n] + bias[z*bias_zs + n]   (bias may be NULL)
- * = the BLSTM input projection (utils/ops.py:366-383: dynamic_rnn applies [x,h].K per step) restricted to a band of time
- * steps of every utterance, both directions in one launch; workspace: ams_gemm_batched_workspace_bytes(M, N, K, nbatch). */
-ams_status ams_gemm_f32_rowseg(int M, int N, int K, const float* A, long lda, const float* B, long ldb, long b_zs, float* C,
-                               long ldc, long c_zs, const float* bias, long bias_zs, int seg_len, long seg_stride, long seg_off,
-                               long seg_off_zs, int nbatch, void* ws, size_t ws_bytes, void* stream);
+                                int mask_skip, const float* amax_a, const float* amax_b, int lds_pad, void* ws, size_t ws_bytes,
+                                void* counters, int n_counters, void* stream);
+/* out[0] = max |x[i]|, i < n, as a float (NaN if any x is NaN): an operand bound for the products above, for operands whose producer
+   does not supply one.  Two stream-ordered launches (a 4-byte clear, the reduction); out is a device pointer. */
+ams_status ams_absmax_f32(const float* x, long n, float* out, void* stream);
 
 /* ---- K7  dominant-speaker masks: one_hot(argmax_s |rep|, S, a, b)   models/network.py:377-378, :501-502 ----
  * rep_non_mix rows are (b,s) row-major, each TF long; Y [B,TF,S]; argmax [B,TF] int32 (may be NULL). */
@@ -153,15 +138,6 @@ ams_status ams_blstm_recurrent_fwd(float* G, float* out, float* cst, const float
                                    int B, int T, int H, void* stream);
 ams_status ams_blstm_recurrent_bwd(float* G, const float* cst, const float* dout, float* dc, const float* Uf, const float* Ub,
                                    long ldu, float* pack, int B, int T, int H, void* stream);
-/* Steps [s_begin, s_end) of the forward recurrence (step s: t = s for the forward direction, T-1-s for the backward one)
- * on a matrix already packed by ams_blstm_pack(..., backward = 0): the host may put stream waits between step ranges. */
-ams_status ams_blstm_recurrent_fwd_steps(float* G, float* out, float* cst, const float* pack, int B, int T, int H, int s_begin,
-                                         int s_end, void* stream);
-
-/* Persistent form of the same recurrence: one launch per layer and pass; workgroup rings exchange h_t / da_t in-launch
- * through epoch-tagged 8-byte granules (csrc/lstm_persist.hip).  ams_blstm_persist_sync_bytes returns 0 when the shape
- * cannot use it (not all workgroups resident, or H > 320): callers then use ams_blstm_recurrent_fwd/bwd.
- * sync word 0 (uint32) is non-zero after the launch if a bounded in-launch wait timed out. */
 ams_status ams_blstm_pack(const float* Uf, const float* Ub, long ldu, float* pack, int H, int backward, void* stream);
 /* The per-step recurrence with DropoutWrapper's STATE dropout (utils/ops.py:363,373,379, --recurrent_dropout / --recurrent_dropout_enhance
  * != 0, training only; TensorFlow 1.4 masks BOTH parts of the LSTMStateTuple): out / cst keep the cell's own h_t / c_t, hs [B,T,2H] and
@@ -174,12 +150,6 @@ ams_status ams_blstm_recurrent_fwd_dropout(float* G, float* out, float* cst, flo
 ams_status ams_blstm_recurrent_bwd_dropout(float* G, const float* cst, const float* cs, const float* dout, float* dc, const float* mh,
                                            const float* mc, const float* Uf, const float* Ub, long ldu, float* pack, int B, int T, int H,
                                            void* stream);
-size_t ams_blstm_persist_sync_bytes(int B, int H, int backward);
-ams_status ams_blstm_persist_fwd(float* G, float* out, float* cst, const float* Uf, const float* Ub, long ldu, float* pack, void* sync,
-                                 size_t sync_bytes, int B, int T, int H, void* stream);
-ams_status ams_blstm_persist_bwd(float* G, const float* cst, const float* dout, const float* Uf, const float* Ub, long ldu, float* pack,
-                                 void* sync, size_t sync_bytes, int B, int T, int H, void* stream);
-
 /* Ring form of the same recurrence (csrc/lstm_ring.hip), the default: one launch per layer and pass; a chain = (direction,
  * 16-row batch tile) is a ring of ceil(H/12) resident workgroups on ONE XCD (verified in-launch through HW_REG_XCC_ID; chains
  * whose members do not share an L2, or safe != 0, use write-through stores instead of plain ones).  Forward: h_t travels as
@@ -201,22 +171,12 @@ ams_status ams_blstm_persist_bwd(float* G, const float* cst, const float* dout, 
  * Replaces the same dynamic_rnn while_loop (utils/ops.py:358-383). */
 size_t ams_blstm_ring_sync_bytes(int B, int H, int backward);
 size_t ams_blstm_ring_sync_head_bytes(int B, int H, int backward);
-/* ONE-SHOT, thread-local (like ams_gemm_set_amax): the next ams_blstm_ring_fwd launched from this thread runs its recurrent product
-   h_{t-1} . U as fp16x3 instead of bf16x6 -- U scaled by a power of two from *amax_u (device pointer: an upper bound of max |U| over
-   both recurrent kernels) and split exactly into two fp16 terms, h_{t-1} (|h| < 1) scaled by 2^13, three fp16 MFMA products, the two
-   cross terms in their own accumulator.  27 instead of 54 MFMAs per wave and step, 149 instead of 196 VGPRs.  AMS_LSTM_RING_F16=0
-   or a NULL pointer: bf16x6 as before. */
-void ams_blstm_ring_set_amax(const float* amax_u);
-ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, const float* Uf, const float* Ub, long ldu, void* sync,
-                              size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream);
-/* Forward ring with the layer's input projection z_t = x_t.Wx + b computed INSIDE it by four extra waves per workgroup that work one step
- * ahead of the ring (the ring's MFMA pipes idle ~55 % of a step otherwise): replaces ams_gemm_f32 (projection) + ams_blstm_ring_fwd.  G is output only (activated gates).
- * x [B,T,D]; Wxf / Wxb: the input rows of the two direction kernels, row stride ldw; ams_blstm_ring_proj_ok(B, H, D): D % 4 == 0,
- * D <= 640 and at most 256 workgroups (8 waves each, one per CU: 4 ring waves + 4 projection waves). */
-int ams_blstm_ring_proj_ok(int B, int H, int D);
-ams_status ams_blstm_ring_fwd_proj(const float* x, int D, const float* Wxf, const float* Wxb, long ldw, const float* bf, const float* bb,
-                                   float* G, float* out, float* cst, float* tch, const float* Uf, const float* Ub, long ldu, void* sync,
-                                   size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream);
+/* amax_u (may be NULL): device pointer to an upper bound of max |U| over both recurrent kernels -> the recurrent product h_{t-1} . U runs
+   as fp16x3 instead of bf16x6 -- U scaled by a power of two from *amax_u and split exactly into two fp16 terms, h_{t-1} (|h| < 1)
+   scaled by 2^13, three fp16 MFMA products, the two cross terms in their own accumulator.  27 instead of 54 MFMAs per wave and step,
+   149 instead of 196 VGPRs.  AMS_LSTM_RING_F16=0 or NULL: bf16x6. */
+ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, const float* Uf, const float* Ub, long ldu, const float* amax_u,
+                              void* sync, size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream);
 ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* tch, const float* dout, float* dbpart, const float* Uf, const float* Ub,
                               long ldu, void* sync, size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream);
 
@@ -244,7 +204,7 @@ ams_status ams_dpcl_loss_bwd(const float* V, const float* Y, const float* inv, c
  * The backward recomputes v = u*inv and applies d loss/dV and the l2-normalise Jacobian in one pass. */
 /* Byte offset, inside the ams_dpcl_loss_fwd_u workspace, of ONE float: max |dU| of the latest ams_dpcl_loss_bwd_u on that workspace
    (cleared by ams_dpcl_loss_fwd_u, raised by every backward since: always an upper bound of the latest dU).  It is the operand
-   bound ams_gemm_set_amax wants for the dense layer's dX and dW products, produced without another pass over the 210 MB of dU.
+   operand bound (amax_a / amax_b of the product entry points) of the dense layer's dX and dW products, produced without another pass over the 210 MB of dU.
    (ams_dpcl_loss_bwd_u takes the workspace as const: this slot is the one thing it writes there.) */
 size_t ams_dpcl_u_amax_offset(int B, long TF, int E, int S);
 size_t ams_dpcl_u_workspace_bytes(int B, long TF, int E, int S);
@@ -283,34 +243,6 @@ ams_status ams_silence_weights(const float* lat, float* w, int rows, long n, flo
 ams_status ams_pretrain_separator_fwd(const float* y, float* out, int B, int S, long TN, int mode, void* stream);
 ams_status ams_pretrain_separator_bwd(const float* dout, float* dy, int B, int S, long TN, int mode, void* stream);
 
-/* ---- f32 products from PRE-SPLIT operands ("x3 images", csrc/gemm_x3.hip) -- same call sites as ams_gemm_f32 (tf.matmul / conv1d
- * k=1 / dynamic_rnn projections and their gradients, utils/ops.py:366-383, 501-503) ----
- * x3 image of a logical row-major f32 matrix X[R, C]: every element split EXACTLY into three bf16 terms (hi + mid + lo == x), stored
- * in 8-row x 16-column units of 768 bytes, [plane][column group of 8][row % 8][column % 8]; rows and columns zero-padded to multiples
- * of 256.  The layout is the LDS image the MFMA operand fragments are read from, so the product's main loop is LDS-DMA -> ds_read ->
- * v_mfma_f32_32x32x16_bf16 with no split arithmetic; arithmetic and error class are those of the bf16x6 form of ams_gemm_f32 (six
- * partial products, two accumulator sets), in EVERY launch configuration.
- * ams_x3_split            img <- X[R, C] (row stride ld floats); writes the whole padded image.
- * ams_x3_split_colsum     the same, and csum[C] (+)= column sums of X in the same pass (fixed order).
- * ams_x3_split_shifted    img <- time-shifted BLSTM output for the recurrent-kernel gradients: logical [B*T, 2 * Hp], Hp = H rounded
- *                         up to 8; columns [0, H) = out[b, t-1, 0:H] (0 at t = 0), [Hp, Hp + H) = out[b, t+1, H:2H] (0 at t = T-1).
- * ams_gemm_x3             C[M, N] (+)= op(A) op(B) (+ bias).  role 0: the contraction index runs along the image's COLUMNS
- *                         (A[m, k] = X[r0 + m, c0 + k]); role 1: along its ROWS (A[m, k] = X[r0 + k, c0 + m]); same for B with n.
- *                         Offsets: multiples of 8 along m / n, of 32 along k.  nbatch products share one launch (z-th: m offset
- *                         + z * a_m_zs, n offset + z * b_n_zs, C + z * c_zs).  ws from ams_gemm_x3_workspace_bytes (split-K slabs).
- * ams_x3_set_capped       thread-local: launches that follow run one 4-wave workgroup per CU (beside a recurrence ring). */
-size_t ams_x3_image_bytes(int R, int C);
-ams_status ams_x3_split(const float* X, long ld, int R, int C, void* img, void* stream);
-size_t ams_x3_split_colsum_workspace_bytes(int R, int C);
-ams_status ams_x3_split_colsum(const float* X, long ld, int R, int C, void* img, float* csum, int accumulate, void* ws, size_t ws_bytes,
-                               void* stream);
-ams_status ams_x3_split_shifted(const float* out, long ld, int BT, int T, int H, void* img, void* stream);
-void ams_x3_set_capped(int on);
-size_t ams_gemm_x3_workspace_bytes(int M, int N, int K, int nbatch);
-ams_status ams_gemm_x3(int roleA, int roleB, int M, int N, int K, const void* A, int a_R, int a_C, int a_r0, int a_c0, const void* B,
-                       int b_R, int b_C, int b_r0, int b_c0, float* C, long ldc, long c_zs, const float* bias, int accumulate, int nbatch,
-                       int a_m_zs, int b_n_zs, void* ws, size_t ws_bytes, void* stream);
-
 /* ---- default-on terms of the pre-training objective   models/adapt.py:127-132 (p_hat, sparse_constraint), 310-316 and 377-384
  * (regularization, non-negativity), utils/ops.py:46-54 (kl_div / logfunc); CLI defaults utils/trainer.py:151-161 ----
  * ams_abs_colsum_fwd:       p_hat[M] = sum_b |y[b, m]| over the Bt rows (tf.reduce_sum(tf.abs(y), 0)); fixed slab order.
@@ -348,7 +280,7 @@ ams_status ams_frames_matmul(const float* x, const float* Bm, float* out, int R,
 
 size_t ams_frames_matmul_bwd_filter_workspace_bytes(int R, int W, int N, int T);
 ams_status ams_frames_matmul_bwd_filter(const float* x, const float* dy, float* dB, int R, int L, int W, int N, int hop, int T,
-                                        int pad_left, void* ws, size_t ws_bytes, void* stream);
+                                        int pad_left, void* ws, size_t ws_bytes, void* counters, int n_counters, void* stream);
 
 /* ---- K5/K21 overlap-and-add: out[r,l] = sum_t frames[r,t,l+pad_left-t*hop]
  * second half of tf.nn.conv2d_transpose (models/adapt.py:241-243) and of inverse_stft (models/network.py:598-602) ---- */

@@ -42,15 +42,14 @@ def ops():
     return o
 
 
-@pytest.mark.parametrize('D,ring', [(600, '1'), (256, '1'), (600, 'safe'), (600, '0'), (600, 'proj')])
+@pytest.mark.parametrize('D,ring', [(600, '1'), (256, '1'), (600, 'safe'), (600, '0')])
 def test_blstm_layer_at_benchmark_shape(ops, monkeypatch, D, ring):
     """One BLSTM layer, B=64, T=80, H=300, D=600 (layers 1-2) / 256 (layer 0): forward and full backward through the DEFAULT
     recurrence -- 8 chain-per-XCD rings of 25 workgroups (csrc/lstm_ring.hip) -- plus its write-through hand-off and the per-step
     kernels (AMS_LSTM_XCD=2 grid) it falls back to (reference utils/ops.py:358-383)."""
     import os
     assert os.environ.get('AMS_LSTM_XCD', '2') == '2'
-    monkeypatch.setattr(ops, 'LSTM_RING', '1' if ring == 'proj' else ring)
-    monkeypatch.setattr(ops, 'LSTM_RING_PROJ', ring == 'proj')
+    monkeypatch.setattr(ops, 'LSTM_RING', ring)
     assert ops.load().ams_blstm_ring_sync_bytes(B, H, 0) != 0 and ops.load().ams_blstm_ring_sync_bytes(B, H, 1) != 0
     rng = np.random.RandomState(D)
     lim = np.sqrt(6.0 / (D + 5 * H))
@@ -76,7 +75,7 @@ def test_blstm_layer_at_benchmark_shape(ops, monkeypatch, D, ring):
 @pytest.mark.parametrize('D', [600, 256])
 def test_forward_ring_as_fp16x3_at_benchmark_shape(ops, D):
     """The same layer with the bounds a training step supplies (functional.BLSTMLayer: input bound, ONE bound over all kernels):
-    input projection AND the ring's recurrent product run as fp16x3 (ams_gemm_set_amax / ams_blstm_ring_set_amax).  Same forward
+    input projection AND the ring's recurrent product run as fp16x3 (amax_a / amax_b of ams_gemm_f32, amax_u of ams_blstm_ring_fwd).  Same forward
     tolerance as the bf16x6 form; the two forms differ (the arithmetic did change) by less than that tolerance."""
     rng = np.random.RandomState(D)
     lim = np.sqrt(6.0 / (D + 5 * H))
@@ -185,14 +184,12 @@ def gemm_arith():
     lib.ams_gemm_set_arith(before)
 
 
-@pytest.mark.parametrize('hip_graph,arith,x3_side', [(False, 1, False), (True, 1, False), (False, 0, False), (True, 1, True)])
-def test_front_dpcl_step_at_benchmark_shape(hip_graph, arith, x3_side, gemm_arith, monkeypatch):
+@pytest.mark.parametrize('hip_graph,arith', [(False, 1), (True, 1), (False, 0)])
+def test_front_dpcl_step_at_benchmark_shape(hip_graph, arith, gemm_arith, monkeypatch):
     """The step bench.py times -- front_DPCL, B=64, full geometry -- against the float64 oracle: cost, every gradient, every
     updated weight after AMSGrad; eager and as the replayed hipGraph (3rd call = first replay), with the default bf16x6 products
     and, eager, with the native f32 MFMA products: the SAME tolerances hold for both arithmetics."""
     from tests.smoke_step import build_front_dpcl
-    from ams_hip import functional as Fn
-    monkeypatch.setattr(Fn, 'X3_SIDE', x3_side)          # side-stream weight gradients from pre-split images (AMS_X3_SIDE=1)
     gemm_arith(arith)
     tmp = tempfile.mkdtemp(prefix='ams_benchshape_')
     trainer, tfds = build_front_dpcl(tmp, B=B, L=L, W=W, N=N, hop=HOP, layer_size=LS, nb_layers=NL, E=E, no_summaries=True,
@@ -269,13 +266,9 @@ def test_ring_recurrence_is_bit_stable_under_uneven_load(ops):
     gen = np.random.RandomState(3)
     for rep in range(12):
         n_before, n_during = int(gen.randint(0, 3)), int(gen.randint(1, 6))
-        lib.ams_gemm_set_lds_pad(50000)                 # the product's residency cap for launches beside a ring
-        try:
-            with torch.cuda.stream(side):
-                for _ in range(n_before + n_during):
-                    ops.gemm(a, bmat)
-        finally:
-            lib.ams_gemm_set_lds_pad(0)
+        with ops.lds_pad(50000), torch.cuda.stream(side):       # the product's residency cap for launches beside a ring
+            for _ in range(n_before + n_during):
+                ops.gemm(a, bmat)
         got = layer()
         torch.cuda.synchronize()
         for i, (g, r) in enumerate(zip(got, ref)):

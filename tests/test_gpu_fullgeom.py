@@ -48,7 +48,6 @@ def test_blstm_layer_at_cfg5_batch(ops, monkeypatch, ring):
     forward + full backward against the float64 oracle, plain and write-through hand-off (utils/ops.py:358-383)."""
     B, D = 128, 600
     monkeypatch.setattr(ops, 'LSTM_RING', ring)
-    monkeypatch.setattr(ops, 'LSTM_RING_PROJ', False)
     assert ops.load().ams_blstm_ring_sync_bytes(B, H, 0) != 0 and ops.load().ams_blstm_ring_sync_bytes(B, H, 1) != 0, \
         'B=128 must run on the ring recurrence (the geometry under test), not on the per-step fallback'
     rng = np.random.RandomState(128)

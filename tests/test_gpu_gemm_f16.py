@@ -1,4 +1,4 @@
-"""GPU: fp16x3 product arithmetic (csrc/gemm.hip, include/ams.h::ams_gemm_set_amax) against float64, next to bf16x6 and the f32 MFMA.
+"""GPU: fp16x3 product arithmetic (csrc/gemm.hip, include/ams.h: amax_a / amax_b of the product entry points) against float64, next to bf16x6 and the f32 MFMA.
 
 The reference's products are f32 tf.matmul / conv2d.  fp16x3 issues each of them as three fp16 MFMA products of
 operands scaled by a power of two taken from a per-tensor bound and split exactly into two fp16 terms.  What must hold:
@@ -51,7 +51,7 @@ def test_fp16x3_matches_float64_like_the_other_arithmetics(ops, M, N, K, tA, tB)
     finally:
         lib.ams_gemm_set_arith(1)
     assert e16 <= max(1.5 * max(e6, e32), 3e-8), (e16, e6, e32)
-    # the setting was one-shot: the next launch without bounds is bf16x6 again, bit for bit
+    # bounds are arguments, not state: the next launch without them is bf16x6 again, bit for bit
     assert torch.equal(ops.gemm(A, B, transA=bool(tA), transB=bool(tB)), out6)
 
 
@@ -90,12 +90,9 @@ def test_fp16x3_under_the_residency_cap_and_with_split_k(ops):
     for (M, N, K, tA, tB) in [(600, 2400, 5120, 1, 0), (600, 10240, 2560, 1, 0), (5120, 600, 2400, 0, 1)]:
         A, B, A64, B64 = _ops_pair(rng, M, N, K, tA, tB, 1e-4, 3.0)
         bounds = (ops.absmax(A), ops.absmax(B))
-        lib.ams_gemm_set_lds_pad(50000)
-        try:
+        with ops.lds_pad(50000):
             capped = ops.gemm(A, B, transA=bool(tA), transB=bool(tB), amax=bounds)
             capped6 = ops.gemm(A, B, transA=bool(tA), transB=bool(tB))
-        finally:
-            lib.ams_gemm_set_lds_pad(0)
         free = ops.gemm(A, B, transA=bool(tA), transB=bool(tB), amax=bounds)
         # the capped variants run one accumulator (tests/test_gpu_gemm_x6.py pins what that costs bf16x6): same ceiling here
         e_c, e_c6, e_f = _err(capped, A64, B64), _err(capped6, A64, B64), _err(free, A64, B64)
@@ -127,11 +124,8 @@ def test_fp16x3_weight_gradient_bias_capped_and_free(ops, M, N, K):
         finally:
             lib.ams_gemm_set_arith(1)
         free = (ops.gemm(a, b, transA=True, amax=bounds).double().cpu().numpy() - ref) / scale
-        lib.ams_gemm_set_lds_pad(50000)
-        try:
+        with ops.lds_pad(50000):
             cap = (ops.gemm(a, b, transA=True, amax=bounds).double().cpu().numpy() - ref) / scale
-        finally:
-            lib.ams_gemm_set_lds_pad(0)
         r0 = np.sqrt((d0 ** 2).mean())
         print('fp16x3 %s %dx%dx%d: native mean %.2e rms %.2e | free mean %.2e rms %.2e | capped mean %.2e rms %.2e'
               % (kind, M, N, K, d0.mean(), r0, free.mean(), np.sqrt((free ** 2).mean()), cap.mean(), np.sqrt((cap ** 2).mean())))

@@ -236,11 +236,9 @@ def test_x6_accumulation_is_unbiased(ops, arith, K, kind):
 def capped():
     """Launch products the way every weight-gradient product of a training step is launched (ams_hip/functional.py::_Overlap:
     side stream, residency cap of 2 workgroups per CU beside a recurrence ring)."""
-    from ams_hip._lib import load
-    lib = load()
-    lib.ams_gemm_set_lds_pad(50000)
-    yield
-    lib.ams_gemm_set_lds_pad(0)
+    from ams_hip import ops
+    with ops.lds_pad(50000):
+        yield
 
 
 def _bias_stats(c, ref, scale):
@@ -252,9 +250,8 @@ def _bias_stats(c, ref, scale):
 # beside a recurrence-ring wave: csrc/gemm.hip, SEP).  All six partial products in one accumulator meet the bf16 MFMA's truncating
 # adder: a COHERENT error toward -inf, measured -0.9e-7 of the term scale at K = 5120 on zero-mean data -- 20x the 5e-9 the
 # two-accumulator form is held to, and what AMSGrad's first moment would integrate over steps.  These tests pin that number (it
-# must not grow) and say where the unbiased alternative is: AMS_X3_SIDE=1 runs the same products from pre-split images with two
-# accumulator sets in every configuration (tests/test_gpu_gemm_x3.py::test_x3_weight_gradient_products_are_unbiased holds THAT to
-# 5e-9 at these shapes; tests/test_gpu_benchshape.py runs the B=64 step both ways), at -3 % step throughput.
+# must not grow).  (An unbiased form of the capped launches -- products from pre-split operand images with two accumulator sets --
+# was built and measured in round 3, -3 % step throughput, and left the tree in round 4: DESIGN.md 4.0b, commit 7fd39ac.)
 CAPPED_BIAS_BOUND = 3e-7
 
 

@@ -109,16 +109,14 @@ def test_make_masks(ops):
         assert np.array_equal(host(Y).reshape(B, T, F, S), Y_ref)
 
 
-@pytest.mark.parametrize('ring', ['1', 'safe', '0', 'proj'])
+@pytest.mark.parametrize('ring', ['1', 'safe', '0'])
 @pytest.mark.parametrize('B,T,D,H', [(5, 7, 12, 8), (20, 9, 24, 20), (3, 4, 16, 300), (17, 6, 10, 6), (33, 12, 8, 37), (4, 5, 6, 336),
                                        (2, 3, 4, 340), (6, 10, 600, 24), (5, 8, 256, 40), (3, 6, 644, 16)])
 def test_blstm_layer(ops, monkeypatch, B, T, D, H, ring):
     """ring = '1': chain-per-XCD ring recurrence (csrc/lstm_ring.hip; plain-store hand-off where the chain shares an L2),
     'safe': the same with the placement-independent write-through hand-off forced, '0': per-step kernels (csrc/lstm.hip).
     H = 340 exceeds the ring's register-resident weight budget and takes the per-step path in every mode."""
-    # 'proj': ring recurrence with the layer's input projection computed inside the forward ring (ams_blstm_ring_fwd_proj; opt-in)
-    monkeypatch.setattr(ops, 'LSTM_RING', '1' if ring == 'proj' else ring)
-    monkeypatch.setattr(ops, 'LSTM_RING_PROJ', ring == 'proj')
+    monkeypatch.setattr(ops, 'LSTM_RING', ring)
     assert (ops.load().ams_blstm_ring_sync_bytes(B, H, 0) != 0) == (H <= 336)
     rng = np.random.RandomState(B * T + H)
     lim = np.sqrt(6.0 / (D + 5 * H))

@@ -357,43 +357,6 @@ def test_mask_weighting_and_silence_weights(ops, mode, sil):
     assert (host(w) != w_ref).sum() <= 2
 
 
-# ---- opt-in overlap forms of the BLSTM forward (ams_hip/ops.py FWD_BANDS / TAIL_CUTS; default off) ----
-@pytest.mark.gpu
-@pytest.mark.parametrize('B,T,D,H', [(5, 40, 24, 20), (3, 33, 16, 12)])
-def test_blstm_banded_and_tail_overlap_match_plain(ops, monkeypatch, B, T, D, H):
-    """Row-segmented projection (ams_gemm_f32_rowseg) + step ranges (ams_blstm_recurrent_fwd_steps): a time-banded input
-    projection, and a next-layer projection / dense product fed from the tail of the recurrence, give the plain results."""
-    from oracle import blstm as oblstm, dense as odense
-    rng = np.random.RandomState(T * 7 + H)
-    lim = np.sqrt(6.0 / (D + 5 * H))
-    x = rng.randn(B, T, D)
-    Kf, Kb = rng.uniform(-lim, lim, (D + H, 4 * H)) * 3, rng.uniform(-lim, lim, (D + H, 4 * H)) * 3
-    bf, bb = rng.randn(4 * H) * 0.1, rng.randn(4 * H) * 0.1
-    out_ref, _ = oblstm.blstm_fwd(x, Kf, bf, Kb, bb)
-    xd, Kfd, Kbd, bfd, bbd = dev(x), dev(Kf), dev(Kb), dev(bf), dev(bb)
-    monkeypatch.setattr(ops, 'FWD_BANDS', '%d,%d' % (T // 10 + 1, T // 2))
-    out, G, cst = ops.blstm_fwd(xd, Kfd, bfd, Kbd, bbd)
-    torch.cuda.synchronize()
-    assert rel(host(out), out_ref) < TOL
-    monkeypatch.setattr(ops, 'FWD_BANDS', '0')
-    # tail-fed dense consumer
-    W, b = rng.randn(2 * H, 50) * 0.3, rng.randn(50) * 0.1
-    Wd, bd = dev(W), dev(b)
-    monkeypatch.setitem(ops.TAIL_CUTS, 'dense', '48,64')
-    out2, _, _ = ops.blstm_fwd(xd, Kfd, bfd, Kbd, bbd, consumer=('dense', Wd, bd))
-    u = ops.dense_fwd(out2, Wd, bd)
-    torch.cuda.synchronize()
-    assert not ops._TAIL_READY                                             # the partial result was picked up
-    assert rel(host(out2), out_ref) < TOL
-    assert rel(host(u), out_ref.reshape(B * T, 2 * H).dot(W).reshape(B, T, 50) + b) < TOL
-    # a consumer that does not match drops the partial result and recomputes
-    out3, _, _ = ops.blstm_fwd(xd, Kfd, bfd, Kbd, bbd, consumer=('dense', Wd, bd))
-    W2 = dev(W * 2.0)
-    u2 = ops.dense_fwd(out3, W2, bd)
-    torch.cuda.synchronize()
-    assert rel(host(u2), out_ref.reshape(B * T, 2 * H).dot(2.0 * W).reshape(B, T, 50) + b) < TOL
-
-
 @pytest.mark.parametrize('Bt,T,N,scale', [(9, 64, 16, 0.02), (192, 80, 256, 0.004), (5, 7, 3, 0.3)])
 def test_sparsity_kl_and_regulariser_kernels(F, ops, Bt, T, N, scale):
     """p_hat = sum_b |y|, sum kl_div(p, p_hat) with both clip_by_value gates (models/adapt.py:130-132, utils/ops.py:46-54), the

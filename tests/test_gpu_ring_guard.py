@@ -94,8 +94,9 @@ def test_a_flagged_training_step_is_repeated_on_the_step_kernels(ops, hip_graph)
 
 
 def test_flagged_evaluation_batches_are_recomputed(ops):
-    """valid_batch / infer / get_embeddings with the word raised: the batch is recomputed on the per-step kernels and the word
-    cleared; the value equals the unflagged one."""
+    """valid_batch / infer / get_embeddings with the word raised DURING the evaluation: the batch is recomputed on the per-step kernels
+    and the word cleared.  Raised BEFORE it (an unhandled training step): the batch is still evaluated on the per-step
+    kernels but the word stays up for its owner (Trainer.train checks it right after the step).  The value equals the unflagged one."""
     from tests.smoke_step import build_front_dpcl
     from models.network import Network
     tmp = tempfile.mkdtemp(prefix='ams_guard_eval_')
@@ -104,14 +105,28 @@ def test_flagged_evaluation_batches_are_recomputed(ops):
     with g.as_default():
         feed = {tfds.handle: tfds.get_handle(tfds.VALID), tfds.chunk_size: 2048}
         vals = []
-        for flagged in (False, True):
+        for flagged in (None, 'during', 'before'):
             tfds.initialize(tfds.VALID)
             before = Network.ring_fallbacks
-            if flagged:
+            node, orig, calls = model.cost_model, model.cost_model.fn, []
+            if flagged == 'before':
                 ops.ring_error_word().fill_(1)
-            vals.append(model.valid_batch(feed, 0))
-            assert Network.ring_fallbacks - before == (1 if flagged else 0) and not ops.ring_error_pending()
-    assert abs(vals[0] - vals[1]) <= 2e-5 * abs(vals[0]), vals
+            if flagged == 'during':
+                def fn(run):
+                    out = orig(run)
+                    if not calls:
+                        ops.ring_error_word().fill_(1)          # "a ring launch of this evaluation gave up"
+                    calls.append(1)
+                    return out
+                node.fn = fn
+            try:
+                vals.append(model.valid_batch(feed, 0))
+            finally:
+                node.fn = orig
+            assert Network.ring_fallbacks - before == (1 if flagged else 0)
+            assert ops.ring_error_pending() == (flagged == 'before')
+            ops.ring_errors_clear()
+    assert abs(vals[0] - vals[1]) <= 2e-5 * abs(vals[0]) and abs(vals[0] - vals[2]) <= 2e-5 * abs(vals[0]), vals
 
 
 def test_results_survive_foreign_uncapped_products_on_a_third_stream(ops):

@@ -41,7 +41,7 @@ def main():
     ap.add_argument('--pad', type=int, default=0, help='dynamic-LDS pad = residency cap of the launches (the step uses 50000 beside a ring)')
     a = ap.parse_args()
     lib = load()
-    lib.ams_gemm_set_lds_pad(a.pad)
+    ops.LDS_PAD[0] = a.pad
     rng = np.random.RandomState(0)
     only = [w for w in a.only.split(',') if w]
     for label, M, N, K, tA, tB in SHAPES:

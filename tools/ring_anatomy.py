@@ -25,21 +25,17 @@ ops.gemm(x.view(B * T, D), ops.blstm_wcat(Kf, Kb, D), bias=torch.cat([bf, bb]), 
 ldu = Kf.stride(0)
 p = lambda t: t.data_ptr()                                                                  # noqa: E731
 st = torch.cuda.current_stream().cuda_stream
-names = {'fwdp': ['wait for h + projection chunks', 'x prefetch + MFMA + acc to LDS', 'barrier', 'gate epilogue + granule store', 'G/cst/out stores'],
-         'fwd': ['wait for h', 'MFMA + acc to LDS', 'barrier', 'gate epilogue + granule store', 'G/cst/out stores'],
+names = {'fwd': ['wait for h', 'MFMA + acc to LDS', 'barrier', 'gate epilogue + granule store', 'G/cst/out stores'],
          'bwd': ['flag wait', 'partial tiles load + sum', 'gate math + LDS write', 'barrier', 'MFMA + tile stores', 'store drain', 'barrier',
                  'flag store']}
 for mode, safe in (('plain stores (same L2)', 2), ('write-through', 3)):
-    for kind in ('fwd', 'fwdp', 'bwd'):
+    for kind in ('fwd', 'bwd'):
         n = lib.ams_blstm_ring_sync_bytes(B, H, int(kind == 'bwd'))
         sync = torch.zeros(n // 4 + 1, dtype=torch.float32, device='cuda')
         G.copy_(G0 if kind == 'bwd' else Gz)
         torch.cuda.synchronize()
-        if kind == 'fwdp':
-            ops.check(lib.ams_blstm_ring_fwd_proj(p(x), D, p(Kf), p(Kb), ldu, p(bf), p(bb), p(G), p(out), p(cst[0]), p(cst[1]), p(Kf[D:]), p(Kb[D:]),
-                                                  ldu, p(sync), n, None, B, T, H, safe, st), 'fp')
-        elif kind == 'fwd':
-            ops.check(lib.ams_blstm_ring_fwd(p(G), p(out), p(cst[0]), p(cst[1]), p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, None, B, T, H, safe, st), 'f')
+        if kind == 'fwd':
+            ops.check(lib.ams_blstm_ring_fwd(p(G), p(out), p(cst[0]), p(cst[1]), p(Kf[D:]), p(Kb[D:]), ldu, None, p(sync), n, None, B, T, H, safe, st), 'f')
         else:
             ops.check(lib.ams_blstm_ring_bwd(p(G), p(cst[0]), p(cst[1]), p(dout), None, p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, None, B, T, H, safe, st), 'b')
         torch.cuda.synchronize()
@@ -61,18 +57,16 @@ if '--beside' in sys.argv:
             sync = torch.zeros(n // 4 + 1, dtype=torch.float32, device='cuda')
             G.copy_(G0 if kind == 'bwd' else Gz)
             torch.cuda.synchronize()
-            with torch.cuda.stream(side):
-                lib.ams_gemm_set_lds_pad(pad)
+            with torch.cuda.stream(side), ops.lds_pad(pad):
                 for _ in range(3):
                     ops.gemm(A, Bm, transA=True, out=Cm)
-                lib.ams_gemm_set_lds_pad(0)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda._sleep(200000)                         # let the product fill the chip first (~100 us)
             e0.record()
             if kind == 'bwd':
                 ops.check(lib.ams_blstm_ring_bwd(p(G), p(cst[0]), p(cst[1]), p(dout), None, p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, None, B, T, H, 2, st), 'b')
             else:
-                ops.check(lib.ams_blstm_ring_fwd(p(G), p(out), p(cst[0]), p(cst[1]), p(Kf[D:]), p(Kb[D:]), ldu, p(sync), n, None, B, T, H, 2, st), 'f')
+                ops.check(lib.ams_blstm_ring_fwd(p(G), p(out), p(cst[0]), p(cst[1]), p(Kf[D:]), p(Kb[D:]), ldu, None, p(sync), n, None, B, T, H, 2, st), 'f')
             e1.record()
             torch.cuda.synchronize()
             w = sync[:64].view(torch.int64).cpu().numpy()
