@@ -94,13 +94,16 @@ def reset_default_graph():
 class Run(object):
     """One evaluation pass (the analogue of a sess.run call): memoises node values and carries the feeds."""
 
-    def __init__(self, feeds=None, training=True):
+    def __init__(self, feeds=None, training=True, new_pass=True):
         self.cache = {}
         self.feeds = feeds or {}
         self.training = training
-        from . import ops
-        ops.PASS[0] += 1                # weight bounds of the fp16x3 products are measured once per pass (ops.param_amax)
-        self.begun = False
+        if new_pass:
+            from . import ops
+            ops.PASS[0] += 1            # weight bounds of the fp16x3 products are measured once per pass (ops.param_amax)
+        # new_pass=False: an auxiliary Run (input probe, the front end of the NEXT batch computed inside this step): it neither counts as
+        # a pass nor begins one
+        self.begun = not new_pass
 
 
 _RUNNING = []                           # the Runs whose nodes are being evaluated (innermost last)

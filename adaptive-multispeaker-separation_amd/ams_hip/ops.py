@@ -148,7 +148,7 @@ def front_conv(x, f, hop):
     ws = _ws(nb, x) if nb else None
     ev = PROFILE.begin() if PROFILE.enabled else None
     cnt = _counters(x) if nb else None
-    check(lib.ams_front_conv_fwd(_p(x), _p(f), _p(y), Bt, L, W, N, hop, _p(ws), nb, _p(cnt), (N_COUNTERS if cnt is not None else 0), _s()),
+    check(lib.ams_front_conv_fwd(_p(x), _p(f), _p(y), Bt, L, W, N, hop, LDS_PAD[0], _p(ws), nb, _p(cnt), (N_COUNTERS if cnt is not None else 0), _s()),
           'ams_front_conv_fwd')
     if ev is not None:      # algorithmic bytes: waveform in, frames out, filter once
         PROFILE.end(ev, 2.0 * Bt * T * N * W, 4.0 * (Bt * L + Bt * T * N + W * N), 'gemm<2,0>', 'front_conv')
@@ -593,13 +593,30 @@ def ring_error_word(device=None):
     return t
 
 
+_ERR_EXTRA = []                                                     # weak refs: words that carry OTHER ranks' ring errors (optim.FlatOptimizer)
+
+
+def register_error_word(t):
+    """A 1-element tensor that is non-zero when a PEER rank's ring launch gave up (the slot the data-parallel optimizer sends through
+    its gradient all-reduce): ring_error_pending() reads it next to this device's own word, ring_errors_clear() zeroes it."""
+    import weakref
+    _ERR_EXTRA.append(weakref.ref(t))
+
+
+def _err_words():
+    live = [r for r in _ERR_EXTRA if r() is not None]
+    _ERR_EXTRA[:] = live
+    return list(_RING_ERR.values()) + [r() for r in live]
+
+
 def ring_error_pending():
-    """True when a ring launch since the last ring_errors_clear() abandoned a bounded wait (one host sync)."""
-    return any(bool(t.item() != 0) for t in _RING_ERR.values())
+    """True when a ring launch since the last ring_errors_clear() abandoned a bounded wait -- on this rank, or (data parallel) on any
+    rank as of the last gradient exchange (one host sync per word)."""
+    return any(bool(t.item() != 0) for t in _err_words())
 
 
 def ring_errors_clear():
-    for t in _RING_ERR.values():
+    for t in _err_words():
         t.zero_()
 
 

@@ -24,7 +24,17 @@ class FlatOptimizer(object):
         n = sum(v.numel() for v in self.vars)
         dev = self.vars[0].device if self.vars else torch.device('cpu')
         self.flat = torch.empty(n, dtype=torch.float32, device=dev)
-        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        # Data parallel on GPUs: ONE extra element behind the gradients carries the recurrence rings' error word through the SAME
+        # all-reduce (a rank whose ring gave up must make every rank skip the update and repeat the step): one collective per step
+        # instead of an all_reduce_max of the word followed by the all_reduce of the gradients.
+        self._dp = dist is not None and getattr(dist, 'world_size', 1) > 1
+        extra = 1 if (self._dp and dev.type == 'cuda') else 0
+        self._gbuf = torch.zeros(n + extra, dtype=torch.float32, device=dev)
+        self.flat_grad = self._gbuf[:n]
+        self._errslot = self._gbuf[n:n + 1] if extra else None
+        if self._errslot is not None:
+            ops.register_error_word(self._errslot)
+        self.exchange_events = None              # bench.py: list of (start, end) events around the gradient all-reduce
         off = 0
         ids = set(id(v) for v in self.vars)
         placed = set()
@@ -85,16 +95,25 @@ class FlatOptimizer(object):
         """defer: zeroed on the side stream when the next evaluation pass begins (ops.zero_deferred) -- for callers whose backward
         pass starts with ops.flush_deferred_zero() + ops.await_pass_side() (Network._backward)."""
         if defer:
-            ops.zero_deferred(self.flat_grad)
+            ops.zero_deferred(self._gbuf)
         else:
-            self.flat_grad.zero_()
+            self._gbuf.zero_()
 
     def exchange(self):
         """Data-parallel gradient exchange: ONE all-reduce (sum) of the flat gradient buffer; returns the scale that
         turns it into the mean (every loss on the hot path is a batch mean) and applies the clip."""
         scale = 1.0
-        if self.dist is not None and self.dist.world_size > 1:
-            self.dist.all_reduce_sum(self.flat_grad)
+        if self._dp:
+            if self._errslot is not None and ops.LSTM_RING != '0':
+                self._errslot.copy_(ops.ring_error_word(self.flat.device))     # int32 0 / 1 -> float: summed over the ranks with the gradients
+            ev = None
+            if self.exchange_events is not None and self._gbuf.is_cuda:
+                ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev[0].record()
+            self.dist.all_reduce_sum(self._gbuf)
+            if ev is not None:
+                ev[1].record()
+                self.exchange_events.append(ev)
             scale = 1.0 / self.dist.world_size
         if self.clip != 0.0:
             gn = math.sqrt(float(self._sumsq(self.flat_grad))) * scale        # norm of the AVERAGED gradient
@@ -116,18 +135,17 @@ class FlatOptimizer(object):
         if self.flat.numel() == 0:
             return
         self._before = (getattr(self, 'b1p', None), getattr(self, 'b2p', None), self.t)
-        if self.dist is not None and self.dist.world_size > 1 and self.flat.is_cuda and ops.LSTM_RING != '0':
-            # a rank whose recurrence ring gave up makes EVERY rank skip this update (the word is the optimizers' guard) and
-            # repeat the step: the gradients it would contribute to the all-reduce are garbage
-            self.dist.all_reduce_max(ops.ring_error_word(self.flat.device))
         scale = self.exchange()
+        # a rank whose recurrence ring gave up makes EVERY rank skip this update and repeat the step (the gradients it contributed to
+        # the all-reduce are garbage): under data parallelism the guard is the summed word that travelled with the gradients
+        guard = self._errslot if (self._errslot is not None and ops.LSTM_RING != '0') else None
         if self.kind == 'Adam':
             lr_t = self.base_lr * math.sqrt(1.0 - self.b2p) / (1.0 - self.b1p)
-            ops.opt_amsgrad(self.flat, self.flat_grad, self.m, self.v, self.vhat, lr_t, self.beta1, self.beta2, self.eps, scale)
+            ops.opt_amsgrad(self.flat, self.flat_grad, self.m, self.v, self.vhat, lr_t, self.beta1, self.beta2, self.eps, scale, guard=guard)
             self.b1p *= self.beta1
             self.b2p *= self.beta2
         elif self.kind == 'RMSProp':
-            ops.opt_rmsprop(self.flat, self.flat_grad, self.ms, self.learning_rate(), 0.9, 1e-10, scale)
+            ops.opt_rmsprop(self.flat, self.flat_grad, self.ms, self.learning_rate(), 0.9, 1e-10, scale, guard=guard)
         else:
-            ops.opt_momentum(self.flat, self.flat_grad, self.acc, self.learning_rate(), 0.9, scale)
+            ops.opt_momentum(self.flat, self.flat_grad, self.acc, self.learning_rate(), 0.9, scale, guard=guard)
         self.t += 1

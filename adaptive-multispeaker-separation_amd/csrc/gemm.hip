@@ -1458,7 +1458,7 @@ size_t ams_front_conv_fwd_workspace_bytes(int Bt, int L, int W, int N, int hop) 
 }
 
 // ws (may be NULL: no split-K) lets the few-tile benchmark shape (5120 x 256 output = 80 tiles) fill 256 CUs.
-ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, void* ws,
+ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, int lds_pad, void* ws,
                               size_t ws_bytes, void* counters, int n_counters, void* stream) {
     AMS_REQUIRE(x && f && y && Bt > 0 && L > 0 && W > 0 && N > 0 && hop > 0);
     const int T = (L + hop - 1) / hop;
@@ -1470,7 +1470,8 @@ ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, 
     g.fr_L = L; g.fr_T = T; g.fr_hop = hop; g.fr_pl = pad_total / 2; g.fr_W = W;
     g.a_vec = aligned16(x) && (L % 4 == 0) && (hop % 4 == 0) && (g.fr_pl % 4 == 0);
     g.b_vec = aligned16(f) && (N % 4 == 0);
-    return launch<A_FRAMES, B_ROW>(g, LaunchOpt{}, ws, ws_bytes, Counters{(unsigned*)counters, n_counters}, (hipStream_t)stream);
+    LaunchOpt o; o.lds_pad = lds_pad;
+    return launch<A_FRAMES, B_ROW>(g, o, ws, ws_bytes, Counters{(unsigned*)counters, n_counters}, (hipStream_t)stream);
 }
 
 // Generic framed product: out[(r,t), n] = sum_k xpad[r, t*hop + k - pad_left] * Bm[k, n]   (STFT as a DFT product)

@@ -229,10 +229,10 @@ class Network(object):
         return path
 
     # --------------------------------------------------------------- session-facing methods
-    def _feeds(self, feed_dict, training):
+    def _feeds(self, feed_dict, training, new_pass=True):
         feeds = dict(feed_dict)
         feeds[self.training] = training
-        return Run(feeds, training)
+        return Run(feeds, training, new_pass)
 
     def _summaries(self, run, keys):
         g = get_default_graph()
@@ -243,22 +243,68 @@ class Network(object):
         return out
 
     # ---- hipGraph replay of forward+backward (the launch-bound inner loops: 80 recurrent steps x 6 cells x 2) ----
+    def _fetch_inputs(self, feed_dict):
+        """One batch from the input pipeline (a probe Run that only evaluates the input nodes)."""
+        # the probe only fetches the input nodes: it must NOT begin a pass (ops.pass_begin clears the ring arena and rewrites the shared
+        # weight bound on the side stream, un-joined, while the replayed graph owns both addresses) nor count as one
+        probe = self._feeds(feed_dict, True, new_pass=False)
+        return [n.value(probe) for n in (self.x_mix, self.x_non_mix, self.I)]
+
+    @staticmethod
+    def _static_like(ins):
+        """Static input buffers of a captured step: x_mix [B,L] and x_non_mix [B,S,L] back to back in one buffer (Adapt's
+        concat([x_mix, x_non_mix rows]) is then a view), the rest cloned."""
+        xm, xn = ins[0], ins[1]
+        if xm.dtype == xn.dtype and xm.dim() == 2 and xn.dim() == 3 and xm.shape[-1] == xn.shape[-1]:
+            flat = torch.empty(xm.numel() + xn.numel(), dtype=xm.dtype, device=xm.device)
+            sm, sn = flat[:xm.numel()].view(xm.shape), flat[xm.numel():].view(xn.shape)
+            sm.copy_(xm)
+            sn.copy_(xn)
+            return [sm, sn] + [t.clone() for t in ins[2:]]
+        return [t.clone() for t in ins]
+
+    def _ahead_nodes(self):
+        """Nodes of the step that depend on NOTHING but the batch and frozen variables -- the frozen front end's output and the
+        masks made from it (Adapt.front_ahead_nodes) -- when the recipe froze `front/` (connect_only_front_to_separator and the
+        fine-tuning recipes: /reference models/adapt.py:443-455): they can be computed for batch i+1 while step i runs.
+        AMS_FRONT_AHEAD=0 switches the pipelining off (A/B runs)."""
+        if os.environ.get('AMS_FRONT_AHEAD', '1') == '0' or not hasattr(self, 'front_ahead_nodes'):
+            return []
+        if any(v.ams_name.startswith('front/') for v in self.optimize.vars):
+            return []
+        return list(self.front_ahead_nodes())
+
+    def _ahead_compute(self, nodes, ins, bufs, bound, feed_dict):
+        """Evaluate the ahead nodes on the batch `ins` into the persistent buffers `bufs` (+ max |front output| into `bound`), on the
+        current stream.  A private Run: nothing of it is cached for the step's own pass."""
+        run = self._feeds(feed_dict, True, new_pass=False)
+        for node, t in zip((self.x_mix, self.x_non_mix, self.I), ins):
+            run.cache[id(node)] = t
+        with torch.no_grad(), K.lds_pad(int(os.environ.get('AMS_FRONT_AHEAD_PAD', '50000'))):
+            for node, buf in zip(nodes, bufs):
+                buf.copy_(node.value(run).reshape(buf.shape))
+            if K.F16X3:
+                K.absmax(bufs[0], out=bound)
+
     def _train_graphed(self, feed_dict, step):
         """Capture zero_grad + forward + backward once (after 2 eager steps) and replay it; inputs are copied into
-        static buffers, the optimizer (per-step lr_t, all-reduce) stays outside the graph."""
-        st = self.__dict__.setdefault('_cg_state', {'n': 0, 'graph': None,
+        static buffers, the optimizer (per-step lr_t, all-reduce) stays outside the graph.
+
+        Frozen front (self._ahead_nodes()): TWO graphs are captured, for even and odd steps.  Graph k reads batch i from input set k and
+        the front output / masks of batch i from the persistent buffers `pre[k]`, and -- on the side stream, beside its forward
+        recurrence, whose rings leave the matrix pipes ~93 % idle -- computes front output / masks of batch i+1 (already resident in
+        input set 1-k) into `pre[1-k]`.  The first projection then starts at the top of the step instead of ~140 us into it.  The
+        input pipeline is read one batch ahead; a batch that is not there (end of a pass) or is stale (the split was re-initialised)
+        is fetched at its own step and its front part computed in line."""
+        st = self.__dict__.setdefault('_cg_state', {'n': 0, 'graph': None, 'graphs': {}, 'ahead': None,
                                                     'stream': torch.cuda.Stream(priority=int(os.environ.get('AMS_MAIN_PRIORITY', '0')))})
-        probe = self._feeds(feed_dict, True)
-        # the probe only fetches the input nodes: it must NOT begin a pass (ops.pass_begin clears the ring arena and rewrites the shared
-        # weight bound on the side stream, un-joined, while the replayed graph owns both addresses)
-        probe.begun = True
-        ins = [n.value(probe) for n in (self.x_mix, self.x_non_mix, self.I)]
         opt = self.optimize
         side = st['stream']
-        if st['graph'] is None:
+        if st['graph'] is None and not st['graphs']:
             st['n'] += 1
             if st['n'] <= 2:
                 # eager warm-up ON THE CAPTURE STREAM, so autograd's AccumulateGrad nodes are bound to it
+                ins = self._fetch_inputs(feed_dict)
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     run = self._feeds(feed_dict, True)
@@ -272,16 +318,94 @@ class Network(object):
                 opt.step()
                 self.last_run = run
                 return cost.detach().reshape(-1)[0]
-            # x_mix [B,L] and x_non_mix [B,S,L] live back to back in one buffer: Adapt's concat([x_mix, x_non_mix rows]) is then a view
-            xm, xn = ins[0], ins[1]
-            if xm.dtype == xn.dtype and xm.dim() == 2 and xn.dim() == 3 and xm.shape[-1] == xn.shape[-1]:
-                flat = torch.empty(xm.numel() + xn.numel(), dtype=xm.dtype, device=xm.device)
-                sm, sn = flat[:xm.numel()].view(xm.shape), flat[xm.numel():].view(xn.shape)
-                sm.copy_(xm)
-                sn.copy_(xn)
-                st['static'] = [sm, sn] + [t.clone() for t in ins[2:]]
+            st['nodes'] = self._ahead_nodes()
+        nodes = st.get('nodes') or []
+        if not nodes:
+            return self._train_graphed_single(feed_dict, st, opt, side)
+
+        # ---------------- two alternating graphs, front end one batch ahead
+        ds = next((getattr(k_, 'dataset', None) for k_ in feed_dict if getattr(k_, 'dataset', None) is not None), None)
+        token = (feed_dict.get(ds.handle), ds.generation.get(feed_dict.get(ds.handle), 0)) if ds is not None else None
+        k = st.get('parity', 0)
+        ah = st['ahead']
+        have_cur = ah is not None and ah['token'] == token and ah['slot'] == k
+        if 'ins' not in st:                                        # first graphed call: buffers from the first batch
+            first = self._fetch_inputs(feed_dict)
+            st['ins'] = [self._static_like(first), self._static_like(first)]
+            with torch.no_grad():
+                run0 = self._feeds(feed_dict, True, new_pass=False)
+                for node, t in zip((self.x_mix, self.x_non_mix, self.I), st['ins'][0]):
+                    run0.cache[id(node)] = t
+                shapes = [node.value(run0) for node in nodes]
+            st['pre'] = [[torch.empty_like(v).contiguous() for v in shapes] for _ in range(2)]
+            st['bound'] = [torch.ones(1, dtype=torch.float32, device=shapes[0].device) for _ in range(2)]
+            st['copy_stream'] = torch.cuda.Stream()
+            cur = first
+        elif not have_cur:
+            cur = self._fetch_inputs(feed_dict)
+        if not have_cur:
+            for dst, src in zip(st['ins'][k], cur):
+                dst.copy_(src)
+            self._ahead_compute(nodes, st['ins'][k], st['pre'][k], st['bound'][k], feed_dict)      # in line: once per pass
+        # the NEXT batch, one step ahead of the trainer's loop
+        try:
+            nxt = self._fetch_inputs(feed_dict)
+        except (StopIteration, IndexError):
+            nxt = None
+        if nxt is not None:
+            cs = st['copy_stream']
+            # input set 1-k was last read by the previous step's graph: wait for THAT, not for the optimizer kernel behind it -- the
+            # copies then run beside the optimizer
+            if st.get('ev_done') is not None:
+                cs.wait_event(st['ev_done'])
             else:
-                st['static'] = [t.clone() for t in ins]
+                cs.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(cs):
+                for dst, src in zip(st['ins'][1 - k], nxt):
+                    dst.copy_(src)
+                    src.record_stream(cs)
+            torch.cuda.current_stream().wait_stream(cs)
+            st['ahead'] = {'token': token, 'slot': 1 - k}
+        else:
+            st['ahead'] = None
+        if k not in st['graphs']:
+            run = self._feeds(feed_dict, True)
+            for node, t in zip((self.x_mix, self.x_non_mix, self.I), st['ins'][k]):
+                run.cache[id(node)] = t
+            K.tag_amax(st['pre'][k][0], st['bound'][k])
+            for node, buf in zip(nodes, st['pre'][k]):
+                run.cache[id(node)] = buf
+            g = torch.cuda.CUDAGraph()
+            torch.cuda.synchronize()
+            # thread_local: a collective library's watchdog thread (RCCL at N > 1) must not be able to invalidate this capture
+            with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
+                opt.zero_grad(defer=True)
+                run.begun = True
+                K.pass_begin(F.OVERLAP.side())                     # weight bound + ring arena + gradient memset on the side stream ...
+                s2 = F.OVERLAP.side()
+                s2.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(s2):                        # ... then the NEXT batch's front end, beside this step's forward rings
+                    self._ahead_compute(nodes, st['ins'][1 - k], st['pre'][1 - k], st['bound'][1 - k], feed_dict)
+                cost = self.cost_model.value(run)
+                self._backward(cost)
+                F.OVERLAP.join()
+            st['graphs'][k] = (g, cost, run)
+        for hook in get_default_graph().pre_replay_hooks:      # host-drawn inputs of captured kernels (k-means seeds)
+            hook()
+        g, cost, run = st['graphs'][k]
+        g.replay()
+        st['ev_done'] = torch.cuda.Event()
+        st['ev_done'].record()
+        opt.step()
+        st['parity'] = 1 - k
+        self.last_run = run
+        return cost.detach().reshape(-1)[0]
+
+    def _train_graphed_single(self, feed_dict, st, opt, side):
+        """One captured graph, front end computed inside the step (front trainable, or AMS_FRONT_AHEAD=0)."""
+        ins = self._fetch_inputs(feed_dict)
+        if st['graph'] is None:
+            st['static'] = self._static_like(ins)
             run = self._feeds(feed_dict, True)
             for node, t in zip((self.x_mix, self.x_non_mix, self.I), st['static']):
                 run.cache[id(node)] = t

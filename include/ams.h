@@ -43,8 +43,8 @@ ams_status ams_front_filter_bwd(const float* w, const float* bases, const float*
 /* ---- K2  analysis filterbank, path A: tf.nn.conv2d stride=hop SAME        models/adapt.py:122 ----
  * x [Bt,L], f [W,N] -> y [Bt,T',N], T' = ceil(L/hop), pad_left = ((T'-1)hop+W-L)/2. */
 size_t ams_front_conv_fwd_workspace_bytes(int Bt, int L, int W, int N, int hop);
-ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, void* ws,
-                              size_t ws_bytes, void* counters, int n_counters, void* stream);      /* counters: see ams_gemm_f32 */
+ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, int lds_pad, void* ws,
+                              size_t ws_bytes, void* counters, int n_counters, void* stream);      /* lds_pad, counters: see ams_gemm_f32 */
 size_t ams_front_conv_bwd_filter_workspace_bytes(int Bt, int L, int W, int N, int hop);
 ams_status ams_front_conv_bwd_filter(const float* x, const float* dy, float* df, int Bt, int L, int W, int N, int hop, void* ws,
                                      size_t ws_bytes, void* counters, int n_counters, void* stream);

@@ -12,7 +12,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-from oracle import step, recipes, kmeans, front, stft, losses  # noqa: E402
+from oracle import step, recipes, kmeans, front, stft, losses, optim  # noqa: E402
 
 
 def synth(rng, B, S, L):
@@ -61,6 +61,101 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'stft.npz'), x=x, mag=np.abs(s), cos=np.cos(np.angle(s)), sin=np.sin(np.angle(s)), rec=rec)
 
 
+def _pick(rng, n, S, rows):
+    return np.stack([rng.choice(n, S, replace=False) for _ in range(rows)]).astype(np.int32)
+
+
+def _save(name, cfg, P, inputs, expect):
+    out = {'cfg/' + k: np.asarray(v) for k, v in cfg.items()}
+    out.update({'P/' + k: v for k, v in P.items()})
+    out.update({'in/' + k: v for k, v in inputs.items()})
+    out.update(expect)
+    np.savez_compressed(os.path.join(HERE, name), **out)
+
+
+def more():
+    """Round 4 (VERDICT r03 missing 1 / next 8): a multi-step TRAJECTORY of the headline recipe and single steps of the recipes the two
+    round-1 fixtures do not touch -- front_L41 (S = 3), front_DPCL_finetuning (soft k-means + back + PIT), STFT_L41_enhance, path-B
+    pre-training.  Own seeds, so the round-1 files above keep their bytes.  Sizes follow tests/test_gpu_recipes.py / test_gpu_cfg4.py."""
+    # ---- 5 AMSGrad steps of front_DPCL on ONE fixed batch (SURVEY 8c harness row: utils/trainer.py:264-390, network.py:228-232)
+    d = np.load(os.path.join(HERE, 'front_dpcl_step.npz'))
+    B, S, L, W, N, hop, LS, NL, E = [int(v) for v in d['cfg']]
+    P = {k[2:]: d[k].copy() for k in d.files if k.startswith('P/')}
+    names = sorted(k for k in P if k.startswith('prediction/'))
+    opt = optim.AMSGrad(1e-3)
+    costs = []
+    for _ in range(5):
+        c, g, _, _ = step.front_dpcl_loss(d['x_mix'], d['x_non_mix'], P, hop, NL, E)
+        costs.append(c)
+        plist = [P[n] for n in names]
+        opt.apply(plist, [g[n] for n in names])
+    out = {'costs': np.array(costs), 'cfg': d['cfg']}
+    out.update({'P5/' + n: P[n] for n in names})
+    np.savez_compressed(os.path.join(HERE, 'front_dpcl_traj.npz'), **out)
+
+    rng = np.random.RandomState(4004)
+    # ---- front_L41, three speakers (models/L41.py:150-178)
+    B, S, L, W, N, hop, LS, NL, E, NSPK = 2, 3, 1024, 64, 16, 16, 12, 2, 8, 251
+    P = step.init_params(rng, np.float64, front_W=W, N=N, D_in=N, layer_size=LS, nb_layers=NL, E=E, F=N, conv1d_scale=0.5, tot_speakers=NSPK)
+    xm, xn = synth(rng, B, S, L)
+    I = np.stack([rng.choice(NSPK, S, replace=False) for _ in range(B)]).astype(np.int64)
+    c, g, V, Y = step.front_l41_loss(xm, xn, I, P, hop, NL, E, True)
+    ex = {'cost': c, 'V': V, 'Y': Y}
+    ex.update({'G/' + k: v for k, v in g.items()})
+    _save('front_l41_step.npz', dict(B=B, S=S, L=L, W=W, N=N, hop=hop, LS=LS, NL=NL, E=E, NSPK=NSPK), P, dict(x_mix=xm, x_non_mix=xn, I=I), ex)
+
+    # ---- front_DPCL_finetuning (models/network.py:697-724 via adapt.py:339-372; Kmeans_2.py soft labels): cost, separated waveforms,
+    # and central-difference probes of the float64 oracle at the largest-gradient entries (the oracle has no analytic soft-k-means backward)
+    B, S, L, W, N, hop, LS, NL, E, tries, steps, beta = 2, 2, 1024, 64, 16, 16, 12, 2, 8, 1, 3, 4.0
+    P = step.init_params(rng, np.float64, front_W=W, N=N, D_in=N, layer_size=LS, nb_layers=NL, E=E, F=N, conv1d_scale=0.5)
+    xm, xn = synth(rng, B, S, L)
+    T = -(-L // hop)
+    idx = _pick(rng, T * N, S, B * tries)
+    args = (hop, NL, E, idx, tries, steps, beta, True, 2.0, True, 'sdr+l2')
+    c, out_w = recipes.front_finetune_cost(xm, xn, P, *args)
+    probes = []
+    for name in ('prediction/W', 'prediction/b', step.lstm_names('prediction', 1)[0], step.lstm_names('prediction', 0)[2]):
+        flat_idx = rng.choice(P[name].size, 3, replace=False)
+        for fi in flat_idx:
+            k = np.unravel_index(int(fi), P[name].shape)
+            h = 1e-5 * max(1.0, abs(P[name][k]))
+            Pp = {n: v.copy() for n, v in P.items()}
+            Pp[name][k] += h
+            cp, _ = recipes.front_finetune_cost(xm, xn, Pp, *args)
+            Pp[name][k] -= 2 * h
+            cm, _ = recipes.front_finetune_cost(xm, xn, Pp, *args)
+            probes.append((name, int(fi), (cp - cm) / (2 * h)))
+    ex = {'cost': c, 'back': out_w, 'probe_names': np.array([p[0] for p in probes]), 'probe_index': np.array([p[1] for p in probes]),
+          'probe_fd': np.array([p[2] for p in probes])}
+    _save('front_dpcl_finetuning_step.npz', dict(B=B, S=S, L=L, W=W, N=N, hop=hop, LS=LS, NL=NL, E=E, tries=tries, steps=steps, beta=beta),
+          P, dict(x_mix=xm, x_non_mix=xn, idx=idx), ex)
+
+    # ---- STFT_L41_enhance (models/network.py:610-693)
+    B, S, L, W, hop, LS, NL, E, tries, steps, LSE, NLE, NSPK = 2, 2, 1024, 64, 16, 12, 2, 8, 2, 3, 8, 2, 251
+    Fq = W // 2 + 1
+    P = step.init_params(rng, np.float64, D_in=Fq, layer_size=LS, nb_layers=NL, E=E, F=Fq, conv1d_scale=0.5, tot_speakers=NSPK)
+    P.update(step.init_enhance_params(rng, np.float64, Fq, LSE, NLE))
+    xm, xn = synth(rng, B, S, L)
+    T = 1 + (L - W) // hop
+    idx = _pick(rng, T * Fq, S, B * tries)
+    c, g = recipes.stft_enhance_loss(xm, xn, P, W, hop, NL, E, NLE, idx, tries, steps, nonlinearity='softmax')
+    ex = {'cost': c}
+    ex.update({'G/' + k: v for k, v in g.items()})
+    _save('stft_l41_enhance_step.npz', dict(B=B, S=S, L=L, W=W, hop=hop, LS=LS, NL=NL, E=E, tries=tries, steps=steps, LSE=LSE, NLE=NLE, NSPK=NSPK),
+          P, dict(x_mix=xm, x_non_mix=xn, idx=idx), ex)
+
+    # ---- pre-training, path B (--with_max_pool: models/adapt.py:115-117, 210-243)
+    B, S, L, W, N, hop, Pool = 2, 2, 1024, 64, 16, 128, 128
+    P = step.init_params(rng, np.float64, front_W=W, N=N)
+    xm, xn = synth(rng, B, S, L)
+    c, g, back, am = recipes.pretrain_loss_maxpool(xm, xn, P, Pool, hop, 'l2', 'perfect')
+    ex = {'cost': c, 'back': back, 'argmax': am}
+    ex.update({'G/' + k: v for k, v in g.items()})
+    _save('pretraining_maxpool_step.npz', dict(B=B, S=S, L=L, W=W, N=N, hop=hop, Pool=Pool), P, dict(x_mix=xm, x_non_mix=xn), ex)
+
+
 if __name__ == '__main__':
-    main()
+    if '--more-only' not in sys.argv:
+        main()
+    more()
     print('golden vectors written to', HERE)

@@ -131,3 +131,58 @@ def test_hip_matches_pretraining_golden():
     assert sorted(grads) == sorted(names)
     for n in names:
         assert rel(grads[n], gp['G/' + n]) < 1e-3, (n, rel(grads[n], gp['G/' + n]))
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# Round 4: trajectory of the headline recipe + single steps of the recipes the round-1 fixtures do not touch (make_golden.py::more)
+# ---------------------------------------------------------------------------------------------------------------------------
+def _split(d):
+    cfg = {k[4:]: (float(d[k]) if d[k].dtype.kind == 'f' else int(d[k])) for k in d if k.startswith('cfg/')}
+    P = {k[2:]: v for k, v in d.items() if k.startswith('P/')}
+    inp = {k[3:]: v for k, v in d.items() if k.startswith('in/')}
+    G = {k[2:]: v for k, v in d.items() if k.startswith('G/')}
+    return cfg, P, inp, G
+
+
+def test_oracle_reproduces_the_trajectory_golden():
+    """5 AMSGrad steps of front_DPCL on one fixed batch (SURVEY 8c harness row; reference utils/trainer.py:264-390,
+    models/network.py:228-232): cost of every step and the weights after the fifth."""
+    from oracle import optim as ooptim
+    d, t = load('front_dpcl_step.npz'), load('front_dpcl_traj.npz')
+    B, S, L, W, N, hop, LS, NL, E = [int(v) for v in d['cfg']]
+    P = {k[2:]: v.copy() for k, v in d.items() if k.startswith('P/')}
+    names = sorted(k for k in P if k.startswith('prediction/'))
+    opt = ooptim.AMSGrad(1e-3)
+    for i in range(5):
+        c, g, _, _ = ostep.front_dpcl_loss(d['x_mix'], d['x_non_mix'], P, hop, NL, E)
+        assert abs(c - t['costs'][i]) < 1e-10 * abs(t['costs'][i]), i
+        opt.apply([P[n] for n in names], [g[n] for n in names])
+    for n in names:
+        assert rel(P[n], t['P5/' + n]) < 1e-10, n
+    assert t['costs'][4] < 0.5 * t['costs'][0]                     # the fixture records a trajectory that actually moves
+
+
+def test_oracle_reproduces_the_recipe_goldens():
+    cfg, P, inp, G = _split(load('front_l41_step.npz'))
+    c, g, V, Y = ostep.front_l41_loss(inp['x_mix'], inp['x_non_mix'], inp['I'], P, cfg['hop'], cfg['NL'], cfg['E'], True)
+    d = load('front_l41_step.npz')
+    assert abs(c - d['cost']) < 1e-12 and rel(V, d['V']) < 1e-12 and np.array_equal(Y, d['Y'])
+    assert sorted(g) == sorted(G) and all(rel(g[k], G[k]) < 1e-10 for k in g)
+
+    d = load('front_dpcl_finetuning_step.npz')
+    cfg, P, inp, _ = _split(d)
+    c, back = orec.front_finetune_cost(inp['x_mix'], inp['x_non_mix'], P, cfg['hop'], cfg['NL'], cfg['E'], inp['idx'], cfg['tries'],
+                                       cfg['steps'], cfg['beta'], True, 2.0, True, 'sdr+l2')
+    assert abs(c - d['cost']) < 1e-12 * abs(d['cost']) and rel(back, d['back']) < 1e-12
+
+    d = load('stft_l41_enhance_step.npz')
+    cfg, P, inp, G = _split(d)
+    c, g = orec.stft_enhance_loss(inp['x_mix'], inp['x_non_mix'], P, cfg['W'], cfg['hop'], cfg['NL'], cfg['E'], cfg['NLE'], inp['idx'],
+                                  cfg['tries'], cfg['steps'], nonlinearity='softmax')
+    assert abs(c - d['cost']) < 1e-12 * abs(d['cost']) and all(rel(g[k], G[k]) < 1e-10 for k in g)
+
+    d = load('pretraining_maxpool_step.npz')
+    cfg, P, inp, G = _split(d)
+    c, g, back, am = orec.pretrain_loss_maxpool(inp['x_mix'], inp['x_non_mix'], P, cfg['Pool'], cfg['hop'], 'l2', 'perfect')
+    assert abs(c - d['cost']) < 1e-12 * abs(d['cost']) and rel(back, d['back']) < 1e-12 and np.array_equal(am, d['argmax'])
+    assert all(rel(g[k], G[k]) < 1e-10 for k in g)
