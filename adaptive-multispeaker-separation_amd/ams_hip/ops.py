@@ -217,7 +217,7 @@ PASS = [0]                                                       # bumped by gra
 
 class _ParamSource(object):
     """One optimizer's flat parameter buffer and the bound measured over it (shared by every variable the optimizer owns)."""
-    __slots__ = ('flat', 'bound', 'seen', 'event', 'used', '__weakref__')
+    __slots__ = ('flat', 'bound', 'seen', 'event', 'used', 'tracked', '__weakref__')
 
     def __init__(self, flat):
         self.flat = flat
@@ -225,6 +225,9 @@ class _ParamSource(object):
         self.seen = -1                  # the pass (PASS[0]) it was last measured in
         self.event = None               # measured on the side stream: recorded there, awaited by the first consumer
         self.used = -1                  # the last pass a product asked for this bound
+        # True: the optimizer keeps `bound` an upper bound of the weights by itself (its update kernels raise it, include/ams.h amax_io;
+        # optim.FlatOptimizer.track_bound): no pass measures it
+        self.tracked = False
 
 
 _SOURCES = []                                                    # weak references: a source lives as long as its variables do
@@ -241,6 +244,8 @@ def param_amax(W):
     src = getattr(W, '_ams_amax_src', None)
     if src is not None:
         src.used = PASS[0]
+        if src.tracked:
+            return src.bound
         if src.seen != PASS[0]:                                  # not measured by pass_begin() (first use of this model): measure here
             absmax(src.flat, out=src.bound)
             src.seen, src.event = PASS[0], None
@@ -382,7 +387,7 @@ def pass_begin(side_stream):
         if src is None:
             continue
         live.append(ref)
-        if not src.flat.is_cuda or src.seen == PASS[0] or src.flat.device != cur.device or src.used < PASS[0] - 2:
+        if not src.flat.is_cuda or src.tracked or src.seen == PASS[0] or src.flat.device != cur.device or src.used < PASS[0] - 2:
             continue                                            # (only models whose bound a recent pass asked for)
         todo.append(src)
     if F16X3:
@@ -416,6 +421,23 @@ def register_param_source(variables, flat):
     for v in variables:
         v._ams_amax_src = src
     _SOURCES.append(weakref.ref(src))
+    return src
+
+
+# One-shot hook: work to enqueue right BEHIND the first input projection of the pass (models/network.py::_train_graphed puts the next
+# batch's front end on the side stream there: started at the top of the step it would take the CUs the projection is waiting for).
+_AFTER_PROJECTION = []
+
+
+def after_first_projection(fn):
+    del _AFTER_PROJECTION[:]
+    if fn is not None:
+        _AFTER_PROJECTION.append(fn)
+
+
+def run_after_projection_hook():
+    if _AFTER_PROJECTION:
+        _AFTER_PROJECTION.pop()()
 
 
 def _bounds(amax):
@@ -668,6 +690,7 @@ def blstm_fwd(x, Kf, bf, Kb, bb, amax=None):
     # ring recurrence: plane 0 = c_t (what every backward reads as `cst`), plane 1 = tanh(c_t) for the backward ring
     cst = torch.empty(((2, B, T, 2, H) if nring else (B, T, 2, H)), dtype=torch.float32, device=x.device)
     gemm(x2, Wcat, bias=bias, out=G, M=B * T, N=8 * H, K=D, lda=D, ldb=8 * H, ldc=8 * H, label='blstm_input_gemm', amax=amax)
+    run_after_projection_hook()
     if nring:
         sync, pre0 = _ring_sync(nring, x)
         check(lib.ams_blstm_ring_fwd(_p(G), _p(out), _p(cst[0]), _p(cst[1]), _p(Kf[D:]), _p(Kb[D:]), ldu,
@@ -1101,21 +1124,21 @@ def _guard(p, guard):
     return ring_error_word(p.device) if guard is None else guard
 
 
-def opt_amsgrad(p, g, m, v, vhat, lr_t, beta1, beta2, eps, grad_scale=1.0, guard=None):
+def opt_amsgrad(p, g, m, v, vhat, lr_t, beta1, beta2, eps, grad_scale=1.0, guard=None, amax=None):
     _chk(p, g, m, v, vhat)
     check(load().ams_opt_amsgrad(_p(p), _p(g), _p(m), _p(v), _p(vhat), p.numel(), lr_t, beta1, beta2, eps, grad_scale,
-                                 _p(_guard(p, guard)), _s()), 'ams_opt_amsgrad')
+                                 _p(_guard(p, guard)), _p(amax), _s()), 'ams_opt_amsgrad')
 
 
-def opt_rmsprop(p, g, ms, lr, decay=0.9, eps=1e-10, grad_scale=1.0, guard=None):
+def opt_rmsprop(p, g, ms, lr, decay=0.9, eps=1e-10, grad_scale=1.0, guard=None, amax=None):
     _chk(p, g, ms)
-    check(load().ams_opt_rmsprop(_p(p), _p(g), _p(ms), p.numel(), lr, decay, eps, grad_scale, _p(_guard(p, guard)), _s()),
+    check(load().ams_opt_rmsprop(_p(p), _p(g), _p(ms), p.numel(), lr, decay, eps, grad_scale, _p(_guard(p, guard)), _p(amax), _s()),
           'ams_opt_rmsprop')
 
 
-def opt_momentum(p, g, acc, lr, momentum=0.9, grad_scale=1.0, guard=None):
+def opt_momentum(p, g, acc, lr, momentum=0.9, grad_scale=1.0, guard=None, amax=None):
     _chk(p, g, acc)
-    check(load().ams_opt_momentum(_p(p), _p(g), _p(acc), p.numel(), lr, momentum, grad_scale, _p(_guard(p, guard)), _s()),
+    check(load().ams_opt_momentum(_p(p), _p(g), _p(acc), p.numel(), lr, momentum, grad_scale, _p(_guard(p, guard)), _p(amax), _s()),
           'ams_opt_momentum')
 
 

@@ -41,7 +41,7 @@ inline const GemmTuning& tuning() {
         v.noprio = getenv("AMS_GEMM_NOPRIO") != nullptr;
         { const char* e = getenv("AMS_X6_PERSIST"); v.x6persist = e ? atoi(e) : 1; }
         { const char* e = getenv("AMS_GEMM_F16X3"); v.f16x3 = !(e && atoi(e) == 0); }
-        { const char* e = getenv("AMS_GEMM_INRED"); v.inred = !(e && atoi(e) == 0); }      // 0: split-K always as two passes (A/B runs)
+        { const char* e = getenv("AMS_GEMM_INRED"); v.inred = e && atoi(e) != 0; }         // 1: split-K reduced inside the producing launch (measured slower: profiles/r04_c_*)
         v.novec = getenv("AMS_GEMM_NOVEC") != nullptr;
         if (const char* f = getenv("AMS_GEMM_X6CFG")) v.x6cfg = atoi(f);       // force one bf16x6 tile configuration (0, 1 or 3: X6Cfg)
         if (const char* f = getenv("AMS_GEMM_X6RULE")) v.x6rule = atoi(f);

@@ -169,6 +169,7 @@ class Network(object):
                     arr = arr.reshape(tuple(v.shape))
                 v.data.copy_(torch.from_numpy(arr.astype(np.float32)).to(v.device))
                 g.initialized.add(name)
+            self._weights_written()
             return
         data = np.load(self._latest_checkpoint(path))
         for name in self.saver:
@@ -178,6 +179,13 @@ class Network(object):
             v = g.variables[name]
             v.data.copy_(torch.from_numpy(data[key]).to(v.device))
             g.initialized.add(name)
+        self._weights_written()
+
+    def _weights_written(self):
+        """Something other than the optimizer wrote variables: a tracked weight bound (FlatOptimizer.track_bound) is measured again."""
+        opt = self.__dict__.get('_cache_optimize')
+        if opt is not None:
+            opt.refresh_bound()
 
     def restore_last_checkpoint(self):
         self.restore_model(self._dir())
@@ -340,6 +348,7 @@ class Network(object):
             st['pre'] = [[torch.empty_like(v).contiguous() for v in shapes] for _ in range(2)]
             st['bound'] = [torch.ones(1, dtype=torch.float32, device=shapes[0].device) for _ in range(2)]
             st['copy_stream'] = torch.cuda.Stream()
+            st['ahead_stream'] = torch.cuda.Stream()
             cur = first
         elif not have_cur:
             cur = self._fetch_inputs(feed_dict)
@@ -369,6 +378,7 @@ class Network(object):
         else:
             st['ahead'] = None
         if k not in st['graphs']:
+            opt.track_bound(True)                                  # the optimizer kernels keep the weight bound: nothing to measure in the graph
             run = self._feeds(feed_dict, True)
             for node, t in zip((self.x_mix, self.x_non_mix, self.I), st['ins'][k]):
                 run.cache[id(node)] = t
@@ -381,14 +391,25 @@ class Network(object):
             with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
                 opt.zero_grad(defer=True)
                 run.begun = True
-                K.pass_begin(F.OVERLAP.side())                     # weight bound + ring arena + gradient memset on the side stream ...
-                s2 = F.OVERLAP.side()
-                s2.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(s2):                        # ... then the NEXT batch's front end, beside this step's forward rings
-                    self._ahead_compute(nodes, st['ins'][1 - k], st['pre'][1 - k], st['bound'][1 - k], feed_dict)
+                K.pass_begin(F.OVERLAP.side())                     # ring arena + gradient memset on the side stream (no weight bound: tracked)
+
+                def ahead(k=k):
+                    # the NEXT batch's front end on the side stream, forked right BEHIND this step's first projection: beside the
+                    # forward rings.  (Forked at the top of the step its capped product took every CU first and the projection --
+                    # whose 8-wave workgroups share a CU with nothing -- started 90 us late: profiles/r04_d_front_ahead_v1.txt.)
+                    s2 = st['ahead_stream'] if os.environ.get('AMS_FRONT_AHEAD_STREAM', '1') == '1' else F.OVERLAP.side()
+                    s2.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(s2):
+                        self._ahead_compute(nodes, st['ins'][1 - k], st['pre'][1 - k], st['bound'][1 - k], feed_dict)
+                if os.environ.get('AMS_FRONT_AHEAD_FORK', '0') == '1':
+                    K.after_first_projection(ahead)
+                else:
+                    ahead()                                        # at the top: its small kernels run first, the capped product arrives behind the projection
                 cost = self.cost_model.value(run)
+                K.run_after_projection_hook()                      # (a model without a BLSTM projection: here)
                 self._backward(cost)
                 F.OVERLAP.join()
+                torch.cuda.current_stream().wait_stream(st['ahead_stream'])
             st['graphs'][k] = (g, cost, run)
         for hook in get_default_graph().pre_replay_hooks:      # host-drawn inputs of captured kernels (k-means seeds)
             hook()

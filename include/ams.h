@@ -260,13 +260,16 @@ ams_status ams_kl_sparsity_bwd(const float* y, const float* p_hat, const float* 
 ams_status ams_negative_energy_fwd(const float* y, float* out, int Bt, long M, void* ws, size_t ws_bytes, void* stream);
 ams_status ams_sumsq_bwd(const float* x, const float* upstream, float scale, float* dx, long n, int mode, int accumulate, void* stream);
 
-/* ---- K24  optimizers     models/network.py:181-194, utils/ops.py:686-703 ---- */
+/* ---- K24  optimizers     models/network.py:181-194, utils/ops.py:686-703 ----
+ * amax_io (may be NULL): a float the kernels RAISE to max |p| over the values they wrote (atomic max, never lowered; NaN sticks) -- a
+ * running upper bound of the weights for the fp16x3 products (amax_b of ams_gemm_f32), kept without a pass over the 47 MB of
+ * parameters per step.  The caller measures it once (ams_absmax_f32) and again whenever something else writes the parameters. */
 ams_status ams_opt_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, long n, float lr_t, float beta1,
-                           float beta2, float eps, float grad_scale, const void* skip_if_set, void* stream);
+                           float beta2, float eps, float grad_scale, const void* skip_if_set, float* amax_io, void* stream);
 ams_status ams_opt_rmsprop(float* p, const float* g, float* ms, long n, float lr, float decay, float eps, float grad_scale,
-                           const void* skip_if_set, void* stream);
+                           const void* skip_if_set, float* amax_io, void* stream);
 ams_status ams_opt_momentum(float* p, const float* g, float* accum, long n, float lr, float momentum, float grad_scale,
-                            const void* skip_if_set, void* stream);
+                            const void* skip_if_set, float* amax_io, void* stream);
 ams_status ams_sumsq(const float* x, float* out, long n, void* ws, size_t ws_bytes, void* stream);
 /* measurement aid: buf[slot] (uint64) = the device's constant-rate wall clock when the stream reaches this point; ams_stamp_rate() =
  * its ticks per second.  Stamps bracket launches INSIDE a replayed hipGraph (HIP events recorded during capture cannot be read back). */
