@@ -147,8 +147,7 @@ def front_conv(x, f, hop):
     nb = lib.ams_front_conv_fwd_workspace_bytes(Bt, L, W, N, hop)
     ws = _ws(nb, x) if nb else None
     ev = PROFILE.begin() if PROFILE.enabled else None
-    cnt = _counters(x) if nb else None
-    check(lib.ams_front_conv_fwd(_p(x), _p(f), _p(y), Bt, L, W, N, hop, LDS_PAD[0], _p(ws), nb, _p(cnt), (N_COUNTERS if cnt is not None else 0), _s()),
+    check(lib.ams_front_conv_fwd(_p(x), _p(f), _p(y), Bt, L, W, N, hop, LDS_PAD[0], _p(ws), nb, _s()),
           'ams_front_conv_fwd')
     if ev is not None:      # algorithmic bytes: waveform in, frames out, filter once
         PROFILE.end(ev, 2.0 * Bt * T * N * W, 4.0 * (Bt * L + Bt * T * N + W * N), 'gemm<2,0>', 'front_conv')
@@ -163,9 +162,7 @@ def front_conv_bwd_filter(x, dy, W, hop):
     nb = lib.ams_front_conv_bwd_filter_workspace_bytes(Bt, L, W, N, hop)
     ws = _ws(nb, x)
     df = torch.empty((W, N), dtype=torch.float32, device=x.device)
-    cnt = _counters(x) if nb else None
-    check(lib.ams_front_conv_bwd_filter(_p(x), _p(dy), _p(df), Bt, L, W, N, hop, _p(ws), nb, _p(cnt), (N_COUNTERS if cnt is not None else 0),
-                                        _s()), 'ams_front_conv_bwd_filter')
+    check(lib.ams_front_conv_bwd_filter(_p(x), _p(dy), _p(df), Bt, L, W, N, hop, _p(ws), nb, _s()), 'ams_front_conv_bwd_filter')
     return df
 
 
@@ -217,7 +214,7 @@ PASS = [0]                                                       # bumped by gra
 
 class _ParamSource(object):
     """One optimizer's flat parameter buffer and the bound measured over it (shared by every variable the optimizer owns)."""
-    __slots__ = ('flat', 'bound', 'seen', 'event', 'used', 'tracked', '__weakref__')
+    __slots__ = ('flat', 'bound', 'seen', 'event', 'used', '__weakref__')
 
     def __init__(self, flat):
         self.flat = flat
@@ -225,9 +222,6 @@ class _ParamSource(object):
         self.seen = -1                  # the pass (PASS[0]) it was last measured in
         self.event = None               # measured on the side stream: recorded there, awaited by the first consumer
         self.used = -1                  # the last pass a product asked for this bound
-        # True: the optimizer keeps `bound` an upper bound of the weights by itself (its update kernels raise it, include/ams.h amax_io;
-        # optim.FlatOptimizer.track_bound): no pass measures it
-        self.tracked = False
 
 
 _SOURCES = []                                                    # weak references: a source lives as long as its variables do
@@ -244,8 +238,6 @@ def param_amax(W):
     src = getattr(W, '_ams_amax_src', None)
     if src is not None:
         src.used = PASS[0]
-        if src.tracked:
-            return src.bound
         if src.seen != PASS[0]:                                  # not measured by pass_begin() (first use of this model): measure here
             absmax(src.flat, out=src.bound)
             src.seen, src.event = PASS[0], None
@@ -387,7 +379,7 @@ def pass_begin(side_stream):
         if src is None:
             continue
         live.append(ref)
-        if not src.flat.is_cuda or src.tracked or src.seen == PASS[0] or src.flat.device != cur.device or src.used < PASS[0] - 2:
+        if not src.flat.is_cuda or src.seen == PASS[0] or src.flat.device != cur.device or src.used < PASS[0] - 2:
             continue                                            # (only models whose bound a recent pass asked for)
         todo.append(src)
     if F16X3:
@@ -424,22 +416,6 @@ def register_param_source(variables, flat):
     return src
 
 
-# One-shot hook: work to enqueue right BEHIND the first input projection of the pass (models/network.py::_train_graphed puts the next
-# batch's front end on the side stream there: started at the top of the step it would take the CUs the projection is waiting for).
-_AFTER_PROJECTION = []
-
-
-def after_first_projection(fn):
-    del _AFTER_PROJECTION[:]
-    if fn is not None:
-        _AFTER_PROJECTION.append(fn)
-
-
-def run_after_projection_hook():
-    if _AFTER_PROJECTION:
-        _AFTER_PROJECTION.pop()()
-
-
 def _bounds(amax):
     """(pointer of A's bound, pointer of B's bound, profile tag prefix) for the product entry points: fp16x3 ('gemm16')
     when both bounds are there, else NULLs = bf16x6 / native f32 ('gemm')."""
@@ -467,22 +443,6 @@ class lds_pad(object):
 
     def __exit__(self, *exc):
         LDS_PAD[0] = self.old
-
-
-# Arrival counters of the in-launch split-K reduce (include/ams.h: `counters`): zero on entry, left zero by the kernel.  Launches on
-# ONE stream are serialised, so they share one block; launches on streams that may run concurrently (main / side) get their own.
-_COUNTERS = {}
-N_COUNTERS = 16384
-
-
-def _counters(like):
-    key = (like.device.index, torch.cuda.current_stream().cuda_stream)
-    c = _COUNTERS.get(key)
-    if c is None:
-        if torch.cuda.is_current_stream_capturing():
-            return None         # a block allocated during capture would live in the graph's private pool: this launch takes the two-pass form
-        c = _COUNTERS[key] = torch.zeros(N_COUNTERS, dtype=torch.int32, device=like.device)
-    return c
 
 
 
@@ -517,11 +477,10 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False
     pad = LDS_PAD[0]
     nb = lib.ams_gemm_workspace_bytes(M, N, K, 1, pad)
     ws = _ws(nb, A) if nb else None
-    cnt = _counters(A) if nb else None
     ev = PROFILE.begin() if PROFILE.enabled else None
     pa, pb, gt = _bounds(amax)
     check(lib.ams_gemm_f32(int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc, _p(bias), int(accumulate),
-                           mask[0], mask[1], pa, pb, pad, _p(ws), nb, _p(cnt), (N_COUNTERS if cnt is not None else 0), _s()), 'ams_gemm_f32')
+                           mask[0], mask[1], pa, pb, pad, _p(ws), nb, _s()), 'ams_gemm_f32')
     if ev is not None:
         PROFILE.end(ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N), gt + '<%d,%d>' % (int(bool(transA)), int(bool(transB))), label)
     return out
@@ -542,12 +501,11 @@ def gemm_at_b_colsum(A, B, out, bsum, accumulate=True, amax=None, ldc=None):
     pad = LDS_PAD[0]
     nb = lib.ams_gemm_workspace_bytes(M, N, K, 1, pad)
     ws = _ws(nb, A) if nb else None
-    cnt = _counters(A) if nb else None
     bws = _ws(32 * N * 4, A)
     ev = PROFILE.begin() if PROFILE.enabled else None
     pa, pb, gt = _bounds(amax)
     check(lib.ams_gemm_f32_at_b_colsum(M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(out), ldc, int(accumulate),
-                                       _p(bsum), int(accumulate), _p(bws), pa, pb, pad, _p(ws), nb, _p(cnt), (N_COUNTERS if cnt is not None else 0), _s()),
+                                       _p(bsum), int(accumulate), _p(bws), pa, pb, pad, _p(ws), nb, _s()),
           'ams_gemm_f32_at_b_colsum')
     if ev is not None:
         PROFILE.end(ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N), gt + '<1,0>', '')
@@ -574,11 +532,10 @@ def gemm_batched(A, B, C, nbatch, a_zs, b_zs, c_zs, transA, transB, M, N, K, lda
     pad = LDS_PAD[0]
     nb = lib.ams_gemm_workspace_bytes(M, N, K, nbatch, pad)
     ws = _ws(nb, A) if nb else None
-    cnt = _counters(A) if nb else None
     ev = PROFILE.begin() if PROFILE.enabled else None
     pa, pb, gt = _bounds(amax)
     check(lib.ams_gemm_f32_batched(int(transA), int(transB), M, N, K, _p(A), lda, a_zs, _p(B), ldb, b_zs, _p(C), ldc, c_zs, nbatch,
-                                   int(accumulate), mask[0], mask[1], pa, pb, pad, _p(ws), nb, _p(cnt), (N_COUNTERS if cnt is not None else 0), _s()),
+                                   int(accumulate), mask[0], mask[1], pa, pb, pad, _p(ws), nb, _s()),
           'ams_gemm_f32_batched')
     if ev is not None:
         PROFILE.end(ev, nbatch * 2.0 * M * N * K, nbatch * 4.0 * (M * K + K * N + M * N), gt + '<%d,%d>' % (int(bool(transA)), int(bool(transB))))
@@ -690,7 +647,6 @@ def blstm_fwd(x, Kf, bf, Kb, bb, amax=None):
     # ring recurrence: plane 0 = c_t (what every backward reads as `cst`), plane 1 = tanh(c_t) for the backward ring
     cst = torch.empty(((2, B, T, 2, H) if nring else (B, T, 2, H)), dtype=torch.float32, device=x.device)
     gemm(x2, Wcat, bias=bias, out=G, M=B * T, N=8 * H, K=D, lda=D, ldb=8 * H, ldc=8 * H, label='blstm_input_gemm', amax=amax)
-    run_after_projection_hook()
     if nring:
         sync, pre0 = _ring_sync(nring, x)
         check(lib.ams_blstm_ring_fwd(_p(G), _p(out), _p(cst[0]), _p(cst[1]), _p(Kf[D:]), _p(Kb[D:]), ldu,
@@ -1124,21 +1080,21 @@ def _guard(p, guard):
     return ring_error_word(p.device) if guard is None else guard
 
 
-def opt_amsgrad(p, g, m, v, vhat, lr_t, beta1, beta2, eps, grad_scale=1.0, guard=None, amax=None):
+def opt_amsgrad(p, g, m, v, vhat, lr_t, beta1, beta2, eps, grad_scale=1.0, guard=None):
     _chk(p, g, m, v, vhat)
     check(load().ams_opt_amsgrad(_p(p), _p(g), _p(m), _p(v), _p(vhat), p.numel(), lr_t, beta1, beta2, eps, grad_scale,
-                                 _p(_guard(p, guard)), _p(amax), _s()), 'ams_opt_amsgrad')
+                                 _p(_guard(p, guard)), _s()), 'ams_opt_amsgrad')
 
 
-def opt_rmsprop(p, g, ms, lr, decay=0.9, eps=1e-10, grad_scale=1.0, guard=None, amax=None):
+def opt_rmsprop(p, g, ms, lr, decay=0.9, eps=1e-10, grad_scale=1.0, guard=None):
     _chk(p, g, ms)
-    check(load().ams_opt_rmsprop(_p(p), _p(g), _p(ms), p.numel(), lr, decay, eps, grad_scale, _p(_guard(p, guard)), _p(amax), _s()),
+    check(load().ams_opt_rmsprop(_p(p), _p(g), _p(ms), p.numel(), lr, decay, eps, grad_scale, _p(_guard(p, guard)), _s()),
           'ams_opt_rmsprop')
 
 
-def opt_momentum(p, g, acc, lr, momentum=0.9, grad_scale=1.0, guard=None, amax=None):
+def opt_momentum(p, g, acc, lr, momentum=0.9, grad_scale=1.0, guard=None):
     _chk(p, g, acc)
-    check(load().ams_opt_momentum(_p(p), _p(g), _p(acc), p.numel(), lr, momentum, grad_scale, _p(_guard(p, guard)), _p(amax), _s()),
+    check(load().ams_opt_momentum(_p(p), _p(g), _p(acc), p.numel(), lr, momentum, grad_scale, _p(_guard(p, guard)), _s()),
           'ams_opt_momentum')
 
 

@@ -81,9 +81,8 @@ class FlatOptimizer(object):
             raise ValueError('unknown optimizer %r' % kind)
         # fp16x3 products (ops.set_amax) scale their weight operand by ONE bound over everything this optimizer owns, measured
         # at its first use in every pass (ops.param_amax)
-        self._src = None
         if ops.F16X3 and dev.type == 'cuda' and n > 0:
-            self._src = ops.register_param_source(self.vars, self.flat)
+            ops.register_param_source(self.vars, self.flat)
 
     # tf.train.exponential_decay(lr, global_epoch, decay_epoch, 0.5, staircase=True)  (network.py:175-177)
     def learning_rate(self):
@@ -121,24 +120,6 @@ class FlatOptimizer(object):
             scale *= self.clip / max(gn, self.clip)                           # tf.clip_by_global_norm
         return scale
 
-    def track_bound(self, on=True):
-        """From now on the update kernels keep the weight bound of the fp16x3 products themselves (include/ams.h: amax_io): measured
-        once here, raised by every update, never measured by a pass again -- the first product of a step then waits for nothing.  The
-        bound only grows between two calls of refresh_bound() (an upper bound up to 2^10 above the maximum costs no precision)."""
-        if self._src is None:
-            return
-        self._src.tracked = bool(on)
-        if on:
-            self.refresh_bound()
-
-    def refresh_bound(self):
-        """Measure the weight bound now (after anything but step() wrote the parameters: restore_model, a test injecting weights)."""
-        if self._src is not None and self._src.tracked:
-            ops.absmax(self.flat, out=self._src.bound)
-
-    def _amax(self):
-        return self._src.bound if (self._src is not None and self._src.tracked) else None
-
     def undo_counters(self):
         """Host-side step counters back to before the last step() (whose device update the guard word skipped)."""
         b1p, b2p, t = getattr(self, '_before', (None, None, self.t))
@@ -160,11 +141,11 @@ class FlatOptimizer(object):
         guard = self._errslot if (self._errslot is not None and ops.LSTM_RING != '0') else None
         if self.kind == 'Adam':
             lr_t = self.base_lr * math.sqrt(1.0 - self.b2p) / (1.0 - self.b1p)
-            ops.opt_amsgrad(self.flat, self.flat_grad, self.m, self.v, self.vhat, lr_t, self.beta1, self.beta2, self.eps, scale, guard=guard, amax=self._amax())
+            ops.opt_amsgrad(self.flat, self.flat_grad, self.m, self.v, self.vhat, lr_t, self.beta1, self.beta2, self.eps, scale, guard=guard)
             self.b1p *= self.beta1
             self.b2p *= self.beta2
         elif self.kind == 'RMSProp':
-            ops.opt_rmsprop(self.flat, self.flat_grad, self.ms, self.learning_rate(), 0.9, 1e-10, scale, guard=guard, amax=self._amax())
+            ops.opt_rmsprop(self.flat, self.flat_grad, self.ms, self.learning_rate(), 0.9, 1e-10, scale, guard=guard)
         else:
-            ops.opt_momentum(self.flat, self.flat_grad, self.acc, self.learning_rate(), 0.9, scale, guard=guard, amax=self._amax())
+            ops.opt_momentum(self.flat, self.flat_grad, self.acc, self.learning_rate(), 0.9, scale, guard=guard)
         self.t += 1

@@ -149,9 +149,7 @@ class FramesConv(Function):
         nb = lib.ams_frames_matmul_bwd_filter_workspace_bytes(R, Wg, N, T)
         ws = ops._ws(nb, x)
         dB = torch.empty((Wg, N), dtype=torch.float32, device=x.device)
-        cnt = ops._counters(x) if nb else None
-        check(lib.ams_frames_matmul_bwd_filter(_p(x), _p(dy), _p(dB), R, L, Wg, N, hop, T, pl, _p(ws), nb, _p(cnt),
-                                               (ops.N_COUNTERS if cnt is not None else 0), _s()), 'ams_frames_matmul_bwd_filter')
+        check(lib.ams_frames_matmul_bwd_filter(_p(x), _p(dy), _p(dB), R, L, Wg, N, hop, T, pl, _p(ws), nb, _s()), 'ams_frames_matmul_bwd_filter')
         return None, dB, None, None, None
 
 
@@ -183,9 +181,7 @@ class SynthFrames(Function):
             nb = lib.ams_frames_matmul_bwd_filter_workspace_bytes(R, Wg, N, T)
             ws = ops._ws(nb, z)
             dB = torch.empty((Wg, N), dtype=torch.float32, device=z.device)
-            cnt = ops._counters(z) if nb else None
-            check(lib.ams_frames_matmul_bwd_filter(_p(dout), _p(z), _p(dB), R, L, Wg, N, hop, T, pl, _p(ws), nb, _p(cnt),
-                                                   (ops.N_COUNTERS if cnt is not None else 0), _s()), 'ams_frames_matmul_bwd_filter')
+            check(lib.ams_frames_matmul_bwd_filter(_p(dout), _p(z), _p(dB), R, L, Wg, N, hop, T, pl, _p(ws), nb, _s()), 'ams_frames_matmul_bwd_filter')
         return dz, dB, None, None, None
 
 

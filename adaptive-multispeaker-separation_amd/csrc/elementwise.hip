@@ -254,63 +254,40 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, float* __res
     out[c] = accumulate ? out[c] + s : s;
 }
 
-// Running upper bound of max |parameter| for the fp16x3 products (include/ams.h: amax_io of the optimizers): every block folds the
-// magnitudes of the values it WROTE into *amax_io with one atomicMax (non-negative floats order like their bit patterns; a NaN wins).
-// The word is never lowered here: it stays an upper bound of everything the optimizer has written since the caller last measured it.
-__device__ __forceinline__ void block_amax_commit(unsigned m, unsigned* __restrict__ amax_io) {
-    __shared__ unsigned sm_amax[4];
-    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
-    if ((threadIdx.x & 63) == 0) sm_amax[threadIdx.x >> 6] = m;
-    __syncthreads();
-    if (threadIdx.x == 0) atomicMax(amax_io, max(max(sm_amax[0], sm_amax[1]), max(sm_amax[2], sm_amax[3])));
-}
-
 // ---- optimizers (reference utils/ops.py:686-703; TF RMSProp/Momentum) ----
 __global__ void amsgrad_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                float* __restrict__ vh, long n, float lr_t, float b1, float b2, float eps, float gscale,
-                               const unsigned* __restrict__ skip, unsigned* __restrict__ amax_io) {
+                               const unsigned* __restrict__ skip) {
     // skip: a recurrence launch of this step gave up a bounded wait (csrc/lstm_ring.hip, sticky error word): its gradients are
     // garbage -- leave parameters and slots untouched so that the caller can repeat the step on the per-step kernels
     if (skip && *skip != 0u) return;
-    unsigned am = 0u;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
         const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
         const float vhi = fmaxf(vi, vh[i]);
         m[i] = mi; v[i] = vi; vh[i] = vhi;
-        const float pn = p[i] - lr_t * mi / (sqrtf(vhi) + eps);
-        p[i] = pn;
-        am = max(am, __float_as_uint(fabsf(pn)));
+        p[i] -= lr_t * mi / (sqrtf(vhi) + eps);
     }
-    if (amax_io) block_amax_commit(am, amax_io);
 }
 __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ ms, long n, float lr,
-                               float decay, float eps, float gscale, const unsigned* __restrict__ skip, unsigned* __restrict__ amax_io) {
+                               float decay, float eps, float gscale, const unsigned* __restrict__ skip) {
     if (skip && *skip != 0u) return;
-    unsigned am = 0u;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
         const float s = decay * ms[i] + (1.0f - decay) * gi * gi;
         ms[i] = s;
-        const float pn = p[i] - lr * gi / sqrtf(s + eps);
-        p[i] = pn;
-        am = max(am, __float_as_uint(fabsf(pn)));
+        p[i] -= lr * gi / sqrtf(s + eps);
     }
-    if (amax_io) block_amax_commit(am, amax_io);
 }
 __global__ void momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ acc, long n, float lr,
-                                float mom, float gscale, const unsigned* __restrict__ skip, unsigned* __restrict__ amax_io) {
+                                float mom, float gscale, const unsigned* __restrict__ skip) {
     if (skip && *skip != 0u) return;
-    unsigned am = 0u;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float a = mom * acc[i] + g[i] * gscale;
         acc[i] = a;
-        const float pn = p[i] - lr * a;
-        p[i] = pn;
-        am = max(am, __float_as_uint(fabsf(pn)));
+        p[i] -= lr * a;
     }
-    if (amax_io) block_amax_commit(am, amax_io);
 }
 
 // sum of squares -> per-block partials -> single value (deterministic two-stage)
@@ -468,26 +445,26 @@ ams_status ams_colsum(const float* x, float* out, long rows, int cols, long ld, 
 }
 
 ams_status ams_opt_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, long n, float lr_t, float beta1,
-                           float beta2, float eps, float grad_scale, const void* skip_if_set, float* amax_io, void* stream) {
+                           float beta2, float eps, float grad_scale, const void* skip_if_set, void* stream) {
     AMS_REQUIRE(p && g && m && v && vhat && n > 0);
     hipLaunchKernelGGL(amsgrad_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vhat, n, lr_t, beta1,
-                       beta2, eps, grad_scale, (const unsigned*)skip_if_set, (unsigned*)amax_io);
+                       beta2, eps, grad_scale, (const unsigned*)skip_if_set);
     return ams_check_launch();
 }
 
 ams_status ams_opt_rmsprop(float* p, const float* g, float* ms, long n, float lr, float decay, float eps, float grad_scale,
-                           const void* skip_if_set, float* amax_io, void* stream) {
+                           const void* skip_if_set, void* stream) {
     AMS_REQUIRE(p && g && ms && n > 0);
     hipLaunchKernelGGL(rmsprop_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, ms, n, lr, decay, eps, grad_scale,
-                       (const unsigned*)skip_if_set, (unsigned*)amax_io);
+                       (const unsigned*)skip_if_set);
     return ams_check_launch();
 }
 
 ams_status ams_opt_momentum(float* p, const float* g, float* accum, long n, float lr, float momentum, float grad_scale,
-                            const void* skip_if_set, float* amax_io, void* stream) {
+                            const void* skip_if_set, void* stream) {
     AMS_REQUIRE(p && g && accum && n > 0);
     hipLaunchKernelGGL(momentum_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, accum, n, lr, momentum, grad_scale,
-                       (const unsigned*)skip_if_set, (unsigned*)amax_io);
+                       (const unsigned*)skip_if_set);
     return ams_check_launch();
 }
 

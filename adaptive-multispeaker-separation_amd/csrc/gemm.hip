@@ -30,7 +30,7 @@ struct LaunchOpt { const float* amax_a = nullptr; const float* amax_b = nullptr;
 std::atomic<int> g_gemm_arith{-1};        // -1: not chosen yet (AMS_GEMM_X6, default 1), 0: native f32 MFMA, 1: bf16x6
 
 // Tuning overrides (A/B runs only): read from the environment ONCE per process, never on the launch path.
-struct GemmTuning { int group_m, splits, x6cfg, x6rule, x6persist; bool noprio, novec, f16x3, inred; double x6waste; };
+struct GemmTuning { int group_m, splits, x6cfg, x6rule, x6persist; bool noprio, novec, f16x3; double x6waste; };
 inline const GemmTuning& tuning() {
     static const GemmTuning t = [] {
         GemmTuning v{0, 0, -1, 2, false, false};
@@ -41,7 +41,6 @@ inline const GemmTuning& tuning() {
         v.noprio = getenv("AMS_GEMM_NOPRIO") != nullptr;
         { const char* e = getenv("AMS_X6_PERSIST"); v.x6persist = e ? atoi(e) : 1; }
         { const char* e = getenv("AMS_GEMM_F16X3"); v.f16x3 = !(e && atoi(e) == 0); }
-        { const char* e = getenv("AMS_GEMM_INRED"); v.inred = e && atoi(e) != 0; }         // 1: split-K reduced inside the producing launch (measured slower: profiles/r04_c_*)
         v.novec = getenv("AMS_GEMM_NOVEC") != nullptr;
         if (const char* f = getenv("AMS_GEMM_X6CFG")) v.x6cfg = atoi(f);       // force one bf16x6 tile configuration (0, 1 or 3: X6Cfg)
         if (const char* f = getenv("AMS_GEMM_X6RULE")) v.x6rule = atoi(f);
@@ -113,13 +112,8 @@ struct GemmArgs {
     // column sums of B (B_ROW, VEC path): the tile_m == 0 workgroups add up the B rows they stage anyway and write one partial
     // row per split to bsum_part [splits, N]; a finishing kernel adds the splits into bsum_out (bias gradient = colsum(dY))
     float* bsum_part;
-    // split-K reduced INSIDE the producing launch (16-bit-pipe kernels): `counters` = one arrival counter per (batch, output tile),
-    // zero on entry and zero again on completion; the slabs of `partial` are then in FRAGMENT order (x6_body).  NULL = the two-pass
-    // form (row-major slabs + splitk_reduce_*_kernel).  bsum_out / bsum_accumulate: where the column sums of B end up when the
-    // launch finishes them itself (splits == 1, or the last-arriving workgroup of a column tile)
-    unsigned* counters;
+    // bsum_out / bsum_accumulate: where the column sums of B go directly when the launch has ONE k-split (no finishing kernel)
     float* bsum_out; int bsum_accumulate;
-    int zb;                    // batch index of the current item (set by locate_tile)
     // fp16x3 arithmetic: device pointers to an upper bound of max|A|, max|B| over the WHOLE operand tensors (all batches); the kernel
     // derives the power-of-two operand scales from them
     const float* amax_a; const float* amax_b;
@@ -167,13 +161,11 @@ __device__ __forceinline__ void locate_tile(GemmArgs& g, int& split, int& tile_m
         item -= zb * (ntiles * g.splits);
         split = item / ntiles;
         bid = item - split * ntiles;
-        g.zb = zb;
 #else
         zb = item / (ntiles * g.splits);                       // round-1 order: per-(z, split) plane, tiles dealt by x % 8
         item -= zb * (ntiles * g.splits);
         split = item / ntiles;
         bid = item - split * ntiles;
-        g.zb = zb;
         const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 #endif
@@ -182,7 +174,7 @@ __device__ __forceinline__ void locate_tile(GemmArgs& g, int& split, int& tile_m
         const long z = zb;
         g.A += z * g.a_zs; g.B += z * g.b_zs; g.C += z * g.c_zs;
         if (g.bias) g.bias += z * g.bias_zs;
-        if (g.partial && !g.counters) g.partial += z * (long)g.splits * g.M * g.N;
+        if (g.partial) g.partial += z * (long)g.splits * g.M * g.N;
     }
     const int GROUP_M = g.group_m > 0 ? g.group_m : 1;        // chosen per launch (choose_group_m)
     const int band = bid / (GROUP_M * tiles_n), within = bid - band * (GROUP_M * tiles_n);
@@ -593,18 +585,6 @@ __global__ __launch_bounds__(256, AMS_GEMM_WPE) void gemm_f32_kernel(GemmArgs g)
 // 232c519).  The kernel draws the board's power limit (1385-1393 W at 2135 MHz; its MFMA-only stream 1050 W at 2400 MHz) and gains
 // 0-4 % with the split arithmetic compiled out: at that limit its run time is the energy of a product, not its instruction schedule
 // (DESIGN.md 4.0).
-typedef int i32x4_t __attribute__((ext_vector_type(4)));
-// Raw buffer accesses with aux bit 16 = sc1: stores write through to the memory side, loads bypass this CU's L1 -- the publish form of
-// MI355X_MICROARCH.md ("publish-large" / "splitk-seam": sc1 payload -> s_waitcnt vmcnt(0) -> agent-scope arrival, sc1 loads on the reader)
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t x6_rsrc(const void* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
-}
-__device__ __forceinline__ float4 ld16_sc1(__amdgpu_buffer_rsrc_t rs, unsigned off) {
-    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
-}
-__device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t rs, unsigned off, float4 v) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), rs, off, 0, 16);
-}
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
@@ -956,13 +936,6 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
             __syncthreads();
         }
 
-        // Split-K reduced in THIS launch (g.counters): every workgroup of an output tile leaves its accumulators in its slab, in FRAGMENT
-        // order (lane l's float4 q of MFMA tile (i, j) of wave w at ((w TM TN + i TN + j) 4 + q) * 1 KB + 16 l: 64 lanes store 1 KB
-        // contiguous, write-through), counts itself in, and the LAST one to arrive adds the slabs 0 .. splits-1 in index order -- the
-        // order of the two-pass reduce kernel, so the sums are bit-identical to it and do not depend on who arrives last -- and runs the
-        // normal epilogue (bias, accumulate).  No second launch, no row-major slab re-read by another grid.
-        const bool inred = g.splits > 1 && g.counters != nullptr;
-        const int tile_lin = (g.nbatch > 1 ? g.zb : 0) * (((g0.M + BMX - 1) / BMX) * ((g0.N + BNX - 1) / BNX)) + tile_m * ((g0.N + BNX - 1) / BNX) + tile_n;
         float4 bs_t = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!BKc && do_bsum) {
             // thread (kb, mb) summed rows 4 kb .. 4 kb + 3 of every k-tile, columns 4 mb .. + 3: the 8 threads of a column group meet
@@ -977,9 +950,13 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
                 for (int j = 1; j < 8; ++j) { const float4 v = sbuf[tid + (BNX / 4) * j]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
                 bs_t = t;
                 const int n = n0 + tid * 4;
-                if (n < g.N && g.splits > 1) {
-                    if (inred) st16_sc1(x6_rsrc(g.bsum_part, (unsigned)((size_t)g.splits * g.N * 4)), (unsigned)(((long)split * g.N + n) * 4), t);
-                    else *reinterpret_cast<float4*>(g.bsum_part + (long)split * g.N + n) = t;
+                if (n < g.N) {
+                    if (g.splits > 1 || !g.bsum_out) *reinterpret_cast<float4*>(g.bsum_part + (long)split * g.N + n) = t;
+                    else {                          // one k-split: this workgroup holds the whole column sums -- no finishing launch
+                        float4* const po = reinterpret_cast<float4*>(g.bsum_out + n);
+                        if (g.bsum_accumulate) { const float4 o = *po; bs_t.x += o.x; bs_t.y += o.y; bs_t.z += o.z; bs_t.w += o.w; }
+                        *po = bs_t;
+                    }
                 }
             }
         }
@@ -1001,70 +978,9 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
             maxpool_epilogue(g, acc, reinterpret_cast<float*>(smem), tile_m, m0, n0, wm, wn, l31, lk);
             return;                                     // (launched with one workgroup per item)
         }
-        bool fin = g.splits == 1;                       // this workgroup writes C (and the column sums) of its tile
-        if (inred) {
-            constexpr unsigned TILE_B = (unsigned)BMX * BNX * 4;
-            const __amdgpu_buffer_rsrc_t rs = x6_rsrc(g0.partial + (long)tile_lin * g.splits * (BMX * BNX), (unsigned)g.splits * TILE_B);
-            const unsigned loff = (unsigned)(wave * TM * TN * 4) * 1024u + (unsigned)lane * 16u;
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        st16_sc1(rs, (unsigned)split * TILE_B + loff + (unsigned)((i * TN + j) * 4 + q) * 1024u,
-                                 make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]));
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the write-through stores have left before the arrival is counted
-            __syncthreads();                                            // (and every wave is done with the LDS images)
-            int* const s_last = reinterpret_cast<int*>(smem);
-            if (tid == 0) {
-                unsigned* const cnt = g0.counters + tile_lin;
-                const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int last = old == (unsigned)g.splits - 1u;
-                if (last) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // zero again for the next launch
-                *s_last = last;
-            }
-            __syncthreads();
-            fin = *s_last != 0;
-            if (fin) {
-                for (int k = 0; k < g.splits; ++k) {
-#pragma unroll
-                    for (int i = 0; i < TM; ++i) {              // TN x 4 16-byte loads in flight per lane
-                        float4 v[TN][4];
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) v[j][q] = ld16_sc1(rs, (unsigned)k * TILE_B + loff + (unsigned)((i * TN + j) * 4 + q) * 1024u);
-#pragma unroll
-                        for (int j = 0; j < TN; ++j)
-#pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                if (k == 0) { acc[i][j][4 * q] = v[j][q].x; acc[i][j][4 * q + 1] = v[j][q].y; acc[i][j][4 * q + 2] = v[j][q].z; acc[i][j][4 * q + 3] = v[j][q].w; }
-                                else { acc[i][j][4 * q] += v[j][q].x; acc[i][j][4 * q + 1] += v[j][q].y; acc[i][j][4 * q + 2] += v[j][q].z; acc[i][j][4 * q + 3] += v[j][q].w; }
-                            }
-                    }
-                }
-                if (!BKc && do_bsum && tid < BNX / 4 && n0 + tid * 4 < g.N) {
-                    const __amdgpu_buffer_rsrc_t rb_ = x6_rsrc(g.bsum_part, (unsigned)((size_t)g.splits * g.N * 4));
-                    float4 t = ld16_sc1(rb_, (unsigned)((n0 + tid * 4) * 4));
-                    for (int k = 1; k < g.splits; ++k) {
-                        const float4 v = ld16_sc1(rb_, (unsigned)(((long)k * g.N + n0 + tid * 4) * 4));
-                        t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w;
-                    }
-                    bs_t = t;
-                }
-            }
-            __syncthreads();                            // s_last is read: the LDS is free for the next item's images
-        }
-        if (!BKc && do_bsum && g.bsum_out && fin && tid < BNX / 4 && n0 + tid * 4 < g.N) {
-            float4* const po = reinterpret_cast<float4*>(g.bsum_out + n0 + tid * 4);
-            if (g.bsum_accumulate) { const float4 o = *po; bs_t.x += o.x; bs_t.y += o.y; bs_t.z += o.z; bs_t.w += o.w; }
-            *po = bs_t;
-        }
         // what the epilogue of THIS item needs, saved before the per-item state moves on
-        const bool two_pass = g.splits > 1 && !inred;
-        float* const out = two_pass ? g.partial + (long)split * g.M * g.N : g.C;
-        const long ldo = two_pass ? g.N : g.ldc;
+        float* const out = g.splits > 1 ? g.partial + (long)split * g.M * g.N : g.C;
+        const long ldo = g.splits > 1 ? g.N : g.ldc;
         const float* const ebias = g.bias;
         const int em0 = m0, en0 = n0;
         const int nxt = vbid + (int)gridDim.x;
@@ -1075,26 +991,24 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
             fetch(0);                                   // the next item's first k-tile is in flight BEFORE this item's stores
         }
         // Epilogue.  C/D layout of a 32x32 MFMA (any input type): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-        if (fin || two_pass) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int col = en0 + (wn * TN + j) * 32 + l31;
                 if (col >= g.N) continue;
-                const float bv = (fin && ebias) ? ebias[col] : 0.f;
+                const float bv = (g.splits == 1 && ebias) ? ebias[col] : 0.f;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = em0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
                     if (row < g.M) {
                         float v = acc[i][j][r] + bv;
                         float* p = out + (long)row * ldo + col;
-                        if (fin && g.accumulate) v += *p;
+                        if (g.splits == 1 && g.accumulate) v += *p;
                         *p = v;
                     }
                 }
             }
-        }
         if (!more) break;
         vbid = nxt;
     }
@@ -1210,18 +1124,7 @@ inline int choose_splits(int M, int N, int K, int nbatch, const TilePlan& tp) {
 inline int choose_splits(int M, int N, int K, int nbatch, bool capped) {
     return choose_splits(M, N, K, nbatch, use_x6() ? x6_plan(x6_choose_cfg(M, N, capped)) : f32_plan());
 }
-// bytes of `splits` partial slabs: row-major [M, N] slabs for the two-pass form, whole (padded) tiles in fragment order for the
-// in-launch reduce of the 16-bit-pipe kernels -- a workspace sized for the larger serves either
-inline size_t slab_bytes(int M, int N, int nbatch, int splits, bool capped) {
-    if (splits <= 1) return 0;
-    size_t b = (size_t)nbatch * splits * M * N * sizeof(float);
-    if (use_x6()) {
-        const int cfg = x6_choose_cfg(M, N, capped);
-        const size_t f = (size_t)nbatch * splits * ceil_div(M, x6_bm(cfg)) * ceil_div(N, x6_bn(cfg)) * x6_bm(cfg) * x6_bn(cfg) * sizeof(float);
-        if (f > b) b = f;
-    }
-    return b;
-}
+inline size_t slab_bytes(int M, int N, int nbatch, int splits) { return splits <= 1 ? 0 : (size_t)nbatch * splits * M * N * sizeof(float); }
 
 // Band height of the tile order: the patch of tiles one XCD works on at a time (its share of the grid, at most ~64 in
 // flight) should be as square as the tile grid allows, so every operand panel is fetched by as few XCDs as possible.
@@ -1247,11 +1150,8 @@ inline void raise_dyn_lds(KernelT* kernel, int bytes) {
     }
 }
 
-// counters / n_counters: arrival counters of the in-launch split-K reduce (zero on entry, left zero); NULL or too few = two-pass
-struct Counters { unsigned* p = nullptr; int n = 0; };
-
 template <int AMODE, int BMODE>
-ams_status launch(GemmArgs& g, const LaunchOpt& opt, void* ws, size_t ws_bytes, Counters cnt, hipStream_t st, int nbatch = 1,
+ams_status launch(GemmArgs& g, const LaunchOpt& opt, void* ws, size_t ws_bytes, hipStream_t st, int nbatch = 1,
                   float* bsum_out = nullptr, int bsum_accumulate = 0, float* bsum_ws = nullptr) {
     constexpr bool AKc = (AMODE == A_ROW), BKcc = (BMODE == B_COL);
     const int lds_pad = opt.lds_pad < 0 ? 0 : opt.lds_pad;
@@ -1270,15 +1170,11 @@ ams_status launch(GemmArgs& g, const LaunchOpt& opt, void* ws, size_t ws_bytes, 
     const TilePlan tp = x6 ? x6_plan(cfg) : f32_plan();
     const int tiles = ceil_div(g.M, tp.bm) * ceil_div(g.N, tp.bn);
     g.group_m = choose_group_m(ceil_div(g.M, tp.bm), ceil_div(g.N, tp.bn));
-    // the in-launch reduce: 16-bit-pipe kernels, a counter per (batch, tile), column sums (if any) addressable as float4
-    const bool inred_ok = x6 && cnt.p != nullptr && (long)tiles * nbatch <= (long)cnt.n && tuning().inred &&
-                          (!bsum_out || (((uintptr_t)bsum_out | (uintptr_t)bsum_ws) & 15) == 0);
     int splits = 1;
     if (ws) {
         splits = choose_splits(g.M, g.N, g.K, nbatch, tp);
         if (tuning().splits > 0) splits = tuning().splits;
-        const size_t per = inred_ok ? (size_t)nbatch * tiles * tp.bm * tp.bn * sizeof(float) : (size_t)nbatch * g.M * g.N * sizeof(float);
-        while (splits > 1 && (size_t)splits * per > ws_bytes) --splits;
+        while (splits > 1 && (size_t)nbatch * splits * g.M * g.N * sizeof(float) > ws_bytes) --splits;
     }
     int kps = ceil_div(g.K, splits);
     kps = ceil_div(kps, tp.bk) * tp.bk;
@@ -1286,10 +1182,8 @@ ams_status launch(GemmArgs& g, const LaunchOpt& opt, void* ws, size_t ws_bytes, 
     g.splits = splits;
     g.k_per_split = kps;
     g.partial = (float*)ws;
-    const bool inred = inred_ok && splits > 1;
-    g.counters = inred ? cnt.p : nullptr;
     g.bsum_part = bsum_out ? bsum_ws : nullptr;
-    const bool bsum_in_launch = x6 && bsum_out && (splits == 1 || inred) && (((uintptr_t)bsum_out) & 15) == 0;
+    const bool bsum_in_launch = x6 && bsum_out && splits == 1 && (((uintptr_t)bsum_out) & 15) == 0;
     g.bsum_out = bsum_in_launch ? bsum_out : nullptr;
     g.bsum_accumulate = bsum_accumulate;
     g.nbatch = nbatch;
@@ -1342,7 +1236,7 @@ ams_status launch(GemmArgs& g, const LaunchOpt& opt, void* ws, size_t ws_bytes, 
     }
     ams_status s = ams_check_launch();
     if (s != AMS_OK) return s;
-    if (splits > 1 && !inred) {
+    if (splits > 1) {
         const long total = (long)g.M * g.N;
         const bool rvec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (g.c_zs % 4 == 0) && (g.bias_zs % 4 == 0) &&
                           (((uintptr_t)g.C | (uintptr_t)g.partial | (uintptr_t)g.bias) & 15) == 0 && total < (1L << 31);
@@ -1380,20 +1274,14 @@ size_t ams_gemm_workspace_bytes(int M, int N, int K, int nbatch, int lds_pad) {
     if (M <= 0 || N <= 0 || K <= 0 || nbatch <= 0) return 0;
     int splits = choose_splits(M, N, K, nbatch, lds_pad > 0);
     if (tuning().splits > 0) splits = tuning().splits;
-    return slab_bytes(M, N, nbatch, splits, lds_pad > 0);
-}
-
-// arrival counters the in-launch reduce of such a product would use: one per (batch, output tile) of the SMALLEST tile configuration
-int ams_gemm_counter_count(int M, int N, int nbatch) {
-    if (M <= 0 || N <= 0 || nbatch <= 0) return 0;
-    return ceil_div(M, 128) * ceil_div(N, 128) * nbatch;
+    return slab_bytes(M, N, nbatch, splits);
 }
 
 // C (+)= A^T . B  AND  bsum_out[N] (+)= column sums of B, in one pass over B (reference: the weight and bias gradients of a
 // width-1 Conv1D, utils/ops.py:501-503 under tf.gradients).  bsum_ws: 32 * N floats (one row per possible split).
 ams_status ams_gemm_f32_at_b_colsum(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                                     int accumulate, float* bsum_out, int bsum_accumulate, float* bsum_ws, const float* amax_a,
-                                    const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* counters, int n_counters,
+                                    const float* amax_b, int lds_pad, void* ws, size_t ws_bytes,
                                     void* stream) {
     AMS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C && bsum_out && bsum_ws);
     GemmArgs g{};
@@ -1404,12 +1292,12 @@ ams_status ams_gemm_f32_at_b_colsum(int M, int N, int K, const float* A, long ld
     g.b_vec = aligned16(B) && (ldb % 4 == 0);
     AMS_REQUIRE(g.a_vec && g.b_vec && M % 4 == 0 && N % 4 == 0 && aligned16(bsum_ws) && !tuning().novec);
     LaunchOpt o; o.amax_a = amax_a; o.amax_b = amax_b; o.lds_pad = lds_pad;
-    return launch<A_COL, B_ROW>(g, o, ws, ws_bytes, Counters{(unsigned*)counters, n_counters}, (hipStream_t)stream, 1, bsum_out, bsum_accumulate, bsum_ws);
+    return launch<A_COL, B_ROW>(g, o, ws, ws_bytes, (hipStream_t)stream, 1, bsum_out, bsum_accumulate, bsum_ws);
 }
 
 ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                         float* C, long ldc, const float* bias, int accumulate, int mask_period, int mask_skip, const float* amax_a,
-                        const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* counters, int n_counters, void* stream) {
+                        const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* stream) {
     AMS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C);
     GemmArgs g{};
     g.A = A; g.B = B; g.C = C; g.bias = bias;
@@ -1420,19 +1308,17 @@ ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float
     g.b_vec = aligned16(B) && (ldb % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
     LaunchOpt o; o.amax_a = amax_a; o.amax_b = amax_b; o.lds_pad = lds_pad;
-    const Counters c{(unsigned*)counters, n_counters};
-    if (!transA && !transB) return launch<A_ROW, B_ROW>(g, o, ws, ws_bytes, c, st);
-    if (!transA && transB) return launch<A_ROW, B_COL>(g, o, ws, ws_bytes, c, st);
-    if (transA && !transB) return launch<A_COL, B_ROW>(g, o, ws, ws_bytes, c, st);
-    return launch<A_COL, B_COL>(g, o, ws, ws_bytes, c, st);
+    if (!transA && !transB) return launch<A_ROW, B_ROW>(g, o, ws, ws_bytes, st);
+    if (!transA && transB) return launch<A_ROW, B_COL>(g, o, ws, ws_bytes, st);
+    if (transA && !transB) return launch<A_COL, B_ROW>(g, o, ws, ws_bytes, st);
+    return launch<A_COL, B_COL>(g, o, ws, ws_bytes, st);
 }
 
 // nbatch products of one shape in ONE launch: operand z is at A + z*a_zs etc. (element offsets, any sign).
 // Used for the two directions' recurrent-kernel gradients: 2 x 30 tiles fill the chip better than 30 twice.
 ams_status ams_gemm_f32_batched(int transA, int transB, int M, int N, int K, const float* A, long lda, long a_zs, const float* B,
                                 long ldb, long b_zs, float* C, long ldc, long c_zs, int nbatch, int accumulate, int mask_period,
-                                int mask_skip, const float* amax_a, const float* amax_b, int lds_pad, void* ws, size_t ws_bytes,
-                                void* counters, int n_counters, void* stream) {
+                                int mask_skip, const float* amax_a, const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* stream) {
     AMS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C && nbatch >= 1 && nbatch <= 64);
     GemmArgs g{};
     g.A = A; g.B = B; g.C = C; g.bias = nullptr;
@@ -1444,11 +1330,10 @@ ams_status ams_gemm_f32_batched(int transA, int transB, int M, int N, int K, con
     g.b_vec = aligned16(B) && (ldb % 4 == 0) && (b_zs % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
     LaunchOpt o; o.amax_a = amax_a; o.amax_b = amax_b; o.lds_pad = lds_pad;
-    const Counters c{(unsigned*)counters, n_counters};
-    if (!transA && !transB) return launch<A_ROW, B_ROW>(g, o, ws, ws_bytes, c, st, nbatch);
-    if (!transA && transB) return launch<A_ROW, B_COL>(g, o, ws, ws_bytes, c, st, nbatch);
-    if (transA && !transB) return launch<A_COL, B_ROW>(g, o, ws, ws_bytes, c, st, nbatch);
-    return launch<A_COL, B_COL>(g, o, ws, ws_bytes, c, st, nbatch);
+    if (!transA && !transB) return launch<A_ROW, B_ROW>(g, o, ws, ws_bytes, st, nbatch);
+    if (!transA && transB) return launch<A_ROW, B_COL>(g, o, ws, ws_bytes, st, nbatch);
+    if (transA && !transB) return launch<A_COL, B_ROW>(g, o, ws, ws_bytes, st, nbatch);
+    return launch<A_COL, B_COL>(g, o, ws, ws_bytes, st, nbatch);
 }
 
 // Adaptive analysis filterbank, path A (reference models/adapt.py:122): y[b,t,n] = sum_k xpad[b,t*hop+k-pl] f[k,n]
@@ -1459,7 +1344,7 @@ size_t ams_front_conv_fwd_workspace_bytes(int Bt, int L, int W, int N, int hop) 
 
 // ws (may be NULL: no split-K) lets the few-tile benchmark shape (5120 x 256 output = 80 tiles) fill 256 CUs.
 ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, int lds_pad, void* ws,
-                              size_t ws_bytes, void* counters, int n_counters, void* stream) {
+                              size_t ws_bytes, void* stream) {
     AMS_REQUIRE(x && f && y && Bt > 0 && L > 0 && W > 0 && N > 0 && hop > 0);
     const int T = (L + hop - 1) / hop;
     int pad_total = (T - 1) * hop + W - L;
@@ -1471,7 +1356,7 @@ ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, 
     g.a_vec = aligned16(x) && (L % 4 == 0) && (hop % 4 == 0) && (g.fr_pl % 4 == 0);
     g.b_vec = aligned16(f) && (N % 4 == 0);
     LaunchOpt o; o.lds_pad = lds_pad;
-    return launch<A_FRAMES, B_ROW>(g, o, ws, ws_bytes, Counters{(unsigned*)counters, n_counters}, (hipStream_t)stream);
+    return launch<A_FRAMES, B_ROW>(g, o, ws, ws_bytes, (hipStream_t)stream);
 }
 
 // Generic framed product: out[(r,t), n] = sum_k xpad[r, t*hop + k - pad_left] * Bm[k, n]   (STFT as a DFT product)
@@ -1484,14 +1369,14 @@ ams_status ams_frames_matmul(const float* x, const float* Bm, float* out, int R,
     g.fr_L = L; g.fr_T = T; g.fr_hop = hop; g.fr_pl = pad_left; g.fr_W = W;
     g.a_vec = aligned16(x) && (L % 4 == 0) && (hop % 4 == 0) && (pad_left % 4 == 0);
     g.b_vec = aligned16(Bm) && (N % 4 == 0);
-    return launch<A_FRAMES, B_ROW>(g, LaunchOpt{}, nullptr, 0, Counters{}, (hipStream_t)stream);
+    return launch<A_FRAMES, B_ROW>(g, LaunchOpt{}, nullptr, 0, (hipStream_t)stream);
 }
 
 // Filter gradient of a framed product with explicit geometry: dB[k,n] = sum_{r,t} xpad[r, t*hop + k - pad_left] * dy[(r,t), n]
 size_t ams_frames_matmul_bwd_filter_workspace_bytes(int R, int W, int N, int T) { return ams_gemm_workspace_bytes(W, N, R * T, 1, 0); }
 
 ams_status ams_frames_matmul_bwd_filter(const float* x, const float* dy, float* dB, int R, int L, int W, int N, int hop, int T,
-                                        int pad_left, void* ws, size_t ws_bytes, void* counters, int n_counters, void* stream) {
+                                        int pad_left, void* ws, size_t ws_bytes, void* stream) {
     AMS_REQUIRE(x && dy && dB && R > 0 && L > 0 && W > 0 && N > 0 && hop > 0 && T > 0 && pad_left >= 0);
     GemmArgs g{};
     g.A = x; g.B = dy; g.C = dB; g.bias = nullptr;
@@ -1499,7 +1384,7 @@ ams_status ams_frames_matmul_bwd_filter(const float* x, const float* dy, float* 
     g.fr_L = L; g.fr_T = T; g.fr_hop = hop; g.fr_pl = pad_left; g.fr_W = W;
     g.a_vec = aligned16(x) && (L % 4 == 0) && (hop % 4 == 0) && (pad_left % 4 == 0);
     g.b_vec = aligned16(dy) && (N % 4 == 0);
-    return launch<A_FRAMES_T, B_ROW>(g, LaunchOpt{}, ws, ws_bytes, Counters{(unsigned*)counters, n_counters}, (hipStream_t)stream);
+    return launch<A_FRAMES_T, B_ROW>(g, LaunchOpt{}, ws, ws_bytes, (hipStream_t)stream);
 }
 
 size_t ams_front_conv_bwd_filter_workspace_bytes(int Bt, int L, int W, int N, int hop) {
@@ -1509,7 +1394,7 @@ size_t ams_front_conv_bwd_filter_workspace_bytes(int Bt, int L, int W, int N, in
 
 // df[k,n] = sum_{b,t} xpad[b,t*hop+k-pl] * dy[b,t,n]   
 ams_status ams_front_conv_bwd_filter(const float* x, const float* dy, float* df, int Bt, int L, int W, int N, int hop,
-                                     void* ws, size_t ws_bytes, void* counters, int n_counters, void* stream) {
+                                     void* ws, size_t ws_bytes, void* stream) {
     AMS_REQUIRE(x && dy && df && Bt > 0 && L > 0 && W > 0 && N > 0 && hop > 0);
     const int T = (L + hop - 1) / hop;
     int pad_total = (T - 1) * hop + W - L;
@@ -1520,7 +1405,7 @@ ams_status ams_front_conv_bwd_filter(const float* x, const float* dy, float* df,
     g.fr_L = L; g.fr_T = T; g.fr_hop = hop; g.fr_pl = pad_total / 2; g.fr_W = W;
     g.a_vec = aligned16(x) && (L % 4 == 0) && (hop % 4 == 0) && (g.fr_pl % 4 == 0);
     g.b_vec = aligned16(dy) && (N % 4 == 0);
-    return launch<A_FRAMES_T, B_ROW>(g, LaunchOpt{}, ws, ws_bytes, Counters{(unsigned*)counters, n_counters}, (hipStream_t)stream);
+    return launch<A_FRAMES_T, B_ROW>(g, LaunchOpt{}, ws, ws_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -173,7 +173,6 @@ class TFDataset(object):
                            self.TEST_OTHER: max(1, nb // 10)}
         self.offsets = {self.TRAIN: 0, self.VALID: 1000000, self.TEST: 2000000, self.TEST_OTHER: 3000000}
         self.cursor = dict.fromkeys(self.nb_batches, 0)
-        self.generation = dict.fromkeys(self.nb_batches, 0)     # bumped by initialize(): a consumer that reads ahead knows its batch is stale
         self.pool = {}
         self.pool_batches = int(kwargs.get('synthetic_pool') or 8)
         # real data: the reference's TFRecord files next to config.workdir (or AMS_DATA_DIR)
@@ -196,7 +195,6 @@ class TFDataset(object):
         g = get_default_graph()
         with g.variable_scope('dataset'):
             self.handle = Placeholder('handle')
-            self.handle.dataset = self                           # (models/network.py::_train_graphed reads the pipeline one batch ahead)
             self.chunk_size = Placeholder('chunk_size')
             batch = Node('batch', self._next)
             self.next_mix = Node('next_mix', lambda run: batch.value(run)[0])
@@ -215,7 +213,6 @@ class TFDataset(object):
 
     def initialize(self, split):
         self.cursor[split] = 0
-        self.generation[split] = self.generation.get(split, 0) + 1
         if self.records is not None:
             self._iters.pop(split, None)
             self._epochs[split] = self._epochs.get(split, -1) + 1       # reshuffle_each_iteration (tf.data default)

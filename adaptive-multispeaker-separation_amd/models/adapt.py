@@ -116,18 +116,6 @@ class Adapt(Network):
     def connect_front(self, separator_class):
         self.sepNet = separator_class(True, **self.args)
 
-    def front_ahead_nodes(self):
-        """What a step needs of the batch that depends on the (frozen) front end only: the front output and the dominant-speaker
-        masks made from its source rows.  Network._train_graphed computes them one batch ahead, beside the previous step's
-        forward recurrence.  Path A only (the pooled fronts carry an argmax the back end reads as well)."""
-        if self.with_max_pool or self.with_average_pool or getattr(self, 'sepNet', None) is None:
-            return []
-        nodes = [self.y]
-        if getattr(self.sepNet, 'y', None) is not None and not (self.sepNet.function_mask in ('linear', 'sqrt', 'square')
-                                                                  or self.sepNet.loss_with_silence):
-            nodes.append(self.sepNet.y)
-        return nodes
-
     def connect_only_front_to_separator(self, separator, freeze_front=True):
         self.connect_front(separator)
         self.sepNet.output = self.sepNet.prediction

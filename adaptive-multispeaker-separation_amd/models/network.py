@@ -169,7 +169,6 @@ class Network(object):
                     arr = arr.reshape(tuple(v.shape))
                 v.data.copy_(torch.from_numpy(arr.astype(np.float32)).to(v.device))
                 g.initialized.add(name)
-            self._weights_written()
             return
         data = np.load(self._latest_checkpoint(path))
         for name in self.saver:
@@ -179,13 +178,6 @@ class Network(object):
             v = g.variables[name]
             v.data.copy_(torch.from_numpy(data[key]).to(v.device))
             g.initialized.add(name)
-        self._weights_written()
-
-    def _weights_written(self):
-        """Something other than the optimizer wrote variables: a tracked weight bound (FlatOptimizer.track_bound) is measured again."""
-        opt = self.__dict__.get('_cache_optimize')
-        if opt is not None:
-            opt.refresh_bound()
 
     def restore_last_checkpoint(self):
         self.restore_model(self._dir())
@@ -271,48 +263,20 @@ class Network(object):
             return [sm, sn] + [t.clone() for t in ins[2:]]
         return [t.clone() for t in ins]
 
-    def _ahead_nodes(self):
-        """Nodes of the step that depend on NOTHING but the batch and frozen variables -- the frozen front end's output and the
-        masks made from it (Adapt.front_ahead_nodes) -- when the recipe froze `front/` (connect_only_front_to_separator and the
-        fine-tuning recipes: /reference models/adapt.py:443-455): they can be computed for batch i+1 while step i runs.
-        AMS_FRONT_AHEAD=0 switches the pipelining off (A/B runs)."""
-        if os.environ.get('AMS_FRONT_AHEAD', '1') == '0' or not hasattr(self, 'front_ahead_nodes'):
-            return []
-        if any(v.ams_name.startswith('front/') for v in self.optimize.vars):
-            return []
-        return list(self.front_ahead_nodes())
-
-    def _ahead_compute(self, nodes, ins, bufs, bound, feed_dict):
-        """Evaluate the ahead nodes on the batch `ins` into the persistent buffers `bufs` (+ max |front output| into `bound`), on the
-        current stream.  A private Run: nothing of it is cached for the step's own pass."""
-        run = self._feeds(feed_dict, True, new_pass=False)
-        for node, t in zip((self.x_mix, self.x_non_mix, self.I), ins):
-            run.cache[id(node)] = t
-        with torch.no_grad(), K.lds_pad(int(os.environ.get('AMS_FRONT_AHEAD_PAD', '50000'))):
-            for node, buf in zip(nodes, bufs):
-                buf.copy_(node.value(run).reshape(buf.shape))
-            if K.F16X3:
-                K.absmax(bufs[0], out=bound)
-
     def _train_graphed(self, feed_dict, step):
         """Capture zero_grad + forward + backward once (after 2 eager steps) and replay it; inputs are copied into
         static buffers, the optimizer (per-step lr_t, all-reduce) stays outside the graph.
-
-        Frozen front (self._ahead_nodes()): TWO graphs are captured, for even and odd steps.  Graph k reads batch i from input set k and
-        the front output / masks of batch i from the persistent buffers `pre[k]`, and -- on the side stream, beside its forward
-        recurrence, whose rings leave the matrix pipes ~93 % idle -- computes front output / masks of batch i+1 (already resident in
-        input set 1-k) into `pre[1-k]`.  The first projection then starts at the top of the step instead of ~140 us into it.  The
-        input pipeline is read one batch ahead; a batch that is not there (end of a pass) or is stale (the split was re-initialised)
-        is fetched at its own step and its front part computed in line."""
-        st = self.__dict__.setdefault('_cg_state', {'n': 0, 'graph': None, 'graphs': {}, 'ahead': None,
+        (Round 4 built a two-graph form that computed a FROZEN front end one batch ahead, beside the previous step's forward rings:
+        measured 0 ... -0.5 %, not kept -- profiles/r04_d_front_ahead_ab.txt, commits 43a78ea..dc02139.)"""
+        st = self.__dict__.setdefault('_cg_state', {'n': 0, 'graph': None,
                                                     'stream': torch.cuda.Stream(priority=int(os.environ.get('AMS_MAIN_PRIORITY', '0')))})
+        ins = self._fetch_inputs(feed_dict)
         opt = self.optimize
         side = st['stream']
-        if st['graph'] is None and not st['graphs']:
+        if st['graph'] is None:
             st['n'] += 1
             if st['n'] <= 2:
                 # eager warm-up ON THE CAPTURE STREAM, so autograd's AccumulateGrad nodes are bound to it
-                ins = self._fetch_inputs(feed_dict)
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     run = self._feeds(feed_dict, True)
@@ -326,106 +290,6 @@ class Network(object):
                 opt.step()
                 self.last_run = run
                 return cost.detach().reshape(-1)[0]
-            st['nodes'] = self._ahead_nodes()
-        nodes = st.get('nodes') or []
-        if not nodes:
-            return self._train_graphed_single(feed_dict, st, opt, side)
-
-        # ---------------- two alternating graphs, front end one batch ahead
-        ds = next((getattr(k_, 'dataset', None) for k_ in feed_dict if getattr(k_, 'dataset', None) is not None), None)
-        token = (feed_dict.get(ds.handle), ds.generation.get(feed_dict.get(ds.handle), 0)) if ds is not None else None
-        k = st.get('parity', 0)
-        ah = st['ahead']
-        have_cur = ah is not None and ah['token'] == token and ah['slot'] == k
-        if 'ins' not in st:                                        # first graphed call: buffers from the first batch
-            first = self._fetch_inputs(feed_dict)
-            st['ins'] = [self._static_like(first), self._static_like(first)]
-            with torch.no_grad():
-                run0 = self._feeds(feed_dict, True, new_pass=False)
-                for node, t in zip((self.x_mix, self.x_non_mix, self.I), st['ins'][0]):
-                    run0.cache[id(node)] = t
-                shapes = [node.value(run0) for node in nodes]
-            st['pre'] = [[torch.empty_like(v).contiguous() for v in shapes] for _ in range(2)]
-            st['bound'] = [torch.ones(1, dtype=torch.float32, device=shapes[0].device) for _ in range(2)]
-            st['copy_stream'] = torch.cuda.Stream()
-            st['ahead_stream'] = torch.cuda.Stream()
-            cur = first
-        elif not have_cur:
-            cur = self._fetch_inputs(feed_dict)
-        if not have_cur:
-            for dst, src in zip(st['ins'][k], cur):
-                dst.copy_(src)
-            self._ahead_compute(nodes, st['ins'][k], st['pre'][k], st['bound'][k], feed_dict)      # in line: once per pass
-        # the NEXT batch, one step ahead of the trainer's loop
-        try:
-            nxt = self._fetch_inputs(feed_dict)
-        except (StopIteration, IndexError):
-            nxt = None
-        if nxt is not None:
-            cs = st['copy_stream']
-            # input set 1-k was last read by the previous step's graph: wait for THAT, not for the optimizer kernel behind it -- the
-            # copies then run beside the optimizer
-            if st.get('ev_done') is not None:
-                cs.wait_event(st['ev_done'])
-            else:
-                cs.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(cs):
-                for dst, src in zip(st['ins'][1 - k], nxt):
-                    dst.copy_(src)
-                    src.record_stream(cs)
-            torch.cuda.current_stream().wait_stream(cs)
-            st['ahead'] = {'token': token, 'slot': 1 - k}
-        else:
-            st['ahead'] = None
-        if k not in st['graphs']:
-            opt.track_bound(True)                                  # the optimizer kernels keep the weight bound: nothing to measure in the graph
-            run = self._feeds(feed_dict, True)
-            for node, t in zip((self.x_mix, self.x_non_mix, self.I), st['ins'][k]):
-                run.cache[id(node)] = t
-            K.tag_amax(st['pre'][k][0], st['bound'][k])
-            for node, buf in zip(nodes, st['pre'][k]):
-                run.cache[id(node)] = buf
-            g = torch.cuda.CUDAGraph()
-            torch.cuda.synchronize()
-            # thread_local: a collective library's watchdog thread (RCCL at N > 1) must not be able to invalidate this capture
-            with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
-                opt.zero_grad(defer=True)
-                run.begun = True
-                K.pass_begin(F.OVERLAP.side())                     # ring arena + gradient memset on the side stream (no weight bound: tracked)
-
-                def ahead(k=k):
-                    # the NEXT batch's front end on the side stream, forked right BEHIND this step's first projection: beside the
-                    # forward rings.  (Forked at the top of the step its capped product took every CU first and the projection --
-                    # whose 8-wave workgroups share a CU with nothing -- started 90 us late: profiles/r04_d_front_ahead_v1.txt.)
-                    s2 = st['ahead_stream'] if os.environ.get('AMS_FRONT_AHEAD_STREAM', '1') == '1' else F.OVERLAP.side()
-                    s2.wait_stream(torch.cuda.current_stream())
-                    with torch.cuda.stream(s2):
-                        self._ahead_compute(nodes, st['ins'][1 - k], st['pre'][1 - k], st['bound'][1 - k], feed_dict)
-                if os.environ.get('AMS_FRONT_AHEAD_FORK', '0') == '1':
-                    K.after_first_projection(ahead)
-                else:
-                    ahead()                                        # at the top: its small kernels run first, the capped product arrives behind the projection
-                cost = self.cost_model.value(run)
-                K.run_after_projection_hook()                      # (a model without a BLSTM projection: here)
-                self._backward(cost)
-                F.OVERLAP.join()
-                torch.cuda.current_stream().wait_stream(st['ahead_stream'])
-            st['graphs'][k] = (g, cost, run)
-        for hook in get_default_graph().pre_replay_hooks:      # host-drawn inputs of captured kernels (k-means seeds)
-            hook()
-        g, cost, run = st['graphs'][k]
-        g.replay()
-        st['ev_done'] = torch.cuda.Event()
-        st['ev_done'].record()
-        opt.step()
-        st['parity'] = 1 - k
-        self.last_run = run
-        return cost.detach().reshape(-1)[0]
-
-    def _train_graphed_single(self, feed_dict, st, opt, side):
-        """One captured graph, front end computed inside the step (front trainable, or AMS_FRONT_AHEAD=0)."""
-        ins = self._fetch_inputs(feed_dict)
-        if st['graph'] is None:
             st['static'] = self._static_like(ins)
             run = self._feeds(feed_dict, True)
             for node, t in zip((self.x_mix, self.x_non_mix, self.I), st['static']):

@@ -252,16 +252,12 @@ def main():
             # same model, same batches, same streams and overlap as the timed graph, plus two one-thread kernels per timed launch.
             # Its replays give the per-launch durations INSIDE the replayed step (each includes ~3 us of kernel boundaries).
             st = model._cg_state
-            timed_graph = (st['graph'], st.get('graphs'))
-            two = bool(st.get('graphs'))                            # frozen front: two alternating graphs (models/network.py)
-            st['graph'], st['graphs'], st['n'] = None, {}, 2        # next call(s) capture again
+            timed_graph = st['graph']
+            st['graph'], st['n'] = None, 2                         # next call captures again
             ops.PROFILE.reset(enabled=True, stamps=True)
-            for j in range(2 if two else 1):
-                one_step(args.warmup + args.steps + j)              # capture (stamps included) + first replay
-            ops.PROFILE.enabled = False                             # the stamps stay in the graph(s); nothing else is recorded
-            prof_steps = 2 if two else 1
-            if two and args.roofline_steps % 2:
-                args.roofline_steps += 1                            # both graphs replayed equally often: every stamp slot is fresh
+            one_step(args.warmup + args.steps)                      # capture (stamps included) + first replay
+            ops.PROFILE.enabled = False                             # the stamps stay in the graph; nothing else is recorded
+            prof_steps = 1
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for i in range(args.roofline_steps):

@@ -44,10 +44,10 @@ ams_status ams_front_filter_bwd(const float* w, const float* bases, const float*
  * x [Bt,L], f [W,N] -> y [Bt,T',N], T' = ceil(L/hop), pad_left = ((T'-1)hop+W-L)/2. */
 size_t ams_front_conv_fwd_workspace_bytes(int Bt, int L, int W, int N, int hop);
 ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, int lds_pad, void* ws,
-                              size_t ws_bytes, void* counters, int n_counters, void* stream);      /* lds_pad, counters: see ams_gemm_f32 */
+                              size_t ws_bytes, void* stream);      /* lds_pad: see ams_gemm_f32 */
 size_t ams_front_conv_bwd_filter_workspace_bytes(int Bt, int L, int W, int N, int hop);
 ams_status ams_front_conv_bwd_filter(const float* x, const float* dy, float* df, int Bt, int L, int W, int N, int hop, void* ws,
-                                     size_t ws_bytes, void* counters, int n_counters, void* stream);
+                                     size_t ws_bytes, void* stream);
 
 /* ---- K3/K4/K5 path B (--with_max_pool): stride-1 conv + tf.nn.max_pool_with_argmax fused (models/adapt.py:115-117);
  * argmax int64 = l*N + n (no batch term).  Sparse (unpool-free) synthesis and gather-form filter
@@ -88,11 +88,6 @@ ams_status ams_synth_unpool_bwd_vals(const float* dout, const int32_t* pos, cons
  *                    variants differ at the 1e-7 level (tests/test_gpu_gemm_f16.py::test_fp16x3_weight_gradient_bias_capped_and_free).
  *   ws, ws_bytes     split-K partial slabs, ams_gemm_workspace_bytes(M, N, K, nbatch, lds_pad); NULL = no split-K.  A workspace sized
  *                    under another setting is never an error: a launch uses as many slabs as it holds (down to none).
- *   counters, n_counters  (optional) uint32 arrival counters, at least ams_gemm_counter_count(M, N, nbatch) of them, ZERO on entry and
- *                    left zero: the 16-bit-pipe kernels then reduce split-K INSIDE the producing launch -- every workgroup of an output
- *                    tile publishes its partial tile (write-through), the last one to arrive adds the slabs in index order (bit-
- *                    identical to the two-pass form, independent of the arrival order) and applies bias / accumulate.  Two launches on
- *                    streams that may run concurrently need disjoint counters.  NULL: partial slabs + a second reduce launch.
  * Arithmetic without bounds (process-wide; default 1, or AMS_GEMM_X6 read once; ams_gemm_set_arith for tests and A/B runs): 1 =
  * "bf16x6" -- both f32 operands are split EXACTLY into three bf16 terms (hi + mid + lo, round-to-nearest) and six of the nine bf16 x
  * bf16 partial products (all but mid.lo, lo.mid, lo.lo <= 2^-26 |a.b|) are accumulated in f32 on v_mfma_f32_32x32x16_bf16, which gfx950
@@ -101,25 +96,23 @@ ams_status ams_synth_unpool_bwd_vals(const float* dout, const int32_t* pos, cons
  * the setting.  Inf / NaN operands give NaN in mode 1 (inf - inf in the split) where mode 0 propagates Inf.
  * Replaces nothing in the reference beyond tf.matmul / conv1d / conv2d in f32: it is how those products are issued. */
 size_t ams_gemm_workspace_bytes(int M, int N, int K, int nbatch, int lds_pad);
-int ams_gemm_counter_count(int M, int N, int nbatch);
 void ams_gemm_set_arith(int mode);
 int ams_gemm_get_arith(void);
 ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C,
                         long ldc, const float* bias, int accumulate, int mask_period, int mask_skip, const float* amax_a,
-                        const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* counters, int n_counters, void* stream);
+                        const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* stream);
 /* C[M,N] (+)= A^T . B with A stored [K, M] and B [K, N], AND bsum_out[N] (+)= column sums of B in the same pass over B: the
  * weight and bias gradients of Conv1D (utils/ops.py:501-503) and of a BLSTM layer's input kernels from one read of dY / dZ.  M, N, lda,
  * ldb multiples of 4, 16-byte aligned operands; bsum_ws = 32 * N floats of scratch (16-byte aligned). */
 ams_status ams_gemm_f32_at_b_colsum(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                                     int accumulate, float* bsum_out, int bsum_accumulate, float* bsum_ws, const float* amax_a,
-                                    const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* counters, int n_counters,
+                                    const float* amax_b, int lds_pad, void* ws, size_t ws_bytes,
                                     void* stream);
 /* nbatch products of ONE shape in one launch; operand z lives at A + z*a_zs, B + z*b_zs, C + z*c_zs (element offsets, any
  * sign).  No bias.  Used for the two BLSTM directions' recurrent-kernel gradients (h_prev^T . dZ). */
 ams_status ams_gemm_f32_batched(int transA, int transB, int M, int N, int K, const float* A, long lda, long a_zs, const float* B,
                                 long ldb, long b_zs, float* C, long ldc, long c_zs, int nbatch, int accumulate, int mask_period,
-                                int mask_skip, const float* amax_a, const float* amax_b, int lds_pad, void* ws, size_t ws_bytes,
-                                void* counters, int n_counters, void* stream);
+                                int mask_skip, const float* amax_a, const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* stream);
 /* out[0] = max |x[i]|, i < n, as a float (NaN if any x is NaN): an operand bound for the products above, for operands whose producer
    does not supply one.  Two stream-ordered launches (a 4-byte clear, the reduction); out is a device pointer. */
 ams_status ams_absmax_f32(const float* x, long n, float* out, void* stream);
@@ -260,16 +253,13 @@ ams_status ams_kl_sparsity_bwd(const float* y, const float* p_hat, const float* 
 ams_status ams_negative_energy_fwd(const float* y, float* out, int Bt, long M, void* ws, size_t ws_bytes, void* stream);
 ams_status ams_sumsq_bwd(const float* x, const float* upstream, float scale, float* dx, long n, int mode, int accumulate, void* stream);
 
-/* ---- K24  optimizers     models/network.py:181-194, utils/ops.py:686-703 ----
- * amax_io (may be NULL): a float the kernels RAISE to max |p| over the values they wrote (atomic max, never lowered; NaN sticks) -- a
- * running upper bound of the weights for the fp16x3 products (amax_b of ams_gemm_f32), kept without a pass over the 47 MB of
- * parameters per step.  The caller measures it once (ams_absmax_f32) and again whenever something else writes the parameters. */
+/* ---- K24  optimizers     models/network.py:181-194, utils/ops.py:686-703 ---- */
 ams_status ams_opt_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, long n, float lr_t, float beta1,
-                           float beta2, float eps, float grad_scale, const void* skip_if_set, float* amax_io, void* stream);
+                           float beta2, float eps, float grad_scale, const void* skip_if_set, void* stream);
 ams_status ams_opt_rmsprop(float* p, const float* g, float* ms, long n, float lr, float decay, float eps, float grad_scale,
-                           const void* skip_if_set, float* amax_io, void* stream);
+                           const void* skip_if_set, void* stream);
 ams_status ams_opt_momentum(float* p, const float* g, float* accum, long n, float lr, float momentum, float grad_scale,
-                            const void* skip_if_set, float* amax_io, void* stream);
+                            const void* skip_if_set, void* stream);
 ams_status ams_sumsq(const float* x, float* out, long n, void* ws, size_t ws_bytes, void* stream);
 /* measurement aid: buf[slot] (uint64) = the device's constant-rate wall clock when the stream reaches this point; ams_stamp_rate() =
  * its ticks per second.  Stamps bracket launches INSIDE a replayed hipGraph (HIP events recorded during capture cannot be read back). */
@@ -283,7 +273,7 @@ ams_status ams_frames_matmul(const float* x, const float* Bm, float* out, int R,
 
 size_t ams_frames_matmul_bwd_filter_workspace_bytes(int R, int W, int N, int T);
 ams_status ams_frames_matmul_bwd_filter(const float* x, const float* dy, float* dB, int R, int L, int W, int N, int hop, int T,
-                                        int pad_left, void* ws, size_t ws_bytes, void* counters, int n_counters, void* stream);
+                                        int pad_left, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- K5/K21 overlap-and-add: out[r,l] = sum_t frames[r,t,l+pad_left-t*hop]
  * second half of tf.nn.conv2d_transpose (models/adapt.py:241-243) and of inverse_stft (models/network.py:598-602) ---- */
