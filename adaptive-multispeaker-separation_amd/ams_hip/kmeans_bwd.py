@@ -1,5 +1,5 @@
-"""Host orchestration of the soft k-means backward: replays the unrolled iterations of the
-SELECTED try in reverse, one streaming HIP pass each (csrc/kmeans.hip: kmeans_soft_bwd_kernel)."""
+"""Host side of the soft k-means backward: picks the SELECTED try's centroid trace and hands it to ONE C call that
+replays the unrolled iterations in reverse (csrc/kmeans_soft.hip)."""
 import torch
 
 from . import ops
@@ -30,33 +30,19 @@ def soft_bwd(xn, inv, init_idx, best, w, trace, dsel, dout, C, tries, iterations
         else:
             wrow = (index % b) if faithful_tile else (index // tries)
             wsel = w[wrow].contiguous()
-    nb = lib.ams_kmeans_workspace_bytes(b, L, E, C)
+    # ONE call: final-assignment pass, the iteration passes in reverse, the dx pass (csrc/kmeans_soft.hip)
+    nb = lib.ams_kmeans_soft_bwd_workspace_bytes(b, L, E, C, iterations)
     ws = ops._ws(nb, xn)
-    # G[i] = d loss / d c_i: the final pass accumulates into G[iterations], iteration i reads G[i+1] and writes G[i] -- the
-    # per-iteration gradients phase 2 needs are then the slice G[1:], with no copies in between
-    G = torch.empty((iterations + 1, b, C, E), dtype=torch.float32, device=dev)
-    if dsel is not None:
-        G[iterations].copy_(dsel)
-    else:
-        G[iterations].zero_()
     p, s = ops._p, ops._s
     w_final = None if assign_at_end else wsel
-    # phase 1: centroid gradients only (dx == NULL): one read of xn per pass, no read-modify-write of dx
-    if dout is not None:
-        dout = dout.contiguous()
-        check(lib.ams_kmeans_soft_bwd_pass(p(xn), p(w_final), p(cents[-1]), p(None), p(None), p(None), p(dout), p(None), p(G[iterations]),
-                                           b, L, E, C, float(beta), 0, p(ws), nb, s()), 'ams_kmeans_soft_bwd_pass(final)')
-    for i in range(iterations - 1, -1, -1):
-        check(lib.ams_kmeans_soft_bwd_pass(p(xn), p(wsel), p(cents[i]), p(cents[i + 1]), p(dens[i]), p(G[i + 1]), p(None), p(None), p(G[i]),
-                                           b, L, E, C, float(beta), 1, p(ws), nb, s()), 'ams_kmeans_soft_bwd_pass(iter)')
-    g = G[0]
-    gs = G[1:]
-    # phase 2: dx of the final assignment and of every iteration in ONE pass over xn
+    cst = torch.stack(cents).contiguous()                                   # [n_it + 1, b, C, E]
+    dst = torch.stack(dens).contiguous() if iterations else None            # [n_it, b, C]
     dxn = torch.empty_like(xn)
-    cst = torch.stack(cents).contiguous()
-    dst = torch.stack(dens).contiguous() if iterations else None
-    check(lib.ams_kmeans_soft_bwd_dx(p(xn), p(wsel), p(w_final), p(cst), p(gs if iterations else None), p(dst), p(dout), p(dxn),
-                                     b, L, E, C, float(beta), iterations, s()), 'ams_kmeans_soft_bwd_dx')
+    g = torch.empty((b, C, E), dtype=torch.float32, device=dev)
+    dsel_c = dsel.contiguous() if dsel is not None else None
+    dout_c = dout.contiguous() if dout is not None else None
+    check(lib.ams_kmeans_soft_bwd(p(xn), p(wsel), p(w_final), p(cst), p(dst), p(dsel_c), p(dout_c), p(dxn), p(g), b, L, E, C, float(beta),
+                                  iterations, p(ws), nb, s()), 'ams_kmeans_soft_bwd')
     # c_0 = xn[idx]: scatter-add the remaining centroid gradient onto the picked points (tiny: b*C rows)
     # (the C picks of a row are distinct -- np.random.choice without replacement, Kmeans_2.py:63 -- so no two updates collide)
     idx_sel = (init_idx if index is None else init_idx[index]).long()   # [b, C]

@@ -447,271 +447,6 @@ __global__ void kmeans_select_kernel(const float* __restrict__ inertia, const fl
 }
 
 
-// ---- soft k-means backward, one streaming pass per unrolled iteration, selected try only ----
-// ITER pass (g = d/d c_{i+1}):   dnum_c = g_c/den_c, dden_c = -<g_c, c_{i+1,c}>/den_c,
-//   dlab[l,c] = w_l <x_l, dnum_c> + dden_c,  dx_l += w_l sum_c lab[l,c] dnum_c
-// FINAL pass (labels returned to the caller): dlab[l,c] = dout[l,c]
-// both: dlogit = lab (dlab - sum_c lab dlab), dd2 = -beta w_l dlogit, dx_l += sum_c 2 (x_l - c_c) dd2[l,c],
-//       g_out[c] = - sum_l 2 (x_l - c_c) dd2[l,c]      (gradient w.r.t. the centroids that produced lab)
-struct KmBwdArgs {
-    const float* xn; const float* w; const float* cent; const float* cent_next; const float* den; const float* g_in;
-    const float* dout; float* dx; float* part; long L; int G; int iter_mode; float beta;
-};
-
-template <int E_, int C_>
-__global__ __launch_bounds__(256) void kmeans_soft_bwd_kernel(KmBwdArgs a) {
-    constexpr int NV = C_ * E_;
-    static_assert(E_ % 4 == 0, "rows are staged as 16-byte vectors");
-    constexpr int LD = E_ + 4, V4 = E_ / 4;
-    constexpr int BUF = (256 * LD > 128 * 64) ? 256 * LD : 128 * 64;
-    __shared__ __attribute__((aligned(16))) float buf[BUF];
-    __shared__ float scent[C_ * E_], sdnum[C_ * E_], sdden[C_];
-    const int r = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const float* xb = a.xn + (long)r * a.L * E_;
-    float* dxb = a.dx ? a.dx + (long)r * a.L * E_ : nullptr;
-    const float* wb = a.w ? a.w + (long)r * a.L : nullptr;
-    for (int i = tid; i < C_ * E_; i += 256) scent[i] = a.cent[(long)r * C_ * E_ + i];
-    if (a.iter_mode) {
-        for (int i = tid; i < C_ * E_; i += 256) sdnum[i] = a.g_in[(long)r * C_ * E_ + i] / a.den[(long)r * C_ + i / E_];
-        if (tid < C_) {
-            float d = 0.f;
-            for (int e = 0; e < E_; ++e) d += a.g_in[((long)r * C_ + tid) * E_ + e] * a.cent_next[((long)r * C_ + tid) * E_ + e];
-            sdden[tid] = -d / a.den[(long)r * C_ + tid];
-        }
-    }
-    float acc[NV];
-#pragma unroll
-    for (int i = 0; i < NV; ++i) acc[i] = 0.f;
-
-    float4 pre[V4];                                 // 16-byte staging; no run-ahead here (2.5 workgroups per CU: it measured slower)
-    auto fetch = [&](int j) {
-        const long q0 = (long)g * CHUNK + (long)j * LANES;
-        const int np = (int)max((long)0, min((long)LANES, a.L - q0));
-        const float4* src = reinterpret_cast<const float4*>(xb + q0 * E_);
-#pragma unroll
-        for (int k = 0; k < V4; ++k) {
-            const int i = tid + 256 * k;
-#ifdef AMS_KM_NOLOAD            /* timing experiment only: the pass without its global reads */
-            pre[k] = make_float4((float)i, 1.f, (float)j, 0.5f);
-#else
-            pre[k] = (i < np * V4) ? src[i] : make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
-        }
-    };
-    for (int j = 0; j < PPL; ++j) {
-        const long p0 = (long)g * CHUNK + (long)j * LANES;
-        const int npts = (int)max((long)0, min((long)LANES, a.L - p0));
-        __syncthreads();
-        fetch(j);
-#pragma unroll
-        for (int k = 0; k < V4; ++k) {
-            const int i = tid + 256 * k;
-            const int row = i / V4, c4 = i - row * V4;
-            *reinterpret_cast<float4*>(&buf[row * LD + c4 * 4]) = pre[k];
-        }
-        __syncthreads();
-        float dxl[E_];
-        if (tid < npts) {
-            float x[E_];
-#pragma unroll
-            for (int e = 0; e < E_; ++e) { x[e] = buf[tid * LD + e]; dxl[e] = 0.f; }
-            const float wv = wb ? wb[p0 + tid] : 1.0f;
-            float lab[C_], dlab[C_], sum = 0.f;
-#pragma unroll
-            for (int c = 0; c < C_; ++c) {
-                float d = 0.f;
-#pragma unroll
-                for (int e = 0; e < E_; ++e) { const float diff = x[e] - scent[c * E_ + e]; d += diff * diff * wv; }
-                lab[c] = expf(-a.beta * d);
-                sum += lab[c];
-            }
-            const float inv = 1.0f / sum;
-            float mean = 0.f;
-#pragma unroll
-            for (int c = 0; c < C_; ++c) {
-                lab[c] *= inv;
-                if (a.iter_mode) {
-                    float dot = 0.f;
-#pragma unroll
-                    for (int e = 0; e < E_; ++e) dot += x[e] * sdnum[c * E_ + e];
-                    dlab[c] = wv * dot + sdden[c];
-#pragma unroll
-                    for (int e = 0; e < E_; ++e) dxl[e] += wv * lab[c] * sdnum[c * E_ + e];
-                } else {
-                    dlab[c] = a.dout[((long)r * a.L + p0 + tid) * C_ + c];
-                }
-                mean += lab[c] * dlab[c];
-            }
-#pragma unroll
-            for (int c = 0; c < C_; ++c) {
-                const float dd2 = -a.beta * wv * lab[c] * (dlab[c] - mean);
-#pragma unroll
-                for (int e = 0; e < E_; ++e) {
-                    const float t2 = 2.0f * (x[e] - scent[c * E_ + e]) * dd2;
-                    dxl[e] += t2;
-                    acc[c * E_ + e] -= t2;
-                }
-            }
-        }
-        // dx += dxl, transposed through LDS for coalesced read-modify-write (skipped when the caller only wants the centroid
-        // gradient: the two-phase backward accumulates dx for ALL iterations in one later pass, kmeans_soft_bwd_dx_kernel)
-        if (a.dx) {
-            __syncthreads();
-            if (tid < npts) {
-#pragma unroll
-                for (int e = 0; e < E_; ++e) buf[tid * LD + e] = dxl[e];
-            }
-            __syncthreads();
-            for (int i = tid; i < npts * E_; i += 256) dxb[p0 * E_ + i] += buf[(i / E_) * LD + (i % E_)];
-        }
-    }
-#pragma unroll
-    for (int v0 = 0; v0 < NV; v0 += 64) {
-        __syncthreads();
-        if (wave >= 2) {
-#pragma unroll
-            for (int i = 0; i < 64; ++i)
-                if (v0 + i < NV) buf[i * 128 + (wave - 2) * 64 + lane] = acc[v0 + i];
-        }
-        __syncthreads();
-        if (wave < 2) {
-#pragma unroll
-            for (int i = 0; i < 64; ++i)
-                if (v0 + i < NV) acc[v0 + i] += buf[i * 128 + wave * 64 + lane];
-        }
-        __syncthreads();
-        if (wave == 1) {
-#pragma unroll
-            for (int i = 0; i < 64; ++i)
-                if (v0 + i < NV) buf[i * 64 + lane] = acc[v0 + i];
-        }
-        __syncthreads();
-        if (wave == 0) {
-#pragma unroll
-            for (int i = 0; i < 64; ++i)
-                if (v0 + i < NV) acc[v0 + i] += buf[i * 64 + lane];
-        }
-    }
-    if (wave == 0) {
-#pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const float v = wave_sum_lane0(acc[i]);                  // VALU tree: 80+ values per workgroup (was 6 ds_bpermute each)
-            if (lane == 0) a.part[((long)r * a.G + g) * NV + i] = v;
-        }
-    }
-}
-
-// Phase 2 of the two-phase soft k-means backward: dx for the FINAL assignment and ALL unrolled iterations in ONE pass over xn
-// (one read of xn, one write of dx, instead of a read-modify-write of dx per iteration).  Per utterance the per-iteration
-// constants -- centroids c_i, dnum_i = g_i/den_i, dden_i = -<g_i, c_{i+1}>/den_i -- sit in LDS (n_it * (2CE + C) floats).
-struct KmDxArgs {
-    const float* xn; const float* w; const float* w_final;
-    const float* cents;    // [n_it + 1, b, C, E]   c_0 .. c_n
-    const float* gs;       // [n_it, b, C, E]       gradient w.r.t. c_{i+1} consumed by iteration i
-    const float* dens;     // [n_it, b, C]
-    const float* dout;     // [b, L, C] or null
-    float* dx;             // [b, L, E]  (fully written)
-    long L; int b, n_it; float beta;
-};
-constexpr int MAX_IT = 24;
-
-template <int E_, int C_>
-__global__ __launch_bounds__(256) void kmeans_soft_bwd_dx_kernel(KmDxArgs a) {
-    constexpr int LD = E_ + 1;
-    constexpr int CE = C_ * E_;
-    __shared__ float buf[256 * LD];
-    extern __shared__ float dynp[];                 // [n_it] x (cent CE | dnum CE | dden C), then the final centroids CE
-    const int r = blockIdx.y, tid = threadIdx.x;
-    const int STRIDE = 2 * CE + C_;
-    for (int it = 0; it < a.n_it; ++it) {
-        float* pc = dynp + it * STRIDE;
-        const float* cen = a.cents + ((long)it * a.b + r) * CE;
-        const float* cnx = a.cents + ((long)(it + 1) * a.b + r) * CE;
-        const float* g = a.gs + ((long)it * a.b + r) * CE;
-        const float* den = a.dens + ((long)it * a.b + r) * C_;
-        for (int i = tid; i < CE; i += 256) { pc[i] = cen[i]; pc[CE + i] = g[i] / den[i / E_]; }
-        if (tid < C_) {
-            float d = 0.f;
-            for (int e = 0; e < E_; ++e) d += g[tid * E_ + e] * cnx[tid * E_ + e];
-            pc[2 * CE + tid] = -d / den[tid];
-        }
-    }
-    float* pfin = dynp + a.n_it * STRIDE;
-    for (int i = tid; i < CE; i += 256) pfin[i] = a.cents[((long)a.n_it * a.b + r) * CE + i];
-    const float* xb = a.xn + (long)r * a.L * E_;
-    float* dxb = a.dx + (long)r * a.L * E_;
-    const float* wb = a.w ? a.w + (long)r * a.L : nullptr;
-    const float* wf = a.w_final ? a.w_final + (long)r * a.L : nullptr;
-
-    for (long p0 = (long)blockIdx.x * 256; p0 < a.L; p0 += (long)gridDim.x * 256) {
-        const int npts = (int)min((long)256, a.L - p0);
-        __syncthreads();
-        for (int i = tid; i < npts * E_; i += 256) buf[(i / E_) * LD + (i % E_)] = xb[p0 * E_ + i];
-        __syncthreads();
-        float dxl[E_];
-        if (tid < npts) {
-            float x[E_];
-#pragma unroll
-            for (int e = 0; e < E_; ++e) { x[e] = buf[tid * LD + e]; dxl[e] = 0.f; }
-            const float wit = wb ? wb[p0 + tid] : 1.0f;
-            const int first = a.dout ? -1 : 0;
-            for (int it = first; it < a.n_it; ++it) {
-                const bool fin = it < 0;
-                const float* pc = fin ? pfin : dynp + it * STRIDE;
-                const float wv = fin ? (wf ? wf[p0 + tid] : 1.0f) : wit;
-                float lab[C_], dlab[C_], sum = 0.f;
-#pragma unroll
-                for (int c = 0; c < C_; ++c) {
-                    float d = 0.f;
-#pragma unroll
-                    for (int e = 0; e < E_; ++e) { const float diff = x[e] - pc[c * E_ + e]; d += diff * diff * wv; }
-                    lab[c] = expf(-a.beta * d);
-                    sum += lab[c];
-                }
-                const float inv = 1.0f / sum;
-                float mean = 0.f;
-#pragma unroll
-                for (int c = 0; c < C_; ++c) {
-                    lab[c] *= inv;
-                    if (!fin) {
-                        float dot = 0.f;
-#pragma unroll
-                        for (int e = 0; e < E_; ++e) dot += x[e] * pc[CE + c * E_ + e];
-                        dlab[c] = wv * dot + pc[2 * CE + c];
-#pragma unroll
-                        for (int e = 0; e < E_; ++e) dxl[e] += wv * lab[c] * pc[CE + c * E_ + e];
-                    } else {
-                        dlab[c] = a.dout[((long)r * a.L + p0 + tid) * C_ + c];
-                    }
-                    mean += lab[c] * dlab[c];
-                }
-#pragma unroll
-                for (int c = 0; c < C_; ++c) {
-                    const float dd2 = -a.beta * wv * lab[c] * (dlab[c] - mean);
-#pragma unroll
-                    for (int e = 0; e < E_; ++e) dxl[e] += 2.0f * (x[e] - pc[c * E_ + e]) * dd2;
-                }
-            }
-        }
-        __syncthreads();
-        if (tid < npts) {
-#pragma unroll
-            for (int e = 0; e < E_; ++e) buf[tid * LD + e] = dxl[e];
-        }
-        __syncthreads();
-        for (int i = tid; i < npts * E_; i += 256) dxb[p0 * E_ + i] = buf[(i / E_) * LD + (i % E_)];
-    }
-}
-
-__global__ void kmeans_bwd_reduce_kernel(const float* __restrict__ part, float* __restrict__ g_out, int R, int G, int NV, int accumulate) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)R * NV) return;
-    const int r = (int)(i / NV), k = (int)(i - (long)r * NV);
-    float s = 0.f;
-    for (int g = 0; g < G; ++g) s += part[((long)r * G + g) * NV + k];
-    g_out[i] = accumulate ? g_out[i] + s : s;
-}
-
 template <int MODE>
 ams_status launch_pass(const KmArgs& a, int R, int E, int C, hipStream_t st) {
     dim3 grid((unsigned)(ceil_div(a.b, 8) * 8 * a.G * a.tries));   // flat: see the work order at the top of kmeans_pass_kernel
@@ -797,62 +532,6 @@ ams_status ams_kmeans_assign(const float* xn, const float* w, const float* cent,
 }
 
 // One backward pass of the unrolled soft k-means for b rows (the selected tries, already gathered by the caller):
-// iter_mode 1: cent = c_i, cent_next = c_{i+1}, den = sum_l lab_i, g_in = d/d c_{i+1};  g_out = d/d c_i (overwritten)
-// iter_mode 0: cent = final centroids, dout = d/d labels [b,L,C];                        g_out += d/d cent
-// dx [b,L,E] is accumulated into.
-ams_status ams_kmeans_soft_bwd_pass(const float* xn, const float* w, const float* cent, const float* cent_next, const float* den,
-                                    const float* g_in, const float* dout, float* dx, float* g_out, int b, long L, int E, int C,
-                                    float beta, int iter_mode, void* ws, size_t ws_bytes, void* stream) {
-    AMS_REQUIRE(xn && cent && g_out && ws && b > 0 && L > 0 && C >= 2 && C <= 4 && beta >= 0.f);      // dx may be NULL
-    AMS_REQUIRE(iter_mode ? (cent_next && den && g_in) : (dout != nullptr));
-    if (ws_bytes < ams_kmeans_workspace_bytes(b, L, E, C)) return AMS_E_WORKSPACE_TOO_SMALL;
-    hipStream_t st = (hipStream_t)stream;
-    KmBwdArgs a{};
-    a.xn = xn; a.w = w; a.cent = cent; a.cent_next = cent_next; a.den = den; a.g_in = g_in; a.dout = dout; a.dx = dx;
-    a.part = (float*)ws; a.L = L; a.G = ceil_div(L, CHUNK); a.iter_mode = iter_mode; a.beta = beta;
-    dim3 grid(a.G, b);
-#define AMS_KB(EE, CC) hipLaunchKernelGGL((kmeans_soft_bwd_kernel<EE, CC>), grid, dim3(256), 0, st, a)
-    if (E == 40 && C == 2) AMS_KB(40, 2);
-    else if (E == 40 && C == 3) AMS_KB(40, 3);
-    else if (E == 40 && C == 4) AMS_KB(40, 4);
-    else if (E == 8 && C == 2) AMS_KB(8, 2);
-    else if (E == 8 && C == 3) AMS_KB(8, 3);
-    else if (E == 20 && C == 2) AMS_KB(20, 2);
-    else return AMS_E_INVALID_ARG;
-#undef AMS_KB
-    hipLaunchKernelGGL(kmeans_bwd_reduce_kernel, dim3(ceil_div((long)b * C * E, 256)), dim3(256), 0, st, (const float*)ws, g_out, b, a.G,
-                       C * E, iter_mode ? 0 : 1);
-    return ams_check_launch();
-}
-
-// Phase 2 of the two-phase backward: dx [b,L,E] (fully written) for the final assignment (dout != NULL) and the n_it unrolled
-// iterations, from the stacked per-iteration centroids [n_it+1,b,C,E], consumed centroid gradients [n_it,b,C,E] and
-// denominators [n_it,b,C] that phase 1 (ams_kmeans_soft_bwd_pass with dx == NULL) produced.
-ams_status ams_kmeans_soft_bwd_dx(const float* xn, const float* w, const float* w_final, const float* cents, const float* gs,
-                                  const float* dens, const float* dout, float* dx, int b, long L, int E, int C, float beta, int n_it,
-                                  void* stream) {
-    AMS_REQUIRE(xn && cents && dx && b > 0 && L > 0 && C >= 2 && C <= 4 && beta >= 0.f && n_it >= 0 && n_it <= MAX_IT);
-    AMS_REQUIRE(n_it == 0 || (gs && dens));
-    KmDxArgs a{};
-    a.xn = xn; a.w = w; a.w_final = w_final; a.cents = cents; a.gs = gs; a.dens = dens; a.dout = dout; a.dx = dx;
-    a.L = L; a.b = b; a.n_it = n_it; a.beta = beta;
-    const size_t dyn = (size_t)(n_it * (2 * C * E + C) + C * E) * sizeof(float);
-    int gx = ceil_div(L, 256);
-    const int cap = max(1, 2048 / b);
-    if (gx > cap) gx = cap;
-    dim3 grid(gx, b);
-#define AMS_KD(EE, CC) hipLaunchKernelGGL((kmeans_soft_bwd_dx_kernel<EE, CC>), grid, dim3(256), dyn, (hipStream_t)stream, a)
-    if (E == 40 && C == 2) AMS_KD(40, 2);
-    else if (E == 40 && C == 3) AMS_KD(40, 3);
-    else if (E == 40 && C == 4) AMS_KD(40, 4);
-    else if (E == 8 && C == 2) AMS_KD(8, 2);
-    else if (E == 8 && C == 3) AMS_KD(8, 3);
-    else if (E == 20 && C == 2) AMS_KD(20, 2);
-    else return AMS_E_INVALID_ARG;
-#undef AMS_KD
-    return ams_check_launch();
-}
-
 ams_status ams_kmeans_select(const float* inertia, const float* centroids, int32_t* best, float* selected, int b, int tries, int E,
                              int C, void* stream) {
     AMS_REQUIRE(inertia && centroids && best && selected && b > 0 && tries > 0);

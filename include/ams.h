@@ -338,16 +338,17 @@ ams_status ams_kmeans_init(const float* xn, const int32_t* init_idx, float* cent
                            void* stream);
 ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent_in, float* cent_out, float* den_out, int b, int tries,
                               long L, int E, int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* stream);
-/* backward of one unrolled soft iteration / of the final soft assignment, for b already-selected rows */
-ams_status ams_kmeans_soft_bwd_pass(const float* xn, const float* w, const float* cent, const float* cent_next, const float* den,
-                                    const float* g_in, const float* dout, float* dx, float* g_out, int b, long L, int E, int C,
-                                    float beta, int iter_mode, void* ws, size_t ws_bytes, void* stream);
-/* two-phase form: call ams_kmeans_soft_bwd_pass with dx == NULL for every iteration (centroid gradients only), then ONE
- * ams_kmeans_soft_bwd_dx over xn: cents [n_it+1,b,C,E] = c_0..c_n, gs [n_it,b,C,E] = gradient w.r.t. c_{i+1} consumed by
- * iteration i, dens [n_it,b,C]; dout [b,L,C] (may be NULL) = gradient of the returned soft labels, w_final its weights. */
-ams_status ams_kmeans_soft_bwd_dx(const float* xn, const float* w, const float* w_final, const float* cents, const float* gs,
-                                  const float* dens, const float* dout, float* dx, int b, long L, int E, int C, float beta, int n_it,
-                                  void* stream);
+/* Backward of the unrolled soft k-means for b already-selected rows (models/Kmeans_2.py:145-188 under tf.gradients;
+ * csrc/kmeans_soft.hip): one call enqueues the final-assignment pass, the n_it iteration passes in reverse (each one streaming read of
+ * xn, partial sums finished by the last-arriving workgroup: no reduce launches) and ONE pass that writes dx.
+ *   xn [b,L,E] normalised embeddings; w [b,L] silence weights of the iterations or NULL; w_final: weights of the returned assignment
+ *   or NULL (--end_assign: all ones); cents [n_it+1,b,C,E] = c_0..c_n; dens [n_it,b,C] = sum_l lab_i; dsel [b,C,E] = d/d c_n or NULL;
+ *   dout [b,L,C] = d/d returned soft labels or NULL.  Out: dx [b,L,E] (fully written), g0 [b,C,E] = d/d c_0 (scattered onto the seed
+ *   points by the caller).  ws: ams_kmeans_soft_bwd_workspace_bytes. */
+size_t ams_kmeans_soft_bwd_workspace_bytes(int b, long L, int E, int C, int n_it);
+ams_status ams_kmeans_soft_bwd(const float* xn, const float* w, const float* w_final, const float* cents, const float* dens, const float* dsel,
+                               const float* dout, float* dx, float* g0, int b, long L, int E, int C, float beta, int n_it, void* ws,
+                               size_t ws_bytes, void* stream);
 ams_status ams_kmeans_assign(const float* xn, const float* w, const float* cent, int32_t* labels, float* soft, float* inertia, int b,
                              int tries, long L, int E, int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* stream);
 ams_status ams_kmeans_select(const float* inertia, const float* centroids, int32_t* best, float* selected, int b, int tries, int E,
