@@ -542,11 +542,21 @@ def gemm_batched(A, B, C, nbatch, a_zs, b_zs, c_zs, transA, transB, M, N, K, lda
 
 
 # ------------------------------------------------------------------ masks
-def make_masks(rep_non_mix, B, S, a, b, take_abs, want_argmax=False):
-    """rep_non_mix: [B*S, ...] rows (b,s) row-major.  Returns Y [B, TF, S] (and int32 argmax [B, TF])."""
+def make_masks(rep_non_mix, B, S, a, b, take_abs, want_argmax=False, dpcl_E=None):
+    """rep_non_mix: [B*S, ...] rows (b,s) row-major.  Returns Y [B, TF, S] (and int32 argmax [B, TF]).
+    dpcl_E: the labels feed the fused deep-clustering loss on E-dimensional embeddings in this pass -- count them as they are written
+    (include/ams.h: ams_dpcl_u_make_masks); dpcl_loss_fwd_u on the same Y then skips its own count launch."""
     _chk(rep_non_mix)
     TF = rep_non_mix.numel() // (B * S)
     Y = torch.empty((B, TF, S), dtype=torch.float32, device=rep_non_mix.device)
+    if dpcl_E is not None and not want_argmax and S <= 8 and dpcl_E + S <= 64:
+        lib = load()
+        nb = lib.ams_dpcl_u_workspace_bytes(B, TF, dpcl_E, S)
+        ws = _ws(nb, Y)
+        check(lib.ams_dpcl_u_make_masks(_p(rep_non_mix), _p(Y), B, S, TF, dpcl_E, float(a), float(b), int(take_abs), _p(ws), nb, _s()),
+              'ams_dpcl_u_make_masks')
+        _DPCL_AHEAD[0] = (Y.data_ptr(), (B, TF, S, dpcl_E), PASS[0], ws)
+        return Y
     am = torch.empty((B, TF), dtype=torch.int32, device=rep_non_mix.device) if want_argmax else None
     check(load().ams_make_masks(_p(rep_non_mix), _p(Y), _p(am), B, S, TF, float(a), float(b), int(take_abs), _s()), 'ams_make_masks')
     return (Y, am) if want_argmax else Y
@@ -928,6 +938,22 @@ def dpcl_loss_fwd(V, Y):
     return out, ws
 
 
+_DPCL_AHEAD = [None]          # (Y.data_ptr(), (B, TF, S, E), PASS[0], workspace) of the latest dpcl_count_labels_ahead / make_masks(dpcl_E=)
+
+
+def dpcl_count_labels_ahead(Y, E):
+    """Label counts of the fused loss, issued before U exists (include/ams.h: ams_dpcl_u_count_labels); the dpcl_loss_fwd_u of the
+    same pass on the same Y picks the workspace up and skips its own count launch."""
+    _chk(Y)
+    lib = load()
+    B, TF, S = Y.shape
+    nb = lib.ams_dpcl_u_workspace_bytes(B, TF, E, S)
+    ws = _ws(nb, Y)
+    check(lib.ams_dpcl_u_count_labels(_p(Y), B, TF, E, S, _p(ws), nb, _s()), 'ams_dpcl_u_count_labels')
+    _DPCL_AHEAD[0] = (Y.data_ptr(), (B, TF, S, E), PASS[0], ws)
+    return ws
+
+
 def dpcl_loss_fwd_u(U, Y, want_V=False):
     """Fused l2-normalise + DPCL loss on the dense output U [B,TF,E] -> (out[4], inv [B,TF], V or None, ws)."""
     _chk(U, Y)
@@ -935,12 +961,15 @@ def dpcl_loss_fwd_u(U, Y, want_V=False):
     B, TF, E = U.shape
     S = Y.shape[2]
     nb = lib.ams_dpcl_u_workspace_bytes(B, TF, E, S)
-    ws = _ws(nb, U)
+    ahead, _DPCL_AHEAD[0] = _DPCL_AHEAD[0], None
+    ready = ahead is not None and ahead[:3] == (Y.data_ptr(), (B, TF, S, E), PASS[0])
+    ws = ahead[3] if ready else _ws(nb, U)
     out = torch.empty(4, dtype=torch.float32, device=U.device)
     inv = torch.empty(B, TF, dtype=torch.float32, device=U.device)
     V = torch.empty_like(U) if want_V else None
     ev = PROFILE.begin() if PROFILE.enabled else None
-    check(lib.ams_dpcl_loss_fwd_u(_p(U), _p(Y), _p(inv), _p(V), _p(out), B, TF, E, S, _p(ws), nb, _s()), 'ams_dpcl_loss_fwd_u')
+    check(lib.ams_dpcl_loss_fwd_u(_p(U), _p(Y), _p(inv), _p(V), _p(out), B, TF, E, S, int(ready), _p(ws), nb, _s()),
+          'ams_dpcl_loss_fwd_u')
     if ev is not None:      # algorithmic bytes: read U and Y once, write 1/|u| (+ V when asked)   
         PROFILE.end(ev, 2.0 * B * TF * (E + S) * (E + S), 4.0 * B * TF * (E + S + 1 + (E if want_V else 0)), 'dpcl_gram_u', 'dpcl')
     return out, inv, V, ws

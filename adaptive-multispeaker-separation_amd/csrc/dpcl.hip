@@ -156,26 +156,57 @@ constexpr int UCHUNK = AMS_DPCL_UCHUNK;           // points per workgroup in the
 #endif
 constexpr int BCHUNK = AMS_DPCL_BCHUNK;           // ... in the backward pass (no per-workgroup partials there: may be smaller)
 
-__global__ __launch_bounds__(256) void dpcl_count_part_kernel(const float* __restrict__ Y, float* __restrict__ cntp, long TF, int S,
-                                                              unsigned* __restrict__ ticket = nullptr) {
-    __shared__ float sm[4][8];
+// MAKE: the labels do not exist yet -- src holds the per-source representations, rows (b, s) of TF values each, and the pass writes
+// Y[b, p, s] = a where s = argmax_s' |src[b, s', p]| (first index wins ties), b_ elsewhere, exactly as make_masks_kernel
+// (csrc/elementwise.hip; reference models/network.py:369-378) and counts what it writes.  The summation order is the same in both
+// forms, so the counts carry the same bits whichever produced them.
+constexpr int CNT_THREADS = 1024;       // 16 waves per workgroup: 8 workgroups per utterance are few, the pass is latency-bound
+template <bool MAKE>
+__global__ __launch_bounds__(CNT_THREADS) void dpcl_count_part_kernel(const float* __restrict__ src, float* __restrict__ cntp, long TF, int S,
+                                                              unsigned* __restrict__ ticket = nullptr, float* __restrict__ Yout = nullptr,
+                                                              float a = 1.f, float b_ = 0.f, int take_abs = 0) {
+    __shared__ float sm[CNT_THREADS / 64][8];
     const int b = blockIdx.y, c = blockIdx.x;
-    if (ticket && b == 0 && c == 0 && threadIdx.x == 0) *ticket = 0u;      // arrival counter of dpcl_finish_kernel (two launches later)
+    // arrival counters of the Gram pass that follows: ticket[0] counts finished utterances, ticket[1 + b] the chunks of utterance b
+    if (ticket && c == 0 && threadIdx.x == 0) { ticket[1 + b] = 0u; if (b == 0) ticket[0] = 0u; }
     const long per = (TF + CP - 1) / CP;
     const long lo = (long)c * per, hi = min(TF, lo + per);
     float acc[8];
 #pragma unroll
     for (int s = 0; s < 8; ++s) acc[s] = 0.f;
-    const float* y = Y + (long)b * TF * S;
-    for (long i = lo + threadIdx.x; i < hi; i += 256)
-        for (int s = 0; s < S; ++s) acc[s] += y[i * S + s];
+    if (MAKE) {
+        const float* r = src + (long)b * S * TF;
+        float* y = Yout + (long)b * TF * S;
+        for (long i = lo + threadIdx.x; i < hi; i += CNT_THREADS) {
+            float best = 0.f;
+            int bi = 0;
+            for (int s = 0; s < S; ++s) {
+                float v = r[(long)s * TF + i];
+                if (take_abs) v = fabsf(v);
+                if (s == 0 || v > best) { best = v; bi = s; }
+            }
+            for (int s = 0; s < S; ++s) {
+                const float v = (s == bi) ? a : b_;
+                y[i * S + s] = v;
+                acc[s] += v;
+            }
+        }
+    } else {
+        const float* y = src + (long)b * TF * S;
+        for (long i = lo + threadIdx.x; i < hi; i += CNT_THREADS)
+            for (int s = 0; s < S; ++s) acc[s] += y[i * S + s];
+    }
     for (int s = 0; s < S; ++s) {
         const float v = wave_sum(acc[s]);
         if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][s] = v;
     }
     __syncthreads();
-    if (threadIdx.x < S)
-        cntp[((long)b * CP + c) * S + threadIdx.x] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+    if (threadIdx.x < S) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < CNT_THREADS / 64; ++w) t += sm[w][threadIdx.x];
+        cntp[((long)b * CP + c) * S + threadIdx.x] = t;
+    }
 }
 
 __device__ __forceinline__ void load_counts(const float* __restrict__ cntp, int b, int S, float (&cn)[8]) {
@@ -188,11 +219,28 @@ __device__ __forceinline__ void load_counts(const float* __restrict__ cntp, int 
     }
 }
 
+template <bool IN_LAUNCH>
+__device__ __forceinline__ void dpcl_finish_utterance(const float* __restrict__ part, float* __restrict__ per_utt, float* __restrict__ mats,
+                                                      int E, int S, int Z, int nchunk, int B, int b, float* __restrict__ gram,
+                                                      float (*sm)[16]);
+__device__ __forceinline__ void dpcl_finish_batch(const float* __restrict__ per_utt, float* __restrict__ out, unsigned* __restrict__ ticket,
+                                                  unsigned* __restrict__ clear, int B, int* last_sh, float* __restrict__ stage, int cap);
+
+// fin: what the pass needs to finish the loss itself (no dpcl_finish_kernel launch: 19 us + a launch boundary on the critical path of
+// a training step): the workgroup that stores the LAST chunk partial of an utterance reduces them (chunk order, as the separate
+// kernel does) and the one that finishes the last utterance writes the batch means.
+struct GramFinish {
+    float* per_utt; float* mats; float* out;
+    unsigned* ticket;                                // [0]: utterances finished, [1 + b]: chunks of utterance b stored (zeroed by the count pass)
+    unsigned* clear;                                 // the backward's max |dU| slot
+    int B;
+};
+
 template <int NT, int EC, int SC>                  // EC / SC: compile-time E / S (0 = use the run-time value; EC != 0 implies 16-byte rows)
 __global__ __launch_bounds__(256) void dpcl_gram_u_kernel(const float* __restrict__ U, const float* __restrict__ Y,
                                                           const float* __restrict__ cntp, float* __restrict__ inv_out,
                                                           float* __restrict__ V_out, float* __restrict__ part, long TF, int E_rt,
-                                                          int S_rt, int nchunk) {
+                                                          int S_rt, int nchunk, GramFinish fin) {
     const int E = EC ? EC : E_rt;
     const int S = SC ? SC : S_rt;
     constexpr int Z = NT * 16;
@@ -341,41 +389,54 @@ __global__ __launch_bounds__(256) void dpcl_gram_u_kernel(const float* __restric
         }
         __syncthreads();
     }
+    // Partials leave with agent-scope (write-through) stores and are read back the same way by whoever arrives last, and the
+    // arrival is counted once this workgroup's stores are acknowledged (workgroup-scope release = s_waitcnt vmcnt(0), then the
+    // barrier).  NOT __threadfence(): an agent-scope release writes the XCD's whole L2 back, and with this kernel's 1/|u| stream
+    // dirty in it 512 such fences doubled the kernel (129 us against 62).
     float* out = part + ((long)b * nchunk + c) * (Z * Z);
-    for (int i = tid; i < Z * Z; i += 256) out[i] = red[i];
-}
+    for (int i = tid; i < Z * Z; i += 256) __hip_atomic_store(out + i, red[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 
-// Per utterance: reduce chunk partials (fixed order), Frobenius norms, cost_b, normalised matrices for bwd.
-// out / ticket / clear (optional, together): the LAST workgroup to arrive also writes the batch means out[0..3] (what dpcl_mean_kernel
-// does in a launch of its own: 8 us on the critical path of a training step) and clears the backward's max |dU| slot; utterances
-// are summed in index order whoever arrives last, so the result does not depend on the arrival order.
-__global__ __launch_bounds__(1024) void dpcl_finish_kernel(const float* __restrict__ part, float* __restrict__ per_utt,
-                                                           float* __restrict__ mats, int E, int S, int Z, int nchunk, int B,
-                                                           float* __restrict__ out = nullptr, unsigned* __restrict__ ticket = nullptr,
-                                                           unsigned* __restrict__ clear = nullptr) {
-    extern __shared__ float gram[];
     __shared__ float sm[3][16];
     __shared__ int last_sh;
-    const int b = blockIdx.x, tid = threadIdx.x, nw = blockDim.x >> 6;
-    for (int i = tid; i < Z * Z; i += blockDim.x) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) last_sh = (atomicAdd(fin.ticket + 1 + b, 1u) == (unsigned)nchunk - 1u) ? 1 : 0;
+    __syncthreads();
+    if (!last_sh) return;                           // uniform over the workgroup
+    dpcl_finish_utterance<true>(part, fin.per_utt, fin.mats, E, S, Z, nchunk, fin.B, b, red, sm);
+    dpcl_finish_batch(fin.per_utt, fin.out, fin.ticket, fin.clear, fin.B, &last_sh, red, PTS * ZP);
+}
+
+// Per utterance: reduce chunk partials (fixed order), Frobenius norms, cost_b, normalised matrices for bwd.  Called by all
+// threads of a workgroup (any size that is a multiple of 64, <= 1024); gram = Z*Z floats of LDS, sm = 3 x 16 floats of LDS.
+// IN_LAUNCH: the partials were stored by other workgroups of the SAME launch (agent-scope stores): read them with agent-scope loads.
+template <bool IN_LAUNCH>
+__device__ __forceinline__ void dpcl_finish_utterance(const float* __restrict__ part, float* __restrict__ per_utt, float* __restrict__ mats,
+                                                      int E, int S, int Z, int nchunk, int B, int b, float* __restrict__ gram,
+                                                      float (*sm)[16]) {
+    const int tid = threadIdx.x, nthr = blockDim.x, nw = nthr >> 6;
+    for (int i = tid; i < Z * Z; i += nthr) {
         // chunk partials summed in chunk order; loads issued 8 at a time (a serial chain of ~1 us round trips made this
-        // kernel 23 us for 8 chunks of a 48x48 Gram)
+        // 23 us for 8 chunks of a 48x48 Gram)
         const float* pp = part + (long)b * nchunk * (Z * Z) + i;
         float s = 0.f;
         int c = 0;
         for (; c + 8 <= nchunk; c += 8) {
             float v[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = pp[(long)(c + j) * (Z * Z)];
+            for (int j = 0; j < 8; ++j)
+                v[j] = IN_LAUNCH ? __hip_atomic_load(pp + (long)(c + j) * (Z * Z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                 : pp[(long)(c + j) * (Z * Z)];
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += v[j];
         }
-        for (; c < nchunk; ++c) s += pp[(long)c * (Z * Z)];
+        for (; c < nchunk; ++c)
+            s += IN_LAUNCH ? __hip_atomic_load(pp + (long)c * (Z * Z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : pp[(long)c * (Z * Z)];
         gram[i] = s;
     }
     __syncthreads();
     float sg = 0.f, sa = 0.f, sc = 0.f;
-    for (int i = tid; i < Z * Z; i += blockDim.x) {
+    for (int i = tid; i < Z * Z; i += nthr) {
         const int r = i / Z, c = i - r * Z;
         const float v = gram[i];
         if (r < E && c < E) sg += v * v;
@@ -388,33 +449,60 @@ __global__ __launch_bounds__(1024) void dpcl_finish_kernel(const float* __restri
     float tg = 0.f, ta = 0.f, tc = 0.f;
     for (int w = 0; w < nw; ++w) { tg += sm[0][w]; ta += sm[1][w]; tc += sm[2][w]; }
     const float nG = sqrtf(tg), nA = sqrtf(ta), nC = sqrtf(tc);
-    if (tid == 0) {
-        per_utt[b * 4 + 0] = nG - 2.0f * nA + nC;
-        per_utt[b * 4 + 1] = nG;
-        per_utt[b * 4 + 2] = -2.0f * nA;
-        per_utt[b * 4 + 3] = nC;
+    if (tid == 0) {                                 // agent-scope stores: dpcl_finish_batch reads them from another workgroup
+        __hip_atomic_store(per_utt + b * 4 + 0, nG - 2.0f * nA + nC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(per_utt + b * 4 + 1, nG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(per_utt + b * 4 + 2, -2.0f * nA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(per_utt + b * 4 + 3, nC, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     // mats[b]: Gn [E,E] then An [E,S]
     float* m = mats + (long)b * (E * E + E * S);
     const float kg = 2.0f / (nG * B), ka = 2.0f / (nA * B);
-    for (int i = tid; i < E * E; i += blockDim.x) m[i] = gram[(i / E) * Z + (i % E)] * kg;
-    for (int i = tid; i < E * S; i += blockDim.x) m[E * E + i] = gram[(i / S) * Z + E + (i % S)] * ka;
-    if (ticket) {
-        if (tid == 0) {
-            __threadfence();                                    // per_utt[b] is out before the arrival is counted
-            last_sh = (atomicAdd(ticket, 1u) == (unsigned)gridDim.x - 1u) ? 1 : 0;
-        }
-        __syncthreads();
-        if (last_sh) {
-            __threadfence();
-            if (tid < 4) {
-                float t = 0.f;
-                for (int u = 0; u < B; ++u) t += __hip_atomic_load(&per_utt[u * 4 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                out[tid] = t / B;
-            }
-            if (tid == 4 && clear) clear[0] = 0u;
-        }
+    for (int i = tid; i < E * E; i += nthr) m[i] = gram[(i / E) * Z + (i % E)] * kg;
+    for (int i = tid; i < E * S; i += nthr) m[E * E + i] = gram[(i / S) * Z + E + (i % S)] * ka;
+}
+
+// The LAST workgroup to finish an utterance also writes the batch means out[0..3] (what dpcl_mean_kernel does in a launch of its own:
+// 8 us on the critical path of a training step) and clears the backward's max |dU| slot; utterances are summed in index order whoever
+// arrives last, so the result does not depend on the arrival order.  Called by all threads; last_sh = one int of LDS, stage = cap >= 4
+// floats of LDS (may be the Gram's: the utterance is finished by then).
+__device__ __forceinline__ void dpcl_finish_batch(const float* __restrict__ per_utt, float* __restrict__ out, unsigned* __restrict__ ticket,
+                                                  unsigned* __restrict__ clear, int B, int* last_sh, float* __restrict__ stage, int cap) {
+    const int tid = threadIdx.x;
+    __syncthreads();
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // per_utt[b] (this thread's agent-scope stores) acknowledged
+        *last_sh = (atomicAdd(ticket, 1u) == (unsigned)B - 1u) ? 1 : 0;
     }
+    __syncthreads();
+    if (*last_sh) {
+        // all 4 B values fetched in one round trip (one load per thread into LDS), then summed in utterance order from there: as a loop
+        // of dependent agent-scope loads this was 64 round trips at the very end of the launch
+        float t = 0.f;
+        const int capu = cap / 4;                               // utterances per round
+        for (int u0 = 0; u0 < B; u0 += capu) {
+            const int n = min(capu, B - u0);
+            if (u0) __syncthreads();
+            for (int i = tid; i < 4 * n; i += blockDim.x)
+                stage[i] = __hip_atomic_load(&per_utt[4 * u0 + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __syncthreads();
+            if (tid < 4)
+                for (int u = 0; u < n; ++u) t += stage[u * 4 + tid];
+        }
+        if (tid < 4) out[tid] = t / B;
+        if (tid == 4 && clear) clear[0] = 0u;
+    }
+}
+
+__global__ __launch_bounds__(1024) void dpcl_finish_kernel(const float* __restrict__ part, float* __restrict__ per_utt,
+                                                           float* __restrict__ mats, int E, int S, int Z, int nchunk, int B,
+                                                           float* __restrict__ out = nullptr, unsigned* __restrict__ ticket = nullptr,
+                                                           unsigned* __restrict__ clear = nullptr) {
+    extern __shared__ float gram[];
+    __shared__ float sm[3][16];
+    __shared__ int last_sh;
+    dpcl_finish_utterance<false>(part, per_utt, mats, E, S, Z, nchunk, B, blockIdx.x, gram, sm);
+    if (ticket) dpcl_finish_batch(per_utt, out, ticket, clear, B, &last_sh, gram, Z * Z);
 }
 
 __global__ void dpcl_mean_kernel(const float* __restrict__ per_utt, float* __restrict__ out, int B, unsigned* __restrict__ clear = nullptr) {
@@ -931,39 +1019,59 @@ size_t ams_dpcl_u_amax_offset(int B, long TF, int E, int S) {
 }
 
 size_t ams_dpcl_u_workspace_bytes(int B, long TF, int E, int S) {
-    // cntp [B,CP,S] | per_utt [B,4] | mats [B, E*E+E*S] | partials [B, nchunk, Z*Z] | bound of dU (1 float, 16-byte slot)
-    return ams_dpcl_u_amax_offset(B, TF, E, S) + 16;
+    // cntp [B,CP,S] | per_utt [B,4] | mats [B, E*E+E*S] | partials [B, nchunk, Z*Z] | bound of dU (1 float) | B + 1 arrival counters
+    return ams_dpcl_u_amax_offset(B, TF, E, S) + ((size_t)(B + 2) * 4 + 15) / 16 * 16;
+}
+
+// The label counts of ams_dpcl_loss_fwd_u, as a call of their own: Y is known long before U (it comes from the front end, U from the
+// whole recurrent stack), so a training step runs this beside the recurrence and passes counts_ready = 1 later.
+ams_status ams_dpcl_u_count_labels(const float* Y, int B, long TF, int E, int S, void* ws, size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(Y && ws && B > 0 && TF > 0 && E > 0 && S > 0 && S <= 8 && E + S <= 64);
+    if (ws_bytes < ams_dpcl_u_workspace_bytes(B, TF, E, S)) return AMS_E_WORKSPACE_TOO_SMALL;
+    unsigned* const slot = (unsigned*)((char*)ws + ams_dpcl_u_amax_offset(B, TF, E, S));
+    hipLaunchKernelGGL(dpcl_count_part_kernel<false>, dim3(CP, B), dim3(CNT_THREADS), 0, (hipStream_t)stream, Y, (float*)ws, TF, S, slot + 1);
+    return ams_check_launch();
+}
+
+// ams_make_masks (without the argmax output) and ams_dpcl_u_count_labels in ONE pass: the labels are counted as they are written.
+ams_status ams_dpcl_u_make_masks(const float* rep_non_mix, float* Y, int B, int S, long TF, int E, float a, float b, int take_abs,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    AMS_REQUIRE(rep_non_mix && Y && ws && B > 0 && TF > 0 && E > 0 && S > 0 && S <= 8 && E + S <= 64);
+    if (ws_bytes < ams_dpcl_u_workspace_bytes(B, TF, E, S)) return AMS_E_WORKSPACE_TOO_SMALL;
+    unsigned* const slot = (unsigned*)((char*)ws + ams_dpcl_u_amax_offset(B, TF, E, S));
+    hipLaunchKernelGGL(dpcl_count_part_kernel<true>, dim3(CP, B), dim3(CNT_THREADS), 0, (hipStream_t)stream, rep_non_mix, (float*)ws, TF, S,
+                       slot + 1, Y, a, b, take_abs);
+    return ams_check_launch();
 }
 
 // Fused l2-normalise + loss forward on the dense output U [B,TF,E].  inv [B,TF] receives 1/|u| (needed by the
 // backward); V_out (may be NULL) receives the normalised embeddings.  ws keeps counts/mats for ams_dpcl_loss_bwd_u.
 ams_status ams_dpcl_loss_fwd_u(const float* U, const float* Y, float* inv, float* V_out, float* out, int B, long TF, int E, int S,
-                               void* ws, size_t ws_bytes, void* stream) {
+                               int counts_ready, void* ws, size_t ws_bytes, void* stream) {
     AMS_REQUIRE(U && Y && inv && out && ws && B > 0 && TF > 0 && E > 0 && S > 0 && S <= 8 && E + S <= 64);
     if (ws_bytes < ams_dpcl_u_workspace_bytes(B, TF, E, S)) return AMS_E_WORKSPACE_TOO_SMALL;
     hipStream_t st = (hipStream_t)stream;
-    const int NT = ceil_div(E + S, 16), Z = NT * 16, nchunk = ceil_div(TF, UCHUNK);
+    const int NT = ceil_div(E + S, 16), nchunk = ceil_div(TF, UCHUNK);
     float* cntp = (float*)ws;
     float* per_utt = cntp + (size_t)B * CP * S;
     float* mats = per_utt + (size_t)B * 4;
     float* part = mats + (size_t)B * (E * E + E * S);
-    unsigned* const slot = (unsigned*)((char*)ws + ams_dpcl_u_amax_offset(B, TF, E, S));      // word 0: max |dU|, word 1: arrival counter
-    hipLaunchKernelGGL(dpcl_count_part_kernel, dim3(CP, B), dim3(256), 0, st, Y, cntp, TF, S, slot + 1);
+    unsigned* const slot = (unsigned*)((char*)ws + ams_dpcl_u_amax_offset(B, TF, E, S));      // word 0: max |dU|, words 1 .. B + 1: arrival counters
+    if (!counts_ready) hipLaunchKernelGGL(dpcl_count_part_kernel<false>, dim3(CP, B), dim3(CNT_THREADS), 0, st, Y, cntp, TF, S, slot + 1);
+    const GramFinish fin = {per_utt, mats, out, slot + 1, slot, B};
     dim3 grid(nchunk, B);
     switch (NT) {
-        case 1: hipLaunchKernelGGL((dpcl_gram_u_kernel<1, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
-        case 2: hipLaunchKernelGGL((dpcl_gram_u_kernel<2, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
+        case 1: hipLaunchKernelGGL((dpcl_gram_u_kernel<1, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk, fin); break;
+        case 2: hipLaunchKernelGGL((dpcl_gram_u_kernel<2, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk, fin); break;
         case 3: {
             const bool al = (((uintptr_t)U & 15) == 0);
-            if (E == 40 && S == 2 && al) hipLaunchKernelGGL((dpcl_gram_u_kernel<3, 40, 2>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk);
-            else if (E == 40 && S == 3 && al) hipLaunchKernelGGL((dpcl_gram_u_kernel<3, 40, 3>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk);
-            else hipLaunchKernelGGL((dpcl_gram_u_kernel<3, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk);
+            if (E == 40 && S == 2 && al) hipLaunchKernelGGL((dpcl_gram_u_kernel<3, 40, 2>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk, fin);
+            else if (E == 40 && S == 3 && al) hipLaunchKernelGGL((dpcl_gram_u_kernel<3, 40, 3>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk, fin);
+            else hipLaunchKernelGGL((dpcl_gram_u_kernel<3, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk, fin);
             break;
         }
-        default: hipLaunchKernelGGL((dpcl_gram_u_kernel<4, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk); break;
+        default: hipLaunchKernelGGL((dpcl_gram_u_kernel<4, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk, fin); break;
     }
-    hipLaunchKernelGGL(dpcl_finish_kernel, dim3(B), dim3(1024), Z * Z * sizeof(float), st, part, per_utt, mats, E, S, Z, nchunk, B, out,
-                       slot + 1, slot);
     return ams_check_launch();
 }
 

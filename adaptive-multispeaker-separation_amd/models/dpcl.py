@@ -19,6 +19,7 @@ class DPCL(Separator):
     def prediction(self):
         # DPCL network (dpcl.py:19-39): BLSTM x nb_layers -> Conv1D -> Reshape [B,T,F,E] -> Normalize(3)
         self.true_masks = self.y
+        self.count_labels_for = self.embedding_size          # network.py create_masks: labels are counted as they are made (fused loss)
         E, Fq = self.embedding_size, self.F
         layers = [BLSTM(self.layer_size, name='BLSTM_' + str(i), drop_val=self.rdropout,
                         in_dim=(Fq if i == 0 else self.layer_size)) for i in range(self.nb_layers)]

@@ -560,7 +560,10 @@ class Separator(Network):
                 def _y(run):
                     rows = self.X_non_mix_rows.value(run)
                     B = rows.shape[0] // S
-                    y = K.make_masks(rows, B, S, self.a, self.b, True)  # [B, TF, S]
+                    # a DPCL training step feeds these labels to the fused loss: count them in the pass that writes them
+                    weighted = self.function_mask in ('linear', 'sqrt', 'square') or self.loss_with_silence
+                    E = getattr(self, 'count_labels_for', None) if (run.training and not weighted) else None
+                    y = K.make_masks(rows, B, S, self.a, self.b, True, dpcl_E=E)  # [B, TF, S]
                     return self._weight_masks(y, run).reshape(B, rows.shape[1], Fq, S)
                 self.y = Node('y', _y)
 

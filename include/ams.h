@@ -201,8 +201,16 @@ ams_status ams_dpcl_loss_bwd(const float* V, const float* Y, const float* inv, c
    (ams_dpcl_loss_bwd_u takes the workspace as const: this slot is the one thing it writes there.) */
 size_t ams_dpcl_u_amax_offset(int B, long TF, int E, int S);
 size_t ams_dpcl_u_workspace_bytes(int B, long TF, int E, int S);
+/* The label counts Y^T 1 that the fused forward needs first (fixed-order partial sums, kept in ws): Y is known long before U, so a
+   training step may issue them early -- beside the recurrence, on another stream -- and pass counts_ready = 1 to the forward on the
+   SAME workspace; with counts_ready = 0 the forward counts by itself. */
+ams_status ams_dpcl_u_count_labels(const float* Y, int B, long TF, int E, int S, void* ws, size_t ws_bytes, void* stream);
+/* ams_make_masks (K12, without its argmax output) and ams_dpcl_u_count_labels in one pass: a plugged training step builds its labels
+   from the per-source representations and counts them as it writes them (same Y, same count bits as the two calls). */
+ams_status ams_dpcl_u_make_masks(const float* rep_non_mix, float* Y, int B, int S, long TF, int E, float a, float b, int take_abs,
+                                 void* ws, size_t ws_bytes, void* stream);
 ams_status ams_dpcl_loss_fwd_u(const float* U, const float* Y, float* inv, float* V_out, float* out, int B, long TF, int E, int S,
-                               void* ws, size_t ws_bytes, void* stream);
+                               int counts_ready, void* ws, size_t ws_bytes, void* stream);
 ams_status ams_dpcl_loss_bwd_u(const float* U, const float* Y, const float* inv, const float* upstream, float* dU, int B, long TF,
                                int E, int S, const void* ws, void* stream);
 

@@ -109,6 +109,32 @@ def test_make_masks(ops):
         assert np.array_equal(host(Y).reshape(B, T, F, S), Y_ref)
 
 
+@pytest.mark.parametrize('B,S,TF,E,a,b', [(3, 2, 1000, 40, 1.0, 0.0), (2, 3, 4097, 40, 1.0, 0.0), (5, 2, 77, 8, 1.0, 0.25),
+                                          (2, 4, 2561, 20, 0.7, 0.1)])
+def test_make_masks_counted_for_the_fused_loss(ops, B, S, TF, E, a, b):
+    """ams_dpcl_u_make_masks = ams_make_masks + ams_dpcl_u_count_labels in one pass (what a plugged DPCL training step runs): same
+    labels, and the fused loss that picks the prepared workspace up returns the bits of the loss that counted by itself -- also for
+    label values whose sums are not integers (the summation order is shared)."""
+    rng = np.random.RandomState(B * TF + S)
+    rep = dev(rng.randn(B * S, TF))
+    U = dev(rng.randn(B, TF, E))
+    Y0 = ops.make_masks(rep, B, S, a, b, True)
+    out0, inv0, _, ws0 = ops.dpcl_loss_fwd_u(U, Y0)
+    du0 = ops.dpcl_loss_bwd_u(U, Y0, inv0, ws0)
+    for _ in range(2):
+        Y1 = ops.make_masks(rep, B, S, a, b, True, dpcl_E=E)
+        assert ops._DPCL_AHEAD[0] is not None and ops._DPCL_AHEAD[0][0] == Y1.data_ptr()
+        ws_prepared = ops._DPCL_AHEAD[0][3]
+        out1, inv1, _, ws1 = ops.dpcl_loss_fwd_u(U, Y1.reshape(B, -1, S))
+        assert ws1 is ws_prepared and ops._DPCL_AHEAD[0] is None
+        assert np.array_equal(host(Y1), host(Y0))
+        assert np.array_equal(host(out1), host(out0)) and np.array_equal(host(inv1), host(inv0))
+        assert np.array_equal(host(ops.dpcl_loss_bwd_u(U, Y1, inv1, ws1)), host(du0))
+    # the oracle's loss on the same labels
+    c_ref, _ = odpcl.dpcl_cost(odense.l2norm_fwd(host(U).reshape(B, -1), E)[0].reshape(B, TF, E), host(Y0))
+    assert abs(float(host(out0)[0]) - c_ref) < TOL * max(1.0, abs(c_ref))
+
+
 @pytest.mark.parametrize('ring', ['1', 'safe', '0'])
 @pytest.mark.parametrize('B,T,D,H', [(5, 7, 12, 8), (20, 9, 24, 20), (3, 4, 16, 300), (17, 6, 10, 6), (33, 12, 8, 37), (4, 5, 6, 336),
                                        (2, 3, 4, 340), (6, 10, 600, 24), (5, 8, 256, 40), (3, 6, 644, 16)])
@@ -175,6 +201,21 @@ def test_l2norm_dpcl(ops, B, TF, E, S):
     assert V_n is None and np.array_equal(host(out_n), ou) and np.array_equal(host(inv_n), host(inv_u))
     du_u = ops.dpcl_loss_bwd_u(Ud, Yd, inv_u, ws_u)
     assert rel(host(du_u).reshape(du_ref.shape), du_ref) < 5 * TOL
+    # label counts issued ahead, on another stream (what a training step does beside the recurrence): same bits, and the forward
+    # picked the prepared workspace up; repeated on the same workspace (arrival counters are re-armed by every count pass)
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            ws_a = ops.dpcl_count_labels_ahead(Yd, E)
+        torch.cuda.current_stream().wait_stream(side)
+        out_a, inv_a, _, ws_b = ops.dpcl_loss_fwd_u(Ud, Yd)
+        assert ws_b is ws_a and ops._DPCL_AHEAD[0] is None
+        assert np.array_equal(host(out_a), ou) and np.array_equal(host(inv_a), host(inv_u))
+        assert np.array_equal(host(ops.dpcl_loss_bwd_u(Ud, Yd, inv_a, ws_b)), host(du_u))
+    ops.dpcl_count_labels_ahead(Yd[:1].contiguous(), E)            # counts of ANOTHER label tensor are not picked up
+    out_c, _, _, ws_c = ops.dpcl_loss_fwd_u(Ud, Yd)
+    assert ws_c is not ws_a and np.array_equal(host(out_c), ou)
     up = dev(np.array([0.5]))
     du_h = ops.dpcl_loss_bwd_u(Ud, Yd, inv_u, ws_u, upstream=up)
     assert rel(host(du_h).reshape(du_ref.shape), 0.5 * du_ref) < 5 * TOL
