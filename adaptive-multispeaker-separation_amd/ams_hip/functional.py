@@ -137,7 +137,7 @@ class BLSTMLayer(Function):
         need_dx = ctx.needs_input_grad[0]
         if OVERLAP.usable(Kf, Kb, bf, bb) and all(ctx.needs_input_grad[1:5]):
             B, T, D = x.shape
-            dbpart = ops.blstm_bwd_recurrent(x, Kf, Kb, G, cst, _c(dout))
+            dbpart = ops.blstm_bwd_recurrent(x, Kf, Kb, G, cst, _c(dout), amax_u=ctx.amax[1] if ctx.amax is not None else None)
             am_dx = am_w = None
             if ctx.amax is not None:
                 az = ops.amax_of(G)                              # G now holds dZ; the ring left its bound, the step kernels do not
@@ -171,7 +171,8 @@ class BLSTMLayer(Function):
             if dx is None and need_dx:
                 dx = ops.blstm_bwd_dx(G, Kf, Kb, B, T, D, amax=am_dx)
             return dx, None, None, None, None, None
-        dx, dKf, dbf, dKb, dbb = ops.blstm_bwd(x, Kf, Kb, out, G, cst, _c(dout), need_dx=need_dx)
+        dx, dKf, dbf, dKb, dbb = ops.blstm_bwd(x, Kf, Kb, out, G, cst, _c(dout), need_dx=need_dx,
+                                                amax_u=ctx.amax[1] if ctx.amax is not None else None)
         return dx, dKf, dbf, dKb, dbb, None
 
 

@@ -687,10 +687,11 @@ def blstm_wcat(Kf, Kb, D):
     return Wcat
 
 
-def blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout):
+def blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout, amax_u=None):
     """BPTT recurrence of one BLSTM layer: overwrites G (activated gates) with d pre-activation.  Returns None, or (ring
     recurrence) dbpart [B, 2, 4H] = sum over t of d pre-activation, which blstm_bwd_weights turns into the bias gradients with a
-    column sum over B rows instead of B*T."""
+    column sum over B rows instead of B*T.
+    amax_u: bound of the recurrent kernels (what blstm_fwd took as amax[1]) -> the ring's recurrent product runs as fp16x3."""
     _chk(x, G, cst, dout)
     _chk_rows(Kf, Kb)
     lib = load()
@@ -702,8 +703,9 @@ def blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout):
     if nring:
         sync, pre0 = _ring_sync(nring, x)
         dbpart = torch.empty((B, 2, 4 * H), dtype=torch.float32, device=x.device)
-        check(lib.ams_blstm_ring_bwd(_p(G), _p(cst[0]), _p(cst[1]), _p(dout), _p(dbpart), _p(Kf[D:]), _p(Kb[D:]), ldu, _p(sync), nring,
-                                     _p(ring_error_word(x.device)), B, T, H, int(LSTM_RING == 'safe') | pre0, _s()), 'ams_blstm_ring_bwd')
+        check(lib.ams_blstm_ring_bwd(_p(G), _p(cst[0]), _p(cst[1]), _p(dout), _p(dbpart), _p(Kf[D:]), _p(Kb[D:]), ldu,
+                                     _p(amax_u if F16X3 else None), _p(sync), nring, _p(ring_error_word(x.device)), B, T, H,
+                                     int(LSTM_RING == 'safe') | pre0, _s()), 'ams_blstm_ring_bwd')
         tag_amax(G, sync.view(-1)[2:3])                          # max |dZ| came out of the same launch (float word 2 of the sync head)
         return dbpart
     pack = torch.empty(lib.ams_blstm_pack_floats(H, 1), dtype=torch.float32, device=x.device)
@@ -872,12 +874,13 @@ def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate, part='all', dbp
                  ldc=dKb.stride(0), mask=(T, T - 1))
 
 
-def blstm_bwd(x, Kf, Kb, out, G, cst, dout, need_dx=True):
-    """BPTT for one BLSTM layer.  DESTROYS G (it becomes d pre-activation).  Returns dx, dKf, dbf, dKb, dbb."""
+def blstm_bwd(x, Kf, Kb, out, G, cst, dout, need_dx=True, amax_u=None):
+    """BPTT for one BLSTM layer.  DESTROYS G (it becomes d pre-activation).  Returns dx, dKf, dbf, dKb, dbb.
+    amax_u: see blstm_bwd_recurrent."""
     _chk(x, out, G, cst, dout)
     B, T, D = x.shape
     H = Kf.shape[1] // 4
-    dbpart = blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout)
+    dbpart = blstm_bwd_recurrent(x, Kf, Kb, G, cst, dout, amax_u=amax_u)
     dKf = torch.empty(Kf.shape, dtype=torch.float32, device=x.device)
     dKb = torch.empty(Kb.shape, dtype=torch.float32, device=x.device)
     dbf = torch.empty(4 * H, dtype=torch.float32, device=x.device)

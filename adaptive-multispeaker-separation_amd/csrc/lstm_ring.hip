@@ -73,7 +73,6 @@ struct RingArgs {
     unsigned* sticky;           // optional: a word the CALLER owns and never zeroes per launch -- set whenever err is set, so that one
                                 // check at the caller's next host sync covers every ring launch since its last check
     unsigned* ids;              // [n_chains][IDS_STRIDE]   XCC id + 1 of every workgroup (placement agreement)
-    unsigned* flags;            // [n_chains][IDS_STRIDE]   backward: last published step + 1
     float* xbuf;                // forward: granules [n_chains][2][TB][NW*4] float4; backward: partial tiles [n_chains][2][NW][NW][UW*TB]
     int B, T, H, NW, n_chains, force_safe, trace;
     const float* amax_u;        // forward, fp16x3: device pointer to an upper bound of max |U| over both recurrent kernels
@@ -220,6 +219,7 @@ __device__ __forceinline__ void ring_split3(float a, float b, unsigned& hi, unsi
 
 typedef _Float16 rf16x8_t __attribute__((ext_vector_type(8)));
 typedef _Float16 rf16x2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 rf16x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void ring_split2h(float a, float b, unsigned& hi, unsigned& mid) {
     const rf32x2_t v = {a, b};
     hi = __builtin_bit_cast(unsigned, __builtin_convertvector(v, rf16x2_t));
@@ -233,6 +233,15 @@ __device__ __forceinline__ float ring_f16_scale(float amax) {
     if (e == 0 || e == 255) return 1.0f;
     const int se = 127 + 13 - (e - 127);
     return (se >= 1 && se <= 254) ? __uint_as_float((unsigned)se << 23) : 1.0f;
+}
+
+// the same scale and its exact inverse (both powers of two; (1, 1) where ring_f16_scale gives 1)
+__device__ __forceinline__ void ring_f16_scale2(float amax, float& sc, float& inv) {
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
+    const int se = 127 + 13 - (e - 127);
+    const bool ok = (e != 0 && e != 255 && se >= 1 && se <= 253);
+    sc = ok ? __uint_as_float((unsigned)se << 23) : 1.0f;
+    inv = ok ? __uint_as_float((unsigned)(254 - se) << 23) : 1.0f;
 }
 
 template <int NR, int ARITH = 0>      // 0: v_mfma_f32_16x16x4_f32, 1: bf16x6, 2: fp16x3 (a.amax_u = bound of the recurrent kernels)
@@ -522,9 +531,45 @@ __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
 // row quad i), g < PG = 5, reads producers g, g + 5, ... (NPG = ceil(NW / 5) float4 loads), the PG group sums meet in LDS and are
 // added in group order -- a fixed order, so the result is deterministic.
 constexpr int PG = 5;
-template <int NI, int NPG>
+
+// Hand-off (round 4): the partial tiles carry their own validity.  Every 16-byte piece of a tile is one lane's store, and the low
+// mantissa bit of each of its four floats holds the PHASE of the step that produced it: 1 for steps 0, 1, then 0 for 2, 3, 1 for
+// 4, 5 ... (a tile buffer is reused every second step, so its phase alternates; the buffers start zeroed, phase 0).  A consumer simply
+// loads the pieces it needs until all four bits of every one show the phase it expects -- one hop.  Until round 4 a producer waited
+// for its stores to be acknowledged (s_waitcnt vmcnt(0): ~1150 cycles), met its workgroup at a barrier, raised a flag; the consumer
+// polled the flags and only then loaded the tiles: three memory round trips on the critical path of each of the 80 steps, ~3000 of
+// ~5900 cycles.  The stolen bit costs each partial 1 ulp (it is cleared before the sum); a piece cannot be seen half-written (one
+// dwordx4 store inside one 64-byte line), and a phase cannot be mistaken for the one before last: a workgroup overwrites a buffer with
+// step s only after it has consumed step s - 1 of every producer, each of which had consumed all of step s - 2 before producing that.
+__device__ __forceinline__ float4 ring_tag4(float4 v, unsigned phase) {
+    const unsigned x = __float_as_uint(v.x) & ~1u, y = __float_as_uint(v.y) & ~1u, z = __float_as_uint(v.z) & ~1u, w = __float_as_uint(v.w) & ~1u;
+    return make_float4(__uint_as_float(x | phase), __uint_as_float(y | phase), __uint_as_float(z | phase), __uint_as_float(w | phase));
+}
+__device__ __forceinline__ bool ring_tagged4(float4 v, unsigned phase) {
+    return ((__float_as_uint(v.x) & __float_as_uint(v.y) & __float_as_uint(v.z) & __float_as_uint(v.w) & 1u) == phase) &&
+           (((__float_as_uint(v.x) | __float_as_uint(v.y) | __float_as_uint(v.z) | __float_as_uint(v.w)) & 1u) == phase);
+}
+__device__ __forceinline__ float ring_untag(float v) { return __uint_as_float(__float_as_uint(v) & ~1u); }
+__device__ __forceinline__ unsigned ring_phase(int s) { return (unsigned)(((s >> 1) & 1) ^ 1); }
+
+// ARITH = 2 (round 4): the recurrent product da . U^T on the 16-bit pipe as fp16x3 (csrc/gemm.hip), as the forward ring has run it
+// since round 3.  The f32 MFMA chain was the longest phase of a step -- 60 v_mfma_f32_16x16x4_f32 of 32 cycles per wave, ~1900 of
+// ~6400 cycles -- and da has no a-priori bound to scale it into fp16 range with.  So the product is TRANSPOSED:
+//     dh^T [units x rows] = U-slice [units x 48] . da^T [48 x rows]
+// U is the A operand (static, scaled once from the caller's bound amax_u, split into two fp16 planes, in registers) and da the B
+// operand, whose COLUMNS are batch rows -- and an MFMA lane owns exactly one output column.  Every batch row therefore gets its own
+// power-of-two scale, 2^(13 - floor(log2 max_k |da[row, k]|)), computed by the lane from the 12 values it reads anyway (the other three
+// lane groups of its row: two v_permlane swaps), undone on the lane's own accumulator registers: no row can lose bits to a larger
+// neighbour, which a per-tile or per-tensor scale would allow.  k order: slot e of lane group q <-> k = 12 q + e (gate q, local unit
+// e) on both sides; 48 k = one K = 32 MFMA (slots 0..7) + one K = 16 MFMA (slots 8..11).  6 MFMAs of ~17 cycles per output tile instead
+// of 12 of 32.
+// The partial tiles change shape with it: a lane holds 4 consecutive UNITS of one row, so a tile is [row][slot] here ([slot][row] in
+// the f32 form), still 16-byte stores and loads.
+template <int NI, int NPG, int ARITH = 0>
 __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds_a[TB][4 * UW + 1];    // da of this workgroup: [row][gate * 12 + local unit]
+    constexpr bool F16 = (ARITH == 2);
+    constexpr int AP = F16 ? 4 * UW + 4 : 4 * UW + 1;          // row pitch of lds_a (fp16x3: 16-byte aligned rows for ds_read_b128)
+    __shared__ __attribute__((aligned(16))) float lds_a[TB][AP];             // da of this workgroup: [row][gate * 12 + local unit]
     __shared__ __attribute__((aligned(16))) float psum[PG][UW * TB];         // partial dh sums of the PG producer groups
     __shared__ int lds_flag;
     int chain, w;
@@ -540,14 +585,43 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
 
     // U^T slice as B fragments: k = own gate column (gate * 12 + local unit), n = unit of the output tile
     const int n16 = lane & 15, q = lane >> 4;
-    float bw[NI][UW];
+    float bw[F16 ? 1 : NI][UW];
+    rf16x8_t wq[F16 ? NI : 1][2];                               // fp16x3: [tile][plane hi / mid], k-slots 0..7 of the lane group (K = 32 MFMA)
+    rf16x4_t wr[F16 ? NI : 1][2];                               //         ... k-slots 8..11 (K = 16 MFMA)
+    float sc_u_inv = 1.0f;
+    if constexpr (F16) {
+        float sc_u;
+        ring_f16_scale2(a.amax_u[0], sc_u, sc_u_inv);
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int tl = wave + 4 * i, unit_row = tl * 16 + n16;
+        for (int i = 0; i < NI; ++i) {
+            const int tl = wave + 4 * i, unit_row = tl * 16 + n16;
+            unsigned hi[6], mid[6];
 #pragma unroll
-        for (int kk = 0; kk < UW; ++kk) {
-            const int k = 4 * kk + q, gate = k / UW, ucol = w * UW + k % UW;
-            bw[i][kk] = (tl < NT && unit_row < H && ucol < H) ? U[(long)unit_row * a.ldu + gate * H + ucol] : 0.f;
+            for (int pr = 0; pr < 6; ++pr) {
+                float v[2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int e = 2 * pr + h, ucol = w * UW + e;            // k = 12 q + e: gate q, local unit e
+                    v[h] = (tl < NT && unit_row < H && ucol < H) ? U[(long)unit_row * a.ldu + q * H + ucol] * sc_u : 0.f;
+                }
+                ring_split2h(v[0], v[1], hi[pr], mid[pr]);
+            }
+            const uint4 h4 = {hi[0], hi[1], hi[2], hi[3]}, m4 = {mid[0], mid[1], mid[2], mid[3]};
+            const uint2 h2 = {hi[4], hi[5]}, m2 = {mid[4], mid[5]};
+            wq[i][0] = __builtin_bit_cast(rf16x8_t, h4);
+            wq[i][1] = __builtin_bit_cast(rf16x8_t, m4);
+            wr[i][0] = __builtin_bit_cast(rf16x4_t, h2);
+            wr[i][1] = __builtin_bit_cast(rf16x4_t, m2);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int tl = wave + 4 * i, unit_row = tl * 16 + n16;
+#pragma unroll
+            for (int kk = 0; kk < UW; ++kk) {
+                const int k = 4 * kk + q, gate = k / UW, ucol = w * UW + k % UW;
+                bw[i][kk] = (tl < NT && unit_row < H && ucol < H) ? U[(long)unit_row * a.ldu + gate * H + ucol] : 0.f;
+            }
         }
     }
 
@@ -559,14 +633,18 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
     float* pb = a.xbuf + (size_t)chain * 2 * NW * NW * tile_f;
     const rsrc_t rs = make_rsrc(pb, (unsigned)((size_t)2 * NW * NW * tile_f * 4));
     // where this lane's column of output tile (wave + 4 i) goes: consumer = unit / 12, slot = unit % 12 (computed once)
+    // (fp16x3: the lane holds units tile * 16 + 4 q .. + 3 of row n16 -- a 4-aligned group never straddles a consumer's 12 units)
     int toff[NI];
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        const int unit = (wave + 4 * i) * 16 + n16;
-        toff[i] = (unit < NW * UW) ? (int)((((size_t)(unit / UW) * NW + w) * tile_f + (unit % UW) * TB + 4 * q) * 4u) : -1;
+        if constexpr (F16) {
+            const int unit = (wave + 4 * i) * 16 + 4 * q;
+            toff[i] = (unit < NW * UW) ? (int)((((size_t)(unit / UW) * NW + w) * tile_f + n16 * UW + unit % UW) * 4u) : -1;
+        } else {
+            const int unit = (wave + 4 * i) * 16 + n16;
+            toff[i] = (unit < NW * UW) ? (int)((((size_t)(unit / UW) * NW + w) * tile_f + (unit % UW) * TB + 4 * q) * 4u) : -1;
+        }
     }
-    unsigned* fl = a.flags + chain * IDS_STRIDE;
-    const rsrc_t rf = make_rsrc(fl, IDS_STRIDE * 4);
     float dc_state = 0.f;
     float dbs[4] = {0.f, 0.f, 0.f, 0.f};                       // running sum over t of this element's four da (bias gradient)
     float amax_f = 0.f;                                         // max |da| of this element over t: operand bound of the products that read dZ
@@ -600,39 +678,44 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
     for (int s = 0; s < T; ++s) {
         const int t = dir ? s : (T - 1 - s);
         const int par = s & 1;
-        if (s > 0 && !abort) {
-            unsigned spins = 0;
-            if (AMS_RING_BWD_SLEEP) __builtin_amdgcn_s_sleep(AMS_RING_BWD_SLEEP);
-            for (;;) {                                          // every wave watches its chain's flags itself: no extra barrier
-                const unsigned v = (lane < NW) ? (unsigned)__builtin_amdgcn_raw_buffer_load_b32(rf, lane * 4, 0, 16) : 0xffffffffu;
-                if (__all(v >= (unsigned)s)) break;
-                if (spin_check(spins, a.err, a.sticky)) { abort = true; break; }
-            }
-        }
-        tr.stamp(0);                                            // flag wait
         float dh = cur.dh;
         const float ig = cur.ig, gg = cur.gg, fg = cur.fg, og = cur.og, tc = cur.tc, c_prev = cur.c_prev;
         if (s > 0) {
-            // thread -> (group pg, float4 index f4 = slot * 4 + row quad); 240 of 256 threads take part
-            const int pg = tid / 48, f4 = tid - pg * 48;
-            if (pg < PG) {
-                const unsigned base = (unsigned)((((size_t)(par ^ 1) * NW + w) * NW) * tile_f + f4 * 4) * 4u;
-                float4 pv[NPG];
+            // thread -> (group pg, float4 index f4 = slot * 4 + row quad; fp16x3: row * 3 + slot quad); 240 of 256 threads take part, the
+            // last 16 re-read group 4's pieces and drop them
+            const int pg = tid / 48, f4 = tid - pg * 48, pgc = min(pg, PG - 1);
+            const unsigned base = (unsigned)((((size_t)(par ^ 1) * NW + w) * NW) * tile_f + f4 * 4) * 4u;
+            const unsigned want = ring_phase(s - 1);
+            float4 pv[NPG];
+            unsigned spins = 0;
+            for (;;) {                                          // every wave waits for the pieces it sums itself
 #pragma unroll
-                for (int k = 0; k < NPG; ++k) pv[k] = ld16_l2(rs, base + (unsigned)(min(pg + PG * k, NW - 1) * tile_f) * 4u);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < NPG; ++k) pv[k] = ld16_l2(rs, base + (unsigned)(min(pgc + PG * k, NW - 1) * tile_f) * 4u);
+                __builtin_amdgcn_sched_barrier(0);              // all requests in flight before the first piece is looked at
+                bool ok = true;
+#pragma unroll
+                for (int k = 0; k < NPG; ++k) ok &= ring_tagged4(pv[k], want);
+                if (__all(ok) || abort) break;
+                if (spin_check(spins, a.err, a.sticky)) { abort = true; break; }
+                if (AMS_RING_BWD_SLEEP) __builtin_amdgcn_s_sleep(AMS_RING_BWD_SLEEP);
+            }
+            tr.stamp(0);                                        // wait for the partial tiles
+            if (pg < PG) {
                 float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int k = 0; k < NPG; ++k) {
                     const float m = (pg + PG * k < NW) ? 1.0f : 0.0f;          // clamped duplicates count as zero
-                    sum.x += pv[k].x * m; sum.y += pv[k].y * m; sum.z += pv[k].z * m; sum.w += pv[k].w * m;
+                    sum.x += ring_untag(pv[k].x) * m; sum.y += ring_untag(pv[k].y) * m;
+                    sum.z += ring_untag(pv[k].z) * m; sum.w += ring_untag(pv[k].w) * m;
                 }
                 *reinterpret_cast<float4*>(&psum[pg][f4 * 4]) = sum;
             }
             __syncthreads();
-            const int e = (nl < UW ? nl : 0) * TB + r;
+            const int e = F16 ? r * UW + (nl < UW ? nl : 0) : (nl < UW ? nl : 0) * TB + r;
 #pragma unroll
             for (int g = 0; g < PG; ++g) dh += psum[g][e];
+        } else {
+            tr.stamp(0);
         }
         tr.stamp(1);                                            // partial tiles loaded + summed
         // next step's operands: requested now (after this step's waits, ~2000 cycles of MFMA work ahead), not behind the publish --
@@ -658,27 +741,8 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
         tr.stamp(2);                                            // gate derivative math + LDS write
         __syncthreads();
         tr.stamp(3);                                            // barrier
-        if (s + 1 < T) {
-            // partial dh_{next} = da_own [16 x 48] . U^T slice [48 x NT*16]; the 12 A fragments of this lane first, ONE wait
-            float av[UW];
-            const float* arow = &lds_a[lane & 15][q];
-#pragma unroll
-            for (int kk = 0; kk < UW; ++kk) av[kk] = arow[4 * kk];
-            f32x4 acc[NI];
-#pragma unroll
-            for (int i = 0; i < NI; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int kk = 0; kk < UW; ++kk) {
-#pragma unroll
-                for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bw[i][kk], acc[i], 0, 0, 0);
-            }
-            // tile column n16 of output tile tl = unit tl*16 + n16 -> consumer unit / 12, slot unit % 12; rows 4q..4q+3 contiguous
-            const unsigned pbase = (unsigned)((size_t)par * NW * NW * tile_f * 4u);
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-                if (toff[i] >= 0) st16(rs, pb, pbase + (unsigned)toff[i], make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]), fast);
-            tr.stamp(4);                                        // MFMA chain + tile stores issued
-        }
+        // da to memory BEFORE the recurrent product, not after it: the publish below waits for this wave's youngest store, and these four
+        // (scattered dwords, the slowest stores of the step) then have the whole MFMA chain to complete in
         if (live) {
             float* gr = gp + t * gst;
             gr[0 * H] = da0;
@@ -687,20 +751,85 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
             gr[3 * H] = da3;
         }
         if (s + 1 < T) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // every tile of this wave has reached the L2 (or memory, write-through)
-            tr.stamp(5);                                        // store drain (also covers the prefetched operands)
-            __syncthreads();                                    // ... of every wave; also: lds_a may be rewritten from here on
-            tr.stamp(6);                                        // barrier
-            if (tid == 0) {
-                if (fast) fl[w] = (unsigned)(s + 1);
-                else __hip_atomic_store(fl + w, (unsigned)(s + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            f32x4 acc[NI];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) acc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if constexpr (F16) {
+                // this lane's B fragment: da[row n16][12 q .. 12 q + 11], three 16-byte reads
+                const float4* brow = reinterpret_cast<const float4*>(&lds_a[n16][UW * q]);
+                const float4 v0 = brow[0], v1 = brow[1], v2 = brow[2];
+                float mx = fmaxf(fmaxf(fmaxf(fabsf(v0.x), fabsf(v0.y)), fmaxf(fabsf(v0.z), fabsf(v0.w))),
+                                 fmaxf(fmaxf(fabsf(v1.x), fabsf(v1.y)), fmaxf(fabsf(v1.z), fabsf(v1.w))));
+                mx = fmaxf(mx, fmaxf(fmaxf(fabsf(v2.x), fabsf(v2.y)), fmaxf(fabsf(v2.z), fabsf(v2.w))));
+                // max over the row's four lane groups (non-negative floats order like their bit patterns)
+                unsigned mu = __float_as_uint(mx);
+                const auto s16 = __builtin_amdgcn_permlane16_swap(mu, mu, false, false);
+                mu = max(s16[0], s16[1]);
+                const auto s32 = __builtin_amdgcn_permlane32_swap(mu, mu, false, false);
+                mu = max(s32[0], s32[1]);
+                float sc, sc_inv;
+                ring_f16_scale2(__uint_as_float(mu), sc, sc_inv);
+                sc_inv *= sc_u_inv;
+                rf16x8_t bq[2];                                 // plane hi / mid, k-slots 0..7
+                rf16x4_t br[2];                                 //                 k-slots 8..11
+                {
+                    unsigned hi[6], mid[6];
+                    ring_split2h(v0.x * sc, v0.y * sc, hi[0], mid[0]);
+                    ring_split2h(v0.z * sc, v0.w * sc, hi[1], mid[1]);
+                    ring_split2h(v1.x * sc, v1.y * sc, hi[2], mid[2]);
+                    ring_split2h(v1.z * sc, v1.w * sc, hi[3], mid[3]);
+                    ring_split2h(v2.x * sc, v2.y * sc, hi[4], mid[4]);
+                    ring_split2h(v2.z * sc, v2.w * sc, hi[5], mid[5]);
+                    const uint4 h4 = {hi[0], hi[1], hi[2], hi[3]}, m4 = {mid[0], mid[1], mid[2], mid[3]};
+                    const uint2 h2 = {hi[4], hi[5]}, m2 = {mid[4], mid[5]};
+                    bq[0] = __builtin_bit_cast(rf16x8_t, h4);
+                    bq[1] = __builtin_bit_cast(rf16x8_t, m4);
+                    br[0] = __builtin_bit_cast(rf16x4_t, h2);
+                    br[1] = __builtin_bit_cast(rf16x4_t, m2);
+                }
+                // ONE accumulator per tile (the workgroup must fit beside two residency-capped product workgroups of 160 registers:
+                // <= 192 in all; with the cross terms in accumulators of their own it needed 230, and a ring launched behind such a
+                // product then waited for its workgroups to retire -- 470 us instead of 300).  Smallest terms first.
+                constexpr int PA[3] = {1, 0, 0};                // U plane: mid.hi, hi.mid, hi.hi
+                constexpr int PB[3] = {0, 1, 0};                // da plane
+                // the K = 16 chain first, then the K = 32 chain, apart: an accumulator handed DIRECTLY from one MFMA shape to the other
+                // came back wrong (the two opcodes differ in passes; back-to-back forwarding of SrcC is a same-opcode affair)
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(wr[i][PA[pp]], br[PB[pp]], acc[i], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[i][PA[pp]], bq[PB[pp]], acc[i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NI; ++i) acc[i] = acc[i] * sc_inv;
+            } else {
+                // partial dh_{next} = da_own [16 x 48] . U^T slice [48 x NT*16]; the 12 A fragments of this lane first, ONE wait
+                float av[UW];
+                const float* arow = &lds_a[lane & 15][q];
+#pragma unroll
+                for (int kk = 0; kk < UW; ++kk) av[kk] = arow[4 * kk];
+#pragma unroll
+                for (int kk = 0; kk < UW; ++kk) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[kk], bw[i][kk], acc[i], 0, 0, 0);
+                }
             }
+            // f32: tile column n16 of output tile tl = unit tl*16 + n16 -> consumer unit / 12, slot unit % 12; rows 4q..4q+3 contiguous
+            const unsigned pbase = (unsigned)((size_t)par * NW * NW * tile_f * 4u);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                if (toff[i] >= 0) st16(rs, pb, pbase + (unsigned)toff[i], ring_tag4(make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]), ring_phase(s)), fast);
+            tr.stamp(4);                                        // MFMA chain + tile stores issued
         }
 #if AMS_RING_FETCH_LATE
         const Ops nxt = fetch(dir ? t + 1 : t - 1);
 #endif
         cur = nxt;
-        tr.stamp(7);                                            // flag store
     }
     if (a.dbpart && live) {
         float* o = a.dbpart + ((long)b * 2 + dir) * (4 * H) + u;
@@ -736,17 +865,15 @@ inline bool ring_shape(int B, int H, int& NW, int& n_chains) {
     return NW <= 4 * MAXR && ceil_div(NW * UW, 16) <= 4 * MAXT && (long)n_chains * NW <= 512 && grid <= ring_capacity();
 }
 
-struct RingLayout { size_t ids, flags, x, total, head; };
+struct RingLayout { size_t ids, x, total, head; };
 
 inline RingLayout ring_layout(int NW, int n_chains, int backward) {
     RingLayout L;
     L.ids = 256;
-    L.flags = L.ids + (size_t)n_chains * IDS_STRIDE * 4;
-    L.head = L.flags + (size_t)n_chains * IDS_STRIDE * 4;      // [0, head): zeroed before every launch
-    L.x = (L.head + 255) & ~(size_t)255;
+    L.x = (L.ids + (size_t)n_chains * IDS_STRIDE * 4 + 255) & ~(size_t)255;
     const size_t xbytes = backward ? (size_t)n_chains * 2 * NW * NW * UW * TB * 4 : (size_t)n_chains * 2 * TB * NW * 4 * 16;
     L.total = L.x + xbytes;
-    if (!backward) L.head = L.total;                            // forward: the granule tags must start at 0 as well
+    L.head = L.total;                       // [0, head) is zeroed before every launch: the granule tags (forward) / phase bits (backward) start at 0
     return L;
 }
 
@@ -759,6 +886,12 @@ inline bool ring_fwd_x6() {
 // AMS_LSTM_RING_F16 (read once): 0 = the forward ring never takes the fp16x3 form, whatever bound it is given
 inline bool ring_fwd_f16() {
     static const bool v = !(getenv("AMS_LSTM_RING_F16") && atoi(getenv("AMS_LSTM_RING_F16")) == 0);
+    return v;
+}
+
+// AMS_LSTM_RING_BWD_F16 (read once): 0 = the backward ring keeps v_mfma_f32_16x16x4_f32 whatever bound it is given (measurement aid)
+inline bool ring_bwd_f16() {
+    static const bool v = !(getenv("AMS_LSTM_RING_BWD_F16") && atoi(getenv("AMS_LSTM_RING_BWD_F16")) == 0);
     return v;
 }
 
@@ -803,7 +936,7 @@ ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, cons
     if (!(safe & 4) && hipMemsetAsync(sync, 0, L.head, st) != hipSuccess) return AMS_E_LAUNCH_FAILED;      // bit 2: the caller cleared [0, head)
     RingArgs a{};
     a.G = G; a.out = out; a.cst = cst; a.tch = tch; a.Uf = Uf; a.Ub = Ub; a.ldu = ldu;
-    a.err = (unsigned*)sync; a.sticky = (unsigned*)sticky_err; a.ids = (unsigned*)((char*)sync + L.ids); a.flags = (unsigned*)((char*)sync + L.flags);
+    a.err = (unsigned*)sync; a.sticky = (unsigned*)sticky_err; a.ids = (unsigned*)((char*)sync + L.ids);
     a.xbuf = (float*)((char*)sync + L.x);
     a.B = B; a.T = T; a.H = H; a.NW = NW; a.n_chains = n_chains; a.force_safe = ((safe & 1) || ring_force_safe()) ? 1 : 0; a.trace = (safe & 2) ? 1 : 0;
     const dim3 grid(8 * NW * ceil_div(n_chains, 8));
@@ -847,8 +980,10 @@ ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, cons
 // Same contract as ams_blstm_recurrent_bwd (on return G holds da), without the dc workspace (the running dc lives in registers).
 // dbpart (optional, [B,2,4H]): receives sum_t da[b,t,dir,:] -- the bias gradient is then a column sum over B rows instead of B*T.
 // On return float word 2 of `sync` holds max |da| (the operand bound of the three products that read dZ).
+// amax_u (optional): device pointer to an upper bound of max |U| over both recurrent kernels -> the recurrent product runs as fp16x3
+// with one scale per batch row (see lstm_ring_bwd_kernel); NULL keeps the f32 MFMA.
 ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* tch, const float* dout, float* dbpart, const float* Uf, const float* Ub,
-                              long ldu, void* sync, size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream) {
+                              long ldu, const float* amax_u, void* sync, size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream) {
     AMS_REQUIRE(G && cst && tch && dout && Uf && Ub && sync && B > 0 && T > 0 && H > 0);
     int NW, n_chains;
     AMS_REQUIRE(ring_shape(B, H, NW, n_chains));
@@ -858,12 +993,22 @@ ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* tch, cons
     if (!(safe & 4) && hipMemsetAsync(sync, 0, L.head, st) != hipSuccess) return AMS_E_LAUNCH_FAILED;      // bit 2: the caller cleared [0, head)
     RingArgs a{};
     a.G = G; a.cst = const_cast<float*>(cst); a.tch = const_cast<float*>(tch); a.dout = dout; a.dbpart = dbpart; a.Uf = Uf; a.Ub = Ub; a.ldu = ldu;
-    a.err = (unsigned*)sync; a.sticky = (unsigned*)sticky_err; a.ids = (unsigned*)((char*)sync + L.ids); a.flags = (unsigned*)((char*)sync + L.flags);
+    a.err = (unsigned*)sync; a.sticky = (unsigned*)sticky_err; a.ids = (unsigned*)((char*)sync + L.ids);
     a.xbuf = (float*)((char*)sync + L.x);
     a.B = B; a.T = T; a.H = H; a.NW = NW; a.n_chains = n_chains; a.force_safe = ((safe & 1) || ring_force_safe()) ? 1 : 0; a.trace = (safe & 2) ? 1 : 0;
     const dim3 grid(8 * NW * ceil_div(n_chains, 8));
     // NW = 1..28 -> NT = ceil(12 NW / 16) = 1..21 -> NI = ceil(NT / 4) = 1..6; producers per group: NPG = ceil(NW / 5) = 1..6
     const int NI = ceil_div(ceil_div(NW * UW, 16), 4);
+    if (ring_fwd_x6() && amax_u && ring_fwd_f16() && ring_bwd_f16()) {
+        a.amax_u = amax_u;
+        if (NW <= 5)       hipLaunchKernelGGL((lstm_ring_bwd_kernel<1, 1, 2>), grid, dim3(256), 0, st, a);
+        else if (NW <= 10) hipLaunchKernelGGL((lstm_ring_bwd_kernel<2, 2, 2>), grid, dim3(256), 0, st, a);
+        else if (NW <= 15) hipLaunchKernelGGL((lstm_ring_bwd_kernel<3, 3, 2>), grid, dim3(256), 0, st, a);
+        else if (NW <= 20) hipLaunchKernelGGL((lstm_ring_bwd_kernel<4, 4, 2>), grid, dim3(256), 0, st, a);
+        else if (NW <= 25) hipLaunchKernelGGL((lstm_ring_bwd_kernel<5, 5, 2>), grid, dim3(256), 0, st, a);
+        else               hipLaunchKernelGGL((lstm_ring_bwd_kernel<6, 6, 2>), grid, dim3(256), 0, st, a);
+        return ams_check_launch();
+    }
     if (NW <= 5)       hipLaunchKernelGGL((lstm_ring_bwd_kernel<1, 1>), grid, dim3(256), 0, st, a);       // NT <= 4
     else if (NW <= 10) hipLaunchKernelGGL((lstm_ring_bwd_kernel<2, 2>), grid, dim3(256), 0, st, a);       // NT <= 8
     else if (NW <= 15) hipLaunchKernelGGL((lstm_ring_bwd_kernel<3, 3>), grid, dim3(256), 0, st, a);       // NT <= 12

@@ -156,8 +156,8 @@ ams_status ams_blstm_recurrent_bwd_dropout(float* G, const float* cst, const flo
  * can be repeated on the per-step kernels instead of being trained on.
  * tch [B,T,2,H]: tanh(c_t), written by the forward ring and read by the backward one (cst keeps c_t).  safe: bit 0 forces the
  * write-through hand-off, bit 1 records a per-phase cycle trace in the sync header (tools/ring_anatomy.py), bit 2 says the CALLER has
- * already zeroed the first ams_blstm_ring_sync_head_bytes() of `sync` in stream order (forward ring: the whole buffer, the granule
- * tags start at 0; backward ring: the error word, ids and flags) -- without it every launch is preceded by its own memset node,
+ * already zeroed the first ams_blstm_ring_sync_head_bytes() of `sync` in stream order (the whole buffer for both rings: the forward's
+ * granule tags and the phase bits of the backward's partial tiles start at 0) -- without it every launch is preceded by its own memset node,
  * ~5 us on the critical path of each of the six ring launches of a training step; the host side (ops.py::_RingArena) clears the
  * buffers of a whole pass with ONE memset on the side stream while the pass starts.
  * dbpart (backward, may be NULL): [B,2,4H] receives sum_t d pre-activation[b,t,dir,:]; the bias gradients are its column sums.
@@ -170,8 +170,16 @@ size_t ams_blstm_ring_sync_head_bytes(int B, int H, int backward);
    149 instead of 196 VGPRs.  AMS_LSTM_RING_F16=0 or NULL: bf16x6. */
 ams_status ams_blstm_ring_fwd(float* G, float* out, float* cst, float* tch, const float* Uf, const float* Ub, long ldu, const float* amax_u,
                               void* sync, size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream);
+/* Backward: amax_u (may be NULL) as above -> the recurrent product da_t . U^T runs as fp16x3 too, computed transposed (U is the MFMA's A
+   operand, da^T the B operand) so that every batch row of da gets its own power-of-two scale from its own maximum: da has no a-priori
+   bound, and a shared scale would let a small row lose bits to a large one.  30 MFMAs of ~17 cycles instead of 60 of 32 per wave and
+   step.  AMS_LSTM_RING_BWD_F16=0 or NULL: v_mfma_f32_16x16x4_f32.
+   Hand-off of both backward forms (round 4): a partial tile carries its validity in the low mantissa bit of its floats (the phase of the
+   step that wrote it; 1 ulp per partial), so a consumer waits on the data itself -- one memory hop per step where the flag protocol of
+   rounds 2-3 had three (store acknowledge, flag, tile load). */
 ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* tch, const float* dout, float* dbpart, const float* Uf, const float* Ub,
-                              long ldu, void* sync, size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe, void* stream);
+                              long ldu, const float* amax_u, void* sync, size_t sync_bytes, void* sticky_err, int B, int T, int H, int safe,
+                              void* stream);
 
 /* ---- K13  tf.nn.l2_normalize over groups of E       utils/ops.py:323-324 ---- */
 ams_status ams_l2norm_fwd(const float* u, float* v, float* inv, long rows, int E, void* stream);

@@ -162,6 +162,41 @@ def test_blstm_layer(ops, monkeypatch, B, T, D, H, ring):
     assert ops.persist_errors() == 0                            # no bounded in-launch wait timed out
 
 
+@pytest.mark.parametrize('ring', ['1', 'safe'])
+@pytest.mark.parametrize('B,T,D,H', [(5, 7, 12, 8), (20, 9, 24, 20), (3, 4, 16, 300), (33, 12, 8, 37), (4, 5, 6, 336), (64, 6, 40, 300),
+                                       (6, 10, 600, 24), (18, 5, 16, 130), (7, 6, 16, 200), (9, 4, 16, 250)])
+def test_backward_ring_as_fp16x3_one_scale_per_row(ops, monkeypatch, B, T, D, H, ring):
+    """ams_blstm_ring_bwd with the kernels' bound (amax_u): the recurrent product da . U^T runs as fp16x3, computed transposed so that
+    every batch row of da is scaled by its own maximum.  Same tolerances as the f32 MFMA form -- and PER BATCH ROW, with upstream
+    gradients whose rows span 2^-60 .. 2^20: a scale shared by the 16 rows of a tile would leave the small rows no bits at all."""
+    monkeypatch.setattr(ops, 'LSTM_RING', ring)
+    monkeypatch.setattr(ops, 'F16X3', True)
+    rng = np.random.RandomState(B * T + H + 1)
+    lim = np.sqrt(6.0 / (D + 5 * H))
+    x = rng.randn(B, T, D)
+    Kf, Kb = rng.uniform(-lim, lim, (D + H, 4 * H)) * 3, rng.uniform(-lim, lim, (D + H, 4 * H)) * 3
+    bf, bb = rng.randn(4 * H) * 0.1, rng.randn(4 * H) * 0.1
+    out_ref, cache = oblstm.blstm_fwd(x, Kf, bf, Kb, bb)
+    xd, Kfd, Kbd = dev(x), dev(Kf), dev(Kb)
+    bound_u = torch.maximum(ops.absmax(Kfd), ops.absmax(Kbd))
+    row_scale = 2.0 ** (20 - 80.0 * rng.permutation(B) / max(B - 1, 1))            # one magnitude per batch row
+    dout = rng.randn(B, T, 2 * H) * row_scale[:, None, None]
+    dx_ref, (dKf_r, dbf_r, dKb_r, dbb_r) = oblstm.blstm_bwd(dout, cache)
+    got = {}
+    for name, au in (('fp16x3', bound_u), ('f32', None)):
+        out, G, cst = ops.blstm_fwd(xd, Kfd, dev(bf), Kbd, dev(bb))
+        dx, dKf, dbf, dKb, dbb = ops.blstm_bwd(xd, Kfd, Kbd, out, G, cst, dev(dout), amax_u=au)
+        got[name] = host(dx)
+        # every batch row to the tolerance of the whole (dx rows are independent of one another)
+        for b in range(B):
+            assert rel(got[name][b], dx_ref[b]) < 5 * TOL, (name, b, rel(got[name][b], dx_ref[b]))
+        assert rel(host(dKf), dKf_r) < 5 * TOL and rel(host(dKb), dKb_r) < 5 * TOL
+        assert rel(host(dbf), dbf_r) < 5 * TOL and rel(host(dbb), dbb_r) < 5 * TOL
+    assert not np.array_equal(got['fp16x3'], got['f32'])        # the arithmetic did change
+    assert ops.persist_errors() == 0
+    ops.raise_on_ring_errors()
+
+
 @pytest.mark.parametrize('B,TF,E,S', [(2, 300, 8, 2), (3, 5000, 40, 2), (2, 2049, 40, 3), (2, 77, 3, 2), (1, 700, 20, 4),
                                         (2, 2561, 40, 8)])
 def test_l2norm_dpcl(ops, B, TF, E, S):
