@@ -92,9 +92,9 @@ def build(args, tmp):
 
 
 def _newest_profile(suffix):
-    """(parsed JSON, repo-relative path) of the highest-round profiles/rNN<suffix>, or (None, None)."""
+    """(parsed JSON, repo-relative path) of the newest profiles/rNN_<letter><suffix> (highest round, then highest letter), or (None, None)."""
     import glob
-    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]' + suffix)))
+    cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r[0-9][0-9]_[a-z]' + suffix)))
     if not cands:
         return None, None
     try:
@@ -350,7 +350,7 @@ def main():
         # from the newest committed summary of `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs of this very workload
         # (tools/pmc_traffic.sh -> tools/pmc_summary.py; gfx950 x2 read correction applied there), tagged with the commit the
         # counters were collected at.  null for any other shape or when no summary is committed.
-        tj, tfile = _newest_profile('_c_hbm_traffic.json')
+        tj, tfile = _newest_profile('_hbm_traffic.json')
         if tj is not None and (B, L, N) == (64, 20480, 256):
             gk = [v for k, v in tj.items() if k.startswith(kname) and isinstance(v, dict)]
             calls = sum(v['calls'] for v in gk)
@@ -362,7 +362,7 @@ def main():
                 roof['algorithmic_bytes_per_launch'] = round(prof['bytes'] / prof['launches'])
         # the same kernels inside the REPLAYED (timed) hipGraph: per-variant averages of a rocprofv3 --kernel-trace pass over
         # `bench.py --graph 1` (tools/prof_step.sh), cited by file
-        rj, rfile = _newest_profile('_b_replay_kernels.json')
+        rj, rfile = _newest_profile('_replay_kernels.json')
         if rj is not None and (B, L, N) == (64, 20480, 256):
             roof['replayed_region'] = {'file': rfile, 'counted_at_commit': (rj.get('_meta') or {}).get('commit'),
                                        'by_kernel': {k: v for k, v in rj.items() if k != '_meta'}}
