@@ -41,13 +41,9 @@ def soft_bwd(xn, inv, init_idx, best, w, trace, dsel, dout, C, tries, iterations
     g = torch.empty((b, C, E), dtype=torch.float32, device=dev)
     dsel_c = dsel.contiguous() if dsel is not None else None
     dout_c = dout.contiguous() if dout is not None else None
-    check(lib.ams_kmeans_soft_bwd(p(xn), p(wsel), p(w_final), p(cst), p(dst), p(dsel_c), p(dout_c), p(dxn), p(g), b, L, E, C, float(beta),
-                                  iterations, p(ws), nb, s()), 'ams_kmeans_soft_bwd')
-    # c_0 = xn[idx]: scatter-add the remaining centroid gradient onto the picked points (tiny: b*C rows)
-    # (the C picks of a row are distinct -- np.random.choice without replacement, Kmeans_2.py:63 -- so no two updates collide)
-    idx_sel = (init_idx if index is None else init_idx[index]).long()   # [b, C]
-    flat = (idx_sel + torch.arange(b, device=dev).unsqueeze(1) * L).reshape(-1)
-    dxn.view(b * L, E).index_add_(0, flat, g.reshape(b * C, E))
-    if inv is None:
-        return dxn
-    return ops.l2norm_bwd(xn.view(b, L * E), inv, dxn.view(b, L * E), E).view(b, L, E)
+    # c_0 = xn[idx]: the remaining centroid gradient goes onto the picked points, and -- when the input was normalised here -- every row
+    # through the l2-normalise Jacobian, both inside the same call (the pass that writes dx holds the point in registers)
+    idx_sel = (init_idx if index is None else init_idx[index]).to(torch.int32).contiguous()      # [b, C]
+    check(lib.ams_kmeans_soft_bwd(p(xn), p(wsel), p(w_final), p(cst), p(dst), p(dsel_c), p(dout_c), p(inv), p(idx_sel), p(dxn), p(g),
+                                  b, L, E, C, float(beta), iterations, p(ws), nb, s()), 'ams_kmeans_soft_bwd')
+    return dxn

@@ -48,6 +48,8 @@ typedef const ks_f2 __attribute__((address_space(4))) ks_cf2;
 struct KsArgs {
     const float* xn; const float* w; const float* w_final; const float* cents; const float* dens; const float* dsel; const float* dout;
     float* dx; float* g0;
+    const float* inv;   // [b, L] or NULL: 1 / |x| of the l2-normalise that produced xn -- dx then leaves as the gradient w.r.t. its INPUT
+    const int* seed;    // [b, C] or NULL: the points c_0 was picked from -- g0 is added onto their rows here instead of by the caller
     float* part;        // [b, G, C*E + C]
     float* rec;         // [b, n_it + 1, N]
     float* G;           // [n_it + 1, b, C*E]
@@ -335,6 +337,17 @@ __global__ __launch_bounds__(256) void ks_dx_kernel(KsArgs a, int chunks_per_wg)
             const ks_f2 kk = {ksum, ksum};
 #pragma unroll
             for (int q = 0; q < E_ / 2; ++q) dxl[q] = __builtin_elementwise_fma(x2[q], kk, dxl[q]);
+            if (a.inv) {
+                // Jacobian of xn = u / |u| applied here (tf.nn.l2_normalize, utils/ops.py:323): du = (dx - xn <xn, dx>) / |u| -- the point
+                // is in registers; as a pass of its own (l2norm_bwd_slab_kernel) it was 630 MB of traffic, 151 us of a fine-tuning step
+                ks_f2 ds = {0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < E_ / 2; ++q) ds = __builtin_elementwise_fma(x2[q], dxl[q], ds);
+                const float dot = ds[0] + ds[1], iv = a.inv[(long)r * a.L + pt];
+                const ks_f2 nd = {-dot, -dot}, i2 = {iv, iv};
+#pragma unroll
+                for (int q = 0; q < E_ / 2; ++q) dxl[q] = __builtin_elementwise_fma(nd, x2[q], dxl[q]) * i2;
+            }
         }
         __syncthreads();
         if (tid < npts) {
@@ -357,6 +370,26 @@ __global__ __launch_bounds__(256) void ks_dx_kernel(KsArgs a, int chunks_per_wg)
     }
 }
 
+// c_0 = xn[seed]: the remaining centroid gradient g0 goes onto the rows it was picked from (the C picks of an utterance are distinct --
+// np.random.choice without replacement, Kmeans_2.py:63 -- so no two updates meet), through the same Jacobian as every other row.
+// grid b, C_ * 64 threads (one wave per cluster).
+template <int E_, int C_>
+__global__ void ks_seed_kernel(KsArgs a) {
+    const int r = blockIdx.x, c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long row = a.seed[r * C_ + c];
+    if (row < 0 || row >= a.L) return;
+    const float* g = a.g0 + ((long)r * C_ + c) * E_;
+    const float* x = a.xn + ((long)r * a.L + row) * E_;
+    float* d = a.dx + ((long)r * a.L + row) * E_;
+    float gv = lane < E_ ? g[lane] : 0.f;
+    if (a.inv) {
+        const float xv = lane < E_ ? x[lane] : 0.f;
+        const float dot = wave_sum(xv * gv);
+        gv = (gv - xv * dot) * a.inv[(long)r * a.L + row];
+    }
+    if (lane < E_) d[lane] += gv;
+}
+
 template <int E_, int C_>
 ams_status ks_run(KsArgs a, hipStream_t st) {
     hipLaunchKernelGGL((ks_init_kernel<E_, C_>), dim3(a.b), dim3(128), 0, st, a);
@@ -374,6 +407,7 @@ ams_status ks_run(KsArgs a, hipStream_t st) {
     int per = ceil_div(chunks, max(1, 4096 / a.b));
     if (per < 1) per = 1;
     hipLaunchKernelGGL((ks_dx_kernel<E_, C_>), dim3(ceil_div(chunks, per), a.b), dim3(256), 0, st, a, per);
+    if (a.seed) hipLaunchKernelGGL((ks_seed_kernel<E_, C_>), dim3(a.b), dim3(C_ * 64), 0, st, a);
     return ams_check_launch();
 }
 
@@ -394,13 +428,17 @@ size_t ams_kmeans_soft_bwd_workspace_bytes(int b, long L, int E, int C, int n_it
 //   xn [b,L,E]; w [b,L] silence weights of the iterations or NULL; w_final: weights of the returned assignment or NULL (end-assign: 1);
 //   cents [n_it+1,b,C,E] = c_0 .. c_n of the selected rows; dens [n_it,b,C] = sum_l lab_i; dsel [b,C,E] = d loss / d c_n or NULL;
 //   dout [b,L,C] = d loss / d returned labels or NULL.   Out: dx [b,L,E] (fully written), g0 [b,C,E] = d loss / d c_0.
+//   seed [b,C] (or NULL): the points c_0 was taken from -> g0 is added onto those rows of dx here; inv [b,L] (or NULL): 1/|u| of the
+//   l2-normalise that produced xn -> dx is the gradient w.r.t. u (both Jacobians in the pass that has the point in registers).
 ams_status ams_kmeans_soft_bwd(const float* xn, const float* w, const float* w_final, const float* cents, const float* dens, const float* dsel,
-                               const float* dout, float* dx, float* g0, int b, long L, int E, int C, float beta, int n_it, void* ws,
-                               size_t ws_bytes, void* stream) {
+                               const float* dout, const float* inv, const int32_t* seed, float* dx, float* g0, int b, long L, int E, int C,
+                               float beta, int n_it, void* ws, size_t ws_bytes, void* stream) {
     AMS_REQUIRE(xn && cents && dx && g0 && ws && b > 0 && L > 0 && C >= 2 && C <= 4 && beta >= 0.f && n_it >= 0 && (n_it == 0 || dens));
+    AMS_REQUIRE(!inv || seed);                      // with the Jacobian applied to dx the caller can no longer add g0 to it
     if (ws_bytes < ams_kmeans_soft_bwd_workspace_bytes(b, L, E, C, n_it)) return AMS_E_WORKSPACE_TOO_SMALL;
     KsArgs a{};
     a.xn = xn; a.w = w; a.w_final = w_final; a.cents = cents; a.dens = dens; a.dsel = dsel; a.dout = dout; a.dx = dx; a.g0 = g0;
+    a.inv = inv; a.seed = seed;
     a.L = L; a.b = b; a.n_it = n_it; a.nG = ks_chunks(b, L); a.spw = ceil_div(ceil_div(L, KS_LANES), a.nG); a.nG = ceil_div(ceil_div(L, KS_LANES), a.spw); a.beta = beta;
     const size_t CE = (size_t)C * E;
     char* p = (char*)ws;

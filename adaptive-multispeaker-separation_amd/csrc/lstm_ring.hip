@@ -688,6 +688,10 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
             const unsigned want = ring_phase(s - 1);
             float4 pv[NPG];
             unsigned spins = 0;
+#ifdef AMS_RING_DBG_ACK                          // anatomy build (-DAMS_RING_DBG_ACK): how long this wave's own stores take to be acknowledged
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // -- 750 cycles, then 1020 of polling: the two are serial in the shipped form
+            tr.stamp(5);                                        // too (1680), vmcnt being one counter for loads and stores
+#endif
             for (;;) {                                          // every wave waits for the pieces it sums itself
 #pragma unroll
                 for (int k = 0; k < NPG; ++k) pv[k] = ld16_l2(rs, base + (unsigned)(min(pgc + PG * k, NW - 1) * tile_f) * 4u);

@@ -359,12 +359,15 @@ ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent
  * xn, partial sums finished by the last-arriving workgroup: no reduce launches) and ONE pass that writes dx.
  *   xn [b,L,E] normalised embeddings; w [b,L] silence weights of the iterations or NULL; w_final: weights of the returned assignment
  *   or NULL (--end_assign: all ones); cents [n_it+1,b,C,E] = c_0..c_n; dens [n_it,b,C] = sum_l lab_i; dsel [b,C,E] = d/d c_n or NULL;
- *   dout [b,L,C] = d/d returned soft labels or NULL.  Out: dx [b,L,E] (fully written), g0 [b,C,E] = d/d c_0 (scattered onto the seed
- *   points by the caller).  ws: ams_kmeans_soft_bwd_workspace_bytes. */
+ *   dout [b,L,C] = d/d returned soft labels or NULL.  Out: dx [b,L,E] (fully written), g0 [b,C,E] = d/d c_0.
+ *   seed [b,C] (may be NULL: the caller scatters g0): the points c_0 was picked from -- g0 is added onto those rows of dx;
+ *   inv [b,L] (may be NULL; needs seed): 1/|u| of the tf.nn.l2_normalize that produced xn (Kmeans_2.py:56, utils/ops.py:323) -- dx then
+ *   leaves as the gradient w.r.t. u, the Jacobian applied in the pass that holds the point in registers instead of in a pass of its
+ *   own.  ws: ams_kmeans_soft_bwd_workspace_bytes. */
 size_t ams_kmeans_soft_bwd_workspace_bytes(int b, long L, int E, int C, int n_it);
 ams_status ams_kmeans_soft_bwd(const float* xn, const float* w, const float* w_final, const float* cents, const float* dens, const float* dsel,
-                               const float* dout, float* dx, float* g0, int b, long L, int E, int C, float beta, int n_it, void* ws,
-                               size_t ws_bytes, void* stream);
+                               const float* dout, const float* inv, const int32_t* seed, float* dx, float* g0, int b, long L, int E, int C,
+                               float beta, int n_it, void* ws, size_t ws_bytes, void* stream);
 ams_status ams_kmeans_assign(const float* xn, const float* w, const float* cent, int32_t* labels, float* soft, float* inertia, int b,
                              int tries, long L, int E, int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* stream);
 ams_status ams_kmeans_select(const float* inertia, const float* centroids, int32_t* best, float* selected, int b, int tries, int E,
