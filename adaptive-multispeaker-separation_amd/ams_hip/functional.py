@@ -838,37 +838,53 @@ class KMeansSoft(Function):
     """Soft k-means (beta set) with gradient to the embeddings (needed by the front_*_finetuning recipes)."""
 
     @staticmethod
-    def forward(ctx, X, init_idx, C, tries, iterations, beta, w, assign_at_end, normalize_input, faithful_tile):
+    def forward(ctx, X, init_idx, C, tries, iterations, beta, w, assign_at_end, normalize_input, faithful_tile, from_u=False):
+        # from_u: X is the embedding network's output BEFORE its Normalize layer (models/dpcl.py:32) and normalize_input is on: both
+        # normalisations in one pass here, both Jacobians in the pass that writes dX (the unit-norm tensor in between is never stored)
         b, L, E = X.shape
-        if normalize_input:
+        inv0 = None
+        if normalize_input and from_u:
+            xn, inv0, inv = ops.l2norm2_fwd(X.view(b, L * E), E)
+            xn = xn.view(b, L, E)
+        elif normalize_input:
             xn, inv = ops.l2norm_fwd(X.view(b, L * E), E)
             xn = xn.view(b, L, E)
         else:
             xn, inv = X, None
         sel, out, best, trace = ops.kmeans_run(xn, init_idx, C, tries, iterations, beta, w, assign_at_end, faithful_tile)
-        extra = [t for t in (inv, w) if t is not None]
+        extra = [t for t in (inv, inv0, w) if t is not None]
         ctx.save_for_backward(xn, init_idx, best, *extra, *trace)
-        ctx.cfg = (C, tries, iterations, beta, inv is not None, w is not None, assign_at_end, faithful_tile)
+        ctx.cfg = (C, tries, iterations, beta, inv is not None, w is not None, assign_at_end, faithful_tile, inv0 is not None)
         ctx.mark_non_differentiable(best)
         return sel, out, best
 
     @staticmethod
     def backward(ctx, dsel, dout, _dbest):
         from .kmeans_bwd import soft_bwd
-        C, tries, iterations, beta, has_inv, has_w, assign_at_end, faithful_tile = ctx.cfg
+        C, tries, iterations, beta, has_inv, has_w, assign_at_end, faithful_tile, has_inv0 = ctx.cfg
         saved = list(ctx.saved_tensors)
         xn, init_idx, best = saved[:3]
         k = 3
         inv = saved[k] if has_inv else None
         k += int(has_inv)
+        inv0 = saved[k] if has_inv0 else None
+        k += int(has_inv0)
         w = saved[k] if has_w else None
         k += int(has_w)
-        dX = soft_bwd(xn, inv, init_idx, best, w, saved[k:], dsel, dout, C, tries, iterations, beta, assign_at_end, faithful_tile)
-        return (dX,) + (None,) * 9
+        dX = soft_bwd(xn, inv, init_idx, best, w, saved[k:], dsel, dout, C, tries, iterations, beta, assign_at_end, faithful_tile, inv0=inv0)
+        return (dX,) + (None,) * 10
 
 
-def kmeans(X, init_idx, C, tries, iterations, beta, w, assign_at_end, normalize_input=True, faithful_tile=True):
-    """KMeans.network (Kmeans_2.py:86-111).  Returns (centroids [b,C,E], labels, best_try)."""
+def kmeans(X, init_idx, C, tries, iterations, beta, w, assign_at_end, normalize_input=True, faithful_tile=True, pre_norm=None):
+    """KMeans.network (Kmeans_2.py:86-111).  Returns (centroids [b,C,E], labels, best_try).
+    pre_norm: a callable returning u with X = l2-normalise(u) over E (same shape) -- a soft k-means under gradient that normalises its
+    input takes u instead of X (see KMeansSoft, from_u); X may then be a callable too and is not evaluated."""
+    if pre_norm is not None and beta is not None and normalize_input and torch.is_grad_enabled():
+        u = _c(pre_norm())
+        if u.requires_grad:
+            return KMeansSoft.apply(u, init_idx, C, tries, iterations, beta, w, assign_at_end, True, faithful_tile, True)
+    if callable(X):
+        X = X()
     X = _c(X)
     if beta is None or not (X.requires_grad and torch.is_grad_enabled()):
         with torch.no_grad():

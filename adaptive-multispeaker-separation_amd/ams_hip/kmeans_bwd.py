@@ -6,8 +6,9 @@ from . import ops
 from ._lib import load, check
 
 
-def soft_bwd(xn, inv, init_idx, best, w, trace, dsel, dout, C, tries, iterations, beta, assign_at_end, faithful_tile):
-    """Returns d loss / d X (pre-normalisation input [b,L,E]).  trace = [c_0, c_1, den_0, c_2, den_1, ...] over all R rows."""
+def soft_bwd(xn, inv, init_idx, best, w, trace, dsel, dout, C, tries, iterations, beta, assign_at_end, faithful_tile, inv0=None):
+    """Returns d loss / d X (pre-normalisation input [b,L,E]; with inv0: the input of the normalisation BEFORE that one, see
+    functional.KMeansSoft).  trace = [c_0, c_1, den_0, c_2, den_1, ...] over all R rows."""
     lib = load()
     b, L, E = xn.shape
     dev = xn.device
@@ -44,6 +45,6 @@ def soft_bwd(xn, inv, init_idx, best, w, trace, dsel, dout, C, tries, iterations
     # c_0 = xn[idx]: the remaining centroid gradient goes onto the picked points, and -- when the input was normalised here -- every row
     # through the l2-normalise Jacobian, both inside the same call (the pass that writes dx holds the point in registers)
     idx_sel = (init_idx if index is None else init_idx[index]).to(torch.int32).contiguous()      # [b, C]
-    check(lib.ams_kmeans_soft_bwd(p(xn), p(wsel), p(w_final), p(cst), p(dst), p(dsel_c), p(dout_c), p(inv), p(idx_sel), p(dxn), p(g),
+    check(lib.ams_kmeans_soft_bwd(p(xn), p(wsel), p(w_final), p(cst), p(dst), p(dsel_c), p(dout_c), p(inv), p(inv0), p(idx_sel), p(dxn), p(g),
                                   b, L, E, C, float(beta), iterations, p(ws), nb, s()), 'ams_kmeans_soft_bwd')
     return dxn

@@ -81,7 +81,7 @@ class KMeans(object):
 
     def __init__(self, nb_clusters, centroids_init=None, nb_tries=10, nb_iterations=10, input_tensor=None,
                  normalize_input=True, latent_space_tensor=None, beta=None, threshold=2.5, assign_at_end=True,
-                 init_indices=None, seeding='reference'):
+                 init_indices=None, seeding='reference', pre_norm=None):
         if seeding not in ('reference', 'fast'):
             raise ValueError("seeding must be 'reference' or 'fast', got %r" % (seeding,))
         self.seeding = seeding
@@ -97,6 +97,9 @@ class KMeans(object):
         self.normalize_input = normalize_input
         self.init_indices = init_indices          # Node / callable giving int32 [b*tries, C]; None -> host RNG as the reference
         self.faithful_tile = True
+        # (node, E) or None: input_tensor is l2-normalise(node) over groups of E -- a soft k-means under gradient that normalises its input
+        # anyway then starts from that node (functional.KMeansSoft, from_u) and input_tensor is not evaluated
+        self.pre_norm = pre_norm
         g = get_default_graph()
         with g.variable_scope('kmeans'):
             self.X_in = input_tensor if input_tensor is not None else Placeholder('Kmeans_input')
@@ -158,16 +161,28 @@ class KMeans(object):
         return buf
 
     def _run(self, run):
-        X = self.X_in.value(run)
-        b, L, E = X.shape
+        pre = None
+        if (self.pre_norm is not None and self.beta is not None and self.normalize_input and run.training and torch.is_grad_enabled()
+                and id(self.X_in) not in run.cache):
+            u = self.pre_norm[0].value(run)
+            if u.requires_grad and u.is_cuda:
+                E = self.pre_norm[1]
+                b = u.shape[0]
+                L = u.numel() // (b * E)
+                pre = lambda: u.reshape(b, L, E)                                               # noqa: E731
+                X, dev = (lambda: self.X_in.value(run)), u.device
+        if pre is None:
+            X = self.X_in.value(run)
+            b, L, E = X.shape
+            dev = X.device
         w = None
         if self.latent_space_tensor is not None:
             from . import ops
             lat = self.latent_space_tensor.value(run).reshape(b, L).contiguous()
             w = ops.silence_weights(lat, self.threshold)                                        # Kmeans_2.py:76-80
-        idx = self._init_idx(run, b * self.nb_tries, L, X.device)
+        idx = self._init_idx(run, b * self.nb_tries, L, dev)
         return F.kmeans(X, idx, self.nb_clusters, self.nb_tries, self.nb_iterations, self.beta, w, self.assign_at_end,
-                        self.normalize_input, self.faithful_tile)
+                        self.normalize_input, self.faithful_tile, pre_norm=pre)
 
     def fit(self, X_train):
         from .graph import Run

@@ -900,6 +900,21 @@ def l2norm_fwd(u, E):
     return v, inv
 
 
+def l2norm2_fwd(u, E):
+    """normalise(normalise(u)) over groups of E in one pass -> (xn, inv = 1/|u|, inv2 = 1/|normalise(u)|): the bits of two l2norm_fwd
+    calls (which is what runs when the rows are not 16-byte addressable or E has no slab kernel)."""
+    _chk(u)
+    rows = u.numel() // E
+    xn = torch.empty_like(u)
+    inv = torch.empty(rows, dtype=torch.float32, device=u.device)
+    inv2 = torch.empty(rows, dtype=torch.float32, device=u.device)
+    st = load().ams_l2norm2_fwd(_p(u), _p(xn), _p(inv), _p(inv2), rows, E, _s())
+    if st != 0:
+        v, inv = l2norm_fwd(u, E)
+        xn, inv2 = l2norm_fwd(v, E)
+    return xn, inv, inv2
+
+
 def l2norm_bwd(v, inv, dv, E):
     _chk(v, inv, dv)
     du = torch.empty_like(v)

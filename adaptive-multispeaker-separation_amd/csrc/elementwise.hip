@@ -104,9 +104,12 @@ __global__ void l2norm_bwd_kernel(const float* __restrict__ v, const float* __re
 // contiguous in memory) with coalesced 16-byte accesses, and thread t works on row t out of LDS (row pitch E + 4 floats: 16-byte
 // aligned rows, conflict-free 16-byte reads).  The quarter-wave kernels issue 4-byte accesses in 64-byte runs and reach
 // 3.2-3.5 TB/s on the 210 MB embedding tensor; these are HBM-speed passes.
-template <int E_>
+// TWICE: v = normalise(normalise(u)) in one pass -- what a k-means that normalises its input (Kmeans_2.py:56) computes on the output of
+// the embedding network's own Normalize layer (dpcl.py:32).  The once-normalised row is rounded to f32 in between exactly as the
+// stored tensor of the two-pass form is, so v, inv and inv2 carry the bits of two ams_l2norm_fwd calls.
+template <int E_, bool TWICE = false>
 __global__ __launch_bounds__(256) void l2norm_fwd_slab_kernel(const float* __restrict__ u, float* __restrict__ v, float* __restrict__ inv,
-                                                              long rows) {
+                                                              long rows, float* __restrict__ inv2 = nullptr) {
     constexpr int V4 = E_ / 4, LD = E_ + 4;
     __shared__ __attribute__((aligned(16))) float tile[256 * LD];
     const int tid = threadIdx.x;
@@ -130,7 +133,18 @@ __global__ __launch_bounds__(256) void l2norm_fwd_slab_kernel(const float* __res
         for (int k = 0; k < V4; ++k) { x[k] = p[k]; ss += x[k].x * x[k].x + x[k].y * x[k].y + x[k].z * x[k].z + x[k].w * x[k].w; }
         const float iv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
 #pragma unroll
-        for (int k = 0; k < V4; ++k) p[k] = make_float4(x[k].x * iv, x[k].y * iv, x[k].z * iv, x[k].w * iv);
+        for (int k = 0; k < V4; ++k) x[k] = make_float4(x[k].x * iv, x[k].y * iv, x[k].z * iv, x[k].w * iv);
+        if (TWICE) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < V4; ++k) s2 += x[k].x * x[k].x + x[k].y * x[k].y + x[k].z * x[k].z + x[k].w * x[k].w;
+            const float iv2 = 1.0f / sqrtf(fmaxf(s2, 1e-12f));
+#pragma unroll
+            for (int k = 0; k < V4; ++k) x[k] = make_float4(x[k].x * iv2, x[k].y * iv2, x[k].z * iv2, x[k].w * iv2);
+            inv2[r0 + tid] = iv2;
+        }
+#pragma unroll
+        for (int k = 0; k < V4; ++k) p[k] = x[k];
         if (inv) inv[r0 + tid] = iv;
     }
     __syncthreads();
@@ -407,6 +421,22 @@ ams_status ams_l2norm_fwd(const float* u, float* v, float* inv, long rows, int E
     else if (vec && E == 20) hipLaunchKernelGGL(l2norm_fwd_slab_kernel<20>, sgrid, dim3(256), 0, st, u, v, inv, rows);
     else if (vec && E == 8) hipLaunchKernelGGL(l2norm_fwd_slab_kernel<8>, sgrid, dim3(256), 0, st, u, v, inv, rows);
     else hipLaunchKernelGGL(l2norm_fwd_kernel, dim3(stream_blocks(rows * 16)), dim3(256), 0, st, u, v, inv, rows, E);
+    return ams_check_launch();
+}
+
+// xn = normalise(normalise(u)), inv = 1/|u|, inv2 = 1/|normalise(u)|: ONE pass (16-byte addressable rows of E = 40, 32, 20 or 8 floats;
+// AMS_E_INVALID_ARG otherwise -- the caller then makes two ams_l2norm_fwd calls, which give the same bits).
+ams_status ams_l2norm2_fwd(const float* u, float* xn, float* inv, float* inv2, long rows, int E, void* stream) {
+    AMS_REQUIRE(u && xn && inv && inv2 && rows > 0 && E > 0);
+    const bool vec = (((uintptr_t)u | (uintptr_t)xn) & 15) == 0 && rows < (1L << 31) * 256;
+    if (!vec) return AMS_E_INVALID_ARG;
+    const dim3 sgrid((unsigned)ceil_div(rows, 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (E == 40) hipLaunchKernelGGL((l2norm_fwd_slab_kernel<40, true>), sgrid, dim3(256), 0, st, u, xn, inv, rows, inv2);
+    else if (E == 32) hipLaunchKernelGGL((l2norm_fwd_slab_kernel<32, true>), sgrid, dim3(256), 0, st, u, xn, inv, rows, inv2);
+    else if (E == 20) hipLaunchKernelGGL((l2norm_fwd_slab_kernel<20, true>), sgrid, dim3(256), 0, st, u, xn, inv, rows, inv2);
+    else if (E == 8) hipLaunchKernelGGL((l2norm_fwd_slab_kernel<8, true>), sgrid, dim3(256), 0, st, u, xn, inv, rows, inv2);
+    else return AMS_E_INVALID_ARG;
     return ams_check_launch();
 }
 

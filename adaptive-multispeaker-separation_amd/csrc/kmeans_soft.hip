@@ -49,6 +49,7 @@ struct KsArgs {
     const float* xn; const float* w; const float* w_final; const float* cents; const float* dens; const float* dsel; const float* dout;
     float* dx; float* g0;
     const float* inv;   // [b, L] or NULL: 1 / |x| of the l2-normalise that produced xn -- dx then leaves as the gradient w.r.t. its INPUT
+    const float* inv0;  // [b, L] or NULL (needs inv): that input was itself v = u / |u|, inv0 = 1 / |u| -- dx leaves as the gradient w.r.t. u
     const int* seed;    // [b, C] or NULL: the points c_0 was picked from -- g0 is added onto their rows here instead of by the caller
     float* part;        // [b, G, C*E + C]
     float* rec;         // [b, n_it + 1, N]
@@ -347,6 +348,18 @@ __global__ __launch_bounds__(256) void ks_dx_kernel(KsArgs a, int chunks_per_wg)
                 const ks_f2 nd = {-dot, -dot}, i2 = {iv, iv};
 #pragma unroll
                 for (int q = 0; q < E_ / 2; ++q) dxl[q] = __builtin_elementwise_fma(nd, x2[q], dxl[q]) * i2;
+                if (a.inv0) {
+                    // ... and of v = u / |u| before it (the embedding network's Normalize layer): v = xn |v| = xn / inv
+                    const float nv = 1.0f / iv, iv0 = a.inv0[(long)r * a.L + pt];
+                    const ks_f2 n2 = {nv, nv};
+                    ks_f2 d0 = {0.f, 0.f};
+#pragma unroll
+                    for (int q = 0; q < E_ / 2; ++q) d0 = __builtin_elementwise_fma(x2[q] * n2, dxl[q], d0);
+                    const float dot0 = (d0[0] + d0[1]) * nv;                     // <v, dv> |v|: the factor v below carries the other |v|
+                    const ks_f2 m0 = {-dot0, -dot0}, j0 = {iv0, iv0};
+#pragma unroll
+                    for (int q = 0; q < E_ / 2; ++q) dxl[q] = __builtin_elementwise_fma(m0, x2[q], dxl[q]) * j0;
+                }
             }
         }
         __syncthreads();
@@ -384,8 +397,12 @@ __global__ void ks_seed_kernel(KsArgs a) {
     float gv = lane < E_ ? g[lane] : 0.f;
     if (a.inv) {
         const float xv = lane < E_ ? x[lane] : 0.f;
-        const float dot = wave_sum(xv * gv);
-        gv = (gv - xv * dot) * a.inv[(long)r * a.L + row];
+        const float iv = a.inv[(long)r * a.L + row];
+        gv = (gv - xv * wave_sum(xv * gv)) * iv;
+        if (a.inv0) {
+            const float vv = xv / iv;
+            gv = (gv - vv * wave_sum(vv * gv)) * a.inv0[(long)r * a.L + row];
+        }
     }
     if (lane < E_) d[lane] += gv;
 }
@@ -429,16 +446,17 @@ size_t ams_kmeans_soft_bwd_workspace_bytes(int b, long L, int E, int C, int n_it
 //   cents [n_it+1,b,C,E] = c_0 .. c_n of the selected rows; dens [n_it,b,C] = sum_l lab_i; dsel [b,C,E] = d loss / d c_n or NULL;
 //   dout [b,L,C] = d loss / d returned labels or NULL.   Out: dx [b,L,E] (fully written), g0 [b,C,E] = d loss / d c_0.
 //   seed [b,C] (or NULL): the points c_0 was taken from -> g0 is added onto those rows of dx here; inv [b,L] (or NULL): 1/|u| of the
-//   l2-normalise that produced xn -> dx is the gradient w.r.t. u (both Jacobians in the pass that has the point in registers).
+//   l2-normalise that produced xn -> dx is the gradient w.r.t. its input; inv0 [b,L] (or NULL): that input was itself a normalised
+//   v = u / |u| with inv0 = 1/|u| (ams_l2norm2_fwd) -> dx is the gradient w.r.t. u.  All in the pass that has the point in registers.
 ams_status ams_kmeans_soft_bwd(const float* xn, const float* w, const float* w_final, const float* cents, const float* dens, const float* dsel,
-                               const float* dout, const float* inv, const int32_t* seed, float* dx, float* g0, int b, long L, int E, int C,
-                               float beta, int n_it, void* ws, size_t ws_bytes, void* stream) {
+                               const float* dout, const float* inv, const float* inv0, const int32_t* seed, float* dx, float* g0, int b, long L,
+                               int E, int C, float beta, int n_it, void* ws, size_t ws_bytes, void* stream) {
     AMS_REQUIRE(xn && cents && dx && g0 && ws && b > 0 && L > 0 && C >= 2 && C <= 4 && beta >= 0.f && n_it >= 0 && (n_it == 0 || dens));
-    AMS_REQUIRE(!inv || seed);                      // with the Jacobian applied to dx the caller can no longer add g0 to it
+    AMS_REQUIRE((!inv || seed) && (!inv0 || inv));  // with a Jacobian applied to dx the caller can no longer add g0 to it
     if (ws_bytes < ams_kmeans_soft_bwd_workspace_bytes(b, L, E, C, n_it)) return AMS_E_WORKSPACE_TOO_SMALL;
     KsArgs a{};
     a.xn = xn; a.w = w; a.w_final = w_final; a.cents = cents; a.dens = dens; a.dsel = dsel; a.dout = dout; a.dx = dx; a.g0 = g0;
-    a.inv = inv; a.seed = seed;
+    a.inv = inv; a.inv0 = inv0; a.seed = seed;
     a.L = L; a.b = b; a.n_it = n_it; a.nG = ks_chunks(b, L); a.spw = ceil_div(ceil_div(L, KS_LANES), a.nG); a.nG = ceil_div(ceil_div(L, KS_LANES), a.spw); a.beta = beta;
     const size_t CE = (size_t)C * E;
     char* p = (char*)ws;

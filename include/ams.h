@@ -184,6 +184,10 @@ ams_status ams_blstm_ring_bwd(float* G, const float* cst, const float* tch, cons
 /* ---- K13  tf.nn.l2_normalize over groups of E       utils/ops.py:323-324 ---- */
 ams_status ams_l2norm_fwd(const float* u, float* v, float* inv, long rows, int E, void* stream);
 ams_status ams_l2norm_bwd(const float* v, const float* inv, const float* dv, float* du, long rows, int E, void* stream);
+/* xn = normalise(normalise(u)) in ONE pass, inv = 1/|u|, inv2 = 1/|normalise(u)| -- the embedding network's Normalize layer
+   (models/dpcl.py:32) followed by the k-means' own normalisation of its input (models/Kmeans_2.py:56); the same bits as two
+   ams_l2norm_fwd calls.  16-byte addressable rows of E = 40, 32, 20 or 8 floats, else AMS_E_INVALID_ARG (make the two calls). */
+ams_status ams_l2norm2_fwd(const float* u, float* xn, float* inv, float* inv2, long rows, int E, void* stream);
 
 /* column sums (bias gradients) */
 size_t ams_colsum_workspace_bytes(long rows, int cols);
@@ -363,11 +367,13 @@ ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent
  *   seed [b,C] (may be NULL: the caller scatters g0): the points c_0 was picked from -- g0 is added onto those rows of dx;
  *   inv [b,L] (may be NULL; needs seed): 1/|u| of the tf.nn.l2_normalize that produced xn (Kmeans_2.py:56, utils/ops.py:323) -- dx then
  *   leaves as the gradient w.r.t. u, the Jacobian applied in the pass that holds the point in registers instead of in a pass of its
- *   own.  ws: ams_kmeans_soft_bwd_workspace_bytes. */
+ *   own; inv0 [b,L] (may be NULL; needs inv): that u was itself normalise(u0) with inv0 = 1/|u0| (ams_l2norm2_fwd: the embedding
+ *   network's Normalize layer, models/dpcl.py:32, followed by the k-means' own) -- dx leaves as the gradient w.r.t. u0.
+ *   ws: ams_kmeans_soft_bwd_workspace_bytes. */
 size_t ams_kmeans_soft_bwd_workspace_bytes(int b, long L, int E, int C, int n_it);
 ams_status ams_kmeans_soft_bwd(const float* xn, const float* w, const float* w_final, const float* cents, const float* dens, const float* dsel,
-                               const float* dout, const float* inv, const int32_t* seed, float* dx, float* g0, int b, long L, int E, int C,
-                               float beta, int n_it, void* ws, size_t ws_bytes, void* stream);
+                               const float* dout, const float* inv, const float* inv0, const int32_t* seed, float* dx, float* g0, int b, long L,
+                               int E, int C, float beta, int n_it, void* ws, size_t ws_bytes, void* stream);
 ams_status ams_kmeans_assign(const float* xn, const float* w, const float* cent, int32_t* labels, float* soft, float* inertia, int b,
                              int tries, long L, int E, int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* stream);
 ams_status ams_kmeans_select(const float* inertia, const float* centroids, int32_t* best, float* selected, int b, int tries, int E,

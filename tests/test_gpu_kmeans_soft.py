@@ -66,3 +66,47 @@ def test_soft_kmeans_backward(b, L, E, C, tries, iters, with_w, end):
     g, g_ref = Xd.grad.cpu().numpy().astype(np.float64), Xt.grad.numpy()
     err = np.abs(g - g_ref).max() / np.abs(g_ref).max()
     assert err < 1e-3, err
+
+
+@pytest.mark.parametrize('b,L,E,C,tries,iters,with_w,end', [(2, 3000, 40, 2, 1, 3, True, True), (2, 2500, 8, 3, 2, 4, True, False),
+                                                              (1, 4200, 40, 2, 1, 2, False, True), (2, 1111, 20, 2, 1, 2, False, True)])
+def test_soft_kmeans_from_the_unnormalised_embeddings(b, L, E, C, tries, iters, with_w, end):
+    """A fine-tuning step hands the k-means the embedding network's output BEFORE its Normalize layer (F.kmeans(pre_norm=...)): both
+    normalisations in one pass (ams_l2norm2_fwd), both Jacobians in the pass that writes the gradient (ams_kmeans_soft_bwd inv / inv0).
+    Forward: the bits of Normalize -> k-means(normalize_input).  Backward: against float64 autograd of the same composition, and close
+    to the two-pass HIP form."""
+    from ams_hip import functional as F
+    rng = np.random.RandomState(L + C + 1)
+    centers = rng.randn(C, E) * 1.5
+    U = (centers[rng.randint(0, C, (b, L))] + rng.randn(b, L, E) * 0.8) * np.exp(rng.randn(b, L, 1))      # rows of very different length
+    w = (rng.rand(b, L) > 0.2).astype(np.float64) if with_w else None
+    idx = np.stack([rng.choice(L, C, replace=False) for _ in range(b * tries)])
+    R1, R2 = rng.randn(b, L, C), rng.randn(b, C, E)
+    beta = 3.0
+    Ut = torch.from_numpy(U).requires_grad_()
+    Vt = Ut * torch.rsqrt(torch.clamp((Ut * Ut).sum(-1, keepdim=True), min=1e-12))
+    sel_r, out_r, best_r = torch_soft_kmeans(Vt, torch.from_numpy(idx), C, tries, iters, beta, None if w is None else torch.from_numpy(w), end)
+    ((out_r * torch.from_numpy(R1)).sum() + (sel_r * torch.from_numpy(R2)).sum()).backward()
+
+    idx_d = torch.from_numpy(idx.astype(np.int32)).cuda()
+    wd = None if w is None else torch.from_numpy(w.astype(np.float32)).cuda()
+    r1, r2 = torch.from_numpy(R1.astype(np.float32)).cuda(), torch.from_numpy(R2.astype(np.float32)).cuda()
+    res = {}
+    for form in ('fused', 'two_pass'):
+        Ud = torch.from_numpy(U.astype(np.float32)).cuda().requires_grad_()
+        if form == 'fused':
+            never = lambda: (_ for _ in ()).throw(AssertionError('the normalised tensor was asked for'))      # noqa: E731
+            sel, out, best = F.kmeans(never, idx_d, C, tries, iters, beta, wd, end, pre_norm=lambda: Ud)
+        else:
+            V = F.l2norm_keep(Ud.reshape(b, L * E), E)[0].reshape(b, L, E)
+            sel, out, best = F.kmeans(V, idx_d, C, tries, iters, beta, wd, end)
+        ((out * r1).sum() + (sel * r2).sum()).backward()
+        res[form] = (sel.detach().cpu().numpy(), out.detach().cpu().numpy(), best.cpu().numpy(), Ud.grad.cpu().numpy().astype(np.float64))
+    f, t = res['fused'], res['two_pass']
+    assert np.array_equal(f[0], t[0]) and np.array_equal(f[1], t[1]) and np.array_equal(f[2], t[2])      # forward: the same bits
+    assert np.array_equal(f[2], best_r.numpy())
+    g_ref = Ut.grad.numpy()
+    for name, g in (('fused', f[3]), ('two_pass', t[3])):
+        err = np.abs(g - g_ref).max() / np.abs(g_ref).max()
+        assert err < 1e-3, (name, err)
+    assert np.abs(f[3] - t[3]).max() / np.abs(t[3]).max() < 1e-5
