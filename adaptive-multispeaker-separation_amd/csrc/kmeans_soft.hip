@@ -208,15 +208,18 @@ __global__ __launch_bounds__(256) void ks_pass_kernel(KsArgs a, int it) {
     }
     __syncthreads();
     float* const mypart = a.part + ((long)r * a.nG + g) * NV;
-    for (int i = tid; i < NV; i += 256) mypart[i] = (buf[i] + buf[NV + i]) + (buf[2 * NV + i] + buf[3 * NV + i]);
+    // partials leave as agent-scope (write-through) stores and are read back the same way below; the arrival is counted once this
+    // workgroup's stores are acknowledged (workgroup-scope release = s_waitcnt vmcnt(0), then the barrier) -- not __threadfence(), whose
+    // agent-scope release writes the XCD's whole L2 back (csrc/dpcl.hip, round 4)
+    for (int i = tid; i < NV; i += 256)
+        __hip_atomic_store(mypart + i, (buf[i] + buf[NV + i]) + (buf[2 * NV + i] + buf[3 * NV + i]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     // the last workgroup of this utterance to arrive adds the chunks in chunk order (the result does not depend on who is last),
     // writes G[it] (FINAL: adds to G[n]) and the constants record of the pass that consumes it
-    if (tid < NV) __threadfence();                             // every writer of `mypart` fences its own stores
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __syncthreads();
     if (tid == 0) last_sh = (atomicAdd(a.ticket + r, 1u) == (unsigned)a.nG - 1u) ? 1 : 0;
     __syncthreads();
     if (!last_sh) return;
-    __threadfence();
     float* const sum = buf;                                    // [NV]
     for (int i = tid; i < NV; i += 256) {
         float s = 0.f;
