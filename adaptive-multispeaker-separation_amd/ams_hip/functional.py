@@ -720,34 +720,36 @@ def apply_masks(X_input, masks):
 
 
 class L41Loss(Function):
-    """models/L41.py:150-178 on already gathered speaker vectors."""
+    """models/L41.py:150-178 on already gathered speaker vectors.  from_u: emb is the network output before Normalize(3) -- normalised
+    inside the loss pass, gradient returned w.r.t. it (include/ams.h: emb_is_u)."""
 
     @staticmethod
-    def forward(ctx, emb, y, vspk):
+    def forward(ctx, emb, y, vspk, from_u=False):
         ctx.save_for_backward(emb, y, vspk)
-        return ops.l41_loss_fwd(emb, y, vspk)
+        ctx.from_u = bool(from_u)
+        return ops.l41_loss_fwd(emb, y, vspk, from_u)
 
     @staticmethod
     def backward(ctx, g):
         emb, y, vspk = ctx.saved_tensors
-        demb, dvs = ops.l41_loss_bwd(emb, y, vspk, _c(g))
-        return demb, None, dvs
+        demb, dvs = ops.l41_loss_bwd(emb, y, vspk, _c(g), ctx.from_u)
+        return demb, None, dvs, None
 
 
 class L41LossNS(Function):
     """models/L41.py:150-178 plus the negative-sampling term (:143-147,165-166) on gathered vectors."""
 
     @staticmethod
-    def forward(ctx, emb, y, vspk, negs, ns_rate):
+    def forward(ctx, emb, y, vspk, negs, ns_rate, from_u=False):
         ctx.save_for_backward(emb, y, vspk, negs)
-        ctx.ns_rate = float(ns_rate)
-        return ops.l41_loss_ns_fwd(emb, y, vspk, negs, ns_rate)
+        ctx.ns_rate, ctx.from_u = float(ns_rate), bool(from_u)
+        return ops.l41_loss_ns_fwd(emb, y, vspk, negs, ns_rate, from_u)
 
     @staticmethod
     def backward(ctx, g):
         emb, y, vspk, negs = ctx.saved_tensors
-        demb, dvs, dnegs = ops.l41_loss_ns_bwd(emb, y, vspk, negs, _c(g), ctx.ns_rate)
-        return demb, None, dvs, dnegs, None
+        demb, dvs, dnegs = ops.l41_loss_ns_bwd(emb, y, vspk, negs, _c(g), ctx.ns_rate, ctx.from_u)
+        return demb, None, dvs, dnegs, None, None
 
 
 class L41Speakers(Function):
@@ -788,22 +790,23 @@ def l41_random_negatives(I, tot_speakers, K):
     return torch.topk(score, int(K), dim=1, largest=False).indices.to(torch.int32).reshape(B, 1, int(K)).contiguous()
 
 
-def l41_loss(emb, y, speaker_vectors, I, normalize, neg_idx=None, ns_rate=0.1):
+def l41_loss(emb, y, speaker_vectors, I, normalize, neg_idx=None, ns_rate=0.1, from_u=False):
     """emb [B,T,F,E], y [B,T,F,S]; speaker_vectors [251,E], I [B,S].  neg_idx (optional, int [B,NSEL,K], NSEL = 1 or S): rows of the
-    speaker table used as negatives (--sampling, L41.py:69-147): the cost gains ns_rate * mean_k -log(sigmoid(-<neg_k, emb>))."""
-    B, E = emb.shape[0], emb.shape[-1]
+    speaker table used as negatives (--sampling, L41.py:69-147): the cost gains ns_rate * mean_k -log(sigmoid(-<neg_k, emb>)).
+    from_u: emb is the network output BEFORE its Normalize(3) layer (any shape [B, ..., k*E]); the loss normalises it in its own pass."""
+    B, E = emb.shape[0], speaker_vectors.shape[1]
     S = y.shape[-1]
     table = _c(speaker_vectors)
     if neg_idx is None:
         vs = L41Speakers.apply(table, I, bool(normalize))                             # [B,S,E]
-        return L41Loss.apply(_c(emb).reshape(B, -1, E), _c(y).reshape(B, -1, S), vs)
+        return L41Loss.apply(_c(emb).reshape(B, -1, E), _c(y).reshape(B, -1, S), vs, bool(from_u))
     NSEL, K = neg_idx.shape[1], neg_idx.shape[2]
     # ONE gather through the normalise Jacobian for the mixture speakers and the negatives: [B, S + NSEL*K, E]
     allidx = torch.cat([I.to(torch.int32).reshape(B, S), neg_idx.to(torch.int32).reshape(B, NSEL * K)], dim=1).contiguous()
     allv = L41Speakers.apply(table, allidx, bool(normalize))
     vs = allv[:, :S].contiguous()
     negs = allv[:, S:].reshape(B, NSEL, K, E).contiguous()
-    return L41LossNS.apply(_c(emb).reshape(B, -1, E), _c(y).reshape(B, -1, S), vs, negs, float(ns_rate))
+    return L41LossNS.apply(_c(emb).reshape(B, -1, E), _c(y).reshape(B, -1, S), vs, negs, float(ns_rate), bool(from_u))
 
 
 class EnhanceOutput(Function):

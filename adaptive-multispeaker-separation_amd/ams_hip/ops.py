@@ -1328,7 +1328,7 @@ def cplx_apply_bwd(dz, phasor, S, T):
 
 
 # ------------------------------------------------------------------ L41 loss
-def l41_loss_fwd(emb, y, vspk):
+def l41_loss_fwd(emb, y, vspk, from_u=False):
     _chk(emb, y, vspk)
     lib = load()
     B, TF, E = emb.shape
@@ -1336,11 +1336,11 @@ def l41_loss_fwd(emb, y, vspk):
     nb = lib.ams_l41_workspace_bytes(B, TF, E, S)
     ws = _ws(nb, emb)
     cost = torch.empty(1, dtype=torch.float32, device=emb.device)
-    check(lib.ams_l41_loss_fwd(_p(emb), _p(y), _p(vspk), _p(cost), B, TF, E, S, _p(ws), nb, _s()), 'ams_l41_loss_fwd')
+    check(lib.ams_l41_loss_fwd(_p(emb), _p(y), _p(vspk), _p(cost), B, TF, E, S, int(from_u), _p(ws), nb, _s()), 'ams_l41_loss_fwd')
     return cost
 
 
-def l41_loss_bwd(emb, y, vspk, upstream):
+def l41_loss_bwd(emb, y, vspk, upstream, from_u=False):
     _chk(emb, y, vspk, upstream)
     lib = load()
     B, TF, E = emb.shape
@@ -1349,11 +1349,12 @@ def l41_loss_bwd(emb, y, vspk, upstream):
     ws = _ws(nb, emb)
     demb = torch.empty_like(emb)
     dvs = torch.empty_like(vspk)
-    check(lib.ams_l41_loss_bwd(_p(emb), _p(y), _p(vspk), _p(upstream), _p(demb), _p(dvs), B, TF, E, S, _p(ws), nb, _s()), 'ams_l41_loss_bwd')
+    check(lib.ams_l41_loss_bwd(_p(emb), _p(y), _p(vspk), _p(upstream), _p(demb), _p(dvs), B, TF, E, S, int(from_u), _p(ws), nb, _s()),
+          'ams_l41_loss_bwd')
     return demb, dvs
 
 
-def l41_loss_ns_fwd(emb, y, vspk, negs, ns_rate):
+def l41_loss_ns_fwd(emb, y, vspk, negs, ns_rate, from_u=False):
     """L41 loss with negative sampling (L41.py:69-147,165-166): negs [B,NSEL,K,E], NSEL = 1 or S."""
     _chk(emb, y, vspk, negs)
     lib = load()
@@ -1363,12 +1364,13 @@ def l41_loss_ns_fwd(emb, y, vspk, negs, ns_rate):
     nb = lib.ams_l41_ns_workspace_bytes(B, TF, E, S, NSEL, K)
     ws = _ws(nb, emb)
     cost = torch.empty(1, dtype=torch.float32, device=emb.device)
-    check(lib.ams_l41_loss_ns_fwd(_p(emb), _p(y), _p(vspk), _p(negs), _p(cost), B, TF, E, S, NSEL, K, float(ns_rate), _p(ws), nb, _s()),
+    check(lib.ams_l41_loss_ns_fwd(_p(emb), _p(y), _p(vspk), _p(negs), _p(cost), B, TF, E, S, NSEL, K, float(ns_rate), int(from_u), _p(ws), nb,
+                                  _s()),
           'ams_l41_loss_ns_fwd')
     return cost
 
 
-def l41_loss_ns_bwd(emb, y, vspk, negs, upstream, ns_rate):
+def l41_loss_ns_bwd(emb, y, vspk, negs, upstream, ns_rate, from_u=False):
     _chk(emb, y, vspk, negs, upstream)
     lib = load()
     B, TF, E = emb.shape
@@ -1378,7 +1380,7 @@ def l41_loss_ns_bwd(emb, y, vspk, negs, upstream, ns_rate):
     ws = _ws(nb, emb)
     demb, dvs, dnegs = torch.empty_like(emb), torch.empty_like(vspk), torch.empty_like(negs)
     check(lib.ams_l41_loss_ns_bwd(_p(emb), _p(y), _p(vspk), _p(negs), _p(upstream), _p(demb), _p(dvs), _p(dnegs), B, TF, E, S, NSEL, K,
-                                  float(ns_rate), _p(ws), nb, _s()), 'ams_l41_loss_ns_bwd')
+                                  float(ns_rate), int(from_u), _p(ws), nb, _s()), 'ams_l41_loss_ns_bwd')
     return demb, dvs, dnegs
 
 

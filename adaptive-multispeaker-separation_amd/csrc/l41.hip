@@ -27,13 +27,19 @@ struct NegArgs {
     float wn;                     // ns_rate * S / K: weight of one negative term relative to one speaker term
 };
 
-template <int E_, bool BWD, bool NEG>
+// FROM_U (round 4): emb is the network output BEFORE tf.nn.l2_normalize (models/L41.py:43 Normalize(3), utils/ops.py:323): the point
+// is normalised in registers on the way in, and the backward applies the normalise Jacobian to the gradient before it writes it -- no
+// l2-normalise pass before the loss (read + write of the embedding tensor) and none after it (two reads + one write): 0.9 ms of a 9.5 ms
+// cfg5 step.  VEC: 16-byte global accesses and LDS rows (E % 4 == 0, 16-byte aligned tensors): the 4-byte form ran the backward at
+// 2.3 TB/s.
+template <int E_, bool BWD, bool NEG, bool FROM_U, bool VEC>
 __global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb, const float* __restrict__ y,
                                                   const float* __restrict__ vs, const float* __restrict__ upstream,
                                                   float* __restrict__ part, float* __restrict__ demb, float* __restrict__ dvs_part,
                                                   long TF, int S, int nblk, float scale, NegArgs na) {
-    constexpr int LD = E_ + 1;
-    __shared__ float tile[256 * LD];
+    constexpr int LD = VEC ? E_ + 4 : E_ + 1;
+    constexpr int V4 = E_ / 4;
+    __shared__ __attribute__((aligned(16))) float tile[256 * LD];
     __shared__ float svs[MAXS * E_];
     __shared__ float red[4][MAXS * E_ + 1];
     __shared__ float sneg[NEG ? MAXN * E_ : 1];
@@ -43,7 +49,17 @@ __global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb,
     const long p0 = (long)blockIdx.x * 256;
     const int npts = (int)min((long)256, TF - p0);
     const float* eb = emb + ((long)b * TF + p0) * E_;
-    for (int i = tid; i < npts * E_; i += 256) tile[(i / E_) * LD + (i % E_)] = eb[i];
+    if constexpr (VEC) {
+        const float4* src = reinterpret_cast<const float4*>(eb);
+#pragma unroll
+        for (int k = 0; k < V4; ++k) {
+            const int i = tid + 256 * k, row = i / V4, c4 = i - row * V4;
+            const float4 v4 = src[min(i, npts * V4 - 1)];                    // unconditional, clamped (rows past npts are never read back)
+            *reinterpret_cast<float4*>(&tile[row * LD + c4 * 4]) = v4;
+        }
+    } else {
+        for (int i = tid; i < npts * E_; i += 256) tile[(i / E_) * LD + (i % E_)] = eb[i];
+    }
     for (int i = tid; i < S * E_; i += 256) svs[i] = vs[(long)b * S * E_ + i];
     if (NEG)
         for (int i = tid; i < na.NSEL * na.K * E_; i += 256) sneg[i] = na.negs[(long)b * na.NSEL * na.K * E_ + i];
@@ -52,9 +68,22 @@ __global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb,
     float dz[MAXS] = {0.f, 0.f, 0.f, 0.f};
     float v[E_];
     int sel = 0;
+    float inv_u = 1.0f;
     if (tid < npts) {
 #pragma unroll
         for (int e = 0; e < E_; ++e) v[e] = tile[tid * LD + e];
+        if constexpr (FROM_U) {
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < E_; ++e) ss += v[e] * v[e];
+            inv_u = 1.0f / sqrtf(fmaxf(ss, 1e-12f));                          // tf.nn.l2_normalize epsilon (utils/ops.py:323)
+#pragma unroll
+            for (int e = 0; e < E_; ++e) v[e] *= inv_u;
+            if (NEG && BWD) {                                                // the negatives' gradient below reads the points from LDS
+#pragma unroll
+                for (int e = 0; e < E_; ++e) tile[tid * LD + e] = v[e];
+            }
+        }
         const float* yp = y + ((long)b * TF + p0 + tid) * S;
         const float up = BWD ? upstream[0] * scale : 0.f;
         for (int s = 0; s < S; ++s) {
@@ -104,14 +133,24 @@ __global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb,
         __syncthreads();
     }
     if (tid < npts) {
+        float dv[E_];
 #pragma unroll
         for (int e = 0; e < E_; ++e) {
             float d = 0.f;
             for (int s = 0; s < S; ++s) d += dz[s] * svs[s * E_ + e];
             if (NEG)
                 for (int k = 0; k < na.K; ++k) d += sdz[tid * MAXK + k] * sneg[(sel * na.K + k) * E_ + e];
-            tile[tid * LD + e] = d;
+            dv[e] = d;
         }
+        if constexpr (FROM_U) {                                                  // du = (dv - v <v, dv>) / |u|
+            float dot = 0.f;
+#pragma unroll
+            for (int e = 0; e < E_; ++e) dot += v[e] * dv[e];
+#pragma unroll
+            for (int e = 0; e < E_; ++e) dv[e] = (dv[e] - v[e] * dot) * inv_u;
+        }
+#pragma unroll
+        for (int e = 0; e < E_; ++e) tile[tid * LD + e] = dv[e];
     }
     for (int s = 0; s < S; ++s) {
 #pragma unroll
@@ -122,7 +161,16 @@ __global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb,
     }
     __syncthreads();
     float* db = demb + ((long)b * TF + p0) * E_;
-    for (int i = tid; i < npts * E_; i += 256) db[i] = tile[(i / E_) * LD + (i % E_)];
+    if constexpr (VEC) {
+        float4* dst = reinterpret_cast<float4*>(db);
+#pragma unroll
+        for (int k = 0; k < V4; ++k) {
+            const int i = tid + 256 * k, row = i / V4, c4 = i - row * V4;
+            if (i < npts * V4) dst[i] = *reinterpret_cast<const float4*>(&tile[row * LD + c4 * 4]);
+        }
+    } else {
+        for (int i = tid; i < npts * E_; i += 256) db[i] = tile[(i / E_) * LD + (i % E_)];
+    }
     for (int i = tid; i < S * E_; i += 256)
         dvs_part[((long)b * nblk + blockIdx.x) * (S * E_) + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
 }
@@ -155,27 +203,35 @@ size_t ams_l41_workspace_bytes(int B, long TF, int E, int S) {
     return sizeof(float) * (size_t)B * nblk * (S * E > 1 ? S * E : 1);
 }
 
+#define AMS_L41_CASE(EE, BWD, NEG, U, V, ...) hipLaunchKernelGGL((l41_kernel<EE, BWD, NEG, U, V>), grid, dim3(256), 0, st, __VA_ARGS__)
+#define AMS_L41_E(EE, BWD, NEG, ...)                                                                          \
+    if (EE % 4 == 0 && vec) { if (from_u) AMS_L41_CASE(EE, BWD, NEG, true, (EE % 4 == 0), __VA_ARGS__); else AMS_L41_CASE(EE, BWD, NEG, false, (EE % 4 == 0), __VA_ARGS__); } \
+    else { if (from_u) AMS_L41_CASE(EE, BWD, NEG, true, false, __VA_ARGS__); else AMS_L41_CASE(EE, BWD, NEG, false, false, __VA_ARGS__); }
 #define AMS_L41_DISPATCH(BWD, NEG, ...)                                                                       \
     switch (E) {                                                                                              \
-        case 40: hipLaunchKernelGGL((l41_kernel<40, BWD, NEG>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
-        case 32: hipLaunchKernelGGL((l41_kernel<32, BWD, NEG>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
-        case 20: hipLaunchKernelGGL((l41_kernel<20, BWD, NEG>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
-        case 16: hipLaunchKernelGGL((l41_kernel<16, BWD, NEG>), grid, dim3(256), 0, st, __VA_ARGS__); break;   \
-        case 8: hipLaunchKernelGGL((l41_kernel<8, BWD, NEG>), grid, dim3(256), 0, st, __VA_ARGS__); break;     \
-        case 4: hipLaunchKernelGGL((l41_kernel<4, BWD, NEG>), grid, dim3(256), 0, st, __VA_ARGS__); break;     \
-        case 3: hipLaunchKernelGGL((l41_kernel<3, BWD, NEG>), grid, dim3(256), 0, st, __VA_ARGS__); break;     \
+        case 40: AMS_L41_E(40, BWD, NEG, __VA_ARGS__) break;                                                   \
+        case 32: AMS_L41_E(32, BWD, NEG, __VA_ARGS__) break;                                                   \
+        case 20: AMS_L41_E(20, BWD, NEG, __VA_ARGS__) break;                                                   \
+        case 16: AMS_L41_E(16, BWD, NEG, __VA_ARGS__) break;                                                   \
+        case 8: AMS_L41_E(8, BWD, NEG, __VA_ARGS__) break;                                                     \
+        case 4: AMS_L41_E(4, BWD, NEG, __VA_ARGS__) break;                                                     \
+        case 3: AMS_L41_E(3, BWD, NEG, __VA_ARGS__) break;                                                     \
         default: return AMS_E_INVALID_ARG;                                                                    \
     }
+inline bool l41_vec(const void* a, const void* b) { return (((uintptr_t)a | (uintptr_t)b) & 15) == 0; }
 
 // emb [B,TF,E], y [B,TF,S] (+1/-1), vspk [B,S,E] (already gathered / normalised) -> cost[0]
-ams_status ams_l41_loss_fwd(const float* emb, const float* y, const float* vspk, float* cost, int B, long TF, int E, int S, void* ws,
-                            size_t ws_bytes, void* stream) {
+// emb_is_u (all four entry points): emb is the network output BEFORE tf.nn.l2_normalize over E (models/L41.py:43): it is normalised
+// inside the pass, and the backward returns the gradient w.r.t. that un-normalised tensor.
+ams_status ams_l41_loss_fwd(const float* emb, const float* y, const float* vspk, float* cost, int B, long TF, int E, int S, int emb_is_u,
+                            void* ws, size_t ws_bytes, void* stream) {
     AMS_REQUIRE(emb && y && vspk && cost && ws && B > 0 && TF > 0 && S > 0 && S <= MAXS);
     if (ws_bytes < ams_l41_workspace_bytes(B, TF, E, S)) return AMS_E_WORKSPACE_TOO_SMALL;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = ceil_div(TF, 256);
     dim3 grid(nblk, B);
     const float scale = 1.0f / ((float)B * (float)TF * S);
+    const bool from_u = emb_is_u != 0, vec = l41_vec(emb, emb);
     AMS_L41_DISPATCH(false, false, emb, y, vspk, (const float*)nullptr, (float*)ws, (float*)nullptr, (float*)nullptr, TF, S, nblk, scale, NegArgs{})
     hipLaunchKernelGGL(l41_cost_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, cost, (long)B * nblk, scale);
     return ams_check_launch();
@@ -183,13 +239,14 @@ ams_status ams_l41_loss_fwd(const float* emb, const float* y, const float* vspk,
 
 // demb [B,TF,E], dvspk [B,S,E]; upstream = device scalar d loss / d cost
 ams_status ams_l41_loss_bwd(const float* emb, const float* y, const float* vspk, const float* upstream, float* demb, float* dvspk,
-                            int B, long TF, int E, int S, void* ws, size_t ws_bytes, void* stream) {
+                            int B, long TF, int E, int S, int emb_is_u, void* ws, size_t ws_bytes, void* stream) {
     AMS_REQUIRE(emb && y && vspk && upstream && demb && dvspk && ws && B > 0 && TF > 0 && S > 0 && S <= MAXS);
     if (ws_bytes < ams_l41_workspace_bytes(B, TF, E, S)) return AMS_E_WORKSPACE_TOO_SMALL;
     hipStream_t st = (hipStream_t)stream;
     const int nblk = ceil_div(TF, 256);
     dim3 grid(nblk, B);
     const float scale = 1.0f / ((float)B * (float)TF * S);
+    const bool from_u = emb_is_u != 0, vec = l41_vec(emb, demb);
     AMS_L41_DISPATCH(true, false, emb, y, vspk, upstream, (float*)nullptr, demb, (float*)ws, TF, S, nblk, scale, NegArgs{})
     hipLaunchKernelGGL(l41_dvs_final_kernel, dim3(ceil_div(B * S * E, 256)), dim3(256), 0, st, (const float*)ws, dvspk, nblk, S * E, B);
     return ams_check_launch();
@@ -202,7 +259,7 @@ size_t ams_l41_ns_workspace_bytes(int B, long TF, int E, int S, int NSEL, int K)
 }
 
 ams_status ams_l41_loss_ns_fwd(const float* emb, const float* y, const float* vspk, const float* negs, float* cost, int B, long TF, int E,
-                               int S, int NSEL, int K, float ns_rate, void* ws, size_t ws_bytes, void* stream) {
+                               int S, int NSEL, int K, float ns_rate, int emb_is_u, void* ws, size_t ws_bytes, void* stream) {
     AMS_REQUIRE(emb && y && vspk && negs && cost && ws && B > 0 && TF > 0 && S > 0 && S <= MAXS);
     AMS_REQUIRE((NSEL == 1 || NSEL == S) && K > 0 && K <= MAXK && NSEL * K <= MAXN);
     if (ws_bytes < ams_l41_ns_workspace_bytes(B, TF, E, S, NSEL, K)) return AMS_E_WORKSPACE_TOO_SMALL;
@@ -211,6 +268,7 @@ ams_status ams_l41_loss_ns_fwd(const float* emb, const float* y, const float* vs
     dim3 grid(nblk, B);
     const float scale = 1.0f / ((float)B * (float)TF * S);
     NegArgs na{negs, nullptr, NSEL, K, ns_rate * (float)S / (float)K};
+    const bool from_u = emb_is_u != 0, vec = l41_vec(emb, emb);
     AMS_L41_DISPATCH(false, true, emb, y, vspk, (const float*)nullptr, (float*)ws, (float*)nullptr, (float*)nullptr, TF, S, nblk, scale, na)
     hipLaunchKernelGGL(l41_cost_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, cost, (long)B * nblk, scale);
     return ams_check_launch();
@@ -218,8 +276,8 @@ ams_status ams_l41_loss_ns_fwd(const float* emb, const float* y, const float* vs
 
 // demb [B,TF,E], dvspk [B,S,E], dnegs [B,NSEL,K,E]
 ams_status ams_l41_loss_ns_bwd(const float* emb, const float* y, const float* vspk, const float* negs, const float* upstream, float* demb,
-                               float* dvspk, float* dnegs, int B, long TF, int E, int S, int NSEL, int K, float ns_rate, void* ws,
-                               size_t ws_bytes, void* stream) {
+                               float* dvspk, float* dnegs, int B, long TF, int E, int S, int NSEL, int K, float ns_rate, int emb_is_u,
+                               void* ws, size_t ws_bytes, void* stream) {
     AMS_REQUIRE(emb && y && vspk && negs && upstream && demb && dvspk && dnegs && ws && B > 0 && TF > 0 && S > 0 && S <= MAXS);
     AMS_REQUIRE((NSEL == 1 || NSEL == S) && K > 0 && K <= MAXK && NSEL * K <= MAXN);
     if (ws_bytes < ams_l41_ns_workspace_bytes(B, TF, E, S, NSEL, K)) return AMS_E_WORKSPACE_TOO_SMALL;
@@ -230,6 +288,7 @@ ams_status ams_l41_loss_ns_bwd(const float* emb, const float* y, const float* vs
     float* dvs_part = (float*)ws;
     float* dneg_part = dvs_part + (size_t)B * nblk * S * E;
     NegArgs na{negs, dneg_part, NSEL, K, ns_rate * (float)S / (float)K};
+    const bool from_u = emb_is_u != 0, vec = l41_vec(emb, demb);
     AMS_L41_DISPATCH(true, true, emb, y, vspk, upstream, (float*)nullptr, demb, dvs_part, TF, S, nblk, scale, na)
     hipLaunchKernelGGL(l41_dvs_final_kernel, dim3(ceil_div(B * S * E, 256)), dim3(256), 0, st, (const float*)dvs_part, dvspk, nblk, S * E, B);
     const int NE = NSEL * K * E;

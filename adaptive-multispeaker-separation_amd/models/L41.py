@@ -51,9 +51,13 @@ class L41Model(Separator):
         conv = Conv1D([1, self.layer_size, E * Fq])
         x_node, normalize = self.X, self.normalize
 
+        # the dense output before Normalize(3): a training step hands THIS to the loss, which normalises inside its own pass (cost below)
+        self._embed = Node('embed', lambda run: conv.f_prop(f_props(layers, x_node.value(run), then=conv)), register=False)
+        self._embed_normalized = bool(normalize)            # prediction = l2-normalise(_embed) only then (separate_host: k-means from _embed)
+        embed = self._embed
+
         def _pred(run):
-            x = x_node.value(run)
-            u = conv.f_prop(f_props(layers, x, then=conv))
+            u = embed.value(run)
             if normalize:
                 return F.l2norm(u, E)
             return u.reshape(u.shape[:-1] + (Fq, E))
@@ -73,6 +77,9 @@ class L41Model(Separator):
                     neg = F.l41_knearest(spk, Iv, sampling, normalize)                 # [B,S,K], set of the bin's dominant speaker
                 else:
                     neg = F.l41_random_negatives(Iv, tot, sampling)                    # [B,1,K], one set per utterance
+            if normalize and run.training and id(pred) not in run.cache:
+                # K13 fused into K15: the un-normalised dense output goes to the loss kernels, V is never written in a training step
+                return F.l41_loss(self._embed.value(run), y.value(run), spk, Iv, normalize, neg_idx=neg, ns_rate=ns_rate, from_u=True)
             return F.l41_loss(pred.value(run), y.value(run), spk, Iv, normalize, neg_idx=neg, ns_rate=ns_rate)
         cost = Node('cost_value', _cost)
         get_default_graph().summaries['cost/cost'] = cost

@@ -30,6 +30,7 @@ class DPCL(Separator):
             x = x_node.value(run)
             return conv.f_prop(f_props(layers, x, then=conv))             # [B, T, F*E]  (column = f*E + e)
         self._embed = Node('embed', _embed, register=False)
+        self._embed_normalized = True                        # prediction = l2-normalise(_embed): separate_host hands _embed to the k-means
         # Reshape + Normalize(3); only evaluated when the embeddings themselves are fetched (inference / k-means):
         # a training step goes u -> fused normalise+loss kernel and never writes V.
         return Node('prediction', lambda run: F.l2norm_keep(self._embed.value(run), E)[0], register=False)

@@ -331,12 +331,16 @@ ams_status ams_cplx_mag_phase(const float* ri, float* mag, float* phasor, long r
 ams_status ams_cplx_apply_fwd(const float* sep, const float* phasor, float* z, long rows, int F, int S, int T, void* stream);
 ams_status ams_cplx_apply_bwd(const float* dz, const float* phasor, float* dsep, long rows, int F, int S, int T, void* stream);
 
-/* ---- K15 L41 loss   models/L41.py:150-178 (sampling=None) ---- */
+/* ---- K15 L41 loss   models/L41.py:150-178 (sampling=None) ----
+ * emb_is_u (all four entry points): 0 = emb holds the embeddings the loss is defined on; 1 = emb is the network output BEFORE
+ * tf.nn.l2_normalize over E (models/L41.py:43 Normalize(3), utils/ops.py:323): every point is normalised in registers inside the pass
+ * and the backward returns the gradient w.r.t. that un-normalised tensor (the normalise Jacobian applied before the store) -- K13
+ * fused into K15 as it is into K14 (ams_dpcl_loss_fwd_u): no l2-normalise pass before the loss and none after it. */
 size_t ams_l41_workspace_bytes(int B, long TF, int E, int S);
-ams_status ams_l41_loss_fwd(const float* emb, const float* y, const float* vspk, float* cost, int B, long TF, int E, int S, void* ws,
-                            size_t ws_bytes, void* stream);
+ams_status ams_l41_loss_fwd(const float* emb, const float* y, const float* vspk, float* cost, int B, long TF, int E, int S, int emb_is_u,
+                            void* ws, size_t ws_bytes, void* stream);
 ams_status ams_l41_loss_bwd(const float* emb, const float* y, const float* vspk, const float* upstream, float* demb, float* dvspk,
-                            int B, long TF, int E, int S, void* ws, size_t ws_bytes, void* stream);
+                            int B, long TF, int E, int S, int emb_is_u, void* ws, size_t ws_bytes, void* stream);
 /* ... with negative sampling (--sampling K)   models/L41.py:69-147,165-166:
  *   cost[b,t,f] += ns_rate * mean_k -log(sigmoid(-<negs[b, sel, k, :], emb[b,t,f,:]>))
  * negs [B,NSEL,K,E] = rows of the (normalised) speaker table the caller gathered: NSEL = 1 -- one set per utterance, ns_method
@@ -344,10 +348,10 @@ ams_status ams_l41_loss_bwd(const float* emb, const float* y, const float* vspk,
  * ns_method 'k-nearest' (:91-116).  K <= 16, NSEL*K <= 32.  dnegs [B,NSEL,K,E] is overwritten. */
 size_t ams_l41_ns_workspace_bytes(int B, long TF, int E, int S, int NSEL, int K);
 ams_status ams_l41_loss_ns_fwd(const float* emb, const float* y, const float* vspk, const float* negs, float* cost, int B, long TF, int E,
-                               int S, int NSEL, int K, float ns_rate, void* ws, size_t ws_bytes, void* stream);
+                               int S, int NSEL, int K, float ns_rate, int emb_is_u, void* ws, size_t ws_bytes, void* stream);
 ams_status ams_l41_loss_ns_bwd(const float* emb, const float* y, const float* vspk, const float* negs, const float* upstream, float* demb,
-                               float* dvspk, float* dnegs, int B, long TF, int E, int S, int NSEL, int K, float ns_rate, void* ws,
-                               size_t ws_bytes, void* stream);
+                               float* dvspk, float* dnegs, int B, long TF, int E, int S, int NSEL, int K, float ns_rate, int emb_is_u,
+                               void* ws, size_t ws_bytes, void* stream);
 
 /* ---- K16-K19 batched k-means   models/Kmeans_2.py:40-188 ----
  * xn [b,L,E] normalised input (ams_kmeans_normalize); rows r = b_idx*tries + try; centroids [b*tries, C, E];

@@ -155,6 +155,45 @@ def test_l41_loss(F, normalize):
     assert rel(host(et.grad), de) < 5 * TOL and rel(host(st.grad), ds) < 5 * TOL
 
 
+@pytest.mark.parametrize('E,Fq', [(40, 70), (20, 33), (3, 50)])
+@pytest.mark.parametrize('method,S,K', [(None, 2, 0), (None, 3, 0), ('k-nearest', 2, 5), ('random', 3, 16)])
+def test_l41_loss_from_the_unnormalised_embeddings(F, E, Fq, method, S, K):
+    """emb_is_u (K13 fused into K15): the loss takes the dense output BEFORE Normalize(3) (models/L41.py:43), normalises every point
+    inside its own pass and returns the gradient w.r.t. that tensor.  Against the oracle's loss on l2-normalise(u) and its gradient
+    pulled back through the normalise Jacobian -- rows of very different length, with and without negative sampling, 16-byte (E = 40,
+    20) and 4-byte (E = 3) staging."""
+    from oracle import dense as odense
+    rng = np.random.RandomState(7 * E + S + K)
+    B, T, NS, rate = 3, 4, 23, 0.3
+    u = rng.randn(B, T, Fq * E) * np.exp(rng.randn(B, T, 1))
+    u[0, 0, :E] = 0.0                                            # the epsilon clamp
+    spk = rng.randn(NS, E)
+    I = np.stack([rng.choice(NS, S, replace=False) for _ in range(B)]).astype(np.int32)
+    lab = rng.randint(0, S, (B, T, Fq))
+    y = np.where(np.eye(S)[lab] > 0, 1.0, -1.0)
+    V, inv = odense.l2norm_fwd(u, E)                                            # [B,T,Fq,E]
+    idx_ref = None
+    if method == 'k-nearest':
+        idx_ref = ol41.knearest_indices(spk, I, K, True)
+    elif method == 'random':
+        idx_ref = ol41.random_indices(I, NS, K, np.random.RandomState(3))
+    c_ref = ol41.l41_cost(V, y, spk, I, True, idx_ref, rate) if idx_ref is not None else ol41.l41_cost(V, y, spk, I, True)
+    dV, ds = ol41.l41_cost_bwd(V, y, spk, I, True, idx_ref, rate) if idx_ref is not None else ol41.l41_cost_bwd(V, y, spk, I, True)
+    du_ref = odense.l2norm_bwd(V, inv, dV.reshape(V.shape)).reshape(u.shape)
+    ut, st = dev(u).requires_grad_(), dev(spk).requires_grad_()
+    idx = dev(idx_ref, np.int32) if idx_ref is not None else None
+    c = F.l41_loss(ut, dev(y), st, dev(I, np.int32), True, neg_idx=idx, ns_rate=rate, from_u=True)
+    assert abs(float(c) - c_ref) < TOL * max(1.0, abs(c_ref))
+    c.backward()
+    assert rel(host(ut.grad), du_ref) < 5 * TOL and rel(host(st.grad), ds) < 5 * TOL
+    # and the two-pass form on the same input agrees (same loss, gradients to round-off)
+    u2, s2 = dev(u).requires_grad_(), dev(spk).requires_grad_()
+    c2 = F.l41_loss(F.l2norm(u2, E), dev(y), s2, dev(I, np.int32), True, neg_idx=idx, ns_rate=rate)
+    c2.backward()
+    assert abs(float(c2) - float(c)) < 1e-6 * max(1.0, abs(c_ref))
+    assert rel(host(u2.grad), host(ut.grad)) < 1e-5
+
+
 @pytest.mark.parametrize('normalize', [True, False])
 @pytest.mark.parametrize('method,S,K', [('k-nearest', 2, 5), ('random', 2, 7), ('k-nearest', 3, 4), ('random', 3, 16)])
 def test_l41_loss_negative_sampling(F, normalize, method, S, K):
