@@ -626,6 +626,15 @@ def raise_on_ring_errors():
                        'per-step recurrence kernels, which need no co-residency.')
 
 
+def _padded_rows(x2, Dp):
+    """[M, D] -> [M, Dp] with zero columns appended: an input width that is not a multiple of 4 (the STFT's F = 257 bins, 2F = 514 in
+    the enhance stack) leaves its rows not 16-byte addressable, and every product reading them falls back to the scalar-load native-f32
+    kernel (csrc/gemm.hip) -- 2-3x slower than the same product on the 16-bit pipe.  The copy is M * Dp * 4 bytes (5 MB at F = 257)."""
+    xp = torch.zeros((x2.shape[0], Dp), dtype=x2.dtype, device=x2.device)
+    xp[:, :x2.shape[1]].copy_(x2)
+    return xp
+
+
 def blstm_fwd(x, Kf, bf, Kb, bb, amax=None):
     """One BLSTM layer (utils/ops.py:358-383).  x [B,T,D]; K* [D+H,4H]; b* [4H].
     Returns out [B,T,2H] and the tensors the backward needs (G = activated gates, cst = cell states).
@@ -656,7 +665,15 @@ def blstm_fwd(x, Kf, bf, Kb, bb, amax=None):
     out = torch.empty((B, T, 2 * H), dtype=torch.float32, device=x.device)
     # ring recurrence: plane 0 = c_t (what every backward reads as `cst`), plane 1 = tanh(c_t) for the backward ring
     cst = torch.empty(((2, B, T, 2, H) if nring else (B, T, 2, H)), dtype=torch.float32, device=x.device)
-    gemm(x2, Wcat, bias=bias, out=G, M=B * T, N=8 * H, K=D, lda=D, ldb=8 * H, ldc=8 * H, label='blstm_input_gemm', amax=amax)
+    Dp = (D + 3) // 4 * 4
+    if Dp != D and x.is_cuda:
+        # rows of D floats are not 16-byte addressable: project zero-padded copies (x: +3 zero columns, kernels: +3 zero rows)
+        Wp = torch.zeros((Dp, 8 * H), dtype=Wcat.dtype, device=Wcat.device)
+        Wp[:D].copy_(Wcat)
+        gemm(_padded_rows(x2, Dp), Wp, bias=bias, out=G, M=B * T, N=8 * H, K=Dp, lda=Dp, ldb=8 * H, ldc=8 * H, label='blstm_input_gemm',
+             amax=amax)
+    else:
+        gemm(x2, Wcat, bias=bias, out=G, M=B * T, N=8 * H, K=D, lda=D, ldb=8 * H, ldc=8 * H, label='blstm_input_gemm', amax=amax)
     if nring:
         sync, pre0 = _ring_sync(nring, x)
         check(lib.ams_blstm_ring_fwd(_p(G), _p(out), _p(cst[0]), _p(cst[1]), _p(Kf[D:]), _p(Kb[D:]), ldu,
@@ -814,8 +831,20 @@ def blstm_bwd_weights(x, out, G, dKf, dbf, dKb, dbb, accumulate, part='all', dbp
     dZb = G.view(-1)[4 * H:]
     acc = bool(accumulate)
     _chk_rows(dKf, dKb)
+    Dp = (D + 3) // 4 * 4
     if part in ('all', 'wx'):
-        if _twin(dKf, dKb):
+        if Dp != D and x.is_cuda:
+            # input width not a multiple of 4 (see _padded_rows): the product runs on a zero-padded copy of x into a [Dp, 8H] scratch,
+            # whose first D rows are the gradient
+            dWcat = gemm(_padded_rows(x2, Dp), dZf, transA=True, M=Dp, N=8 * H, K=M, lda=Dp, ldb=8 * H, ldc=8 * H,
+                         out=torch.empty((Dp, 8 * H), dtype=torch.float32, device=x.device), amax=am_wx)
+            if acc:
+                dKf[:D].add_(dWcat[:D, :4 * H])
+                dKb[:D].add_(dWcat[:D, 4 * H:])
+            else:
+                dKf[:D].copy_(dWcat[:D, :4 * H])
+                dKb[:D].copy_(dWcat[:D, 4 * H:])
+        elif _twin(dKf, dKb):
             # twin-interleaved gradient block: [dWx_f | dWx_b] IS a row-major [D, 8H] matrix -> written in place; when the two bias
             # gradients are adjacent too, db = column sums of dZ come out of the SAME pass over dZ (the product's tile_m == 0
             # workgroups add up the rows they stage anyway, finished inside the launch): no column-sum launches at all
