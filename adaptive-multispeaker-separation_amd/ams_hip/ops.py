@@ -1332,11 +1332,12 @@ def overlap_metric_bwd(y, upstream, B, S):
 
 # ------------------------------------------------------------------ complex glue
 def cplx_mag_phase(ri, F, want_phase=True):
+    """ri [rows, >= 2F] = [Re | Im | padding] -> (|.| [rows, F], unit phasor [rows, 2F] or None)."""
     _chk(ri)
     rows = ri.shape[0]
     mag = torch.empty((rows, F), dtype=torch.float32, device=ri.device)
     ph = torch.empty((rows, 2 * F), dtype=torch.float32, device=ri.device) if want_phase else None
-    check(load().ams_cplx_mag_phase(_p(ri), _p(mag), _p(ph), rows, F, _s()), 'ams_cplx_mag_phase')
+    check(load().ams_cplx_mag_phase(_p(ri), _p(mag), _p(ph), rows, F, ri.shape[1], _s()), 'ams_cplx_mag_phase')
     return mag, ph
 
 

@@ -12,12 +12,12 @@ namespace {
 
 // ri [rows, 2F] -> mag [rows, F], phasor [rows, 2F] = (cos theta | sin theta), theta = angle (angle(0) = 0)
 __global__ void cplx_mag_phase_kernel(const float* __restrict__ ri, float* __restrict__ mag, float* __restrict__ ph, long rows,
-                                      int F) {
+                                      int F, long ld) {
     const long total = rows * F;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / F;
         const int f = (int)(i - r * F);
-        const float re = ri[r * 2 * F + f], im = ri[r * 2 * F + F + f];
+        const float re = ri[r * ld + f], im = ri[r * ld + F + f];
         const float m = sqrtf(re * re + im * im);
         mag[i] = m;
         if (ph) {
@@ -64,9 +64,10 @@ inline int blocks_for(long n) {
 
 extern "C" {
 
-ams_status ams_cplx_mag_phase(const float* ri, float* mag, float* phasor, long rows, int F, void* stream) {
+// ld_ri: floats between two rows of ri (>= 2F; the DFT product may have padded its output rows to a multiple of 4 floats)
+ams_status ams_cplx_mag_phase(const float* ri, float* mag, float* phasor, long rows, int F, long ld_ri, void* stream) {
     AMS_REQUIRE(ri && mag && rows > 0 && F > 0);
-    hipLaunchKernelGGL(cplx_mag_phase_kernel, dim3(blocks_for(rows * F)), dim3(256), 0, (hipStream_t)stream, ri, mag, phasor, rows, F);
+    hipLaunchKernelGGL(cplx_mag_phase_kernel, dim3(blocks_for(rows * F)), dim3(256), 0, (hipStream_t)stream, ri, mag, phasor, rows, F, ld_ri);
     return ams_check_launch();
 }
 

@@ -327,7 +327,9 @@ ams_status ams_overlap_metric_fwd(const float* y, float* out, int B, int S, long
 ams_status ams_overlap_metric_bwd(const float* y, const float* upstream, float* dy, int B, int S, long TN, void* stream);
 
 /* ---- K6/K7/K21 complex glue around the DFT products   models/network.py:497-499, 589-596 ---- */
-ams_status ams_cplx_mag_phase(const float* ri, float* mag, float* phasor, long rows, int F, void* stream);
+/* ri [rows, ld_ri] = [Re(F) | Im(F) | padding]: ld_ri >= 2F floats between rows (the DFT product pads its output rows to a multiple of 4
+   floats so that it stays on the 16-byte fetch path: F = W/2 + 1 is odd) */
+ams_status ams_cplx_mag_phase(const float* ri, float* mag, float* phasor, long rows, int F, long ld_ri, void* stream);
 ams_status ams_cplx_apply_fwd(const float* sep, const float* phasor, float* z, long rows, int F, int S, int T, void* stream);
 ams_status ams_cplx_apply_bwd(const float* dz, const float* phasor, float* dsep, long rows, int F, int S, int T, void* stream);
 
