@@ -45,6 +45,9 @@
 #ifndef AMS_RING_FWD_SLEEP
 #define AMS_RING_FWD_SLEEP 0
 #endif
+#ifndef AMS_RING_FWD_STORE_LATE
+#define AMS_RING_FWD_STORE_LATE 1      // 1: the stores only the backward pass needs are issued one step later, right behind the NEXT wait
+#endif
 #ifndef AMS_RING_BWD_SLEEP
 #define AMS_RING_BWD_SLEEP 0
 #endif
@@ -354,6 +357,10 @@ __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
 
     Trace tr;
     tr.begin(reinterpret_cast<unsigned long long*>(a.err) + 8, a.trace && chain == 0 && w == 0 && tid == 0);
+#if AMS_RING_FWD_STORE_LATE
+    float pend_v[7] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    int pend_t = -1;
+#endif
     for (int s = 0; s < T; ++s) {
         const int t = dir ? (T - 1 - s) : s;
         const int par = s & 1;
@@ -387,6 +394,13 @@ __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
                 }
             }
             tr.stamp(0);                                        // wait for h_{s-1}
+#if AMS_RING_FWD_STORE_LATE
+            if (live && pend_t >= 0) {
+                float* gr = gp + pend_t * gst;
+                gr[0 * H] = pend_v[0]; gr[1 * H] = pend_v[1]; gr[2 * H] = pend_v[2]; gr[3 * H] = pend_v[3];
+                cp[pend_t * cst_st] = pend_v[4]; tp_[pend_t * cst_st] = pend_v[5]; op[pend_t * cst_st] = pend_v[6];
+            }
+#endif
 #if !AMS_RING_FWD_FETCH_LATE
             {
                 const float* gn = gp + min(max(dir ? t - 1 : t + 1, 0), T - 1) * gst;
@@ -498,8 +512,12 @@ __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
         if (ul < UW && ul % 3 == 0)
             st16(rs, xb, (unsigned)(((par * TB + row) * NG) + w * 4 + ul / 3) * 16u, make_float4(h, h1, h2, __uint_as_float((unsigned)(s + 1))), fast);
         tr.stamp(3);                                            // gate epilogue up to the granule store
-        // what the backward pass needs -- issued behind the publish: these stores overlap the hand-off's transit (measured: moving
-        // them beside the next MFMA chain instead lengthened the step by 0.26 us)
+        // what the backward pass needs: kept in registers and stored one step later, right behind the NEXT wait (AMS_RING_FWD_STORE_LATE):
+        // vmcnt counts loads and stores together, so seven scattered stores issued here sit in front of the poll that follows (round 4:
+        // 4343 -> 4221 cycles per step; in round 2, with the 2300-cycle f32 MFMA chain, the same move had cost 0.26 us)
+#if AMS_RING_FWD_STORE_LATE
+        pend_v[0] = ig; pend_v[1] = gg; pend_v[2] = fg; pend_v[3] = og; pend_v[4] = c; pend_v[5] = tc; pend_v[6] = h; pend_t = t;
+#else
         if (live) {
             float* gr = gp + t * gst;
             gr[0 * H] = ig;
@@ -510,6 +528,7 @@ __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
             tp_[t * cst_st] = tc;
             op[t * cst_st] = h;
         }
+#endif
 #if AMS_RING_FWD_FETCH_LATE
         {
             const float* gn = gp + min(max(dir ? t - 1 : t + 1, 0), T - 1) * gst;
@@ -521,6 +540,13 @@ __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
         for (int g = 0; g < 4; ++g) zq[g] = zn[g];
         tr.stamp(4);                                            // G / cst / tanh(c) / out stores
     }
+#if AMS_RING_FWD_STORE_LATE
+    if (live && pend_t >= 0) {
+        float* gr = gp + pend_t * gst;
+        gr[0 * H] = pend_v[0]; gr[1 * H] = pend_v[1]; gr[2 * H] = pend_v[2]; gr[3 * H] = pend_v[3];
+        cp[pend_t * cst_st] = pend_v[4]; tp_[pend_t * cst_st] = pend_v[5]; op[pend_t * cst_st] = pend_v[6];
+    }
+#endif
     tr.end();
 }
 

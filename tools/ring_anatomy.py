@@ -24,7 +24,7 @@ Gz = torch.empty_like(G)
 ops.gemm(x.view(B * T, D), ops.blstm_wcat(Kf, Kb, D), bias=torch.cat([bf, bb]), out=Gz, M=B * T, N=8 * H, K=D, lda=D, ldb=8 * H, ldc=8 * H)
 ldu = Kf.stride(0)
 _AU = ops.absmax(torch.cat([Kf[D:], Kb[D:]]))                                              # bound of the recurrent kernels
-AU = _AU.data_ptr() if os.environ.get('AMS_ANATOMY_BWD_F16', '1') != '0' else None
+AU = _AU.data_ptr() if os.environ.get('AMS_ANATOMY_F16', '1') != '0' else None
 p = lambda t: t.data_ptr()                                                                  # noqa: E731
 st = torch.cuda.current_stream().cuda_stream
 names = {'fwd': ['wait for h', 'MFMA + acc to LDS', 'barrier', 'gate epilogue + granule store', 'G/cst/out stores'],
@@ -36,7 +36,7 @@ for mode, safe in (('plain stores (same L2)', 2), ('write-through', 3)):
         G.copy_(G0 if kind == 'bwd' else Gz)
         torch.cuda.synchronize()
         if kind == 'fwd':
-            ops.check(lib.ams_blstm_ring_fwd(p(G), p(out), p(cst[0]), p(cst[1]), p(Kf[D:]), p(Kb[D:]), ldu, None, p(sync), n, None, B, T, H, safe, st), 'f')
+            ops.check(lib.ams_blstm_ring_fwd(p(G), p(out), p(cst[0]), p(cst[1]), p(Kf[D:]), p(Kb[D:]), ldu, AU, p(sync), n, None, B, T, H, safe, st), 'f')
         else:
             ops.check(lib.ams_blstm_ring_bwd(p(G), p(cst[0]), p(cst[1]), p(dout), None, p(Kf[D:]), p(Kb[D:]), ldu, AU, p(sync), n, None, B, T, H, safe, st), 'b')
         torch.cuda.synchronize()
@@ -67,7 +67,7 @@ if '--beside' in sys.argv:
             if kind == 'bwd':
                 ops.check(lib.ams_blstm_ring_bwd(p(G), p(cst[0]), p(cst[1]), p(dout), None, p(Kf[D:]), p(Kb[D:]), ldu, AU, p(sync), n, None, B, T, H, 2, st), 'b')
             else:
-                ops.check(lib.ams_blstm_ring_fwd(p(G), p(out), p(cst[0]), p(cst[1]), p(Kf[D:]), p(Kb[D:]), ldu, None, p(sync), n, None, B, T, H, 2, st), 'f')
+                ops.check(lib.ams_blstm_ring_fwd(p(G), p(out), p(cst[0]), p(cst[1]), p(Kf[D:]), p(Kb[D:]), ldu, AU, p(sync), n, None, B, T, H, 2, st), 'f')
             e1.record()
             torch.cuda.synchronize()
             w = sync[:64].view(torch.int64).cpu().numpy()
