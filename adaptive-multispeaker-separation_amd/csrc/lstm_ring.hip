@@ -508,7 +508,10 @@ __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
         const float h = live ? tc * og : 0.f;                         // dead rows / units publish zeros
         c_state = c;
         // hand h_s to the ring first: lanes ul = 0, 3, 6, 9 assemble {h[ul], h[ul+1], h[ul+2], tag}
-        const float h1 = __shfl_down(h, 1, 64), h2 = __shfl_down(h, 2, 64);
+        // h of the next two lanes of this 16-lane row: DPP row shifts on the VALU (the ds_bpermute form of __shfl_down goes through the LDS
+        // crossbar: two more round trips on the hand-off's critical path)
+        const float h1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(h), 0x101, 0xf, 0xf, true));     // row_shl:1
+        const float h2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(h), 0x102, 0xf, 0xf, true));     // row_shl:2
         if (ul < UW && ul % 3 == 0)
             st16(rs, xb, (unsigned)(((par * TB + row) * NG) + w * 4 + ul / 3) * 16u, make_float4(h, h1, h2, __uint_as_float((unsigned)(s + 1))), fast);
         tr.stamp(3);                                            // gate epilogue up to the granule store
