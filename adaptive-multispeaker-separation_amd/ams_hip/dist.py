@@ -23,7 +23,14 @@ class Dist(object):
                 # AMS_DIST_BACKEND=gloo lets several ranks share ONE GPU (plumbing tests on a 1-GPU box; RCCL refuses that)
                 backend = os.environ.get('AMS_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
             if torch.cuda.is_available():
-                self.local_rank %= max(1, torch.cuda.device_count())
+                ndev = max(1, torch.cuda.device_count())
+                if int(os.environ.get('LOCAL_WORLD_SIZE', self.world_size)) > ndev and os.environ.get('AMS_LSTM_RING') is None:
+                    # several ranks time-share one GPU (plumbing tests on a 1-GPU box): the ring recurrence needs every workgroup of a
+                    # launch resident at once, which two processes' kernels on the same CUs cannot promise each other (measured: 2 of
+                    # 6 two-rank runs gave up a bounded wait) -- such ranks take the per-step recurrence kernels
+                    from . import ops
+                    ops.LSTM_RING = '0'
+                self.local_rank %= ndev
                 torch.cuda.set_device(self.local_rank)
             td.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
 

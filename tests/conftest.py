@@ -10,3 +10,24 @@ for p in (ROOT, PKG):
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+import pytest
+
+
+@pytest.fixture(autouse=True)
+def _release_captured_graphs(request):
+    """After every GPU test: collect the models the test built.  A captured step (models/network.py::_train_graphed) sits in a reference
+    cycle with its model, so its hipGraphExec -- and the internal streams the HIP runtime gave it -- lived until some later collection;
+    with enough of them alive, hipGraphLaunch of a NEW graph crashed inside the runtime (hip::Graph::UpdateStreams, ROCm 7.2) late in
+    the suite.  Collecting per test keeps at most one test's graphs alive."""
+    yield
+    if request.node.get_closest_marker('gpu') is not None:
+        import gc
+        gc.collect()
+        try:
+            import torch
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+        except ImportError:
+            pass
