@@ -282,6 +282,8 @@ class TFDataset(object):
         key = (split, b % self.pool_batches, L)
         if key not in self.pool:
             mix, non_mix, ind = synthetic_mixtures(self._batch_indices(split, b % self.pool_batches), self.S, L)
-            self.pool[key] = (torch.from_numpy(mix).to(self.device), torch.from_numpy(non_mix).to(self.device),
-                              torch.from_numpy(ind).to(self.device))
+            # mixtures and sources back to back in ONE device buffer: a captured step then stages a batch with one copy instead of two
+            # (models/network.py::_train_graphed)
+            flat = torch.from_numpy(np.concatenate([mix.ravel(), non_mix.ravel()])).to(self.device)
+            self.pool[key] = (flat[:mix.size].view(mix.shape), flat[mix.size:].view(non_mix.shape), torch.from_numpy(ind).to(self.device))
         return self.pool[key]

@@ -251,6 +251,12 @@ class Network(object):
         return [n.value(probe) for n in (self.x_mix, self.x_non_mix, self.I)]
 
     @staticmethod
+    def _back_to_back(a, b):
+        return (a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.device == b.device and
+                a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and
+                a.data_ptr() + a.numel() * a.element_size() == b.data_ptr())
+
+    @staticmethod
     def _static_like(ins):
         """Static input buffers of a captured step: x_mix [B,L] and x_non_mix [B,S,L] back to back in one buffer (Adapt's
         concat([x_mix, x_non_mix rows]) is then a view), the rest cloned."""
@@ -303,7 +309,13 @@ class Network(object):
                 self._backward(cost)
                 F.OVERLAP.join()
             st['graph'], st['cost'], st['run'] = g, cost, run
-        for dst, src in zip(st['static'], ins):
+        pairs = list(zip(st['static'], ins))
+        if self._back_to_back(st['static'][0], st['static'][1]) and self._back_to_back(ins[0], ins[1]):
+            # x_mix and x_non_mix adjacent on both sides (_static_like; the synthetic pool stores them so): one copy
+            n = ins[0].numel() + ins[1].numel()
+            torch.as_strided(st['static'][0], (n,), (1,)).copy_(torch.as_strided(ins[0], (n,), (1,)))
+            pairs = pairs[2:]
+        for dst, src in pairs:
             dst.copy_(src)
         for hook in get_default_graph().pre_replay_hooks:      # host-drawn inputs of captured kernels (k-means seeds)
             hook()
