@@ -234,11 +234,15 @@ def test_front_dpcl_step_at_benchmark_shape(hip_graph, arith, gemm_arith, monkey
     assert max(v for k, v in errs.items() if k.startswith('update ')) < 1e-5, worst
 
 
-def test_ring_recurrence_is_bit_stable_under_uneven_load(ops):
-    """The in-launch hand-off of csrc/lstm_ring.hip (plain stores through the chain's L2 + L1-bypassing loads, tags / flags) must
+@pytest.mark.parametrize('arith', ['fp16x3', 'bf16x6_f32'])
+def test_ring_recurrence_is_bit_stable_under_uneven_load(ops, arith):
+    """The in-launch hand-off of csrc/lstm_ring.hip (plain stores through the chain's L2 + L1-bypassing loads; granule tags forward,
+    phase bits in the partial tiles backward) must
     not depend on what else the chip is doing: a stale or torn read would change bits.  One BLSTM layer at the benchmark shape,
     forward + BPTT, 12 times while a second stream keeps the CUs busy with large products (uneven: the load starts and stops at
     random points of the recurrence) -- every repetition must reproduce the idle run bit for bit, and no bounded wait may time out.
+    arith: 'fp16x3' = both rings with the kernels' bound, as a training step runs them (forward fp16x3, backward fp16x3 with one scale
+    per batch row); 'bf16x6_f32' = no bounds (forward bf16x6, backward on the f32 MFMAs).
     The side products are launched the way the product launches EVERYTHING that runs beside a ring (ams_hip/functional.py: side
     stream, residency cap): a ring needs all its workgroups resident at once, and an uncapped bf16x6 product (8 waves x ~230
     VGPRs, one workgroup per CU) admits no ring workgroup on a CU it occupies -- with several of those queued the ring's bounded
@@ -254,9 +258,12 @@ def test_ring_recurrence_is_bit_stable_under_uneven_load(ops):
     from ams_hip._lib import load
     lib = load()
 
+    bound_w = torch.maximum(ops.absmax(Kf), ops.absmax(Kb)) if arith == 'fp16x3' else None
+    bound_x = ops.absmax(x) if arith == 'fp16x3' else None
+
     def layer():
-        out, G, cst = ops.blstm_fwd(x, Kf, bf, Kb, bb)
-        grads = ops.blstm_bwd(x, Kf, Kb, out, G, cst, dout)
+        out, G, cst = ops.blstm_fwd(x, Kf, bf, Kb, bb, amax=(bound_x, bound_w) if bound_w is not None else None)
+        grads = ops.blstm_bwd(x, Kf, Kb, out, G, cst, dout, amax_u=bound_w)
         return [out] + list(grads)
     ref = [t.clone() for t in layer()]
     torch.cuda.synchronize()
