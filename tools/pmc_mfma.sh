@@ -3,6 +3,7 @@
 #   MfmaUtil = SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE x 256 CUs x 4 SIMDs), MFMA ops by input type.
 # usage (on the GPU box): bash tools/pmc_mfma.sh   -> gpurun_out/mfma_util.{txt,json}
 R=${GRAFT_REPO_ROOT:-/root/repo}
+export AMS_COMMIT=${AMS_COMMIT:-$(cat $R/.ams_commit 2>/dev/null || echo unknown)}
 cd /tmp && export TMPDIR=/tmp
 CMD="python $R/bench.py --no-cpu-baseline --no-secondary --no-native-f32 --graph 0 --steps 3 --warmup 2 --roofline-steps 1 --quiet"
 rm -rf /tmp/pmc_mfma

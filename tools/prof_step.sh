@@ -2,6 +2,7 @@
 # kernel trace of the default bench + per-step timeline.  TAG=<suffix> names the outputs (gpurun_out/kernel_stats<TAG>.txt, ...);
 # environment variables of the caller (AMS_*) reach the bench.
 R=${GRAFT_REPO_ROOT:-/root/repo}
+export AMS_COMMIT=${AMS_COMMIT:-$(cat $R/.ams_commit 2>/dev/null || echo unknown)}
 T=${TAG:-}
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof -o run -- python $R/bench.py --no-cpu-baseline --no-secondary --no-native-f32 --quiet > $R/gpurun_out/prof_bench$T.log 2>&1
