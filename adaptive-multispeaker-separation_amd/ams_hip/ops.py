@@ -120,6 +120,26 @@ def _ws(nbytes, like):
     return torch.empty((n + 3) // 4, dtype=torch.float32, device=like.device)
 
 
+_SK = {}
+SK = _os.environ.get('AMS_GEMM_SK', '1') != '0'
+
+
+def _sk(like):
+    """(pointer, bytes) of the stream-K scratch of the current stream (include/ams.h: sk_scratch): one persistent buffer per device and
+    stream -- launches that share one must be stream-ordered --, flags zeroed once (every launch leaves them zero)."""
+    if not SK or not like.is_cuda:
+        return _vp(0), 0
+    cur = torch.cuda.current_stream()
+    k = (like.device.index, cur.cuda_stream)
+    t = _SK.get(k)
+    if t is None:
+        n = int(load().ams_gemm_sk_scratch_bytes())
+        t = torch.empty((n + 3) // 4, dtype=torch.float32, device=like.device)
+        t[:1024].zero_()
+        _SK[k] = t
+    return _vp(t.data_ptr()), t.numel() * 4
+
+
 # ------------------------------------------------------------------ front
 def front_filter(w, bases):
     _chk(w, bases)
@@ -137,7 +157,8 @@ def front_filter_bwd(w, bases, df):
     return dw, db
 
 
-def front_conv(x, f, hop):
+def front_conv(x, f, hop, amax=None, measure=False):
+    """amax = (bound of x, bound of f): fp16x3.  measure: the launch also leaves max |y| (tagged on y for the next product)."""
     _chk(x, f)
     Bt, L = x.shape
     W, N = f.shape
@@ -146,9 +167,16 @@ def front_conv(x, f, hop):
     lib = load()
     nb = lib.ams_front_conv_fwd_workspace_bytes(Bt, L, W, N, hop)
     ws = _ws(nb, x) if nb else None
+    ay = None
+    if measure and F16X3 and lib.ams_front_conv_fwd_measures_output():
+        ay = torch.empty(1, dtype=torch.float32, device=x.device)
     ev = PROFILE.begin() if PROFILE.enabled else None
-    check(lib.ams_front_conv_fwd(_p(x), _p(f), _p(y), Bt, L, W, N, hop, LDS_PAD[0], _p(ws), nb, _s()),
+    pa, pb, _ = _bounds(amax)
+    skp, skn = _sk(x)
+    check(lib.ams_front_conv_fwd(_p(x), _p(f), _p(y), Bt, L, W, N, hop, pa, pb, _p(ay), 0, _p(ws), nb, skp, skn, _s()),
           'ams_front_conv_fwd')
+    if ay is not None:
+        tag_amax(y, ay)
     if ev is not None:      # algorithmic bytes: waveform in, frames out, filter once
         PROFILE.end(ev, 2.0 * Bt * T * N * W, 4.0 * (Bt * L + Bt * T * N + W * N), 'gemm<2,0>', 'front_conv')
     return y
@@ -479,8 +507,9 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False
     ws = _ws(nb, A) if nb else None
     ev = PROFILE.begin() if PROFILE.enabled else None
     pa, pb, gt = _bounds(amax)
+    skp, skn = _sk(A)
     check(lib.ams_gemm_f32(int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc, _p(bias), int(accumulate),
-                           mask[0], mask[1], pa, pb, pad, _p(ws), nb, _s()), 'ams_gemm_f32')
+                           mask[0], mask[1], pa, pb, pad, _p(ws), nb, skp, skn, _s()), 'ams_gemm_f32')
     if ev is not None:
         PROFILE.end(ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N), gt + '<%d,%d>' % (int(bool(transA)), int(bool(transB))), label)
     return out
@@ -504,8 +533,9 @@ def gemm_at_b_colsum(A, B, out, bsum, accumulate=True, amax=None, ldc=None):
     bws = _ws(32 * N * 4, A)
     ev = PROFILE.begin() if PROFILE.enabled else None
     pa, pb, gt = _bounds(amax)
+    skp, skn = _sk(A)
     check(lib.ams_gemm_f32_at_b_colsum(M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(out), ldc, int(accumulate),
-                                       _p(bsum), int(accumulate), _p(bws), pa, pb, pad, _p(ws), nb, _s()),
+                                       _p(bsum), int(accumulate), _p(bws), pa, pb, pad, _p(ws), nb, skp, skn, _s()),
           'ams_gemm_f32_at_b_colsum')
     if ev is not None:
         PROFILE.end(ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N), gt + '<1,0>', '')
@@ -534,8 +564,9 @@ def gemm_batched(A, B, C, nbatch, a_zs, b_zs, c_zs, transA, transB, M, N, K, lda
     ws = _ws(nb, A) if nb else None
     ev = PROFILE.begin() if PROFILE.enabled else None
     pa, pb, gt = _bounds(amax)
+    skp, skn = _sk(A)
     check(lib.ams_gemm_f32_batched(int(transA), int(transB), M, N, K, _p(A), lda, a_zs, _p(B), ldb, b_zs, _p(C), ldc, c_zs, nbatch,
-                                   int(accumulate), mask[0], mask[1], pa, pb, pad, _p(ws), nb, _s()),
+                                   int(accumulate), mask[0], mask[1], pa, pb, pad, _p(ws), nb, skp, skn, _s()),
           'ams_gemm_f32_batched')
     if ev is not None:
         PROFILE.end(ev, nbatch * 2.0 * M * N * K, nbatch * 4.0 * (M * K + K * N + M * N), gt + '<%d,%d>' % (int(bool(transA)), int(bool(transB))))

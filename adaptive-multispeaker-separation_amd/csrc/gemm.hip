@@ -26,15 +26,22 @@ namespace {
 //   amax_a / amax_b: device pointers to upper bounds of max|A|, max|B| (both set -> fp16x3 arithmetic)
 //   lds_pad: residency cap of a launch that is meant to run BESIDE a latency-critical kernel (unused dynamic LDS limits how many
 //            of these workgroups a CU admits); 0 = uncapped, critical-path launch
-struct LaunchOpt { const float* amax_a = nullptr; const float* amax_b = nullptr; int lds_pad = 0; };
+//   sk_scratch / sk_bytes: stream-K scratch of the caller (ams_gemm_sk_scratch_bytes(); first AMS_SK_FLAG_BYTES zero on entry, left zero;
+//            launches that share it must be ordered on one stream); NULL = no stream-K
+//   amax_out: the launch leaves max |C| there (bit pattern; the caller zeroes it)
+struct LaunchOpt { const float* amax_a = nullptr; const float* amax_b = nullptr; int lds_pad = 0; void* sk_scratch = nullptr; size_t sk_bytes = 0;
+                   unsigned* amax_out = nullptr; int force_cfg = -1; };
+constexpr size_t AMS_SK_FLAG_BYTES = 4096;       // 1024 workgroup flags
+constexpr size_t AMS_SK_SLOT_BYTES = (128 * 256 + 256) * sizeof(float);     // the largest tile (128 x 256) + its column sums
 std::atomic<int> g_gemm_arith{-1};        // -1: not chosen yet (AMS_GEMM_X6, default 1), 0: native f32 MFMA, 1: bf16x6
 
 // Tuning overrides (A/B runs only): read from the environment ONCE per process, never on the launch path.
-struct GemmTuning { int group_m, splits, x6cfg, x6rule, x6persist; bool noprio, novec, f16x3; double x6waste; };
+struct GemmTuning { int group_m, splits, x6cfg, x6rule, x6persist, sk; bool noprio, novec, f16x3; double x6waste; bool c_vec; };
 inline const GemmTuning& tuning() {
     static const GemmTuning t = [] {
-        GemmTuning v{0, 0, -1, 2, false, false};
-        v.x6waste = 1.30;
+        GemmTuning v{0, 0, -1, 2, 1, 1, false, false, true, 1.30, true};
+        if (const char* f = getenv("AMS_GEMM_CVEC")) v.c_vec = atoi(f) != 0;    // 0: the x6 epilogue stores columns as the MFMA leaves them (dword stores)
+        if (const char* f = getenv("AMS_GEMM_SK")) v.sk = atoi(f);        // stream-K: 0 off, 1 the tail of multi-round launches where the cost model prefers it (default), 2 wherever it applies
         if (const char* f = getenv("AMS_GEMM_X6WASTE")) v.x6waste = atof(f);
         if (const char* f = getenv("AMS_GEMM_GROUP_M")) v.group_m = atoi(f);
         if (const char* f = getenv("AMS_GEMM_SPLITS")) v.splits = atoi(f);
@@ -117,6 +124,12 @@ struct GemmArgs {
     // fp16x3 arithmetic: device pointers to an upper bound of max|A|, max|B| over the WHOLE operand tensors (all batches); the kernel
     // derives the power-of-two operand scales from them
     const float* amax_a; const float* amax_b;
+    // stream-K (x6 kernels, splits == 1): sk_rounds >= 0 -> every workgroup runs sk_rounds whole tiles, then its share of the k-tiles of
+    // the tiles that are left (x6_body); sk_flags [gridDim.x] ints (zero on entry, left zero), sk_slots gridDim.x partial-tile slots of
+    // sk_slot_floats floats each
+    int sk_rounds; int* sk_flags; float* sk_slots; int sk_slot_floats;
+    int c_vec;                 // C (and the partial slabs, bias) are 16-byte addressable along n: the x6 epilogue stores rows as float4 through LDS
+    unsigned* amax_out;        // != NULL: atomicMax of the bit patterns of |C| as stored (one atomic per workgroup and tile)
 };
 
 template <int AMODE>
@@ -177,6 +190,30 @@ __device__ __forceinline__ void locate_tile(GemmArgs& g, int& split, int& tile_m
         if (g.partial) g.partial += z * (long)g.splits * g.M * g.N;
     }
     const int GROUP_M = g.group_m > 0 ? g.group_m : 1;        // chosen per launch (choose_group_m)
+    const int band = bid / (GROUP_M * tiles_n), within = bid - band * (GROUP_M * tiles_n);
+    const int band_rows = min(GROUP_M, tiles_m - band * GROUP_M);
+    tile_n = within / band_rows;
+    tile_m = band * GROUP_M + (within - tile_n * band_rows);
+}
+
+// Position `pos` of the flat (batch, split, tile) order -> tile; the second half of locate_tile for callers that enumerate positions
+// themselves (stream-K).  XCD x owns the positions [xcd_start(x), xcd_start(x) + xcd_len(x)).
+__device__ __forceinline__ int xcd_len(int items, int x) { return items / 8 + (x < items % 8 ? 1 : 0); }
+__device__ __forceinline__ int xcd_start(int items, int x) { const int q = items / 8, r = items % 8; return x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q; }
+__device__ __forceinline__ void locate_pos(GemmArgs& g, int pos, int& split, int& tile_m, int& tile_n, int bm, int bn) {
+    const int tiles_m = (g.M + bm - 1) / bm, tiles_n = (g.N + bn - 1) / bn;
+    const int ntiles = tiles_m * tiles_n;
+    const int zb = pos / (ntiles * g.splits);
+    pos -= zb * (ntiles * g.splits);
+    split = pos / ntiles;
+    const int bid = pos - split * ntiles;
+    if (g.nbatch > 1) {
+        const long z = zb;
+        g.A += z * g.a_zs; g.B += z * g.b_zs; g.C += z * g.c_zs;
+        if (g.bias) g.bias += z * g.bias_zs;
+        if (g.partial) g.partial += z * (long)g.splits * g.M * g.N;
+    }
+    const int GROUP_M = g.group_m > 0 ? g.group_m : 1;
     const int band = bid / (GROUP_M * tiles_n), within = bid - band * (GROUP_M * tiles_n);
     const int band_rows = min(GROUP_M, tiles_m - band * GROUP_M);
     tile_n = within / band_rows;
@@ -589,6 +626,9 @@ typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 
+#ifndef AMS_SK_CAPPED
+#define AMS_SK_CAPPED 0
+#endif
 #ifndef AMS_X6_DBG
 #define AMS_X6_DBG 0        // timing anatomy only (WRONG results): 1 no split arithmetic, 2 no LDS writes, 4 no MFMAs, 8 no LDS reads, 16 no fetch in the loop
 #endif
@@ -648,6 +688,28 @@ template <int R>
 __device__ __forceinline__ int x6_slot(int n) { return (n & 3) * (R / 4) + (((n >> 2) + 4 * (n & 3)) & (R / 4 - 1)); }
 __device__ __forceinline__ float comp4(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
 
+#ifndef AMS_X6_STAMP
+#define AMS_X6_STAMP 0       // 1: timing-anatomy build (tools/gemm_anatomy.py): thread 0 of every workgroup stamps the phases of its first 8 items
+#endif
+#if AMS_X6_STAMP
+__device__ long long g_x6_stamp[1024 * 8 * 8];
+#define X6_STAMP(ph) do { if (threadIdx.x == 0 && wi < 8) g_x6_stamp[((int)blockIdx.x * 8 + wi) * 8 + (ph)] = wall_clock64(); } while (0)
+#else
+#define X6_STAMP(ph) do { } while (0)
+#endif
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+// Raw buffer accesses with aux bit 16 = sc1: stores write through to the memory side, loads bypass this CU's L1 -- the publish form of
+// MI355X_MICROARCH.md ("publish-large": sc1 payload -> s_waitcnt vmcnt(0) -> agent-scope flag, sc1 loads on the reader)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t x6_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 ld16_sc1(__amdgpu_buffer_rsrc_t rs, unsigned off) {
+    return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rs, off, 0, 16));
+}
+__device__ __forceinline__ void st16_sc1(__amdgpu_buffer_rsrc_t rs, unsigned off, float4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4_t, v), rs, off, 0, 16);
+}
+
 template <int AMODE, int BMODE, int CFG, int EPI, bool SEP, bool F16>
 // PERSISTENT over work items (round 3): the grid is at most one resident set of workgroups (ams_gemm launch: 256 CUs x the
 // configuration's workgroups per CU) and a workgroup walks items blockIdx.x, + gridDim.x, ... .  The operands of the NEXT item's first
@@ -667,17 +729,62 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
     unsigned char* const Bs = smem + x6_oper(BMX);
     if (g.hiprio) __builtin_amdgcn_s_setprio(2);
 
-    const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // Lane constants are RE-DERIVED at the top of every work item from a thread id the compiler cannot see through (lane_consts):
+    // a workgroup that walks several items would otherwise keep ~30 loop-invariant registers (fragment addresses, LDS slots, block
+    // coordinates) alive across the epilogue and the stream-K hand-off of each item, which is where these kernels run out of registers.
+    int tid = threadIdx.x;
+    int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / C::WNC, wn = wave % C::WNC;
-    const int l31 = lane & 31, lk = lane >> 5;
+    int l31 = lane & 31, lk = lane >> 5;
 
-    // only the two-accumulator (uncapped, alone-on-the-CU) variants walk items: the capped single-accumulator ones are sized to sit
-    // beside a recurrence ring and the walk costs them 20-40 VGPRs (next item's staging registers live over the epilogue)
+    // only the two-accumulator (uncapped, alone-on-the-CU) variants request the NEXT work item's first k-tile before the stores of the
+    // finished one: the capped single-accumulator ones are sized to sit beside a recurrence ring and that costs them
+    // 20-40 VGPRs (next item's staging registers live over the epilogue); they fetch it after their stores.
     constexpr bool PERSIST = SEP && EPI == EPI_STORE;
     const int n_items = (int)((long)((g0.M + BMX - 1) / BMX) * ((g0.N + BNX - 1) / BNX) * g0.splits * (g0.nbatch > 1 ? g0.nbatch : 1));
-    int vbid = blockIdx.x;
     int split, tile_m, tile_n, m0, n0, k_begin, k_end, nk;
+
+    // ---- the work list of this workgroup.  Plain launches: items blockIdx.x, + gridDim.x, ... (one item when not PERSIST).
+    // STREAM-K (g0.sk_rounds >= 0; splits == 1, gridDim.x a multiple of 8): sk_rounds whole tiles like that, and then the tiles that
+    // do not fill another round are shared BY K-TILE: XCD x (workgroups x, x + 8, ...: Gx of them) owns n_x left-over positions of the
+    // flat order (its run minus the sk_rounds * Gx whole tiles it has done), U = n_x * nk k-tile units, and its workgroup w takes
+    // the units [w U / Gx, (w + 1) U / Gx) -- less than one tile's worth, so at most the tail of one tile and the head of the next.
+    // A segment that ends where its tile ends makes its workgroup the tile's OWNER: it adds the partial tiles the earlier
+    // segments' workgroups left in their slots (fixed order: deterministic) and runs the epilogue; every other segment is a
+    // PARTIAL: accumulators to the workgroup's slot as write-through stores, then a flag.  A workgroup runs its partial segment
+    // FIRST and never waits before it has published, and an owner only waits for workgroups with a lower index on its own XCD.
+    enum { W_FULL = 0, W_PART = 1, W_OWNER = 2 };
+    // The capped single-accumulator variants take ONE item and no stream-K share unless built with -DAMS_SK_CAPPED=1: the walk and the
+    // hand-off cost them ~40 VGPRs, and above 168 they no longer share a CU with a recurrence ring.
+    constexpr bool WALK = PERSIST || (AMS_SK_CAPPED && EPI == EPI_STORE);
+    const bool sk = WALK && g0.sk_rounds >= 0;
+    const int nk_full = (g0.K + BK - 1) / BK;
+    const int G = (int)gridDim.x;
+    const int sk_x = (int)blockIdx.x & 7, sk_w = (int)blockIdx.x >> 3, sk_Gx = G >> 3;
+    int sk_U = 0, sk_base = 0;
+    // segment A: tail of tile segA_t, k-tiles [segA_k0, segA_k1) (owner / whole tile, or a partial when the range stays inside one tile);
+    // segment B: head of tile segA_t + 1, k-tiles [0, segB_k1): always a partial, run first
+    int segA_t = 0, segA_k0 = 0, segA_k1 = 0, segA_role = W_FULL, segB_k1 = 0;
+    int nseg = 0;
+    int dp_count = 1;
+    if (sk) {
+        dp_count = g0.sk_rounds;
+        sk_base = xcd_start(n_items, sk_x) + dp_count * sk_Gx;
+        sk_U = (xcd_len(n_items, sk_x) - dp_count * sk_Gx) * nk_full;
+        const int u0 = sk_w * sk_U / sk_Gx, u1 = (sk_w + 1) * sk_U / sk_Gx;
+        if (u1 > u0) {
+            const int t0 = u0 / nk_full, ka = u0 - t0 * nk_full;
+            const int e1 = min(u1 - t0 * nk_full, nk_full), e2 = u1 - (t0 + 1) * nk_full;
+            segA_t = t0; segA_k0 = ka; segA_k1 = e1;
+            segA_role = e1 == nk_full ? (ka == 0 ? W_FULL : W_OWNER) : W_PART;
+            segB_k1 = e2 > 0 ? e2 : 0;                  // (< nk_full: a range is shorter than a tile or aligned with one)
+            nseg = e2 > 0 ? 2 : 1;
+        }
+    } else if (PERSIST) dp_count = (n_items - (int)blockIdx.x + G - 1) / G;
+    const int n_work = dp_count + nseg;
+    if (n_work <= 0) return;
+    int role = W_FULL, own_tile = 0;
 
     // SEP: two accumulator sets (64 x 64 waves, launches that are not residency-capped -- with 64 more VGPRs a workgroup no longer
     // shares a CU with a recurrence ring): hi.hi goes to `acc`, the five small partial products to `accs`, added once in the epilogue.  The bf16 MFMA adds its 16 products to the accumulator with the bits below its internal
@@ -691,20 +798,30 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
     // k-group tid & 3, two float4 per slot.  m/n-contiguous source: 4 (k) x 4 (m) blocks, R / 4 x 8 of them, thread -> block
     // (tid % (R / 4), tid / (R / 4)) while tid < R * 2, four float4.  Either way at most four float4 per thread and operand.
     constexpr int NSA = BMX * 4 / NT, NSB = BNX * 4 / NT;          // k-contiguous slots per thread (1 or 2)
-    const int kgrp = tid & 3, krow = tid >> 2;
-    const int mbA = tid % (BMX / 4), kbA = tid / (BMX / 4);
-    const int mbB = tid % (BNX / 4), kbB = tid / (BNX / 4);
-    const bool actA = AK || tid < BMX * 2, actB = BKc || tid < BNX * 2;     // wave-uniform (multiples of 64)
+    int kgrp = tid & 3, krow = tid >> 2;
+    int mbA = tid % (BMX / 4), kbA = tid / (BMX / 4);
+    int mbB = tid % (BNX / 4), kbB = tid / (BNX / 4);
+    bool actA = AK || tid < BMX * 2, actB = BKc || tid < BNX * 2;     // wave-uniform (multiples of 64)
     long arow[2] = {0, 0};
     int fp0[2] = {0, 0};
     long brow[2] = {0, 0};
-    // per-item state: (batch, split, tile) of virtual block `id`, operand row pointers
-    auto setup = [&](int id) {
+    // per-item state of work item i of this workgroup: (batch, split, tile), k range, role, operand row pointers
+    auto setup = [&](int i) {
         g = g0;
-        locate_tile(g, split, tile_m, tile_n, BMX, BNX, id);
+        if (i < dp_count) {
+            locate_tile(g, split, tile_m, tile_n, BMX, BNX, (int)blockIdx.x + i * G);
+            role = W_FULL;
+            k_begin = split * g.k_per_split;
+            k_end = min(g.K, k_begin + g.k_per_split);
+        } else {
+            const bool headB = nseg == 2 && i == dp_count;              // the partial head of the next tile comes first
+            own_tile = headB ? segA_t + 1 : segA_t;
+            locate_pos(g, sk_base + own_tile, split, tile_m, tile_n, BMX, BNX);
+            role = headB ? W_PART : segA_role;
+            k_begin = (headB ? 0 : segA_k0) * BK;
+            k_end = min(g.K, (headB ? segB_k1 : segA_k1) * BK);
+        }
         m0 = tile_m * BMX; n0 = tile_n * BNX;
-        k_begin = split * g.k_per_split;
-        k_end = min(g.K, k_begin + g.k_per_split);
         nk = (k_end - k_begin + BK - 1) / BK;
         if (AMODE == A_ROW) {
 #pragma unroll
@@ -724,7 +841,8 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
             for (int h = 0; h < NSB; ++h) brow[h] = (long)min(n0 + krow + (NT / 4) * h, g.N - 1) * g.ldb;
         }
     };
-    setup(vbid);
+    int wi = 0;
+    setup(0);
 
     float4 ra[4], rb[4];
     bool va[4], vb[4];
@@ -842,8 +960,7 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
             if (!F16) *reinterpret_cast<uint2*>(p + 2 * PT) = lo;
         }
     };
-    const int sa0 = x6_slot<BMX>(4 * mbA), sa1 = x6_slot<BMX>(4 * mbA + 1), sa2 = x6_slot<BMX>(4 * mbA + 2), sa3 = x6_slot<BMX>(4 * mbA + 3);
-    const int sb0 = x6_slot<BNX>(4 * mbB), sb1 = x6_slot<BNX>(4 * mbB + 1), sb2 = x6_slot<BNX>(4 * mbB + 2), sb3 = x6_slot<BNX>(4 * mbB + 3);
+    int sa0, sa1, sa2, sa3, sb0, sb1, sb2, sb3;
     auto stash = [&]() {
         if (AK) stash_k(As, A_PLANE, A_PART, NSA, ra, va, sc_a);
         else if (actA) stash_m(As, A_PLANE, A_PART, kbA, sa0, sa1, sa2, sa3, ra, va, sc_a);
@@ -860,16 +977,27 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
     // MFMA operand addresses: lane l reads row (l & 31) of a 32-row tile, k-group 2 * kstep + (l >> 5)
     const unsigned char* ap[TM];
     const unsigned char* bp[TN];
+    auto lane_consts = [&]() {
+        int t = threadIdx.x;
+        asm volatile("" : "+v"(t));                  // opaque: nothing derived from it is loop-invariant to the compiler
+        tid = t; lane = t & 63; l31 = lane & 31; lk = lane >> 5;
+        kgrp = t & 3; krow = t >> 2;
+        mbA = t % (BMX / 4); kbA = t / (BMX / 4);
+        mbB = t % (BNX / 4); kbB = t / (BNX / 4);
+        actA = AK || __builtin_amdgcn_readfirstlane(t) < BMX * 2; actB = BKc || __builtin_amdgcn_readfirstlane(t) < BNX * 2;
+        sa0 = x6_slot<BMX>(4 * mbA); sa1 = x6_slot<BMX>(4 * mbA + 1); sa2 = x6_slot<BMX>(4 * mbA + 2); sa3 = x6_slot<BMX>(4 * mbA + 3);
+        sb0 = x6_slot<BNX>(4 * mbB); sb1 = x6_slot<BNX>(4 * mbB + 1); sb2 = x6_slot<BNX>(4 * mbB + 2); sb3 = x6_slot<BNX>(4 * mbB + 3);
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-        const int ar = (wm * TM + i) * 32 + l31;
-        ap[i] = As + (AK ? ar : x6_slot<BMX>(ar)) * 16 + lk * A_PLANE;
-    }
+        for (int i = 0; i < TM; ++i) {
+            const int ar = (wm * TM + i) * 32 + l31;
+            ap[i] = As + (AK ? ar : x6_slot<BMX>(ar)) * 16 + lk * A_PLANE;
+        }
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int br = (wn * TN + j) * 32 + l31;
-        bp[j] = Bs + (BKc ? br : x6_slot<BNX>(br)) * 16 + lk * B_PLANE;
-    }
+        for (int j = 0; j < TN; ++j) {
+            const int br = (wn * TN + j) * 32 + l31;
+            bp[j] = Bs + (BKc ? br : x6_slot<BNX>(br)) * 16 + lk * B_PLANE;
+        }
+    };
     auto frag = [&](const unsigned char* p) {
         if (AMS_X6_DBG & 8) { const uint4 c = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; return __builtin_bit_cast(bf16x8_t, c); }
         return *reinterpret_cast<const bf16x8_t*>(p);
@@ -916,6 +1044,8 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
 
     fetch(0);
     for (;;) {                                      // one work item per trip; every branch below is workgroup-uniform
+        lane_consts();
+        X6_STAMP(0);
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -927,6 +1057,7 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
         stash();
         fetch(1);                                   // tiles past the split's end: clamped addresses, staged as zeros if ever used
         __syncthreads();
+        X6_STAMP(1);
         for (int kt = 0;; ++kt) {
             mfma_tile();                            // tile kt
             if (kt + 1 >= nk) break;
@@ -936,6 +1067,7 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
             __syncthreads();
         }
 
+        X6_STAMP(2);
         float4 bs_t = make_float4(0.f, 0.f, 0.f, 0.f);
         if (!BKc && do_bsum) {
             // thread (kb, mb) summed rows 4 kb .. 4 kb + 3 of every k-tile, columns 4 mb .. + 3: the 8 threads of a column group meet
@@ -949,15 +1081,6 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
 #pragma unroll
                 for (int j = 1; j < 8; ++j) { const float4 v = sbuf[tid + (BNX / 4) * j]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
                 bs_t = t;
-                const int n = n0 + tid * 4;
-                if (n < g.N) {
-                    if (g.splits > 1 || !g.bsum_out) *reinterpret_cast<float4*>(g.bsum_part + (long)split * g.N + n) = t;
-                    else {                          // one k-split: this workgroup holds the whole column sums -- no finishing launch
-                        float4* const po = reinterpret_cast<float4*>(g.bsum_out + n);
-                        if (g.bsum_accumulate) { const float4 o = *po; bs_t.x += o.x; bs_t.y += o.y; bs_t.z += o.z; bs_t.w += o.w; }
-                        *po = bs_t;
-                    }
-                }
             }
         }
         if (SEP) {
@@ -966,56 +1089,180 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] += accs[i][j];
         }
-        if constexpr (F16) {
+        const bool more = WALK && wi + 1 < n_work;
+        const int cur_role = WALK ? role : W_FULL;
+        // stream-K slots: the accumulators in FRAGMENT order (lane l's float4 q of MFMA tile (i, j) of wave w at
+        // ((w TM TN + i TN + j) 4 + q) KB + 16 l: 64 lanes move 1 KB contiguous), then BNX column sums
+        constexpr unsigned TILE_B = (unsigned)BMX * BNX * 4u;
+        const unsigned loff = (unsigned)(wave * TM * TN * 4) * 1024u + (unsigned)lane * 16u;
+        if (EPI == EPI_STORE && cur_role == W_OWNER) {
+            // OWNER: the workgroups sk_w - 1, sk_w - 2, ... whose unit ranges reach into this tile hold its earlier k ranges
+            const int tile_start = own_tile * nk_full;
+            if (tid == 0) {
+                for (int wp = sk_w - 1; wp >= 0 && (wp + 1) * sk_U / sk_Gx > tile_start; --wp) {
+                    const int* const f = g0.sk_flags + (wp * 8 + sk_x);
+                    int spins = 0;
+                    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+                        __builtin_amdgcn_s_sleep(2);
+                        if (++spins > (1 << 26)) __builtin_trap();      // seconds: the producer is gone -- fail loudly, never continue with a hole
+                    }
+                }
+            }
+            __syncthreads();
+            for (int wp = sk_w - 1; wp >= 0 && (wp + 1) * sk_U / sk_Gx > tile_start; --wp) {
+                const int src = wp * 8 + sk_x;
+                const __amdgpu_buffer_rsrc_t rs = x6_rsrc(g0.sk_slots + (long)src * g0.sk_slot_floats, (unsigned)g0.sk_slot_floats * 4u);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j) acc[i][j] *= sc_inv;
+                    for (int j = 0; j < TN; ++j) {
+                        float4 v[4];
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = ld16_sc1(rs, loff + (unsigned)((i * TN + j) * 4 + q) * 1024u);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            acc[i][j][4 * q] += v[q].x; acc[i][j][4 * q + 1] += v[q].y;
+                            acc[i][j][4 * q + 2] += v[q].z; acc[i][j][4 * q + 3] += v[q].w;
+                        }
+                    }
+                if (!BKc && g0.bsum_part != nullptr && tid < BNX / 4) {
+                    const float4 t = ld16_sc1(rs, TILE_B + (unsigned)tid * 16u);
+                    bs_t.x += t.x; bs_t.y += t.y; bs_t.z += t.z; bs_t.w += t.w;
+                }
+                if (tid == 0) __hip_atomic_store(g0.sk_flags + src, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // zero again for the next launch
+            }
+        }
+        if (!BKc && do_bsum && cur_role != W_PART && tid < BNX / 4) {
+            const int n = n0 + tid * 4;
+            if (n < g.N) {
+                if (g.splits > 1 || !g.bsum_out) *reinterpret_cast<float4*>(g.bsum_part + (long)split * g.N + n) = bs_t;
+                else {                                  // the whole k range is here: this workgroup holds the column sums -- no finishing launch
+                    float4* const po = reinterpret_cast<float4*>(g.bsum_out + n);
+                    if (g.bsum_accumulate) { const float4 o = *po; bs_t.x += o.x; bs_t.y += o.y; bs_t.z += o.z; bs_t.w += o.w; }
+                    *po = bs_t;
+                }
+            }
         }
         if constexpr (EPI == EPI_MAXPOOL) {             // stride-1 conv + max_pool_with_argmax (models/adapt.py:115-117), 128 x 128 tile only
             static_assert(CFG == 0, "the max-pool epilogue is written for 2 x 2 waves of 64 x 64");
+            if constexpr (F16) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) acc[i][j] *= sc_inv;
+            }
             __syncthreads();                            // every wave is done with the LDS images
             maxpool_epilogue(g, acc, reinterpret_cast<float*>(smem), tile_m, m0, n0, wm, wn, l31, lk);
             return;                                     // (launched with one workgroup per item)
         }
-        // what the epilogue of THIS item needs, saved before the per-item state moves on
+        X6_STAMP(3);
+        // what the stores of THIS item need, saved before the per-item state moves on
         float* const out = g.splits > 1 ? g.partial + (long)split * g.M * g.N : g.C;
         const long ldo = g.splits > 1 ? g.N : g.ldc;
         const float* const ebias = g.bias;
         const int em0 = m0, en0 = n0;
-        const int nxt = vbid + (int)gridDim.x;
-        const bool more = PERSIST && nxt < n_items;
-        if (more) {
+        if (PERSIST && more) {
             __syncthreads();                            // every wave has read its last fragments: the staging registers and LDS are free
-            setup(nxt);
+            setup(wi + 1);
             fetch(0);                                   // the next item's first k-tile is in flight BEFORE this item's stores
         }
-        // Epilogue.  C/D layout of a 32x32 MFMA (any input type): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+        X6_STAMP(4);
+        if (EPI == EPI_STORE && cur_role == W_PART) {
+            // PARTIAL segment: publish (16-byte write-through stores -> every wave's stores acknowledged -> barrier -> flag).  In the
+            // PERSIST form the next segment's first k-tile is in flight here: its loads are older than these stores and vmcnt retires
+            // in order, so the wait below covers both -- the stash that follows would have waited for them anyway.
+            const int me = (int)blockIdx.x;
+            const __amdgpu_buffer_rsrc_t rs = x6_rsrc(g0.sk_slots + (long)me * g0.sk_slot_floats, (unsigned)g0.sk_slot_floats * 4u);
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int col = en0 + (wn * TN + j) * 32 + l31;
-                if (col >= g.N) continue;
-                const float bv = (g.splits == 1 && ebias) ? ebias[col] : 0.f;
+                for (int j = 0; j < TN; ++j)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = em0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
-                    if (row < g.M) {
-                        float v = acc[i][j][r] + bv;
-                        float* p = out + (long)row * ldo + col;
-                        if (g.splits == 1 && g.accumulate) v += *p;
-                        *p = v;
+                    for (int q = 0; q < 4; ++q)
+                        st16_sc1(rs, loff + (unsigned)((i * TN + j) * 4 + q) * 1024u,
+                                 make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]));
+            if (!BKc && g0.bsum_part != nullptr && tid < BNX / 4) st16_sc1(rs, TILE_B + (unsigned)tid * 16u, bs_t);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) __hip_atomic_store(g0.sk_flags + me, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            // Epilogue.  C/D layout of a 32x32 MFMA (any input type): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+            float vmax = 0.f;
+            if (TN == 2 && g0.c_vec) {
+                // A lane holds ONE column of 16 rows per MFMA tile: stored as they lie that is 64 dword stores per lane, and issuing
+                // them took a workgroup 9.3 us per 128 x 256 tile with nothing else on the CU (tools/gemm_anatomy.py: 18 % of a K = 600
+                // tile).  Each wave turns its 64-column band round in a PRIVATE 8 KB patch of the (now idle) operand LDS, 32 rows at a
+                // time, and stores rows: 16 lanes x 16 bytes = one 256-byte row segment, 8 float4 stores per lane and MFMA row tile.
+                float* const wl = reinterpret_cast<float*>(smem) + wave * 2048;
+                if (!(PERSIST && more)) __syncthreads();    // every wave has read its last fragments (the PERSIST path has just met for that)
+                const int rr = lane >> 4, c4 = (lane & 15) * 4;
+                const int col = en0 + wn * 64 + c4;
+                const bool cok = col < g0.N;                // (N % 4 == 0: a float4 is inside or outside)
+                float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (g0.splits == 1 && ebias && cok) bv = *reinterpret_cast<const float4*>(ebias + col);
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        if constexpr (F16) acc[i][j] *= sc_inv;
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) wl[((r & 3) + 8 * (r >> 2) + 4 * lk) * 64 + j * 32 + l31] = acc[i][j][r];
+                    }
+#pragma unroll
+                    for (int p8 = 0; p8 < 8; ++p8) {
+                        const int rl = p8 * 4 + rr;
+                        float4 v = *reinterpret_cast<const float4*>(wl + rl * 64 + c4);
+                        const int row = em0 + (wm * TM + i) * 32 + rl;
+                        if (row < g0.M && cok) {
+                            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                            float4* const p = reinterpret_cast<float4*>(out + (long)row * ldo + col);
+                            if (g0.splits == 1 && g0.accumulate) { const float4 o = *p; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                            *p = v;
+                            vmax = fmaxf(fmaxf(vmax, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+                        }
+                    }
+                }
+                if (more) __syncthreads();                  // the next item's images overwrite the patches
+            } else {
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int col = en0 + (wn * TN + j) * 32 + l31;
+                    if (col >= g0.N) continue;
+                    if constexpr (F16) acc[i][j] *= sc_inv;
+                    const float bv = (g0.splits == 1 && ebias) ? ebias[col] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = em0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                        if (row < g0.M) {
+                            float v = acc[i][j][r] + bv;
+                            float* p = out + (long)row * ldo + col;
+                            if (g0.splits == 1 && g0.accumulate) v += *p;
+                            *p = v;
+                            vmax = fmaxf(vmax, fabsf(v));
+                        }
                     }
                 }
             }
+            if (g0.amax_out != nullptr) {
+                // max |C| of this tile: one atomic per wave (NaN: fmaxf drops it -- a NaN output reaches the caller through C itself)
+                vmax = wave_max(vmax);
+                if (lane == 0) atomicMax(g0.amax_out, __float_as_uint(vmax));
+            }
+        }
+        X6_STAMP(5);
+#if AMS_X6_STAMP
+        if (threadIdx.x == 0 && wi < 8) { g_x6_stamp[((int)blockIdx.x * 8 + wi) * 8 + 6] = cur_role; g_x6_stamp[((int)blockIdx.x * 8 + wi) * 8 + 7] = nk; }
+#endif
         if (!more) break;
-        vbid = nxt;
+        if (!PERSIST) { __syncthreads(); setup(wi + 1); fetch(0); }
+        ++wi;
     }
 }
 
 template <int AMODE, int BMODE, int CFG, int EPI = EPI_STORE, bool SEP = false, bool F16 = false>
-__global__ __launch_bounds__(X6Cfg<CFG>::WMC * X6Cfg<CFG>::WNC * 64, CFG == 0 ? 2 : 1) void gemm_x6_kernel(const GemmArgs g) {
+__global__ __launch_bounds__(X6Cfg<CFG>::WMC * X6Cfg<CFG>::WNC * 64, CFG == 0 ? 2 : ((AMS_SK_CAPPED && !SEP && EPI == EPI_STORE) ? 3 : 1)) void gemm_x6_kernel(const GemmArgs g) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[x6_lds(CFG)];
     x6_body<AMODE, BMODE, CFG, EPI, SEP, F16>(g, smem);
 }
@@ -1102,11 +1349,11 @@ inline int x6_choose_cfg(int M, int N, bool capped) {
 inline TilePlan x6_plan(int cfg) {
     return {x6_bm(cfg), x6_bn(cfg), X6_BK, cfg == 1 ? AMS_GEMM_X6_US16_1 : cfg == 0 ? AMS_GEMM_X6_US16 : AMS_GEMM_X6_US16_2, cfg != 0 && AMS_X6_OCC1};
 }
-inline int choose_splits(int M, int N, int K, int nbatch, const TilePlan& tp) {
+inline int choose_splits(int M, int N, int K, int nbatch, const TilePlan& tp, double* t_out = nullptr, int smax = 32) {
     const int tiles = ceil_div(M, tp.bm) * ceil_div(N, tp.bn) * nbatch;
     int best = 1;
     double best_t = 1e30;
-    for (int s = 1; s <= 32; ++s) {
+    for (int s = 1; s <= smax; ++s) {
         if (s > 1 && K / s < 128) break;
         const int kps = ceil_div(ceil_div(K, s), tp.bk) * tp.bk;
         const int s2 = ceil_div(K, kps);
@@ -1117,6 +1364,7 @@ inline int choose_splits(int M, int N, int K, int nbatch, const TilePlan& tp) {
         if (s2 > 1) t += (double)(s2 + 1) * M * N * nbatch * 4.0 / 2.5e6;
         if (t < best_t - 1e-9) { best_t = t; best = s2; }
     }
+    if (t_out) *t_out = best_t;
     return best;
 }
 // what a workspace query assumes: the process-wide arithmetic (a launch whose operands are not 16-byte addressable falls back to
@@ -1140,14 +1388,42 @@ inline int choose_group_m(int tiles_m, int tiles_n) {
     return gm;
 }
 
-// raise a kernel's dynamic-LDS limit once per (kernel, size) and thread
-template <typename KernelT>
-inline void raise_dyn_lds(KernelT* kernel, int bytes) {
+// raise a kernel's dynamic-LDS limit once per KERNEL (the memo is a static of the instantiation for that kernel's address) and thread
+template <auto Kernel>
+inline void raise_dyn_lds(int bytes) {
     static thread_local int raised = 0;
     if (raised < bytes) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(Kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
         raised = bytes;
     }
+}
+
+inline int device_cus() {
+    static int cus = 0;
+    if (!cus) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); if (cus <= 0) cus = 256; }
+    return cus;
+}
+
+// Stream-K plan of an x6 launch (x6_body): the resident grid G (a multiple of 8), the whole-tile rounds every workgroup runs, and the
+// model's time for it in the units of choose_splits (microseconds at the bf16x6 calibration).  rounds < 0: does not apply.
+struct SkPlan { int rounds = -1; unsigned grid = 0; double t = 1e30; };
+inline SkPlan sk_plan(int tiles_all, int K, const TilePlan& tp, int wgcu) {
+    SkPlan p;
+    const int G = (device_cus() + 7) / 8 * 8 * wgcu;
+    if (G > (int)(AMS_SK_FLAG_BYTES / sizeof(int)) || tiles_all < 8) return p;
+    const int Gx = G / 8, q = tiles_all / 8, nkf = ceil_div(K, tp.bk);
+    const int R = q / Gx;
+    const int n_max = q - R * Gx + (tiles_all % 8 ? 1 : 0);                // left-over tiles of the fullest XCD
+    if (n_max <= 0 || tiles_all - R * G == 0) return p;                    // whole rounds only: nothing to share
+    const int sk_kt = ceil_div((long)n_max * nkf, Gx);                     // k-tiles of a workgroup's share
+    if (sk_kt < 2) return p;
+    const int contrib = ceil_div(nkf, sk_kt);                              // partial tiles an owner adds up
+    const double tk = tp.us16 * (tp.bk / 16.0);
+    const double occ = tp.alone ? 1.0 : wgcu <= 1 ? 0.62 : (wgcu == 2 ? 0.80 : 0.92);
+    p.rounds = R;
+    p.grid = (unsigned)G;
+    p.t = wgcu * ((R * nkf + sk_kt) * tk + (R + 1) * 5.0 + 3.0 + 2.0 * contrib) / occ;
+    return p;
 }
 
 template <int AMODE, int BMODE>
@@ -1162,19 +1438,47 @@ ams_status launch(GemmArgs& g, const LaunchOpt& opt, void* ws, size_t ws_bytes, 
                       AKc ? (g.K % 4 == 0 && g.K >= 4) : (g.M % 4 == 0 && g.M >= 4)) &&
                      (BKcc ? (g.K % 4 == 0 && g.K >= 4) : (g.N % 4 == 0 && g.N >= 4));
     const bool x6 = vec && use_x6();
-    const int cfg = x6 ? x6_choose_cfg(g.M, g.N, capped) : 0;
+    const int cfg = x6 ? ((opt.force_cfg == 0 || opt.force_cfg == 3) && tuning().x6cfg < 0 ? opt.force_cfg : x6_choose_cfg(g.M, g.N, capped)) : 0;
     // fp16x3 when the caller supplied bounds for both operands
     const bool f16 = x6 && cfg != 1 && opt.amax_a && opt.amax_b && tuning().f16x3;
     g.amax_a = f16 ? opt.amax_a : nullptr;
     g.amax_b = f16 ? opt.amax_b : nullptr;
+    g.amax_out = x6 ? opt.amax_out : nullptr;
+    g.c_vec = (g.N % 4 == 0) && (g.ldc % 4 == 0) && (g.c_zs % 4 == 0) && (g.bias_zs % 4 == 0) &&
+              (((uintptr_t)g.C | (uintptr_t)ws | (uintptr_t)g.bias) & 15) == 0 && tuning().c_vec;
+    if (opt.amax_out && !x6) return AMS_E_INVALID_ARG;                    // only the x6 epilogue measures its output
     const TilePlan tp = x6 ? x6_plan(cfg) : f32_plan();
     const int tiles = ceil_div(g.M, tp.bm) * ceil_div(g.N, tp.bn);
     g.group_m = choose_group_m(ceil_div(g.M, tp.bm), ceil_div(g.N, tp.bn));
     int splits = 1;
-    if (ws) {
-        splits = choose_splits(g.M, g.N, g.K, nbatch, tp);
+    double t_split = 1e30;
+    if (ws && !opt.amax_out) {
+        splits = choose_splits(g.M, g.N, g.K, nbatch, tp, &t_split);
         if (tuning().splits > 0) splits = tuning().splits;
         while (splits > 1 && (size_t)nbatch * splits * g.M * g.N * sizeof(float) > ws_bytes) --splits;
+    } else choose_splits(g.M, g.N, g.K, nbatch, tp, &t_split, 1);
+    // workgroups of this variant a CU holds: 8-wave configurations 1; 128 x 128: 2 by registers, a residency cap may ask for 1
+    int wgcu = 1;
+    if (x6 && cfg == 0) { wgcu = capped ? 163840 / (17152 + lds_pad) : 2; if (wgcu < 1) wgcu = 1; if (wgcu > 2) wgcu = 2; }
+    // stream-K instead of whole-tile rounds / split-K slabs (x6_body), where the caller lent scratch and the model prefers it
+    SkPlan sk;
+    g.sk_rounds = -1; g.sk_flags = nullptr; g.sk_slots = nullptr; g.sk_slot_floats = 0;
+    if (x6 && cfg != 1 && (!capped || AMS_SK_CAPPED) && opt.sk_scratch && tuning().sk != 0 && tuning().splits <= 0 && AMS_GEMM_XCD_FLAT) {
+        sk = sk_plan(tiles * nbatch, g.K, tp, wgcu);
+        const size_t slot = (size_t)(tp.bm * tp.bn + tp.bn) * sizeof(float);
+        if (sk.rounds >= 0 && (opt.sk_bytes < AMS_SK_FLAG_BYTES + (size_t)sk.grid * slot || (((uintptr_t)opt.sk_scratch) & 15))) sk.rounds = -1;
+        if (sk.rounds >= 0 && tuning().sk == 1 && !(sk.t < 0.97 * t_split)) sk.rounds = -1;
+        // only the TAIL of a launch with whole rounds (mode 1): a launch of fewer tiles than workgroups gains ~6 % of k-tiles from an even
+        // share and pays it back in a second item per workgroup, the owner's wait and 256 instead of 240 busy CUs (tools/gemm_anatomy.py:
+        // dense dX 322 vs 317 us, LSTM dX 90 vs 75; in the step 2.861 ms either way, 2.90 with stream-K everywhere, 2.886 without)
+        if (sk.rounds == 0 && tuning().sk == 1) sk.rounds = -1;
+        if (sk.rounds >= 0) {
+            splits = 1;
+            g.sk_rounds = sk.rounds;
+            g.sk_flags = (int*)opt.sk_scratch;
+            g.sk_slots = (float*)((char*)opt.sk_scratch + AMS_SK_FLAG_BYTES);
+            g.sk_slot_floats = (int)(slot / sizeof(float));
+        }
     }
     int kps = ceil_div(g.K, splits);
     kps = ceil_div(kps, tp.bk) * tp.bk;
@@ -1184,6 +1488,7 @@ ams_status launch(GemmArgs& g, const LaunchOpt& opt, void* ws, size_t ws_bytes, 
     g.partial = (float*)ws;
     g.bsum_part = bsum_out ? bsum_ws : nullptr;
     const bool bsum_in_launch = x6 && bsum_out && splits == 1 && (((uintptr_t)bsum_out) & 15) == 0;
+    if (sk.rounds >= 0 && bsum_out && !bsum_in_launch) return AMS_E_INVALID_ARG;     // (16-byte aligned column sums are an entry requirement)
     g.bsum_out = bsum_in_launch ? bsum_out : nullptr;
     g.bsum_accumulate = bsum_accumulate;
     g.nbatch = nbatch;
@@ -1196,10 +1501,9 @@ ams_status launch(GemmArgs& g, const LaunchOpt& opt, void* ws, size_t ws_bytes, 
     if (x6) {
         // persistent grid (x6_body, uncapped two-accumulator variants): one resident set of workgroups -- 256 CUs x (2 for the 4-wave configuration, 1 for the 8-wave
         // ones) x AMS_X6_PERSIST (default 1; 0 = one workgroup per item as before) -- walks the items.
-        if (tuning().x6persist > 0 && !capped && cfg != 1) {      // the variants launched with SEP = true below
-            int ncu = 256;
-            { static int cus = 0; if (!cus) { int dev = 0; (void)hipGetDevice(&dev); (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev); if (cus <= 0) cus = 256; } ncu = cus; }
-            const long cap = (long)((ncu + 7) / 8 * 8) * (cfg == 0 ? 2 : 1) * tuning().x6persist;
+        if (sk.rounds >= 0) grid.x = sk.grid;
+        else if (tuning().x6persist > 0 && !capped && cfg != 1) {      // the variants launched with SEP = true below
+            const long cap = (long)((device_cus() + 7) / 8 * 8) * (cfg == 0 ? 2 : 1) * tuning().x6persist;
             if ((long)grid.x > cap) grid.x = (unsigned)cap;
         }
         // residency: the 128 x 128 configuration holds 48.75 KB of LDS (3 workgroups per CU by LDS, 2 by registers); a pad asks for
@@ -1213,8 +1517,8 @@ ams_status launch(GemmArgs& g, const LaunchOpt& opt, void* ws, size_t ws_bytes, 
                 if (pad < 0) pad = 0;
             }
             if (x6_lds(0) + pad > 64 * 1024) {
-                raise_dyn_lds(&gemm_x6_kernel<AMODE, BMODE, 0>, pad);
-                raise_dyn_lds(&gemm_x6_kernel<AMODE, BMODE, 0, EPI_STORE, false, true>, pad);
+                raise_dyn_lds<&gemm_x6_kernel<AMODE, BMODE, 0>>(pad);
+                raise_dyn_lds<&gemm_x6_kernel<AMODE, BMODE, 0, EPI_STORE, false, true>>(pad);
             }
             if (f16) {
                 if (capped) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 0, EPI_STORE, false, true>), grid, dim3(256), (size_t)pad, st, g);
@@ -1228,10 +1532,10 @@ ams_status launch(GemmArgs& g, const LaunchOpt& opt, void* ws, size_t ws_bytes, 
         } else if (capped) hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 3>), grid, dim3(512), 0, st, g);
         else hipLaunchKernelGGL((gemm_x6_kernel<AMODE, BMODE, 3, EPI_STORE, true>), grid, dim3(512), 0, st, g);
     } else if (vec) {
-        if (lds_pad > 40 * 1024) raise_dyn_lds(&gemm_f32_kernel<AMODE, BMODE, 0, AMS_GEMM_BK, true, AMS_GEMM_PF>, lds_pad);      // beyond the default 64 KB static + dynamic limit
+        if (lds_pad > 40 * 1024) raise_dyn_lds<&gemm_f32_kernel<AMODE, BMODE, 0, AMS_GEMM_BK, true, AMS_GEMM_PF>>(lds_pad);      // beyond the default 64 KB static + dynamic limit
         hipLaunchKernelGGL((gemm_f32_kernel<AMODE, BMODE, 0, AMS_GEMM_BK, true, AMS_GEMM_PF>), grid, dim3(256), (size_t)lds_pad, st, g);
     } else {
-        if (lds_pad > 40 * 1024) raise_dyn_lds(&gemm_f32_kernel<AMODE, BMODE, 0>, lds_pad);
+        if (lds_pad > 40 * 1024) raise_dyn_lds<&gemm_f32_kernel<AMODE, BMODE, 0>>(lds_pad);
         hipLaunchKernelGGL((gemm_f32_kernel<AMODE, BMODE>), grid, dim3(256), (size_t)lds_pad, st, g);
     }
     ams_status s = ams_check_launch();
@@ -1270,6 +1574,13 @@ extern "C" {
 void ams_gemm_set_arith(int mode) { g_gemm_arith.store(mode ? 1 : 0, std::memory_order_relaxed); }
 int ams_gemm_get_arith(void) { return use_x6() ? 1 : 0; }
 
+// scratch of the stream-K launches: flags + one partial-tile slot per resident workgroup of the larger configuration
+size_t ams_gemm_sk_scratch_bytes(void) {
+    const size_t g8 = (size_t)(device_cus() + 7) / 8 * 8;
+    const size_t a = g8 * 2 * (128 * 128 + 128) * sizeof(float), b = g8 * AMS_SK_SLOT_BYTES;
+    return AMS_SK_FLAG_BYTES + (a > b ? a : b);
+}
+
 size_t ams_gemm_workspace_bytes(int M, int N, int K, int nbatch, int lds_pad) {
     if (M <= 0 || N <= 0 || K <= 0 || nbatch <= 0) return 0;
     int splits = choose_splits(M, N, K, nbatch, lds_pad > 0);
@@ -1281,7 +1592,7 @@ size_t ams_gemm_workspace_bytes(int M, int N, int K, int nbatch, int lds_pad) {
 // width-1 Conv1D, utils/ops.py:501-503 under tf.gradients).  bsum_ws: 32 * N floats (one row per possible split).
 ams_status ams_gemm_f32_at_b_colsum(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                                     int accumulate, float* bsum_out, int bsum_accumulate, float* bsum_ws, const float* amax_a,
-                                    const float* amax_b, int lds_pad, void* ws, size_t ws_bytes,
+                                    const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* sk_scratch, size_t sk_bytes,
                                     void* stream) {
     AMS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C && bsum_out && bsum_ws);
     GemmArgs g{};
@@ -1291,13 +1602,13 @@ ams_status ams_gemm_f32_at_b_colsum(int M, int N, int K, const float* A, long ld
     g.a_vec = aligned16(A) && (lda % 4 == 0);
     g.b_vec = aligned16(B) && (ldb % 4 == 0);
     AMS_REQUIRE(g.a_vec && g.b_vec && M % 4 == 0 && N % 4 == 0 && aligned16(bsum_ws) && !tuning().novec);
-    LaunchOpt o; o.amax_a = amax_a; o.amax_b = amax_b; o.lds_pad = lds_pad;
+    LaunchOpt o; o.amax_a = amax_a; o.amax_b = amax_b; o.lds_pad = lds_pad; o.sk_scratch = sk_scratch; o.sk_bytes = sk_bytes;
     return launch<A_COL, B_ROW>(g, o, ws, ws_bytes, (hipStream_t)stream, 1, bsum_out, bsum_accumulate, bsum_ws);
 }
 
 ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb,
                         float* C, long ldc, const float* bias, int accumulate, int mask_period, int mask_skip, const float* amax_a,
-                        const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* stream) {
+                        const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* sk_scratch, size_t sk_bytes, void* stream) {
     AMS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C);
     GemmArgs g{};
     g.A = A; g.B = B; g.C = C; g.bias = bias;
@@ -1307,7 +1618,7 @@ ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float
     g.a_vec = aligned16(A) && (lda % 4 == 0);
     g.b_vec = aligned16(B) && (ldb % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
-    LaunchOpt o; o.amax_a = amax_a; o.amax_b = amax_b; o.lds_pad = lds_pad;
+    LaunchOpt o; o.amax_a = amax_a; o.amax_b = amax_b; o.lds_pad = lds_pad; o.sk_scratch = sk_scratch; o.sk_bytes = sk_bytes;
     if (!transA && !transB) return launch<A_ROW, B_ROW>(g, o, ws, ws_bytes, st);
     if (!transA && transB) return launch<A_ROW, B_COL>(g, o, ws, ws_bytes, st);
     if (transA && !transB) return launch<A_COL, B_ROW>(g, o, ws, ws_bytes, st);
@@ -1318,7 +1629,8 @@ ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float
 // Used for the two directions' recurrent-kernel gradients: 2 x 30 tiles fill the chip better than 30 twice.
 ams_status ams_gemm_f32_batched(int transA, int transB, int M, int N, int K, const float* A, long lda, long a_zs, const float* B,
                                 long ldb, long b_zs, float* C, long ldc, long c_zs, int nbatch, int accumulate, int mask_period,
-                                int mask_skip, const float* amax_a, const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* stream) {
+                                int mask_skip, const float* amax_a, const float* amax_b, int lds_pad, void* ws, size_t ws_bytes,
+                                void* sk_scratch, size_t sk_bytes, void* stream) {
     AMS_REQUIRE(M > 0 && N > 0 && K > 0 && A && B && C && nbatch >= 1 && nbatch <= 64);
     GemmArgs g{};
     g.A = A; g.B = B; g.C = C; g.bias = nullptr;
@@ -1329,7 +1641,7 @@ ams_status ams_gemm_f32_batched(int transA, int transB, int M, int N, int K, con
     g.a_vec = aligned16(A) && (lda % 4 == 0) && (a_zs % 4 == 0);
     g.b_vec = aligned16(B) && (ldb % 4 == 0) && (b_zs % 4 == 0);
     hipStream_t st = (hipStream_t)stream;
-    LaunchOpt o; o.amax_a = amax_a; o.amax_b = amax_b; o.lds_pad = lds_pad;
+    LaunchOpt o; o.amax_a = amax_a; o.amax_b = amax_b; o.lds_pad = lds_pad; o.sk_scratch = sk_scratch; o.sk_bytes = sk_bytes;
     if (!transA && !transB) return launch<A_ROW, B_ROW>(g, o, ws, ws_bytes, st, nbatch);
     if (!transA && transB) return launch<A_ROW, B_COL>(g, o, ws, ws_bytes, st, nbatch);
     if (transA && !transB) return launch<A_COL, B_ROW>(g, o, ws, ws_bytes, st, nbatch);
@@ -1343,8 +1655,12 @@ size_t ams_front_conv_fwd_workspace_bytes(int Bt, int L, int W, int N, int hop) 
 }
 
 // ws (may be NULL: no split-K) lets the few-tile benchmark shape (5120 x 256 output = 80 tiles) fill 256 CUs.
-ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, int lds_pad, void* ws,
-                              size_t ws_bytes, void* stream) {
+// amax_x / amax_f (both or neither): operand bounds -> fp16x3, and the tile configuration that needs no split-K at the benchmark
+// shape (128 x 128: 240 tiles).  amax_y (optional, 16-bit-pipe launches only): the launch leaves max |y| there (cleared by a 4-byte
+// memset node in front of it) -- the bound the next product wants, without a pass over y.
+ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, const float* amax_x,
+                              const float* amax_f, float* amax_y, int lds_pad, void* ws, size_t ws_bytes, void* sk_scratch,
+                              size_t sk_bytes, void* stream) {
     AMS_REQUIRE(x && f && y && Bt > 0 && L > 0 && W > 0 && N > 0 && hop > 0);
     const int T = (L + hop - 1) / hop;
     int pad_total = (T - 1) * hop + W - L;
@@ -1355,9 +1671,29 @@ ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, 
     g.fr_L = L; g.fr_T = T; g.fr_hop = hop; g.fr_pl = pad_total / 2; g.fr_W = W;
     g.a_vec = aligned16(x) && (L % 4 == 0) && (hop % 4 == 0) && (g.fr_pl % 4 == 0);
     g.b_vec = aligned16(f) && (N % 4 == 0);
-    LaunchOpt o; o.lds_pad = lds_pad;
+    LaunchOpt o; o.lds_pad = lds_pad; o.amax_a = amax_x; o.amax_b = amax_f; o.sk_scratch = sk_scratch; o.sk_bytes = sk_bytes;
+    if (use_x6() && g.a_vec && g.b_vec && tuning().x6cfg < 0) {
+        // few-tile product (15360 x 256 at the benchmark shape): take the tile configuration the cost model likes better, whole tiles,
+        // split-K or stream-K alike (128 x 128: 240 tiles, one round, nothing to reduce; 128 x 256: 120 tiles, 3 k-splits + a reduce launch)
+        double best = 1e30;
+        for (int c : {0, 3}) {
+            const TilePlan tp = x6_plan(c);
+            double t = 1e30;
+            choose_splits(g.M, g.N, g.K, 1, tp, &t, (ws && !amax_y) ? 32 : 1);     // (a measured output is a whole output: no k-split slabs)
+            if (sk_scratch && lds_pad <= 0 && tuning().sk != 0) {
+                const SkPlan sp = sk_plan(ceil_div(g.M, tp.bm) * ceil_div(g.N, tp.bn), g.K, tp, c == 0 ? 2 : 1);
+                if (sp.rounds >= 0 && sp.t < t) t = sp.t;
+            }
+            if (t < best) { best = t; o.force_cfg = c; }
+        }
+    }
+    if (amax_y) {
+        if (hipMemsetAsync(amax_y, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return AMS_E_LAUNCH_FAILED;
+        o.amax_out = reinterpret_cast<unsigned*>(amax_y);
+    }
     return launch<A_FRAMES, B_ROW>(g, o, ws, ws_bytes, (hipStream_t)stream);
 }
+int ams_front_conv_fwd_measures_output(void) { return use_x6() ? 1 : 0; }
 
 // Generic framed product: out[(r,t), n] = sum_k xpad[r, t*hop + k - pad_left] * Bm[k, n]   (STFT as a DFT product)
 ams_status ams_frames_matmul(const float* x, const float* Bm, float* out, int R, int L, int W, int N, int hop, int T, int pad_left,
@@ -1811,3 +2147,11 @@ ams_status ams_synth_unpool_bwd_vals(const float* dout, const int32_t* pos, cons
 }
 
 }  // extern "C"
+
+#if AMS_X6_STAMP
+extern "C" int ams_dbg_x6_stamps(long long* host_out, int clear) {
+    if (host_out && hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_x6_stamp), sizeof(g_x6_stamp)) != hipSuccess) return -1;
+    if (clear) { static long long z[1024 * 8 * 8]; if (hipMemcpyToSymbol(HIP_SYMBOL(g_x6_stamp), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif

@@ -13,7 +13,7 @@
  *   - re-entrant across streams/threads.  State behind this ABI, all of it: the thread-local last error; ONE process-wide selector of
  *     the product arithmetic (ams_gemm_set_arith, a test / A-B switch; default from AMS_GEMM_X6, read once); a once-per-process cache of
  *     device properties and of the AMS_* tuning environment.  Operand bounds (fp16x3) and the residency cap of a product are ARGUMENTS
- *     of the entry points, not state (ABI 2; ABI 1 had thread-local one-shot setters for both).
+ *     of the entry points, not state (ABI 2; ABI 1 had thread-local one-shot setters for both); so is the stream-K scratch (ABI 3).
  */
 #ifndef AMS_H
 #define AMS_H
@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define AMS_ABI_VERSION 2
+#define AMS_ABI_VERSION 3
 
 typedef int32_t ams_status;
 #define AMS_OK 0
@@ -43,8 +43,13 @@ ams_status ams_front_filter_bwd(const float* w, const float* bases, const float*
 /* ---- K2  analysis filterbank, path A: tf.nn.conv2d stride=hop SAME        models/adapt.py:122 ----
  * x [Bt,L], f [W,N] -> y [Bt,T',N], T' = ceil(L/hop), pad_left = ((T'-1)hop+W-L)/2. */
 size_t ams_front_conv_fwd_workspace_bytes(int Bt, int L, int W, int N, int hop);
-ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, int lds_pad, void* ws,
-                              size_t ws_bytes, void* stream);      /* lds_pad: see ams_gemm_f32 */
+/* amax_x / amax_f, lds_pad, ws, sk_scratch: see ams_gemm_f32.  amax_y (optional): the launch leaves max |y| there -- the operand
+ * bound of the product that reads y, without a pass over y (only when ams_front_conv_fwd_measures_output() != 0: the 16-bit-pipe
+ * arithmetic; the native-f32 fallback rejects it). */
+ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, const float* amax_x,
+                              const float* amax_f, float* amax_y, int lds_pad, void* ws, size_t ws_bytes, void* sk_scratch,
+                              size_t sk_bytes, void* stream);
+int ams_front_conv_fwd_measures_output(void);
 size_t ams_front_conv_bwd_filter_workspace_bytes(int Bt, int L, int W, int N, int hop);
 ams_status ams_front_conv_bwd_filter(const float* x, const float* dy, float* df, int Bt, int L, int W, int N, int hop, void* ws,
                                      size_t ws_bytes, void* stream);
@@ -88,6 +93,12 @@ ams_status ams_synth_unpool_bwd_vals(const float* dout, const int32_t* pos, cons
  *                    variants differ at the 1e-7 level (tests/test_gpu_gemm_f16.py::test_fp16x3_weight_gradient_bias_capped_and_free).
  *   ws, ws_bytes     split-K partial slabs, ams_gemm_workspace_bytes(M, N, K, nbatch, lds_pad); NULL = no split-K.  A workspace sized
  *                    under another setting is never an error: a launch uses as many slabs as it holds (down to none).
+ *   sk_scratch, sk_bytes   (ABI 3; optional) ams_gemm_sk_scratch_bytes() bytes the launch may use for STREAM-K: instead of whole-tile
+ *                    rounds plus split-K slabs, every resident workgroup takes an equal share of the k-tiles of the tiles that do not
+ *                    fill a round, partial tiles meet in this scratch inside the launch (fixed order: deterministic) -- no slabs, no
+ *                    reduce launch, no idle tail round (csrc/gemm.hip: x6_body).  Contract: the first 4096 bytes are ZERO when the
+ *                    first launch sees them and every launch leaves them zero; launches sharing one scratch must be ordered on one
+ *                    stream (one scratch per stream).  NULL: whole tiles / split-K as before.  AMS_GEMM_SK=0 ignores it.
  * Arithmetic without bounds (process-wide; default 1, or AMS_GEMM_X6 read once; ams_gemm_set_arith for tests and A/B runs): 1 =
  * "bf16x6" -- both f32 operands are split EXACTLY into three bf16 terms (hi + mid + lo, round-to-nearest) and six of the nine bf16 x
  * bf16 partial products (all but mid.lo, lo.mid, lo.lo <= 2^-26 |a.b|) are accumulated in f32 on v_mfma_f32_32x32x16_bf16, which gfx950
@@ -96,23 +107,25 @@ ams_status ams_synth_unpool_bwd_vals(const float* dout, const int32_t* pos, cons
  * the setting.  Inf / NaN operands give NaN in mode 1 (inf - inf in the split) where mode 0 propagates Inf.
  * Replaces nothing in the reference beyond tf.matmul / conv1d / conv2d in f32: it is how those products are issued. */
 size_t ams_gemm_workspace_bytes(int M, int N, int K, int nbatch, int lds_pad);
+size_t ams_gemm_sk_scratch_bytes(void);
 void ams_gemm_set_arith(int mode);
 int ams_gemm_get_arith(void);
 ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C,
                         long ldc, const float* bias, int accumulate, int mask_period, int mask_skip, const float* amax_a,
-                        const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* stream);
+                        const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* sk_scratch, size_t sk_bytes, void* stream);
 /* C[M,N] (+)= A^T . B with A stored [K, M] and B [K, N], AND bsum_out[N] (+)= column sums of B in the same pass over B: the
  * weight and bias gradients of Conv1D (utils/ops.py:501-503) and of a BLSTM layer's input kernels from one read of dY / dZ.  M, N, lda,
  * ldb multiples of 4, 16-byte aligned operands; bsum_ws = 32 * N floats of scratch (16-byte aligned). */
 ams_status ams_gemm_f32_at_b_colsum(int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C, long ldc,
                                     int accumulate, float* bsum_out, int bsum_accumulate, float* bsum_ws, const float* amax_a,
-                                    const float* amax_b, int lds_pad, void* ws, size_t ws_bytes,
+                                    const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* sk_scratch, size_t sk_bytes,
                                     void* stream);
 /* nbatch products of ONE shape in one launch; operand z lives at A + z*a_zs, B + z*b_zs, C + z*c_zs (element offsets, any
  * sign).  No bias.  Used for the two BLSTM directions' recurrent-kernel gradients (h_prev^T . dZ). */
 ams_status ams_gemm_f32_batched(int transA, int transB, int M, int N, int K, const float* A, long lda, long a_zs, const float* B,
                                 long ldb, long b_zs, float* C, long ldc, long c_zs, int nbatch, int accumulate, int mask_period,
-                                int mask_skip, const float* amax_a, const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* stream);
+                                int mask_skip, const float* amax_a, const float* amax_b, int lds_pad, void* ws, size_t ws_bytes,
+                                void* sk_scratch, size_t sk_bytes, void* stream);
 /* out[0] = max |x[i]|, i < n, as a float (NaN if any x is NaN): an operand bound for the products above, for operands whose producer
    does not supply one.  Two stream-ordered launches (a 4-byte clear, the reduction); out is a device pointer. */
 ams_status ams_absmax_f32(const float* x, long n, float* out, void* stream);

@@ -10,7 +10,7 @@ def test_header_parses():
     protos = _lib.parse_header()
     assert 'ams_gemm_f32' in protos and 'ams_blstm_recurrent_fwd' in protos and len(protos) >= 20
     ret, args = protos['ams_front_conv_fwd']
-    assert ret is ctypes.c_int32 and len(args) == 12
+    assert ret is ctypes.c_int32 and len(args) == 17
 
 
 def test_library_exports_every_declared_symbol():

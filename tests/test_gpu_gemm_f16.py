@@ -104,7 +104,9 @@ def test_fp16x3_weight_gradient_bias_capped_and_free(ops, M, N, K):
     """The weight-gradient products of the training step run as fp16x3 UNDER THE RESIDENCY CAP (side stream, one accumulator set:
     gemm_x6_kernel<.., SEP = false, F16 = true>).  Signed mean error against float64 at the step's own shapes, zero-mean and
     all-positive data: the capped form is held to the bound tests/test_gpu_gemm_x6.py pins for capped bf16x6 (3e-7 of the term
-    scale), the uncapped two-accumulator form to the 5e-9 of the default kernels; rms at the native f32 kernel's level."""
+    scale), the uncapped two-accumulator form to 2e-8 (5e-9 while these shapes were cut into 5-12 k-split slabs; under stream-K a
+    workgroup's accumulation chain is up to 4x longer and the MFMA's truncating adder shows it on all-positive data: measured -1.1e-8,
+    a thirtieth of the native kernel's rms); rms at the native f32 kernel's level."""
     from ams_hip._lib import load
     lib = load()
     rng = np.random.RandomState(M + N + 1)
@@ -129,7 +131,7 @@ def test_fp16x3_weight_gradient_bias_capped_and_free(ops, M, N, K):
         r0 = np.sqrt((d0 ** 2).mean())
         print('fp16x3 %s %dx%dx%d: native mean %.2e rms %.2e | free mean %.2e rms %.2e | capped mean %.2e rms %.2e'
               % (kind, M, N, K, d0.mean(), r0, free.mean(), np.sqrt((free ** 2).mean()), cap.mean(), np.sqrt((cap ** 2).mean())))
-        assert abs(free.mean()) < 5e-9 and np.sqrt((free ** 2).mean()) <= 1.05 * r0, (kind, free.mean(), d0.mean())
+        assert abs(free.mean()) < 2e-8 and np.sqrt((free ** 2).mean()) <= 1.05 * r0, (kind, free.mean(), d0.mean())
         assert abs(cap.mean()) < 3e-7 and np.sqrt((cap ** 2).mean()) <= 1.5 * r0, (kind, cap.mean(), d0.mean())
 
 
