@@ -135,7 +135,7 @@ def _sk(like):
     if t is None:
         n = int(load().ams_gemm_sk_scratch_bytes())
         t = torch.empty((n + 3) // 4, dtype=torch.float32, device=like.device)
-        t[:1024].zero_()
+        t[:2048].zero_()
         _SK[k] = t
     return _vp(t.data_ptr()), t.numel() * 4
 
@@ -171,14 +171,14 @@ def front_conv(x, f, hop, amax=None, measure=False):
     if measure and F16X3 and lib.ams_front_conv_fwd_measures_output():
         ay = torch.empty(1, dtype=torch.float32, device=x.device)
     ev = PROFILE.begin() if PROFILE.enabled else None
-    pa, pb, _ = _bounds(amax)
+    pa, pb, gt = _bounds(amax)
     skp, skn = _sk(x)
     check(lib.ams_front_conv_fwd(_p(x), _p(f), _p(y), Bt, L, W, N, hop, pa, pb, _p(ay), 0, _p(ws), nb, skp, skn, _s()),
           'ams_front_conv_fwd')
     if ay is not None:
         tag_amax(y, ay)
     if ev is not None:      # algorithmic bytes: waveform in, frames out, filter once
-        PROFILE.end(ev, 2.0 * Bt * T * N * W, 4.0 * (Bt * L + Bt * T * N + W * N), 'gemm<2,0>', 'front_conv')
+        PROFILE.end(ev, 2.0 * Bt * T * N * W, 4.0 * (Bt * L + Bt * T * N + W * N), gt + '<2,0>', 'front_conv')
     return y
 
 
@@ -242,11 +242,13 @@ PASS = [0]                                                       # bumped by gra
 
 class _ParamSource(object):
     """One optimizer's flat parameter buffer and the bound measured over it (shared by every variable the optimizer owns)."""
-    __slots__ = ('flat', 'bound', 'seen', 'event', 'used', '__weakref__')
+    __slots__ = ('flat', 'bound', 'seen', 'event', 'used', 'next', 'rolled', '__weakref__')
 
     def __init__(self, flat):
         self.flat = flat
         self.bound = torch.zeros(1, dtype=torch.float32, device=flat.device)
+        self.next = torch.zeros(192, dtype=torch.int32, device=flat.device)    # include/ams.h: amax_slots of the optimizer kernels
+        self.rolled = False             # an optimizer kernel keeps `bound` current (it leaves max |p| of what it writes there)
         self.seen = -1                  # the pass (PASS[0]) it was last measured in
         self.event = None               # measured on the side stream: recorded there, awaited by the first consumer
         self.used = -1                  # the last pass a product asked for this bound
@@ -420,11 +422,15 @@ def pass_begin(side_stream):
         return
     side_stream.wait_stream(cur)
     with torch.cuda.stream(side_stream):
+        for src in todo:
+            if src.rolled and ROLL_BOUNDS and torch.cuda.is_current_stream_capturing():
+                # inside a captured step only the optimizer writes these weights between replays, and its kernel leaves their bound
+                # in src.bound as it goes (include/ams.h: bound_out): nothing to measure, nothing to launch
+                continue
+            absmax(src.flat, out=src.bound)
         for t in zeros:
             t.zero_()
         _DEFER_ZERO[:] = [t for t in _DEFER_ZERO if t.device != cur.device]
-        for src in todo:
-            absmax(src.flat, out=src.bound)
         if ar is not None:
             ar.begin(side_stream, cur.device)
         ev = torch.cuda.Event()
@@ -434,10 +440,23 @@ def pass_begin(side_stream):
     _PASS_SIDE.event, _PASS_SIDE.n, _PASS_SIDE.waited = ev, PASS[0], set()
 
 
+ROLL_BOUNDS = _os.environ.get('AMS_ROLL_BOUNDS', '1') != '0'
+
+
+def param_bounds_dirty():
+    """Somebody other than an optimizer kernel wrote weights (checkpoint restore): a captured step, which takes the bound the optimizer
+    kernel keeps, must not see a stale one -- measure every live source now."""
+    for ref in _SOURCES:
+        src = ref()
+        if src is not None and src.flat.is_cuda:
+            absmax(src.flat, out=src.bound)
+
+
 def register_param_source(variables, flat):
     """FlatOptimizer: every variable it owns takes its bound from one measurement of the flat buffer."""
     import weakref
     src = _ParamSource(flat)
+    flat._ams_src = src
     for v in variables:
         v._ams_amax_src = src
     _SOURCES.append(weakref.ref(src))
@@ -1187,22 +1206,49 @@ def _guard(p, guard):
     return ring_error_word(p.device) if guard is None else guard
 
 
+def _slots_args(p):
+    """(amax_slots, bound_out) of the optimizer entry points: the parameter source that owns flat buffer `p` gets its bound kept current."""
+    src = getattr(p, '_ams_src', None)
+    if src is None or not F16X3:
+        return _vp(0), _vp(0)
+    src.rolled = True
+    return _p(src.next), _p(src.bound)
+
+
 def opt_amsgrad(p, g, m, v, vhat, lr_t, beta1, beta2, eps, grad_scale=1.0, guard=None):
     _chk(p, g, m, v, vhat)
     check(load().ams_opt_amsgrad(_p(p), _p(g), _p(m), _p(v), _p(vhat), p.numel(), lr_t, beta1, beta2, eps, grad_scale,
-                                 _p(_guard(p, guard)), _s()), 'ams_opt_amsgrad')
+                                 _p(_guard(p, guard)), *_slots_args(p), _s()), 'ams_opt_amsgrad')
 
 
 def opt_rmsprop(p, g, ms, lr, decay=0.9, eps=1e-10, grad_scale=1.0, guard=None):
     _chk(p, g, ms)
-    check(load().ams_opt_rmsprop(_p(p), _p(g), _p(ms), p.numel(), lr, decay, eps, grad_scale, _p(_guard(p, guard)), _s()),
+    check(load().ams_opt_rmsprop(_p(p), _p(g), _p(ms), p.numel(), lr, decay, eps, grad_scale, _p(_guard(p, guard)), *_slots_args(p), _s()),
           'ams_opt_rmsprop')
 
 
 def opt_momentum(p, g, acc, lr, momentum=0.9, grad_scale=1.0, guard=None):
     _chk(p, g, acc)
-    check(load().ams_opt_momentum(_p(p), _p(g), _p(acc), p.numel(), lr, momentum, grad_scale, _p(_guard(p, guard)), _s()),
+    check(load().ams_opt_momentum(_p(p), _p(g), _p(acc), p.numel(), lr, momentum, grad_scale, _p(_guard(p, guard)), *_slots_args(p), _s()),
           'ams_opt_momentum')
+
+
+_STAGE = {}
+
+
+def stage_inputs(src, dst, src2=None, dst2=None, want_amax=True):
+    """dst <- src (flat fp32, 16-byte aligned), dst2 <- src2 (any small contiguous pair), and a persistent 1-element tensor holding
+    max |src| (None when not wanted / fp16x3 off): one launch (include/ams.h: ams_stage_inputs)."""
+    lib = load()
+    k = (dst.device.index, dst.data_ptr())
+    st = _STAGE.get(k)
+    if st is None:
+        n = int(lib.ams_stage_inputs_scratch_bytes())
+        st = _STAGE[k] = (torch.zeros(n // 4, dtype=torch.int32, device=dst.device), torch.zeros(1, dtype=torch.float32, device=dst.device))
+    am = st[1] if (want_amax and F16X3) else None
+    n2 = src2.numel() * src2.element_size() if src2 is not None else 0
+    check(lib.ams_stage_inputs(_p(src), _p(dst), src.numel(), _p(src2), _p(dst2), n2, _p(am), _p(st[0]), _s()), 'ams_stage_inputs')
+    return am
 
 
 def sumsq(x):

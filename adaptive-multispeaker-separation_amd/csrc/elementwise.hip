@@ -268,40 +268,91 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, float* __res
     out[c] = accumulate ? out[c] + s : s;
 }
 
+// max |p| of what an optimizer kernel has just written, for the NEXT step's fp16x3 products (ops.param_amax), folded into `bound` by
+// the launch itself: per thread in the update loop; per block one atomicMax into slot blockIdx & 63 (2048 blocks finishing together
+// on ONE address are served one after another, ~10 ns each; 64 addresses are not); the block that completes its slot's group counts
+// the group in, and the block that completes the last group folds the 64 slots into bound[0] and clears slots and tickets.
+// slots: [0, 64) maxima, [64, 128) group tickets, [128] final ticket -- zero before the first launch, left zero.
+constexpr int AMS_BOUND_SLOTS = 64;
+__device__ __forceinline__ void block_amax_finish(unsigned m, unsigned* __restrict__ slots, float* __restrict__ bound) {
+    __shared__ unsigned sm_amax[4];
+    __shared__ int sm_last;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) sm_amax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned s = blockIdx.x & (AMS_BOUND_SLOTS - 1);
+        const unsigned old = atomicMax(slots + s, max(max(sm_amax[0], sm_amax[1]), max(sm_amax[2], sm_amax[3])));
+        asm volatile("" :: "v"(old));                   // returned: the maximum is in place before this block is counted in
+        const unsigned in_group = (gridDim.x - s + AMS_BOUND_SLOTS - 1) / AMS_BOUND_SLOTS;
+        int last = 0;
+        if (atomicAdd(slots + AMS_BOUND_SLOTS + s, 1u) == in_group - 1u) {
+            const unsigned groups = min(gridDim.x, (unsigned)AMS_BOUND_SLOTS);
+            last = atomicAdd(slots + 2 * AMS_BOUND_SLOTS, 1u) == groups - 1u;
+        }
+        sm_last = last;
+    }
+    __syncthreads();
+    if (sm_last && threadIdx.x < AMS_BOUND_SLOTS) {
+        unsigned t = __hip_atomic_load(slots + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slots + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(slots + AMS_BOUND_SLOTS + threadIdx.x, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t = max(t, (unsigned)__shfl_xor((int)t, o));
+        if (threadIdx.x == 0) {
+            __hip_atomic_store(slots + 2 * AMS_BOUND_SLOTS, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (t != 0u) bound[0] = __uint_as_float(t);
+        }
+    }
+}
+
 // ---- optimizers (reference utils/ops.py:686-703; TF RMSProp/Momentum) ----
 __global__ void amsgrad_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                float* __restrict__ vh, long n, float lr_t, float b1, float b2, float eps, float gscale,
-                               const unsigned* __restrict__ skip) {
+                               const unsigned* __restrict__ skip, unsigned* __restrict__ amax_slots, float* __restrict__ bound) {
     // skip: a recurrence launch of this step gave up a bounded wait (csrc/lstm_ring.hip, sticky error word): its gradients are
     // garbage -- leave parameters and slots untouched so that the caller can repeat the step on the per-step kernels
     if (skip && *skip != 0u) return;
+    unsigned am = 0u;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
         const float mi = b1 * m[i] + (1.0f - b1) * gi;
         const float vi = b2 * v[i] + (1.0f - b2) * gi * gi;
         const float vhi = fmaxf(vi, vh[i]);
         m[i] = mi; v[i] = vi; vh[i] = vhi;
-        p[i] -= lr_t * mi / (sqrtf(vhi) + eps);
+        const float pn = p[i] - lr_t * mi / (sqrtf(vhi) + eps);
+        p[i] = pn;
+        am = max(am, __float_as_uint(pn) & 0x7fffffffu);
     }
+    if (amax_slots) block_amax_finish(am, amax_slots, bound);
 }
 __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ ms, long n, float lr,
-                               float decay, float eps, float gscale, const unsigned* __restrict__ skip) {
+                               float decay, float eps, float gscale, const unsigned* __restrict__ skip, unsigned* __restrict__ amax_slots, float* __restrict__ bound) {
     if (skip && *skip != 0u) return;
+    unsigned am = 0u;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
         const float s = decay * ms[i] + (1.0f - decay) * gi * gi;
         ms[i] = s;
-        p[i] -= lr * gi / sqrtf(s + eps);
+        const float pn = p[i] - lr * gi / sqrtf(s + eps);
+        p[i] = pn;
+        am = max(am, __float_as_uint(pn) & 0x7fffffffu);
     }
+    if (amax_slots) block_amax_finish(am, amax_slots, bound);
 }
 __global__ void momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ acc, long n, float lr,
-                                float mom, float gscale, const unsigned* __restrict__ skip) {
+                                float mom, float gscale, const unsigned* __restrict__ skip, unsigned* __restrict__ amax_slots, float* __restrict__ bound) {
     if (skip && *skip != 0u) return;
+    unsigned am = 0u;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float a = mom * acc[i] + g[i] * gscale;
         acc[i] = a;
-        p[i] -= lr * a;
+        const float pn = p[i] - lr * a;
+        p[i] = pn;
+        am = max(am, __float_as_uint(pn) & 0x7fffffffu);
     }
+    if (amax_slots) block_amax_finish(am, amax_slots, bound);
 }
 
 // sum of squares -> per-block partials -> single value (deterministic two-stage)
@@ -357,6 +408,60 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x
     if (threadIdx.x == 0) atomicMax(out, max(max(sm[0], sm[1]), max(sm[2], sm[3])));
 }
 
+// One batch into the static buffers of a captured step, and max |x| of it on the way: dst[0..n) = src[0..n) (16-byte loads), the second,
+// small pair (the speaker indices) by block 0, per-block maxima as write-through stores, and the block that arrives last folds them
+// (the last-arriver form of csrc/dpcl.hip: workgroup-scope release before the ticket, agent-scope loads of the partials).
+// scratch: [0] ticket (zero on entry, left zero), [1 .. 1 + gridDim.x) partials.
+__global__ __launch_bounds__(256) void stage_inputs_kernel(const float* __restrict__ src, float* __restrict__ dst, long n,
+                                                           const unsigned char* __restrict__ src2, unsigned char* __restrict__ dst2, long n2,
+                                                           float* __restrict__ amax_out, unsigned* __restrict__ scratch) {
+    __shared__ unsigned sm[4];
+    __shared__ int last_sh;
+    unsigned m = 0u;
+    const long n4 = n / 4, stride = (long)gridDim.x * 256;
+    const uint4* s4 = reinterpret_cast<const uint4*>(src);
+    uint4* d4 = reinterpret_cast<uint4*>(dst);
+    long i = (long)blockIdx.x * 256 + threadIdx.x;
+    auto fold = [&](const uint4& v) {
+        m = max(max(m, v.x & 0x7fffffffu), max(max(v.y & 0x7fffffffu, v.z & 0x7fffffffu), v.w & 0x7fffffffu));
+    };
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        uint4 v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = s4[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { d4[i + k * stride] = v[k]; fold(v[k]); }
+    }
+    for (; i < n4; i += stride) { const uint4 v = s4[i]; d4[i] = v; fold(v); }
+    for (long j = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; j < n; j += stride) { dst[j] = src[j]; m = max(m, __float_as_uint(src[j]) & 0x7fffffffu); }
+    if (blockIdx.x == 0)
+        for (long j = threadIdx.x; j < n2; j += 256) dst2[j] = src2[j];
+    if (!amax_out) return;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(scratch + 1 + blockIdx.x, max(max(sm[0], sm[1]), max(sm[2], sm[3])), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        last_sh = (atomicAdd(scratch, 1u) == gridDim.x - 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!last_sh) return;
+    unsigned t = 0u;
+    for (unsigned b = threadIdx.x; b < gridDim.x; b += 256) t = max(t, __hip_atomic_load(scratch + 1 + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) t = max(t, (unsigned)__shfl_xor((int)t, o));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        amax_out[0] = __uint_as_float(max(max(sm[0], sm[1]), max(sm[2], sm[3])));
+        __hip_atomic_store(scratch, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 // one device-clock stamp (constant 100 MHz counter): brackets a launch INSIDE a captured hipGraph, where HIP events cannot be read back
 __global__ void stamp_kernel(unsigned long long* __restrict__ buf, int slot) { buf[slot] = wall_clock64(); }
 
@@ -372,6 +477,19 @@ ams_status ams_absmax_f32(const float* x, long n, float* out, void* stream) {
     if (blocks < 1) blocks = 1;                     // arrive at one address at about the same time and are served one after another
     if (blocks > AMS_ABSMAX_BLOCKS) blocks = AMS_ABSMAX_BLOCKS;
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, (unsigned*)out);
+    return ams_check_launch();
+}
+
+size_t ams_stage_inputs_scratch_bytes(void) { return (1 + 512) * sizeof(unsigned); }
+ams_status ams_stage_inputs(const float* src, float* dst, long n, const void* src2, void* dst2, long n2_bytes, float* amax_out,
+                            void* scratch, void* stream) {
+    AMS_REQUIRE(src && dst && n > 0 && (n2_bytes == 0 || (src2 && dst2)) && (!amax_out || scratch));
+    AMS_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0);
+    long blocks = (n / 4 + 255) / 256 / 4;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 512) blocks = 512;
+    hipLaunchKernelGGL(stage_inputs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n, (const unsigned char*)src2,
+                       (unsigned char*)dst2, n2_bytes, amax_out, (unsigned*)scratch);
     return ams_check_launch();
 }
 
@@ -475,26 +593,26 @@ ams_status ams_colsum(const float* x, float* out, long rows, int cols, long ld, 
 }
 
 ams_status ams_opt_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, long n, float lr_t, float beta1,
-                           float beta2, float eps, float grad_scale, const void* skip_if_set, void* stream) {
+                           float beta2, float eps, float grad_scale, const void* skip_if_set, void* amax_slots, float* bound_out, void* stream) {
     AMS_REQUIRE(p && g && m && v && vhat && n > 0);
     hipLaunchKernelGGL(amsgrad_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vhat, n, lr_t, beta1,
-                       beta2, eps, grad_scale, (const unsigned*)skip_if_set);
+                       beta2, eps, grad_scale, (const unsigned*)skip_if_set, bound_out ? (unsigned*)amax_slots : nullptr, bound_out);
     return ams_check_launch();
 }
 
 ams_status ams_opt_rmsprop(float* p, const float* g, float* ms, long n, float lr, float decay, float eps, float grad_scale,
-                           const void* skip_if_set, void* stream) {
+                           const void* skip_if_set, void* amax_slots, float* bound_out, void* stream) {
     AMS_REQUIRE(p && g && ms && n > 0);
     hipLaunchKernelGGL(rmsprop_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, ms, n, lr, decay, eps, grad_scale,
-                       (const unsigned*)skip_if_set);
+                       (const unsigned*)skip_if_set, bound_out ? (unsigned*)amax_slots : nullptr, bound_out);
     return ams_check_launch();
 }
 
 ams_status ams_opt_momentum(float* p, const float* g, float* accum, long n, float lr, float momentum, float grad_scale,
-                            const void* skip_if_set, void* stream) {
+                            const void* skip_if_set, void* amax_slots, float* bound_out, void* stream) {
     AMS_REQUIRE(p && g && accum && n > 0);
     hipLaunchKernelGGL(momentum_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, accum, n, lr, momentum, grad_scale,
-                       (const unsigned*)skip_if_set);
+                       (const unsigned*)skip_if_set, bound_out ? (unsigned*)amax_slots : nullptr, bound_out);
     return ams_check_launch();
 }
 

@@ -31,7 +31,7 @@ namespace {
 //   amax_out: the launch leaves max |C| there (bit pattern; the caller zeroes it)
 struct LaunchOpt { const float* amax_a = nullptr; const float* amax_b = nullptr; int lds_pad = 0; void* sk_scratch = nullptr; size_t sk_bytes = 0;
                    unsigned* amax_out = nullptr; int force_cfg = -1; };
-constexpr size_t AMS_SK_FLAG_BYTES = 4096;       // 1024 workgroup flags
+constexpr size_t AMS_SK_FLAG_BYTES = 8192;       // ints [0, 512) stream-K flags, [512, 1024) per-workgroup output maxima, [1024] their ticket
 constexpr size_t AMS_SK_SLOT_BYTES = (128 * 256 + 256) * sizeof(float);     // the largest tile (128 x 256) + its column sums
 std::atomic<int> g_gemm_arith{-1};        // -1: not chosen yet (AMS_GEMM_X6, default 1), 0: native f32 MFMA, 1: bf16x6
 
@@ -129,6 +129,7 @@ struct GemmArgs {
     // sk_slot_floats floats each
     int sk_rounds; int* sk_flags; float* sk_slots; int sk_slot_floats;
     int c_vec;                 // C (and the partial slabs, bias) are 16-byte addressable along n: the x6 epilogue stores rows as float4 through LDS
+    int amax_fold;             // amax_out is folded inside the launch through sk_flags[512 ..] (else: atomicMax on a word the entry point cleared)
     unsigned* amax_out;        // != NULL: atomicMax of the bit patterns of |C| as stored (one atomic per workgroup and tile)
 };
 
@@ -783,8 +784,9 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
         }
     } else if (PERSIST) dp_count = (n_items - (int)blockIdx.x + G - 1) / G;
     const int n_work = dp_count + nseg;
-    if (n_work <= 0) return;
+    if (n_work <= 0 && !(EPI == EPI_STORE && g0.amax_out != nullptr && g0.amax_fold)) return;
     int role = W_FULL, own_tile = 0;
+    float vmax_wg = 0.f;                            // max |C| over this workgroup's stores (g0.amax_out)
 
     // SEP: two accumulator sets (64 x 64 waves, launches that are not residency-capped -- with 64 more VGPRs a workgroup no longer
     // shares a CU with a recurrence ring): hi.hi goes to `acc`, the five small partial products to `accs`, added once in the epilogue.  The bf16 MFMA adds its 16 products to the accumulator with the bits below its internal
@@ -1043,7 +1045,7 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
     };
 
     fetch(0);
-    for (;;) {                                      // one work item per trip; every branch below is workgroup-uniform
+    for (; n_work > 0;) {                           // one work item per trip; every branch below is workgroup-uniform
         lane_consts();
         X6_STAMP(0);
 #pragma unroll
@@ -1245,11 +1247,7 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
                     }
                 }
             }
-            if (g0.amax_out != nullptr) {
-                // max |C| of this tile: one atomic per wave (NaN: fmaxf drops it -- a NaN output reaches the caller through C itself)
-                vmax = wave_max(vmax);
-                if (lane == 0) atomicMax(g0.amax_out, __float_as_uint(vmax));
-            }
+            vmax_wg = fmaxf(vmax_wg, vmax);
         }
         X6_STAMP(5);
 #if AMS_X6_STAMP
@@ -1258,6 +1256,48 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
         if (!more) break;
         if (!PERSIST) { __syncthreads(); setup(wi + 1); fetch(0); }
         ++wi;
+    }
+    if (EPI == EPI_STORE && g0.amax_out != nullptr) {
+        // max |C| of the launch.  With the caller's scratch (sk_flags): every workgroup leaves its maximum as a write-through store,
+        // counts itself in, and the LAST one folds them into amax_out[0] and zeroes words and ticket again -- nothing to clear in
+        // front of the launch, gridDim.x stores instead of that many atomics on one word.  Without scratch: atomicMax on a word the
+        // entry point cleared.  (NaN: fmaxf drops it -- a NaN output reaches the caller through C itself.)
+        __syncthreads();
+        float* const sm = reinterpret_cast<float*>(smem);
+        int* const sl = reinterpret_cast<int*>(smem) + 16;
+        const float wmax = wave_max(vmax_wg);
+        if (lane == 0) sm[wave] = wmax;
+        __syncthreads();
+        if (tid == 0) {
+            float t = 0.f;
+            for (int w = 0; w < NT / 64; ++w) t = fmaxf(t, sm[w]);
+            if (!g0.amax_fold) { atomicMax(g0.amax_out, __float_as_uint(t)); *sl = 0; }
+            else {
+                unsigned* const part = reinterpret_cast<unsigned*>(g0.sk_flags) + 512;
+                __hip_atomic_store(part + blockIdx.x, __float_as_uint(t), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                *sl = __hip_atomic_fetch_add(part + 512, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1u;
+            }
+        }
+        __syncthreads();
+        if (*sl) {
+            unsigned* const part = reinterpret_cast<unsigned*>(g0.sk_flags) + 512;
+            unsigned t = 0u;
+            for (int b = tid; b < G; b += NT) {
+                t = max(t, __hip_atomic_load(part + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                __hip_atomic_store(part + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) t = max(t, (unsigned)__shfl_xor((int)t, o));
+            __syncthreads();
+            if (lane == 0) reinterpret_cast<unsigned*>(sm)[wave] = t;
+            __syncthreads();
+            if (tid == 0) {
+                for (int w = 1; w < NT / 64; ++w) t = max(t, reinterpret_cast<unsigned*>(sm)[w]);
+                g0.amax_out[0] = t;
+                __hip_atomic_store(part + 512, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
 }
 
@@ -1410,7 +1450,7 @@ struct SkPlan { int rounds = -1; unsigned grid = 0; double t = 1e30; };
 inline SkPlan sk_plan(int tiles_all, int K, const TilePlan& tp, int wgcu) {
     SkPlan p;
     const int G = (device_cus() + 7) / 8 * 8 * wgcu;
-    if (G > (int)(AMS_SK_FLAG_BYTES / sizeof(int)) || tiles_all < 8) return p;
+    if (G > 512 || tiles_all < 8) return p;
     const int Gx = G / 8, q = tiles_all / 8, nkf = ceil_div(K, tp.bk);
     const int R = q / Gx;
     const int n_max = q - R * Gx + (tiles_all % 8 ? 1 : 0);                // left-over tiles of the fullest XCD
@@ -1462,7 +1502,7 @@ ams_status launch(GemmArgs& g, const LaunchOpt& opt, void* ws, size_t ws_bytes, 
     if (x6 && cfg == 0) { wgcu = capped ? 163840 / (17152 + lds_pad) : 2; if (wgcu < 1) wgcu = 1; if (wgcu > 2) wgcu = 2; }
     // stream-K instead of whole-tile rounds / split-K slabs (x6_body), where the caller lent scratch and the model prefers it
     SkPlan sk;
-    g.sk_rounds = -1; g.sk_flags = nullptr; g.sk_slots = nullptr; g.sk_slot_floats = 0;
+    g.sk_rounds = -1; g.sk_flags = nullptr; g.sk_slots = nullptr; g.sk_slot_floats = 0; g.amax_fold = 0;
     if (x6 && cfg != 1 && (!capped || AMS_SK_CAPPED) && opt.sk_scratch && tuning().sk != 0 && tuning().splits <= 0 && AMS_GEMM_XCD_FLAT) {
         sk = sk_plan(tiles * nbatch, g.K, tp, wgcu);
         const size_t slot = (size_t)(tp.bm * tp.bn + tp.bn) * sizeof(float);
@@ -1471,7 +1511,8 @@ ams_status launch(GemmArgs& g, const LaunchOpt& opt, void* ws, size_t ws_bytes, 
         // only the TAIL of a launch with whole rounds (mode 1): a launch of fewer tiles than workgroups gains ~6 % of k-tiles from an even
         // share and pays it back in a second item per workgroup, the owner's wait and 256 instead of 240 busy CUs (tools/gemm_anatomy.py:
         // dense dX 322 vs 317 us, LSTM dX 90 vs 75; in the step 2.861 ms either way, 2.90 with stream-K everywhere, 2.886 without)
-        if (sk.rounds == 0 && tuning().sk == 1) sk.rounds = -1;
+        // (a launch that measures its output cannot be cut into k-split slabs: there the even share is the only way to fill the chip)
+        if (sk.rounds == 0 && tuning().sk == 1 && !opt.amax_out) sk.rounds = -1;
         if (sk.rounds >= 0) {
             splits = 1;
             g.sk_rounds = sk.rounds;
@@ -1495,6 +1536,16 @@ ams_status launch(GemmArgs& g, const LaunchOpt& opt, void* ws, size_t ws_bytes, 
     dim3 grid((unsigned)((long)tiles * splits * nbatch));
     const bool prio_off = tuning().noprio;
     g.hiprio = (!capped && !prio_off) ? 1 : 0;
+    if (g.amax_out) {
+        // the launch folds its output maximum itself when the caller lent scratch (words [512, 1025) of its flag area) and the grid fits
+        unsigned gx = grid.x;
+        if (sk.rounds >= 0) gx = sk.grid;
+        else if (x6 && tuning().x6persist > 0 && !capped && cfg != 1) { const long cap = (long)((device_cus() + 7) / 8 * 8) * (cfg == 0 ? 2 : 1) * tuning().x6persist; if ((long)gx > cap) gx = (unsigned)cap; }
+        if (opt.sk_scratch && opt.sk_bytes >= AMS_SK_FLAG_BYTES && gx <= 512 && (((uintptr_t)opt.sk_scratch) & 15) == 0) {
+            g.amax_fold = 1;
+            g.sk_flags = (int*)opt.sk_scratch;
+        } else if (hipMemsetAsync(g.amax_out, 0, sizeof(float), st) != hipSuccess) return AMS_E_LAUNCH_FAILED;
+    }
     // Occupancy cap for launches that are meant to run BESIDE latency-critical kernels (weight-gradient products on
     // the side stream): unused dynamic LDS limits how many of these workgroups a CU admits, leaving registers/slots
     // for the recurrence.  An explicit argument of the entry points (LaunchOpt::lds_pad).
@@ -1657,7 +1708,7 @@ size_t ams_front_conv_fwd_workspace_bytes(int Bt, int L, int W, int N, int hop) 
 // ws (may be NULL: no split-K) lets the few-tile benchmark shape (5120 x 256 output = 80 tiles) fill 256 CUs.
 // amax_x / amax_f (both or neither): operand bounds -> fp16x3, and the tile configuration that needs no split-K at the benchmark
 // shape (128 x 128: 240 tiles).  amax_y (optional, 16-bit-pipe launches only): the launch leaves max |y| there (cleared by a 4-byte
-// memset node in front of it) -- the bound the next product wants, without a pass over y.
+// memset node in front of it when the caller lends no scratch) -- the bound the next product wants, without a pass over y.
 ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, const float* amax_x,
                               const float* amax_f, float* amax_y, int lds_pad, void* ws, size_t ws_bytes, void* sk_scratch,
                               size_t sk_bytes, void* stream) {
@@ -1687,10 +1738,7 @@ ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, 
             if (t < best) { best = t; o.force_cfg = c; }
         }
     }
-    if (amax_y) {
-        if (hipMemsetAsync(amax_y, 0, sizeof(float), (hipStream_t)stream) != hipSuccess) return AMS_E_LAUNCH_FAILED;
-        o.amax_out = reinterpret_cast<unsigned*>(amax_y);
-    }
+    if (amax_y) o.amax_out = reinterpret_cast<unsigned*>(amax_y);
     return launch<A_FRAMES, B_ROW>(g, o, ws, ws_bytes, (hipStream_t)stream);
 }
 int ams_front_conv_fwd_measures_output(void) { return use_x6() ? 1 : 0; }

@@ -48,7 +48,12 @@ class Adapt(Network):
                         and xm.untyped_storage().data_ptr() == xn.untyped_storage().data_ptr()):
                     # the hipGraph step keeps its static inputs back to back in ONE buffer (models/network.py): the concatenation
                     # already exists -- a view instead of a 15.7 MB copy per step
-                    return torch.as_strided(xm, (xm.shape[0] + xn.numel() // L, L), (L, 1))
+                    x = torch.as_strided(xm, (xm.shape[0] + xn.numel() // L, L), (L, 1))
+                    am = getattr(xm, '_ams_x_amax', None)
+                    if am is not None:                       # the staging launch measured max |waveform| on the way (Network._stage)
+                        from ams_hip import ops as K
+                        K.tag_amax(x, am)
+                    return x
                 return torch.cat([xm, xn.reshape(-1, L)], dim=0)
             self.x = Node('x', _x)
 
@@ -70,7 +75,30 @@ class Adapt(Network):
         self.window_filter = get_scope_variable('window', 'w', shape=(self.window,), initializer=xavier_uniform)
         self.bases = get_scope_variable('bases', 'bases', shape=(self.window, self.N), initializer=xavier_uniform)
         w, bases, x = self.window_filter, self.bases, self.x
-        self.conv_filter = Node('conv_filter', lambda run: F.front_filter(w, bases))
+        cache = {}
+
+        def _filt(run):
+            # A FROZEN front (front_* recipes, adapt.py:443-455 / utils/trainer.py:587-588): |w| * bases and its bound are constants of
+            # the run.  Eager passes still derive them (into persistent buffers: always fresh); a pass that is being CAPTURED takes the
+            # buffers as they are -- no filter launch, no measurement in the replayed step -- and a restore refreshes them
+            # (Network._weights_written bumps weights_epoch; the next eager pass, or the capture's warm-up, recomputes).
+            if w.is_cuda and not (w.requires_grad or bases.requires_grad):
+                from ams_hip import ops as K
+                epoch = getattr(get_default_graph(), 'weights_epoch', 0)
+                if cache.get('epoch') == epoch and torch.cuda.is_current_stream_capturing():
+                    return cache['f']
+                f = F.front_filter(w.detach(), bases.detach())
+                if 'f' not in cache or cache['f'].shape != f.shape:
+                    cache['f'] = torch.empty_like(f)
+                    cache['amax'] = torch.zeros(1, dtype=torch.float32, device=f.device)
+                cache['f'].copy_(f)
+                if K.F16X3:
+                    K.absmax(cache['f'], out=cache['amax'])
+                    K.tag_amax(cache['f'], cache['amax'])
+                cache['epoch'] = epoch
+                return cache['f']
+            return F.front_filter(w, bases)
+        self.conv_filter = Node('conv_filter', _filt)
         filt = self.conv_filter
         hop, P = self.hop_size, self.max_pool_value
 

@@ -169,6 +169,7 @@ class Network(object):
                     arr = arr.reshape(tuple(v.shape))
                 v.data.copy_(torch.from_numpy(arr.astype(np.float32)).to(v.device))
                 g.initialized.add(name)
+            self._weights_written()
             return
         data = np.load(self._latest_checkpoint(path))
         for name in self.saver:
@@ -178,6 +179,16 @@ class Network(object):
             v = g.variables[name]
             v.data.copy_(torch.from_numpy(data[key]).to(v.device))
             g.initialized.add(name)
+        self._weights_written()
+
+    @staticmethod
+    def _weights_written():
+        """Variables were written by something other than an optimizer kernel: what captured steps keep across replays instead of
+        re-deriving it from the weights (the weights' operand bound, a frozen front's filter) must be refreshed."""
+        g = get_default_graph()
+        g.weights_epoch = getattr(g, 'weights_epoch', 0) + 1
+        if torch.cuda.is_available():
+            K.param_bounds_dirty()
 
     def restore_last_checkpoint(self):
         self.restore_model(self._dir())
@@ -269,6 +280,25 @@ class Network(object):
             return [sm, sn] + [t.clone() for t in ins[2:]]
         return [t.clone() for t in ins]
 
+    def _stage(self, static, ins):
+        """This batch into the static buffers of the captured step.  x_mix and x_non_mix adjacent on both sides (_static_like; the
+        synthetic pool stores them so): ONE launch moves them, the small third input (speaker indices) with them, and leaves
+        max |waveform| -- the front product's operand bound -- on the way (K.stage_inputs); anything else: plain copies."""
+        pairs = list(zip(static, ins))
+        if (self._back_to_back(static[0], static[1]) and self._back_to_back(ins[0], ins[1]) and ins[0].is_cuda
+                and ins[0].dtype == torch.float32 and ins[0].data_ptr() % 16 == 0 and static[0].data_ptr() % 16 == 0):
+            n = ins[0].numel() + ins[1].numel()
+            src2 = dst2 = None
+            rest = pairs[2:]
+            if len(rest) == 1 and rest[0][1].is_contiguous() and rest[0][0].is_contiguous() and rest[0][1].numel() * rest[0][1].element_size() <= 65536:
+                dst2, src2 = rest[0]
+                rest = []
+            am = K.stage_inputs(torch.as_strided(ins[0], (n,), (1,)), torch.as_strided(static[0], (n,), (1,)), src2, dst2)
+            static[0]._ams_x_amax = am              # models/adapt.py::Adapt._x tags the concatenated view with it
+            pairs = rest
+        for dst, src in pairs:
+            dst.copy_(src)
+
     def _train_graphed(self, feed_dict, step):
         """Capture zero_grad + forward + backward once (after 2 eager steps) and replay it; inputs are copied into
         static buffers, the optimizer (per-step lr_t, all-reduce) stays outside the graph.
@@ -297,6 +327,7 @@ class Network(object):
                 self.last_run = run
                 return cost.detach().reshape(-1)[0]
             st['static'] = self._static_like(ins)
+            self._stage(st['static'], ins)          # (also attaches the waveforms' bound to the static buffer before the capture reads it)
             run = self._feeds(feed_dict, True)
             for node, t in zip((self.x_mix, self.x_non_mix, self.I), st['static']):
                 run.cache[id(node)] = t
@@ -309,14 +340,7 @@ class Network(object):
                 self._backward(cost)
                 F.OVERLAP.join()
             st['graph'], st['cost'], st['run'] = g, cost, run
-        pairs = list(zip(st['static'], ins))
-        if self._back_to_back(st['static'][0], st['static'][1]) and self._back_to_back(ins[0], ins[1]):
-            # x_mix and x_non_mix adjacent on both sides (_static_like; the synthetic pool stores them so): one copy
-            n = ins[0].numel() + ins[1].numel()
-            torch.as_strided(st['static'][0], (n,), (1,)).copy_(torch.as_strided(ins[0], (n,), (1,)))
-            pairs = pairs[2:]
-        for dst, src in pairs:
-            dst.copy_(src)
+        self._stage(st['static'], ins)
         for hook in get_default_graph().pre_replay_hooks:      # host-drawn inputs of captured kernels (k-means seeds)
             hook()
         st['graph'].replay()

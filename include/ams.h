@@ -96,7 +96,7 @@ ams_status ams_synth_unpool_bwd_vals(const float* dout, const int32_t* pos, cons
  *   sk_scratch, sk_bytes   (ABI 3; optional) ams_gemm_sk_scratch_bytes() bytes the launch may use for STREAM-K: instead of whole-tile
  *                    rounds plus split-K slabs, every resident workgroup takes an equal share of the k-tiles of the tiles that do not
  *                    fill a round, partial tiles meet in this scratch inside the launch (fixed order: deterministic) -- no slabs, no
- *                    reduce launch, no idle tail round (csrc/gemm.hip: x6_body).  Contract: the first 4096 bytes are ZERO when the
+ *                    reduce launch, no idle tail round (csrc/gemm.hip: x6_body).  Contract: the first 8192 bytes are ZERO when the
  *                    first launch sees them and every launch leaves them zero; launches sharing one scratch must be ordered on one
  *                    stream (one scratch per stream).  NULL: whole tiles / split-K as before.  AMS_GEMM_SK=0 ignores it.
  * Arithmetic without bounds (process-wide; default 1, or AMS_GEMM_X6 read once; ams_gemm_set_arith for tests and A/B runs): 1 =
@@ -288,11 +288,22 @@ ams_status ams_sumsq_bwd(const float* x, const float* upstream, float scale, flo
 
 /* ---- K24  optimizers     models/network.py:181-194, utils/ops.py:686-703 ---- */
 ams_status ams_opt_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, long n, float lr_t, float beta1,
-                           float beta2, float eps, float grad_scale, const void* skip_if_set, void* stream);
+                           float beta2, float eps, float grad_scale, const void* skip_if_set, void* amax_slots, float* bound_out, void* stream);
 ams_status ams_opt_rmsprop(float* p, const float* g, float* ms, long n, float lr, float decay, float eps, float grad_scale,
-                           const void* skip_if_set, void* stream);
+                           const void* skip_if_set, void* amax_slots, float* bound_out, void* stream);
 ams_status ams_opt_momentum(float* p, const float* g, float* accum, long n, float lr, float momentum, float grad_scale,
-                            const void* skip_if_set, void* stream);
+                            const void* skip_if_set, void* amax_slots, float* bound_out, void* stream);
+/* amax_slots + bound_out (optional, both or neither; amax_slots = 192 uint32 of scratch, zero before the first use, left zero): the
+ * kernels also leave bound_out[0] = max |p| of what they wrote (folded inside the launch by the last block to finish; a step whose update
+ * was skipped leaves the bound as it was).  The fp16x3 products of the NEXT step scale the weights by that bound: no pass over the 47 MB
+ * of parameters in front of the first product (ops.param_amax; the measuring form is ams_absmax_f32). */
+/* One batch into the static input buffers of a captured step: dst[0..n) = src[0..n) (both 16-byte aligned), dst2 = src2 (n2_bytes, may be
+ * 0: the speaker indices), and amax_out[0] = max |src| (optional; scratch = ams_stage_inputs_scratch_bytes() bytes, first word zero on
+ * first use, left zero).  Replaces three copy launches and the pass that bounded the waveforms for the front product
+ * (models/network.py: the feed of inputs/mix_input, non_mix_input, indicies -- reference models/network.py:44-85). */
+size_t ams_stage_inputs_scratch_bytes(void);
+ams_status ams_stage_inputs(const float* src, float* dst, long n, const void* src2, void* dst2, long n2_bytes, float* amax_out,
+                            void* scratch, void* stream);
 ams_status ams_sumsq(const float* x, float* out, long n, void* ws, size_t ws_bytes, void* stream);
 /* measurement aid: buf[slot] (uint64) = the device's constant-rate wall clock when the stream reaches this point; ams_stamp_rate() =
  * its ticks per second.  Stamps bracket launches INSIDE a replayed hipGraph (HIP events recorded during capture cannot be read back). */

@@ -144,9 +144,11 @@ def test_nan_and_inf_propagate(ops):
 
 
 def test_the_training_step_takes_fp16x3_wherever_bounds_are_at_hand(ops):
-    """A front_DPCL step at a shape whose products all take the 16-byte-fetch path: every product but the front conv (which has no
-    bounds) is launched with bounds -- a regression to bf16x6 would be silent otherwise -- and the only bounds MEASURED
-    by a pass of their own are the front output's and the weights' (dZ and dU bring theirs from the kernels that wrote them)."""
+    """A front_DPCL step at a shape whose products all take the 16-byte-fetch path: every product, the front conv included (round 5),
+    is launched with bounds -- a regression to bf16x6 would be silent otherwise -- and the only bounds MEASURED by a pass of their own
+    in an EAGER step are the waveforms', the frozen filter's and the weights' (a replayed step measures none of the three: the staging
+    launch, the frozen-filter cache and the optimizer kernel supply them); the front output's comes out of the conv launch, dZ and dU
+    bring theirs from the kernels that wrote them."""
     import tempfile
     from tests.smoke_step import build_front_dpcl
     tmp = tempfile.mkdtemp(prefix='ams_f16_step_')
@@ -175,5 +177,5 @@ def test_the_training_step_takes_fp16x3_wherever_bounds_are_at_hand(ops):
         ops.PROFILE.reset(False)
     assert np.isfinite(c)
     n16 = sum(t.startswith('gemm16') for t in tags)
-    assert n16 >= 10 and len(tags) - n16 <= 1, tags              # 2 projections, dense fwd/dX/dW, 1 LSTM dX, 2 dWx, 2 dU; front conv
-    assert len(calls) <= 2, calls                                 # the front output X and the optimizer's flat weight buffer
+    assert n16 >= 11 and len(tags) == n16, tags                  # front conv, 2 projections, dense fwd/dX/dW, 1 LSTM dX, 2 dWx, 2 dU
+    assert len(calls) <= 3, calls                                 # the waveforms, the frozen filter, the optimizer's flat weight buffer

@@ -52,13 +52,13 @@ def test_stream_k_is_the_same_product(ops, M, N, K, tA, tB, f16):
         ref = ref + bias.double().cpu().numpy()[None, :]
     bounds = (ops.absmax(A), ops.absmax(B)) if f16 else None
     sc = _scratch(ops, A)
-    sc[1024:].fill_(float('nan'))                                   # slots: a hole in the hand-off would show as NaN
+    sc[2048:].fill_(float('nan'))                                   # slots: a hole in the hand-off would show as NaN
     torch.cuda.synchronize()
     out = ops.gemm(A, B, transA=bool(tA), transB=bool(tB), bias=bias, amax=bounds)
     out2 = ops.gemm(A, B, transA=bool(tA), transB=bool(tB), bias=bias, amax=bounds)
     torch.cuda.synchronize()
-    assert int(sc[:1024].view(torch.int32).abs().sum()) == 0        # flags left zero
-    used = bool(torch.isfinite(sc[1024:]).any())
+    assert int(sc[:2048].view(torch.int32).abs().sum()) == 0        # flags left zero
+    used = bool(torch.isfinite(sc[2048:]).any())
     old, ops.SK = ops.SK, False
     try:
         plain = ops.gemm(A, B, transA=bool(tA), transB=bool(tB), bias=bias, amax=bounds)
