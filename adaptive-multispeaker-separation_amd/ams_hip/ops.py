@@ -324,8 +324,9 @@ class _RingArena(object):
         self.cleared = -1           # the pass whose pass_begin() zeroed the slots
         self.used = -1              # the last pass a ring launch asked for a slot
 
-    def begin(self, side_stream, device):
-        """Called by pass_begin() inside `with torch.cuda.stream(side_stream)`.  True when it enqueued the memset."""
+    def begin(self, side_stream, device, zero=True):
+        """Called by pass_begin() (inside `with torch.cuda.stream(side_stream)` when zero).  True when the slots are (being) cleared for this
+        pass; zero=False: the caller clears self.flat itself."""
         self.next = 0
         if not self.want or self.used < PASS[0] - 2:
             return False
@@ -339,7 +340,8 @@ class _RingArena(object):
             for n in sizes:
                 self.slots.append(self.flat[off // 4:(off + n) // 4])
                 off += n
-        self.flat.zero_()
+        if zero:
+            self.flat.zero_()
         self.cleared = PASS[0]
         return True
 
@@ -394,6 +396,9 @@ def await_pass_side():
     _await_pass_side()
 
 
+ROLL_BOUNDS = _os.environ.get('AMS_ROLL_BOUNDS', '1') != '0'
+
+
 def pass_begin(side_stream):
     """First node evaluation of a pass (graph.Node.value): work that depends on nothing the pass computes goes on the side stream,
     beside whatever the pass starts with (input staging, the front conv) -- the live optimizers' flat buffers are measured there
@@ -418,15 +423,38 @@ def pass_begin(side_stream):
     if ar is not None:
         ar.next = 0
     zeros = [t for t in _DEFER_ZERO if t.device == cur.device]
-    if not todo and not zeros and (ar is None or not ar.want or ar.used < PASS[0] - 2):
+    # sources whose bound the optimizer kernel keeps current (include/ams.h: bound_out) need nothing inside a captured step, where only
+    # that kernel writes the weights between replays
+    measure = [src for src in todo if not (src.rolled and ROLL_BOUNDS and torch.cuda.is_current_stream_capturing())]
+    for src in todo:
+        if src not in measure:
+            src.seen, src.event = PASS[0], None
+    if not measure and not zeros and (ar is None or not ar.want or ar.used < PASS[0] - 2):
+        return
+    if not measure:
+        # nothing but clearing: ONE launch on the pass's own stream.  As a second root branch of a captured step the two fills cost
+        # the replay a join of ~12 us in front of the first projection (profiles/r05_*), more than the ~12 us the launch takes.
+        _DEFER_ZERO[:] = [t for t in _DEFER_ZERO if t.device != cur.device]
+        arena = None
+        if ar is not None and ar.begin(cur, cur.device, zero=False):
+            arena = ar.flat
+        regs = [t for t in zeros] + ([arena] if arena is not None else [])
+        while regs:
+            a = regs.pop(0)
+            b = regs.pop(0) if regs else None
+            ok = all(r is None or (r.is_contiguous() and r.data_ptr() % 16 == 0 and (r.numel() * r.element_size()) % 16 == 0) for r in (a, b))
+            if ok:
+                check(load().ams_zero2(_p(a), a.numel() * a.element_size(), _p(b), (b.numel() * b.element_size()) if b is not None else 0, _s()),
+                      'ams_zero2')
+            else:
+                a.zero_()
+                if b is not None:
+                    b.zero_()
+        _PASS_SIDE.event, _PASS_SIDE.n, _PASS_SIDE.waited = None, PASS[0], set()
         return
     side_stream.wait_stream(cur)
     with torch.cuda.stream(side_stream):
-        for src in todo:
-            if src.rolled and ROLL_BOUNDS and torch.cuda.is_current_stream_capturing():
-                # inside a captured step only the optimizer writes these weights between replays, and its kernel leaves their bound
-                # in src.bound as it goes (include/ams.h: bound_out): nothing to measure, nothing to launch
-                continue
+        for src in measure:
             absmax(src.flat, out=src.bound)
         for t in zeros:
             t.zero_()
@@ -435,12 +463,9 @@ def pass_begin(side_stream):
             ar.begin(side_stream, cur.device)
         ev = torch.cuda.Event()
         ev.record(side_stream)
-    for src in todo:
+    for src in measure:
         src.seen, src.event = PASS[0], ev
     _PASS_SIDE.event, _PASS_SIDE.n, _PASS_SIDE.waited = ev, PASS[0], set()
-
-
-ROLL_BOUNDS = _os.environ.get('AMS_ROLL_BOUNDS', '1') != '0'
 
 
 def param_bounds_dirty():

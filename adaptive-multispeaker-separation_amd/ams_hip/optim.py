@@ -29,7 +29,8 @@ class FlatOptimizer(object):
         # instead of an all_reduce_max of the word followed by the all_reduce of the gradients.
         self._dp = dist is not None and getattr(dist, 'world_size', 1) > 1
         extra = 1 if (self._dp and dev.type == 'cuda') else 0
-        self._gbuf = torch.zeros(n + extra, dtype=torch.float32, device=dev)
+        # (padded to whole 16-byte groups: cleared by the fused zero launch at the head of a step, ops.pass_begin)
+        self._gbuf = torch.zeros((n + extra + 3) // 4 * 4, dtype=torch.float32, device=dev)
         self.flat_grad = self._gbuf[:n]
         self._errslot = self._gbuf[n:n + 1] if extra else None
         if self._errslot is not None:

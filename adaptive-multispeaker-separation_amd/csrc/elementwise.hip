@@ -462,6 +462,15 @@ __global__ __launch_bounds__(256) void stage_inputs_kernel(const float* __restri
     }
 }
 
+// zero two regions in one launch (16-byte stores; both 16-byte aligned, sizes multiples of 16)
+__global__ __launch_bounds__(256) void zero2_kernel(uint4* __restrict__ a, long na, uint4* __restrict__ b, long nb) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    const long stride = (long)gridDim.x * 256;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < na + nb; i += stride) {
+        if (i < na) a[i] = z; else b[i - na] = z;
+    }
+}
+
 // one device-clock stamp (constant 100 MHz counter): brackets a launch INSIDE a captured hipGraph, where HIP events cannot be read back
 __global__ void stamp_kernel(unsigned long long* __restrict__ buf, int slot) { buf[slot] = wall_clock64(); }
 
@@ -480,14 +489,25 @@ ams_status ams_absmax_f32(const float* x, long n, float* out, void* stream) {
     return ams_check_launch();
 }
 
-size_t ams_stage_inputs_scratch_bytes(void) { return (1 + 512) * sizeof(unsigned); }
+ams_status ams_zero2(void* a, size_t a_bytes, void* b, size_t b_bytes, void* stream) {
+    AMS_REQUIRE((a || a_bytes == 0) && (b || b_bytes == 0) && a_bytes % 16 == 0 && b_bytes % 16 == 0 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0);
+    const long n = (long)(a_bytes + b_bytes) / 16;
+    if (n == 0) return AMS_OK;
+    long blocks = (n + 255) / 256 / 8;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(zero2_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (uint4*)a, (long)a_bytes / 16, (uint4*)b, (long)b_bytes / 16);
+    return ams_check_launch();
+}
+
+size_t ams_stage_inputs_scratch_bytes(void) { return (1 + 1024) * sizeof(unsigned); }
 ams_status ams_stage_inputs(const float* src, float* dst, long n, const void* src2, void* dst2, long n2_bytes, float* amax_out,
                             void* scratch, void* stream) {
     AMS_REQUIRE(src && dst && n > 0 && (n2_bytes == 0 || (src2 && dst2)) && (!amax_out || scratch));
     AMS_REQUIRE((((uintptr_t)src | (uintptr_t)dst) & 15) == 0);
     long blocks = (n / 4 + 255) / 256 / 4;
     if (blocks < 1) blocks = 1;
-    if (blocks > 512) blocks = 512;
+    if (blocks > 1024) blocks = 1024;
     hipLaunchKernelGGL(stage_inputs_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, src, dst, n, (const unsigned char*)src2,
                        (unsigned char*)dst2, n2_bytes, amax_out, (unsigned*)scratch);
     return ams_check_launch();

@@ -301,6 +301,9 @@ ams_status ams_opt_momentum(float* p, const float* g, float* accum, long n, floa
  * 0: the speaker indices), and amax_out[0] = max |src| (optional; scratch = ams_stage_inputs_scratch_bytes() bytes, first word zero on
  * first use, left zero).  Replaces three copy launches and the pass that bounded the waveforms for the front product
  * (models/network.py: the feed of inputs/mix_input, non_mix_input, indicies -- reference models/network.py:44-85). */
+/* zero two device regions in ONE launch (16-byte aligned, sizes multiples of 16; either may be empty): the gradient buffer and the
+ * recurrence rings' sync arena at the head of a training step. */
+ams_status ams_zero2(void* a, size_t a_bytes, void* b, size_t b_bytes, void* stream);
 size_t ams_stage_inputs_scratch_bytes(void);
 ams_status ams_stage_inputs(const float* src, float* dst, long n, const void* src2, void* dst2, long n2_bytes, float* amax_out,
                             void* scratch, void* stream);
