@@ -415,11 +415,13 @@ def main():
     pf = ops.PROFILE.summary(label='front_conv')
     if pf['launches']:
         t = pf['ms'] * 1e-3
+        conv16 = any(r[5] == 'front_conv' and r[4].startswith('gemm16') for r in ops.PROFILE.records)
         targets['front_conv'] = {
-            'kernel': kname + '<A_FRAMES> (+ split-K reduce)', 'avg_launch_us': round(pf['ms'] / pf['launches'] * 1e3, 2),
+            'kernel': kname + '<A_FRAMES> (stream-K inside the launch; max |y| folded in the launch)', 'avg_launch_us': round(pf['ms'] / pf['launches'] * 1e3, 2),
             'TFLOP/s': round(pf['flops'] / t / 1e12, 2),
-            'mfma_frac': round(pf['flops'] / t / 1e12 / ((MFMA_BF16_PEAK_TFLOPS / 6.0) if x6 else MFMA_F32_PEAK_TFLOPS), 4),
-            'arithmetic': 'bf16x6 (6 MFMA products per f32 product: this launch has no operand bounds at hand)' if x6 else 'native f32 MFMA',
+            'mfma_frac': round(pf['flops'] / t / 1e12 / ((MFMA_BF16_PEAK_TFLOPS / (3.0 if conv16 else 6.0)) if x6 else MFMA_F32_PEAK_TFLOPS), 4),
+            'arithmetic': (('fp16x3 (3 MFMA products per f32 product; bounds from the staging launch and the frozen-filter cache)' if conv16 else
+                            'bf16x6 (6 MFMA products per f32 product)') if x6 else 'native f32 MFMA'),
             'vs_native_f32_mfma_peak': round(pf['flops'] / t / 1e12 / MFMA_F32_PEAK_TFLOPS, 4),
             'algorithmic_GB/s': round(pf['bytes'] / t / 1e9, 1), 'hbm_frac': round(pf['bytes'] / t / 8e12, 4),
             'note': 'strided analysis conv = dense contraction, AI ~ 250 flop/B: MFMA-bound, not HBM-bound (DESIGN.md 4)'}
