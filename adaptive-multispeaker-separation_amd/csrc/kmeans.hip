@@ -7,9 +7,10 @@
 //
 // Bit-exact hard labels.  tf.unsorted_segment_sum is order-nondeterministic; oracle/kmeans.py and these kernels
 // share ONE summation order: 2048-point chunks; lane j (0..255) adds its 8 points j, j+256, .. sequentially; a
-// halving tree v[j] += v[j+s], s = 128..1, combines the lanes; chunk totals are added in chunk order.  Distances
-// accumulate left-to-right over e with separate multiply and add (__fmul_rn/__fadd_rn: no FMA contraction), sqrt
-// is IEEE, ties pick the lowest cluster (tf.argmin).
+// halving tree v[j] += v[j+s], s = 128..1, combines the lanes; chunk totals are added in chunk order.  HARD distances are ONE
+// fused chain over e, d <- fma((x_e - c_e) w, x_e - c_e, d) (round 5: oracle/kmeans.py sqdist_fused, fma32); everything else
+// (soft distances, normalisation, inertia) accumulates left-to-right with separate multiply and add (no contraction), sqrt is IEEE,
+// ties pick the lowest cluster (tf.argmin).
 //
 // Algorithmic bytes per pass: L*E*4 per row (+ L*4 weights); x[b] is shared by the `tries` rows of an utterance
 // through L2.
@@ -205,41 +206,45 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? 3 :
                     d2[c] = d;
                 }
             } else {
-                // WT = per-term weights (d2 = sum_e w (x - c)^2, Kmeans_2.py:175-181); without weights the loop is multiply-free
+                // d2[c] = fused chain over e of ((x_e - c_e) w) (x_e - c_e)  (Kmeans_2.py:175-181 restated as ONE FMA chain per cluster:
+                // oracle/kmeans.py sqdist_fused).  Two clusters share a packed register: per e ONE v_pk_add (x_e - {c0_e, c1_e}), ONE
+                // v_pk_fma (+ one v_pk_mul with weights) for both -- 80 packed instructions per point at E = 40, C = 2, where separate
+                // multiply and add were 160 plus the pinning of the add chains.  The pair's chain IS the serial order; nothing to pin.
                 auto dist = [&](auto WT) {
                     constexpr bool W = decltype(WT)::value;
+                    constexpr int CP = (C_ + 1) / 2;
+                    f2 dp[CP];
 #pragma unroll
-                    for (int c = 0; c < C_; ++c) d2[c] = 0.f;
+                    for (int cp = 0; cp < CP; ++cp) dp[cp] = (f2){0.f, 0.f};
 #pragma unroll
-                    for (int q4 = 0; q4 < V4; ++q4) {              // q outer, c inner: each d2[c] still adds its terms in e order
+                    for (int q4 = 0; q4 < V4; ++q4) {
                         asm volatile("" ::: "memory");              // LDS operands just in time: no wholesale preload into VGPRs
-                        // ... and the running sums are DUE here: the squares of all ten groups are independent while each d2[c] is one
-                        // serial chain, so the scheduler computed every square first (80 live registers, 72-105 spilled under the
-                        // 168-VGPR bound) and ran the add chains at the end
+                        // the differences of all ten groups are independent while a pair's chain is serial: left alone the scheduler
+                        // computes every difference first (80 live registers, spilled under the 168-VGPR bound) -- the chains are DUE here
 #pragma unroll
-                        for (int c = 0; c < C_; ++c) if (!W) asm volatile("" : "+v"(d2[c]));      // the weighted form fits as scheduled
+                        for (int cp = 0; cp < CP; ++cp) asm volatile("" : "+v"(dp[cp]));
                         const float4 v = *reinterpret_cast<const float4*>(xrow + q4 * 4);
 #pragma unroll
-                        for (int c = 0; c < C_; ++c) {
+                        for (int k = 0; k < 4; ++k) {
+                            const float xe = k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
+                            const f2 xx = {xe, xe};
+#pragma unroll
+                            for (int cp = 0; cp < CP; ++cp) {
+                                constexpr int dummy = 0;
+                                const int c0 = 2 * cp, c1 = (2 * cp + 1 < C_) ? 2 * cp + 1 : 2 * cp;
 #if AMS_KM_SGPR_CENT
-                            const f2 c0 = {cs[(c * E_ + 4 * q4) % (SOFT ? 1 : C_ * E_)], cs[(c * E_ + 4 * q4 + 1) % (SOFT ? 1 : C_ * E_)]};
-                            const f2 c1 = {cs[(c * E_ + 4 * q4 + 2) % (SOFT ? 1 : C_ * E_)], cs[(c * E_ + 4 * q4 + 3) % (SOFT ? 1 : C_ * E_)]};
+                                const f2 cc = {cs[(c0 * E_ + 4 * q4 + k) % (SOFT ? 1 : C_ * E_)], cs[(c1 * E_ + 4 * q4 + k) % (SOFT ? 1 : C_ * E_)]};
 #else
-                            const f2 c0 = *reinterpret_cast<const f2*>(&scent[c * E_ + 4 * q4]);
-                            const f2 c1 = *reinterpret_cast<const f2*>(&scent[c * E_ + 4 * q4 + 2]);
+                                const f2 cc = {scent[c0 * E_ + 4 * q4 + k], scent[c1 * E_ + 4 * q4 + k]};
 #endif
-                            const f2 x0 = {v.x, v.y}, x1 = {v.z, v.w};
-                            const f2 df0 = x0 - c0, df1 = x1 - c1;
-                            f2 s0 = df0 * df0, s1 = df1 * df1;
-                            if (W) { s0 = s0 * wv2; s1 = s1 * wv2; }
-                            float d = d2[c];
-                            d = __fadd_rn(d, s0.x);
-                            d = __fadd_rn(d, s0.y);
-                            d = __fadd_rn(d, s1.x);
-                            d = __fadd_rn(d, s1.y);
-                            d2[c] = d;
+                                (void)dummy;
+                                const f2 df = xx - cc;
+                                dp[cp] = __builtin_elementwise_fma(W ? df * wv2 : df, df, dp[cp]);
+                            }
                         }
                     }
+#pragma unroll
+                    for (int c = 0; c < C_; ++c) d2[c] = (c & 1) ? dp[c / 2].y : dp[c / 2].x;
                 };
                 // (a 0/1 weight could be folded into one multiply per point -- w * sum == sum of w * terms bit for bit -- with the
                 // per-term loop kept for other values; both loops in one kernel spill 21-72 VGPRs under the 168 bound and the

@@ -23,7 +23,12 @@ GPU, so any fixed order is a valid restatement.  For bit-exact label parity the 
 kernel share ONE order (`ordered_sum`): points are cut into chunks of 2048; inside a chunk lane
 j (0..255) adds its 8 points j, j+256, ... sequentially, the 256 lane partials are combined by a
 halving tree (v[j] += v[j+s], s = 128..1), and chunk totals are added sequentially in chunk order.
-Distances accumulate left-to-right over e with separate multiply and add (no FMA).
+HARD distances (round 5) are ONE fused chain over e, d <- fma((x_e - c_e) * w, x_e - c_e, d): TensorFlow's reduction order and
+contraction are unspecified, so a fused chain restates `sum((x - c)^2 * w)` as validly as separate multiplies and adds did, and it is
+half the vector instructions on the device (one packed subtract + one packed FMA per e for TWO clusters).  For 0/1 silence weights
+(x - c) * w is exact, so weighted and unweighted forms agree where w = 1.  `fma32` below is the correctly rounded float32 FMA
+(float64 product is exact; the float64 sum is rounded to odd before the final rounding, which removes the double rounding).
+The soft distances, the input normalisation and the inertia keep separate multiply and add.
 """
 import numpy as np
 from .dense import L2_EPS
@@ -62,6 +67,32 @@ def l2_normalize_rows(x):
     return x * inv[..., None]
 
 
+def fma32(a, b, c):
+    """Correctly rounded fused multiply-add for float32 arrays (what v_fma_f32 / v_pk_fma_f32 compute); plain a*b+c for float64."""
+    if np.result_type(a, b, c) != np.float32:
+        return a * b + c
+    p = a.astype(np.float64) * b.astype(np.float64)                # exact: 24 + 24 significant bits
+    c64 = np.broadcast_to(c.astype(np.float64), p.shape)
+    s = p + c64                                                     # round to nearest in float64
+    bb = s - p
+    err = (p - (s - bb)) + (c64 - bb)                               # TwoSum: s + err == p + c exactly
+    odd = (s.view(np.int64) & 1) == 1
+    nudge = (err != 0) & ~odd & np.isfinite(s)                      # round to odd: an inexact even sum moves to its odd neighbour
+    s = np.where(nudge, np.nextafter(s, np.where(err > 0, np.inf, -np.inf)), s)
+    return s.astype(np.float32)
+
+
+def sqdist_fused(x, cent, w):
+    """d2[l,c] = fused chain over e of ((x[l,e]-cent[c,e]) * w[l]) * (x[l,e]-cent[c,e]) (module doc).  x [L,E], cent [C,E], w [L]."""
+    L, E = x.shape
+    C = cent.shape[0]
+    d = np.zeros((L, C), dtype=x.dtype)
+    for e in range(E):
+        diff = x[:, e:e + 1] - cent[None, :, e]
+        d = fma32(diff * w[:, None], diff, d)
+    return d
+
+
 def sqdist(x, cent, w):
     """d2[l,c] = sum_e ((x[l,e]-cent[c,e])^2 * w[l]), sequential over e.  x [L,E], cent [C,E], w [L]."""
     L, E = x.shape
@@ -74,7 +105,7 @@ def sqdist(x, cent, w):
 
 
 def labels_hard(x, cent, w):
-    return np.argmin(np.sqrt(sqdist(x, cent, w)), axis=1).astype(np.int32)
+    return np.argmin(np.sqrt(sqdist_fused(x, cent, w)), axis=1).astype(np.int32)
 
 
 def labels_soft(x, cent, w, beta):

@@ -154,6 +154,16 @@ def more():
     _save('pretraining_maxpool_step.npz', dict(B=B, S=S, L=L, W=W, N=N, hop=hop, Pool=Pool), P, dict(x_mix=xm, x_non_mix=xn), ex)
 
 
+def regen_kmeans():
+    """Outputs of kmeans_hard.npz again from its stored inputs (round 5: the hard distance became a fused chain, oracle/kmeans.py)."""
+    k = np.load(os.path.join(HERE, 'kmeans_hard.npz'))
+    C, tries, iters = [int(v) for v in k['cfg']]
+    cent, lab, best = kmeans.kmeans(k['X'], k['idx'], C, tries, iters, beta=None, notsilent=k['w'], assign_at_end=True)
+    assert np.isfinite(cent).all()
+    np.savez_compressed(os.path.join(HERE, 'kmeans_hard.npz'), X=k['X'], w=k['w'], idx=k['idx'], centroids=cent, labels=lab, best=best,
+                        cfg=k['cfg'])
+
+
 if __name__ == '__main__':
     if '--more-only' not in sys.argv:
         main()
