@@ -77,14 +77,51 @@ class _ReferenceSeeds(object):
 _REFERENCE_SEEDS = _ReferenceSeeds()
 
 
+def _mix64(x):
+    """splitmix64 finaliser on uint64 arrays (wrap-around arithmetic)."""
+    x = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+    x = (x ^ (x >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return x ^ (x >> np.uint64(31))
+
+
+def keyed_seeds(draw, row0, R, L, C, seed=42):
+    """int32 [R, C]: C distinct bins in [0, L) for the GLOBAL rows row0 .. row0 + R - 1 of draw number `draw`: a counter-based stream
+    (splitmix64 of (seed, draw, global row, cluster, attempt)), so a row's seeds depend on nothing but its global index -- the same
+    whatever the number of ranks and their shard sizes.  Same distribution as the reference's np.random.choice(l, C, replace=False)
+    (uniform C-subsets in uniform order: rows with a repeated bin are redrawn), a different stream."""
+    rows = (np.arange(R, dtype=np.uint64) + np.uint64(row0))[:, None]
+    cl = np.arange(C, dtype=np.uint64)[None, :]
+    out = np.zeros((R, C), dtype=np.int64)
+    todo = np.arange(R)
+    attempt = 0
+    with np.errstate(over='ignore'):
+        base = _mix64(np.full((1, 1), seed, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15) + np.uint64(draw))
+        while todo.size:
+            h = _mix64(_mix64(base ^ (rows[todo] * np.uint64(0xD1342543DE82EF95))) + cl * np.uint64(0x2545F4914F6CDD1D)
+                       + np.uint64(attempt) * np.uint64(0x9E3779B97F4A7C15))
+            a = ((h >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53)) * L).astype(np.int64)      # uniform in [0, L)
+            out[todo] = a
+            srt = np.sort(a, axis=1)
+            todo = todo[(srt[:, 1:] == srt[:, :-1]).any(axis=1)] if C > 1 else todo[:0]
+            attempt += 1
+    return out.astype(np.int32)
+
+
 class KMeans(object):
 
     def __init__(self, nb_clusters, centroids_init=None, nb_tries=10, nb_iterations=10, input_tensor=None,
                  normalize_input=True, latent_space_tensor=None, beta=None, threshold=2.5, assign_at_end=True,
-                 init_indices=None, seeding='reference', pre_norm=None):
-        if seeding not in ('reference', 'fast'):
-            raise ValueError("seeding must be 'reference' or 'fast', got %r" % (seeding,))
+                 init_indices=None, seeding='reference', pre_norm=None, dist=None):
+        if seeding not in ('reference', 'fast', 'keyed'):
+            raise ValueError("seeding must be 'reference', 'fast' or 'keyed', got %r" % (seeding,))
+        # Data parallel: the host streams of 'reference' / 'fast' are consumed row by row, so with G ranks utterance j of EVERY shard
+        # would get rank 0's seeds and results would depend on G.  Ranks > 1 therefore draw 'keyed' seeds -- a counter-based stream
+        # indexed by (seed 42, draw number, GLOBAL row) (SURVEY 8e "Partitioning") -- unless the caller asked for something else by name.
+        self.dist = dist
+        if dist is not None and getattr(dist, 'enabled', False) and seeding == 'reference':
+            seeding = 'keyed'
         self.seeding = seeding
+        self._draws = 0
         if centroids_init is not None:
             raise NotImplementedError('explicit centroids_init (Kmeans_2.py:72-74) is unused by the reference recipes')
         self.nb_clusters = nb_clusters
@@ -119,6 +156,13 @@ class KMeans(object):
         (C distinct bins, uniform) in one vectorised call from the same global RNG, rows with a repeated index redrawn -- a
         DIFFERENT stream, hence different (equally valid) restarts."""
         C = self.nb_clusters
+        if self.seeding == 'keyed':
+            d = self.dist
+            world = d.world_size if (d is not None and getattr(d, 'enabled', False)) else 1
+            rank = d.rank if world > 1 else 0
+            out = keyed_seeds(self._draws, rank * R, R, L, C)           # rank r holds the global rows [r R, (r + 1) R)
+            self._draws += 1
+            return torch.from_numpy(out)
         if self.seeding == 'reference':
             return torch.from_numpy(_REFERENCE_SEEDS.draw(R, L, C))
         a = np.random.randint(0, L, size=(R, C))

@@ -1240,21 +1240,21 @@ def _slots_args(p):
     return _p(src.next), _p(src.bound)
 
 
-def opt_amsgrad(p, g, m, v, vhat, lr_t, beta1, beta2, eps, grad_scale=1.0, guard=None):
+def opt_amsgrad(p, g, m, v, vhat, lr_t, beta1, beta2, eps, grad_scale=1.0, guard=None, scale_dev=None):
     _chk(p, g, m, v, vhat)
     check(load().ams_opt_amsgrad(_p(p), _p(g), _p(m), _p(v), _p(vhat), p.numel(), lr_t, beta1, beta2, eps, grad_scale,
-                                 _p(_guard(p, guard)), *_slots_args(p), _s()), 'ams_opt_amsgrad')
+                                 _p(_guard(p, guard)), *_slots_args(p), _p(scale_dev), _s()), 'ams_opt_amsgrad')
 
 
-def opt_rmsprop(p, g, ms, lr, decay=0.9, eps=1e-10, grad_scale=1.0, guard=None):
+def opt_rmsprop(p, g, ms, lr, decay=0.9, eps=1e-10, grad_scale=1.0, guard=None, scale_dev=None):
     _chk(p, g, ms)
-    check(load().ams_opt_rmsprop(_p(p), _p(g), _p(ms), p.numel(), lr, decay, eps, grad_scale, _p(_guard(p, guard)), *_slots_args(p), _s()),
+    check(load().ams_opt_rmsprop(_p(p), _p(g), _p(ms), p.numel(), lr, decay, eps, grad_scale, _p(_guard(p, guard)), *_slots_args(p), _p(scale_dev), _s()),
           'ams_opt_rmsprop')
 
 
-def opt_momentum(p, g, acc, lr, momentum=0.9, grad_scale=1.0, guard=None):
+def opt_momentum(p, g, acc, lr, momentum=0.9, grad_scale=1.0, guard=None, scale_dev=None):
     _chk(p, g, acc)
-    check(load().ams_opt_momentum(_p(p), _p(g), _p(acc), p.numel(), lr, momentum, grad_scale, _p(_guard(p, guard)), *_slots_args(p), _s()),
+    check(load().ams_opt_momentum(_p(p), _p(g), _p(acc), p.numel(), lr, momentum, grad_scale, _p(_guard(p, guard)), *_slots_args(p), _p(scale_dev), _s()),
           'ams_opt_momentum')
 
 
@@ -1274,6 +1274,13 @@ def stage_inputs(src, dst, src2=None, dst2=None, want_amax=True):
     n2 = src2.numel() * src2.element_size() if src2 is not None else 0
     check(lib.ams_stage_inputs(_p(src), _p(dst), src.numel(), _p(src2), _p(dst2), n2, _p(am), _p(st[0]), _s()), 'ams_stage_inputs')
     return am
+
+
+def clip_scale(ss, pre_scale, clip):
+    """1-element device tensor clip / max(sqrt(ss) * pre_scale, clip) (tf.clip_by_global_norm, network.py:185-190): no host sync."""
+    out = torch.empty(1, dtype=torch.float32, device=ss.device)
+    check(load().ams_clip_scale(_p(ss), float(pre_scale), float(clip), _p(out), _s()), 'ams_clip_scale')
+    return out
 
 
 def sumsq(x):

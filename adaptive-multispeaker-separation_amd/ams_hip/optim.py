@@ -116,9 +116,15 @@ class FlatOptimizer(object):
                 ev[1].record()
                 self.exchange_events.append(ev)
             scale = 1.0 / self.dist.world_size
+        self._scale_dev = None
         if self.clip != 0.0:
-            gn = math.sqrt(float(self._sumsq(self.flat_grad))) * scale        # norm of the AVERAGED gradient
-            scale *= self.clip / max(gn, self.clip)                           # tf.clip_by_global_norm
+            if self.flat_grad.is_cuda:
+                # norm of the AVERAGED gradient and tf.clip_by_global_norm's factor stay on the device (no .item() between the
+                # all-reduce and the update): the optimizer kernel multiplies it in (include/ams.h: grad_scale_dev)
+                self._scale_dev = ops.clip_scale(ops.sumsq(self.flat_grad), scale, self.clip)
+            else:
+                gn = math.sqrt(float(self._sumsq(self.flat_grad))) * scale
+                scale *= self.clip / max(gn, self.clip)
         return scale
 
     def undo_counters(self):
@@ -142,11 +148,11 @@ class FlatOptimizer(object):
         guard = self._errslot if (self._errslot is not None and ops.LSTM_RING != '0') else None
         if self.kind == 'Adam':
             lr_t = self.base_lr * math.sqrt(1.0 - self.b2p) / (1.0 - self.b1p)
-            ops.opt_amsgrad(self.flat, self.flat_grad, self.m, self.v, self.vhat, lr_t, self.beta1, self.beta2, self.eps, scale, guard=guard)
+            ops.opt_amsgrad(self.flat, self.flat_grad, self.m, self.v, self.vhat, lr_t, self.beta1, self.beta2, self.eps, scale, guard=guard, scale_dev=self._scale_dev)
             self.b1p *= self.beta1
             self.b2p *= self.beta2
         elif self.kind == 'RMSProp':
-            ops.opt_rmsprop(self.flat, self.flat_grad, self.ms, self.learning_rate(), 0.9, 1e-10, scale, guard=guard)
+            ops.opt_rmsprop(self.flat, self.flat_grad, self.ms, self.learning_rate(), 0.9, 1e-10, scale, guard=guard, scale_dev=self._scale_dev)
         else:
-            ops.opt_momentum(self.flat, self.flat_grad, self.acc, self.learning_rate(), 0.9, scale, guard=guard)
+            ops.opt_momentum(self.flat, self.flat_grad, self.acc, self.learning_rate(), 0.9, scale, guard=guard, scale_dev=self._scale_dev)
         self.t += 1

@@ -16,7 +16,7 @@ def build_separate(sep, KMeans):
     km = KMeans(nb_clusters=S, nb_tries=sep.nb_tries, nb_iterations=sep.nb_steps, input_tensor=emb, beta=sep.beta,
                 latent_space_tensor=lat, threshold=sep.threshold, assign_at_end=sep.args['end_assign'],
                 init_indices=sep.args.get('kmeans_init_indices'), seeding=sep.args.get('kmeans_seeding') or 'reference',
-                pre_norm=(sep._embed, E) if getattr(sep, '_embed_normalized', False) else None)
+                pre_norm=(sep._embed, E) if getattr(sep, '_embed_normalized', False) else None, dist=getattr(sep, 'dist', None))
     sep.kmeans = km
     _, labels = km.network
 

@@ -310,10 +310,11 @@ __device__ __forceinline__ void block_amax_finish(unsigned m, unsigned* __restri
 // ---- optimizers (reference utils/ops.py:686-703; TF RMSProp/Momentum) ----
 __global__ void amsgrad_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m, float* __restrict__ v,
                                float* __restrict__ vh, long n, float lr_t, float b1, float b2, float eps, float gscale,
-                               const unsigned* __restrict__ skip, unsigned* __restrict__ amax_slots, float* __restrict__ bound) {
+                               const unsigned* __restrict__ skip, unsigned* __restrict__ amax_slots, float* __restrict__ bound, const float* __restrict__ gscale_dev) {
     // skip: a recurrence launch of this step gave up a bounded wait (csrc/lstm_ring.hip, sticky error word): its gradients are
     // garbage -- leave parameters and slots untouched so that the caller can repeat the step on the per-step kernels
     if (skip && *skip != 0u) return;
+    if (gscale_dev) gscale *= gscale_dev[0];         // tf.clip_by_global_norm factor, computed on the device (ams_clip_scale)
     unsigned am = 0u;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
@@ -328,8 +329,10 @@ __global__ void amsgrad_kernel(float* __restrict__ p, const float* __restrict__ 
     if (amax_slots) block_amax_finish(am, amax_slots, bound);
 }
 __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ ms, long n, float lr,
-                               float decay, float eps, float gscale, const unsigned* __restrict__ skip, unsigned* __restrict__ amax_slots, float* __restrict__ bound) {
+                               float decay, float eps, float gscale, const unsigned* __restrict__ skip, unsigned* __restrict__ amax_slots, float* __restrict__ bound,
+                               const float* __restrict__ gscale_dev) {
     if (skip && *skip != 0u) return;
+    if (gscale_dev) gscale *= gscale_dev[0];
     unsigned am = 0u;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float gi = g[i] * gscale;
@@ -342,8 +345,10 @@ __global__ void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ 
     if (amax_slots) block_amax_finish(am, amax_slots, bound);
 }
 __global__ void momentum_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ acc, long n, float lr,
-                                float mom, float gscale, const unsigned* __restrict__ skip, unsigned* __restrict__ amax_slots, float* __restrict__ bound) {
+                                float mom, float gscale, const unsigned* __restrict__ skip, unsigned* __restrict__ amax_slots, float* __restrict__ bound,
+                                const float* __restrict__ gscale_dev) {
     if (skip && *skip != 0u) return;
+    if (gscale_dev) gscale *= gscale_dev[0];
     unsigned am = 0u;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const float a = mom * acc[i] + g[i] * gscale;
@@ -471,6 +476,13 @@ __global__ __launch_bounds__(256) void zero2_kernel(uint4* __restrict__ a, long 
     }
 }
 
+// out[0] = clip / max(sqrt(sumsq[0]) * pre_scale, clip): tf.clip_by_global_norm's factor for gradients that the optimizer kernel will
+// first multiply by pre_scale (the 1 / world of the data-parallel mean) -- on the device, so that a clipped step has no host round trip
+__global__ void clip_scale_kernel(const float* __restrict__ sumsq, float pre_scale, float clip, float* __restrict__ out) {
+    const float gn = sqrtf(sumsq[0]) * pre_scale;
+    out[0] = clip / fmaxf(gn, clip);
+}
+
 // one device-clock stamp (constant 100 MHz counter): brackets a launch INSIDE a captured hipGraph, where HIP events cannot be read back
 __global__ void stamp_kernel(unsigned long long* __restrict__ buf, int slot) { buf[slot] = wall_clock64(); }
 
@@ -486,6 +498,12 @@ ams_status ams_absmax_f32(const float* x, long n, float* out, void* stream) {
     if (blocks < 1) blocks = 1;                     // arrive at one address at about the same time and are served one after another
     if (blocks > AMS_ABSMAX_BLOCKS) blocks = AMS_ABSMAX_BLOCKS;
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, (unsigned*)out);
+    return ams_check_launch();
+}
+
+ams_status ams_clip_scale(const float* sumsq, float pre_scale, float clip, float* out, void* stream) {
+    AMS_REQUIRE(sumsq && out && clip > 0.f);
+    hipLaunchKernelGGL(clip_scale_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, sumsq, pre_scale, clip, out);
     return ams_check_launch();
 }
 
@@ -613,26 +631,26 @@ ams_status ams_colsum(const float* x, float* out, long rows, int cols, long ld, 
 }
 
 ams_status ams_opt_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, long n, float lr_t, float beta1,
-                           float beta2, float eps, float grad_scale, const void* skip_if_set, void* amax_slots, float* bound_out, void* stream) {
+                           float beta2, float eps, float grad_scale, const void* skip_if_set, void* amax_slots, float* bound_out, const float* grad_scale_dev, void* stream) {
     AMS_REQUIRE(p && g && m && v && vhat && n > 0);
     hipLaunchKernelGGL(amsgrad_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vhat, n, lr_t, beta1,
-                       beta2, eps, grad_scale, (const unsigned*)skip_if_set, bound_out ? (unsigned*)amax_slots : nullptr, bound_out);
+                       beta2, eps, grad_scale, (const unsigned*)skip_if_set, bound_out ? (unsigned*)amax_slots : nullptr, bound_out, grad_scale_dev);
     return ams_check_launch();
 }
 
 ams_status ams_opt_rmsprop(float* p, const float* g, float* ms, long n, float lr, float decay, float eps, float grad_scale,
-                           const void* skip_if_set, void* amax_slots, float* bound_out, void* stream) {
+                           const void* skip_if_set, void* amax_slots, float* bound_out, const float* grad_scale_dev, void* stream) {
     AMS_REQUIRE(p && g && ms && n > 0);
     hipLaunchKernelGGL(rmsprop_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, ms, n, lr, decay, eps, grad_scale,
-                       (const unsigned*)skip_if_set, bound_out ? (unsigned*)amax_slots : nullptr, bound_out);
+                       (const unsigned*)skip_if_set, bound_out ? (unsigned*)amax_slots : nullptr, bound_out, grad_scale_dev);
     return ams_check_launch();
 }
 
 ams_status ams_opt_momentum(float* p, const float* g, float* accum, long n, float lr, float momentum, float grad_scale,
-                            const void* skip_if_set, void* amax_slots, float* bound_out, void* stream) {
+                            const void* skip_if_set, void* amax_slots, float* bound_out, const float* grad_scale_dev, void* stream) {
     AMS_REQUIRE(p && g && accum && n > 0);
     hipLaunchKernelGGL(momentum_kernel, dim3(stream_blocks(n)), dim3(256), 0, (hipStream_t)stream, p, g, accum, n, lr, momentum, grad_scale,
-                       (const unsigned*)skip_if_set, bound_out ? (unsigned*)amax_slots : nullptr, bound_out);
+                       (const unsigned*)skip_if_set, bound_out ? (unsigned*)amax_slots : nullptr, bound_out, grad_scale_dev);
     return ams_check_launch();
 }
 

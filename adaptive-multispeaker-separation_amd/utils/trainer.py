@@ -61,9 +61,10 @@ class MyArgs(object):
         parser.add_argument('--hip_graph', help='[ams] capture forward+backward of the training step into a hipGraph after two '
                             'eager steps and replay it (fixed batch shape; the 480 recurrent launches of a 3xBLSTM step become '
                             'one graph launch)', action="store_true")
-        parser.add_argument('--kmeans_seeding', choices=['reference', 'fast'], default='reference',
+        parser.add_argument('--kmeans_seeding', choices=['reference', 'fast', 'keyed'], default='reference',
                             help="[ams] k-means restarts: 'reference' = one np.random.choice per row exactly as models/Kmeans_2.py:61-66 "
-                            "(bit-exact index stream, serial host draw); 'fast' = one vectorised draw (same distribution, other stream)")
+                            "(bit-exact index stream, serial host draw); 'fast' = one vectorised draw (same distribution, other stream); 'keyed' = a "
+                            "counter-based stream indexed by the GLOBAL row (what N > 1 ranks use instead of 'reference': independent of N)")
         self.parser = parser
 
     def add_stft_args(self):

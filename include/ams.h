@@ -288,11 +288,14 @@ ams_status ams_sumsq_bwd(const float* x, const float* upstream, float scale, flo
 
 /* ---- K24  optimizers     models/network.py:181-194, utils/ops.py:686-703 ---- */
 ams_status ams_opt_amsgrad(float* p, const float* g, float* m, float* v, float* vhat, long n, float lr_t, float beta1,
-                           float beta2, float eps, float grad_scale, const void* skip_if_set, void* amax_slots, float* bound_out, void* stream);
+                           float beta2, float eps, float grad_scale, const void* skip_if_set, void* amax_slots, float* bound_out, const float* grad_scale_dev, void* stream);
 ams_status ams_opt_rmsprop(float* p, const float* g, float* ms, long n, float lr, float decay, float eps, float grad_scale,
-                           const void* skip_if_set, void* amax_slots, float* bound_out, void* stream);
+                           const void* skip_if_set, void* amax_slots, float* bound_out, const float* grad_scale_dev, void* stream);
 ams_status ams_opt_momentum(float* p, const float* g, float* accum, long n, float lr, float momentum, float grad_scale,
-                            const void* skip_if_set, void* amax_slots, float* bound_out, void* stream);
+                            const void* skip_if_set, void* amax_slots, float* bound_out, const float* grad_scale_dev, void* stream);
+/* grad_scale_dev (optional): one more factor on the gradients, read from the device -- the tf.clip_by_global_norm factor
+ * (models/network.py:185-190) from ams_clip_scale: out[0] = clip / max(sqrt(sumsq[0]) * pre_scale, clip). */
+ams_status ams_clip_scale(const float* sumsq, float pre_scale, float clip, float* out, void* stream);
 /* amax_slots + bound_out (optional, both or neither; amax_slots = 192 uint32 of scratch, zero before the first use, left zero): the
  * kernels also leave bound_out[0] = max |p| of what they wrote (folded inside the launch by the last block to finish; a step whose update
  * was skipped leaves the bound as it was).  The fp16x3 products of the NEXT step scale the weights by that bound: no pass over the 47 MB

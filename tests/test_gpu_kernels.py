@@ -297,6 +297,38 @@ def test_optimizers(ops):
     assert abs(host(ops.sumsq(dev(g[0])))[0] - np.sum(g[0].astype(np.float32).astype(np.float64) ** 2)) < 1e-4 * n
 
 
+def test_global_norm_clip_and_weight_bound_stay_on_the_device(ops):
+    """tf.clip_by_global_norm (models/network.py:185-190) through FlatOptimizer without a host round trip: the factor
+    clip / max(|g| * pre_scale, clip) is computed by ams_clip_scale and multiplied in by the optimizer kernel (grad_scale_dev); and the
+    kernels leave max |p| of what they wrote (bound_out) -- the next step's fp16x3 weight bound -- exactly."""
+    from ams_hip.optim import FlatOptimizer
+    rng = np.random.RandomState(6)
+    for kind, clip in (('SGD', 0.5), ('SGD', 1e9), ('RMSProp', 0.5), ('Adam', 0.5)):
+        vs = [torch.nn.Parameter(dev(rng.randn(300, 40))), torch.nn.Parameter(dev(rng.randn(77)))]
+        p0 = [host(v).copy() for v in vs]
+        opt = FlatOptimizer(vs, kind, 0.1, 50, clip)
+        g = [rng.randn(*v.shape) for v in vs]
+        for v, gi in zip(vs, g):
+            v.grad.copy_(dev(gi))
+        gn = np.sqrt(sum((gi.astype(np.float32).astype(np.float64) ** 2).sum() for gi in g))
+        k = clip / max(gn, clip)
+        opt.step()
+        src = opt.flat._ams_src if hasattr(opt.flat, '_ams_src') else None
+        if kind == 'SGD':
+            for v, a, gi in zip(vs, p0, g):
+                assert rel(host(v), a - 0.1 * k * gi) < 1e-5, (kind, clip)
+        else:                                                     # the clipped update equals the unclipped update of the scaled gradient
+            vs2 = [torch.nn.Parameter(dev(a)) for a in p0]
+            opt2 = FlatOptimizer(vs2, kind, 0.1, 50, 0.0)
+            for v, gi in zip(vs2, g):
+                v.grad.copy_(dev(gi * k))
+            opt2.step()
+            for v, w in zip(vs, vs2):
+                assert rel(host(v), host(w)) < 1e-5, (kind, clip)
+        if src is not None:
+            assert float(src.bound) == float(opt.flat.abs().max()), kind
+
+
 @pytest.mark.parametrize('M,N,K', [(600, 10240, 5120), (64, 128, 40), (600, 256, 5120), (16, 64, 3000), (132, 388, 777)])
 def test_gemm_at_b_colsum(ops, M, N, K):
     """dW = x^T dY and db = colsum(dY) from one pass over dY (Conv1D gradients, utils/ops.py:501-503): the fused launch against the

@@ -202,3 +202,31 @@ def test_tf_eval_running_mean_and_model_choices():
         tf_eval.main(['--model_folder', '/nonexistent', '--model', 'front_L41_finetuned'])
     with pytest.raises(SystemExit):                                       # --model is required (utils/trainer.py:112-117)
         tf_eval.main(['--model_folder', '/nonexistent'])
+
+
+def test_keyed_kmeans_seeds_do_not_depend_on_the_number_of_ranks():
+    """SURVEY 8e "Partitioning": with G ranks the k-means restarts of utterance j must not depend on G.  'keyed' seeding (what
+    ams_hip.kmeans_host.KMeans uses under data parallelism instead of the row-by-row host stream of Kmeans_2.py:61-66) indexes a
+    counter-based stream by (draw, GLOBAL row): the rows of two half-size shards are the rows of the whole batch; C distinct bins."""
+    from ams_hip.kmeans_host import KMeans, keyed_seeds
+    from ams_hip.graph import Graph
+    whole = keyed_seeds(5, 0, 64 * 10, 20480, 2)
+    halves = np.concatenate([keyed_seeds(5, 0, 32 * 10, 20480, 2), keyed_seeds(5, 32 * 10, 32 * 10, 20480, 2)])
+    assert np.array_equal(whole, halves)
+    assert whole.min() >= 0 and whole.max() < 20480 and (whole[:, 0] != whole[:, 1]).all()
+    assert not np.array_equal(whole, keyed_seeds(6, 0, 64 * 10, 20480, 2))          # the next draw is another one
+    three = keyed_seeds(0, 0, 5000, 7, 3)                                           # small L: collisions are redrawn
+    assert all(len(set(r)) == 3 for r in three.tolist())
+
+    class _D(object):
+        enabled, world_size = True, 2
+
+        def __init__(self, rank):
+            self.rank = rank
+    with Graph().as_default():
+        kms = [KMeans(2, nb_tries=10, dist=_D(r)) for r in (0, 1)]
+        one = KMeans(2, nb_tries=10, seeding='keyed')
+    assert kms[0].seeding == 'keyed'                                                # 'reference' is a single-process stream
+    for step in range(2):
+        parts = [km._draw(320, 20480).numpy() for km in kms]
+        assert np.array_equal(np.concatenate(parts), one._draw(640, 20480).numpy())
