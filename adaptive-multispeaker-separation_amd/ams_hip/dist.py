@@ -16,23 +16,52 @@ class Dist(object):
         self.rank = int(os.environ.get('RANK', '0'))
         self.local_rank = int(os.environ.get('LOCAL_RANK', '0'))
         self.enabled = self.world_size > 1
-        if self.enabled and not td.is_initialized():
-            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-            os.environ.setdefault('MASTER_PORT', '29500')
-            if backend is None:
-                # AMS_DIST_BACKEND=gloo lets several ranks share ONE GPU (plumbing tests on a 1-GPU box; RCCL refuses that)
-                backend = os.environ.get('AMS_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+        if self.enabled:
+            fresh = not td.is_initialized()
+            if fresh:
+                os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+                os.environ.setdefault('MASTER_PORT', '29500')
+                if backend is None:
+                    # AMS_DIST_BACKEND=gloo lets several ranks share ONE GPU (plumbing tests on a 1-GPU box; RCCL refuses that)
+                    backend = os.environ.get('AMS_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
             if torch.cuda.is_available():
                 ndev = max(1, torch.cuda.device_count())
-                if int(os.environ.get('LOCAL_WORLD_SIZE', self.world_size)) > ndev and os.environ.get('AMS_LSTM_RING') is None:
-                    # several ranks time-share one GPU (plumbing tests on a 1-GPU box): the ring recurrence needs every workgroup of a
-                    # launch resident at once, which two processes' kernels on the same CUs cannot promise each other (measured: 2 of
-                    # 6 two-rank runs gave up a bounded wait) -- such ranks take the per-step recurrence kernels
-                    from . import ops
-                    ops.LSTM_RING = '0'
-                self.local_rank %= ndev
-                torch.cuda.set_device(self.local_rank)
-            td.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
+                if fresh:
+                    self.local_rank %= ndev
+                    torch.cuda.set_device(self.local_rank)
+            if fresh:
+                td.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size)
+            if torch.cuda.is_available() and os.environ.get('AMS_LSTM_RING') is None and self._ranks_on_this_node() > ndev:
+                # several ranks time-share one GPU (plumbing tests on a 1-GPU box): the ring recurrence needs every workgroup of a
+                # launch resident at once, which two processes' kernels on the same CUs cannot promise each other (measured: 2 of
+                # 6 two-rank runs gave up a bounded wait) -- such ranks take the per-step recurrence kernels.  Checked whether or not
+                # the caller had already initialised the process group; said once.
+                from . import ops
+                if ops.LSTM_RING != '0' and self.rank == 0:
+                    print('[ams] %d ranks share %d GPU(s) on this node: per-step recurrence kernels instead of the rings '
+                          '(AMS_LSTM_RING=1 keeps the rings)' % (self._ranks_on_this_node(), ndev))
+                ops.LSTM_RING = '0'
+
+    def _ranks_on_this_node(self):
+        """Ranks of this job on this host: LOCAL_WORLD_SIZE when the launcher set it (torchrun); else counted by host name over the
+        process group (srun / mpirun launches, where WORLD_SIZE spans nodes); 1 -- no sharing assumed -- when neither is possible."""
+        n = getattr(self, '_node_ranks', None)
+        if n is not None:
+            return n
+        v = os.environ.get('LOCAL_WORLD_SIZE')
+        if v is not None:
+            n = int(v)
+        else:
+            n = 1
+            try:
+                import socket
+                names = [None] * self.world_size
+                td.all_gather_object(names, socket.gethostname())
+                n = sum(1 for h in names if h == socket.gethostname())
+            except Exception:
+                n = 1
+        self._node_ranks = n
+        return n
 
     def all_reduce_sum(self, t):
         if self.enabled:

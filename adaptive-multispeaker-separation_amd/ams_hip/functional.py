@@ -64,6 +64,19 @@ class _Overlap(object):
             self.n_cap += 1
         ops.LDS_PAD[0] = pad if on else 0               # handed to every product launched until the next cap() (include/ams.h: lds_pad)
 
+    def capped(self, kind='dense', on=True):
+        """with OVERLAP.capped('lstm'): ...  -- the products inside carry the residency cap, and the cap is lifted again whatever
+        happens inside (a product that raises must not leave every later critical-path product capped)."""
+        ov = self
+
+        class _Cap(object):
+            def __enter__(self_):
+                ov.cap(on, kind)
+
+            def __exit__(self_, *exc):
+                ov.cap(False)
+        return _Cap()
+
     def join(self):
         self.n_cap = 0
         if self.stream is not None:
@@ -164,13 +177,12 @@ class BLSTMLayer(Function):
                     ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart, amax=am_w)
                 return None, None, None, None, None, None
             with torch.cuda.stream(s):
-                OVERLAP.cap(True, 'lstm')
-                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart, amax=am_w)
+                with OVERLAP.capped('lstm'):
+                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='wx', dbpart=dbpart, amax=am_w)
                 # the LAST capped product of the backward pass (recurrent-kernel gradient of the layer above the first one) ends
                 # after the BPTT it hides behind: 2 workgroups per CU there (+0.6 %)
-                OVERLAP.cap(True, 'lstm_last' if ctx.last_capped else 'lstm')
-                ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u', amax=am_w)
-                OVERLAP.cap(False)
+                with OVERLAP.capped('lstm_last' if ctx.last_capped else 'lstm'):
+                    ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u', amax=am_w)
             if dx is None and need_dx:
                 dx = ops.blstm_bwd_dx(G, Kf, Kb, B, T, D, amax=am_dx)
             return dx, None, None, None, None, None
@@ -235,12 +247,11 @@ class Dense(Function):
                 dx = ops.gemm(du2, W, transB=True, amax=am_dx).view(x.shape)
             s = OVERLAP.fork(x2, du2)
             with torch.cuda.stream(s):
-                OVERLAP.cap(_DENSE_MODE == 0)
-                # dW = x^T dU and db = colsum(dU) from ONE pass over dU (210 MB at the benchmark shape)
-                fused = ops.gemm_at_b_colsum(x2, du2, W.grad, b.grad, accumulate=True, amax=am_dw)
-                if not fused:
-                    ops.gemm(x2, du2, transA=True, out=W.grad, accumulate=True, amax=am_dw)
-                OVERLAP.cap(False)
+                with OVERLAP.capped('dense', _DENSE_MODE == 0):
+                    # dW = x^T dU and db = colsum(dU) from ONE pass over dU (210 MB at the benchmark shape)
+                    fused = ops.gemm_at_b_colsum(x2, du2, W.grad, b.grad, accumulate=True, amax=am_dw)
+                    if not fused:
+                        ops.gemm(x2, du2, transA=True, out=W.grad, accumulate=True, amax=am_dw)
                 if not fused:
                     ops.colsum_into(du2, b.grad, True)
             if _DENSE_MODE == 2 and ctx.needs_input_grad[0]:

@@ -171,7 +171,7 @@ def front_conv(x, f, hop, amax=None, measure=False):
     if measure and F16X3 and lib.ams_front_conv_fwd_measures_output():
         ay = torch.empty(1, dtype=torch.float32, device=x.device)
     ev = PROFILE.begin() if PROFILE.enabled else None
-    pa, pb, gt = _bounds(amax)
+    pa, pb, gt = _bounds(amax, ('front_conv', Bt, L, W, N, hop), ((x, Bt, L, L, 0), (f, W, N, N, 1)))
     skp, skn = _sk(x)
     check(lib.ams_front_conv_fwd(_p(x), _p(f), _p(y), Bt, L, W, N, hop, pa, pb, _p(ay), 0, _p(ws), nb, skp, skn, _s()),
           'ams_front_conv_fwd')
@@ -488,10 +488,68 @@ def register_param_source(variables, flat):
     return src
 
 
-def _bounds(amax):
+class _F16Audit(object):
+    """Run-time guard of the fp16x3 products (include/ams.h: ams_range_share).  fp16x3 scales an operand by ONE power of two taken from
+    its bound; entries below bound * 2^-17 keep fewer than 22 bits (absolute error bound * 2^-39 each).  While `active`, every product
+    launched with bounds also measures, for both operands, how many non-zero entries lie down there and their energy; finish() turns that
+    into the estimated relative error the lost bits add to the operand, r = sqrt(n_small) * bound * 2^-39 / |operand|_F; it also counts
+    the operand's non-zero OUTER slices (rows of op(A), columns of op(B): what an output row / column is computed from) that lie
+    entirely below the threshold -- an output row of such a slice is only accurate to ~2^-15 of its own scale (include/ams.h), however
+    little energy it carries.  A product CLASS (entry point, shape, layouts) whose r exceeds `limit` (default 2^-22: the level of the f32
+    arithmetic itself) or of whose outer slices more than `row_limit` (default 1 %) are out of range is DENIED: from then on _bounds()
+    hands it NULL bounds, i.e. bf16x6, which needs no range.  Trainer.train audits one eager step every
+    --f16_audit_every steps (models/network.py::train_audited) and re-captures its step graph when a class was denied."""
+
+    def __init__(self):
+        self.active = False
+        self.records = []
+        self.denied = set()
+        self.limit = float(_os.environ.get('AMS_F16_AUDIT_LIMIT', 2.0 ** -22))
+        self.row_limit = float(_os.environ.get('AMS_F16_AUDIT_ROWS', 0.01))
+        self.report = []                # (key, operand 'A'/'B', n_small, energy share, r, share of outer slices out of range) of the last audit
+
+    def begin(self):
+        self.active, self.records = True, []
+
+    def measure(self, key, role, t, rows, cols, ld, bound, outer=0):
+        out = torch.zeros(3, dtype=torch.float32, device=t.device)
+        check(load().ams_range_share(_p(t), rows, cols, ld, _p(bound), _p(out), _s()), 'ams_range_share')
+        # outer slices entirely below the threshold (index glue of an audit that runs once in ~1000 steps, not a product path)
+        v = torch.as_strided(t, (rows, cols), (ld, 1), t.storage_offset()).abs().amax(dim=1 - outer)
+        slices = torch.stack([((v > 0) & (v < bound * 2.0 ** -17)).sum(), (v > 0).sum()]).to(torch.float32)
+        self.records.append((key, role, out, bound, slices))
+
+    def finish(self):
+        """Host sync.  Returns the product classes newly denied."""
+        self.active = False
+        new, self.report = [], []
+        for key, role, out, bound, slices in self.records:
+            n_small, e_small, e_tot = [float(v) for v in out.cpu()]
+            b = float(bound.cpu())
+            r = (n_small ** 0.5) * b * 2.0 ** -39 / (e_tot ** 0.5) if e_tot > 0 else 0.0
+            s_out, s_live = [float(v) for v in slices.cpu()]
+            frac = s_out / s_live if s_live > 0 else 0.0
+            self.report.append((key, role, n_small, e_small / e_tot if e_tot > 0 else 0.0, r, frac))
+            if (r > self.limit or frac > self.row_limit) and key not in self.denied:
+                self.denied.add(key)
+                new.append(key)
+        self.records = []
+        return new
+
+
+F16_AUDIT = _F16Audit()
+
+
+def _bounds(amax, key=None, operands=None):
     """(pointer of A's bound, pointer of B's bound, profile tag prefix) for the product entry points: fp16x3 ('gemm16')
-    when both bounds are there, else NULLs = bf16x6 / native f32 ('gemm')."""
+    when both bounds are there, else NULLs = bf16x6 / native f32 ('gemm').  key: the product class (F16_AUDIT may have denied it);
+    operands: ((tensor, rows, cols, ld), (...)) of A and B as stored, measured while an audit is active."""
+    if key is not None and key in F16_AUDIT.denied:
+        return _vp(0), _vp(0), 'gemm'
     if F16X3 and amax is not None and amax[0] is not None and amax[1] is not None:
+        if F16_AUDIT.active and key is not None and operands is not None:
+            for role, (t, rows, cols, ld, outer), bnd in (('A', operands[0], amax[0]), ('B', operands[1], amax[1])):
+                F16_AUDIT.measure(key, role, t, rows, cols, ld, bnd, outer)
         cur = torch.cuda.current_stream()
         amax[0].record_stream(cur)      # the launch may be on the side stream (functional.OVERLAP): the caching allocator must not
         amax[1].record_stream(cur)      # hand a bound's 4 bytes to a main-stream tensor while that product has yet to read them
@@ -550,7 +608,8 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False
     nb = lib.ams_gemm_workspace_bytes(M, N, K, 1, pad)
     ws = _ws(nb, A) if nb else None
     ev = PROFILE.begin() if PROFILE.enabled else None
-    pa, pb, gt = _bounds(amax)
+    pa, pb, gt = _bounds(amax, ('gemm', label, M, N, K, bool(transA), bool(transB)),
+                         ((A, K if transA else M, M if transA else K, lda, int(bool(transA))), (B, N if transB else K, K if transB else N, ldb, int(not transB))))
     skp, skn = _sk(A)
     check(lib.ams_gemm_f32(int(transA), int(transB), M, N, K, _p(A), lda, _p(B), ldb, _p(out), ldc, _p(bias), int(accumulate),
                            mask[0], mask[1], pa, pb, pad, _p(ws), nb, skp, skn, _s()), 'ams_gemm_f32')
@@ -576,7 +635,7 @@ def gemm_at_b_colsum(A, B, out, bsum, accumulate=True, amax=None, ldc=None):
     ws = _ws(nb, A) if nb else None
     bws = _ws(32 * N * 4, A)
     ev = PROFILE.begin() if PROFILE.enabled else None
-    pa, pb, gt = _bounds(amax)
+    pa, pb, gt = _bounds(amax, ('at_b_colsum', M, N, K), ((A, K, M, A.stride(0), 1), (B, K, N, B.stride(0), 1)))
     skp, skn = _sk(A)
     check(lib.ams_gemm_f32_at_b_colsum(M, N, K, _p(A), A.stride(0), _p(B), B.stride(0), _p(out), ldc, int(accumulate),
                                        _p(bsum), int(accumulate), _p(bws), pa, pb, pad, _p(ws), nb, skp, skn, _s()),
@@ -607,7 +666,8 @@ def gemm_batched(A, B, C, nbatch, a_zs, b_zs, c_zs, transA, transB, M, N, K, lda
     nb = lib.ams_gemm_workspace_bytes(M, N, K, nbatch, pad)
     ws = _ws(nb, A) if nb else None
     ev = PROFILE.begin() if PROFILE.enabled else None
-    pa, pb, gt = _bounds(amax)
+    pa, pb, gt = _bounds(amax, ('batched', M, N, K, nbatch, bool(transA), bool(transB)),
+                         ((A, K if transA else M, M if transA else K, lda, int(bool(transA))), (B, N if transB else K, K if transB else N, ldb, int(not transB))))
     skp, skn = _sk(A)
     check(lib.ams_gemm_f32_batched(int(transA), int(transB), M, N, K, _p(A), lda, a_zs, _p(B), ldb, b_zs, _p(C), ldc, c_zs, nbatch,
                                    int(accumulate), mask[0], mask[1], pa, pb, pad, _p(ws), nb, skp, skn, _s()),

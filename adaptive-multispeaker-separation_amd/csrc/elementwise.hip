@@ -483,6 +483,27 @@ __global__ void clip_scale_kernel(const float* __restrict__ sumsq, float pre_sca
     out[0] = clip / fmaxf(gn, clip);
 }
 
+// fp16x3 range audit of one operand (ops.f16_audit): out[0] += number of non-zero entries with |x| < bound * 2^-17 (the entries the
+// arithmetic keeps fewer than 22 bits of), out[1] += their energy, out[2] += the operand's energy.  Float atomics: an audit, not a result.
+__global__ __launch_bounds__(256) void range_share_kernel(const float* __restrict__ x, long rows, long cols, long ld, const float* __restrict__ bound,
+                                                          float* __restrict__ out) {
+    __shared__ float sm[3][4];
+    const float thr = bound[0] * 1.52587890625e-05f * 0.5f;      // 2^-17
+    float cnt = 0.f, es = 0.f, et = 0.f;
+    const long n = rows * cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const long r = i / cols, c = i - r * cols;
+        const float v = x[r * ld + c], a = fabsf(v);
+        const float e = v * v;
+        et += e;
+        if (a < thr && a > 0.f) { cnt += 1.f; es += e; }
+    }
+    cnt = wave_sum(cnt); es = wave_sum(es); et = wave_sum(et);
+    if ((threadIdx.x & 63) == 0) { sm[0][threadIdx.x >> 6] = cnt; sm[1][threadIdx.x >> 6] = es; sm[2][threadIdx.x >> 6] = et; }
+    __syncthreads();
+    if (threadIdx.x < 3) atomicAdd(out + threadIdx.x, sm[threadIdx.x][0] + sm[threadIdx.x][1] + sm[threadIdx.x][2] + sm[threadIdx.x][3]);
+}
+
 // one device-clock stamp (constant 100 MHz counter): brackets a launch INSIDE a captured hipGraph, where HIP events cannot be read back
 __global__ void stamp_kernel(unsigned long long* __restrict__ buf, int slot) { buf[slot] = wall_clock64(); }
 
@@ -498,6 +519,15 @@ ams_status ams_absmax_f32(const float* x, long n, float* out, void* stream) {
     if (blocks < 1) blocks = 1;                     // arrive at one address at about the same time and are served one after another
     if (blocks > AMS_ABSMAX_BLOCKS) blocks = AMS_ABSMAX_BLOCKS;
     hipLaunchKernelGGL(absmax_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, n, (unsigned*)out);
+    return ams_check_launch();
+}
+
+ams_status ams_range_share(const float* x, long rows, long cols, long ld, const float* bound, float* out3, void* stream) {
+    AMS_REQUIRE(x && bound && out3 && rows > 0 && cols > 0 && ld >= cols);
+    long blocks = (rows * cols + 255) / 256 / 8;
+    if (blocks < 1) blocks = 1;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(range_share_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, rows, cols, ld, bound, out3);
     return ams_check_launch();
 }
 

@@ -380,6 +380,21 @@ class Network(object):
         self.last_run = run
         return cost.detach().reshape(-1)[0]
 
+    def train_audited(self, feed_dict, step):
+        """One training step, EAGER, with the fp16x3 range audit on (K.F16_AUDIT): every product launched with operand bounds also
+        measures how much of each operand lies below bound * 2^-17.  A product class whose lost bits exceed the f32 level is sent back
+        to bf16x6 from then on; a captured step is dropped so that the next call re-captures without it.  Returns (cost, newly denied)."""
+        K.F16_AUDIT.begin()
+        hg, self.args['hip_graph'] = self.args.get('hip_graph'), False
+        try:
+            c = self.train(feed_dict, step)
+        finally:
+            self.args['hip_graph'] = hg
+            new = K.F16_AUDIT.finish()
+        if new:
+            self.__dict__.pop('_cg_state', None)
+        return c, new
+
     # ---- a recurrence ring that could not get all its workgroups resident gives up a bounded wait and flags it in the device's
     # sticky error word (csrc/lstm_ring.hip, K.ring_error_word): the batch is then REPEATED on the per-step recurrence kernels,
     # which need no co-residency -- safe rather than loud.  `ring_fallbacks` counts how often that happened.
@@ -396,8 +411,11 @@ class Network(object):
         # stays up
         pre = K.LSTM_RING != '0' and self._ring_error_any()
         run = self._feeds(feed_dict, training)
-        with torch.no_grad():
-            out = fn(run)
+        if not pre:
+            with torch.no_grad():
+                out = fn(run)
+        # (pre: the word is up already -- a ring evaluation would be run, thrown away and leave nothing new to learn: straight to the
+        # per-step kernels, one collective per batch instead of two)
         if K.LSTM_RING != '0' and (pre or self._ring_error_any()):
             ins = self._inputs_of(run)
             if not pre:
@@ -501,7 +519,7 @@ class Network(object):
                               'men', 'women', 'recurrent_dropout', 'recurrent_dropout_enhance',
                               # this build's own switches follow the CURRENT command line, not the loaded model's
                               'hip_graph', 'no_summaries', 'summaries', 'synthetic_batches', 'synthetic_pool', 'run_id',
-                              'kmeans_seeding', 'dist']
+                              'kmeans_seeding', 'f16_audit_every', 'dist']
             to_modify = {key: modified_args[key] for key in keys_to_update if key in modified_args.keys()}
             to_modify.update({key: val for key, val in modified_args.items() if key not in args.keys()})
         args.update(to_modify)

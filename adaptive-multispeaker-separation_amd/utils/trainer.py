@@ -61,6 +61,9 @@ class MyArgs(object):
         parser.add_argument('--hip_graph', help='[ams] capture forward+backward of the training step into a hipGraph after two '
                             'eager steps and replay it (fixed batch shape; the 480 recurrent launches of a 3xBLSTM step become '
                             'one graph launch)', action="store_true")
+        parser.add_argument('--f16_audit_every', type=int, default=1000, help='[ams] every N steps (and at step 10) one training step runs '
+                            'eagerly with the fp16x3 operand-range audit on: a product class whose operands leave the fp16 range falls '
+                            'back to bf16x6 (0 = never)')
         parser.add_argument('--kmeans_seeding', choices=['reference', 'fast', 'keyed'], default='reference',
                             help="[ams] k-means restarts: 'reference' = one np.random.choice per row exactly as models/Kmeans_2.py:61-66 "
                             "(bit-exact index stream, serial host draw); 'fast' = one vectorised draw (same distribution, other stream); 'keyed' = a "
@@ -261,7 +264,14 @@ class Trainer(object):
             for epoch in range(epochs):
                 tfds.initialize(tfds.TRAIN)
                 for b in range(n_train):
-                    c = self.model.train(feeds[tfds.TRAIN], step)
+                    audit = int(self.args.get('f16_audit_every') or 0)
+                    if audit > 0 and ops.F16X3 and (step == 10 or (step + 1) % audit == 0):
+                        # run-time guard of the fp16x3 products: this step eagerly with the operand-range audit on (ops.F16_AUDIT)
+                        c, denied = self.model.train_audited(feeds[tfds.TRAIN], step)
+                        for k in denied:
+                            self._say('fp16x3 audit: operands of product class', k, 'leave the fp16 range: bf16x6 from now on')
+                    else:
+                        c = self.model.train(feeds[tfds.TRAIN], step)
                     c = float(c)                   # host sync, as sess.run returning the cost does
                     if ops.ring_error_pending():
                         # a ring recurrence of this step could not get its workgroups resident in time: the optimizer skipped

@@ -126,6 +126,11 @@ ams_status ams_gemm_f32_batched(int transA, int transB, int M, int N, int K, con
                                 long ldb, long b_zs, float* C, long ldc, long c_zs, int nbatch, int accumulate, int mask_period,
                                 int mask_skip, const float* amax_a, const float* amax_b, int lds_pad, void* ws, size_t ws_bytes,
                                 void* sk_scratch, size_t sk_bytes, void* stream);
+/* Range audit of an fp16x3 operand x [rows, cols] (row pitch ld) against the bound it would be scaled with: out3[0] += the number of
+   non-zero entries below bound * 2^-17 (they keep fewer than 22 bits), out3[1] += their energy, out3[2] += the operand's energy
+   (the caller zeroes out3).  ops.f16_audit runs it over the operands of a whole step and sends a product class back to bf16x6
+   when the estimated relative error of the lost bits exceeds the f32 level (DESIGN 4.0a "guard"). */
+ams_status ams_range_share(const float* x, long rows, long cols, long ld, const float* bound, float* out3, void* stream);
 /* out[0] = max |x[i]|, i < n, as a float (NaN if any x is NaN): an operand bound for the products above, for operands whose producer
    does not supply one.  Two stream-ordered launches (a 4-byte clear, the reduction); out is a device pointer. */
 ams_status ams_absmax_f32(const float* x, long n, float* out, void* stream);

@@ -179,3 +179,43 @@ def test_the_training_step_takes_fp16x3_wherever_bounds_are_at_hand(ops):
     n16 = sum(t.startswith('gemm16') for t in tags)
     assert n16 >= 11 and len(tags) == n16, tags                  # front conv, 2 projections, dense fwd/dX/dW, 1 LSTM dX, 2 dWx, 2 dU
     assert len(calls) <= 3, calls                                 # the waveforms, the frozen filter, the optimizer's flat weight buffer
+
+
+def test_audited_training_step_and_recapture_after_a_denial(ops):
+    """Network.train_audited: one eager step with the range audit on, inside a hipGraph-replayed run.  Nothing is denied on sane data and
+    the replay goes on; with the limit forced to zero every audited class is denied, the captured step is dropped, the next calls
+    re-capture, and the step then runs those products as bf16x6 -- same cost trajectory to 1e-4."""
+    import tempfile
+    from tests.smoke_step import build_front_dpcl
+    costs = {}
+    for mode in ('plain', 'audited', 'denied'):
+        tmp = tempfile.mkdtemp(prefix='ams_audit_')
+        ops.PASS[0] += 10
+        trainer, tfds = build_front_dpcl(tmp, B=8, L=4096, W=64, N=64, hop=64, layer_size=600, nb_layers=2, E=40, no_summaries=True, hip_graph=True)
+        g, model = trainer.graph, trainer.model
+        old_limit = ops.F16_AUDIT.limit
+        cs = []
+        try:
+            with g.as_default():
+                feed = {tfds.handle: tfds.get_handle(tfds.TRAIN), tfds.chunk_size: 4096}
+                tfds.initialize(tfds.TRAIN)
+                for i in range(8):
+                    if mode != 'plain' and i == 4:
+                        if mode == 'denied':
+                            ops.F16_AUDIT.limit = -1.0
+                        c, new = model.train_audited(feed, i)
+                        assert (len(new) > 0) == (mode == 'denied'), (mode, new)
+                        assert ('_cg_state' in model.__dict__) == (mode != 'denied')
+                    else:
+                        c = model.train(feed, i)
+                    cs.append(float(c))
+        finally:
+            ops.F16_AUDIT.limit = old_limit
+            if mode == 'denied':
+                assert len(ops.F16_AUDIT.denied) >= 5
+            ops.F16_AUDIT.denied.clear()
+        costs[mode] = np.array(cs)
+        ops.raise_on_ring_errors()
+    assert np.isfinite(costs['denied']).all()
+    assert np.abs(costs['audited'] - costs['plain']).max() <= 1e-5 * np.abs(costs['plain']).max()
+    assert np.abs(costs['denied'] - costs['plain']).max() <= 1e-4 * np.abs(costs['plain']).max()

@@ -25,13 +25,26 @@ pytestmark = pytest.mark.gpu
 B, L, W, N, HOP, LS, NL, E = 64, 20480, 1024, 256, 256, 600, 3, 40
 
 
-def _capture_step_products():
-    """Run two eager training steps; record every product launch of the second one (operands cloned)."""
+def _capture_step_products(pre_steps=1, silence=False, audit=None):
+    """Run `pre_steps` eager training steps; record every product launch of the next one (operands cloned).  silence: the second half of
+    every waveform of the batch is digital silence (exact zeros in x_mix and x_non_mix alike).  audit: a list that receives the range
+    audit's report of that same step (ops.F16_AUDIT)."""
     from tests.smoke_step import build_front_dpcl
     from ams_hip import ops
     tmp = tempfile.mkdtemp(prefix='ams_rowwise_')
     trainer, tfds = build_front_dpcl(tmp, B=B, L=L, W=W, N=N, hop=HOP, layer_size=LS, nb_layers=NL, E=E, no_summaries=True)
     g, model = trainer.graph, trainer.model
+    if silence:
+        orig_next, done = tfds._next, set()
+
+        def silent(run):
+            mix, non_mix, ind = orig_next(run)                      # the pooled device tensors themselves (data/dataset.py::_next)
+            if mix.data_ptr() not in done:
+                mix[..., mix.shape[-1] // 2:] = 0.0
+                non_mix[..., non_mix.shape[-1] // 2:] = 0.0
+                done.add(mix.data_ptr())
+            return mix, non_mix, ind
+        tfds._next = silent
     # SURVEY 8(d) bench initialisation of the dense layer (the reference's +-12 would saturate nothing but is not what bench.py times)
     gen = torch.Generator(device='cpu').manual_seed(9)
     Wd = g.variables['prediction/W']
@@ -76,10 +89,17 @@ def _capture_step_products():
     try:
         with g.as_default():
             feed = {tfds.handle: tfds.get_handle(tfds.TRAIN), tfds.chunk_size: L}
-            model.train(feed, 0)
+            for i in range(pre_steps):
+                model.train(feed, i)
             state['on'] = True
-            model.train(feed, 1)
+            if audit is not None:
+                ops.F16_AUDIT.begin()
+            model.train(feed, pre_steps)
             torch.cuda.synchronize()
+            if audit is not None:
+                denied = ops.F16_AUDIT.finish()
+                audit.extend(ops.F16_AUDIT.report)
+                assert not denied, denied
     finally:
         for k, v in orig.items():
             setattr(ops, k, v)
@@ -93,11 +113,18 @@ def _errors(C, ref):
     return (d.norm(dim=1).cpu().numpy(), ref.norm(dim=1).cpu().numpy(), d.norm(dim=0).cpu().numpy(), ref.norm(dim=0).cpu().numpy())
 
 
-def test_every_product_of_the_step_row_by_row():
+@pytest.mark.parametrize('state', ['fresh', 'trained300', 'half_silent'])
+def test_every_product_of_the_step_row_by_row(state):
+    """fresh: step 2 of a freshly initialised model (round 4).  trained300: the same after 300 training steps (gates that have started
+    to saturate, weights that have moved).  half_silent: a batch whose second half is digital silence -- exact
+    zeros are outside the question (0 is exact in any arithmetic), what matters is what the silence does to the range of everything
+    downstream.  The run-time guard (ops.F16_AUDIT) audits the SAME step: it must deny nothing, and its report is kept."""
     from ams_hip import ops
     from ams_hip._lib import load
     lib = load()
-    recs = _capture_step_products()
+    audit = []
+    recs = _capture_step_products(pre_steps={'fresh': 1, 'trained300': 300, 'half_silent': 1}[state], silence=state == 'half_silent',
+                                  audit=audit)
     assert len(recs) >= 12, [r['name'] for r in recs]
     assert any(r['amax'] is not None for r in recs), 'the step passed no operand bounds: fp16x3 is not what it runs'
     lines, failures = [], []
@@ -154,10 +181,46 @@ def test_every_product_of_the_step_row_by_row():
                     failures.append((i, r['name'], arith, axis, 'in-range ratio', worst))
                 if o_abs > 2.0 ** -20:
                     failures.append((i, r['name'], arith, axis, 'out-of-range abs', o_abs))
+    lines.append('# run-time range audit of the same step (ops.F16_AUDIT): product class, operand, non-zero entries below bound * 2^-17, '
+                 'their energy share, estimated relative error of the lost bits (limit %.1e)' % ops.F16_AUDIT.limit)
+    for key, role, n_small, share, r, frac in audit:
+        lines.append('#   %-60s %s  n_small %-10d energy share %.2e  est. rel. error %.2e  outer slices out of range %.2e'
+                     % (str(key), role, int(n_small), share, r, frac))
     report = '\n'.join(lines)
     print(report)
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out')
     if os.path.isdir(out_dir):
-        with open(os.path.join(out_dir, 'rowwise_products.txt'), 'w') as f:
+        with open(os.path.join(out_dir, 'rowwise_products_%s.txt' % state), 'w') as f:
             f.write(report + '\n')
+    assert audit and max(a[4] for a in audit) <= ops.F16_AUDIT.limit and max(a[5] for a in audit) <= ops.F16_AUDIT.row_limit
     assert not failures, failures
+
+
+def test_range_audit_denies_a_product_whose_operand_leaves_the_fp16_range():
+    """An operand with most of its rows 2^-30 below its bound: the audit's estimate exceeds the f32 level, the class is denied, and the
+    next launch of that class runs as bf16x6 (bit-equal to a launch without bounds) although bounds are passed."""
+    from ams_hip import ops
+    rng = np.random.RandomState(3)
+    A = torch.from_numpy(rng.randn(512, 256).astype(np.float32)).cuda()
+    A[8:] *= 2.0 ** -30
+    Bm = torch.from_numpy(rng.randn(256, 384).astype(np.float32)).cuda()
+    am = (ops.absmax(A), ops.absmax(Bm))
+    key = ('gemm', 'audit_test', 512, 384, 256, False, False)
+    ops.F16_AUDIT.denied.discard(key)
+    c16 = ops.gemm(A, Bm, amax=am, label='audit_test')
+    c6 = ops.gemm(A, Bm, label='audit_test')
+    assert not torch.equal(c16, c6)
+    ops.F16_AUDIT.begin()
+    ops.gemm(A, Bm, amax=am, label='audit_test')
+    new = ops.F16_AUDIT.finish()
+    try:
+        assert new == [key], (new, ops.F16_AUDIT.report)
+        rep = {r[1]: r for r in ops.F16_AUDIT.report}
+        assert rep['A'][5] > 0.9 and rep['B'][5] == 0.0 and rep['B'][4] <= ops.F16_AUDIT.limit       # 504 of 512 rows of A out of range
+        assert torch.equal(ops.gemm(A, Bm, amax=am, label='audit_test'), c6)          # denied: bf16x6 whatever the caller passes
+        Aok = torch.from_numpy(rng.randn(512, 256).astype(np.float32)).cuda()
+        ops.F16_AUDIT.begin()
+        ops.gemm(Aok, Bm, amax=(ops.absmax(Aok), am[1]), label='audit_ok')
+        assert ops.F16_AUDIT.finish() == []
+    finally:
+        ops.F16_AUDIT.denied.discard(key)
