@@ -23,6 +23,7 @@ class _Overlap(object):
         self.enabled = False
         self.stream = None
         self.n_cap = 0
+        self.deferred = []
 
     def side(self):
         if self.stream is None:
@@ -77,7 +78,23 @@ class _Overlap(object):
                 ov.cap(False)
         return _Cap()
 
+    def defer(self, fn):
+        """A piece of side-stream work that need not run in the window it was produced in (a column block of the dense weight
+        gradient): run by flush() in a LATER window, behind that window's own products."""
+        self.deferred.append(fn)
+
+    def flush(self, n=1):
+        """Run up to n deferred pieces on the side stream (the caller has forked it)."""
+        s = self.side()
+        with torch.cuda.stream(s):
+            for _ in range(min(n, len(self.deferred))):
+                self.deferred.pop(0)()
+
     def join(self):
+        if self.deferred:
+            s = self.side()
+            s.wait_stream(torch.cuda.current_stream())
+            self.flush(len(self.deferred))
         self.n_cap = 0
         if self.stream is not None:
             torch.cuda.current_stream().wait_stream(self.stream)
@@ -125,6 +142,22 @@ _ORDER = int(_os.environ.get('AMS_OVERLAP_ORDER', '2'))
 # 2 = dW alone, then dX (8.97 k) -- measured on the B=64 step, kept as a tuning aid
 _DENSE_MODE = int(_os.environ.get('AMS_DENSE_MODE', '0'))
 _L1_TAIL = int(_os.environ.get('AMS_L1_TAIL', '0'))
+# column blocks (in 256-column tiles) of the dense weight gradient: the first runs beside the top BPTT ring, the others one per later window
+_DW_SPLIT = [int(v) for v in _os.environ.get('AMS_DW_SPLIT', '26,7,7').split(',') if v]
+
+
+def _dw_cuts(N):
+    tiles = N // 256
+    if N % 256 or len(_DW_SPLIT) < 2 or tiles < sum(_DW_SPLIT):
+        return [(0, N)]
+    tot = sum(_DW_SPLIT)
+    cuts, n0 = [], 0
+    for i, f in enumerate(_DW_SPLIT):
+        n1 = N if i == len(_DW_SPLIT) - 1 else n0 + (tiles * f // tot) * 256
+        if n1 > n0:
+            cuts.append((n0, n1))
+        n0 = n1
+    return cuts
 
 class BLSTMLayer(Function):
     """utils/ops.py:358-383 (BasicLSTMCell x 2 directions, concat)."""
@@ -183,6 +216,7 @@ class BLSTMLayer(Function):
                 # after the BPTT it hides behind: 2 workgroups per CU there (+0.6 %)
                 with OVERLAP.capped('lstm_last' if ctx.last_capped else 'lstm'):
                     ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u', amax=am_w)
+                OVERLAP.flush(1)                    # one deferred column block of the dense weight gradient per window
             if dx is None and need_dx:
                 dx = ops.blstm_bwd_dx(G, Kf, Kb, B, T, D, amax=am_dx)
             return dx, None, None, None, None, None
@@ -246,14 +280,27 @@ class Dense(Function):
             if _DENSE_MODE == 0 and _ORDER >= 1 and ctx.needs_input_grad[0]:
                 dx = ops.gemm(du2, W, transB=True, amax=am_dx).view(x.shape)
             s = OVERLAP.fork(x2, du2)
-            with torch.cuda.stream(s):
+            Nw = W.shape[1]
+            cuts = _dw_cuts(Nw) if (_DENSE_MODE == 0 and ctx.needs_input_grad[0] and W.grad.stride(0) == Nw) else [(0, Nw)]
+
+            def piece(n0, n1):
+                # dW[:, n0:n1] = x^T dU[:, n0:n1] and db[n0:n1] = colsum from ONE pass over those columns of dU
+                Wg = W.grad if (n0, n1) == (0, Nw) else W.grad[:, n0:n1]
+                dus = du2 if (n0, n1) == (0, Nw) else du2[:, n0:n1]
                 with OVERLAP.capped('dense', _DENSE_MODE == 0):
-                    # dW = x^T dU and db = colsum(dU) from ONE pass over dU (210 MB at the benchmark shape)
-                    fused = ops.gemm_at_b_colsum(x2, du2, W.grad, b.grad, accumulate=True, amax=am_dw)
+                    fused = ops.gemm_at_b_colsum(x2, dus, Wg, b.grad[n0:n1], accumulate=True, amax=am_dw, ldc=W.grad.stride(0))
                     if not fused:
-                        ops.gemm(x2, du2, transA=True, out=W.grad, accumulate=True, amax=am_dw)
+                        ops.gemm(x2, dus, transA=True, out=Wg, accumulate=True, amax=am_dw, M=x2.shape[1], N=n1 - n0, K=x2.shape[0],
+                                 lda=x2.stride(0), ldb=du2.stride(0), ldc=W.grad.stride(0))
                 if not fused:
-                    ops.colsum_into(du2, b.grad, True)
+                    ops.colsum_into(_c(dus), b.grad[n0:n1], True)
+            with torch.cuda.stream(s):
+                piece(*cuts[0])
+            # The product (394 us beside the top layer's 300-us BPTT ring) used to run 130 us into the next layer's dX, which then
+            # took 151 us instead of 73: its trailing column blocks run in the LATER BPTT windows instead, behind those windows' own
+            # weight-gradient products (the windows of the two lower layers have ~55 us of slack each).
+            for c in cuts[1:]:
+                OVERLAP.defer(lambda c=c: piece(*c))
             if _DENSE_MODE == 2 and ctx.needs_input_grad[0]:
                 # the weight-gradient product runs FIRST and alone (uncapped), dX after it: nothing of the dense layer is left
                 # on the side stream when the recurrence below starts
