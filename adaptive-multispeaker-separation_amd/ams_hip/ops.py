@@ -1592,6 +1592,9 @@ def kmeans_normalize(x):
     return xn
 
 
+_KM_TICKETS = {}
+
+
 def kmeans_run(xn, init_idx, C, tries, iterations, beta=None, w=None, assign_at_end=True, faithful_tile=True):
     """Whole KMeans.network (Kmeans_2.py:86-111) on normalised input xn [b,L,E].
     init_idx int32 [b*tries, C].  Returns (centroids [b,C,E], labels int32 [b,L] | soft [b,L,C], best [b], cent_trace)
@@ -1608,6 +1611,10 @@ def kmeans_run(xn, init_idx, C, tries, iterations, beta=None, w=None, assign_at_
     bval = -1.0 if hard else float(beta)
     nb = lib.ams_kmeans_workspace_bytes(R, L, E, C)
     ws = _ws(nb, xn)
+    # row tickets of the in-launch finish (include/ams.h): persistent per device and stream, zero once, every pass leaves them zero
+    tk = _KM_TICKETS.get((dev.index, torch.cuda.current_stream().cuda_stream))
+    if tk is None or tk.numel() < R:
+        tk = _KM_TICKETS[(dev.index, torch.cuda.current_stream().cuda_stream)] = torch.zeros(max(R, 1024), dtype=torch.int32, device=dev)
     cent = torch.empty((R, C, E), dtype=torch.float32, device=dev)
     check(lib.ams_kmeans_init(_p(xn), _p(init_idx), _p(cent), b, tries, L, E, C, _s()), 'ams_kmeans_init')
     trace = [cent]
@@ -1615,7 +1622,7 @@ def kmeans_run(xn, init_idx, C, tries, iterations, beta=None, w=None, assign_at_
     for _ in range(iterations):
         nxt = torch.empty_like(cent)
         den = torch.empty((R, C), dtype=torch.float32, device=dev) if not hard else None
-        check(lib.ams_kmeans_iterate(_p(xn), _p(w), _p(cent), _p(nxt), _p(den), b, tries, L, E, C, bval, wm, _p(ws), nb, _s()),
+        check(lib.ams_kmeans_iterate(_p(xn), _p(w), _p(cent), _p(nxt), _p(den), b, tries, L, E, C, bval, wm, _p(ws), nb, _p(tk), _s()),
               'ams_kmeans_iterate')
         cent = nxt
         trace.append(cent)
@@ -1625,14 +1632,14 @@ def kmeans_run(xn, init_idx, C, tries, iterations, beta=None, w=None, assign_at_
     labels = torch.empty((R, L), dtype=torch.int32, device=dev) if (hard and not assign_at_end) else None
     soft = torch.empty((R, L, C), dtype=torch.float32, device=dev) if (not hard and not assign_at_end) else None
     check(lib.ams_kmeans_assign(_p(xn), _p(w), _p(cent), _p(labels), _p(soft), _p(inertia), b, tries, L, E, C, bval, wm, _p(ws), nb,
-                                _s()), 'ams_kmeans_assign')
+                                _p(tk), _s()), 'ams_kmeans_assign')
     best = torch.empty(b, dtype=torch.int32, device=dev)
     sel = torch.empty((b, C, E), dtype=torch.float32, device=dev)
     check(lib.ams_kmeans_select(_p(inertia), _p(cent), _p(best), _p(sel), b, tries, E, C, _s()), 'ams_kmeans_select')
     if assign_at_end:
         out_l = torch.empty((b, L), dtype=torch.int32, device=dev) if hard else None
         out_s = torch.empty((b, L, C), dtype=torch.float32, device=dev) if not hard else None
-        check(lib.ams_kmeans_assign(_p(xn), _p(None), _p(sel), _p(out_l), _p(out_s), _p(None), b, 1, L, E, C, bval, 0, _p(ws), nb, _s()),
+        check(lib.ams_kmeans_assign(_p(xn), _p(None), _p(sel), _p(out_l), _p(out_s), _p(None), b, 1, L, E, C, bval, 0, _p(ws), nb, _p(None), _s()),
               'ams_kmeans_assign(end)')
         out = out_l if hard else out_s
     else:

@@ -65,6 +65,11 @@ struct KmArgs {
     int w_mod_b;           // 1: weight row = r % b (reference tile quirk), 0: r / tries
     float beta;
     float one;             // 1.0f, opaque to the compiler (see the HARD modes of kmeans_pass_kernel)
+    // in-launch finish (tickets != NULL): the workgroup that stores a row's LAST chunk partial adds the row's chunks up in chunk order and
+    // writes the centroids (ACC passes: fin_out [R, C, E], fin_den [R, C] or NULL) / the inertia (FINAL passes: fin_out [R]) -- what
+    // kmeans_reduce_kernel did in a launch of its own, ~5 us + a kernel boundary on the serial chain of each of the 11 passes
+    unsigned* tickets;     // [R], zero on entry, left zero
+    float* fin_out; float* fin_den;
 };
 
 typedef float f2 __attribute__((ext_vector_type(2)));
@@ -394,8 +399,50 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? 3 :
             v = __fadd_rn(v, lane_above<4>(v));
             v = __fadd_rn(v, lane_above<2>(v));
             v = __fadd_rn(v, lane_above<1>(v));
-            if (lane == 0) a.part[((long)r * a.G + g) * NV + i] = v;
+            if (lane == 0) {
+                float* const dst = a.part + ((long)r * a.G + g) * NV + i;
+                if (a.tickets) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through: read by the finisher
+                else *dst = v;
+            }
         }
+    }
+    if (a.tickets == nullptr) return;
+    // the partials leave with agent-scope stores and the arrival is counted once they are acknowledged (workgroup-scope release =
+    // s_waitcnt vmcnt(0); NOT __threadfence(): csrc/dpcl.hip); the last chunk's workgroup finishes the row
+    __shared__ int last_sh;
+    if (tid == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const int last = atomicAdd(a.tickets + r, 1u) == (unsigned)a.G - 1u;
+        if (last) __hip_atomic_store(a.tickets + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_sh = last;
+    }
+    __syncthreads();
+    if (!last_sh) return;
+    const float* pr = a.part + (long)r * a.G * NV;
+    if (ACC) {
+        if (tid < C_ * E_) {
+            const int c = tid / E_;
+            float num = 0.f, den = 0.f;
+            for (int gg = 0; gg < a.G; ++gg) {
+                num = __fadd_rn(num, __hip_atomic_load(pr + (long)gg * NV + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                den = __fadd_rn(den, __hip_atomic_load(pr + (long)gg * NV + C_ * E_ + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+            a.fin_out[(long)r * C_ * E_ + tid] = ((num) / (den));
+            if (a.fin_den && (tid % E_) == 0) a.fin_den[(long)r * C_ + c] = den;
+        }
+    } else if (tid == 0 && a.fin_out) {
+        float inertia = 0.f;
+#pragma unroll
+        for (int c = 0; c < C_; ++c) {
+            float tot = 0.f, cnt = 0.f;
+            for (int gg = 0; gg < a.G; ++gg) {
+                tot = __fadd_rn(tot, __hip_atomic_load(pr + (long)gg * NV + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                cnt = __fadd_rn(cnt, __hip_atomic_load(pr + (long)gg * NV + C_ + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            }
+            inertia = __fadd_rn(inertia, ((tot) / (cnt)));
+        }
+        a.fin_out[r] = inertia;
     }
 }
 
@@ -502,7 +549,7 @@ ams_status ams_kmeans_init(const float* xn, const int32_t* init_idx, float* cent
 // One Lloyd iteration for all R = b*tries rows: labels from `cent_in`, new centroids to `cent_out`.
 // beta < 0: hard assignment (argmin), else soft assignment softmax(-beta d^2).
 ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent_in, float* cent_out, float* den_out, int b, int tries,
-                              long L, int E, int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* stream) {
+                              long L, int E, int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* tickets, void* stream) {
     AMS_REQUIRE(xn && cent_in && cent_out && ws && b > 0 && tries > 0 && L > 0 && C >= 2 && C <= 4);
     const int R = b * tries;
     if (ws_bytes < ams_kmeans_workspace_bytes(R, L, E, C)) return AMS_E_WORKSPACE_TOO_SMALL;
@@ -510,8 +557,9 @@ ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent
     KmArgs a{};
     a.xn = xn; a.w = w; a.cent = cent_in; a.part = (float*)ws; a.L = L; a.b = b; a.tries = tries; a.G = ceil_div(L, CHUNK);
     a.w_mod_b = w_mod_b; a.beta = beta; a.one = 1.0f;
+    a.tickets = (unsigned*)tickets; a.fin_out = cent_out; a.fin_den = den_out;
     ams_status s = beta < 0.f ? launch_pass<HARD_ACC>(a, R, E, C, st) : launch_pass<SOFT_ACC>(a, R, E, C, st);
-    if (s != AMS_OK) return s;
+    if (s != AMS_OK || tickets) return s;
     hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(ceil_div((long)R * C * E, 256)), dim3(256), 0, st, (const float*)ws, cent_out, den_out, R,
                        a.G, C, E, 0);
     return ams_check_launch();
@@ -519,7 +567,7 @@ ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent
 
 // Labels for `cent` (+ per-row inertia).  hard: labels int32 [R,L]; soft: soft [R,L,C].  Either output may be NULL.
 ams_status ams_kmeans_assign(const float* xn, const float* w, const float* cent, int32_t* labels, float* soft, float* inertia, int b,
-                             int tries, long L, int E, int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* stream) {
+                             int tries, long L, int E, int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* tickets, void* stream) {
     AMS_REQUIRE(xn && cent && ws && b > 0 && tries > 0 && L > 0 && C >= 2 && C <= 4);
     const int R = b * tries;
     if (ws_bytes < ams_kmeans_workspace_bytes(R, L, E, C)) return AMS_E_WORKSPACE_TOO_SMALL;
@@ -527,9 +575,10 @@ ams_status ams_kmeans_assign(const float* xn, const float* w, const float* cent,
     KmArgs a{};
     a.xn = xn; a.w = w; a.cent = cent; a.part = (float*)ws; a.labels = labels; a.soft = soft; a.L = L; a.b = b; a.tries = tries;
     a.G = ceil_div(L, CHUNK); a.w_mod_b = w_mod_b; a.beta = beta; a.one = 1.0f;
+    a.tickets = inertia ? (unsigned*)tickets : nullptr; a.fin_out = inertia; a.fin_den = nullptr;
     ams_status s = beta < 0.f ? launch_pass<HARD_FINAL>(a, R, E, C, st) : launch_pass<SOFT_FINAL>(a, R, E, C, st);
     if (s != AMS_OK) return s;
-    if (inertia) {
+    if (inertia && !tickets) {
         hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, st, (const float*)ws, inertia, (float*)nullptr, R, a.G, C, E, 1);
         s = ams_check_launch();
     }

@@ -398,7 +398,10 @@ size_t ams_kmeans_workspace_bytes(int R, long L, int E, int C);
 ams_status ams_kmeans_init(const float* xn, const int32_t* init_idx, float* centroids, int b, int tries, long L, int E, int C,
                            void* stream);
 ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent_in, float* cent_out, float* den_out, int b, int tries,
-                              long L, int E, int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* stream);
+                              long L, int E, int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* tickets, void* stream);
+/* tickets (ams_kmeans_iterate / ams_kmeans_assign; optional): b * tries uint32, zero before the first use and left zero -- the chunk
+ * partials of a row are then added up INSIDE the pass by the workgroup that stores the row's last one (same chunk order: same bits),
+ * instead of by a reduce launch behind each of the nb_steps + 1 passes. */
 /* Backward of the unrolled soft k-means for b already-selected rows (models/Kmeans_2.py:145-188 under tf.gradients;
  * csrc/kmeans_soft.hip): one call enqueues the final-assignment pass, the n_it iteration passes in reverse (each one streaming read of
  * xn, partial sums finished by the last-arriving workgroup: no reduce launches) and ONE pass that writes dx.
@@ -416,7 +419,7 @@ ams_status ams_kmeans_soft_bwd(const float* xn, const float* w, const float* w_f
                                const float* dout, const float* inv, const float* inv0, const int32_t* seed, float* dx, float* g0, int b, long L,
                                int E, int C, float beta, int n_it, void* ws, size_t ws_bytes, void* stream);
 ams_status ams_kmeans_assign(const float* xn, const float* w, const float* cent, int32_t* labels, float* soft, float* inertia, int b,
-                             int tries, long L, int E, int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* stream);
+                             int tries, long L, int E, int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* tickets, void* stream);
 ams_status ams_kmeans_select(const float* inertia, const float* centroids, int32_t* best, float* selected, int b, int tries, int E,
                              int C, void* stream);
 
