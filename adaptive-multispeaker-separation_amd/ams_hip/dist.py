@@ -63,6 +63,9 @@ class Dist(object):
         self._node_ranks = n
         return n
 
+    def backend(self):
+        return td.get_backend() if self.enabled else 'none'
+
     def all_reduce_sum(self, t):
         if self.enabled:
             td.all_reduce(t, op=td.ReduceOp.SUM)

@@ -24,6 +24,7 @@ class _Overlap(object):
         self.stream = None
         self.n_cap = 0
         self.deferred = []
+        self.on_ready = None                     # FlatOptimizer.bucket_ready under AMS_DP_OVERLAP=1 (models/network.py::optimize)
 
     def side(self):
         if self.stream is None:
@@ -77,6 +78,11 @@ class _Overlap(object):
             def __exit__(self_, *exc):
                 ov.cap(False)
         return _Cap()
+
+    def ready(self, *params):
+        """The side stream now holds the last writer of these parameters' gradients: a data-parallel optimizer may start exchanging them."""
+        if self.on_ready is not None:
+            self.on_ready(params, self.side())
 
     def defer(self, fn):
         """A piece of side-stream work that need not run in the window it was produced in (a column block of the dense weight
@@ -216,6 +222,7 @@ class BLSTMLayer(Function):
                 # after the BPTT it hides behind: 2 workgroups per CU there (+0.6 %)
                 with OVERLAP.capped('lstm_last' if ctx.last_capped else 'lstm'):
                     ops.blstm_bwd_weights(x, out, G, Kf.grad, bf.grad, Kb.grad, bb.grad, True, part='u', amax=am_w)
+                OVERLAP.ready(Kf, bf, Kb, bb)
                 OVERLAP.flush(1)                    # one deferred column block of the dense weight gradient per window
             if dx is None and need_dx:
                 dx = ops.blstm_bwd_dx(G, Kf, Kb, B, T, D, amax=am_dx)
@@ -299,8 +306,11 @@ class Dense(Function):
             # The product (394 us beside the top layer's 300-us BPTT ring) used to run 130 us into the next layer's dX, which then
             # took 151 us instead of 73: its trailing column blocks run in the LATER BPTT windows instead, behind those windows' own
             # weight-gradient products (the windows of the two lower layers have ~55 us of slack each).
-            for c in cuts[1:]:
-                OVERLAP.defer(lambda c=c: piece(*c))
+            for i, c in enumerate(cuts[1:]):
+                last = i == len(cuts) - 2
+                OVERLAP.defer(lambda c=c, last=last: (piece(*c), OVERLAP.ready(W, b) if last else None))
+            if len(cuts) == 1:
+                OVERLAP.ready(W, b)
             if _DENSE_MODE == 2 and ctx.needs_input_grad[0]:
                 # the weight-gradient product runs FIRST and alone (uncapped), dX after it: nothing of the dense layer is left
                 # on the side stream when the recurrence below starts

@@ -36,6 +36,14 @@ class FlatOptimizer(object):
         if self._errslot is not None:
             ops.register_error_word(self._errslot)
         self.exchange_events = None              # bench.py: list of (start, end) events around the gradient all-reduce
+        # AMS_DP_OVERLAP=1 (off by default: never run on multi-GPU hardware yet): gradients are exchanged in BUCKETS as the backward
+        # pass finishes them -- bucket_ready() all-reduces the flat-buffer range of a layer on a communication stream behind the side
+        # stream that wrote it; exchange() then only reduces what is left (the first layer, the error word) and joins.  Inside a
+        # captured step that needs a capturable collective (RCCL): with gloo under --hip_graph the buckets are skipped.
+        import os
+        self.overlap = self._dp and os.environ.get('AMS_DP_OVERLAP', '0') == '1'
+        self._done = []                          # [lo, hi) element ranges of _gbuf already all-reduced in this step
+        self._comm = None
         off = 0
         ids = set(id(v) for v in self.vars)
         placed = set()
@@ -100,6 +108,42 @@ class FlatOptimizer(object):
         else:
             self._gbuf.zero_()
 
+    def range_of(self, *params):
+        """[lo, hi) element range of the flat gradient buffer spanned by the gradients of `params` (a layer's variables are adjacent;
+        a twin-interleaved variable's rows alternate with its partner's, so the partner is part of the span)."""
+        base, es = self._gbuf.data_ptr(), self._gbuf.element_size()
+        lo, hi = None, None
+        for p in params:
+            for t in (p, getattr(p, '_ams_twin', None)):
+                if t is None or t.grad is None:
+                    continue
+                g = t.grad
+                start = (g.data_ptr() - base) // es
+                span = (g.shape[0] - 1) * g.stride(0) + g.shape[1] if g.dim() == 2 else g.numel()
+                lo = start if lo is None else min(lo, start)
+                hi = start + span if hi is None else max(hi, start + span)
+        return int(lo), int(hi)
+
+    def bucket_ready(self, params, after_stream=None):
+        """The gradients of `params` are final (written by work already enqueued on `after_stream`): start their all-reduce now."""
+        if not self.overlap or any(p.grad is None for p in params):
+            return
+        gb = self._gbuf
+        if gb.is_cuda and torch.cuda.is_current_stream_capturing() and self.dist.backend() != 'nccl':
+            return                               # a gloo collective cannot be part of a captured step: left to exchange()
+        lo, hi = self.range_of(*params)
+        if any(not (hi <= a or lo >= b) for a, b in self._done):
+            return                               # overlaps a range already sent (shared variables): left to exchange()
+        if gb.is_cuda:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream()
+            self._comm.wait_stream(after_stream if after_stream is not None else torch.cuda.current_stream())
+            with torch.cuda.stream(self._comm):
+                self.dist.all_reduce_sum(gb[lo:hi])
+        else:
+            self.dist.all_reduce_sum(gb[lo:hi])
+        self._done.append((lo, hi))
+
     def exchange(self):
         """Data-parallel gradient exchange: ONE all-reduce (sum) of the flat gradient buffer; returns the scale that
         turns it into the mean (every loss on the hot path is a batch mean) and applies the clip."""
@@ -111,7 +155,18 @@ class FlatOptimizer(object):
             if self.exchange_events is not None and self._gbuf.is_cuda:
                 ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
                 ev[0].record()
-            self.dist.all_reduce_sum(self._gbuf)
+            if self._done:
+                # what bucket_ready() has not sent: the gaps between its ranges (first layer, padding, the error word)
+                pos = 0
+                for a, b in sorted(self._done) + [(self._gbuf.numel(), self._gbuf.numel())]:
+                    if a > pos:
+                        self.dist.all_reduce_sum(self._gbuf[pos:a])
+                    pos = max(pos, b)
+                if self._comm is not None:
+                    torch.cuda.current_stream().wait_stream(self._comm)
+                self._done = []
+            else:
+                self.dist.all_reduce_sum(self._gbuf)
             if ev is not None:
                 ev[1].record()
                 self.exchange_events.append(ev)

@@ -216,6 +216,7 @@ class Network(object):
                             self.gradient_clip, self.dist)
         F.OVERLAP.enabled = (bool(self.args.get('overlap_weight_grads', True)) and torch.cuda.is_available()
                              and os.environ.get('AMS_OVERLAP', '1') != '0')
+        F.OVERLAP.on_ready = opt.bucket_ready if getattr(opt, 'overlap', False) else None
         self.optimizer = opt
         self.increment_epoch = opt.increment_epoch
         g.summaries['optimize/learning_rate'] = Node('learning_rate', lambda run: opt.learning_rate())

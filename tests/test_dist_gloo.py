@@ -88,8 +88,30 @@ def _worker(rank, world, port, tmp, q):
     # shard itself, so compare d/d(shard) x (1/world) with the matching rows of the full-batch gradient: the mean term carries
     # 1/(2*world) vs 1/2 locally (-> x 1/world), the KL term must come out unscaled.
     kl_ok = bool(torch.allclose(mine.grad / world, ya.grad[2 * rank:2 * rank + 2], rtol=1e-10, atol=1e-12))
+    # 7. bucketed exchange (AMS_DP_OVERLAP=1; ams_hip/optim.py::bucket_ready): the layers' ranges sent one by one as the backward
+    #    pass finishes them + exchange() for what is left == ONE all-reduce of the whole buffer, bit for bit; ranges cover whole
+    #    twin-interleaved blocks and never overlap
+    opt.clip = 0.0
+    opt.overlap, opt._done = True, []
+    ref = torch.arange(opt._gbuf.numel(), dtype=torch.float32).mul_(0.37 * (rank + 1)).sin_()
+    opt._gbuf.copy_(ref)
+    tv = model.trainable_variables
+    layer = [v for v in tv if 'BLSTM_0' in v.ams_name]
+    dense = [v for v in tv if v.ams_name in ('prediction/W', 'prediction/b')]
+    ranges = [opt.range_of(*layer), opt.range_of(*dense)]
+    opt.bucket_ready(dense)
+    opt.bucket_ready(layer)
+    sent = sorted(opt._done)
+    opt.exchange()
+    bucketed = opt._gbuf.clone()
+    opt._gbuf.copy_(ref)
+    opt.overlap = False
+    opt.exchange()
+    n_l, n_d = sum(v.numel() for v in layer), sum(v.numel() for v in dense)
+    bucket_ok = (torch.equal(bucketed, opt._gbuf) and sent == sorted(ranges) and ranges[0][1] - ranges[0][0] == n_l
+                 and ranges[1][1] - ranges[1][0] == n_d and (ranges[0][1] <= ranges[1][0] or ranges[1][1] <= ranges[0][0]) and not opt._done)
     q.put((rank, same, idx.tolist(), bool(torch.allclose(avg, expect)), abs(s2 - (1.0 / world) * 0.5 / max(gn, 0.5)) < 1e-6,
-           same_id, kl_ok))
+           same_id, kl_ok, bucket_ok))
     dist.barrier()
     torch.distributed.destroy_process_group()
 
@@ -112,3 +134,4 @@ def test_two_rank_gloo_data_parallel(tmp_path):
     assert all(r[4] for r in res), 'global-norm clip must use the averaged gradient'
     assert all(r[5] for r in res), 'run id differs across ranks'
     assert all(r[6] for r in res), 'sparsity (KL of the batch-summed p_hat) gradient is not the single-process gradient'
+    assert all(r[7] for r in res), 'bucketed gradient exchange differs from the single all-reduce'

@@ -47,7 +47,9 @@ def _train(B, hip_graph, tmp):
     return costs, {v.ams_name: v.detach().cpu().numpy().copy() for v in model.trainable_variables}, trainer
 
 
-def _worker(rank, world, port, tmp, B, hip_graph, q, ring=False):
+def _worker(rank, world, port, tmp, B, hip_graph, q, ring=False, overlap=False):
+    if overlap:
+        os.environ['AMS_DP_OVERLAP'] = '1'           # gradients leave in per-layer buckets behind the side stream (ams_hip/optim.py)
     if ring:
         os.environ['AMS_LSTM_RING'] = '1'            # forced: ams_hip.dist keeps the ring recurrence although the ranks share a GPU
     os.environ.update(RANK=str(rank), LOCAL_RANK='0', WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
@@ -67,10 +69,13 @@ def _worker(rank, world, port, tmp, B, hip_graph, q, ring=False):
         q.put((rank, None, None, '%s\n%s' % (e, traceback.format_exc())))
 
 
-@pytest.mark.parametrize('hip_graph,ring', [(False, False), (True, False), (False, True), (True, True)])
-def test_two_ranks_on_one_gpu_match_single_process(hip_graph, ring):
+@pytest.mark.parametrize('hip_graph,ring,overlap', [(False, False, False), (True, False, False), (False, True, False), (True, True, False),
+                                                    (False, False, True), (True, False, True)])
+def test_two_ranks_on_one_gpu_match_single_process(hip_graph, ring, overlap):
     """ring: the ranks keep the RING recurrence (AMS_LSTM_RING=1 forced; by default ranks sharing a GPU take the per-step kernels):
-    data parallelism + rings + the guard word that rides in the gradient all-reduce, with the trainer's repeat-on-give-up."""
+    data parallelism + rings + the guard word that rides in the gradient all-reduce, with the trainer's repeat-on-give-up.
+    overlap: AMS_DP_OVERLAP=1 -- per-layer gradient buckets all-reduced on a communication stream while the backward pass goes on (with
+    gloo under --hip_graph the buckets are skipped and exchange() sends everything: a gloo collective cannot be captured)."""
     import torch.multiprocessing as mp
     B, world = 4, 2
     tmp = tempfile.mkdtemp(prefix='ams_dp_')
@@ -80,7 +85,7 @@ def test_two_ranks_on_one_gpu_match_single_process(hip_graph, ring):
     port = _free_port()
     ctx = mp.get_context('spawn')
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, tmp, B, hip_graph, q, ring)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, tmp, B, hip_graph, q, ring, overlap)) for r in range(world)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=600) for _ in range(world)), key=lambda r: r[0])
