@@ -1,0 +1,13 @@
+mkdir -p gpurun_out
+python bench.py --quiet > gpurun_out/r05_g_bench.json 2> gpurun_out/r05_g_bench.err
+tail -c 400 gpurun_out/r05_g_bench.json
+TAG=_r05g bash tools/prof_step.sh
+bash tools/pmc_traffic.sh
+bash tools/pmc_mfma.sh
+bash tools/prof_cfg.sh STFT_L41_enhance_graph pmc
+bash tools/prof_cfg.sh front_L41_S3_N512_B128_graph pmc
+bash tools/prof_cfg.sh front_DPCL_finetuning_graph
+bash tools/prof_cfg.sh front_DPCL_inference
+python tools/bench_configs.py > gpurun_out/r05_g_other_configs.jsonl 2>/dev/null
+python -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/r05_g_gpu_suite.txt
+cat gpurun_out/r05_g_gpu_suite.txt

@@ -14,28 +14,46 @@ import sys
 
 # launch grid (workgroups) -> what that launch is in the B=64 front_DPCL step (bench.py): the product family runs many shapes under
 # one kernel name, and traffic only means something per shape
-STEP_SHAPES = {
-    ('<2, 0', 240): 'front conv 15360x256x1024 (3-way split-K)', ('<0, 0', 400): 'projection 5120x2400xD', ('<0, 0', 1600): 'dense fwd 5120x10240x600',
-    ('<0, 1', 1000): 'dX 5120x600xK (dense: K=10240 5-way split-K / LSTM: K=2400)', ('<1, 0', 1000): 'dense dW 600x10240x5120',
-    ('<1, 0', 250): 'LSTM dWx 600x2400x5120', ('<1, 0', 240): 'LSTM dU 2x300x1200x5120 / L0 dWx 256x2400x5120',
-}
+# Round 5: persistent / stream-K grids make several shapes launch the same number of workgroups, so a launch is named by its POSITION in
+# the step's product sequence (host issue order of an eager step = dispatch order; a step starts at the front conv, variant <2, 0, ...>):
+STEP_SEQUENCE = ['front conv 15360x256x1024 (stream-K)', 'projection L0 5120x2400x256', 'projection L1 5120x2400x600',
+                 'projection L2 5120x2400x600', 'dense fwd 5120x10240x600', 'dense dX 5120x600x10240', 'dense dW block 0 600x6656x5120 (capped)',
+                 'LSTM dX L2 5120x600x2400', 'LSTM dWx L2 600x2400x5120 (capped)', 'LSTM dU L2 2x300x1200x5119 (capped)',
+                 'dense dW block 1 600x1792x5120 (capped)', 'LSTM dX L1 5120x600x2400', 'LSTM dWx L1 600x2400x5120 (capped)',
+                 'LSTM dU L1 2x300x1200x5119 (capped)', 'dense dW block 2 600x1792x5120 (capped)', 'LSTM dU L0 2x300x1200x5119',
+                 'LSTM dWx L0 256x2400x5120']
+# the variant each position is launched as (A loader, B loader, ..., two accumulator sets): a step whose sequence differs (the first
+# pass of a model, bench.py's side-stream-off 'alone' step) is left unlabelled instead of mislabelled
+STEP_VARIANT = ['<2, 0', '<0, 0', '<0, 0', '<0, 0', '<0, 0', '<0, 1', '<1, 0, 3, 0, false', '<0, 1', '<1, 0, 3, 0, false', '<1, 0, 3, 0, false',
+                '<1, 0, 3, 0, false', '<0, 1', '<1, 0, 3, 0, false', '<1, 0, 3, 0, false', '<1, 0, 3, 0, false', '<1, 0, 3, 0, true', '<1, 0, 3, 0, true']
+
+
+def step_label(variant, pos):
+    """(label, next position) of a product launch of kernel variant `variant` ('<..>' template arguments) at sequence position pos."""
+    if variant.startswith('<2, 0'):
+        pos = 0
+    if pos is None or pos >= len(STEP_SEQUENCE) or not variant.startswith(STEP_VARIANT[pos]):
+        return '', None
+    return STEP_SEQUENCE[pos], pos + 1
 
 
 def per_kernel(path, counter):
     db = sqlite3.connect(path)
     cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
     wg = 'workgroup_size_x' if 'workgroup_size_x' in cols else '256'
-    rows = db.execute("select kernel_name, grid_size_x, %s, value from counters_collection where counter_name=?" % wg,
-                      (counter,)).fetchall()
+    did = 'dispatch_id' if 'dispatch_id' in cols else 'rowid'
+    rows = db.execute("select kernel_name, grid_size_x, %s, sum(value), %s from counters_collection where counter_name=? group by %s order by %s"
+                      % (wg, did, did, did), (counter,)).fetchall()
     out = {}
-    for name, gx, wx, v in rows:
-        # the product family runs many shapes under one name: keep them apart by launch grid (= by shape)
+    pos = None
+    for name, gx, wx, v, _ in rows:
+        # the product family runs many shapes under one name: keep them apart by their position in the step (see STEP_SEQUENCE)
         m = re.search(r'gemm_(f32|x6|x3)_kernel<[^>]*>', name)
         if m is None:
             key = name
         else:
             nwg = int(gx) // max(1, int(wx))
-            what = next((v2 for (pre, g), v2 in STEP_SHAPES.items() if g == nwg and m.group(0).split('kernel')[1].startswith(pre)), '')
+            what, pos = step_label(m.group(0).split('kernel')[1], pos)
             key = '%s grid=%d%s' % (m.group(0), nwg, (' [' + what + ']') if what else '')
         out.setdefault(key, []).append(float(v))
     return out
