@@ -85,8 +85,14 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef AMS_KM_ACC_DEPTH
 #define AMS_KM_ACC_DEPTH 1
 #endif
+#ifndef AMS_KM_XREG
+#define AMS_KM_XREG 0       // 1: HARD_ACC keeps the point (E floats) in registers between the distance and the accumulation (one LDS read per group instead of two)
+#endif
 template <int E_, int C_, int MODE, bool HAS_W>
-__global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? 3 : 1) void kmeans_pass_kernel(KmArgs a) {
+#ifndef AMS_KM_WAVES
+#define AMS_KM_WAVES 3
+#endif
+__global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? AMS_KM_WAVES : 1) void kmeans_pass_kernel(KmArgs a) {
     static_assert(E_ % 4 == 0, "rows are staged as 16-byte vectors");
     constexpr bool ACC = (MODE == HARD_ACC || MODE == SOFT_ACC);
     constexpr bool SOFT = (MODE == SOFT_ACC || MODE == SOFT_FINAL);
@@ -193,6 +199,7 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? 3 :
             // multiplied by an opaque 1.0f instead.)
             const float wv = HAS_W ? wb[p0 + tid] : 1.0f;
             const f2 wv2 = {wv, wv};
+            float4 xv4[(AMS_KM_XREG && MODE == HARD_ACC) ? V4 : 1];
             float d2[C_];
             if (SOFT) {
 #pragma unroll
@@ -229,6 +236,7 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? 3 :
 #pragma unroll
                         for (int cp = 0; cp < CP; ++cp) asm volatile("" : "+v"(dp[cp]));
                         const float4 v = *reinterpret_cast<const float4*>(xrow + q4 * 4);
+                        if (AMS_KM_XREG && MODE == HARD_ACC) xv4[q4 % ((AMS_KM_XREG && MODE == HARD_ACC) ? V4 : 1)] = v;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
                             const float xe = k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
@@ -282,13 +290,13 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? 3 :
 #pragma unroll
                         for (int d = 0; d < D; ++d) {
                             asm volatile("" ::: "memory");
-                            vq[d] = *reinterpret_cast<const float4*>(xrow + (d < V4 ? d : V4 - 1) * 4);
+                            if (!AMS_KM_XREG) vq[d] = *reinterpret_cast<const float4*>(xrow + (d < V4 ? d : V4 - 1) * 4);
                         }
 #pragma unroll
                         for (int q4 = 0; q4 < V4; ++q4) {
                             asm volatile("" ::: "memory");
-                            if (q4 + D < V4) vq[(q4 + D) % (D + 1)] = *reinterpret_cast<const float4*>(xrow + (q4 + D) * 4);
-                            const float4 v = vq[q4 % (D + 1)];
+                            if (!AMS_KM_XREG && q4 + D < V4) vq[(q4 + D) % (D + 1)] = *reinterpret_cast<const float4*>(xrow + (q4 + D) * 4);
+                            const float4 v = AMS_KM_XREG ? xv4[q4 % (AMS_KM_XREG ? V4 : 1)] : vq[q4 % (D + 1)];
                             f2 t0 = {v.x, v.y}, t1 = {v.z, v.w};
                             if (W) { t0 = t0 * wv2; t1 = t1 * wv2; }
 #pragma unroll
