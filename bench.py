@@ -28,7 +28,7 @@ for _p in (ROOT, PKG):
 MFMA_F32_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
 MFMA_BF16_PEAK_TFLOPS = 2500.0    # same guide: v_mfma_f32_32x32x16_bf16 dense peak
 # The products run on the 16-bit matrix pipe as f32 arithmetic (csrc/gemm.hip): "fp16x3" where the caller has a bound of each operand
-# (every product of this step but the front conv: both f32 operands scaled by a power of two and split EXACTLY into two fp16 terms,
+# (every product of this step, the front conv included since round 5: both f32 operands scaled by a power of two and split EXACTLY into two fp16 terms,
 # three fp16 MFMA products per f32 product), "bf16x6" otherwise (three bf16 terms, six products) -- f32-level error either way
 # (tests/test_gpu_gemm_f16.py, test_gpu_gemm_x6.py).  The roofline prices the ALGORITHMIC f32 flops (2 M N K) against what that
 # pipe can deliver for them: 16-bit MFMA peak / (MFMA products issued per f32 product, flop-weighted over the launches).
