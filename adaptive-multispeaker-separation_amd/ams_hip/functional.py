@@ -149,7 +149,7 @@ _ORDER = int(_os.environ.get('AMS_OVERLAP_ORDER', '2'))
 _DENSE_MODE = int(_os.environ.get('AMS_DENSE_MODE', '0'))
 _L1_TAIL = int(_os.environ.get('AMS_L1_TAIL', '0'))
 # column blocks (in 256-column tiles) of the dense weight gradient: the first runs beside the top BPTT ring, the others one per later window
-_DW_SPLIT = [int(v) for v in _os.environ.get('AMS_DW_SPLIT', '26,7,7').split(',') if v]
+_DW_SPLIT = [int(v) for v in _os.environ.get('AMS_DW_SPLIT', '24,12,4').split(',') if v]
 
 
 def _dw_cuts(N):
