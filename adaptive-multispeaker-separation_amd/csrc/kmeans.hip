@@ -85,6 +85,9 @@ typedef float f2 __attribute__((ext_vector_type(2)));
 #ifndef AMS_KM_ACC_DEPTH
 #define AMS_KM_ACC_DEPTH 1
 #endif
+#ifndef AMS_KM_DIST_DEPTH
+#define AMS_KM_DIST_DEPTH 1
+#endif
 #ifndef AMS_KM_XREG
 #define AMS_KM_XREG 0       // 1: HARD_ACC keeps the point (E floats) in registers between the distance and the accumulation (one LDS read per group instead of two)
 #endif
@@ -228,14 +231,22 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? AMS
                     f2 dp[CP];
 #pragma unroll
                     for (int cp = 0; cp < CP; ++cp) dp[cp] = (f2){0.f, 0.f};
+                    // the point's groups come from LDS AMS_KM_DIST_DEPTH ahead of the group being consumed: read just in time, each of the
+                    // ten groups put a full LDS round trip (~120 cycles) in front of its eight dependent instructions -- with three waves
+                    // per SIMD that latency, not issue, was the pass (2100 cycles per 64 point-tries against ~740 of issue)
+                    constexpr int DD = AMS_KM_DIST_DEPTH;
+                    float4 vd[DD + 1];
+#pragma unroll
+                    for (int d = 0; d < DD; ++d) vd[d] = *reinterpret_cast<const float4*>(xrow + (d < V4 ? d : V4 - 1) * 4);
 #pragma unroll
                     for (int q4 = 0; q4 < V4; ++q4) {
-                        asm volatile("" ::: "memory");              // LDS operands just in time: no wholesale preload into VGPRs
+                        asm volatile("" ::: "memory");              // no wholesale preload of the point into VGPRs
                         // the differences of all ten groups are independent while a pair's chain is serial: left alone the scheduler
                         // computes every difference first (80 live registers, spilled under the 168-VGPR bound) -- the chains are DUE here
 #pragma unroll
                         for (int cp = 0; cp < CP; ++cp) asm volatile("" : "+v"(dp[cp]));
-                        const float4 v = *reinterpret_cast<const float4*>(xrow + q4 * 4);
+                        if (q4 + DD < V4) vd[(q4 + DD) % (DD + 1)] = *reinterpret_cast<const float4*>(xrow + (q4 + DD) * 4);
+                        const float4 v = vd[q4 % (DD + 1)];
                         if (AMS_KM_XREG && MODE == HARD_ACC) xv4[q4 % ((AMS_KM_XREG && MODE == HARD_ACC) ? V4 : 1)] = v;
 #pragma unroll
                         for (int k = 0; k < 4; ++k) {
@@ -243,14 +254,12 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? AMS
                             const f2 xx = {xe, xe};
 #pragma unroll
                             for (int cp = 0; cp < CP; ++cp) {
-                                constexpr int dummy = 0;
                                 const int c0 = 2 * cp, c1 = (2 * cp + 1 < C_) ? 2 * cp + 1 : 2 * cp;
 #if AMS_KM_SGPR_CENT
                                 const f2 cc = {cs[(c0 * E_ + 4 * q4 + k) % (SOFT ? 1 : C_ * E_)], cs[(c1 * E_ + 4 * q4 + k) % (SOFT ? 1 : C_ * E_)]};
 #else
                                 const f2 cc = {scent[c0 * E_ + 4 * q4 + k], scent[c1 * E_ + 4 * q4 + k]};
 #endif
-                                (void)dummy;
                                 const f2 df = xx - cc;
                                 dp[cp] = __builtin_elementwise_fma(W ? df * wv2 : df, df, dp[cp]);
                             }
@@ -428,29 +437,44 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? AMS
     __syncthreads();
     if (!last_sh) return;
     const float* pr = a.part + (long)r * a.G * NV;
+    // chunk partials fetched EIGHT AT A TIME and then added in chunk order: as one dependent chain of agent-scope loads per element the
+    // finish put ~20 us at the end of every pass (225 us instead of 199 + a 5-us reduce launch)
+    auto chunk_sum = [&](int k) {
+        float s = 0.f;
+        int gg = 0;
+        for (; gg + 8 <= a.G; gg += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = __hip_atomic_load(pr + (long)(gg + j) * NV + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s = __fadd_rn(s, v[j]);
+        }
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (gg + j < a.G) ? __hip_atomic_load(pr + (long)min(gg + j, a.G - 1) * NV + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) if (gg + j < a.G) s = __fadd_rn(s, v[j]);
+        return s;
+    };
     if (ACC) {
         if (tid < C_ * E_) {
             const int c = tid / E_;
-            float num = 0.f, den = 0.f;
-            for (int gg = 0; gg < a.G; ++gg) {
-                num = __fadd_rn(num, __hip_atomic_load(pr + (long)gg * NV + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                den = __fadd_rn(den, __hip_atomic_load(pr + (long)gg * NV + C_ * E_ + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            }
+            const float num = chunk_sum(tid), den = chunk_sum(C_ * E_ + c);
             a.fin_out[(long)r * C_ * E_ + tid] = ((num) / (den));
             if (a.fin_den && (tid % E_) == 0) a.fin_den[(long)r * C_ + c] = den;
         }
-    } else if (tid == 0 && a.fin_out) {
-        float inertia = 0.f;
+    } else if (tid < C_ && a.fin_out) {
+        const float tot = chunk_sum(tid), cnt = chunk_sum(C_ + tid);
+        __shared__ float q_sh[C_];
+        q_sh[tid] = ((tot) / (cnt));
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (tid == 0) {
+            float inertia = 0.f;
 #pragma unroll
-        for (int c = 0; c < C_; ++c) {
-            float tot = 0.f, cnt = 0.f;
-            for (int gg = 0; gg < a.G; ++gg) {
-                tot = __fadd_rn(tot, __hip_atomic_load(pr + (long)gg * NV + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-                cnt = __fadd_rn(cnt, __hip_atomic_load(pr + (long)gg * NV + C_ + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            }
-            inertia = __fadd_rn(inertia, ((tot) / (cnt)));
+            for (int c = 0; c < C_; ++c) inertia = __fadd_rn(inertia, q_sh[c]);
+            a.fin_out[r] = inertia;
         }
-        a.fin_out[r] = inertia;
     }
 }
 
