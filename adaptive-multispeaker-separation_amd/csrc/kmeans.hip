@@ -6,8 +6,10 @@
 // for the next iteration, and nothing larger than [R, chunks, C*(E+1)] partial sums is written.
 //
 // Bit-exact hard labels.  tf.unsorted_segment_sum is order-nondeterministic; oracle/kmeans.py and these kernels
-// share ONE summation order: 2048-point chunks; lane j (0..255) adds its 8 points j, j+256, .. sequentially; a
-// halving tree v[j] += v[j+s], s = 128..1, combines the lanes; chunk totals are added in chunk order.  HARD distances are ONE
+// share ONE summation order: 8192-point chunks; lane j (0..255) adds its 32 points j, j+256, .. sequentially; each wavefront
+// (64 consecutive lanes) combines its lanes by a halving tree v[j] += v[j+s], s = 32..1; the wavefront totals are added sequentially
+// in (chunk, wavefront) order.  (The SOFT modes, which are tolerance-checked, keep 2048-point chunks and one 256-lane tree: their
+// 64 rows would not fill the device with 8192-point workgroups.)  HARD distances are ONE
 // fused chain over e, d <- fma((x_e - c_e) w, x_e - c_e, d) (round 5: oracle/kmeans.py sqdist_fused, fma32); everything else
 // (soft distances, normalisation, inertia) accumulates left-to-right with separate multiply and add (no contraction), sqrt is IEEE,
 // ties pick the lowest cluster (tf.argmin).
@@ -15,6 +17,7 @@
 // Algorithmic bytes per pass: L*E*4 per row (+ L*4 weights); x[b] is shared by the `tries` rows of an utterance
 // through L2.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 // Bit-exact parity with oracle/kmeans.py needs IEEE mul/add (no FMA contraction), sqrt and divide: contraction is
 // switched off for this translation unit (see Makefile) and sqrtf / operator/ are the correctly rounded forms
@@ -24,7 +27,8 @@
 
 namespace {
 
-constexpr int CHUNK = 2048, LANES = 256, PPL = CHUNK / LANES;
+constexpr int CHUNK_SOFT = 2048, CHUNK_HARD = 8192, LANES = 256;
+__host__ __device__ constexpr int chunk_of(bool soft) { return soft ? CHUNK_SOFT : CHUNK_HARD; }
 
 enum { HARD_ACC = 0, SOFT_ACC = 1, HARD_FINAL = 2, SOFT_FINAL = 3 };
 
@@ -61,7 +65,7 @@ struct KmArgs {
     int32_t* labels;       // [R, L] (hard final) or null
     float* soft;           // [R, L, C] (soft final) or null
     long L;
-    int b, tries, G;
+    int b, tries, G;       // G chunks per row; partial rows per row: G (soft modes) or 4 G (hard modes: one per wavefront)
     int w_mod_b;           // 1: weight row = r % b (reference tile quirk), 0: r / tries
     float beta;
     float one;             // 1.0f, opaque to the compiler (see the HARD modes of kmeans_pass_kernel)
@@ -100,6 +104,7 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? AMS
     constexpr bool ACC = (MODE == HARD_ACC || MODE == SOFT_ACC);
     constexpr bool SOFT = (MODE == SOFT_ACC || MODE == SOFT_FINAL);
     constexpr int NV = ACC ? C_ * (E_ + 1) : 2 * C_;
+    constexpr int CHUNK = chunk_of(SOFT), PPL = CHUNK / LANES;
     constexpr int LD = E_ + 4;                     // 16-byte aligned rows; 16 lanes x 16 B at this pitch cover all 64 banks
     constexpr int V4 = E_ / 4, V2 = E_ / 2;
     constexpr int BUF = (256 * LD > 128 * 64) ? 256 * LD : 128 * 64;
@@ -372,7 +377,29 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? AMS
             }
         }
     }
-    // halving tree over the 256 lanes: s = 128, 64 through LDS (in batches of <= 64 values, VALUE-major so the 64 lanes of a
+    constexpr int NPW = SOFT ? 1 : 4;                              // partial rows per workgroup
+    if (!SOFT) {
+        // HARD modes: every wavefront is a partial of its own -- lanes combined by the halving tree l += l + s (s = 32 .. 1) on the VALU
+        // (gfx950's v_permlane32_swap / v_permlane16_swap bring the upper half / the odd 16-lane rows down, row_shl DPP does the rest);
+        // the four totals are added by the finisher in wavefront order.  No LDS, no barrier, all four waves busy.
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            float v = acc[i];
+            v = __fadd_rn(v, lane_above<32>(v));
+            v = __fadd_rn(v, lane_above<16>(v));
+            v = __fadd_rn(v, lane_above<8>(v));
+            v = __fadd_rn(v, lane_above<4>(v));
+            v = __fadd_rn(v, lane_above<2>(v));
+            v = __fadd_rn(v, lane_above<1>(v));
+            if (lane == 0) {
+                float* const dst = a.part + (((long)r * a.G + g) * 4 + wave) * NV + i;
+                if (a.tickets) __hip_atomic_store(dst, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // write-through: read by the finisher
+                else *dst = v;
+            }
+        }
+        if (a.tickets) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's partial is acknowledged before the barrier below
+    } else {
+    // SOFT modes: halving tree over the 256 lanes: s = 128, 64 through LDS (in batches of <= 64 values, VALUE-major so the 64 lanes of a
     // wave touch 64 consecutive words -- lane-major put every lane on one bank: 64-way conflicts), s = 32..1 by shuffles.
     // NV is a compile-time constant, so both loops unroll fully and `acc` stays in registers.
 #pragma unroll
@@ -406,10 +433,6 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? AMS
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             float v = acc[i];
-            // lane j += lane j + s for s = 32 .. 1 -- the halving tree of the summation order -- on the VALU: gfx950's
-            // v_permlane32_swap / v_permlane16_swap bring the upper half / the odd 16-lane rows down, row_shl DPP does the rest.
-            // (As __shfl_down this was 6 ds_bpermute round trips per value, 492 per workgroup, all on wave 0: the tail of the
-            // workgroup was 27 % of its lifetime.)
             v = __fadd_rn(v, lane_above<32>(v));
             v = __fadd_rn(v, lane_above<16>(v));
             v = __fadd_rn(v, lane_above<8>(v));
@@ -423,10 +446,12 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? AMS
             }
         }
     }
+    }
     if (a.tickets == nullptr) return;
     // the partials leave with agent-scope stores and the arrival is counted once they are acknowledged (workgroup-scope release =
     // s_waitcnt vmcnt(0); NOT __threadfence(): csrc/dpcl.hip); the last chunk's workgroup finishes the row
     __shared__ int last_sh;
+    if (!SOFT) __syncthreads();                                    // all four wavefronts' partials are out
     if (tid == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -436,13 +461,14 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? AMS
     }
     __syncthreads();
     if (!last_sh) return;
-    const float* pr = a.part + (long)r * a.G * NV;
+    const int NP = a.G * NPW;
+    const float* pr = a.part + (long)r * NP * NV;
     // chunk partials fetched EIGHT AT A TIME and then added in chunk order: as one dependent chain of agent-scope loads per element the
     // finish put ~20 us at the end of every pass (225 us instead of 199 + a 5-us reduce launch)
     auto chunk_sum = [&](int k) {
         float s = 0.f;
         int gg = 0;
-        for (; gg + 8 <= a.G; gg += 8) {
+        for (; gg + 8 <= NP; gg += 8) {
             float v[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[j] = __hip_atomic_load(pr + (long)(gg + j) * NV + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -451,9 +477,9 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? AMS
         }
         float v[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (gg + j < a.G) ? __hip_atomic_load(pr + (long)min(gg + j, a.G - 1) * NV + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+        for (int j = 0; j < 8; ++j) v[j] = (gg + j < NP) ? __hip_atomic_load(pr + (long)min(gg + j, NP - 1) * NV + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) if (gg + j < a.G) s = __fadd_rn(s, v[j]);
+        for (int j = 0; j < 8; ++j) if (gg + j < NP) s = __fadd_rn(s, v[j]);
         return s;
     };
     if (ACC) {
@@ -478,7 +504,7 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? AMS
     }
 }
 
-// Sum chunk partials in chunk order; ACC passes: centroid = num / den.  FINAL passes: inertia[r] = sum_c tot_c/cnt_c.
+// Sum the G partial rows of a row in order; ACC passes: centroid = num / den.  FINAL passes: inertia[r] = sum_c tot_c/cnt_c.
 __global__ void kmeans_reduce_kernel(const float* __restrict__ part, float* __restrict__ out, float* __restrict__ den_out, int R,
                                      int G, int C, int E, int final_) {
     const int NV = final_ ? 2 * C : C * (E + 1);
@@ -502,6 +528,271 @@ __global__ void kmeans_reduce_kernel(const float* __restrict__ part, float* __re
         out[(long)r * C * E + k] = ((num) / (den));
         if (den_out && (k % E) == 0) den_out[(long)r * C + c] = den;
     }
+}
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// HARD_ACC for E = 40, C = 2, no silence weights, tries a multiple of 5: TQ tries of an utterance from ONE read of its points.
+//
+// kmeans_pass_kernel gives every try a workgroup of its own: the point is staged and read per try (10 x the LDS traffic and L2 reads of
+// the utterance) and each lane carries the 82 running sums of ITS points -- 3 waves per SIMD, a latency mix at 0.13 of HBM
+// (profiles/r05_i_cfg_*: 205-210 us per pass).  Here a workgroup of TEN waves owns one 64-lane column of a chunk (the unit of the
+// summation order, see the top of the file) for TQ = 5 tries, and every wave has two roles per iteration of two 64-point slabs:
+//   labels   wave (try tt = wave % 5, slab k = wave / 5): lane = point, the point's 40 values from LDS, the try's centroids in SGPRs
+//            for the whole launch, the fused distance chains of kmeans_pass_kernel, argmin -> ONE 64-bit ballot per (slab, try) in LDS;
+//   sums     wave q owns components 4q .. 4q+3: its float4 of the point stays in registers and is accumulated into 5 tries x 2
+//            clusters x 4 running sums (40 registers instead of 82) under the ballots of the previous iteration, as v_pk_fma with a
+//            0/1 factor exactly like kmeans_pass_kernel; wave q < 5 also keeps try q's two counts.
+// Same operations on the same operands in the same order per running sum as kmeans_pass_kernel => bit-identical partials; the
+// centroids are read once per workgroup, the points once per 5 tries (420 MB per pass at the benchmark shape instead of 2.1 GB).
+// One barrier per iteration: labels of iteration i and sums of iteration i-1 run between the same two barriers (x and the ballots are
+// double-buffered).  <= 96 VGPRs: two workgroups (20 waves) per CU.
+constexpr int TQ = 5;
+constexpr size_t KT_LDS_BYTES = 3 * 128 * 40 * sizeof(float);      // kmeans_hard_tries_kernel's x buffers (dynamic LDS)
+struct KtArgs {
+    const float* xn; const float* cent; float* part; unsigned* tickets; float* fin_out; float* fin_den;
+    long L; int b, tries, G;
+    unsigned long long* dbg;           // AMS_KT_DBG builds: per (workgroup, wave) {HW_ID | XCC_ID << 32, start, end} (s_memrealtime)
+};
+
+__device__ __forceinline__ float mask_to_float(unsigned long long m) {       // 1.0f in the lanes whose bit of the (wave-uniform) mask is set
+    float f;
+    // the "s" constraint does not make a value scalar: pinned with readfirstlane (folded away where the compiler knows it is uniform)
+    const unsigned long long ms = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(m >> 32)) << 32) |
+                                  (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+    asm volatile("v_cndmask_b32_e64 %0, 0, 1.0, %1" : "=v"(f) : "s"(ms));
+    return f;
+}
+
+// Halving trees l += l + s (s = 32 .. 1) of FOUR values with the additions of four lane_above trees: v_permlane32_swap exchanges the upper
+// half of a with the lower half of b, so ONE add does s = 32 for both; v_permlane16_swap (odd 16-lane rows of the first <-> even rows of
+// the second) does the same for s = 16 on the two sums; s = 8 .. 1 run inside the 16-lane rows on one register.  3 swaps + 7 adds for
+// what was 8 swaps + 24 adds.  The totals of a / c / b / d are in lanes 0 / 16 / 32 / 48.
+__device__ __forceinline__ float tree4(float a, float b, float c, float d) {
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+    float ab = __fadd_rn(a, b);
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(c), "+v"(d));
+    float cd = __fadd_rn(c, d);
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(ab), "+v"(cd));
+    float v = __fadd_rn(ab, cd);
+    v = __fadd_rn(v, lane_above<8>(v));
+    v = __fadd_rn(v, lane_above<4>(v));
+    v = __fadd_rn(v, lane_above<2>(v));
+    v = __fadd_rn(v, lane_above<1>(v));
+    return v;
+}
+
+#ifndef AMS_KT_WAVES
+#define AMS_KT_WAVES 6
+#endif
+__global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(KtArgs a) {
+    constexpr int E_ = 40, C_ = 2, NV = C_ * (E_ + 1), LD = E_, V4 = E_ / 4, SL = CHUNK_HARD / LANES;
+    // x is TRIPLE-buffered: the labels read slab pair `it`, the sums re-read their components of pair it - 1 (no copy kept in registers),
+    // the staging writes pair it + 1 -- all between the same two barriers.  Rows are UNPADDED (3 x 20 KB: two workgroups fit beside each
+    // other, 128 KB of LDS are usable per CU) and the 16-byte groups of a row are rotated by one for rows 8..15 of every 16: group c of
+    // row p sits at slot (c + ((p >> 3) & 1)) % 10, so that 16 lanes reading the same group of 16 consecutive rows (160 B apart: 10 p
+    // mod 16 takes only the 8 even values) still cover all 64 banks.
+    // (dynamic: with the size in sight hipcc sees that six waves per SIMD cannot be reached, settles for five and spends 87-99 VGPRs;
+    // the workgroup's ten waves sit 3 + 3 + 2 + 2 on the SIMDs, so a second workgroup needs SIX slots on a SIMD: <= 80 VGPRs)
+    extern __shared__ __attribute__((aligned(16))) float kt_dyn[];
+    float (*xbuf)[128 * LD] = reinterpret_cast<float (*)[128 * LD]>(kt_dyn);
+    __shared__ float mf[2][2][TQ][64];                             // 1.0 where (slab, try, lane) chose cluster 1 and is a point, else 0.0
+    __shared__ int cbuf[TQ][C_];
+    __shared__ int last_sh[TQ];
+#ifdef AMS_KT_PAD                       /* occupancy experiment: extra LDS so that fewer workgroups share a CU */
+    __shared__ float padbuf[AMS_KT_PAD];
+    if (a.L < 0) padbuf[threadIdx.x] = 1.f, a.part[0] = padbuf[threadIdx.x ^ 1];
+#endif
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const unsigned long long dbg_t0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;       // placement / lifetime probe (tools/kt_probe.py); null in production
+    // workgroup -> (utterance, try group, column, chunk), the chunk slowest: a short last chunk's workgroups come last
+    int id = blockIdx.x;
+    const int ntg = a.tries / TQ;
+    const int ub = id % a.b; id /= a.b;
+    const int tg = id % ntg; id /= ntg;
+    const int k4 = id & 3, g = id >> 2;
+    const float* xb = a.xn + (long)ub * a.L * E_;
+    const long base = (long)g * CHUNK_HARD + k4 * 64;              // slab i of this column: points base + 256 i .. + 63
+    const long left = a.L - base;
+    const int nsl = left <= 0 ? 0 : (int)min((long)SL, (left + LANES - 1) / LANES);
+    const int nit = (nsl + 1) / 2;
+    const int row0 = ub * a.tries + tg * TQ;
+    auto valid_of = [&](int slab) {                                 // lanes of a slab that are points of the utterance
+        const long nv = a.L - (base + (long)slab * LANES);
+        return nv >= 64 ? ~0ull : (nv <= 0 ? 0ull : ((1ull << nv) - 1ull));
+    };
+
+    // label role
+    const int tt = wave % TQ, kk = wave / TQ;
+    float cs[C_ * E_];
+    {
+        const float* cg = a.cent + (long)(row0 + tt) * C_ * E_;
+#pragma unroll
+        for (int i = 0; i < C_ * E_; ++i) cs[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cg[i])));
+    }
+    // the counts are integers (<= 2048 per column and chunk): every order of adding them in float gives the same float, so the label
+    // wave counts the bits of its ballots on the scalar unit instead of the sums role adding 0/1 factors lane by lane
+    int n0 = 0, n1 = 0;
+    // sums role
+    float acc[TQ][C_][4];
+#pragma unroll
+    for (int t = 0; t < TQ; ++t)
+#pragma unroll
+        for (int c = 0; c < C_; ++c)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[t][c][j] = 0.f;
+
+    // staging: thread -> (point pr of a slab, 16-byte group c4) of BOTH slabs of an iteration
+    const int pr = tid / V4, c4 = tid - pr * V4;
+    float4 pf[2];
+    auto fetch = [&](int it) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const long p = base + (long)(2 * it + k) * LANES + pr;
+            pf[k] = (p < a.L) ? *reinterpret_cast<const float4*>(xb + p * E_ + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    const int c4s = (c4 + ((pr >> 3) & 1)) % V4;                   // this group's slot in its row
+    auto stage = [&](int bf) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) *reinterpret_cast<float4*>(&xbuf[bf][(k * 64 + pr) * LD + c4s * 4]) = pf[k];
+    };
+    // reads: lane = row; group c at slot c + f (f = 0 / 1) except group 9 of the rotated rows, which wrapped to slot 0
+    const int rot = (lane >> 3) & 1;
+    const int off_lab = (kk * 64 + lane) * LD + rot * 4;            // + 4 c for c < 9
+    const int off_lab9 = (kk * 64 + lane) * LD + (rot ? 0 : 36);
+    const int off_sum = lane * LD + ((wave + rot) % V4) * 4;        // + 64 LD k
+    if (nit > 0) {
+        fetch(0);
+        stage(0);
+        if (nit > 1) fetch(1);
+    }
+    __syncthreads();
+    int bprev = 2, bcur = 0, bnext = 1;
+    for (int it = 0; it <= nit; ++it) {
+        const int cur = it & 1;
+        if (it > 0) {
+            // ---- sums of iteration it - 1 under its labels: the 0/1 factors come from LDS as floats (as ballots they cost two v_readlane
+            // and two v_cndmask per try and slab on the VALU, which is what bounds this kernel)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const float vf = mask_to_float(valid_of(2 * (it - 1) + k));
+                const float4 xs = *reinterpret_cast<const float4*>(&xbuf[bprev][off_sum + k * 64 * LD]);
+                float m1[TQ];
+#pragma unroll
+                for (int t = 0; t < TQ; ++t) m1[t] = mf[cur ^ 1][k][t][lane];
+                const f2 t0 = {xs.x, xs.y}, t1 = {xs.z, xs.w};
+#pragma unroll
+                for (int t = 0; t < TQ; ++t) {
+                    // {m0, m1} in ONE register pair: the packed FMAs of cluster c take component c for both halves (op_sel)
+                    const f2 mm = {vf - m1[t], m1[t]};
+                    const f2 mm0 = __builtin_shufflevector(mm, mm, 0, 0), mm1 = __builtin_shufflevector(mm, mm, 1, 1);
+                    f2 a00 = {acc[t][0][0], acc[t][0][1]}, a01 = {acc[t][0][2], acc[t][0][3]};
+                    f2 a10 = {acc[t][1][0], acc[t][1][1]}, a11 = {acc[t][1][2], acc[t][1][3]};
+                    // m is 0 or 1, so t * m is exact and the fused form rounds exactly like multiply-then-add (kmeans_pass_kernel)
+                    a00 = __builtin_elementwise_fma(t0, mm0, a00); a01 = __builtin_elementwise_fma(t1, mm0, a01);
+                    a10 = __builtin_elementwise_fma(t0, mm1, a10); a11 = __builtin_elementwise_fma(t1, mm1, a11);
+                    asm volatile("" : "+v"(a00), "+v"(a01), "+v"(a10), "+v"(a11));      // due HERE: left alone they sink below the labels
+                    acc[t][0][0] = a00.x; acc[t][0][1] = a00.y; acc[t][0][2] = a01.x; acc[t][0][3] = a01.y;
+                    acc[t][1][0] = a10.x; acc[t][1][1] = a10.y; acc[t][1][2] = a11.x; acc[t][1][3] = a11.y;
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);                          // sums and labels are independent streams: interleaved they need both register sets
+        if (it < nit) {
+            // ---- labels of (slab kk, try tt): fused chains d <- fma(x_e - c_e, x_e - c_e, d), both clusters in one packed register
+            const float* xrow = &xbuf[bcur][off_lab];
+            f2 dp = {0.f, 0.f};
+            float4 vd[2];
+            vd[0] = *reinterpret_cast<const float4*>(xrow);
+#pragma unroll
+            for (int q4 = 0; q4 < V4; ++q4) {
+                asm volatile("" ::: "memory");                      // no wholesale preload of the point into VGPRs
+                asm volatile("" : "+v"(dp));
+                if (q4 + 1 < V4) vd[(q4 + 1) & 1] = *reinterpret_cast<const float4*>(q4 + 1 < V4 - 1 ? xrow + (q4 + 1) * 4 : &xbuf[bcur][off_lab9]);
+                const float4 v = vd[q4 & 1];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float xe = k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
+                    const f2 xx = {xe, xe};
+                    const f2 cc = {cs[4 * q4 + k], cs[E_ + 4 * q4 + k]};
+                    const f2 df = xx - cc;
+                    dp = __builtin_elementwise_fma(df, df, dp);
+                }
+            }
+            const bool one = sqrtf(dp.y) < sqrtf(dp.x);            // ties pick cluster 0 (tf.argmin)
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(one);
+            const unsigned long long valid = valid_of(2 * it + kk);
+            mf[cur][kk][tt][lane] = mask_to_float(bal & valid);
+            n1 += __builtin_popcountll(bal & valid);
+            n0 += __builtin_popcountll(~bal & valid);
+            // ---- stage the next iteration's slabs, request the ones after it
+            if (it + 1 < nit) {
+                stage(bnext);
+                if (it + 2 < nit) fetch(it + 2);
+            }
+        }
+        __syncthreads();
+        const int bt = bprev; bprev = bcur; bcur = bnext; bnext = bt;
+    }
+
+    // every wave's lanes by the halving tree, FOUR running sums per tree (tree4): components 4 wave .. + 3 of the TQ rows; always
+    // write-through stores (the finisher may sit on another XCD)
+    const int NP = 4 * a.G, pi = g * 4 + k4;
+    const int jl = ((lane >> 4) & 1) * 2 + (lane >> 5);            // lanes 0 / 16 / 32 / 48 hold components 0 / 2 / 1 / 3 of a group
+#pragma unroll
+    for (int t = 0; t < TQ; ++t)
+#pragma unroll
+        for (int c = 0; c < C_; ++c) {
+            const float v = tree4(acc[t][c][0], acc[t][c][1], acc[t][c][2], acc[t][c][3]);
+            if ((lane & 15) == 0)
+                __hip_atomic_store(a.part + ((long)(row0 + t) * NP + pi) * NV + c * E_ + wave * 4 + jl, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    if (a.dbg && lane == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        unsigned long long* d = a.dbg + ((long)blockIdx.x * 10 + wave) * 4;
+        d[0] = hw | ((unsigned long long)xcc << 32);
+        d[1] = dbg_t0;
+        d[2] = __builtin_amdgcn_s_memrealtime();
+    }
+    // counts of try tt: slab parity 1's wave hands its bits to parity 0's, which stores the totals
+    if (kk == 1 && lane == 0) { cbuf[tt][0] = n0; cbuf[tt][1] = n1; }
+    __syncthreads();
+    if (kk == 0 && lane < C_) {
+        const int tot = (lane == 0 ? n0 : n1) + cbuf[tt][lane];
+        __hip_atomic_store(a.part + ((long)(row0 + tt) * NP + pi) * NV + C_ * E_ + lane, (float)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (a.tickets == nullptr) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's partials are acknowledged
+    __syncthreads();
+    if (tid < TQ) {
+        const int r = row0 + tid;
+        const int last = atomicAdd(a.tickets + r, 1u) == (unsigned)NP - 1u;
+        if (last) __hip_atomic_store(a.tickets + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_sh[tid] = last;
+    }
+    __syncthreads();
+    // rows whose last partial this workgroup stored are finished here: 80 threads per row, partial rows in order, eight loads at a time
+    const int ft = tid / (C_ * E_), fk = tid - ft * (C_ * E_);
+    if (ft >= TQ || !last_sh[ft]) return;
+    const int r = row0 + ft;
+    const float* prr = a.part + (long)r * NP * NV;
+    auto chunk_sum = [&](int k) {
+        float s = 0.f;
+        for (int gg = 0; gg < NP; gg += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = __hip_atomic_load(prr + (long)min(gg + j, NP - 1) * NV + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (gg + j < NP) s = __fadd_rn(s, v[j]);
+        }
+        return s;
+    };
+    const int c = fk / E_;
+    const float num = chunk_sum(fk), den = chunk_sum(C_ * E_ + c);
+    a.fin_out[(long)r * C_ * E_ + fk] = ((num) / (den));
+    if (a.fin_den && (fk % E_) == 0) a.fin_den[(long)r * C_ + c] = den;
 }
 
 // centroids[r,c,:] = xn[r/tries, idx[r,c], :]                 (Kmeans_2.py:61-71)
@@ -564,9 +855,22 @@ ams_status ams_kmeans_normalize(const float* x, float* xn, long nrows, int E, vo
     return ams_check_launch();
 }
 
+#ifdef AMS_KT_DBG
+static unsigned long long* g_kt_dbg = nullptr;
+unsigned long long* ams_dbg_kt_buffer(size_t words) {       // device buffer the next launches write their placement / times to
+    if (!g_kt_dbg) { hipMalloc((void**)&g_kt_dbg, words * 8); hipMemset(g_kt_dbg, 0, words * 8); }
+    return g_kt_dbg;
+}
+int ams_dbg_kt_occupancy() {
+    int n = -1;
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kmeans_hard_tries_kernel, 640, KT_LDS_BYTES);
+    return n;
+}
+#endif
+
 size_t ams_kmeans_workspace_bytes(int R, long L, int E, int C) {
-    const int G = ceil_div(L, CHUNK);
-    return sizeof(float) * (size_t)R * G * C * (E + 1);
+    const int NP = max(ceil_div(L, CHUNK_SOFT), 4 * ceil_div(L, CHUNK_HARD));      // partial rows per row, whichever mode runs
+    return sizeof(float) * (size_t)R * NP * C * (E + 1);
 }
 
 ams_status ams_kmeans_init(const float* xn, const int32_t* init_idx, float* centroids, int b, int tries, long L, int E, int C,
@@ -587,13 +891,29 @@ ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent
     if (ws_bytes < ams_kmeans_workspace_bytes(R, L, E, C)) return AMS_E_WORKSPACE_TOO_SMALL;
     hipStream_t st = (hipStream_t)stream;
     KmArgs a{};
-    a.xn = xn; a.w = w; a.cent = cent_in; a.part = (float*)ws; a.L = L; a.b = b; a.tries = tries; a.G = ceil_div(L, CHUNK);
+    a.xn = xn; a.w = w; a.cent = cent_in; a.part = (float*)ws; a.L = L; a.b = b; a.tries = tries; a.G = ceil_div(L, chunk_of(beta >= 0.f));
     a.w_mod_b = w_mod_b; a.beta = beta; a.one = 1.0f;
     a.tickets = (unsigned*)tickets; a.fin_out = cent_out; a.fin_den = den_out;
+    // AMS_KM_TRIES=0: every try a workgroup of its own (kmeans_pass_kernel) also where kmeans_hard_tries_kernel applies -- same bits
+    static const bool tries_kernel = [] { const char* e = getenv("AMS_KM_TRIES"); return !(e && e[0] == '0'); }();
+    if (tries_kernel && beta < 0.f && !w && E == 40 && C == 2 && tries % TQ == 0) {
+        KtArgs k{};
+        k.xn = xn; k.cent = cent_in; k.part = (float*)ws; k.tickets = (unsigned*)tickets; k.fin_out = cent_out; k.fin_den = den_out;
+        k.L = L; k.b = b; k.tries = tries; k.G = a.G;
+#ifdef AMS_KT_DBG
+        k.dbg = g_kt_dbg;
+#endif
+        hipLaunchKernelGGL(kmeans_hard_tries_kernel, dim3((unsigned)(b * (tries / TQ) * 4 * a.G)), dim3(640), KT_LDS_BYTES, st, k);
+        ams_status s2 = ams_check_launch();
+        if (s2 != AMS_OK || tickets) return s2;
+        hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(ceil_div((long)R * C * E, 256)), dim3(256), 0, st, (const float*)ws, cent_out, den_out, R,
+                           4 * a.G, C, E, 0);
+        return ams_check_launch();
+    }
     ams_status s = beta < 0.f ? launch_pass<HARD_ACC>(a, R, E, C, st) : launch_pass<SOFT_ACC>(a, R, E, C, st);
     if (s != AMS_OK || tickets) return s;
     hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(ceil_div((long)R * C * E, 256)), dim3(256), 0, st, (const float*)ws, cent_out, den_out, R,
-                       a.G, C, E, 0);
+                       beta < 0.f ? 4 * a.G : a.G, C, E, 0);
     return ams_check_launch();
 }
 
@@ -606,12 +926,12 @@ ams_status ams_kmeans_assign(const float* xn, const float* w, const float* cent,
     hipStream_t st = (hipStream_t)stream;
     KmArgs a{};
     a.xn = xn; a.w = w; a.cent = cent; a.part = (float*)ws; a.labels = labels; a.soft = soft; a.L = L; a.b = b; a.tries = tries;
-    a.G = ceil_div(L, CHUNK); a.w_mod_b = w_mod_b; a.beta = beta; a.one = 1.0f;
+    a.G = ceil_div(L, chunk_of(beta >= 0.f)); a.w_mod_b = w_mod_b; a.beta = beta; a.one = 1.0f;
     a.tickets = inertia ? (unsigned*)tickets : nullptr; a.fin_out = inertia; a.fin_den = nullptr;
     ams_status s = beta < 0.f ? launch_pass<HARD_FINAL>(a, R, E, C, st) : launch_pass<SOFT_FINAL>(a, R, E, C, st);
     if (s != AMS_OK) return s;
     if (inertia && !tickets) {
-        hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, st, (const float*)ws, inertia, (float*)nullptr, R, a.G, C, E, 1);
+        hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, st, (const float*)ws, inertia, (float*)nullptr, R, beta < 0.f ? 4 * a.G : a.G, C, E, 1);
         s = ams_check_launch();
     }
     return s;

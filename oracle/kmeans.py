@@ -20,9 +20,12 @@ Restated behaviour (quirks kept):
 
 Summation order.  TensorFlow's unsorted_segment_sum is atomics-based and order-nondeterministic on
 GPU, so any fixed order is a valid restatement.  For bit-exact label parity the oracle and the HIP
-kernel share ONE order (`ordered_sum`): points are cut into chunks of 2048; inside a chunk lane
-j (0..255) adds its 8 points j, j+256, ... sequentially, the 256 lane partials are combined by a
-halving tree (v[j] += v[j+s], s = 128..1), and chunk totals are added sequentially in chunk order.
+kernels share ONE order (`ordered_sum`): points are cut into chunks of 8192; inside a chunk lane
+j (0..255) adds its 32 points j, j+256, ... sequentially; each group of 64 consecutive lanes (one
+wavefront) combines its lane partials by a halving tree (v[j] += v[j+s], s = 32..1); the group totals
+are added sequentially in (chunk, group) order.  (Rounds 1-4: chunks of 2048 and one 256-lane tree;
+round 5 moved the cross-wavefront part of the tree into the sequential tail so that a 64-lane column
+of a chunk is a unit of work that needs no other column -- csrc/kmeans.hip, kmeans_hard_tries_kernel.)
 HARD distances (round 5) are ONE fused chain over e, d <- fma((x_e - c_e) * w, x_e - c_e, d): TensorFlow's reduction order and
 contraction are unspecified, so a fused chain restates `sum((x - c)^2 * w)` as validly as separate multiplies and adds did, and it is
 half the vector instructions on the device (one packed subtract + one packed FMA per e for TWO clusters).  For 0/1 silence weights
@@ -33,8 +36,9 @@ The soft distances, the input normalisation and the inertia keep separate multip
 import numpy as np
 from .dense import L2_EPS
 
-CHUNK = 2048
+CHUNK = 8192
 LANES = 256
+WAVE = 64
 
 
 def ordered_sum(a):
@@ -50,11 +54,13 @@ def ordered_sum(a):
         v = a[g, 0].copy()
         for j in range(1, CHUNK // LANES):
             v = v + a[g, j]
-        s = LANES // 2
-        while s >= 1:
-            v = v[:s] + v[s:2 * s]
-            s //= 2
-        tot = v[0] if tot is None else tot + v[0]
+        for k in range(LANES // WAVE):
+            u = v[k * WAVE:(k + 1) * WAVE]
+            s = WAVE // 2
+            while s >= 1:
+                u = u[:s] + u[s:2 * s]
+                s //= 2
+            tot = u[0] if tot is None else tot + u[0]
     return tot
 
 

@@ -155,7 +155,7 @@ def more():
 
 
 def regen_kmeans():
-    """Outputs of kmeans_hard.npz again from its stored inputs (round 5: the hard distance became a fused chain, oracle/kmeans.py)."""
+    """Outputs of kmeans_hard.npz again from its stored inputs (round 5: the hard distance became a fused chain, then the summation order 8192-point chunks with one tree per wavefront -- oracle/kmeans.py)."""
     k = np.load(os.path.join(HERE, 'kmeans_hard.npz'))
     C, tries, iters = [int(v) for v in k['cfg']]
     cent, lab, best = kmeans.kmeans(k['X'], k['idx'], C, tries, iters, beta=None, notsilent=k['w'], assign_at_end=True)

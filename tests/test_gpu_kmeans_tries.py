@@ -1,0 +1,78 @@
+"""GPU: the hard k-means accumulation pass that serves FIVE tries of an utterance from one read of its points (csrc/kmeans.hip,
+kmeans_hard_tries_kernel; reference models/Kmeans_2.py:145-188 with nb_tries restarts, :47-54).
+
+It applies at E = 40, C = 2, tries a multiple of 5, no silence weights -- the inference / enhance geometry.  What must hold:
+  * labels, centroids and the best restart are IDENTICAL to the float32 oracle (oracle/kmeans.py: one summation order), at ragged
+    lengths, lengths below one 64-point slab, several 8192-point chunks;
+  * it is bit-identical to the one-workgroup-per-try kernel (AMS_KM_TRIES=0, a process of its own) at the full benchmark size, where the
+    oracle would take minutes."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+
+from oracle import kmeans as okm
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+
+def _data(seed, b, L, E=40, C=2, tries=5, spread=0.9):
+    rng = np.random.RandomState(seed)
+    centers = rng.randn(C, E).astype(np.float32) * 1.5
+    lab_true = rng.randint(0, C, (b, L))
+    X = (centers[lab_true] + rng.randn(b, L, E).astype(np.float32) * spread).astype(np.float32)
+    idx = np.stack([rng.choice(L, C, replace=False) for _ in range(b * tries)]).astype(np.int32)
+    return X, idx
+
+
+@pytest.mark.parametrize('b,L,tries,iters', [(2, 3000, 5, 4), (1, 9000, 10, 3), (3, 197, 5, 3), (2, 64, 5, 2), (1, 20480, 5, 3),
+                                            (9, 8192 + 257, 5, 2)])
+def test_five_tries_per_read_is_bit_exact(b, L, tries, iters):
+    from ams_hip import functional as F
+    X, idx = _data(L + tries, b, L, tries=tries)
+    cent_ref, lab_ref, best_ref = okm.kmeans(X, idx, 2, tries, iters, beta=None, notsilent=None, assign_at_end=True)
+    cent, lab, best = F.kmeans(torch.from_numpy(X).cuda(), torch.from_numpy(idx).cuda(), 2, tries, iters, None, None, True)
+    torch.cuda.synchronize()
+    assert np.array_equal(best.cpu().numpy(), best_ref)
+    assert np.array_equal(cent.cpu().numpy(), cent_ref)
+    assert np.array_equal(lab.cpu().numpy(), lab_ref)
+
+
+_CHILD = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[3]); sys.path.insert(0, sys.argv[4])
+from ams_hip import ops
+d = np.load(sys.argv[1])
+xn = ops.kmeans_normalize(torch.from_numpy(d['X']).cuda())
+cent, lab, best, _ = ops.kmeans_run(xn, torch.from_numpy(d['idx']).cuda(), 2, int(d['tries']), int(d['iters']))
+torch.cuda.synchronize()
+np.savez(sys.argv[2], cent=cent.cpu().numpy(), lab=lab.cpu().numpy(), best=best.cpu().numpy())
+'''
+
+
+def test_same_bits_as_one_workgroup_per_try_at_benchmark_size():
+    """b = 64 utterances x 10 restarts x 10 iterations at TF = 20480 (cfg3 inference): every centroid bit, label and chosen restart equal to
+    what kmeans_pass_kernel gives (AMS_KM_TRIES=0 is read once per process, hence the child)."""
+    from ams_hip import ops
+    if os.environ.get('AMS_KM_TRIES') == '0':
+        pytest.skip('this process runs the per-try kernel itself')
+    b, L, tries, iters = 64, 20480, 10, 10
+    X, idx = _data(77, b, L, tries=tries, spread=1.3)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory(prefix='ams_km_') as tmp:
+        np.savez(os.path.join(tmp, 'in.npz'), X=X, idx=idx, tries=tries, iters=iters)
+        env = dict(os.environ, AMS_KM_TRIES='0')
+        r = subprocess.run([sys.executable, '-c', _CHILD, os.path.join(tmp, 'in.npz'), os.path.join(tmp, 'out.npz'),
+                            os.path.join(root, 'adaptive-multispeaker-separation_amd'), root], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        ref = np.load(os.path.join(tmp, 'out.npz'))
+        xn = ops.kmeans_normalize(torch.from_numpy(X).cuda())
+        cent, lab, best, _ = ops.kmeans_run(xn, torch.from_numpy(idx).cuda(), 2, tries, iters)
+        torch.cuda.synchronize()
+        assert np.array_equal(best.cpu().numpy(), ref['best'])
+        assert np.array_equal(cent.cpu().numpy(), ref['cent'])
+        assert np.array_equal(lab.cpu().numpy(), ref['lab'])
