@@ -603,7 +603,9 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
     if (a.L < 0) padbuf[threadIdx.x] = 1.f, a.part[0] = padbuf[threadIdx.x ^ 1];
 #endif
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const unsigned long long dbg_t0 = a.dbg ? __builtin_amdgcn_s_memrealtime() : 0ull;       // placement / lifetime probe (tools/kt_probe.py); null in production
+#ifdef AMS_KT_DBG
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();                    // placement / lifetime probe (tools/kt_probe.py)
+#endif
     // workgroup -> (utterance, try group, column, chunk), the chunk slowest: a short last chunk's workgroups come last
     int id = blockIdx.x;
     const int ntg = a.tries / TQ;
@@ -616,8 +618,9 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
     const int nsl = left <= 0 ? 0 : (int)min((long)SL, (left + LANES - 1) / LANES);
     const int nit = (nsl + 1) / 2;
     const int row0 = ub * a.tries + tg * TQ;
+    const int left32 = (int)min(max(left, (long)0), (long)(SL * LANES));
     auto valid_of = [&](int slab) {                                 // lanes of a slab that are points of the utterance
-        const long nv = a.L - (base + (long)slab * LANES);
+        const int nv = left32 - slab * LANES;
         return nv >= 64 ? ~0ull : (nv <= 0 ? 0ull : ((1ull << nv) - 1ull));
     };
 
@@ -643,13 +646,15 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
 
     // staging: thread -> (point pr of a slab, 16-byte group c4) of BOTH slabs of an iteration
     const int pr = tid / V4, c4 = tid - pr * V4;
+    // the utterance as a buffer resource: 32-bit offsets, and rows past L come back as zeros without a test (raw buffer bounds check)
+    typedef int kt_i32x4 __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), (short)0, (int)(a.L * E_ * 4), 0x00020000);
     float4 pf[2];
+    unsigned foff = (unsigned)((base + pr) * E_ + c4 * 4) * 4u;   // byte offset of this thread's group in slab 0 of the column
     auto fetch = [&](int it) {
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const long p = base + (long)(2 * it + k) * LANES + pr;
-            pf[k] = (p < a.L) ? *reinterpret_cast<const float4*>(xb + p * E_ + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
+        for (int k = 0; k < 2; ++k)
+            pf[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, foff + (unsigned)((2 * it + k) * LANES * E_ * 4), 0, 0));
     };
     const int c4s = (c4 + ((pr >> 3) & 1)) % V4;                   // this group's slot in its row
     auto stage = [&](int bf) {
@@ -737,7 +742,16 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
 
     // every wave's lanes by the halving tree, FOUR running sums per tree (tree4): components 4 wave .. + 3 of the TQ rows; always
     // write-through stores (the finisher may sit on another XCD)
-    const int NP = 4 * a.G, pi = g * 4 + k4;
+    // The output pointers are read from the kernel-argument segment only HERE: held in SGPRs across the loop beside the 80 centroid
+    // scalars they were spilled, and hipcc then shuffled forty SGPR pairs per iteration to make room for the buffer resource.
+    const __attribute__((address_space(4))) KtArgs* ka = (const __attribute__((address_space(4))) KtArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    float* const a_part = ka->part; unsigned* const a_tickets = ka->tickets; float* const a_fin_out = ka->fin_out;
+    float* const a_fin_den = ka->fin_den;
+#ifdef AMS_KT_DBG
+    unsigned long long* const a_dbg = ka->dbg;
+#endif
+    const int NP = 4 * ka->G, pi = g * 4 + k4;
     const int jl = ((lane >> 4) & 1) * 2 + (lane >> 5);            // lanes 0 / 16 / 32 / 48 hold components 0 / 2 / 1 / 3 of a group
 #pragma unroll
     for (int t = 0; t < TQ; ++t)
@@ -745,31 +759,33 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
         for (int c = 0; c < C_; ++c) {
             const float v = tree4(acc[t][c][0], acc[t][c][1], acc[t][c][2], acc[t][c][3]);
             if ((lane & 15) == 0)
-                __hip_atomic_store(a.part + ((long)(row0 + t) * NP + pi) * NV + c * E_ + wave * 4 + jl, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a_part + ((long)(row0 + t) * NP + pi) * NV + c * E_ + wave * 4 + jl, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-    if (a.dbg && lane == 0) {
+#ifdef AMS_KT_DBG
+    if (a_dbg && lane == 0) {
         unsigned hw, xcc;
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
         asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        unsigned long long* d = a.dbg + ((long)blockIdx.x * 10 + wave) * 4;
+        unsigned long long* d = a_dbg + ((long)blockIdx.x * 10 + wave) * 4;
         d[0] = hw | ((unsigned long long)xcc << 32);
         d[1] = dbg_t0;
         d[2] = __builtin_amdgcn_s_memrealtime();
     }
+#endif
     // counts of try tt: slab parity 1's wave hands its bits to parity 0's, which stores the totals
     if (kk == 1 && lane == 0) { cbuf[tt][0] = n0; cbuf[tt][1] = n1; }
     __syncthreads();
     if (kk == 0 && lane < C_) {
         const int tot = (lane == 0 ? n0 : n1) + cbuf[tt][lane];
-        __hip_atomic_store(a.part + ((long)(row0 + tt) * NP + pi) * NV + C_ * E_ + lane, (float)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a_part + ((long)(row0 + tt) * NP + pi) * NV + C_ * E_ + lane, (float)tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (a.tickets == nullptr) return;
+    if (a_tickets == nullptr) return;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's partials are acknowledged
     __syncthreads();
     if (tid < TQ) {
         const int r = row0 + tid;
-        const int last = atomicAdd(a.tickets + r, 1u) == (unsigned)NP - 1u;
-        if (last) __hip_atomic_store(a.tickets + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const int last = atomicAdd(a_tickets + r, 1u) == (unsigned)NP - 1u;
+        if (last) __hip_atomic_store(a_tickets + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         last_sh[tid] = last;
     }
     __syncthreads();
@@ -777,7 +793,7 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
     const int ft = tid / (C_ * E_), fk = tid - ft * (C_ * E_);
     if (ft >= TQ || !last_sh[ft]) return;
     const int r = row0 + ft;
-    const float* prr = a.part + (long)r * NP * NV;
+    const float* prr = a_part + (long)r * NP * NV;
     auto chunk_sum = [&](int k) {
         float s = 0.f;
         for (int gg = 0; gg < NP; gg += 8) {
@@ -791,8 +807,8 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
     };
     const int c = fk / E_;
     const float num = chunk_sum(fk), den = chunk_sum(C_ * E_ + c);
-    a.fin_out[(long)r * C_ * E_ + fk] = ((num) / (den));
-    if (a.fin_den && (fk % E_) == 0) a.fin_den[(long)r * C_ + c] = den;
+    a_fin_out[(long)r * C_ * E_ + fk] = ((num) / (den));
+    if (a_fin_den && (fk % E_) == 0) a_fin_den[(long)r * C_ + c] = den;
 }
 
 // centroids[r,c,:] = xn[r/tries, idx[r,c], :]                 (Kmeans_2.py:61-71)
