@@ -30,7 +30,7 @@ namespace {
 constexpr int CHUNK_SOFT = 2048, CHUNK_HARD = 8192, LANES = 256;
 __host__ __device__ constexpr int chunk_of(bool soft) { return soft ? CHUNK_SOFT : CHUNK_HARD; }
 
-enum { HARD_ACC = 0, SOFT_ACC = 1, HARD_FINAL = 2, SOFT_FINAL = 3 };
+enum { HARD_ACC = 0, SOFT_ACC = 1, HARD_FINAL = 2, SOFT_FINAL = 3, HARD_LABELS = 4 };     // HARD_LABELS: HARD_FINAL without the inertia
 
 // x [nrows, E] -> xn: x * (1/sqrt(max(sum_e x^2, 1e-12))), sequential over e (tf.nn.l2_normalize, Kmeans_2.py:40-41).
 // Rows are staged through LDS in slabs of 256 so global traffic is coalesced while each thread still sums ITS row left to right
@@ -99,12 +99,13 @@ template <int E_, int C_, int MODE, bool HAS_W>
 #ifndef AMS_KM_WAVES
 #define AMS_KM_WAVES 3
 #endif
-__global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? AMS_KM_WAVES : 1) void kmeans_pass_kernel(KmArgs a) {
+__global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL || MODE == HARD_LABELS) ? AMS_KM_WAVES : 1) void kmeans_pass_kernel(KmArgs a) {
     static_assert(E_ % 4 == 0, "rows are staged as 16-byte vectors");
     constexpr bool ACC = (MODE == HARD_ACC || MODE == SOFT_ACC);
     constexpr bool SOFT = (MODE == SOFT_ACC || MODE == SOFT_FINAL);
     constexpr int NV = ACC ? C_ * (E_ + 1) : 2 * C_;
-    constexpr int CHUNK = chunk_of(SOFT), PPL = CHUNK / LANES;
+    // labels alone have no summation order to keep: the small chunks, which fill the device when R = b (the re-assignment at the end)
+    constexpr int CHUNK = chunk_of(SOFT || MODE == HARD_LABELS), PPL = CHUNK / LANES;
     constexpr int LD = E_ + 4;                     // 16-byte aligned rows; 16 lanes x 16 B at this pitch cover all 64 banks
     constexpr int V4 = E_ / 4, V2 = E_ / 2;
     constexpr int BUF = (256 * LD > 128 * 64) ? 256 * LD : 128 * 64;
@@ -326,6 +327,8 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? AMS
                         }
                     };
                     if (HAS_W) accum(std::true_type{}); else accum(std::false_type{});
+                } else if (MODE == HARD_LABELS) {
+                    a.labels[(long)r * a.L + p0 + tid] = lab;
                 } else {
                     // inertia terms: unweighted distance to the assigned centroid (Kmeans_2.py:131-136)
                     float dist = 0.f;
@@ -378,6 +381,7 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL) ? AMS
         }
     }
     constexpr int NPW = SOFT ? 1 : 4;                              // partial rows per workgroup
+    if (MODE == HARD_LABELS) return;
     if (!SOFT) {
         // HARD modes: every wavefront is a partial of its own -- lanes combined by the halving tree l += l + s (s = 32 .. 1) on the VALU
         // (gfx950's v_permlane32_swap / v_permlane16_swap bring the upper half / the odd 16-lane rows down, row_shl DPP does the rest);
@@ -551,6 +555,7 @@ constexpr size_t KT_LDS_BYTES = 3 * 128 * 40 * sizeof(float);      // kmeans_har
 struct KtArgs {
     const float* xn; const float* cent; float* part; unsigned* tickets; float* fin_out; float* fin_den;
     long L; int b, tries, G;
+    int32_t* labels;                   // kmeans_hard_tries_final_kernel: [R, L] or null
     unsigned long long* dbg;           // AMS_KT_DBG builds: per (workgroup, wave) {HW_ID | XCC_ID << 32, start, end} (s_memrealtime)
 };
 
@@ -647,7 +652,6 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
     // staging: thread -> (point pr of a slab, 16-byte group c4) of BOTH slabs of an iteration
     const int pr = tid / V4, c4 = tid - pr * V4;
     // the utterance as a buffer resource: 32-bit offsets, and rows past L come back as zeros without a test (raw buffer bounds check)
-    typedef int kt_i32x4 __attribute__((ext_vector_type(4)));
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), (short)0, (int)(a.L * E_ * 4), 0x00020000);
     float4 pf[2];
     unsigned foff = (unsigned)((base + pr) * E_ + c4 * 4) * 4u;   // byte offset of this thread's group in slab 0 of the column
@@ -811,6 +815,147 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
     if (a_fin_den && (fk % E_) == 0) a_fin_den[(long)r * C_ + c] = den;
 }
 
+// HARD_FINAL in the same shape (E = 40, C = 2, no silence weights, tries a multiple of 5): labels and inertia terms of TQ tries from one
+// read of the points.  No sums role: wave (try tt, kk) owns COLUMN 2 cp + kk of the chunk for all its slabs, so its lanes' running sums
+// tot_c += dist * [label == c] follow the summation order on their own; one slab of both columns (128 consecutive points) per iteration,
+// x double-buffered, one barrier.  dist = sum_e (x_e - c_e)^2 of the assigned centroid with separate multiply and add (oracle
+// inertia_hard), both clusters packed beside the fused label chain, which shares the differences.  Counts by popcount (integers).
+__global__ __launch_bounds__(640, 6) void kmeans_hard_tries_final_kernel(KtArgs a) {
+    constexpr int E_ = 40, C_ = 2, LD = E_, V4 = E_ / 4, SL = CHUNK_HARD / LANES, NVF = 2 * C_;
+    extern __shared__ __attribute__((aligned(16))) float kt_dyn[];
+    float (*xbuf)[128 * LD] = reinterpret_cast<float (*)[128 * LD]>(kt_dyn);
+    __shared__ int last_sh[TQ];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    int id = blockIdx.x;
+    const int ntg = a.tries / TQ;
+    const int ub = id % a.b; id /= a.b;
+    const int tg = id % ntg; id /= ntg;
+    const int cp = id & 1, g = id >> 1;
+    const float* xb = a.xn + (long)ub * a.L * E_;
+    const long base = (long)g * CHUNK_HARD + cp * 128;             // slab i of the column pair: points base + 256 i .. + 127
+    const long left = a.L - base;
+    const int nit = left <= 0 ? 0 : (int)min((long)SL, (left + LANES - 1) / LANES);
+    const int left32 = (int)min(max(left, (long)0), (long)(SL * LANES));
+    const int row0 = ub * a.tries + tg * TQ;
+    const int tt = wave % TQ, kk = wave / TQ;
+    auto valid_of = [&](int slab) {
+        const int nv = left32 - slab * LANES - kk * 64;
+        return nv >= 64 ? ~0ull : (nv <= 0 ? 0ull : ((1ull << nv) - 1ull));
+    };
+    float cs[C_ * E_];
+    {
+        const float* cg = a.cent + (long)(row0 + tt) * C_ * E_;
+#pragma unroll
+        for (int i = 0; i < C_ * E_; ++i) cs[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cg[i])));
+    }
+    int n0 = 0, n1 = 0;
+    float tot0 = 0.f, tot1 = 0.f;
+    const int pr = tid / V4, c4 = tid - pr * V4;
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), (short)0, (int)(a.L * E_ * 4), 0x00020000);
+    float4 pf[2];
+    const unsigned foff = (unsigned)((base + pr) * E_ + c4 * 4) * 4u;
+    auto fetch = [&](int it) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            pf[k] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(xrs, foff + (unsigned)((it * LANES + k * 64) * E_ * 4), 0, 0));
+    };
+    const int c4s = (c4 + ((pr >> 3) & 1)) % V4;                   // rotated groups: see kmeans_hard_tries_kernel
+    auto stage = [&](int bf) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) *reinterpret_cast<float4*>(&xbuf[bf][(k * 64 + pr) * LD + c4s * 4]) = pf[k];
+    };
+    const int rot = (lane >> 3) & 1;
+    const int off_lab = (kk * 64 + lane) * LD + rot * 4;
+    const int off_lab9 = (kk * 64 + lane) * LD + (rot ? 0 : 36);
+    if (nit > 0) {
+        fetch(0);
+        stage(0);
+        if (nit > 1) fetch(1);
+    }
+    __syncthreads();
+    int32_t* const lrow = a.labels ? a.labels + (long)(row0 + tt) * a.L + base + kk * 64 + lane : nullptr;
+    for (int it = 0; it < nit; ++it) {
+        const int cur = it & 1;
+        const float* xrow = &xbuf[cur][off_lab];
+        f2 dp = {0.f, 0.f}, dq = {0.f, 0.f};
+        float4 vd[2];
+        vd[0] = *reinterpret_cast<const float4*>(xrow);
+#pragma unroll
+        for (int q4 = 0; q4 < V4; ++q4) {
+            asm volatile("" ::: "memory");
+            asm volatile("" : "+v"(dp), "+v"(dq));
+            if (q4 + 1 < V4) vd[(q4 + 1) & 1] = *reinterpret_cast<const float4*>(q4 + 1 < V4 - 1 ? xrow + (q4 + 1) * 4 : &xbuf[cur][off_lab9]);
+            const float4 v = vd[q4 & 1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float xe = k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
+                const f2 xx = {xe, xe};
+                const f2 cc = {cs[4 * q4 + k], cs[E_ + 4 * q4 + k]};
+                const f2 df = xx - cc;
+                dp = __builtin_elementwise_fma(df, df, dp);         // label distance: fused chain (sqdist_fused)
+                dq = dq + df * df;                                  // inertia distance: multiply, then add (contraction is off in this file)
+            }
+        }
+        const bool one = sqrtf(dp.y) < sqrtf(dp.x);
+        const unsigned long long bal = __builtin_amdgcn_ballot_w64(one);
+        const unsigned long long valid = valid_of(it);
+        n1 += __builtin_popcountll(bal & valid);
+        n0 += __builtin_popcountll(~bal & valid);
+        const float dist = one ? dq.y : dq.x;
+        const float vf = mask_to_float(valid);
+        // tot_c += dist * [label == c] for the lanes that are points (kmeans_pass_kernel skips the others: adding +0 is the same)
+        const float m1 = one ? 1.0f : 0.0f, m0 = 1.0f - m1;
+        const float t0v = __fmul_rn(dist, m0), t1v = __fmul_rn(dist, m1);
+        tot0 = __fadd_rn(tot0, vf != 0.f ? t0v : 0.f);
+        tot1 = __fadd_rn(tot1, vf != 0.f ? t1v : 0.f);
+        if (lrow && vf != 0.f) lrow[(long)it * LANES] = one ? 1 : 0;
+        if (it + 1 < nit) {
+            stage(cur ^ 1);
+            if (it + 2 < nit) fetch(it + 2);
+        }
+        __syncthreads();
+    }
+    const __attribute__((address_space(4))) KtArgs* ka = (const __attribute__((address_space(4))) KtArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    float* const a_part = ka->part; unsigned* const a_tickets = ka->tickets; float* const a_fin_out = ka->fin_out;
+    const int NP = 4 * ka->G, pi = g * 4 + cp * 2 + kk;
+    {
+        float* const dst = a_part + ((long)(row0 + tt) * NP + pi) * NVF;
+        const float v = tree4(tot0, tot1, 0.f, 0.f);               // lanes 0 / 32: tot of cluster 0 / 1
+        if ((lane & 31) == 0) __hip_atomic_store(dst + (lane >> 5), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < C_) __hip_atomic_store(dst + C_ + lane, (float)(lane == 0 ? n0 : n1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (a_tickets == nullptr) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid < TQ) {
+        const int r = row0 + tid;
+        const int last = atomicAdd(a_tickets + r, 1u) == (unsigned)(NP / 2) - 1u;      // one arrival per (column pair, chunk)
+        if (last) __hip_atomic_store(a_tickets + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_sh[tid] = last;
+    }
+    __syncthreads();
+    // inertia[r] = sum_c tot_c / cnt_c, partial rows in order (kmeans_pass_kernel's finish): one lane pair per finished row
+    const int ft = tid >> 1, c = tid & 1;
+    if (ft >= TQ || !last_sh[ft]) return;
+    const int r = row0 + ft;
+    const float* prr = a_part + (long)r * NP * NVF;
+    auto chunk_sum = [&](int k) {
+        float s = 0.f;
+        for (int gg = 0; gg < NP; gg += 8) {
+            float v[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = __hip_atomic_load(prr + (long)min(gg + j, NP - 1) * NVF + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) if (gg + j < NP) s = __fadd_rn(s, v[j]);
+        }
+        return s;
+    };
+    const float q = chunk_sum(c) / chunk_sum(C_ + c);
+    const float q1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(q), 0x101, 0xf, 0xf, true));     // row_shl:1: lane pair's cluster 1
+    if (c == 0) a_fin_out[r] = __fadd_rn(__fadd_rn(0.f, q), q1);
+}
+
 // centroids[r,c,:] = xn[r/tries, idx[r,c], :]                 (Kmeans_2.py:61-71)
 __global__ void kmeans_init_kernel(const float* __restrict__ xn, const int32_t* __restrict__ idx, float* __restrict__ cent, int R,
                                    int C, int E, long L, int tries) {
@@ -942,9 +1087,22 @@ ams_status ams_kmeans_assign(const float* xn, const float* w, const float* cent,
     hipStream_t st = (hipStream_t)stream;
     KmArgs a{};
     a.xn = xn; a.w = w; a.cent = cent; a.part = (float*)ws; a.labels = labels; a.soft = soft; a.L = L; a.b = b; a.tries = tries;
-    a.G = ceil_div(L, chunk_of(beta >= 0.f)); a.w_mod_b = w_mod_b; a.beta = beta; a.one = 1.0f;
+    const bool labels_only = beta < 0.f && !inertia && labels;
+    a.G = ceil_div(L, chunk_of(beta >= 0.f || labels_only)); a.w_mod_b = w_mod_b; a.beta = beta; a.one = 1.0f;
     a.tickets = inertia ? (unsigned*)tickets : nullptr; a.fin_out = inertia; a.fin_den = nullptr;
-    ams_status s = beta < 0.f ? launch_pass<HARD_FINAL>(a, R, E, C, st) : launch_pass<SOFT_FINAL>(a, R, E, C, st);
+    static const bool tries_kernel = [] { const char* e = getenv("AMS_KM_TRIES"); return !(e && e[0] == '0'); }();
+    if (tries_kernel && beta < 0.f && inertia && !w && E == 40 && C == 2 && tries % TQ == 0) {
+        KtArgs k{};
+        k.xn = xn; k.cent = cent; k.part = (float*)ws; k.tickets = (unsigned*)tickets; k.fin_out = inertia; k.labels = labels;
+        k.L = L; k.b = b; k.tries = tries; k.G = a.G;
+        hipLaunchKernelGGL(kmeans_hard_tries_final_kernel, dim3((unsigned)(b * (tries / TQ) * 2 * a.G)), dim3(640), 2 * 128 * 40 * sizeof(float), st, k);
+        ams_status s2 = ams_check_launch();
+        if (s2 != AMS_OK || tickets) return s2;
+        hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, st, (const float*)ws, inertia, (float*)nullptr, R, 4 * a.G, C, E, 1);
+        return ams_check_launch();
+    }
+    ams_status s = labels_only ? launch_pass<HARD_LABELS>(a, R, E, C, st)
+                 : beta < 0.f ? launch_pass<HARD_FINAL>(a, R, E, C, st) : launch_pass<SOFT_FINAL>(a, R, E, C, st);
     if (s != AMS_OK) return s;
     if (inertia && !tickets) {
         hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, st, (const float*)ws, inertia, (float*)nullptr, R, beta < 0.f ? 4 * a.G : a.G, C, E, 1);
