@@ -230,6 +230,14 @@ __device__ __forceinline__ void ring_split2h(float a, float b, unsigned& hi, uns
     const rf32x2_t r = {a - (float)h[0], b - (float)h[1]};
     mid = __builtin_bit_cast(unsigned, __builtin_convertvector(r, rf16x2_t));
 }
+// One value as the two fp16 terms of ring_split2h in ONE dword, hi | mid << 16: what the PRODUCER of h_t publishes in the fp16x3 forward
+// ring (round 5).  A consumer then builds its MFMA operand planes with two v_perm_b32 per pair of k-slots; splitting on arrival was two
+// conversions back, two subtractions and two packed conversions per pair in each of the 25 consumers' four waves, on the hand-off cycle.
+__device__ __forceinline__ unsigned ring_pack_hm(float v) {
+    const _Float16 hi = (_Float16)v;
+    const _Float16 mid = (_Float16)(v - (float)hi);
+    return (unsigned)__builtin_bit_cast(unsigned short, hi) | ((unsigned)__builtin_bit_cast(unsigned short, mid) << 16);
+}
 // 2^(13 - floor(log2(amax))); 1 for 0, denormals, Inf, NaN (csrc/gemm.hip::f16_scale)
 __device__ __forceinline__ float ring_f16_scale(float amax) {
     const int e = (int)((__float_as_uint(amax) >> 23) & 0xffu);
@@ -417,10 +425,12 @@ __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
                         unsigned hi[4], mid[4];
 #pragma unroll
                         for (int pr = 0; pr < 4; ++pr) {
+                            // the granules carry hi | mid << 16 per value (ring_pack_hm at the producer): plane dwords by byte permutes
                             const int e0 = 8 * m + 2 * pr, e1 = e0 + 1;
-                            const float v0 = e0 < 3 * NR ? (e0 % 3 == 0 ? hv[e0 / 3].x : e0 % 3 == 1 ? hv[e0 / 3].y : hv[e0 / 3].z) : 0.f;
-                            const float v1 = e1 < 3 * NR ? (e1 % 3 == 0 ? hv[e1 / 3].x : e1 % 3 == 1 ? hv[e1 / 3].y : hv[e1 / 3].z) : 0.f;
-                            ring_split2h(v0 * 8192.0f, v1 * 8192.0f, hi[pr], mid[pr]);
+                            const unsigned p0 = e0 < 3 * NR ? __float_as_uint(e0 % 3 == 0 ? hv[e0 / 3].x : e0 % 3 == 1 ? hv[e0 / 3].y : hv[e0 / 3].z) : 0u;
+                            const unsigned p1 = e1 < 3 * NR ? __float_as_uint(e1 % 3 == 0 ? hv[e1 / 3].x : e1 % 3 == 1 ? hv[e1 / 3].y : hv[e1 / 3].z) : 0u;
+                            hi[pr] = __builtin_amdgcn_perm(p1, p0, 0x05040100u);
+                            mid[pr] = __builtin_amdgcn_perm(p1, p0, 0x07060302u);
                         }
                         const uint4 h4 = {hi[0], hi[1], hi[2], hi[3]}, m4 = {mid[0], mid[1], mid[2], mid[3]};
                         aq[m][0] = __builtin_bit_cast(rf16x8_t, h4);
@@ -510,10 +520,13 @@ __global__ __launch_bounds__(256) void lstm_ring_fwd_kernel(RingArgs a) {
         // hand h_s to the ring first: lanes ul = 0, 3, 6, 9 assemble {h[ul], h[ul+1], h[ul+2], tag}
         // h of the next two lanes of this 16-lane row: DPP row shifts on the VALU (the ds_bpermute form of __shfl_down goes through the LDS
         // crossbar: two more round trips on the hand-off's critical path)
-        const float h1 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(h), 0x101, 0xf, 0xf, true));     // row_shl:1
-        const float h2 = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(h), 0x102, 0xf, 0xf, true));     // row_shl:2
+        // fp16x3: the published value is h * 2^13 already split (ring_pack_hm) -- one split per value instead of one per consumer wave
+        const int hb = F16 ? (int)ring_pack_hm(h * 8192.0f) : __float_as_int(h);
+        const float h0 = __int_as_float(hb);
+        const float h1 = __int_as_float(__builtin_amdgcn_update_dpp(0, hb, 0x101, 0xf, 0xf, true));     // row_shl:1
+        const float h2 = __int_as_float(__builtin_amdgcn_update_dpp(0, hb, 0x102, 0xf, 0xf, true));     // row_shl:2
         if (ul < UW && ul % 3 == 0)
-            st16(rs, xb, (unsigned)(((par * TB + row) * NG) + w * 4 + ul / 3) * 16u, make_float4(h, h1, h2, __uint_as_float((unsigned)(s + 1))), fast);
+            st16(rs, xb, (unsigned)(((par * TB + row) * NG) + w * 4 + ul / 3) * 16u, make_float4(h0, h1, h2, __uint_as_float((unsigned)(s + 1))), fast);
         tr.stamp(3);                                            // gate epilogue up to the granule store
         // what the backward pass needs: kept in registers and stored one step later, right behind the NEXT wait (AMS_RING_FWD_STORE_LATE):
         // vmcnt counts loads and stores together, so seven scattered stores issued here sit in front of the poll that follows (round 4:
