@@ -1,13 +1,15 @@
+# Everything the round-end record needs, in one call:  T=r05_k bash tools/final_run.sh   -> gpurun_out/${T}_*
+T=${T:-r05_k}
 mkdir -p gpurun_out
-python bench.py --quiet > gpurun_out/r05_g_bench.json 2> gpurun_out/r05_g_bench.err
-tail -c 400 gpurun_out/r05_g_bench.json
-TAG=_r05g bash tools/prof_step.sh
+python bench.py --quiet > gpurun_out/${T}_bench.json 2> gpurun_out/${T}_bench.err
+tail -c 400 gpurun_out/${T}_bench.json
+TAG=_${T} bash tools/prof_step.sh
 bash tools/pmc_traffic.sh
 bash tools/pmc_mfma.sh
 bash tools/prof_cfg.sh STFT_L41_enhance_graph pmc
 bash tools/prof_cfg.sh front_L41_S3_N512_B128_graph pmc
 bash tools/prof_cfg.sh front_DPCL_finetuning_graph
 bash tools/prof_cfg.sh front_DPCL_inference
-python tools/bench_configs.py > gpurun_out/r05_g_other_configs.jsonl 2>/dev/null
-python -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/r05_g_gpu_suite.txt
-cat gpurun_out/r05_g_gpu_suite.txt
+python tools/bench_configs.py > gpurun_out/${T}_other_configs.jsonl 2>/dev/null
+python -m pytest tests -m gpu -q 2>&1 | tail -4 > gpurun_out/${T}_gpu_suite.txt
+cat gpurun_out/${T}_gpu_suite.txt
