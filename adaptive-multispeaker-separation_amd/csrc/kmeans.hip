@@ -551,6 +551,7 @@ __global__ void kmeans_reduce_kernel(const float* __restrict__ part, float* __re
 // One barrier per iteration: labels of iteration i and sums of iteration i-1 run between the same two barriers (x and the ballots are
 // double-buffered).  <= 96 VGPRs: two workgroups (20 waves) per CU.
 constexpr int TQ = 5;
+typedef __attribute__((address_space(4))) float kt_cfloat;                // constant address space: uniform reads become s_load
 constexpr size_t KT_LDS_BYTES = 3 * 128 * 40 * sizeof(float);      // kmeans_hard_tries_kernel's x buffers (dynamic LDS)
 struct KtArgs {
     const float* xn; const float* cent; float* part; unsigned* tickets; float* fin_out; float* fin_den;
@@ -558,6 +559,15 @@ struct KtArgs {
     int32_t* labels;                   // kmeans_hard_tries_final_kernel: [R, L] or null
     unsigned long long* dbg;           // AMS_KT_DBG builds: per (workgroup, wave) {HW_ID | XCC_ID << 32, start, end} (s_memrealtime)
 };
+
+// one component of the packed distance chains: df = {x - c0, x - c1} with x broadcast from the low (KT_LO) or high (KT_HI) half of a
+// register pair and {c0, c1} a scalar pair; d <- fma(df, df, d); KT_DIST2 also q <- q + df * df (two roundings: the inertia distance)
+#define KT_LO "op_sel_hi:[0,1]"
+#define KT_HI "op_sel:[1,0] op_sel_hi:[1,1]"
+#define KT_DIST(D, X, SEL, C) do { f2 df_; asm("v_pk_add_f32 %1, %2, %3 " SEL " neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_fma_f32 %0, %1, %1, %0" \
+                                              : "+v"(D), "=&v"(df_) : "v"(X), "s"(C)); } while (0)
+#define KT_DIST2(D, Q, X, SEL, C) do { f2 df_; asm("v_pk_add_f32 %2, %3, %4 " SEL " neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_fma_f32 %0, %2, %2, %0\n\t" \
+                                                  "v_pk_mul_f32 %2, %2, %2\n\tv_pk_add_f32 %1, %1, %2" : "+v"(D), "+v"(Q), "=&v"(df_) : "v"(X), "s"(C)); } while (0)
 
 __device__ __forceinline__ float mask_to_float(unsigned long long m) {       // 1.0f in the lanes whose bit of the (wave-uniform) mask is set
     float f;
@@ -631,11 +641,13 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
 
     // label role
     const int tt = wave % TQ, kk = wave / TQ;
-    float cs[C_ * E_];
+    // the try's centroids as 40 scalar PAIRS {c0_e, c1_e}, fetched with scalar loads (uniform address, written by the previous launch):
+    // as 80 vector loads + v_readfirstlane they were 160 vector instructions per wave in every workgroup's prologue
+    unsigned long long cpair[E_];
     {
-        const float* cg = a.cent + (long)(row0 + tt) * C_ * E_;
+        const kt_cfloat* cg = (const kt_cfloat*)(a.cent + (long)(row0 + tt) * C_ * E_);
 #pragma unroll
-        for (int i = 0; i < C_ * E_; ++i) cs[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cg[i])));
+        for (int e = 0; e < E_; ++e) cpair[e] = ((unsigned long long)__float_as_uint(cg[E_ + e]) << 32) | __float_as_uint(cg[e]);
     }
     // the counts are integers (<= 2048 per column and chunk): every order of adding them in float gives the same float, so the label
     // wave counts the bits of its ballots on the scalar unit instead of the sums role adding 0/1 factors lane by lane
@@ -719,14 +731,11 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
                 asm volatile("" : "+v"(dp));
                 if (q4 + 1 < V4) vd[(q4 + 1) & 1] = *reinterpret_cast<const float4*>(q4 + 1 < V4 - 1 ? xrow + (q4 + 1) * 4 : &xbuf[bcur][off_lab9]);
                 const float4 v = vd[q4 & 1];
-#pragma unroll
-                for (int k = 0; k < 4; ++k) {
-                    const float xe = k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
-                    const f2 xx = {xe, xe};
-                    const f2 cc = {cs[4 * q4 + k], cs[E_ + 4 * q4 + k]};
-                    const f2 df = xx - cc;
-                    dp = __builtin_elementwise_fma(df, df, dp);
-                }
+                // d <- fma(x_e - c, x_e - c, d) for both clusters: the point's value broadcast by op_sel from its place in the float4 (left to
+                // the compiler, every second broadcast was a v_mov), the centroid pair a scalar operand
+                const f2 xlo = {v.x, v.y}, xhi = {v.z, v.w};
+                KT_DIST(dp, xlo, KT_LO, cpair[4 * q4 + 0]); KT_DIST(dp, xlo, KT_HI, cpair[4 * q4 + 1]);
+                KT_DIST(dp, xhi, KT_LO, cpair[4 * q4 + 2]); KT_DIST(dp, xhi, KT_HI, cpair[4 * q4 + 3]);
             }
             const bool one = sqrtf(dp.y) < sqrtf(dp.x);            // ties pick cluster 0 (tf.argmin)
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(one);
@@ -842,11 +851,13 @@ __global__ __launch_bounds__(640, 6) void kmeans_hard_tries_final_kernel(KtArgs 
         const int nv = left32 - slab * LANES - kk * 64;
         return nv >= 64 ? ~0ull : (nv <= 0 ? 0ull : ((1ull << nv) - 1ull));
     };
-    float cs[C_ * E_];
+    // the try's centroids as 40 scalar PAIRS {c0_e, c1_e}, fetched with scalar loads (uniform address, written by the previous launch):
+    // as 80 vector loads + v_readfirstlane they were 160 vector instructions per wave in every workgroup's prologue
+    unsigned long long cpair[E_];
     {
-        const float* cg = a.cent + (long)(row0 + tt) * C_ * E_;
+        const kt_cfloat* cg = (const kt_cfloat*)(a.cent + (long)(row0 + tt) * C_ * E_);
 #pragma unroll
-        for (int i = 0; i < C_ * E_; ++i) cs[i] = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, cg[i])));
+        for (int e = 0; e < E_; ++e) cpair[e] = ((unsigned long long)__float_as_uint(cg[E_ + e]) << 32) | __float_as_uint(cg[e]);
     }
     int n0 = 0, n1 = 0;
     float tot0 = 0.f, tot1 = 0.f;
@@ -886,15 +897,10 @@ __global__ __launch_bounds__(640, 6) void kmeans_hard_tries_final_kernel(KtArgs 
             asm volatile("" : "+v"(dp), "+v"(dq));
             if (q4 + 1 < V4) vd[(q4 + 1) & 1] = *reinterpret_cast<const float4*>(q4 + 1 < V4 - 1 ? xrow + (q4 + 1) * 4 : &xbuf[cur][off_lab9]);
             const float4 v = vd[q4 & 1];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float xe = k == 0 ? v.x : k == 1 ? v.y : k == 2 ? v.z : v.w;
-                const f2 xx = {xe, xe};
-                const f2 cc = {cs[4 * q4 + k], cs[E_ + 4 * q4 + k]};
-                const f2 df = xx - cc;
-                dp = __builtin_elementwise_fma(df, df, dp);         // label distance: fused chain (sqdist_fused)
-                dq = dq + df * df;                                  // inertia distance: multiply, then add (contraction is off in this file)
-            }
+            // label distance: fused chain (sqdist_fused); inertia distance: multiply, then add -- both from the same differences
+            const f2 xlo = {v.x, v.y}, xhi = {v.z, v.w};
+            KT_DIST2(dp, dq, xlo, KT_LO, cpair[4 * q4 + 0]); KT_DIST2(dp, dq, xlo, KT_HI, cpair[4 * q4 + 1]);
+            KT_DIST2(dp, dq, xhi, KT_LO, cpair[4 * q4 + 2]); KT_DIST2(dp, dq, xhi, KT_HI, cpair[4 * q4 + 3]);
         }
         const bool one = sqrtf(dp.y) < sqrtf(dp.x);
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(one);

@@ -401,7 +401,12 @@ ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent
                               long L, int E, int C, float beta, int w_mod_b, void* ws, size_t ws_bytes, void* tickets, void* stream);
 /* tickets (ams_kmeans_iterate / ams_kmeans_assign; optional): b * tries uint32, zero before the first use and left zero -- the chunk
  * partials of a row are then added up INSIDE the pass by the workgroup that stores the row's last one (same chunk order: same bits),
- * instead of by a reduce launch behind each of the nb_steps + 1 passes. */
+ * instead of by a reduce launch behind each of the nb_steps + 1 passes.
+ * Hard passes with E = 40, C = 2, w = NULL and tries a multiple of 5 serve FIVE tries of an utterance from one read of its points
+ * (csrc/kmeans.hip, kmeans_hard_tries_kernel / _final_kernel; AMS_KM_TRIES=0 in the environment: one workgroup per try as elsewhere);
+ * every path produces the same bits: the summation order is part of the contract (oracle/kmeans.py: 8192-point chunks, lane j of 256
+ * adds its 32 points in sequence, one halving tree per wavefront, wavefront totals in (chunk, wavefront) order).  ams_kmeans_assign with
+ * inertia = NULL writes labels only. */
 /* Backward of the unrolled soft k-means for b already-selected rows (models/Kmeans_2.py:145-188 under tf.gradients;
  * csrc/kmeans_soft.hip): one call enqueues the final-assignment pass, the n_it iteration passes in reverse (each one streaming read of
  * xn, partial sums finished by the last-arriving workgroup: no reduce launches) and ONE pass that writes dx.
