@@ -1063,7 +1063,7 @@ ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent
     a.tickets = (unsigned*)tickets; a.fin_out = cent_out; a.fin_den = den_out;
     // AMS_KM_TRIES=0: every try a workgroup of its own (kmeans_pass_kernel) also where kmeans_hard_tries_kernel applies -- same bits
     static const bool tries_kernel = [] { const char* e = getenv("AMS_KM_TRIES"); return !(e && e[0] == '0'); }();
-    if (tries_kernel && beta < 0.f && !w && E == 40 && C == 2 && tries % TQ == 0) {
+    if (tries_kernel && beta < 0.f && !w && E == 40 && C == 2 && tries % TQ == 0 && L * E * 4 < (1L << 31))   /* 32-bit buffer offsets */ {
         KtArgs k{};
         k.xn = xn; k.cent = cent_in; k.part = (float*)ws; k.tickets = (unsigned*)tickets; k.fin_out = cent_out; k.fin_den = den_out;
         k.L = L; k.b = b; k.tries = tries; k.G = a.G;
@@ -1097,7 +1097,7 @@ ams_status ams_kmeans_assign(const float* xn, const float* w, const float* cent,
     a.G = ceil_div(L, chunk_of(beta >= 0.f || labels_only)); a.w_mod_b = w_mod_b; a.beta = beta; a.one = 1.0f;
     a.tickets = inertia ? (unsigned*)tickets : nullptr; a.fin_out = inertia; a.fin_den = nullptr;
     static const bool tries_kernel = [] { const char* e = getenv("AMS_KM_TRIES"); return !(e && e[0] == '0'); }();
-    if (tries_kernel && beta < 0.f && inertia && !w && E == 40 && C == 2 && tries % TQ == 0) {
+    if (tries_kernel && beta < 0.f && inertia && !w && E == 40 && C == 2 && tries % TQ == 0 && L * E * 4 < (1L << 31))   /* 32-bit buffer offsets */ {
         KtArgs k{};
         k.xn = xn; k.cent = cent; k.part = (float*)ws; k.tickets = (unsigned*)tickets; k.fin_out = inertia; k.labels = labels;
         k.L = L; k.b = b; k.tries = tries; k.G = a.G;
