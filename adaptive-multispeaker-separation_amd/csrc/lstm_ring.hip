@@ -796,6 +796,9 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
             gr[2 * H] = da2;
             gr[3 * H] = da3;
         }
+#ifdef AMS_RING_DBG_FINE                         // anatomy build: the last phase of a step in four pieces (tools/ring_anatomy.py, AMS_ANATOMY_FINE=1)
+        tr.stamp(5);                                            // dZ stores issued
+#endif
         if (s + 1 < T) {
             f32x4 acc[NI];
 #pragma unroll
@@ -836,6 +839,10 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
                 // ONE accumulator per tile (the workgroup must fit beside two residency-capped product workgroups of 160 registers:
                 // <= 192 in all; with the cross terms in accumulators of their own it needed 230, and a ring launched behind such a
                 // product then waited for its workgroups to retire -- 470 us instead of 300).  Smallest terms first.
+#ifdef AMS_RING_DBG_FINE
+                asm volatile("" : "+v"(bq[0]), "+v"(bq[1]), "+v"(br[0]), "+v"(br[1]));
+                tr.stamp(6);                                    // B operand read, scaled, split
+#endif
                 constexpr int PA[3] = {1, 0, 0};                // U plane: mid.hi, hi.mid, hi.hi
                 constexpr int PB[3] = {0, 1, 0};                // da plane
                 // the K = 16 chain first, then the K = 32 chain, apart: an accumulator handed DIRECTLY from one MFMA shape to the other
@@ -853,6 +860,11 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
                     for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[i][PA[pp]], bq[PB[pp]], acc[i], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < NI; ++i) acc[i] = acc[i] * sc_inv;
+#ifdef AMS_RING_DBG_FINE
+#pragma unroll
+                for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(acc[i]));
+                tr.stamp(7);                                    // MFMA chains + rescale
+#endif
             } else {
                 // partial dh_{next} = da_own [16 x 48] . U^T slice [48 x NT*16]; the 12 A fragments of this lane first, ONE wait
                 float av[UW];

@@ -28,7 +28,8 @@ AU = _AU.data_ptr() if os.environ.get('AMS_ANATOMY_F16', '1') != '0' else None
 p = lambda t: t.data_ptr()                                                                  # noqa: E731
 st = torch.cuda.current_stream().cuda_stream
 names = {'fwd': ['wait for h', 'MFMA + acc to LDS', 'barrier', 'gate epilogue + granule store', 'G/cst/out stores'],
-         'bwd': ['wait for the tagged partial tiles', 'sum (LDS, barrier)', 'gate math + LDS write', 'barrier', 'dZ stores + MFMA + tile stores']}   # (-DAMS_RING_DBG_ACK builds add slot 5: own stores acknowledged)
+         'bwd': ['wait for the tagged partial tiles', 'sum (LDS, barrier)', 'gate math + LDS write', 'barrier', 'dZ stores + MFMA + tile stores'] +
+                (['(fine) dZ stores issued', '(fine) B operand read / scaled / split', '(fine) MFMA chains + rescale'] if os.environ.get('AMS_ANATOMY_FINE') else [])}   # (-DAMS_RING_DBG_ACK builds add slot 5: own stores acknowledged)
 for mode, safe in (('plain stores (same L2)', 2), ('write-through', 3)):
     for kind in ('fwd', 'bwd'):
         n = lib.ams_blstm_ring_sync_bytes(B, H, int(kind == 'bwd'))
