@@ -973,6 +973,146 @@ __global__ __launch_bounds__(640, 6) void kmeans_hard_tries_final_kernel(KtArgs 
     if (c == 0) a_fin_out[r] = __fadd_rn(__fadd_rn(0.f, q), q1);
 }
 
+// ------------------------------------------------------------------------------------------------------------------------------
+// SOFT_ACC the way csrc/kmeans_soft.hip runs its backward passes (round 5; E = 40, tolerance-checked like every soft mode):
+//   * the row's centroids are SCALAR operands (s_load through the constant address space) of packed FMAs, not LDS broadcast reads
+//     (40 ds_read_b64 per point in kmeans_pass_kernel's soft branch);
+//   * d_c = w (|x|^2 - 2 <x, c> + |c|^2): one dot product per cluster (20 v_pk_fma) instead of subtract / multiply / add per element;
+//   * sums as v_pk_fma with the factor w lab_c; slab j + 1 is requested while slab j is worked on; ONE resident round of workgroups
+//     (512 / R chunks per row).
+// ~120 vector instructions per point instead of ~480: 60 -> see DESIGN 4.4 us per pass at 64 rows x 20480 points.
+struct KsfArgs {
+    const float* xn; const float* w; const float* cent; float* part; unsigned* tickets; float* cent_out; float* den_out;
+    long L; int b, tries, nG, spw, w_mod_b; float beta;
+};
+typedef const f2 __attribute__((address_space(4))) kt_cf2;
+
+template <int C_, bool HAS_W>
+__global__ __launch_bounds__(256) void kmeans_soft_acc_kernel(KsfArgs a) {
+    constexpr int E_ = 40, CE = C_ * E_, NV = CE + C_, LD = E_ + 4, V4 = E_ / 4, H = E_ / 2;
+    __shared__ __attribute__((aligned(16))) float buf[256 * LD];
+    __shared__ int last_sh;
+    const int r = blockIdx.y, g = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int bi = r / a.tries;
+    const float* xb = a.xn + (long)bi * a.L * E_;
+    const float* wb = HAS_W ? a.w + (long)(a.w_mod_b ? (r % a.b) : bi) * a.L : nullptr;
+    const kt_cfloat* cen = (const kt_cfloat*)(a.cent + (long)r * CE);
+    kt_cf2* cen2 = (kt_cf2*)cen;
+    float cc[C_];                                               // |c|^2 (uniform: scalar operands)
+#pragma unroll
+    for (int c = 0; c < C_; ++c) {
+        float v = 0.f;
+#pragma unroll
+        for (int e = 0; e < E_; ++e) v = fmaf(cen[c * E_ + e], cen[c * E_ + e], v);
+        cc[c] = v;
+    }
+    f2 acc2[C_][H];
+    float den[C_];
+#pragma unroll
+    for (int c = 0; c < C_; ++c) {
+        den[c] = 0.f;
+#pragma unroll
+        for (int q = 0; q < H; ++q) acc2[c][q] = (f2){0.f, 0.f};
+    }
+    float4 pre[V4];
+    float wpre = 1.0f;
+    auto fetch = [&](int j) {
+        const long q0 = ((long)g * a.spw + j) * LANES;
+        const long lim = (a.L - q0) * V4;
+        const float4* src = reinterpret_cast<const float4*>(xb + q0 * E_);
+#pragma unroll
+        for (int k = 0; k < V4; ++k) {
+            const long i = tid + 256 * k;
+            pre[k] = src[i < lim ? i : (lim > 0 ? lim - 1 : -q0 * V4)];       // clamped inside the utterance's rows
+        }
+        if (HAS_W) wpre = wb[min(q0 + tid, a.L - 1)];
+    };
+    fetch(0);
+    for (int j = 0; j < a.spw; ++j) {
+        const long p0 = ((long)g * a.spw + j) * LANES;
+        const int npts = (int)max((long)0, min((long)LANES, a.L - p0));
+        if (npts <= 0) break;                                   // (workgroup-uniform)
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < V4; ++k) {
+            const int i = tid + 256 * k;
+            const int row = i / V4, c4 = i - row * V4;
+            *reinterpret_cast<float4*>(&buf[row * LD + c4 * 4]) = (i < npts * V4) ? pre[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads();
+        const float wv = wpre;
+        if (j + 1 < a.spw) fetch(j + 1);
+        if (tid < npts) {
+            f2 x2[H];
+            f2 xs = {0.f, 0.f};
+#pragma unroll
+            for (int q = 0; q < V4; ++q) {
+                const float4 v = *reinterpret_cast<const float4*>(&buf[tid * LD + q * 4]);
+                x2[2 * q] = (f2){v.x, v.y}; x2[2 * q + 1] = (f2){v.z, v.w};
+                xs = __builtin_elementwise_fma(x2[2 * q], x2[2 * q], xs);
+                xs = __builtin_elementwise_fma(x2[2 * q + 1], x2[2 * q + 1], xs);
+            }
+            const float xx = xs[0] + xs[1];
+            float lab[C_], sum = 0.f;
+#pragma unroll
+            for (int c = 0; c < C_; ++c) {
+                f2 sd = {0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < H; ++q) sd = __builtin_elementwise_fma(x2[q], (f2)cen2[c * H + q], sd);
+                const float d = fmaxf(xx - 2.0f * (sd[0] + sd[1]) + cc[c], 0.f) * (HAS_W ? wv : 1.0f);
+                lab[c] = expf(-a.beta * d);
+                sum += lab[c];
+            }
+            const float inv = 1.0f / sum;
+#pragma unroll
+            for (int c = 0; c < C_; ++c) {
+                const float lb = lab[c] * inv, wl = HAS_W ? wv * lb : lb;
+                const f2 wl2 = {wl, wl};
+#pragma unroll
+                for (int q = 0; q < H; ++q) acc2[c][q] = __builtin_elementwise_fma(x2[q], wl2, acc2[c][q]);
+                den[c] += lb;
+            }
+        }
+    }
+    // workgroup sum of the NV values: a lane tree per wave (VALU), the four wave totals meet in LDS
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < C_; ++c) {
+#pragma unroll
+        for (int q = 0; q < H; ++q) {
+            const float v0 = wave_sum_lane0(acc2[c][q][0]), v1 = wave_sum_lane0(acc2[c][q][1]);
+            if (lane == 0) { buf[wave * NV + c * E_ + 2 * q] = v0; buf[wave * NV + c * E_ + 2 * q + 1] = v1; }
+        }
+        const float vd = wave_sum_lane0(den[c]);
+        if (lane == 0) buf[wave * NV + CE + c] = vd;
+    }
+    __syncthreads();
+    float* const mypart = a.part + ((long)r * a.nG + g) * NV;
+    for (int i = tid; i < NV; i += 256) {
+        const float v = (buf[i] + buf[NV + i]) + (buf[2 * NV + i] + buf[3 * NV + i]);
+        if (a.tickets) __hip_atomic_store(mypart + i, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else mypart[i] = v;
+    }
+    if (a.tickets == nullptr) return;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) {
+        const int last = atomicAdd(a.tickets + r, 1u) == (unsigned)a.nG - 1u;
+        if (last) __hip_atomic_store(a.tickets + r, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_sh = last;
+    }
+    __syncthreads();
+    if (!last_sh || tid >= CE) return;
+    const int c = tid / E_;
+    float num = 0.f, dn = 0.f;
+    for (int q = 0; q < a.nG; ++q) {
+        num += __hip_atomic_load(a.part + ((long)r * a.nG + q) * NV + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        dn += __hip_atomic_load(a.part + ((long)r * a.nG + q) * NV + CE + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    a.cent_out[(long)r * CE + tid] = num / dn;
+    if (a.den_out && (tid % E_) == 0) a.den_out[(long)r * C_ + c] = dn;
+}
+
 // centroids[r,c,:] = xn[r/tries, idx[r,c], :]                 (Kmeans_2.py:61-71)
 __global__ void kmeans_init_kernel(const float* __restrict__ xn, const int32_t* __restrict__ idx, float* __restrict__ cent, int R,
                                    int C, int E, long L, int tries) {
@@ -1086,6 +1226,27 @@ ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent
         if (s2 != AMS_OK || tickets) return s2;
         hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(ceil_div((long)R * C * E, 256)), dim3(256), 0, st, (const float*)ws, cent_out, den_out, R,
                            4 * a.G, C, E, 0);
+        return ams_check_launch();
+    }
+    // AMS_KM_SOFT=0: the soft accumulation pass of kmeans_pass_kernel also where kmeans_soft_acc_kernel applies
+    static const bool soft_kernel = [] { const char* e = getenv("AMS_KM_SOFT"); return !(e && e[0] == '0'); }();
+    if (soft_kernel && beta >= 0.f && E == 40) {
+        KsfArgs k{};
+        k.xn = xn; k.w = w; k.cent = cent_in; k.part = (float*)ws; k.tickets = (unsigned*)tickets; k.cent_out = cent_out; k.den_out = den_out;
+        k.L = L; k.b = b; k.tries = tries; k.w_mod_b = w_mod_b; k.beta = beta;
+        const int slabs = ceil_div(L, LANES);
+        int nG = 512 / R; if (nG < 1) nG = 1; if (nG > slabs) nG = slabs;
+        if (nG > a.G) nG = a.G;                                 // the workspace holds a.G partial rows per row
+        k.spw = ceil_div(slabs, nG); k.nG = ceil_div(slabs, k.spw);
+        const dim3 grid(k.nG, R);
+#define AMS_KSF(CC) do { if (w) hipLaunchKernelGGL((kmeans_soft_acc_kernel<CC, true>), grid, dim3(256), 0, st, k); \
+                         else hipLaunchKernelGGL((kmeans_soft_acc_kernel<CC, false>), grid, dim3(256), 0, st, k); } while (0)
+        if (C == 2) AMS_KSF(2); else if (C == 3) AMS_KSF(3); else AMS_KSF(4);
+#undef AMS_KSF
+        ams_status s2 = ams_check_launch();
+        if (s2 != AMS_OK || tickets) return s2;
+        hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(ceil_div((long)R * C * E, 256)), dim3(256), 0, st, (const float*)ws, cent_out, den_out, R,
+                           k.nG, C, E, 0);
         return ams_check_launch();
     }
     ams_status s = beta < 0.f ? launch_pass<HARD_ACC>(a, R, E, C, st) : launch_pass<SOFT_ACC>(a, R, E, C, st);
