@@ -980,7 +980,7 @@ __global__ __launch_bounds__(640, 6) void kmeans_hard_tries_final_kernel(KtArgs 
 //   * d_c = w (|x|^2 - 2 <x, c> + |c|^2): one dot product per cluster (20 v_pk_fma) instead of subtract / multiply / add per element;
 //   * sums as v_pk_fma with the factor w lab_c; slab j + 1 is requested while slab j is worked on; ONE resident round of workgroups
 //     (512 / R chunks per row).
-// ~120 vector instructions per point instead of ~480: 60 -> see DESIGN 4.4 us per pass at 64 rows x 20480 points.
+// ~120 vector instructions per point instead of ~480: 66 -> 42 us per pass at 64 rows x 20480 points (fine-tuning step 4.54 -> 4.33 ms).
 struct KsfArgs {
     const float* xn; const float* w; const float* cent; float* part; unsigned* tickets; float* cent_out; float* den_out;
     long L; int b, tries, nG, spw, w_mod_b; float beta;
