@@ -957,6 +957,14 @@ def kmeans(X, init_idx, C, tries, iterations, beta, w, assign_at_end, normalize_
         u = _c(pre_norm())
         if u.requires_grad:
             return KMeansSoft.apply(u, init_idx, C, tries, iterations, beta, w, assign_at_end, True, faithful_tile, True)
+    if pre_norm is not None and normalize_input and callable(X) and (beta is None or not torch.is_grad_enabled()):
+        # no gradient wanted: the Normalize layer and the k-means' own normalisation in ONE pass over u (the bits of the two passes);
+        # the once-normalised tensor is not evaluated
+        with torch.no_grad():
+            u = _c(pre_norm())
+            xn = ops.l2norm_kmeans_normalize(u, u.shape[-1])
+            sel, out, best, _ = ops.kmeans_run(xn, init_idx, C, tries, iterations, beta, w, assign_at_end, faithful_tile)
+        return sel, out, best
     if callable(X):
         X = X()
     X = _c(X)

@@ -206,10 +206,11 @@ class KMeans(object):
 
     def _run(self, run):
         pre = None
-        if (self.pre_norm is not None and self.beta is not None and self.normalize_input and run.training and torch.is_grad_enabled()
-                and id(self.X_in) not in run.cache):
+        soft_grad = self.beta is not None and run.training and torch.is_grad_enabled()
+        no_grad = self.beta is None or not torch.is_grad_enabled()
+        if (self.pre_norm is not None and self.normalize_input and (soft_grad or no_grad) and id(self.X_in) not in run.cache):
             u = self.pre_norm[0].value(run)
-            if u.requires_grad and u.is_cuda:
+            if u.is_cuda and (u.requires_grad or no_grad):
                 E = self.pre_norm[1]
                 b = u.shape[0]
                 L = u.numel() // (b * E)

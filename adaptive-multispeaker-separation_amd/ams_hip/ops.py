@@ -1079,6 +1079,18 @@ def l2norm2_fwd(u, E):
     return xn, inv, inv2
 
 
+def l2norm_kmeans_normalize(u, E):
+    """kmeans_normalize(l2norm_fwd(u)) in one pass, same bits (include/ams.h); the two calls where the fused kernel does not apply."""
+    _chk(u)
+    rows = u.numel() // E
+    xn = torch.empty_like(u)
+    st = load().ams_l2norm_kmeans_normalize(_p(u), _p(xn), rows, E, _s())
+    if st != 0:
+        v, _ = l2norm_fwd(u, E)
+        xn = kmeans_normalize(v.view(-1, E)).view_as(u)
+    return xn
+
+
 def l2norm_bwd(v, inv, dv, E):
     _chk(v, inv, dv)
     du = torch.empty_like(v)

@@ -107,7 +107,9 @@ __global__ void l2norm_bwd_kernel(const float* __restrict__ v, const float* __re
 // TWICE: v = normalise(normalise(u)) in one pass -- what a k-means that normalises its input (Kmeans_2.py:56) computes on the output of
 // the embedding network's own Normalize layer (dpcl.py:32).  The once-normalised row is rounded to f32 in between exactly as the
 // stored tensor of the two-pass form is, so v, inv and inv2 carry the bits of two ams_l2norm_fwd calls.
-template <int E_, bool TWICE = false>
+// TWICE = 2: the second normalisation is the k-means' own (ams_kmeans_normalize, csrc/kmeans.hip: squares added left to right, separate
+// multiply and add) -- the bits of ams_l2norm_fwd followed by ams_kmeans_normalize, which the bit-exact hard k-means consumes.
+template <int E_, int TWICE = 0>
 __global__ __launch_bounds__(256) void l2norm_fwd_slab_kernel(const float* __restrict__ u, float* __restrict__ v, float* __restrict__ inv,
                                                               long rows, float* __restrict__ inv2 = nullptr) {
     constexpr int V4 = E_ / 4, LD = E_ + 4;
@@ -134,7 +136,7 @@ __global__ __launch_bounds__(256) void l2norm_fwd_slab_kernel(const float* __res
         const float iv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
 #pragma unroll
         for (int k = 0; k < V4; ++k) x[k] = make_float4(x[k].x * iv, x[k].y * iv, x[k].z * iv, x[k].w * iv);
-        if (TWICE) {
+        if (TWICE == 1) {
             float s2 = 0.f;
 #pragma unroll
             for (int k = 0; k < V4; ++k) s2 += x[k].x * x[k].x + x[k].y * x[k].y + x[k].z * x[k].z + x[k].w * x[k].w;
@@ -142,6 +144,16 @@ __global__ __launch_bounds__(256) void l2norm_fwd_slab_kernel(const float* __res
 #pragma unroll
             for (int k = 0; k < V4; ++k) x[k] = make_float4(x[k].x * iv2, x[k].y * iv2, x[k].z * iv2, x[k].w * iv2);
             inv2[r0 + tid] = iv2;
+        } else if (TWICE == 2) {
+            float s2 = 0.f;
+#pragma unroll
+            for (int k = 0; k < V4; ++k) {
+                s2 = __fadd_rn(s2, __fmul_rn(x[k].x, x[k].x)); s2 = __fadd_rn(s2, __fmul_rn(x[k].y, x[k].y));
+                s2 = __fadd_rn(s2, __fmul_rn(x[k].z, x[k].z)); s2 = __fadd_rn(s2, __fmul_rn(x[k].w, x[k].w));
+            }
+            const float iv2 = 1.0f / sqrtf(fmaxf(s2, 1e-12f));
+#pragma unroll
+            for (int k = 0; k < V4; ++k) x[k] = make_float4(__fmul_rn(x[k].x, iv2), __fmul_rn(x[k].y, iv2), __fmul_rn(x[k].z, iv2), __fmul_rn(x[k].w, iv2));
         }
 #pragma unroll
         for (int k = 0; k < V4; ++k) p[k] = x[k];
@@ -618,10 +630,27 @@ ams_status ams_l2norm2_fwd(const float* u, float* xn, float* inv, float* inv2, l
     if (!vec) return AMS_E_INVALID_ARG;
     const dim3 sgrid((unsigned)ceil_div(rows, 256));
     hipStream_t st = (hipStream_t)stream;
-    if (E == 40) hipLaunchKernelGGL((l2norm_fwd_slab_kernel<40, true>), sgrid, dim3(256), 0, st, u, xn, inv, rows, inv2);
-    else if (E == 32) hipLaunchKernelGGL((l2norm_fwd_slab_kernel<32, true>), sgrid, dim3(256), 0, st, u, xn, inv, rows, inv2);
-    else if (E == 20) hipLaunchKernelGGL((l2norm_fwd_slab_kernel<20, true>), sgrid, dim3(256), 0, st, u, xn, inv, rows, inv2);
-    else if (E == 8) hipLaunchKernelGGL((l2norm_fwd_slab_kernel<8, true>), sgrid, dim3(256), 0, st, u, xn, inv, rows, inv2);
+    if (E == 40) hipLaunchKernelGGL((l2norm_fwd_slab_kernel<40, 1>), sgrid, dim3(256), 0, st, u, xn, inv, rows, inv2);
+    else if (E == 32) hipLaunchKernelGGL((l2norm_fwd_slab_kernel<32, 1>), sgrid, dim3(256), 0, st, u, xn, inv, rows, inv2);
+    else if (E == 20) hipLaunchKernelGGL((l2norm_fwd_slab_kernel<20, 1>), sgrid, dim3(256), 0, st, u, xn, inv, rows, inv2);
+    else if (E == 8) hipLaunchKernelGGL((l2norm_fwd_slab_kernel<8, 1>), sgrid, dim3(256), 0, st, u, xn, inv, rows, inv2);
+    else return AMS_E_INVALID_ARG;
+    return ams_check_launch();
+}
+
+// xn = kmeans_normalize(l2norm(u)) in ONE pass: the embedding network's Normalize layer (models/dpcl.py:32) followed by the k-means' own
+// normalisation (models/Kmeans_2.py:40-41), with the bits of ams_l2norm_fwd followed by ams_kmeans_normalize.  E = 40, 32, 20, 8 and
+// 16-byte addressable rows; AMS_E_INVALID_ARG otherwise (the caller then makes the two calls).
+ams_status ams_l2norm_kmeans_normalize(const float* u, float* xn, long rows, int E, void* stream) {
+    AMS_REQUIRE(u && xn && rows > 0 && E > 0);
+    const bool vec = (((uintptr_t)u | (uintptr_t)xn) & 15) == 0 && rows < (1L << 31) * 256;
+    if (!vec) return AMS_E_INVALID_ARG;
+    const dim3 sgrid((unsigned)ceil_div(rows, 256));
+    hipStream_t st = (hipStream_t)stream;
+    if (E == 40) hipLaunchKernelGGL((l2norm_fwd_slab_kernel<40, 2>), sgrid, dim3(256), 0, st, u, xn, (float*)nullptr, rows, (float*)nullptr);
+    else if (E == 32) hipLaunchKernelGGL((l2norm_fwd_slab_kernel<32, 2>), sgrid, dim3(256), 0, st, u, xn, (float*)nullptr, rows, (float*)nullptr);
+    else if (E == 20) hipLaunchKernelGGL((l2norm_fwd_slab_kernel<20, 2>), sgrid, dim3(256), 0, st, u, xn, (float*)nullptr, rows, (float*)nullptr);
+    else if (E == 8) hipLaunchKernelGGL((l2norm_fwd_slab_kernel<8, 2>), sgrid, dim3(256), 0, st, u, xn, (float*)nullptr, rows, (float*)nullptr);
     else return AMS_E_INVALID_ARG;
     return ams_check_launch();
 }

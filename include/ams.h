@@ -206,6 +206,10 @@ ams_status ams_l2norm_bwd(const float* v, const float* inv, const float* dv, flo
    (models/dpcl.py:32) followed by the k-means' own normalisation of its input (models/Kmeans_2.py:56); the same bits as two
    ams_l2norm_fwd calls.  16-byte addressable rows of E = 40, 32, 20 or 8 floats, else AMS_E_INVALID_ARG (make the two calls). */
 ams_status ams_l2norm2_fwd(const float* u, float* xn, float* inv, float* inv2, long rows, int E, void* stream);
+/* xn = ams_kmeans_normalize(ams_l2norm_fwd(u)) in one pass and with exactly those bits: the Normalize layer of the embedding network
+ * (models/dpcl.py:32) followed by the k-means' own normalisation (models/Kmeans_2.py:40-41) on the inference / enhance paths, where
+ * nothing else reads the once-normalised tensor.  E in {40, 32, 20, 8}, 16-byte aligned; AMS_E_INVALID_ARG otherwise. */
+ams_status ams_l2norm_kmeans_normalize(const float* u, float* xn, long rows, int E, void* stream);
 
 /* column sums (bias gradients) */
 size_t ams_colsum_workspace_bytes(long rows, int cols);

@@ -78,3 +78,23 @@ def test_same_bits_as_one_workgroup_per_try_at_benchmark_size():
         assert np.array_equal(best.cpu().numpy(), ref['best'])
         assert np.array_equal(cent.cpu().numpy(), ref['cent'])
         assert np.array_equal(lab.cpu().numpy(), ref['lab'])
+
+
+@pytest.mark.parametrize('E', [40, 32, 20, 8])
+def test_fused_normalisations_carry_the_bits_of_the_two_passes(E):
+    """ams_l2norm_kmeans_normalize (the Normalize layer, models/dpcl.py:32, and the k-means' own normalisation, Kmeans_2.py:40-41, in one
+    pass over the dense output -- what the inference / enhance paths run) against ams_l2norm_fwd followed by ams_kmeans_normalize, and
+    against the float32 oracle's normalisation of the once-normalised rows: zero rows, tiny rows, a ragged last slab."""
+    from ams_hip import ops
+    rng = np.random.RandomState(E)
+    b, L = 3, 1000 + E
+    u = (rng.randn(b, L, E) * rng.uniform(1e-3, 30.0, (b, L, 1))).astype(np.float32)
+    u[0, 5] = 0.0
+    u[1, 7] = 1e-20
+    ud = torch.from_numpy(u).cuda()
+    v, _ = ops.l2norm_fwd(ud.view(b, L * E), E)
+    ref = ops.kmeans_normalize(v.view(b, L, E))
+    xn = ops.l2norm_kmeans_normalize(ud.view(b, L * E), E).view(b, L, E)
+    torch.cuda.synchronize()
+    assert torch.equal(xn, ref)
+    assert np.array_equal(xn.cpu().numpy(), okm.l2_normalize_rows(v.view(b, L, E).cpu().numpy()))
