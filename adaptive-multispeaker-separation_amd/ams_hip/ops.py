@@ -240,6 +240,19 @@ def amax_of(t):
 PASS = [0]                                                       # bumped by graph.Run: one evaluation pass = one measurement
 
 
+def _frozen(*ts):
+    """Every tensor carries the mark Network.freeze_weights() sets (inference recipes: nothing writes the variables between passes, and
+    Network._weights_written() drops what was derived from them): bounds, gathered kernels and concatenated biases derived from such
+    weights are kept ACROSS passes instead of being re-derived in every one."""
+    return all(getattr(t, '_ams_frozen', False) for t in ts)
+
+
+def drop_frozen_derivatives(t):
+    for k in ('_ams_amax_cache', '_ams_wcat', '_ams_wcat_amax', '_ams_kbound', '_ams_bcat'):
+        if hasattr(t, k):
+            delattr(t, k)
+
+
 class _ParamSource(object):
     """One optimizer's flat parameter buffer and the bound measured over it (shared by every variable the optimizer owns)."""
     __slots__ = ('flat', 'bound', 'seen', 'event', 'used', 'next', 'rolled', '__weakref__')
@@ -275,7 +288,7 @@ def param_amax(W):
             _await_pass_side()
         return src.bound
     c = getattr(W, '_ams_amax_cache', None)
-    if c is None or c[0] != PASS[0]:
+    if c is None or (c[0] != PASS[0] and not _frozen(W)):
         W._ams_amax_cache = c = (PASS[0], absmax(W.detach(), out=c[1] if c is not None else None))
     return c[1]
 
@@ -783,15 +796,37 @@ def blstm_fwd(x, Kf, bf, Kb, bb, amax=None):
     if Kb.stride(0) != ldu:
         raise AmsError('blstm: the two direction kernels must share one row stride')
     x2 = x.view(B * T, D)
-    Wcat = blstm_wcat(Kf, Kb, D)
+    frozen = _frozen(Kf, Kb, bf, bb)
+    if frozen:                                                   # inference recipes: gathered once, not in every pass
+        c = getattr(Kf, '_ams_wcat', None)
+        if c is None or c[0] is not Kb or c[1] != D:
+            Kf._ams_wcat = c = (Kb, D, blstm_wcat(Kf, Kb, D))
+        Wcat = c[2]
+    else:
+        Wcat = blstm_wcat(Kf, Kb, D)
     u_amax = amax[1] if amax is not None else None               # the caller's weight bound covers the recurrent kernels too
     if amax is None and F16X3 and x.is_cuda:
-        # no optimizer, hence no common bound of the two kernels (inference): the gathered [D, 8H] matrix is measured once per pass
-        c = getattr(Kf, '_ams_wcat_amax', None)
-        if c is None or c[0] != PASS[0]:
-            Kf._ams_wcat_amax = c = (PASS[0], absmax(Wcat, out=c[1] if c is not None else None))
-        amax = (amax_of(x), c[1])
-    bias = torch.as_strided(bf, (8 * H,), (1,)) if _twin(bf, bb) else torch.cat([bf, bb])
+        if frozen:
+            # ONE bound over both whole kernels, measured once: the projection AND the ring's recurrent product run as fp16x3
+            c = getattr(Kf, '_ams_kbound', None)
+            if c is None or c[0] is not Kb:
+                Kf._ams_kbound = c = (Kb, torch.maximum(absmax(Kf), absmax(Kb)))
+            amax, u_amax = (amax_of(x), c[1]), c[1]
+        else:
+            # no optimizer, hence no common bound of the two kernels: the gathered [D, 8H] matrix is measured once per pass
+            c = getattr(Kf, '_ams_wcat_amax', None)
+            if c is None or c[0] != PASS[0]:
+                Kf._ams_wcat_amax = c = (PASS[0], absmax(Wcat, out=c[1] if c is not None else None))
+            amax = (amax_of(x), c[1])
+    if _twin(bf, bb):
+        bias = torch.as_strided(bf, (8 * H,), (1,))
+    elif frozen:
+        c = getattr(bf, '_ams_bcat', None)
+        if c is None or c[0] is not bb:
+            bf._ams_bcat = c = (bb, torch.cat([bf, bb]))
+        bias = c[1]
+    else:
+        bias = torch.cat([bf, bb])
     G = torch.empty((B, T, 2, 4 * H), dtype=torch.float32, device=x.device)
     # hoisted input projection of BOTH directions as ONE MFMA GEMM [B*T, D] x [D, 8H]: the two [D,4H] halves of the TF
     # kernels are gathered side by side (a 2 x D x 4H copy) so N = 8H gives 19 x 40 = 760 tiles = 2.97 per CU instead of

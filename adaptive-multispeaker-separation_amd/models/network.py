@@ -189,6 +189,19 @@ class Network(object):
         g.weights_epoch = getattr(g, 'weights_epoch', 0) + 1
         if torch.cuda.is_available():
             K.param_bounds_dirty()
+        for v in g.variables.values():                 # (freeze_weights: what was derived from the old values)
+            K.drop_frozen_derivatives(v)
+
+    def freeze_weights(self):
+        """Inference recipes (no optimizer is ever built): nothing writes the variables between passes, so what a pass derives from
+        them alone -- operand bounds of the fp16x3 products, the gathered [D, 8H] projection kernels, concatenated biases -- is kept
+        across passes (ams_hip/ops.py::_frozen) instead of being re-derived in each: ~45 us of launches per BLSTM layer and pass in
+        an eager inference step, and the recurrent product of the rings gets a bound, i.e. runs as fp16x3 as in training.
+        restore_model() / anything that calls _weights_written() drops the derived tensors; code that writes `.data` of a variable
+        behind the model's back must call _weights_written() itself (as it must for captured steps)."""
+        for v in get_default_graph().variables.values():
+            K.drop_frozen_derivatives(v)
+            v._ams_frozen = True
 
     def restore_last_checkpoint(self):
         self.restore_model(self._dir())

@@ -11,6 +11,7 @@ torchrun's environment (WORLD_SIZE/RANK/LOCAL_RANK), one process per GPU, RCCL a
 from __future__ import print_function
 
 import argparse
+import os
 import time
 
 import numpy as np
@@ -422,7 +423,11 @@ def _make_recipe(name):
         def __init__(self, separator, name, **kwargs):
             self.separator = separator
             Trainer.__init__(self, trainer_type=name, **kwargs)
-    return type(name, (Trainer,), {'__init__': __init__, 'build': lambda self: _wire(self, WIRING[name]),
+    def build(self):
+        _wire(self, WIRING[name])
+        if name.endswith('_Inference') and not os.environ.get('AMS_NO_FREEZE'):
+            self.model.freeze_weights()         # no optimizer in these recipes: weight-derived operands are kept across passes
+    return type(name, (Trainer,), {'__init__': __init__, 'build': build,
                                    '__doc__': 'wiring: WIRING[%r]' % name})
 
 

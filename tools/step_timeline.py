@@ -17,6 +17,11 @@ def main():
     rows = c.execute("select s.kernel_name, d.start, d.end, d.grid_size_x, d.grid_size_y, d.stream_id from %s d join %s s "
                      "on d.kernel_id=s.id order by d.start" % (kd, ks)).fetchall()
     idx = [i for i, r in enumerate(rows) if 'amsgrad' in r[0] or 'rmsprop' in r[0] or 'momentum' in r[0]]
+    if len(idx) <= back:                                       # no optimizer (inference): a step ends with its last overlap-add / k-means select
+        for anchor in ('overlap_add_kernel', 'kmeans_select_kernel'):
+            idx = [i for i, r in enumerate(rows) if anchor in r[0]]
+            if len(idx) > back:
+                break
     a, b = idx[-back - 1], idx[-back]
     t0 = rows[a][2]
     print('# step span %.1f us' % ((rows[b][2] - t0) / 1e3))
