@@ -85,8 +85,8 @@ class Adapt(Network):
             if w.is_cuda and not (w.requires_grad or bases.requires_grad):
                 from ams_hip import ops as K
                 epoch = getattr(get_default_graph(), 'weights_epoch', 0)
-                if cache.get('epoch') == epoch and torch.cuda.is_current_stream_capturing():
-                    return cache['f']
+                if cache.get('epoch') == epoch and (torch.cuda.is_current_stream_capturing() or K._frozen(w, bases)):
+                    return cache['f']                           # (inference recipes, Network.freeze_weights: also in eager passes)
                 f = F.front_filter(w.detach(), bases.detach())
                 if 'f' not in cache or cache['f'].shape != f.shape:
                     cache['f'] = torch.empty_like(f)
