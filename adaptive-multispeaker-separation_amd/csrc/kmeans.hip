@@ -546,7 +546,7 @@ __global__ void kmeans_reduce_kernel(const float* __restrict__ part, float* __re
 }
 
 // ------------------------------------------------------------------------------------------------------------------------------
-// HARD_ACC for E = 40, C = 2, no silence weights, tries a multiple of 5: TQ tries of an utterance from ONE read of its points.
+// HARD_ACC for E = 40, C = 2, tries a multiple of 5 (HAS_W: with silence weights): TQ tries of an utterance from ONE read of its points.
 //
 // kmeans_pass_kernel gives every try a workgroup of its own: the point is staged and read per try (10 x the LDS traffic and L2 reads of
 // the utterance) and each lane carries the 82 running sums of ITS points -- 3 waves per SIMD, a latency mix at 0.13 of HBM
@@ -568,6 +568,7 @@ struct KtArgs {
     const float* xn; const float* cent; float* part; unsigned* tickets; float* fin_out; float* fin_den;
     long L; int b, tries, G;
     int32_t* labels;                   // kmeans_hard_tries_final_kernel: [R, L] or null
+    const float* w; int w_mod_b;       // silence weights [b, L] or null; row of try r: r % b (the reference's tile quirk) or r / tries
     unsigned long long* dbg;           // AMS_KT_DBG builds: per (workgroup, wave) {HW_ID | XCC_ID << 32, start, end} (s_memrealtime)
 };
 
@@ -579,6 +580,13 @@ struct KtArgs {
                                               : "+v"(D), "=&v"(df_) : "v"(X), "s"(C)); } while (0)
 #define KT_DIST2(D, Q, X, SEL, C) do { f2 df_; asm("v_pk_add_f32 %2, %3, %4 " SEL " neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_fma_f32 %0, %2, %2, %0\n\t" \
                                                   "v_pk_mul_f32 %2, %2, %2\n\tv_pk_add_f32 %1, %1, %2" : "+v"(D), "+v"(Q), "=&v"(df_) : "v"(X), "s"(C)); } while (0)
+
+// the same with silence weights: d <- fma(df * w, df, d) (w = {w, w}: the weighted difference is rounded, as in kmeans_pass_kernel)
+#define KT_DISTW(D, X, SEL, C, W) do { f2 df_, dw_; asm("v_pk_add_f32 %1, %3, %4 " SEL " neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_mul_f32 %2, %1, %5\n\t" \
+                                                       "v_pk_fma_f32 %0, %2, %1, %0" : "+v"(D), "=&v"(df_), "=&v"(dw_) : "v"(X), "s"(C), "v"(W)); } while (0)
+#define KT_DIST2W(D, Q, X, SEL, C, W) do { f2 df_, dw_; asm("v_pk_add_f32 %2, %4, %5 " SEL " neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_mul_f32 %3, %2, %6\n\t" \
+                                                           "v_pk_fma_f32 %0, %3, %2, %0\n\tv_pk_mul_f32 %2, %2, %2\n\tv_pk_add_f32 %1, %1, %2" \
+                                                           : "+v"(D), "+v"(Q), "=&v"(df_), "=&v"(dw_) : "v"(X), "s"(C), "v"(W)); } while (0)
 
 __device__ __forceinline__ float mask_to_float(unsigned long long m) {       // 1.0f in the lanes whose bit of the (wave-uniform) mask is set
     float f;
@@ -610,6 +618,7 @@ __device__ __forceinline__ float tree4(float a, float b, float c, float d) {
 #ifndef AMS_KT_WAVES
 #define AMS_KT_WAVES 6
 #endif
+template <bool HAS_W>
 __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(KtArgs a) {
     constexpr int E_ = 40, C_ = 2, NV = C_ * (E_ + 1), LD = E_, V4 = E_ / 4, SL = CHUNK_HARD / LANES;
     // x is TRIPLE-buffered: the labels read slab pair `it`, the sums re-read their components of pair it - 1 (no copy kept in registers),
@@ -622,6 +631,7 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
     extern __shared__ __attribute__((aligned(16))) float kt_dyn[];
     float (*xbuf)[128 * LD] = reinterpret_cast<float (*)[128 * LD]>(kt_dyn);
     __shared__ float mf[2][2][TQ][64];                             // 1.0 where (slab, try, lane) chose cluster 1 and is a point, else 0.0
+    __shared__ float wf[HAS_W ? 2 : 1][2][TQ][HAS_W ? 64 : 1];    // silence weights: the weight of (slab, try, lane) (every try may have its own row)
     __shared__ int cbuf[TQ][C_];
     __shared__ int last_sh[TQ];
 #ifdef AMS_KT_PAD                       /* occupancy experiment: extra LDS so that fewer workgroups share a CU */
@@ -663,6 +673,14 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
     // the counts are integers (<= 2048 per column and chunk): every order of adding them in float gives the same float, so the label
     // wave counts the bits of its ballots on the scalar unit instead of the sums role adding 0/1 factors lane by lane
     int n0 = 0, n1 = 0;
+    // silence weights of this wave's (try, slab parity): requested one iteration ahead, like x (zeros past L: bounds-checked buffer loads)
+    __amdgpu_buffer_rsrc_t wrs;
+    float w_nxt = 1.0f;
+    if constexpr (HAS_W) {
+        const int r1 = row0 + tt;
+        wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w + (long)(a.w_mod_b ? (r1 % a.b) : ub) * a.L), (short)0, (int)(a.L * 4), 0x00020000);
+        w_nxt = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, (unsigned)((base + (long)kk * LANES + lane) * 4), 0, 0));
+    }
     // sums role
     float acc[TQ][C_][4];
 #pragma unroll
@@ -709,12 +727,18 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
             for (int k = 0; k < 2; ++k) {
                 const float vf = mask_to_float(valid_of(2 * (it - 1) + k));
                 const float4 xs = *reinterpret_cast<const float4*>(&xbuf[bprev][off_sum + k * 64 * LD]);
-                float m1[TQ];
+                float m1[TQ], wt[HAS_W ? TQ : 1];
 #pragma unroll
                 for (int t = 0; t < TQ; ++t) m1[t] = mf[cur ^ 1][k][t][lane];
-                const f2 t0 = {xs.x, xs.y}, t1 = {xs.z, xs.w};
+                if constexpr (HAS_W) {
+#pragma unroll
+                    for (int t = 0; t < TQ; ++t) wt[t] = wf[cur ^ 1][k][t][lane];
+                }
+                const f2 x0 = {xs.x, xs.y}, x1 = {xs.z, xs.w};
 #pragma unroll
                 for (int t = 0; t < TQ; ++t) {
+                    f2 t0 = x0, t1 = x1;
+                    if constexpr (HAS_W) { const f2 w2 = {wt[t], wt[t]}; t0 = x0 * w2; t1 = x1 * w2; }      // x w first (rounded), as kmeans_pass_kernel
                     // {m0, m1} in ONE register pair: the packed FMAs of cluster c take component c for both halves (op_sel)
                     const f2 mm = {vf - m1[t], m1[t]};
                     const f2 mm0 = __builtin_shufflevector(mm, mm, 0, 0), mm1 = __builtin_shufflevector(mm, mm, 1, 1);
@@ -732,6 +756,10 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
         __builtin_amdgcn_sched_barrier(0);                          // sums and labels are independent streams: interleaved they need both register sets
         if (it < nit) {
             // ---- labels of (slab kk, try tt): fused chains d <- fma(x_e - c_e, x_e - c_e, d), both clusters in one packed register
+            const float wv = w_nxt;
+            const f2 wv2 = {wv, wv};
+            if constexpr (HAS_W)                                    // (clamped inside the chunk's slabs: past them nothing is consumed)
+                w_nxt = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, (unsigned)((base + (long)(2 * (it + 1) + kk) * LANES + lane) * 4), 0, 0));
             const float* xrow = &xbuf[bcur][off_lab];
             f2 dp = {0.f, 0.f};
             float4 vd[2];
@@ -745,13 +773,19 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
                 // d <- fma(x_e - c, x_e - c, d) for both clusters: the point's value broadcast by op_sel from its place in the float4 (left to
                 // the compiler, every second broadcast was a v_mov), the centroid pair a scalar operand
                 const f2 xlo = {v.x, v.y}, xhi = {v.z, v.w};
-                KT_DIST(dp, xlo, KT_LO, cpair[4 * q4 + 0]); KT_DIST(dp, xlo, KT_HI, cpair[4 * q4 + 1]);
-                KT_DIST(dp, xhi, KT_LO, cpair[4 * q4 + 2]); KT_DIST(dp, xhi, KT_HI, cpair[4 * q4 + 3]);
+                if constexpr (HAS_W) {
+                    KT_DISTW(dp, xlo, KT_LO, cpair[4 * q4 + 0], wv2); KT_DISTW(dp, xlo, KT_HI, cpair[4 * q4 + 1], wv2);
+                    KT_DISTW(dp, xhi, KT_LO, cpair[4 * q4 + 2], wv2); KT_DISTW(dp, xhi, KT_HI, cpair[4 * q4 + 3], wv2);
+                } else {
+                    KT_DIST(dp, xlo, KT_LO, cpair[4 * q4 + 0]); KT_DIST(dp, xlo, KT_HI, cpair[4 * q4 + 1]);
+                    KT_DIST(dp, xhi, KT_LO, cpair[4 * q4 + 2]); KT_DIST(dp, xhi, KT_HI, cpair[4 * q4 + 3]);
+                }
             }
             const bool one = sqrtf(dp.y) < sqrtf(dp.x);            // ties pick cluster 0 (tf.argmin)
             const unsigned long long bal = __builtin_amdgcn_ballot_w64(one);
             const unsigned long long valid = valid_of(2 * it + kk);
             mf[cur][kk][tt][lane] = mask_to_float(bal & valid);
+            if constexpr (HAS_W) wf[cur][kk][tt][lane] = wv;
             n1 += __builtin_popcountll(bal & valid);
             n0 += __builtin_popcountll(~bal & valid);
             // ---- stage the next iteration's slabs, request the ones after it
@@ -835,11 +869,12 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
     if (a_fin_den && (fk % E_) == 0) a_fin_den[(long)r * C_ + c] = den;
 }
 
-// HARD_FINAL in the same shape (E = 40, C = 2, no silence weights, tries a multiple of 5): labels and inertia terms of TQ tries from one
+// HARD_FINAL in the same shape (E = 40, C = 2, tries a multiple of 5; HAS_W: the labels are weighted, the inertia distance is not): labels and inertia terms of TQ tries from one
 // read of the points.  No sums role: wave (try tt, kk) owns COLUMN 2 cp + kk of the chunk for all its slabs, so its lanes' running sums
 // tot_c += dist * [label == c] follow the summation order on their own; one slab of both columns (128 consecutive points) per iteration,
 // x double-buffered, one barrier.  dist = sum_e (x_e - c_e)^2 of the assigned centroid with separate multiply and add (oracle
 // inertia_hard), both clusters packed beside the fused label chain, which shares the differences.  Counts by popcount (integers).
+template <bool HAS_W>
 __global__ __launch_bounds__(640, 6) void kmeans_hard_tries_final_kernel(KtArgs a) {
     constexpr int E_ = 40, C_ = 2, LD = E_, V4 = E_ / 4, SL = CHUNK_HARD / LANES, NVF = 2 * C_;
     extern __shared__ __attribute__((aligned(16))) float kt_dyn[];
@@ -872,6 +907,13 @@ __global__ __launch_bounds__(640, 6) void kmeans_hard_tries_final_kernel(KtArgs 
     }
     int n0 = 0, n1 = 0;
     float tot0 = 0.f, tot1 = 0.f;
+    __amdgpu_buffer_rsrc_t wrs;
+    float w_nxt = 1.0f;
+    if constexpr (HAS_W) {                                          // silence weights: the LABELS are weighted, the inertia distance is not
+        const int r1 = row0 + tt;
+        wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.w + (long)(a.w_mod_b ? (r1 % a.b) : ub) * a.L), (short)0, (int)(a.L * 4), 0x00020000);
+        w_nxt = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, (unsigned)((base + kk * 64 + lane) * 4), 0, 0));
+    }
     const int pr = tid / V4, c4 = tid - pr * V4;
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), (short)0, (int)(a.L * E_ * 4), 0x00020000);
     float4 pf[2];
@@ -898,6 +940,10 @@ __global__ __launch_bounds__(640, 6) void kmeans_hard_tries_final_kernel(KtArgs 
     int32_t* const lrow = a.labels ? a.labels + (long)(row0 + tt) * a.L + base + kk * 64 + lane : nullptr;
     for (int it = 0; it < nit; ++it) {
         const int cur = it & 1;
+        const float wv = w_nxt;
+        const f2 wv2 = {wv, wv};
+        if constexpr (HAS_W)
+            w_nxt = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, (unsigned)((base + (long)(it + 1) * LANES + kk * 64 + lane) * 4), 0, 0));
         const float* xrow = &xbuf[cur][off_lab];
         f2 dp = {0.f, 0.f}, dq = {0.f, 0.f};
         float4 vd[2];
@@ -910,8 +956,13 @@ __global__ __launch_bounds__(640, 6) void kmeans_hard_tries_final_kernel(KtArgs 
             const float4 v = vd[q4 & 1];
             // label distance: fused chain (sqdist_fused); inertia distance: multiply, then add -- both from the same differences
             const f2 xlo = {v.x, v.y}, xhi = {v.z, v.w};
-            KT_DIST2(dp, dq, xlo, KT_LO, cpair[4 * q4 + 0]); KT_DIST2(dp, dq, xlo, KT_HI, cpair[4 * q4 + 1]);
-            KT_DIST2(dp, dq, xhi, KT_LO, cpair[4 * q4 + 2]); KT_DIST2(dp, dq, xhi, KT_HI, cpair[4 * q4 + 3]);
+            if constexpr (HAS_W) {
+                KT_DIST2W(dp, dq, xlo, KT_LO, cpair[4 * q4 + 0], wv2); KT_DIST2W(dp, dq, xlo, KT_HI, cpair[4 * q4 + 1], wv2);
+                KT_DIST2W(dp, dq, xhi, KT_LO, cpair[4 * q4 + 2], wv2); KT_DIST2W(dp, dq, xhi, KT_HI, cpair[4 * q4 + 3], wv2);
+            } else {
+                KT_DIST2(dp, dq, xlo, KT_LO, cpair[4 * q4 + 0]); KT_DIST2(dp, dq, xlo, KT_HI, cpair[4 * q4 + 1]);
+                KT_DIST2(dp, dq, xhi, KT_LO, cpair[4 * q4 + 2]); KT_DIST2(dp, dq, xhi, KT_HI, cpair[4 * q4 + 3]);
+            }
         }
         const bool one = sqrtf(dp.y) < sqrtf(dp.x);
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(one);
@@ -1181,7 +1232,7 @@ unsigned long long* ams_dbg_kt_buffer(size_t words) {       // device buffer the
 }
 int ams_dbg_kt_occupancy() {
     int n = -1;
-    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kmeans_hard_tries_kernel, 640, KT_LDS_BYTES);
+    hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kmeans_hard_tries_kernel<false>, 640, KT_LDS_BYTES);
     return n;
 }
 #endif
@@ -1214,14 +1265,15 @@ ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent
     a.tickets = (unsigned*)tickets; a.fin_out = cent_out; a.fin_den = den_out;
     // AMS_KM_TRIES=0: every try a workgroup of its own (kmeans_pass_kernel) also where kmeans_hard_tries_kernel applies -- same bits
     static const bool tries_kernel = [] { const char* e = getenv("AMS_KM_TRIES"); return !(e && e[0] == '0'); }();
-    if (tries_kernel && beta < 0.f && !w && E == 40 && C == 2 && tries % TQ == 0 && L * E * 4 < (1L << 31))   /* 32-bit buffer offsets */ {
+    if (tries_kernel && beta < 0.f && E == 40 && C == 2 && tries % TQ == 0 && L * E * 4 < (1L << 31))   /* 32-bit buffer offsets */ {
         KtArgs k{};
         k.xn = xn; k.cent = cent_in; k.part = (float*)ws; k.tickets = (unsigned*)tickets; k.fin_out = cent_out; k.fin_den = den_out;
-        k.L = L; k.b = b; k.tries = tries; k.G = a.G;
+        k.L = L; k.b = b; k.tries = tries; k.G = a.G; k.w = w; k.w_mod_b = w_mod_b;
 #ifdef AMS_KT_DBG
         k.dbg = g_kt_dbg;
 #endif
-        hipLaunchKernelGGL(kmeans_hard_tries_kernel, dim3((unsigned)(b * (tries / TQ) * 4 * a.G)), dim3(640), KT_LDS_BYTES, st, k);
+        if (w) hipLaunchKernelGGL(kmeans_hard_tries_kernel<true>, dim3((unsigned)(b * (tries / TQ) * 4 * a.G)), dim3(640), KT_LDS_BYTES, st, k);
+        else hipLaunchKernelGGL(kmeans_hard_tries_kernel<false>, dim3((unsigned)(b * (tries / TQ) * 4 * a.G)), dim3(640), KT_LDS_BYTES, st, k);
         ams_status s2 = ams_check_launch();
         if (s2 != AMS_OK || tickets) return s2;
         hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(ceil_div((long)R * C * E, 256)), dim3(256), 0, st, (const float*)ws, cent_out, den_out, R,
@@ -1269,11 +1321,12 @@ ams_status ams_kmeans_assign(const float* xn, const float* w, const float* cent,
     a.G = ceil_div(L, chunk_of(beta >= 0.f || labels_only)); a.w_mod_b = w_mod_b; a.beta = beta; a.one = 1.0f;
     a.tickets = inertia ? (unsigned*)tickets : nullptr; a.fin_out = inertia; a.fin_den = nullptr;
     static const bool tries_kernel = [] { const char* e = getenv("AMS_KM_TRIES"); return !(e && e[0] == '0'); }();
-    if (tries_kernel && beta < 0.f && inertia && !w && E == 40 && C == 2 && tries % TQ == 0 && L * E * 4 < (1L << 31))   /* 32-bit buffer offsets */ {
+    if (tries_kernel && beta < 0.f && inertia && E == 40 && C == 2 && tries % TQ == 0 && L * E * 4 < (1L << 31))   /* 32-bit buffer offsets */ {
         KtArgs k{};
         k.xn = xn; k.cent = cent; k.part = (float*)ws; k.tickets = (unsigned*)tickets; k.fin_out = inertia; k.labels = labels;
-        k.L = L; k.b = b; k.tries = tries; k.G = a.G;
-        hipLaunchKernelGGL(kmeans_hard_tries_final_kernel, dim3((unsigned)(b * (tries / TQ) * 2 * a.G)), dim3(640), 2 * 128 * 40 * sizeof(float), st, k);
+        k.L = L; k.b = b; k.tries = tries; k.G = a.G; k.w = w; k.w_mod_b = w_mod_b;
+        if (w) hipLaunchKernelGGL(kmeans_hard_tries_final_kernel<true>, dim3((unsigned)(b * (tries / TQ) * 2 * a.G)), dim3(640), 2 * 128 * 40 * sizeof(float), st, k);
+        else hipLaunchKernelGGL(kmeans_hard_tries_final_kernel<false>, dim3((unsigned)(b * (tries / TQ) * 2 * a.G)), dim3(640), 2 * 128 * 40 * sizeof(float), st, k);
         ams_status s2 = ams_check_launch();
         if (s2 != AMS_OK || tickets) return s2;
         hipLaunchKernelGGL(kmeans_reduce_kernel, dim3(ceil_div(R, 256)), dim3(256), 0, st, (const float*)ws, inertia, (float*)nullptr, R, 4 * a.G, C, E, 1);

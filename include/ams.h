@@ -406,7 +406,7 @@ ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent
 /* tickets (ams_kmeans_iterate / ams_kmeans_assign; optional): b * tries uint32, zero before the first use and left zero -- the chunk
  * partials of a row are then added up INSIDE the pass by the workgroup that stores the row's last one (same chunk order: same bits),
  * instead of by a reduce launch behind each of the nb_steps + 1 passes.
- * Hard passes with E = 40, C = 2, w = NULL and tries a multiple of 5 serve FIVE tries of an utterance from one read of its points
+ * Hard passes with E = 40, C = 2 and tries a multiple of 5 (with or without silence weights) serve FIVE tries of an utterance from one read of its points
  * (csrc/kmeans.hip, kmeans_hard_tries_kernel / _final_kernel; AMS_KM_TRIES=0 in the environment: one workgroup per try as elsewhere);
  * every path produces the same bits: the summation order is part of the contract (oracle/kmeans.py: 8192-point chunks, lane j of 256
  * adds its 32 points in sequence, one halving tree per wavefront, wavefront totals in (chunk, wavefront) order).  ams_kmeans_assign with

@@ -44,6 +44,28 @@ def test_five_tries_per_read_is_bit_exact(b, L, tries, iters, end):
     assert np.array_equal(lab.cpu().numpy(), lab_ref)
 
 
+@pytest.mark.parametrize('b,L,tries,iters,kind,end', [(2, 3000, 5, 3, 'mask', True), (3, 8192 + 300, 10, 2, 'mask', False), (2, 2500, 5, 3, 'real', True),
+                                                     (1, 20480, 5, 2, 'mixed', True), (4, 700, 5, 2, 'mask', False)])
+def test_five_tries_per_read_with_silence_weights(b, L, tries, iters, kind, end):
+    """Silence weights (Kmeans_2.py:76-82, 175-181): the 0/1 mask the reference builds, arbitrary positive weights, a mix -- and the
+    reference's weight-tile quirk (row r of the tiled problem takes weight row r % b: with b > 1 every try of an utterance may see another
+    utterance's weights), which is why the sums role takes its weights per try."""
+    from ams_hip import functional as F
+    X, idx = _data(L * 3 + tries, b, L, tries=tries, spread=2.0)
+    rng = np.random.RandomState(b + L)
+    w = (rng.rand(b, L) > 0.25).astype(np.float32)
+    if kind == 'real':
+        w = rng.uniform(0.05, 1.7, (b, L)).astype(np.float32)
+    elif kind == 'mixed':
+        w[:, ::3] = rng.uniform(0.05, 1.7, (b, L))[:, ::3].astype(np.float32)
+    cent_ref, lab_ref, best_ref = okm.kmeans(X, idx, 2, tries, iters, beta=None, notsilent=w, assign_at_end=end)
+    cent, lab, best = F.kmeans(torch.from_numpy(X).cuda(), torch.from_numpy(idx).cuda(), 2, tries, iters, None, torch.from_numpy(w).cuda(), end)
+    torch.cuda.synchronize()
+    assert np.array_equal(best.cpu().numpy(), best_ref)
+    assert np.array_equal(cent.cpu().numpy(), cent_ref, equal_nan=True)
+    assert np.array_equal(lab.cpu().numpy(), lab_ref)
+
+
 _CHILD = r'''
 import sys, numpy as np, torch
 sys.path.insert(0, sys.argv[3]); sys.path.insert(0, sys.argv[4])
