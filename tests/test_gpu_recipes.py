@@ -200,6 +200,52 @@ def test_front_separator_inference(beta, with_silence):
     assert err < INFER_TOL, err
 
 
+def test_inference_recipe_keeps_weight_derivatives_until_the_weights_are_written():
+    """Network.freeze_weights (inference recipes: no optimizer exists): bounds / gathered kernels derived from the variables are kept across
+    passes -- a second pass gives the same bits -- and dropped by _weights_written() (restore, or whoever writes `.data` and says so): the
+    next pass must see the new weights, exactly as a recipe built without the caches (AMS_NO_FREEZE) does."""
+    from models.dpcl import DPCL
+    from utils.trainer import Front_Separator_Inference
+    from ams_hip import ops
+    rng = np.random.RandomState(13)
+    B, S, L, W, N, hop, LS, NL, E, tries, steps = 2, 2, 2048, 64, 16, 16, 12, 2, 8, 5, 2
+    T = -(-L // hop)
+    idx = np.stack([rng.choice(T * N, S, replace=False) for _ in range(B * tries)]).astype(np.int32)
+    outs = {}
+    for frozen in (True, False):
+        tmp = tempfile.mkdtemp(prefix='ams_inf_')
+        folder, params, P = _full_checkpoint(tmp, np.random.RandomState(11), W, N, hop, L, B, S, LS, NL, E, N, N)
+        a = base_args(**params)
+        a.update(model_folder=folder, nb_tries=tries, nb_steps=steps, beta_kmeans=None, with_silence=False, end_assign=True,
+                 kmeans_init_indices=idx, out=False)
+        a.pop('type')
+        if not frozen:
+            os.environ['AMS_NO_FREEZE'] = '1'
+        try:
+            tr = Front_Separator_Inference(DPCL, 'front_DPCL_inference', **a)
+            dist, tfds = tr.prepare()
+        finally:
+            os.environ.pop('AMS_NO_FREEZE', None)
+        g, model = tr.graph, tr.model
+        with g.as_default():
+            feed = {tfds.handle: tfds.get_handle(tfds.TEST), tfds.chunk_size: L}
+            o1 = model.infer(feed, 0)[2].clone()
+            o2 = model.infer(feed, 0)[2].clone()
+            Kf = g.variables['prediction/forward_BLSTM_0/rnn/basic_lstm_cell/kernel']
+            assert ops._frozen(Kf) == frozen and hasattr(Kf, '_ams_wcat') == frozen
+            Kf.data.mul_(1.5)
+            g.variables['prediction/W'].data.mul_(0.7)
+            model._weights_written()
+            assert not hasattr(Kf, '_ams_wcat')
+            o3 = model.infer(feed, 0)[2].clone()
+        assert torch.equal(o1, o2)
+        assert torch.isfinite(o3).all() and not torch.equal(o1, o3)
+        outs[frozen] = (o1, o3)
+    for i in (0, 1):      # frozen: the rings' recurrent product runs as fp16x3 (it has a bound), otherwise bf16x6: same to round-off
+        err = float((outs[True][i] - outs[False][i]).norm() / outs[False][i].norm())
+        assert err < INFER_TOL, (i, err)
+
+
 def test_stft_separator_inference():
     """STFT_Separator_Inference: STFT -> DPCL -> hard k-means -> iSTFT (trainer.py:406-417)."""
     from models.dpcl import DPCL
