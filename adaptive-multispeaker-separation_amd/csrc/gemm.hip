@@ -2004,13 +2004,32 @@ __global__ __launch_bounds__(256) void synth_unpool_kernel(const float* __restri
     int t1 = (l_hi + pl) / hop;
     if (t1 > T - 1) t1 = T - 1;
     float s = 0.f;
-    const int32_t* am = pos + (long)(r / S) * T * N;
-    const float* vr = vals + (long)r * T * N;
-    for (int t = t0; t <= t1; ++t)
-        for (int n = 0; n < N; ++n) {
-            const int k = l - am[(long)t * N + n] + pl;                 // uniform offset: consecutive l -> consecutive k
-            if (k >= 0 && k < W) s += vr[(long)t * N + n] * f2t[(long)n * W + k];
-        }                                                               // (eight filters per round, unconditional loads: 1.68 -> 2.17 ms)
+    // the window's position and value are the same for every sample of the block: read through the CONSTANT address space they are
+    // scalar loads (both tensors were written by earlier launches), and the vector memory pipe is left with the one load that differs
+    // per lane -- as three vector loads per term the kernel was bound by issuing them (round 5: 1.71 ms -> see HISTORY)
+    typedef const __attribute__((address_space(4))) int32_t c_i32;
+    typedef const __attribute__((address_space(4))) float c_f32;
+    c_i32* am = (c_i32*)(pos + (long)(r / S) * T * N);
+    c_f32* vr = (c_f32*)(vals + (long)r * T * N);
+    auto rounds = [&](auto EVEN) {                                      // eight windows per round: two s_load_dwordx8 when N % 8 == 0
+        constexpr bool even = decltype(EVEN)::value;
+        for (int t = t0; t <= t1; ++t)
+            for (int n0 = 0; n0 < N; n0 += 8) {
+                int pa[8];
+                float va[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const long i = (long)t * N + (even ? n0 + j : min(n0 + j, N - 1));
+                    pa[j] = am[i]; va[j] = vr[i];
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int k = l - pa[j] + pl;                       // uniform offset: consecutive l -> consecutive k
+                    if ((even || n0 + j < N) && k >= 0 && k < W) s += va[j] * f2t[(long)(n0 + j) * W + k];
+                }
+            }
+    };
+    if ((N & 7) == 0) rounds(std::true_type{}); else rounds(std::false_type{});
     if (l < L) out[(long)r * L + l] = s;
 }
 
