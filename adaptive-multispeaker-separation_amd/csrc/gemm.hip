@@ -2045,15 +2045,41 @@ __global__ __launch_bounds__(256) void synth_unpool_bwd_vals_kernel(const float*
     c_i32* pr = (c_i32*)(pos + ((long)(r / S) * T + t) * N);
     const float* dr = dout + (long)r * L;
     float* out = dvals + (long)rt * N;
+    // the N windows of a frame start within one pooling window of each other: their union [pmin - pl, pmax - pl + W) of the upstream row
+    // is staged in LDS once (zeros outside the row) when it fits, and every filter reads its window from there
+    constexpr int SPAN = 4096;
+    __shared__ float seg[SPAN];
+    __shared__ int mm[2][4];
+    int lo = 0x7fffffff, hi = -0x7fffffff;
+    for (int n = threadIdx.x; n < N; n += 256) { const int q = pos[((long)(r / S) * T + t) * N + n]; lo = min(lo, q); hi = max(hi, q); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { lo = min(lo, __shfl_xor(lo, o)); hi = max(hi, __shfl_xor(hi, o)); }
+    if (lane == 0) { mm[0][wave] = lo; mm[1][wave] = hi; }
+    __syncthreads();
+    const int pmin = min(min(mm[0][0], mm[0][1]), min(mm[0][2], mm[0][3])), pmax = max(max(mm[1][0], mm[1][1]), max(mm[1][2], mm[1][3]));
+    const bool staged = pmax - pmin + W <= SPAN;
+    if (staged) {
+        for (int i = threadIdx.x; i < pmax - pmin + W; i += 256) {
+            const int p = pmin - pl + i;
+            seg[i] = (p >= 0 && p < L) ? dr[p] : 0.f;
+        }
+        __syncthreads();
+    }
     for (int n = wave; n < N; n += 4) {
         const int p0 = pr[n] - pl;
         const float* fr = f2t + (long)n * W;
         float s = 0.f;
+        if (staged) {
+            const float* sg = seg + (p0 + pl - pmin);
 #pragma unroll 4
-        for (int k = lane; k < W; k += 64) {
-            const int p = p0 + k;
-            const float dv = dr[min(max(p, 0), L - 1)], fv = fr[k];     // unconditional loads: four rounds in flight
-            if (p >= 0 && p < L) s += dv * fv;
+            for (int k = lane; k < W; k += 64) s += sg[k] * fr[k];
+        } else {
+#pragma unroll 4
+            for (int k = lane; k < W; k += 64) {
+                const int p = p0 + k;
+                const float dv = dr[min(max(p, 0), L - 1)], fv = fr[k];     // unconditional loads: four rounds in flight
+                if (p >= 0 && p < L) s += dv * fv;
+            }
         }
         s = wave_sum_lane0(s);
         if (lane == 0) out[n] = s;
