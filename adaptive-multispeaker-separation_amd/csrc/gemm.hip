@@ -1992,10 +1992,11 @@ __global__ void gather_filter_reduce_kernel(const float* __restrict__ part, floa
     df[i] = s;
 }
 
+template <int SS>                      // SS rows (the S sources of one mixture share its positions) per workgroup: ONE filter load serves all
 __global__ __launch_bounds__(256) void synth_unpool_kernel(const float* __restrict__ vals, const int32_t* __restrict__ pos,
                                                            const float* __restrict__ f2t, float* __restrict__ out, int R, int L, int W,
                                                            int N, int T, int P, int hop, int pl, int S) {
-    const int r = blockIdx.y;
+    const int r = blockIdx.y * SS;                                      // (SS > 1 only when S % SS == 0: rows r .. r + SS - 1 share r / S)
     const int l = blockIdx.x * blockDim.x + threadIdx.x;
     const int l_lo = blockIdx.x * blockDim.x, l_hi = min(L, l_lo + (int)blockDim.x) - 1;
     // windows whose positions [t*hop, t*hop+P) can reach any sample of this block: pos in (l+pl-W, l+pl]
@@ -2003,34 +2004,47 @@ __global__ __launch_bounds__(256) void synth_unpool_kernel(const float* __restri
     t0 = t0 <= 0 ? 0 : t0 / hop;
     int t1 = (l_hi + pl) / hop;
     if (t1 > T - 1) t1 = T - 1;
-    float s = 0.f;
+    float s[SS];
+#pragma unroll
+    for (int q = 0; q < SS; ++q) s[q] = 0.f;
     // the window's position and value are the same for every sample of the block: read through the CONSTANT address space they are
     // scalar loads (both tensors were written by earlier launches), and the vector memory pipe is left with the one load that differs
-    // per lane -- as three vector loads per term the kernel was bound by issuing them (round 5: 1.71 ms -> see HISTORY)
+    // per lane -- as three vector loads per term the kernel was bound by issuing them (round 5: 1.71 -> 1.22 ms; then the filter
+    // load shared by the sources of a mixture)
     typedef const __attribute__((address_space(4))) int32_t c_i32;
     typedef const __attribute__((address_space(4))) float c_f32;
     c_i32* am = (c_i32*)(pos + (long)(r / S) * T * N);
     c_f32* vr = (c_f32*)(vals + (long)r * T * N);
-    auto rounds = [&](auto EVEN) {                                      // eight windows per round: two s_load_dwordx8 when N % 8 == 0
+    const long rstride = (long)T * N;
+    auto rounds = [&](auto EVEN) {                                      // eight windows per round (independent scalar loads)
         constexpr bool even = decltype(EVEN)::value;
         for (int t = t0; t <= t1; ++t)
             for (int n0 = 0; n0 < N; n0 += 8) {
                 int pa[8];
-                float va[8];
+                float va[SS][8];
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const long i = (long)t * N + (even ? n0 + j : min(n0 + j, N - 1));
-                    pa[j] = am[i]; va[j] = vr[i];
+                    pa[j] = am[i];
+#pragma unroll
+                    for (int q = 0; q < SS; ++q) va[q][j] = vr[i + q * rstride];
                 }
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int k = l - pa[j] + pl;                       // uniform offset: consecutive l -> consecutive k
-                    if ((even || n0 + j < N) && k >= 0 && k < W) s += va[j] * f2t[(long)(n0 + j) * W + k];
+                    if ((even || n0 + j < N) && k >= 0 && k < W) {
+                        const float fv = f2t[(long)(n0 + j) * W + k];
+#pragma unroll
+                        for (int q = 0; q < SS; ++q) s[q] += va[q][j] * fv;
+                    }
                 }
             }
     };
     if ((N & 7) == 0) rounds(std::true_type{}); else rounds(std::false_type{});
-    if (l < L) out[(long)r * L + l] = s;
+    if (l < L) {
+#pragma unroll
+        for (int q = 0; q < SS; ++q) out[(long)(r + q) * L + l] = s[q];
+    }
 }
 
 // dvals[r,t,n] = sum_k dout_pad[r, pos + k] * f2[k,n]: one workgroup per (r, t), wave w takes filters n = w, w + 4, ...
@@ -2225,8 +2239,12 @@ ams_status ams_gather_filter_grad(const float* x, const float* v, const int32_t*
 ams_status ams_synth_unpool_fwd(const float* vals, const int32_t* pos, const float* f2t, float* out, int R, int L, int W, int N, int T,
                                 int P, int hop, int S, void* stream) {
     AMS_REQUIRE(vals && pos && f2t && out && R > 0 && L > 0 && W > 0 && N > 0 && T > 0 && P > 0 && hop > 0 && S > 0);
-    hipLaunchKernelGGL(synth_unpool_kernel, dim3(ceil_div(L, 256), R), dim3(256), 0, (hipStream_t)stream, vals, pos, f2t, out, R, L, W,
-                       N, T, P, hop, (W - 1) / 2, S);
+    if (S % 2 == 0 && R % 2 == 0)
+        hipLaunchKernelGGL(synth_unpool_kernel<2>, dim3(ceil_div(L, 256), R / 2), dim3(256), 0, (hipStream_t)stream, vals, pos, f2t, out, R, L, W,
+                           N, T, P, hop, (W - 1) / 2, S);
+    else
+        hipLaunchKernelGGL(synth_unpool_kernel<1>, dim3(ceil_div(L, 256), R), dim3(256), 0, (hipStream_t)stream, vals, pos, f2t, out, R, L, W,
+                           N, T, P, hop, (W - 1) / 2, S);
     return ams_check_launch();
 }
 
