@@ -623,7 +623,7 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
     constexpr int E_ = 40, C_ = 2, NV = C_ * (E_ + 1), LD = E_, V4 = E_ / 4, SL = CHUNK_HARD / LANES;
     // x is TRIPLE-buffered: the labels read slab pair `it`, the sums re-read their components of pair it - 1 (no copy kept in registers),
     // the staging writes pair it + 1 -- all between the same two barriers.  Rows are UNPADDED (3 x 20 KB: two workgroups fit beside each
-    // other, 128 KB of LDS are usable per CU) and the 16-byte groups of a row are rotated by one for rows 8..15 of every 16: group c of
+    // other with room for the 0/1 factors and the weights) and the 16-byte groups of a row are rotated by one for rows 8..15 of every 16: group c of
     // row p sits at slot (c + ((p >> 3) & 1)) % 10, so that 16 lanes reading the same group of 16 consecutive rows (160 B apart: 10 p
     // mod 16 takes only the 8 even values) still cover all 64 banks.
     // (dynamic: with the size in sight hipcc sees that six waves per SIMD cannot be reached, settles for five and spends 87-99 VGPRs;
@@ -634,10 +634,6 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
     __shared__ float wf[HAS_W ? 2 : 1][2][TQ][HAS_W ? 64 : 1];    // silence weights: the weight of (slab, try, lane) (every try may have its own row)
     __shared__ int cbuf[TQ][C_];
     __shared__ int last_sh[TQ];
-#ifdef AMS_KT_PAD                       /* occupancy experiment: extra LDS so that fewer workgroups share a CU */
-    __shared__ float padbuf[AMS_KT_PAD];
-    if (a.L < 0) padbuf[threadIdx.x] = 1.f, a.part[0] = padbuf[threadIdx.x ^ 1];
-#endif
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 #ifdef AMS_KT_DBG
     const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();                    // placement / lifetime probe (tools/kt_probe.py)
