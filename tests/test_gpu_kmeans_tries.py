@@ -72,34 +72,67 @@ sys.path.insert(0, sys.argv[3]); sys.path.insert(0, sys.argv[4])
 from ams_hip import ops
 d = np.load(sys.argv[1])
 xn = ops.kmeans_normalize(torch.from_numpy(d['X']).cuda())
-cent, lab, best, _ = ops.kmeans_run(xn, torch.from_numpy(d['idx']).cuda(), 2, int(d['tries']), int(d['iters']))
+w = torch.from_numpy(d['w']).cuda() if 'w' in d.files else None
+beta = float(d['beta']) if 'beta' in d.files else None
+cent, lab, best, _ = ops.kmeans_run(xn, torch.from_numpy(d['idx']).cuda(), 2, int(d['tries']), int(d['iters']), beta=beta, w=w)
 torch.cuda.synchronize()
 np.savez(sys.argv[2], cent=cent.cpu().numpy(), lab=lab.cpu().numpy(), best=best.cpu().numpy())
 '''
 
 
-def test_same_bits_as_one_workgroup_per_try_at_benchmark_size():
-    """b = 64 utterances x 10 restarts x 10 iterations at TF = 20480 (cfg3 inference): every centroid bit, label and chosen restart equal to
-    what kmeans_pass_kernel gives (AMS_KM_TRIES=0 is read once per process, hence the child)."""
+def _in_child(env_var, X, idx, tries, iters, w=None, beta=None):
+    """The same k-means in a process of its own with `env_var`=0 (the switches are read once per process)."""
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory(prefix='ams_km_') as tmp:
+        extra = {}
+        if w is not None:
+            extra['w'] = w
+        if beta is not None:
+            extra['beta'] = beta
+        np.savez(os.path.join(tmp, 'in.npz'), X=X, idx=idx, tries=tries, iters=iters, **extra)
+        env = dict(os.environ, **{env_var: '0'})
+        r = subprocess.run([sys.executable, '-c', _CHILD, os.path.join(tmp, 'in.npz'), os.path.join(tmp, 'out.npz'),
+                            os.path.join(root, 'adaptive-multispeaker-separation_amd'), root], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        ref = np.load(os.path.join(tmp, 'out.npz'))
+        return {k: ref[k] for k in ref.files}
+
+
+@pytest.mark.parametrize('weights', [False, True])
+def test_same_bits_as_one_workgroup_per_try_at_benchmark_size(weights):
+    """b = 64 utterances x 10 restarts x 10 iterations at TF = 20480 (cfg3 inference), without and with silence weights: every centroid
+    bit, label and chosen restart equal to what kmeans_pass_kernel gives (AMS_KM_TRIES=0 is read once per process, hence the child)."""
     from ams_hip import ops
     if os.environ.get('AMS_KM_TRIES') == '0':
         pytest.skip('this process runs the per-try kernel itself')
     b, L, tries, iters = 64, 20480, 10, 10
     X, idx = _data(77, b, L, tries=tries, spread=1.3)
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    with tempfile.TemporaryDirectory(prefix='ams_km_') as tmp:
-        np.savez(os.path.join(tmp, 'in.npz'), X=X, idx=idx, tries=tries, iters=iters)
-        env = dict(os.environ, AMS_KM_TRIES='0')
-        r = subprocess.run([sys.executable, '-c', _CHILD, os.path.join(tmp, 'in.npz'), os.path.join(tmp, 'out.npz'),
-                            os.path.join(root, 'adaptive-multispeaker-separation_amd'), root], env=env, capture_output=True, text=True, timeout=900)
-        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-        ref = np.load(os.path.join(tmp, 'out.npz'))
-        xn = ops.kmeans_normalize(torch.from_numpy(X).cuda())
-        cent, lab, best, _ = ops.kmeans_run(xn, torch.from_numpy(idx).cuda(), 2, tries, iters)
-        torch.cuda.synchronize()
-        assert np.array_equal(best.cpu().numpy(), ref['best'])
-        assert np.array_equal(cent.cpu().numpy(), ref['cent'])
-        assert np.array_equal(lab.cpu().numpy(), ref['lab'])
+    w = (np.random.RandomState(5).rand(b, L) > 0.3).astype(np.float32) if weights else None
+    ref = _in_child('AMS_KM_TRIES', X, idx, tries, iters, w=w)
+    xn = ops.kmeans_normalize(torch.from_numpy(X).cuda())
+    cent, lab, best, _ = ops.kmeans_run(xn, torch.from_numpy(idx).cuda(), 2, tries, iters, w=None if w is None else torch.from_numpy(w).cuda())
+    torch.cuda.synchronize()
+    assert np.array_equal(best.cpu().numpy(), ref['best'])
+    assert np.array_equal(cent.cpu().numpy(), ref['cent'])
+    assert np.array_equal(lab.cpu().numpy(), ref['lab'])
+
+
+def test_soft_accumulation_kernel_agrees_with_the_pass_kernel_at_benchmark_size():
+    """kmeans_soft_acc_kernel (scalar centroid operands, |x|^2 - 2 <x, c> + |c|^2) against the soft branch of kmeans_pass_kernel
+    (AMS_KM_SOFT=0, a process of its own) at the fine-tuning geometry: 64 utterances, TF = 20480, beta = 10, silence weights, 10 iterations:
+    centroids and soft labels to 2e-5 (the soft modes are tolerance-checked everywhere: tests/test_gpu_kmeans_soft.py vs float64)."""
+    from ams_hip import ops
+    if os.environ.get('AMS_KM_SOFT') == '0':
+        pytest.skip('this process runs the pass kernel itself')
+    b, L, tries, iters, beta = 64, 20480, 1, 10, 10.0
+    X, idx = _data(78, b, L, tries=tries, spread=1.3)
+    w = (np.random.RandomState(6).rand(b, L) > 0.3).astype(np.float32)
+    ref = _in_child('AMS_KM_SOFT', X, idx, tries, iters, w=w, beta=beta)
+    xn = ops.kmeans_normalize(torch.from_numpy(X).cuda())
+    cent, lab, best, _ = ops.kmeans_run(xn, torch.from_numpy(idx).cuda(), 2, tries, iters, beta=beta, w=torch.from_numpy(w).cuda())
+    torch.cuda.synchronize()
+    assert np.abs(cent.cpu().numpy() - ref['cent']).max() < 2e-5 * max(1.0, np.abs(ref['cent']).max())
+    assert np.abs(lab.cpu().numpy() - ref['lab']).max() < 2e-4
 
 
 @pytest.mark.parametrize('E', [40, 32, 20, 8])
