@@ -279,7 +279,7 @@ def test_kmeans_soft_forward(F):
 
 
 @pytest.mark.parametrize('Bt,L,W,N,P,hop,S', [(4, 512, 64, 16, 128, 128, 2), (6, 1024, 128, 40, 256, 128, 2), (2, 300, 32, 5, 40, 24, 1),
-                                               (3, 2048, 1024, 256, 256, 256, 1)])
+                                               (3, 2048, 1024, 256, 256, 256, 1), (2, 12000, 64, 8, 4200, 4200, 2)])   # last: pooling window wider than the LDS segment of the values' backward
 def test_maxpool_front_and_sparse_synthesis(F, Bt, L, W, N, P, hop, S):
     """Path B: fused conv+max-pool (MFMA path when 128-aligned, generic kernel otherwise), gather filter gradient,
     sparse synthesis and its gradients -- vs the oracle (which itself is checked against dense unpool + conv_transpose)."""
