@@ -147,6 +147,9 @@ __global__ __launch_bounds__(256) void dpcl_gram_kernel(const float* __restrict_
 //   * normalisation is applied on the MFMA operand fetch (per-lane factor: 1/|u| for embedding columns, 1 for
 //     label columns), the rows in LDS stay raw.
 constexpr int CP = 8;                  // label-count partials per utterance
+#ifndef AMS_DPCL_BWD_F16
+#define AMS_DPCL_BWD_F16 1          // dpcl_bwd_u2_kernel: the product on the 16-bit pipe as fp16x3 (0: v_mfma_f32_16x16x4_f32)
+#endif
 #ifndef AMS_DPCL_UCHUNK
 #define AMS_DPCL_UCHUNK 2560
 #endif
@@ -835,6 +838,48 @@ __global__ __launch_bounds__(256) void dpcl_bwd_u2_kernel(const float* __restric
                     am[j][i][ft] = v;
                 }
     }
+#if AMS_DPCL_BWD_F16
+    // fp16x3 (csrc/gemm.hip): M scaled by a power of two from its own maximum and split exactly into two fp16 terms, once per workgroup;
+    // z (|u / |u|| <= 1, labels 0 / 1) scaled by 2^13 and split per group.  A lane's four k-slots of block j are exactly its A / B
+    // fragment of a v_mfma_f32_16x16x16_f16, blocks 0 and 1 together those of a 16x16x32: 18 MFMAs of ~16 cycles per group of 16 points
+    // instead of 36 v_mfma_f32_16x16x4_f32 of 32 (38 us of matrix pipe per launch at 64 x 20480 points).
+    typedef _Float16 dh8 __attribute__((ext_vector_type(8)));
+    typedef _Float16 dh4 __attribute__((ext_vector_type(4)));
+    dh8 a8[NT][2];                                  // [feature tile][plane hi / lo], k-blocks 0 and 1
+    dh4 a4[NT][2];                                  //                                 k-block 2
+    float m_inv;
+    {
+        float mx = 0.f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int ft = 0; ft < NT; ++ft) mx = fmaxf(mx, fabsf(am[j][i][ft]));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        const int ex = (int)((__float_as_uint(mx) >> 23) & 0xffu);
+        const int se = 127 + 13 - (ex - 127);
+        const bool ok = ex != 0 && ex != 255 && se >= 1 && se <= 253;
+        const float m_sc = ok ? __uint_as_float((unsigned)se << 23) : 1.0f;
+        m_inv = (ok ? __uint_as_float((unsigned)(254 - se) << 23) : 1.0f) * (1.0f / 8192.0f);
+#pragma unroll
+        for (int ft = 0; ft < NT; ++ft) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = am[e >> 2][e & 3][ft] * m_sc;
+                const _Float16 h = (_Float16)v;
+                a8[ft][0][e] = h; a8[ft][1][e] = (_Float16)(v - (float)h);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = am[2][e][ft] * m_sc;
+                const _Float16 h = (_Float16)v;
+                a4[ft][0][e] = h; a4[ft][1][e] = (_Float16)(v - (float)h);
+            }
+        }
+    }
+#endif
     const long p_begin = (long)c * BCH2, p_end = min(TF, p_begin + BCH2);
     const float* Ub = U + (long)b * TF * E;
     const float* Yb = Y + (long)b * TF * S;
@@ -878,6 +923,39 @@ __global__ __launch_bounds__(256) void dpcl_bwd_u2_kernel(const float* __restric
         f32x4 acc[NT];
 #pragma unroll
         for (int ft = 0; ft < NT; ++ft) acc[ft] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#if AMS_DPCL_BWD_F16
+        {
+            dh8 z8[2];
+            dh4 z4[2];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float v = z[e >> 2][e & 3] * 8192.0f;
+                const _Float16 h = (_Float16)v;
+                z8[0][e] = h; z8[1][e] = (_Float16)(v - (float)h);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float v = z[2][e] * 8192.0f;
+                const _Float16 h = (_Float16)v;
+                z4[0][e] = h; z4[1][e] = (_Float16)(v - (float)h);
+            }
+            // the K = 16 chain in accumulators of its own (an accumulator handed from one MFMA shape to the other needs wait states:
+            // csrc/lstm_ring.hip); smallest terms first: lo.hi, hi.lo, hi.hi
+            f32x4 acc16[NT];
+#pragma unroll
+            for (int ft = 0; ft < NT; ++ft) acc16[ft] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+#pragma unroll
+            for (int pp = 0; pp < 3; ++pp)
+#pragma unroll
+                for (int ft = 0; ft < NT; ++ft) {
+                    acc[ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8[ft][PA[pp]], z8[PB[pp]], acc[ft], 0, 0, 0);
+                    acc16[ft] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4[ft][PA[pp]], z4[PB[pp]], acc16[ft], 0, 0, 0);
+                }
+#pragma unroll
+            for (int ft = 0; ft < NT; ++ft) acc[ft] = (acc[ft] + acc16[ft]) * m_inv;
+        }
+#else
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
 #pragma unroll
@@ -887,6 +965,7 @@ __global__ __launch_bounds__(256) void dpcl_bwd_u2_kernel(const float* __restric
                     if (AMS_DPCL_DBG & 1) acc[ft][i] += am[j][i][ft] * z[j][i];
                     else acc[ft] = __builtin_amdgcn_mfma_f32_16x16x4f32(am[j][i][ft], z[j][i], acc[ft], 0, 0, 0);
                 }
+#endif
         // acc[ft][r]: feature 16 ft + 4 slot + r of point e_lo -- the positions of the lane's own float4 number ft
         float dd[NT][4], dot = 0.f;
 #pragma unroll
