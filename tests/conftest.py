@@ -31,3 +31,20 @@ def _release_captured_graphs(request):
                 torch.cuda.synchronize()
         except ImportError:
             pass
+
+
+@pytest.fixture(autouse=True)
+def _seed_global_generators(request):
+    """Every test starts from global numpy / torch generator states derived from its own name: synthetic batches and initialisers drawn
+    from the global generators then do not depend on which tests ran before (a check that sits near its tolerance -- rounding noise on an
+    analytically zero gradient, say -- passed or failed with the ORDER of the selection: `-k dpcl` failed where the whole suite passed)."""
+    import zlib
+    import numpy as np
+    seed = zlib.crc32(request.node.nodeid.encode()) & 0x7fffffff
+    np.random.seed(seed)
+    try:
+        import torch
+        torch.manual_seed(seed)
+    except ImportError:
+        pass
+    yield
