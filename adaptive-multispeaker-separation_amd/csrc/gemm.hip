@@ -1905,12 +1905,15 @@ __global__ __launch_bounds__(256) void gather_filter_grad_kernel(const float* __
 // x a slice of the (r, t) pairs stages the part of the segment its taps need ONCE in LDS and every thread accumulates 4 taps x 16
 // filters in registers from it (8-byte LDS reads; a second copy of the segment shifted by one sample serves the odd shifts).
 constexpr int GF_TAPS = 256, GF_FILT = 64, GF_SEG = 1536;      // segment capacity: spread of the positions + 256 taps + 1
+constexpr int GF_QB = 4;                                        // (row, frame) pairs per round: wave w prepares pair w, ONE barrier triple
+                                                                // per four pairs (round 5: one pair per round was three barriers around 64
+                                                                // FMAs per thread -- 0.86 ms per launch at the path-B shape, latency-bound)
 __global__ __launch_bounds__(256) void gather_filter_grad_lds_kernel(const float* __restrict__ x, const float* __restrict__ v,
                                                                      const int32_t* __restrict__ pos, float* __restrict__ part, int R,
                                                                      int L, int W, int N, int T, int pl, int rdiv, long pairs_per_z) {
-    __shared__ __attribute__((aligned(16))) float seg0[GF_SEG + 8], seg1[GF_SEG + 8];
-    __shared__ float sv[GF_FILT];
-    __shared__ int ss[GF_FILT], smm[2];
+    __shared__ __attribute__((aligned(16))) float seg0[GF_QB][GF_SEG + 8], seg1[GF_QB][GF_SEG + 8];
+    __shared__ float sv[GF_QB][GF_FILT];
+    __shared__ int ss[GF_QB][GF_FILT], smm[GF_QB][2];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int k0 = blockIdx.x * GF_TAPS, n0 = blockIdx.y * GF_FILT;
     const long q_lo = (long)blockIdx.z * pairs_per_z, q_hi = min((long)R * T, q_lo + pairs_per_z);
@@ -1919,55 +1922,73 @@ __global__ __launch_bounds__(256) void gather_filter_grad_lds_kernel(const float
     for (int a = 0; a < 16; ++a)
 #pragma unroll
         for (int b = 0; b < 4; ++b) acc[a][b] = 0.f;
-    for (long q = q_lo; q < q_hi; ++q) {
-        const int r = (int)(q / T), t = (int)(q - (long)r * T);
-        if (tid < 64) {
-            const int n = n0 + tid;
-            const bool live = n < N;
+    for (long q0 = q_lo; q0 < q_hi; q0 += GF_QB) {
+        {   // wave w: positions and values of pair q0 + w for the workgroup's 64 filters, the spread of the positions
+            const long q = q0 + wave;
+            const bool pair = q < q_hi;
+            const int r = pair ? (int)(q / T) : 0, t = pair ? (int)(q - (long)r * T) : 0;
+            const int n = n0 + lane;
+            const bool live = pair && n < N;
             const int p = live ? pos[((long)(r / rdiv) * T + t) * N + n] : 0;
-            sv[tid] = live ? v[((long)r * T + t) * N + n] : 0.f;
+            sv[wave][lane] = live ? v[((long)r * T + t) * N + n] : 0.f;          // a missing pair contributes zeros
             int mn = live ? p : 0x7fffffff, mx = live ? p : -0x7fffffff;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) { mn = min(mn, __shfl_xor(mn, o, 64)); mx = max(mx, __shfl_xor(mx, o, 64)); }
-            ss[tid] = live ? p - mn : 0;
-            if (tid == 0) { smm[0] = mn; smm[1] = mx; }
+            if (mn > mx) { mn = 0; mx = 0; }
+            ss[wave][lane] = live ? p - mn : 0;
+            if (lane == 0) { smm[wave][0] = mn; smm[wave][1] = mx; }
         }
         __syncthreads();
-        const int mn = smm[0], span = smm[1] - mn;                 // workgroup-uniform
-        const float* xr = x + (long)r * L;
-        if (span + GF_TAPS + 1 <= GF_SEG) {
-            const int base = mn - pl + k0, len = span + GF_TAPS + 1;
-            for (int i = tid; i < len; i += 256) {
-                const int pp = base + i;
-                const float val = (pp >= 0 && pp < L) ? xr[pp] : 0.f;
-                seg0[i] = val;
-                if (i > 0) seg1[i - 1] = val;                      // seg1[i] = seg0[i + 1]
+        bool staged[GF_QB];
+#pragma unroll
+        for (int j = 0; j < GF_QB; ++j) {
+            const long q = min(q0 + j, q_hi - 1);
+            const int r = (int)(q / T);
+            const int mn = smm[j][0], span = smm[j][1] - mn;          // workgroup-uniform
+            const float* xr = x + (long)r * L;
+            staged[j] = span + GF_TAPS + 1 <= GF_SEG;
+            if (staged[j]) {
+                const int base = mn - pl + k0, len = span + GF_TAPS + 1;
+                for (int i = tid; i < len; i += 256) {
+                    const int pp = base + i;
+                    const float val = (pp >= 0 && pp < L) ? xr[pp] : 0.f;
+                    seg0[j][i] = val;
+                    if (i > 0) seg1[j][i - 1] = val;                  // seg1[i] = seg0[i + 1]
+                }
             }
-            __syncthreads();
+        }
+        __syncthreads();
 #pragma unroll
-            for (int nn = 0; nn < 16; ++nn) {
-                const int f = wave * 16 + nn;
-                const int sh = ss[f];
-                const float vv = sv[f];
-                // taps 2 lane, 2 lane + 1 and + 128: seg[sh + kk], seg[sh + kk + 1] as ONE 8-byte read (even index into seg0, or seg1 shifted)
-                const float* sb = (sh & 1) ? (seg1 + (sh - 1)) : (seg0 + sh);
-                const float2 a = *reinterpret_cast<const float2*>(sb + 2 * lane);
-                const float2 b = *reinterpret_cast<const float2*>(sb + 2 * lane + 128);
-                acc[nn][0] = fmaf(vv, a.x, acc[nn][0]);
-                acc[nn][1] = fmaf(vv, a.y, acc[nn][1]);
-                acc[nn][2] = fmaf(vv, b.x, acc[nn][2]);
-                acc[nn][3] = fmaf(vv, b.y, acc[nn][3]);
-            }
-        } else {                                                  // positions spread wider than the staging buffer: direct reads
+        for (int j = 0; j < GF_QB; ++j) {
+            if (staged[j]) {
 #pragma unroll
-            for (int nn = 0; nn < 16; ++nn) {
-                const int f = wave * 16 + nn;
-                const int p0 = mn + ss[f] - pl + k0;
-                const float vv = sv[f];
+                for (int nn = 0; nn < 16; ++nn) {
+                    const int f = wave * 16 + nn;
+                    const int sh = ss[j][f];
+                    const float vv = sv[j][f];
+                    // taps 2 lane, 2 lane + 1 and + 128: seg[sh + kk], seg[sh + kk + 1] as ONE 8-byte read (even index into seg0, or seg1 shifted)
+                    const float* sb = (sh & 1) ? (seg1[j] + (sh - 1)) : (seg0[j] + sh);
+                    const float2 a = *reinterpret_cast<const float2*>(sb + 2 * lane);
+                    const float2 b = *reinterpret_cast<const float2*>(sb + 2 * lane + 128);
+                    acc[nn][0] = fmaf(vv, a.x, acc[nn][0]);
+                    acc[nn][1] = fmaf(vv, a.y, acc[nn][1]);
+                    acc[nn][2] = fmaf(vv, b.x, acc[nn][2]);
+                    acc[nn][3] = fmaf(vv, b.y, acc[nn][3]);
+                }
+            } else {                                              // positions spread wider than the staging buffer: direct reads
+                const long q = min(q0 + j, q_hi - 1);
+                const float* xr = x + (long)(q / T) * L;
+                const int mn = smm[j][0];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const int pp = p0 + 2 * lane + (j & 1) + 128 * (j >> 1);
-                    acc[nn][j] = fmaf(vv, (pp >= 0 && pp < L) ? xr[pp] : 0.f, acc[nn][j]);
+                for (int nn = 0; nn < 16; ++nn) {
+                    const int f = wave * 16 + nn;
+                    const int p0 = mn + ss[j][f] - pl + k0;
+                    const float vv = sv[j][f];
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj) {
+                        const int pp = p0 + 2 * lane + (jj & 1) + 128 * (jj >> 1);
+                        acc[nn][jj] = fmaf(vv, (pp >= 0 && pp < L) ? xr[pp] : 0.f, acc[nn][jj]);
+                    }
                 }
             }
         }
