@@ -247,14 +247,15 @@ __device__ __forceinline__ void store_tile(const GemmArgs& g, const f32x16 (&acc
         }
 }
 
-// Fused max-pool partial, shared by the f32 and the bf16x6 kernel (2 x 2 waves of 64 x 64):
+// Fused max-pool partial, shared by the f32 and the bf16x6 kernel (2 x WNC waves of 64 x 64: WNC = 2, or 4 for the 128 x 256 tile):
+template <int WNC = 2>
 __device__ __forceinline__ void maxpool_epilogue(const GemmArgs& g, const f32x16 (&acc)[2][2], float* smem, int tile_m, int m0, int n0,
                                                  int wm, int wn, int l31, int lk) {
         // Fused max-pool partial (reference models/adapt.py:115-117: stride-1 conv + max_pool_with_argmax): the [Bt,L,N]
         // conv output is never written; each 128-row tile emits, per column, its maximum and the row that holds it
         // (first maximum wins ties).  A second small kernel combines tiles into pooling windows.
-        float* sred = smem;                                     // [2 wn][2 j][32] values then rows
-        int* srow = reinterpret_cast<int*>(smem + 128);
+        float* sred = smem;                                     // [WNC wn][2 j][32] values then rows
+        int* srow = reinterpret_cast<int*>(smem + WNC * 64);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             float best = -3.4e38f;
@@ -1146,7 +1147,7 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
             }
         }
         if constexpr (EPI == EPI_MAXPOOL) {             // stride-1 conv + max_pool_with_argmax (models/adapt.py:115-117), 128 x 128 tile only
-            static_assert(CFG == 0, "the max-pool epilogue is written for 2 x 2 waves of 64 x 64");
+            static_assert(CFG == 0 || CFG == 3, "the max-pool epilogue is written for 2 x WNC waves of 64 x 64");
             if constexpr (F16) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
@@ -1154,7 +1155,7 @@ __device__ __forceinline__ void x6_body(const GemmArgs& g0, unsigned char* const
                     for (int j = 0; j < TN; ++j) acc[i][j] *= sc_inv;
             }
             __syncthreads();                            // every wave is done with the LDS images
-            maxpool_epilogue(g, acc, reinterpret_cast<float*>(smem), tile_m, m0, n0, wm, wn, l31, lk);
+            maxpool_epilogue<C::WNC>(g, acc, reinterpret_cast<float*>(smem), tile_m, m0, n0, wm, wn, l31, lk);
             return;                                     // (launched with one workgroup per item)
         }
         X6_STAMP(3);
@@ -2185,6 +2186,12 @@ ams_status ams_front_maxpool_fwd(const float* x, const float* f, float* y, long 
                 g.k_per_split = ceil_div(W, X6_BK) * X6_BK;
                 if (mp_aa && mp_ab && tuning().f16x3) {
                     g.amax_a = mp_aa; g.amax_b = mp_ab;
+                    // N a multiple of 256: the 128 x 256 tile (8 waves) -- every frame sample is split and staged once per 256 filters
+                    // instead of once per 128, and that stage, not the MFMAs, is what this kernel spends its time on (AMS_MAXPOOL_CFG=0: 128 x 128)
+                    static const bool wide = [] { const char* e = getenv("AMS_MAXPOOL_CFG"); return !(e && e[0] == '0'); }();
+                    if (wide && N % 256 == 0)
+                        hipLaunchKernelGGL((gemm_x6_kernel<A_FRAMES, B_ROW, 3, EPI_MAXPOOL, true, true>), dim3(tiles_m * (N / 256), 1), dim3(512), 0, st, g);
+                    else
                     hipLaunchKernelGGL((gemm_x6_kernel<A_FRAMES, B_ROW, 0, EPI_MAXPOOL, true, true>), grid, dim3(256), 0, st, g);
                 } else
                 hipLaunchKernelGGL((gemm_x6_kernel<A_FRAMES, B_ROW, 0, EPI_MAXPOOL, true>), grid, dim3(256), 0, st, g);
