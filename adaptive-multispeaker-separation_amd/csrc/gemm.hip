@@ -1372,7 +1372,7 @@ inline TilePlan f32_plan() { return {BM, BN, BK, 1.024, false}; }
 // bf16x6 tile configuration (X6Cfg) of an M x N output.  Default (rule 2): 128 x 256 (8 waves of 64 x 64) where it wastes under
 // 30 % of the columns it covers (AMS_GEMM_X6WASTE = 1.30; 1.10 until the fp16x3 products: with half the MFMAs per k-tile the
 // 8-wave tile wins even at N = 600 -> 768 -- LSTM dX 98 -> 87 us, dense dX 289 -> 277 us alone, the B = 64 step 3.14 -> 3.09 ms,
-// tools/cfg_sweep.sh + tools/ab_bench.sh), 128 x 128 otherwise -- both carry the second accumulator set (SEP) when they are not
+// tools/probes/cfg_sweep.sh + tools/probes/ab_bench.sh), 128 x 128 otherwise -- both carry the second accumulator set (SEP) when they are not
 // residency-capped.  Rule 1 (AMS_GEMM_X6RULE=1) adds the 256 x 256 tile (8 waves of 128 x 64) where both sides fit: +0.7 % on the
 // step (projections 107 vs 121 us), but no registers for SEP -- its outputs carry the bf16 MFMA's truncation bias (-0.3 .. -1 ulp
 // each, coherent: the LSTM bias gradients, sums over 5120 rows downstream of it, were 1.2e-5 off the oracle instead of < 1e-6), so

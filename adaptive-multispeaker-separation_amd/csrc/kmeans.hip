@@ -636,7 +636,7 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
     __shared__ int last_sh[TQ];
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 #ifdef AMS_KT_DBG
-    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();                    // placement / lifetime probe (tools/kt_probe.py)
+    const unsigned long long dbg_t0 = __builtin_amdgcn_s_memrealtime();                    // placement / lifetime probe (tools/probes/kt_probe.py)
 #endif
     // workgroup -> (utterance, try group, column, chunk), the chunk slowest: a short last chunk's workgroups come last
     int id = blockIdx.x;

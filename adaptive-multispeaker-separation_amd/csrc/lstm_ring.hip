@@ -7,7 +7,7 @@
 //
 // Placement.  Workgroup ids are dealt round-robin to the 8 XCDs (id % 8; observed, not promised), so chain c takes ids = c mod 8:
 // B = 64 gives exactly 8 chains, one per XCD, and every hand-off of a chain goes through ONE L2.  That is what makes the exchange
-// cheap (tools/xcd_exchange_bench.hip, 25 workgroups per chain, all 8 chains live):
+// cheap (tools/probes/xcd_exchange_bench.hip, 25 workgroups per chain, all 8 chains live):
 //     plain 16-byte stores + L1-bypassing (sc1) loads through the shared L2 ....... 1.5 us per step, one hop ~500 cycles
 //     write-through (sc1) stores + sc1 loads, placement independent ................. 3.8 us per step
 //     plain stores + agent release fence + flag (the generic recipe) ................. 4.9 us per step

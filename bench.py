@@ -378,8 +378,8 @@ def main():
                                for t, v in alone['by_tag'].items() if v['launches']},
                 'ceiling_note': ('the MFMA-only instruction stream of this kernel (split, LDS and fetch compiled out) runs the 4096^3 product in '
                                  '379 us = 362 TFLOP/s f32-equivalent at 2400 MHz / 1050 W; the whole kernel draws 1385-1393 W, i.e. the board '
-                                 'power limit, at 2135 MHz (tools/clock_probe.sh, DESIGN.md 4)') if x6 else
-                                ('tools/mfma_peak.hip on the same boxes: dependent-free v_mfma_f32_32x32x2_f32 streams reach 152-156 TFLOP/s '
+                                 'power limit, at 2135 MHz (tools/probes/clock_probe.sh, DESIGN.md 4)') if x6 else
+                                ('tools/probes/mfma_peak.hip on the same boxes: dependent-free v_mfma_f32_32x32x2_f32 streams reach 152-156 TFLOP/s '
                                  'for ~100 us and settle at ~125 TFLOP/s when sustained (power management), DESIGN.md 4')}
         for tag in ops.PROFILE.tags():
             if not tag.startswith('gemm'):

@@ -14,6 +14,21 @@
  *     the product arithmetic (ams_gemm_set_arith, a test / A-B switch; default from AMS_GEMM_X6, read once); a once-per-process cache of
  *     device properties and of the AMS_* tuning environment.  Operand bounds (fp16x3) and the residency cap of a product are ARGUMENTS
  *     of the entry points, not state (ABI 2; ABI 1 had thread-local one-shot setters for both); so is the stream-K scratch (ABI 3).
+ *
+ * Environment read by the library -- the COMPLETE list (tests/test_abi.py greps csrc/ for getenv and holds this block to it).  Every
+ * variable is read ONCE per process (function-local static), never on the launch path, selects between code paths that the tests hold
+ * to the same oracle, and exists for A/B measurements and fault-injection tests; a deployment sets none of them.
+ *   products (csrc/gemm.hip)   AMS_GEMM_X6 (initial value of ams_gemm_set_arith: 0 = native f32 MFMA), AMS_GEMM_F16X3 (0 = ignore operand
+ *                              bounds: bf16x6), AMS_GEMM_SK (stream-K 0/1/2), AMS_GEMM_CVEC (0 = dword epilogue stores), AMS_GEMM_X6CFG,
+ *                              AMS_GEMM_X6RULE, AMS_GEMM_X6WASTE (tile choice), AMS_X6_PERSIST (0 = one tile per workgroup),
+ *                              AMS_GEMM_SPLITS, AMS_GEMM_GROUP_M (split-K / band height overrides), AMS_GEMM_NOVEC (force the dword-fetch
+ *                              f32 kernel), AMS_GEMM_NOPRIO, AMS_MAXPOOL_CFG (0 = 128x128 tile for the fused conv + max-pool),
+ *                              AMS_GATHER_LDS (0 = register form of ams_gather_filter_grad)
+ *   recurrence (lstm*.hip)     AMS_LSTM_RING_X6, AMS_LSTM_RING_F16, AMS_LSTM_RING_BWD_F16 (arithmetic of the rings' recurrent products),
+ *                              AMS_LSTM_RING_SAFE (write-through hand-off), AMS_LSTM_RING_CUS (pretend a smaller device: fallback tests),
+ *                              AMS_LSTM_XCD, AMS_LSTM_FWD_PIPE (per-step fallback kernels: grid order, fetch pipelining)
+ *   losses / k-means           AMS_DPCL_LDS (1 = LDS-staged DPCL passes),
+ *                              AMS_KM_TRIES (0 = one workgroup per try), AMS_KM_SOFT (0 = soft accumulation inside kmeans_pass_kernel)
  */
 #ifndef AMS_H
 #define AMS_H

@@ -36,6 +36,22 @@ def test_library_exports_nothing_the_header_does_not_declare():
     assert exported == declared, (sorted(exported - declared), sorted(declared - exported))
 
 
+def test_header_lists_every_environment_variable_the_library_reads():
+    """State behind the ABI: the library's only process-wide inputs besides ams_gemm_set_arith are AMS_* variables read
+    once; include/ams.h lists them all, and lists none the sources no longer read."""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    read = set()
+    for f in glob.glob(os.path.join(root, 'adaptive-multispeaker-separation_amd', 'csrc', '*.hip')) + \
+            glob.glob(os.path.join(root, 'adaptive-multispeaker-separation_amd', 'csrc', '*.h')):
+        read |= set(re.findall(r'getenv\("(AMS_[A-Z0-9_]+)"\)', open(f).read()))
+    head = open(os.path.join(root, 'include', 'ams.h')).read()
+    block = head[head.index('Environment read by the library'):head.index('#ifndef AMS_H')]
+    listed = set(re.findall(r'\bAMS_[A-Z0-9_]+\b', block))
+    assert read == listed, (sorted(read - listed), sorted(listed - read))
+
+
 def test_ops_refuse_cpu_tensors():
     torch = pytest.importorskip('torch')
     from ams_hip import ops, AmsError

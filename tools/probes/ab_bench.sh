@@ -1,6 +1,6 @@
 #!/bin/bash
 # A/B of the default bench under environment variants, interleaved (boxes and processes differ by a few %):
-#   tools/ab_bench.sh 2 "AMS_RING_ARENA=0" "" "AMS_GEMM_X6WASTE=1.3"      -> gpurun_out/ab_bench.txt
+#   tools/probes/ab_bench.sh 2 "AMS_RING_ARENA=0" "" "AMS_GEMM_X6WASTE=1.3"      -> gpurun_out/ab_bench.txt
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/ab_bench.txt
 rounds=$1; shift

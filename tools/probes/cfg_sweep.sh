@@ -1,6 +1,6 @@
 #!/bin/bash
 # fp16x3 products of the step alone under each tile configuration (AMS_GEMM_X6CFG 0 = 128x128, 3 = 128x256, unset = the rule),
-# uncapped and with the side-stream pad; optional forced split-K counts ("SPLITS=2,4 tools/cfg_sweep.sh").  -> gpurun_out/cfg_sweep.txt
+# uncapped and with the side-stream pad; optional forced split-K counts ("SPLITS=2,4 tools/probes/cfg_sweep.sh").  -> gpurun_out/cfg_sweep.txt
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/cfg_sweep.txt
 : > $O

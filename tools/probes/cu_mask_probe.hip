@@ -1,5 +1,5 @@
 // Which CU does bit b of a hipExtStreamCreateWithCUMask mask select, and does a mask survive hipGraph capture + replay?
-//   hipcc --offload-arch=gfx950 -O2 -o /tmp/cu_mask_probe tools/cu_mask_probe.hip && /tmp/cu_mask_probe
+//   hipcc --offload-arch=gfx950 -O2 -o /tmp/cu_mask_probe tools/probes/cu_mask_probe.hip && /tmp/cu_mask_probe
 // Output: one line per mask bit (xcc, se, sh, cu as the wave itself reads them from HW_REG_XCC_ID / HW_REG_HW_ID), then the number
 // of distinct CUs a 2048-workgroup launch touched (a) directly on a masked stream, (b) replayed from a graph captured on that stream.
 #include <hip/hip_runtime.h>

@@ -1,4 +1,4 @@
-# k-means pass A/B over variant libraries: tools/km_ab.sh "" ktpad ...   ("" = the shipped library)
+# k-means pass A/B over variant libraries: tools/probes/km_ab.sh "" ktpad ...   ("" = the shipped library)
 R=$PWD; P=$PWD/adaptive-multispeaker-separation_amd/ams_hip
 mkdir -p gpurun_out; : > gpurun_out/km_ab.txt
 cd /tmp && export TMPDIR=/tmp

@@ -1,7 +1,7 @@
 """Hard k-means (10 tries x 10 iterations, b = 64, L = 20480, E = 40) with and without silence weights: ms per run.
-   python tools/km_w_bench.py      (AMS_KM_TRIES=0: one workgroup per try)"""
+   python tools/probes/km_w_bench.py      (AMS_KM_TRIES=0: one workgroup per try)"""
 import os, sys, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'adaptive-multispeaker-separation_amd')]
 from ams_hip import ops
 b, L, E, tries = 64, 20480, 40, 10

@@ -1,4 +1,4 @@
-# soft k-means passes in the fine-tuning config, per variant library:  tools/ks_ab.sh base ks1024 ...
+# soft k-means passes in the fine-tuning config, per variant library:  tools/probes/ks_ab.sh base ks1024 ...
 R=$PWD; P=$PWD/adaptive-multispeaker-separation_amd/ams_hip
 cd /tmp && export TMPDIR=/tmp
 for v in "$@"; do

@@ -1,7 +1,7 @@
 """Where and when the workgroups of kmeans_hard_tries_kernel ran (AMS_KT_DBG build): per CU the number of workgroups resident at once."""
 import ctypes, os, sys, collections
 import numpy as np, torch
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'adaptive-multispeaker-separation_amd'))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..', 'adaptive-multispeaker-separation_amd'))
 os.environ['AMS_HIP_LIB'] = os.path.abspath(sys.argv[1])
 from ams_hip import ops
 from ams_hip._lib import load

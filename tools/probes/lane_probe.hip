@@ -1,4 +1,4 @@
-// What do v_permlane32_swap / v_permlane16_swap / row_shl DPP deliver to each lane?  (gfx950; hipcc tools/lane_probe.hip -o /tmp/lp && /tmp/lp)
+// What do v_permlane32_swap / v_permlane16_swap / row_shl DPP deliver to each lane?  (gfx950; hipcc tools/probes/lane_probe.hip -o /tmp/lp && /tmp/lp)
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __global__ void k(unsigned* o) {

@@ -1,5 +1,5 @@
 // Sustained fp32 MFMA ceiling of the box the bench runs on: v_mfma_f32_32x32x2_f32 only, no memory traffic.
-//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_peak tools/mfma_peak.hip && /tmp/mfma_peak
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_peak tools/probes/mfma_peak.hip && /tmp/mfma_peak
 #include <hip/hip_runtime.h>
 #include <cstdio>
 typedef float f32x16 __attribute__((ext_vector_type(16)));

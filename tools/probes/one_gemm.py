@@ -1,7 +1,7 @@
-"""One product shape, a few launches (for counter sweeps): python tools/one_gemm.py M,N,K,tA,tB [n]"""
+"""One product shape, a few launches (for counter sweeps): python tools/probes/one_gemm.py M,N,K,tA,tB [n]"""
 import os
 import sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for _p in (ROOT, os.path.join(ROOT, 'adaptive-multispeaker-separation_amd')):
     sys.path.insert(0, _p)
 import torch                        # noqa: E402

@@ -1,13 +1,13 @@
 """Does the HBM-bound DPCL loss chain of one half of the batch hide behind the MFMA-bound dense products of the other half?
 Times, at the B = 64 step's shapes: dense fwd (rows of 26 utterances), dense dX (rows of 38), the fused l2norm + DPCL forward and
-backward (38 / 26 utterances), each alone and the pairs side by side on two streams.   python tools/overlap_probe.py"""
+backward (38 / 26 utterances), each alone and the pairs side by side on two streams.   python tools/probes/overlap_probe.py"""
 import os
 import sys
 
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, 'adaptive-multispeaker-separation_amd')]
 from ams_hip import ops  # noqa: E402
 

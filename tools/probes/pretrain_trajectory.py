@@ -2,7 +2,7 @@
 Answers VERDICT r01: `pretraining_A_graph` reported cost 2.38e7 vs 3.9e3 eager after a different number of steps -- replay bug or
 an SDR-term blow-up of the recipe itself (lr 1e-3 AMSGrad on `mix * (non_mix / mix)` masks + sdr loss)?
 
-    python tools/pretrain_trajectory.py [--steps 20]  ->  one JSON line per mode with the whole trajectory
+    python tools/probes/pretrain_trajectory.py [--steps 20]  ->  one JSON line per mode with the whole trajectory
 """
 import argparse
 import contextlib
@@ -11,7 +11,7 @@ import os
 import sys
 import tempfile
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for _p in (ROOT, os.path.join(ROOT, 'adaptive-multispeaker-separation_amd'), os.path.join(ROOT, 'tools')):
     if _p not in sys.path:
         sys.path.insert(0, _p)

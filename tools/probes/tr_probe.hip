@@ -1,6 +1,6 @@
 // Probe: semantics of ds_read_b64_tr_b16 on gfx950.  LDS holds u16 element e at byte 2e (value = e).  Every lane supplies its own
 // 8-byte-aligned address; the result (4 x u16 per lane) is printed so that the lane <-> (source lane, element) permutation can be read off.
-//   hipcc --offload-arch=gfx950 -O2 tools/tr_probe.hip -o /tmp/tr_probe && /tmp/tr_probe
+//   hipcc --offload-arch=gfx950 -O2 tools/probes/tr_probe.hip -o /tmp/tr_probe && /tmp/tr_probe
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>

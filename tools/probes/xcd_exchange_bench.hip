@@ -1,7 +1,7 @@
 // Micro-benchmark behind the persistent BLSTM recurrence: what does one step of an in-launch ring cost when the
 // NW workgroups of a chain sit on ONE XCD and hand a [16 x H] fp32 state to each other through that XCD's L2?
 //
-//   hipcc --offload-arch=gfx950 -O3 -o /tmp/xcd_exchange_bench tools/xcd_exchange_bench.hip && /tmp/xcd_exchange_bench
+//   hipcc --offload-arch=gfx950 -O3 -o /tmp/xcd_exchange_bench tools/probes/xcd_exchange_bench.hip && /tmp/xcd_exchange_bench
 //
 // Each chain = NW workgroups (blockIdx % 8 = chain -> observed XCD = chain).  Step s: wait until every producer of the chain has
 // published step s-1, read the whole [16 x H] row block (16-byte L1-bypassing loads), run NMFMA dependent-free v_mfma_f32_16x16x4
