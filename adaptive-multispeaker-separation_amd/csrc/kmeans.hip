@@ -9,9 +9,8 @@
 // share ONE summation order: 8192-point chunks; lane j (0..255) adds its 32 points j, j+256, .. sequentially; each wavefront
 // (64 consecutive lanes) combines its lanes by a halving tree v[j] += v[j+s], s = 32..1; the wavefront totals are added sequentially
 // in (chunk, wavefront) order.  (The SOFT modes, which are tolerance-checked, keep 2048-point chunks and one 256-lane tree: their
-// 64 rows would not fill the device with 8192-point workgroups.)  HARD distances are ONE
-// fused chain over e, d <- fma((x_e - c_e) w, x_e - c_e, d) (round 5: oracle/kmeans.py sqdist_fused, fma32); everything else
-// (soft distances, normalisation, inertia) accumulates left-to-right with separate multiply and add (no contraction), sqrt is IEEE,
+// 64 rows would not fill the device with 8192-point workgroups.)  Everything that is compared bit for bit
+// (hard distances, normalisation, inertia) accumulates left-to-right with separate, individually rounded multiply and add (no contraction), sqrt is IEEE,
 // ties pick the lowest cluster (tf.argmin).
 //
 // Algorithmic bytes per pass: L*E*4 per row (+ L*4 weights); x[b] is shared by the `tries` rows of an utterance
@@ -229,10 +228,11 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL || MOD
                     d2[c] = HAS_W ? (dk.x + dk.y) * wv : (dk.x + dk.y);
                 }
             } else {
-                // d2[c] = fused chain over e of ((x_e - c_e) w) (x_e - c_e)  (Kmeans_2.py:175-181 restated as ONE FMA chain per cluster:
-                // oracle/kmeans.py sqdist_fused).  Two clusters share a packed register: per e ONE v_pk_add (x_e - {c0_e, c1_e}), ONE
-                // v_pk_fma (+ one v_pk_mul with weights) for both -- 80 packed instructions per point at E = 40, C = 2, where separate
-                // multiply and add were 160 plus the pinning of the add chains.  The pair's chain IS the serial order; nothing to pin.
+                // d2[c] = sum over e, left to right, of (x_e - c_e)^2 w with the square ROUNDED before it is weighted and added
+                // (Kmeans_2.py:187: tf.square, the multiply by notsilent and reduce_sum are three ops; oracle/kmeans.py sqdist).  Two
+                // clusters share a packed register: per e one v_pk_add (x_e - {c0_e, c1_e}), one v_pk_mul, (one more with weights,) one
+                // v_pk_add for both -- 120 packed instructions per point at E = 40, C = 2.  (Round 5 ran this as ONE v_pk_fma chain, 80
+                // instructions; that is not an evaluation of the reference's graph -- tests/test_kmeans_distance_forms.py -- and went.)
                 auto dist = [&](auto WT) {
                     constexpr bool W = decltype(WT)::value;
                     constexpr int CP = (C_ + 1) / 2;
@@ -269,7 +269,8 @@ __global__ __launch_bounds__(256, (MODE == HARD_ACC || MODE == HARD_FINAL || MOD
                                 const f2 cc = {scent[c0 * E_ + 4 * q4 + k], scent[c1 * E_ + 4 * q4 + k]};
 #endif
                                 const f2 df = xx - cc;
-                                dp[cp] = __builtin_elementwise_fma(W ? df * wv2 : df, df, dp[cp]);
+                                const f2 sq = df * df;                           // rounded on its own (contraction is off in this unit)
+                                dp[cp] = dp[cp] + (W ? sq * wv2 : sq);
                             }
                         }
                     }
@@ -553,7 +554,7 @@ __global__ void kmeans_reduce_kernel(const float* __restrict__ part, float* __re
 // (profiles/r05_i_cfg_*: 205-210 us per pass).  Here a workgroup of TEN waves owns one 64-lane column of a chunk (the unit of the
 // summation order, see the top of the file) for TQ = 5 tries, and every wave has two roles per iteration of two 64-point slabs:
 //   labels   wave (try tt = wave % 5, slab k = wave / 5): lane = point, the point's 40 values from LDS, the try's centroids in SGPRs
-//            for the whole launch, the fused distance chains of kmeans_pass_kernel, argmin -> ONE 64-bit ballot per (slab, try) in LDS;
+//            for the whole launch, the packed distance chains of kmeans_pass_kernel, argmin -> ONE 64-bit ballot per (slab, try) in LDS;
 //   sums     wave q owns components 4q .. 4q+3: its float4 of the point stays in registers and is accumulated into 5 tries x 2
 //            clusters x 4 running sums (40 registers instead of 82) under the ballots of the previous iteration, as v_pk_fma with a
 //            0/1 factor exactly like kmeans_pass_kernel; wave q < 5 also keeps try q's two counts.
@@ -573,20 +574,18 @@ struct KtArgs {
 };
 
 // one component of the packed distance chains: df = {x - c0, x - c1} with x broadcast from the low (KT_LO) or high (KT_HI) half of a
-// register pair and {c0, c1} a scalar pair; d <- fma(df, df, d); KT_DIST2 also q <- q + df * df (two roundings: the inertia distance)
+// register pair and {c0, c1} a scalar pair; sq = df * df ROUNDED (tf.square is an op of its own, Kmeans_2.py:187); d <- d + sq
 #define KT_LO "op_sel_hi:[0,1]"
 #define KT_HI "op_sel:[1,0] op_sel_hi:[1,1]"
-#define KT_DIST(D, X, SEL, C) do { f2 df_; asm("v_pk_add_f32 %1, %2, %3 " SEL " neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_fma_f32 %0, %1, %1, %0" \
-                                              : "+v"(D), "=&v"(df_) : "v"(X), "s"(C)); } while (0)
-#define KT_DIST2(D, Q, X, SEL, C) do { f2 df_; asm("v_pk_add_f32 %2, %3, %4 " SEL " neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_fma_f32 %0, %2, %2, %0\n\t" \
-                                                  "v_pk_mul_f32 %2, %2, %2\n\tv_pk_add_f32 %1, %1, %2" : "+v"(D), "+v"(Q), "=&v"(df_) : "v"(X), "s"(C)); } while (0)
+#define KT_DIST(D, X, SEL, C) do { f2 df_; asm("v_pk_add_f32 %1, %2, %3 " SEL " neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_mul_f32 %1, %1, %1\n\t" \
+                                              "v_pk_add_f32 %0, %0, %1" : "+v"(D), "=&v"(df_) : "v"(X), "s"(C)); } while (0)
 
-// the same with silence weights: d <- fma(df * w, df, d) (w = {w, w}: the weighted difference is rounded, as in kmeans_pass_kernel)
-#define KT_DISTW(D, X, SEL, C, W) do { f2 df_, dw_; asm("v_pk_add_f32 %1, %3, %4 " SEL " neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_mul_f32 %2, %1, %5\n\t" \
-                                                       "v_pk_fma_f32 %0, %2, %1, %0" : "+v"(D), "=&v"(df_), "=&v"(dw_) : "v"(X), "s"(C), "v"(W)); } while (0)
-#define KT_DIST2W(D, Q, X, SEL, C, W) do { f2 df_, dw_; asm("v_pk_add_f32 %2, %4, %5 " SEL " neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_mul_f32 %3, %2, %6\n\t" \
-                                                           "v_pk_fma_f32 %0, %3, %2, %0\n\tv_pk_mul_f32 %2, %2, %2\n\tv_pk_add_f32 %1, %1, %2" \
-                                                           : "+v"(D), "+v"(Q), "=&v"(df_), "=&v"(dw_) : "v"(X), "s"(C), "v"(W)); } while (0)
+// the same with silence weights: d <- d + (df * df) * w (w = {w, w}); KT_DIST2W also q <- q + df * df, the unweighted inertia distance
+#define KT_DISTW(D, X, SEL, C, W) do { f2 df_; asm("v_pk_add_f32 %1, %2, %3 " SEL " neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_mul_f32 %1, %1, %1\n\t" \
+                                                  "v_pk_mul_f32 %1, %1, %4\n\tv_pk_add_f32 %0, %0, %1" : "+v"(D), "=&v"(df_) : "v"(X), "s"(C), "v"(W)); } while (0)
+#define KT_DIST2W(D, Q, X, SEL, C, W) do { f2 df_; asm("v_pk_add_f32 %2, %3, %4 " SEL " neg_lo:[0,1] neg_hi:[0,1]\n\tv_pk_mul_f32 %2, %2, %2\n\t" \
+                                                      "v_pk_add_f32 %1, %1, %2\n\tv_pk_mul_f32 %2, %2, %5\n\tv_pk_add_f32 %0, %0, %2" \
+                                                      : "+v"(D), "+v"(Q), "=&v"(df_) : "v"(X), "s"(C), "v"(W)); } while (0)
 
 __device__ __forceinline__ float mask_to_float(unsigned long long m) {       // 1.0f in the lanes whose bit of the (wave-uniform) mask is set
     float f;
@@ -751,7 +750,7 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
         }
         __builtin_amdgcn_sched_barrier(0);                          // sums and labels are independent streams: interleaved they need both register sets
         if (it < nit) {
-            // ---- labels of (slab kk, try tt): fused chains d <- fma(x_e - c_e, x_e - c_e, d), both clusters in one packed register
+            // ---- labels of (slab kk, try tt): d <- d + round((x_e - c_e)^2), both clusters in one packed register
             const float wv = w_nxt;
             const f2 wv2 = {wv, wv};
             if constexpr (HAS_W)                                    // (clamped inside the chunk's slabs: past them nothing is consumed)
@@ -766,7 +765,7 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
                 asm volatile("" : "+v"(dp));
                 if (q4 + 1 < V4) vd[(q4 + 1) & 1] = *reinterpret_cast<const float4*>(q4 + 1 < V4 - 1 ? xrow + (q4 + 1) * 4 : &xbuf[bcur][off_lab9]);
                 const float4 v = vd[q4 & 1];
-                // d <- fma(x_e - c, x_e - c, d) for both clusters: the point's value broadcast by op_sel from its place in the float4 (left to
+                // one component of both clusters' chains: the point's value broadcast by op_sel from its place in the float4 (left to
                 // the compiler, every second broadcast was a v_mov), the centroid pair a scalar operand
                 const f2 xlo = {v.x, v.y}, xhi = {v.z, v.w};
                 if constexpr (HAS_W) {
@@ -869,7 +868,7 @@ __global__ __launch_bounds__(640, AMS_KT_WAVES) void kmeans_hard_tries_kernel(Kt
 // read of the points.  No sums role: wave (try tt, kk) owns COLUMN 2 cp + kk of the chunk for all its slabs, so its lanes' running sums
 // tot_c += dist * [label == c] follow the summation order on their own; one slab of both columns (128 consecutive points) per iteration,
 // x double-buffered, one barrier.  dist = sum_e (x_e - c_e)^2 of the assigned centroid with separate multiply and add (oracle
-// inertia_hard), both clusters packed beside the fused label chain, which shares the differences.  Counts by popcount (integers).
+// inertia_hard), both clusters packed beside the (weighted) label chain, which shares the squares.  Counts by popcount (integers).
 template <bool HAS_W>
 __global__ __launch_bounds__(640, 6) void kmeans_hard_tries_final_kernel(KtArgs a) {
     constexpr int E_ = 40, C_ = 2, LD = E_, V4 = E_ / 4, SL = CHUNK_HARD / LANES, NVF = 2 * C_;
@@ -950,16 +949,17 @@ __global__ __launch_bounds__(640, 6) void kmeans_hard_tries_final_kernel(KtArgs 
             asm volatile("" : "+v"(dp), "+v"(dq));
             if (q4 + 1 < V4) vd[(q4 + 1) & 1] = *reinterpret_cast<const float4*>(q4 + 1 < V4 - 1 ? xrow + (q4 + 1) * 4 : &xbuf[cur][off_lab9]);
             const float4 v = vd[q4 & 1];
-            // label distance: fused chain (sqdist_fused); inertia distance: multiply, then add -- both from the same differences
+            // label distance (weighted) and inertia distance (not) from the same rounded squares; without weights they are one chain
             const f2 xlo = {v.x, v.y}, xhi = {v.z, v.w};
             if constexpr (HAS_W) {
                 KT_DIST2W(dp, dq, xlo, KT_LO, cpair[4 * q4 + 0], wv2); KT_DIST2W(dp, dq, xlo, KT_HI, cpair[4 * q4 + 1], wv2);
                 KT_DIST2W(dp, dq, xhi, KT_LO, cpair[4 * q4 + 2], wv2); KT_DIST2W(dp, dq, xhi, KT_HI, cpair[4 * q4 + 3], wv2);
             } else {
-                KT_DIST2(dp, dq, xlo, KT_LO, cpair[4 * q4 + 0]); KT_DIST2(dp, dq, xlo, KT_HI, cpair[4 * q4 + 1]);
-                KT_DIST2(dp, dq, xhi, KT_LO, cpair[4 * q4 + 2]); KT_DIST2(dp, dq, xhi, KT_HI, cpair[4 * q4 + 3]);
+                KT_DIST(dp, xlo, KT_LO, cpair[4 * q4 + 0]); KT_DIST(dp, xlo, KT_HI, cpair[4 * q4 + 1]);
+                KT_DIST(dp, xhi, KT_LO, cpair[4 * q4 + 2]); KT_DIST(dp, xhi, KT_HI, cpair[4 * q4 + 3]);
             }
         }
+        if constexpr (!HAS_W) dq = dp;
         const bool one = sqrtf(dp.y) < sqrtf(dp.x);
         const unsigned long long bal = __builtin_amdgcn_ballot_w64(one);
         const unsigned long long valid = valid_of(it);

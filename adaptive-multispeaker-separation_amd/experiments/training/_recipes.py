@@ -13,16 +13,16 @@ RECIPES = {
     'STFT_L41': ('STFT_Separator_Trainer', 'L41Model', 'STFT_L41', False, False, ('stft', 'separator'), None),
     'STFT_DPCL_enhance': ('STFT_Separator_enhance_Trainer', 'DPCL', 'STFT_DPCL_enhance', True, False, ('stft', 'separator', 'enhance_layer'), None),
     'STFT_L41_enhance': ('STFT_Separator_enhance_Trainer', 'L41Model', 'STFT_L41_enhance', True, False, ('stft', 'separator', 'enhance_layer'), None),
-    'STFT_DPCL_finetuning': ('STFT_Separator_FineTune_Trainer', 'DPCL', 'STFT_DPCL_finetuning', True, False, ('stft', 'separator', 'enhance_layer', 'finetuning'), None),
-    'STFT_L41_finetuning': ('STFT_Separator_FineTune_Trainer', 'L41Model', 'STFT_L41_finetuning', True, False, ('stft', 'separator', 'enhance_layer', 'finetuning'), None),
+    'STFT_DPCL_finetuning': ('STFT_Separator_FineTune_Trainer', 'DPCL', 'STFT_DPCL_finetuning', True, False, ('stft', 'finetuning', 'separator'), None),
+    'STFT_L41_finetuning': ('STFT_Separator_FineTune_Trainer', 'L41Model', 'STFT_L41_finetuning', True, False, ('stft', 'finetuning', 'separator'), None),
     'front_DPCL': ('Front_Separator_Trainer', 'DPCL', 'front_DPCL', True, True, ('separator',), False),
     'front_L41': ('Front_Separator_Trainer', 'L41Model', 'front_L41', True, True, ('separator',), False),
     'front_DPCL_enhance': ('Front_Separator_Enhance_Trainer', 'DPCL', 'front_DPCL_enhance', True, False, ('separator', 'enhance_layer'), False),
     'front_L41_enhance': ('Front_Separator_Enhance_Trainer', 'L41Model', 'front_L41_enhance', True, False, ('separator', 'enhance_layer'), False),
     'front_DPCL_finetuning': ('Front_Separator_Finetuning_Trainer', 'DPCL', 'front_L41_finetuning', True, False, ('adapt', 'separator'), False),
     'front_L41_finetuning': ('Front_Separator_Finetuning_Trainer', 'L41Model', 'front_L41_finetuning', True, False, ('adapt', 'separator'), False),
-    'front_DPCL_enhance_finetuning': ('Front_Separator_Enhance_Finetuning_Trainer', 'DPCL', 'front_DPCL_finetuning', True, False, ('adapt', 'separator', 'enhance_layer', 'finetuning'), False),
-    'front_L41_enhance_finetuning': ('Front_Separator_Enhance_Finetuning_Trainer', 'L41Model', 'front_L41_finetuning', True, False, ('adapt', 'separator', 'enhance_layer', 'finetuning'), False),
+    'front_DPCL_enhance_finetuning': ('Front_Separator_Enhance_Finetuning_Trainer', 'DPCL', 'front_DPCL_finetuning', True, False, ('adapt', 'separator', 'finetuning', 'enhance_layer'), False),
+    'front_L41_enhance_finetuning': ('Front_Separator_Enhance_Finetuning_Trainer', 'L41Model', 'front_L41_finetuning', True, False, ('adapt', 'separator', 'finetuning', 'enhance_layer'), False),
 }
 
 

@@ -26,12 +26,14 @@ wavefront) combines its lane partials by a halving tree (v[j] += v[j+s], s = 32.
 are added sequentially in (chunk, group) order.  (Rounds 1-4: chunks of 2048 and one 256-lane tree;
 round 5 moved the cross-wavefront part of the tree into the sequential tail so that a 64-lane column
 of a chunk is a unit of work that needs no other column -- csrc/kmeans.hip, kmeans_hard_tries_kernel.)
-HARD distances (round 5) are ONE fused chain over e, d <- fma((x_e - c_e) * w, x_e - c_e, d): TensorFlow's reduction order and
-contraction are unspecified, so a fused chain restates `sum((x - c)^2 * w)` as validly as separate multiplies and adds did, and it is
-half the vector instructions on the device (one packed subtract + one packed FMA per e for TWO clusters).  For 0/1 silence weights
-(x - c) * w is exact, so weighted and unweighted forms agree where w = 1.  `fma32` below is the correctly rounded float32 FMA
-(float64 product is exact; the float64 sum is rounded to odd before the final rounding, which removes the double rounding).
-The soft distances, the input normalisation and the inertia keep separate multiply and add.
+HARD distances: d = sum over e, left to right, of round(round((x_e - c_e)^2) * w) -- `sqdist`.  tf.square, the multiply by notsilent
+and reduce_sum are three ops of the TF-1.4 graph (Kmeans_2.py:187, no XLA): every square is rounded to float32 before it is weighted
+and added.  Only the ORDER of reduce_sum over e is the library's (Eigen packets on the CPU, a tree on the GPU) and is restated here as
+left to right.  Round 5 restated the chain as d <- fma((x_e - c_e) * w, x_e - c_e, d) (`sqdist_fused`, kept below with its correctly
+rounded `fma32` only for the record): that is NOT an evaluation of the reference's graph under any reduction order, and although the
+two forms give identical labels, centroids and best tries on the golden fixture and on the benchmark-shape inputs, they disagree on
+about one point-pass in 10^7 on structureless data (tests/test_kmeans_distance_forms.py measures both) -- so round 6 went back to
+rounded squares in the oracle and in csrc/kmeans.hip.
 """
 import numpy as np
 from .dense import L2_EPS
@@ -110,8 +112,11 @@ def sqdist(x, cent, w):
     return d
 
 
-def labels_hard(x, cent, w):
-    return np.argmin(np.sqrt(sqdist_fused(x, cent, w)), axis=1).astype(np.int32)
+HARD_DIST = sqdist                # the hard distance in force (module doc); tests/test_kmeans_distance_forms.py holds it there
+
+
+def labels_hard(x, cent, w, dist=None):
+    return np.argmin(np.sqrt((dist or HARD_DIST)(x, cent, w)), axis=1).astype(np.int32)
 
 
 def labels_soft(x, cent, w, beta):

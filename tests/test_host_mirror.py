@@ -86,6 +86,87 @@ def test_entry_point_table_registers_the_reference_flags():
         R.build_parser('front_DPCL').get_args(['--men'])             # --model_folder is required there
 
 
+# ---- the CLI boundary against the reference itself: tests/golden/cli.json is what tests/golden/make_cli_golden.py read off
+# /root/reference/utils/trainer.py:10-176 (MyArgs executed in place) and experiments/training/*.py (ast) ----
+
+AMS_FLAGS = {'--synthetic_batches', '--synthetic_pool', '--no_summaries', '--hip_graph', '--f16_audit_every', '--kmeans_seeding'}
+# reference scripts that hang off models outside SURVEY 8 (models/SC_V2.py, models/focus.py, models/enhanced_L41.py): not built
+OUT_OF_SCOPE_SCRIPTS = {'STFT_L41V2': 'models.SC_V2', 'front_L41V2': 'models.SC_V2', 'front_focus': 'models.focus',
+                        'front_mm': 'models.enhanced_L41'}
+
+
+def _cli_golden():
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'cli.json')) as f:
+        return json.load(f)
+
+
+def _describe(action):
+    return {'flags': list(action.option_strings), 'dest': action.dest, 'kind': type(action).__name__.lstrip('_'),
+            'type': action.type.__name__ if action.type is not None else None, 'default': action.default,
+            'required': bool(action.required), 'choices': list(action.choices) if action.choices is not None else None,
+            'nargs': action.nargs}
+
+
+def test_myargs_registers_exactly_the_reference_flags():
+    """Every flag of the reference's MyArgs -- name, dest, type, default, required, choices, nargs, store / store_true / store_false --
+    in the base parser and in each add_*_args group, in the reference's order; the only extras are this implementation's six
+    documented additions in the base parser."""
+    import argparse
+    from utils.trainer import MyArgs
+    gold = _cli_golden()['myargs']
+    base = [_describe(a) for a in MyArgs().parser._actions if not isinstance(a, argparse._HelpAction)]
+    extras = [a for a in base if a['flags'][0] in AMS_FLAGS]
+    assert [a for a in base if a['flags'][0] not in AMS_FLAGS] == gold['base']
+    assert {a['flags'][0] for a in extras} == AMS_FLAGS and not any(a['required'] for a in extras)
+    for method, want in gold['groups'].items():
+        p = MyArgs()
+        n0 = len(p.parser._actions)
+        getattr(p, method)()
+        assert [_describe(a) for a in p.parser._actions[n0:]] == want, method
+    for argv, sex in gold['sex'].items():
+        assert MyArgs().get_args(argv.split()).sex == sex
+
+
+def test_entry_points_are_the_reference_scripts():
+    """Per entry script of the reference: Trainer class, separator class, `type` string, the pretraining keyword, the argument groups
+    in order, --model_folder / --model_previous with their `required`.  Scripts of the reference that are absent here are exactly the
+    four that import a model outside the hot path."""
+    from experiments.training import _recipes as R
+    gold = _cli_golden()['scripts']
+    assert set(gold) - set(R.RECIPES) == set(OUT_OF_SCOPE_SCRIPTS) and not set(R.RECIPES) - set(gold)
+    for name, module in OUT_OF_SCOPE_SCRIPTS.items():
+        assert gold[name]['separator_import']['module'] == module
+    for name, (trainer, sep, typ, need_folder, has_prev, groups, pre) in R.RECIPES.items():
+        g = gold[name]
+        assert g['construct']['trainer'] == trainer and g['calls'] == ['train'], name
+        assert g['construct']['args'] == ([] if sep is None else [sep, typ]), name
+        assert g['construct']['kwargs'] == ({} if pre is None else {'pretraining': pre}), name
+        assert (g['separator_import'] or {'names': [None]})['names'] == [sep], name
+        assert tuple(m[len('add_'):-len('_args')] for m in g['groups']) == groups, name
+        inline = {f['flags'][0]: f for f in g['inline_flags']}
+        assert set(inline) == ({'--model_folder'} if need_folder is not None else set()) | ({'--model_previous'} if has_prev else set()), name
+        if need_folder is not None:
+            assert inline['--model_folder'].get('required', False) == need_folder, name
+        # and the parser this table builds says the same
+        acts = {a.option_strings[0]: a for a in R.build_parser(name).parser._actions if a.option_strings}
+        for flag, f in inline.items():
+            assert acts[flag].required == f.get('required', False) and acts[flag].default == f.get('default'), (name, flag)
+
+
+def test_trainer_classes_are_the_reference_classes():
+    import utils.trainer as T
+    gold = _cli_golden()['trainer_classes']
+    not_on_path = {'Adapt_Enhance', 'MultiChannel_Pretrainer'}        # utils/trainer.py:539-569: an undefined MultiAdapt / SURVEY 2 row 15
+    for name, c in gold.items():
+        if name in not_on_path:
+            assert not hasattr(T, name)
+            continue
+        cls = getattr(T, name)
+        assert cls.__mro__[1].__name__ == c['base'], name
+        for m in c['methods']:
+            assert callable(getattr(cls, m)), (name, m)
+
+
 def test_front_dpcl_construction_names_and_freeze(tmp_path):
     from tests.smoke_step import build_front_dpcl
     trainer, tfds = build_front_dpcl(str(tmp_path), B=2, L=256, W=32, N=8, hop=8, layer_size=8, nb_layers=2, E=4)
