@@ -168,7 +168,7 @@ def front_conv(x, f, hop, amax=None, measure=False):
     nb = lib.ams_front_conv_fwd_workspace_bytes(Bt, L, W, N, hop)
     ws = _ws(nb, x) if nb else None
     ay = None
-    if measure and F16X3 and lib.ams_front_conv_fwd_measures_output():
+    if measure and F16X3 and lib.ams_front_conv_fwd_measures_output(_p(x), _p(f), L, W, N, hop):
         ay = torch.empty(1, dtype=torch.float32, device=x.device)
     ev = PROFILE.begin() if PROFILE.enabled else None
     pa, pb, gt = _bounds(amax, ('front_conv', Bt, L, W, N, hop), ((x, Bt, L, L, 0), (f, W, N, N, 1)))

@@ -38,8 +38,8 @@ class FlatOptimizer(object):
         self.exchange_events = None              # bench.py: list of (start, end) events around the gradient all-reduce
         # AMS_DP_OVERLAP=1 (off by default: never run on multi-GPU hardware yet): gradients are exchanged in BUCKETS as the backward
         # pass finishes them -- bucket_ready() all-reduces the flat-buffer range of a layer on a communication stream behind the side
-        # stream that wrote it; exchange() then only reduces what is left (the first layer, the error word) and joins.  Inside a
-        # captured step that needs a capturable collective (RCCL): with gloo under --hip_graph the buckets are skipped.
+        # stream that wrote it; exchange() then only reduces what is left (the first layer, the error word) and joins.  Eager steps
+        # only: a captured step keeps the single exchange (bucket_ready warns once).
         import os
         self.overlap = self._dp and os.environ.get('AMS_DP_OVERLAP', '0') == '1'
         self._done = []                          # [lo, hi) element ranges of _gbuf already all-reduced in this step
@@ -129,11 +129,23 @@ class FlatOptimizer(object):
         if not self.overlap or any(p.grad is None for p in params):
             return
         gb = self._gbuf
-        if gb.is_cuda and torch.cuda.is_current_stream_capturing() and self.dist.backend() != 'nccl':
-            return                               # a gloo collective cannot be part of a captured step: left to exchange()
+        if gb.is_cuda and torch.cuda.is_current_stream_capturing():
+            # A bucket issued while the step is being CAPTURED would (a) fork the communication stream from the capturing stream and leave
+            # it unjoined when the capture ends -- exchange(), which joins it, runs outside -- and (b) fill _done at capture time only, so
+            # that every replay all-reduced the bucket inside the graph AND again, whole, in exchange().  The captured step
+            # therefore keeps the single exchange, whatever the backend, and says so once.
+            if not getattr(self, '_warned_capture', False):
+                import warnings
+                warnings.warn('AMS_DP_OVERLAP=1 has no effect inside a captured step (--hip_graph): the gradients are exchanged by ONE '
+                              'all-reduce after the replay', RuntimeWarning)
+                self._warned_capture = True
+            return
         lo, hi = self.range_of(*params)
+        # ranges never overlap: a layer's variables are adjacent in the flat buffer and every layer announces itself once per step.  A
+        # gradient accumulated into a range AFTER its all-reduce was issued would never be reduced -- refuse that loudly instead
         if any(not (hi <= a or lo >= b) for a, b in self._done):
-            return                               # overlaps a range already sent (shared variables): left to exchange()
+            raise RuntimeError('bucket_ready: range [%d, %d) overlaps a bucket already exchanged in this step %r (a variable shared '
+                               'between layers cannot be bucketed)' % (lo, hi, self._done))
         if gb.is_cuda:
             if self._comm is None:
                 self._comm = torch.cuda.Stream()

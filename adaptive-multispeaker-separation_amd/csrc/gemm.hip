@@ -1710,6 +1710,15 @@ size_t ams_front_conv_fwd_workspace_bytes(int Bt, int L, int W, int N, int hop) 
 // amax_x / amax_f (both or neither): operand bounds -> fp16x3, and the tile configuration that needs no split-K at the benchmark
 // shape (128 x 128: 240 tiles).  amax_y (optional, 16-bit-pipe launches only): the launch leaves max |y| there (cleared by a 4-byte
 // memset node in front of it when the caller lends no scratch) -- the bound the next product wants, without a pass over y.
+// the 16-byte-fetch (and with it the 16-bit-pipe) form of the strided analysis product applies: mirrors launch<A_FRAMES, B_ROW>'s test
+static bool front_conv_is_x6(const float* x, const float* f, int L, int W, int N, int hop) {
+    const int T = (L + hop - 1) / hop;
+    int pad_total = (T - 1) * hop + W - L;
+    if (pad_total < 0) pad_total = 0;
+    const bool a_vec = aligned16(x) && (L % 4 == 0) && (hop % 4 == 0) && ((pad_total / 2) % 4 == 0);
+    const bool b_vec = aligned16(f) && (N % 4 == 0);
+    return use_x6() && a_vec && b_vec && !tuning().novec && W % 4 == 0 && L >= 4 && N >= 4;
+}
 ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, const float* amax_x,
                               const float* amax_f, float* amax_y, int lds_pad, void* ws, size_t ws_bytes, void* sk_scratch,
                               size_t sk_bytes, void* stream) {
@@ -1742,7 +1751,9 @@ ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, 
     if (amax_y) o.amax_out = reinterpret_cast<unsigned*>(amax_y);
     return launch<A_FRAMES, B_ROW>(g, o, ws, ws_bytes, (hipStream_t)stream);
 }
-int ams_front_conv_fwd_measures_output(void) { return use_x6() ? 1 : 0; }
+int ams_front_conv_fwd_measures_output(const float* x, const float* f, int L, int W, int N, int hop) {
+    return (x && f && L > 0 && W > 0 && N > 0 && hop > 0 && front_conv_is_x6(x, f, L, W, N, hop)) ? 1 : 0;
+}
 
 // Generic framed product: out[(r,t), n] = sum_k xpad[r, t*hop + k - pad_left] * Bm[k, n]   (STFT as a DFT product)
 ams_status ams_frames_matmul(const float* x, const float* Bm, float* out, int R, int L, int W, int N, int hop, int T, int pad_left,

@@ -39,7 +39,7 @@
 extern "C" {
 #endif
 
-#define AMS_ABI_VERSION 3
+#define AMS_ABI_VERSION 4
 
 typedef int32_t ams_status;
 #define AMS_OK 0
@@ -59,12 +59,14 @@ ams_status ams_front_filter_bwd(const float* w, const float* bases, const float*
  * x [Bt,L], f [W,N] -> y [Bt,T',N], T' = ceil(L/hop), pad_left = ((T'-1)hop+W-L)/2. */
 size_t ams_front_conv_fwd_workspace_bytes(int Bt, int L, int W, int N, int hop);
 /* amax_x / amax_f, lds_pad, ws, sk_scratch: see ams_gemm_f32.  amax_y (optional): the launch leaves max |y| there -- the operand
- * bound of the product that reads y, without a pass over y (only when ams_front_conv_fwd_measures_output() != 0: the 16-bit-pipe
- * arithmetic; the native-f32 fallback rejects it). */
+ * bound of the product that reads y, without a pass over y -- only when ams_front_conv_fwd_measures_output(same x, f, geometry) != 0:
+ * the 16-bit-pipe form, which needs 16-byte addressable operands (L, hop, pad_left, N, W multiples of 4); the scalar-fetch f32 form
+ * such launches fall back to REJECTS amax_y (AMS_E_INVALID_ARG) -- ask first, measure y with ams_absmax_f32 otherwise (ABI 4: the
+ * query takes the launch's operands; ABI 3's took none and said yes for shapes the launch then refused). */
 ams_status ams_front_conv_fwd(const float* x, const float* f, float* y, int Bt, int L, int W, int N, int hop, const float* amax_x,
                               const float* amax_f, float* amax_y, int lds_pad, void* ws, size_t ws_bytes, void* sk_scratch,
                               size_t sk_bytes, void* stream);
-int ams_front_conv_fwd_measures_output(void);
+int ams_front_conv_fwd_measures_output(const float* x, const float* f, int L, int W, int N, int hop);
 size_t ams_front_conv_bwd_filter_workspace_bytes(int Bt, int L, int W, int N, int hop);
 ams_status ams_front_conv_bwd_filter(const float* x, const float* dy, float* df, int Bt, int L, int W, int N, int hop, void* ws,
                                      size_t ws_bytes, void* stream);

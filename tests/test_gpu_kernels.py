@@ -95,6 +95,28 @@ def test_front_conv_and_filter(ops, Bt, L, W, N, hop):
     assert rel(host(dw), dw_ref) < TOL and rel(host(db), db_ref) < TOL
 
 
+@pytest.mark.parametrize('Bt,L,W,N,hop', [(3, 1001, 128, 8, 48), (2, 1000, 128, 8, 50), (2, 1000, 126, 8, 48), (2, 1000, 128, 6, 48),
+                                           (2, 1000, 128, 8, 48)])
+def test_model_front_conv_at_shapes_the_16_byte_fetch_does_not_take(ops, Bt, L, W, N, hop):
+    """functional.front_conv (what models/adapt.py calls) asks the launch to leave max |y| (it asked unconditionally and the
+    scalar-fetch f32 form, which L, hop, pad_left, W or N not a multiple of 4 fall back to, rejects that -- arbitrary-length inference
+    utterances raised AmsError).  Since ABI 4 the query takes the launch's geometry: such shapes run, get the right values, and their
+    output carries no stale bound (the consumer measures); the aligned shape still gets its bound from the launch."""
+    from ams_hip import functional as F
+    rng = np.random.RandomState(L + W + N + hop)
+    x, f = rng.randn(Bt, L), rng.randn(W, N)
+    xd, fd = dev(x), dev(f)
+    y = F.front_conv(xd, fd, hop)
+    y_ref = ofront.conv_strided(x, f, hop)
+    assert y.shape == y_ref.shape and rel(host(y), y_ref) < TOL
+    T = -(-L // hop)
+    pl = max((T - 1) * hop + W - L, 0) // 2
+    takes = all(v % 4 == 0 for v in (L, hop, pl, W, N))
+    tagged = getattr(y, '_ams_amax', None) is not None
+    assert tagged == (takes and ops.F16X3)
+    assert abs(float(ops.amax_of(y)) - np.abs(host(y)).max()) <= 1e-6 * np.abs(y_ref).max()
+
+
 def test_make_masks(ops):
     rng = np.random.RandomState(2)
     B, S, T, F = 3, 3, 5, 7
