@@ -248,7 +248,7 @@ def _frozen(*ts):
 
 
 def drop_frozen_derivatives(t):
-    for k in ('_ams_amax_cache', '_ams_wcat', '_ams_wcat_amax', '_ams_kbound', '_ams_bcat'):
+    for k in ('_ams_amax_cache', '_ams_wcat', '_ams_wcat_amax', '_ams_kbound', '_ams_bcat', '_ams_ps_w'):
         if hasattr(t, k):
             delattr(t, k)
 
@@ -631,6 +631,102 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False
     return out
 
 
+# ------------------------------------------------------------------ products from pre-split fp16 operand images (csrc/gemm_ps.hip)
+PRESPLIT = _os.environ.get('AMS_GEMM_PRESPLIT', '1') != '0' and F16X3
+
+
+def ps_pack_rows(x2, amax, img=None):
+    """PS32 image (include/ams.h) of x2 [R, K] (dense rows, any row pitch): uint8 [R, pitch]."""
+    if x2.dtype != torch.float32 or not x2.is_cuda or x2.dim() != 2 or x2.stride(1) != 1:
+        raise AmsError('ps_pack_rows: fp32 device matrix with dense rows expected')
+    lib = load()
+    R, K = x2.shape
+    pitch = lib.ams_ps_image_pitch(K)
+    if img is None:
+        img = torch.empty((R, pitch), dtype=torch.uint8, device=x2.device)
+    check(lib.ams_ps_pack_rows(_p(x2), x2.stride(0), _p(img), R, K, _p(amax), _s()), 'ams_ps_pack_rows')
+    return img
+
+
+def ps_pack_cols(w2, amax, img=None):
+    """PS32 image of w2^T for w2 [K, N] (dense rows, any row pitch): uint8 [N, pitch] -- the B operand of x . w2."""
+    if w2.dtype != torch.float32 or not w2.is_cuda or w2.dim() != 2 or w2.stride(1) != 1:
+        raise AmsError('ps_pack_cols: fp32 device matrix with dense rows expected')
+    lib = load()
+    K, N = w2.shape
+    pitch = lib.ams_ps_image_pitch(K)
+    if img is None:
+        img = torch.empty((N, pitch), dtype=torch.uint8, device=w2.device)
+    check(lib.ams_ps_pack_cols(_p(w2), w2.stride(0), _p(img), K, N, _p(amax), _s()), 'ams_ps_pack_cols')
+    return img
+
+
+def gemm_ps(a_img, b_img, K, amax, bias=None, out=None, ldc=None, label=''):
+    """out[M, N] = A . B^T (+ bias) from the two PS32 images (a_img [M, pitch], b_img [N, pitch]); amax = the bounds they were cut with."""
+    lib = load()
+    M, N = a_img.shape[0], b_img.shape[0]
+    if out is None:
+        out = torch.empty((M, N), dtype=torch.float32, device=a_img.device)
+        ldc = N
+    elif ldc is None:
+        ldc = out.stride(0) if out.dim() == 2 else N
+    ev = PROFILE.begin() if PROFILE.enabled else None
+    cur = torch.cuda.current_stream()
+    amax[0].record_stream(cur)
+    amax[1].record_stream(cur)
+    check(lib.ams_gemm_ps(M, N, K, _p(a_img), _p(b_img), _p(out), ldc, _p(bias), _p(amax[0]), _p(amax[1]), _s()), 'ams_gemm_ps')
+    if ev is not None:
+        PROFILE.end(ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N), 'gemm16ps<0,1>', label)
+    return out
+
+
+def tag_ps_image(t, img):
+    """A producer that wrote the PS32 image of `t` (cut with the bound it tagged `t` with) attaches it; forward_product() finds it."""
+    if PRESPLIT and img is not None:
+        t._ams_ps = (img, t._version)
+    return t
+
+
+def _ps_rows_image(x2, amax_x):
+    b = x2
+    while b is not None:                                         # a view that keeps rows and columns of a tagged tensor shares its image
+        tag = getattr(b, '_ams_ps', None)
+        if tag is not None and tag[1] == b._version and b.numel() == x2.numel() and b.data_ptr() == x2.data_ptr():
+            return tag[0]
+        b = b._base
+    return ps_pack_rows(x2, amax_x)
+
+
+def _ps_weight_image(W2, amax_w, owner):
+    """PS32 image of W2^T, cut once per evaluation pass (inside a captured step: by every replay) and kept across passes for frozen
+    weights (Network.freeze_weights; dropped with the other derived tensors by drop_frozen_derivatives): cached on `owner`."""
+    c = getattr(owner, '_ams_ps_w', None)
+    if (c is not None and c[1] == W2.data_ptr() and c[2] == tuple(W2.shape) and c[3] is amax_w and (c[0] == PASS[0] or _frozen(owner))):
+        return c[4]
+    img = ps_pack_cols(W2, amax_w)
+    owner._ams_ps_w = (PASS[0], W2.data_ptr(), tuple(W2.shape), amax_w, img)
+    return img
+
+
+def forward_product(x2, W2, bias, out, amax, label, owner, ldc=None):
+    """out[M, N] = x2 [M, K] . W2 [K, N] + bias: the forward products of the path (BLSTM input projection, Conv1D).  With both operand
+    bounds at hand and fp16x3 not denied for this product class: from pre-split operand images (csrc/gemm_ps.hip) -- x2's image is the
+    one its producer attached (tag_ps_image) or is cut here, W2's is cut once per pass; otherwise ams_gemm_f32."""
+    M, K = x2.shape
+    N = W2.shape[1]
+    ldc = (out.stride(0) if out.dim() == 2 else N) if ldc is None else ldc
+    key = ('gemm', label, M, N, K, False, False)
+    use = (PRESPLIT and amax is not None and amax[0] is not None and amax[1] is not None and key not in F16_AUDIT.denied
+           and not F16_AUDIT.active and LDS_PAD[0] == 0 and N % 4 == 0 and ldc % 4 == 0 and out.data_ptr() % 16 == 0
+           and (bias is None or bias.data_ptr() % 16 == 0) and x2.stride(1) == 1 and W2.stride(1) == 1
+           and max(M, N) * ((K + 31) // 32 * 128) < 2 ** 31 and load().ams_gemm_get_arith() != 0)
+    if not use:
+        return gemm(x2, W2, bias=bias, out=out, M=M, N=N, K=K, lda=x2.stride(0), ldb=W2.stride(0), ldc=ldc, label=label, amax=amax)
+    a_img = _ps_rows_image(x2, amax[0])
+    b_img = _ps_weight_image(W2, amax[1], owner)
+    return gemm_ps(a_img, b_img, K, amax, bias=bias, out=out, ldc=ldc, label=label)
+
+
 def gemm_at_b_colsum(A, B, out, bsum, accumulate=True, amax=None, ldc=None):
     """out[M,N] (+)= A^T B and bsum[N] (+)= column sums of B in ONE pass over B (A [K,M], B [K,N] row-major).  Returns False when
     the shapes / alignments do not allow the fused form (the caller then uses gemm + colsum)."""
@@ -843,7 +939,7 @@ def blstm_fwd(x, Kf, bf, Kb, bb, amax=None):
         gemm(_padded_rows(x2, Dp), Wp, bias=bias, out=G, M=B * T, N=8 * H, K=Dp, lda=Dp, ldb=8 * H, ldc=8 * H, label='blstm_input_gemm',
              amax=amax)
     else:
-        gemm(x2, Wcat, bias=bias, out=G, M=B * T, N=8 * H, K=D, lda=D, ldb=8 * H, ldc=8 * H, label='blstm_input_gemm', amax=amax)
+        forward_product(x2, Wcat, bias, G.view(B * T, 8 * H), amax, 'blstm_input_gemm', Kf)
     if nring:
         sync, pre0 = _ring_sync(nring, x)
         check(lib.ams_blstm_ring_fwd(_p(G), _p(out), _p(cst[0]), _p(cst[1]), _p(Kf[D:]), _p(Kb[D:]), ldu,
@@ -859,7 +955,8 @@ def blstm_fwd(x, Kf, bf, Kb, bb, amax=None):
 def dense_fwd(x, W, b, amax=None):
     """u = x.W + b over the last axis (utils/ops.py:486-503)."""
     x2 = x.reshape(-1, x.shape[-1])
-    return gemm(x2, W, bias=b, amax=amax).view(x.shape[:-1] + (W.shape[1],))
+    out = torch.empty((x2.shape[0], W.shape[1]), dtype=torch.float32, device=x.device)
+    return forward_product(x2, W, b, out, amax, '', W).view(x.shape[:-1] + (W.shape[1],))
 
 
 def blstm_wcat(Kf, Kb, D):

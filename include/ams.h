@@ -130,6 +130,24 @@ int ams_gemm_get_arith(void);
 ams_status ams_gemm_f32(int transA, int transB, int M, int N, int K, const float* A, long lda, const float* B, long ldb, float* C,
                         long ldc, const float* bias, int accumulate, int mask_period, int mask_skip, const float* amax_a,
                         const float* amax_b, int lds_pad, void* ws, size_t ws_bytes, void* sk_scratch, size_t sk_bytes, void* stream);
+/* ---- products from PRE-SPLIT fp16 operand images (ABI 4; csrc/gemm_ps.hip) ----
+ * The fp16x3 arithmetic of ams_gemm_f32 with the cut made ONCE per operand and step by whoever writes the operand, instead of once per
+ * element and workgroup inside the product: C[M,N] = A[M,K] . B[N,K]^T (+ bias[N]) with A and B handed over as "PS32" images.
+ *   image of X [R, K] (k contiguous), bound b:  s = 2^(13 - floor(log2 b));  row r = ams_ps_image_pitch(K) bytes (K rounded up to 32
+ *   floats' worth: the size of the f32 row); k-tile t of a row = 128 bytes = 32 x fp16 hi | 32 x fp16 lo, hi = fp16(x s),
+ *   lo = fp16(x s - hi); k >= K zero.  16-byte aligned.  The bound rule is ams_gemm_f32's (true max below 4 x bound, else Inf/NaN).
+ * ams_ps_pack_rows: image of x [R, K] (row pitch ldx floats).  ams_ps_pack_cols: image of w^T for w [K, N] row-major (row pitch ldw):
+ * image row n = w[:, n] -- what a forward product x . w needs of its weights.  amax: device pointer to the bound; ams_gemm_ps must be
+ * given the SAME values (it undoes both scales on the accumulators).  Results agree with ams_gemm_f32's fp16x3 form to the last bits
+ * (same terms, same products, same two accumulator sets; the k order differs).  N, ldc multiples of 4; C, bias 16-byte aligned;
+ * images below 2 GB.  Replaces: utils/ops.py:366-383 (dynamic_rnn input projection), :501-503 (conv1d k = 1) in the forward pass. */
+size_t ams_ps_image_pitch(int K);
+size_t ams_ps_image_bytes(int rows, int K);
+ams_status ams_ps_pack_rows(const float* x, long ldx, void* img, int R, int K, const float* amax, void* stream);
+ams_status ams_ps_pack_cols(const float* w, long ldw, void* img, int K, int N, const float* amax, void* stream);
+ams_status ams_gemm_ps(int M, int N, int K, const void* A_img, const void* B_img, float* C, long ldc, const float* bias,
+                       const float* amax_a, const float* amax_b, void* stream);
+
 /* C[M,N] (+)= A^T . B with A stored [K, M] and B [K, N], AND bsum_out[N] (+)= column sums of B in the same pass over B: the
  * weight and bias gradients of Conv1D (utils/ops.py:501-503) and of a BLSTM layer's input kernels from one read of dY / dZ.  M, N, lda,
  * ldb multiples of 4, 16-byte aligned operands; bsum_ws = 32 * N floats of scratch (16-byte aligned). */

@@ -1,0 +1,113 @@
+"""GPU: products from pre-split fp16 operand images (csrc/gemm_ps.hip, include/ams.h "PS32") against float64 and against the in-product
+fp16x3 form of ams_gemm_f32 -- same terms, same three products, f32 accumulation: the two differ only in summation order."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+
+
+def unpack(img, K):
+    """PS32 image -> (hi, lo) float64 [R, K] (the oracle of the layout: row pitch ceil(K / 32) * 128, k-tile = 32 hi | 32 lo)."""
+    raw = img.cpu().numpy()
+    R, pitch = raw.shape
+    h = raw.view(np.float16).reshape(R, pitch // 128, 2, 32).astype(np.float64)
+    return h[:, :, 0, :].reshape(R, -1)[:, :K], h[:, :, 1, :].reshape(R, -1)[:, :K], h
+
+
+@pytest.mark.parametrize('R,K,ld', [(7, 600, 600), (130, 256, 300), (33, 45, 45), (64, 32, 32), (5, 1, 4)])
+def test_pack_rows_is_the_exact_two_term_cut(R, K, ld):
+    from ams_hip import ops
+    rng = np.random.RandomState(R + K)
+    x = (rng.randn(R, ld) * np.exp(rng.randn(R, ld) * 2)).astype(np.float32)
+    xd = dev(x)[:, :K]
+    bound = ops.absmax(xd.contiguous())
+    img = ops.ps_pack_rows(xd, bound)
+    hi, lo, full = unpack(img, K)
+    b = float(bound)
+    s = 2.0 ** (13 - np.floor(np.log2(b)))
+    xs = x[:, :K].astype(np.float64) * s
+    assert np.array_equal(hi, xs.astype(np.float16).astype(np.float64))               # hi = fp16(x s), round to nearest even
+    assert np.array_equal(lo, (xs - hi).astype(np.float32).astype(np.float16).astype(np.float64))
+    assert np.abs(hi + lo - xs).max() <= 2.0 ** -22 * np.abs(xs).max() + 2.0 ** -25   # 22 bits for entries within 2^17 of the bound
+    Kp = (K + 31) // 32 * 32
+    assert img.shape[1] == Kp * 4
+    tail = full.reshape(R, -1, 2, 32)
+    pad = np.concatenate([tail[:, :, 0, :].reshape(R, -1)[:, K:], tail[:, :, 1, :].reshape(R, -1)[:, K:]], axis=1)
+    assert not pad.any()                                                                # k >= K: zeros in both planes
+
+
+@pytest.mark.parametrize('K,N,ld', [(600, 2400, 2400), (256, 40, 48), (45, 130, 130), (33, 7, 8)])
+def test_pack_cols_is_pack_rows_of_the_transpose(K, N, ld):
+    from ams_hip import ops
+    rng = np.random.RandomState(K + N)
+    w = rng.randn(K, ld).astype(np.float32)
+    wd = dev(w)[:, :N]
+    bound = ops.absmax(wd.contiguous())
+    a = ops.ps_pack_cols(wd, bound)
+    b = ops.ps_pack_rows(wd.t().contiguous(), bound)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('M,N,K,bias', [(128, 256, 32, False), (128, 256, 64, True), (128, 256, 600, True), (256, 512, 96, False),
+                                        (100, 40, 45, True), (5120, 2400, 600, True), (1000, 10240, 600, True), (5120, 2400, 256, False),
+                                        (130, 260, 33, True), (640, 1200, 300, False)])
+def test_product_matches_float64_and_the_in_product_cut(M, N, K, bias):
+    from ams_hip import ops
+    rng = np.random.RandomState(M + N + K)
+    A = rng.randn(M, K).astype(np.float32)
+    W = (rng.randn(K, N) * 0.3).astype(np.float32)
+    b = rng.randn(N).astype(np.float32) if bias else None
+    Ad, Wd, bd = dev(A), dev(W), (dev(b) if bias else None)
+    am = (ops.absmax(Ad), ops.absmax(Wd))
+    ai, bi = ops.ps_pack_rows(Ad, am[0]), ops.ps_pack_cols(Wd, am[1])
+    out = torch.full((M, N), float('nan'), device='cuda')
+    ops.gemm_ps(ai, bi, K, am, bias=bd, out=out)
+    ref_gemm = ops.gemm(Ad, Wd, bias=bd, amax=am)
+    torch.cuda.synchronize()
+    rows = np.unique(np.concatenate([np.arange(min(M, 200)), np.linspace(0, M - 1, min(M, 300)).astype(int)]))
+    ref = A[rows].astype(np.float64) @ W.astype(np.float64) + (b.astype(np.float64) if bias else 0.0)
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    scale = np.linalg.norm(A[rows].astype(np.float64), axis=1)[:, None] * np.linalg.norm(W.astype(np.float64), axis=0)[None, :]
+    err = np.abs(got[rows] - ref) / (scale + 1e-30)
+    err_g = np.abs(ref_gemm.cpu().numpy()[rows] - ref) / (scale + 1e-30)
+    assert err.max() < 2e-7 and err.max() <= 2.0 * err_g.max() + 1e-8, (err.max(), err_g.max())
+    rel = np.linalg.norm(got[rows] - ref) / np.linalg.norm(ref)
+    assert rel < 2e-6, rel
+
+
+def test_rows_and_columns_past_the_edge_are_zeros_not_neighbours():
+    """M and N that end inside a tile: the out-of-range rows of the LDS-DMA come back as zeros (buffer range check) and nothing is
+    stored past the edge: a guard band around C stays untouched."""
+    from ams_hip import ops
+    M, N, K = 129, 260, 70
+    rng = np.random.RandomState(9)
+    A, W = rng.randn(M, K).astype(np.float32), rng.randn(K, N).astype(np.float32)
+    Ad, Wd = dev(A), dev(W)
+    am = (ops.absmax(Ad), ops.absmax(Wd))
+    big = torch.full((M + 2, N + 8), 7.0, device='cuda')
+    out = big[1:M + 1, 4:N + 4]
+    ops.gemm_ps(ops.ps_pack_rows(Ad, am[0]), ops.ps_pack_cols(Wd, am[1]), K, am, out=out, ldc=big.stride(0))
+    torch.cuda.synchronize()
+    g = big.cpu().numpy()
+    ref = A.astype(np.float64) @ W.astype(np.float64)
+    assert np.abs(g[1:M + 1, 4:N + 4] - ref).max() < 1e-4 * np.abs(ref).max()
+    g[1:M + 1, 4:N + 4] = 7.0
+    assert (g == 7.0).all()
+
+
+def test_launches_back_to_back_are_deterministic():
+    from ams_hip import ops
+    M, N, K = 5120, 2400, 600
+    rng = np.random.RandomState(4)
+    Ad, Wd = dev(rng.randn(M, K)), dev(rng.randn(K, N) * 0.1)
+    am = (ops.absmax(Ad), ops.absmax(Wd))
+    ai, bi = ops.ps_pack_rows(Ad, am[0]), ops.ps_pack_cols(Wd, am[1])
+    first = ops.gemm_ps(ai, bi, K, am).clone()
+    for _ in range(20):
+        assert torch.equal(ops.gemm_ps(ai, bi, K, am), first)
