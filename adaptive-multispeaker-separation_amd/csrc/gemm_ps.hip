@@ -97,15 +97,18 @@ __global__ __launch_bounds__(256) void ps_pack_cols_kernel(const float* __restri
         t[ty * 8 + i][tx] = (k < K && n < N) ? w[(long)k * ldw + n] : 0.f;
     }
     __syncthreads();
+    // a wave writes 16 image rows x (4 groups of 8 k): 64 contiguous bytes of hi and of lo per row (as (n, group) = (tid & 63, tid >> 6)
+    // a wave wrote 64 rows x 16 bytes: 21.6 us for the 600 x 10240 dense kernel, 2.3 TB/s)
     const float s = ps_scale(amax[0]);
-    const int n = n0 + tx;
+    const int nl = threadIdx.x >> 2, kg = threadIdx.x & 3;
+    const int n = n0 + nl;
     if (n >= N) return;
     uint4 hi, lo;
-    ps_split2(t[ty * 8 + 0][tx] * s, t[ty * 8 + 1][tx] * s, hi.x, lo.x);
-    ps_split2(t[ty * 8 + 2][tx] * s, t[ty * 8 + 3][tx] * s, hi.y, lo.y);
-    ps_split2(t[ty * 8 + 4][tx] * s, t[ty * 8 + 5][tx] * s, hi.z, lo.z);
-    ps_split2(t[ty * 8 + 6][tx] * s, t[ty * 8 + 7][tx] * s, hi.w, lo.w);
-    unsigned char* p = img + (long)n * pitch + (k0 >> 5) * 128 + ty * 16;
+    ps_split2(t[kg * 8 + 0][nl] * s, t[kg * 8 + 1][nl] * s, hi.x, lo.x);
+    ps_split2(t[kg * 8 + 2][nl] * s, t[kg * 8 + 3][nl] * s, hi.y, lo.y);
+    ps_split2(t[kg * 8 + 4][nl] * s, t[kg * 8 + 5][nl] * s, hi.z, lo.z);
+    ps_split2(t[kg * 8 + 6][nl] * s, t[kg * 8 + 7][nl] * s, hi.w, lo.w);
+    unsigned char* p = img + (long)n * pitch + (k0 >> 5) * 128 + kg * 16;
     *reinterpret_cast<uint4*>(p) = hi;
     *reinterpret_cast<uint4*>(p + 64) = lo;
 }
