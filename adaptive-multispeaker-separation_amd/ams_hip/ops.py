@@ -1692,8 +1692,10 @@ def l41_loss_bwd(emb, y, vspk, upstream, from_u=False):
     ws = _ws(nb, emb)
     demb = torch.empty_like(emb)
     dvs = torch.empty_like(vspk)
-    check(lib.ams_l41_loss_bwd(_p(emb), _p(y), _p(vspk), _p(upstream), _p(demb), _p(dvs), B, TF, E, S, int(from_u), _p(ws), nb, _s()),
+    am = torch.empty(1, dtype=torch.float32, device=emb.device) if F16X3 else None      # max |demb| out of the same pass
+    check(lib.ams_l41_loss_bwd(_p(emb), _p(y), _p(vspk), _p(upstream), _p(demb), _p(dvs), _p(am), B, TF, E, S, int(from_u), _p(ws), nb, _s()),
           'ams_l41_loss_bwd')
+    tag_amax(demb, am)
     return demb, dvs
 
 
@@ -1722,8 +1724,10 @@ def l41_loss_ns_bwd(emb, y, vspk, negs, upstream, ns_rate, from_u=False):
     nb = lib.ams_l41_ns_workspace_bytes(B, TF, E, S, NSEL, K)
     ws = _ws(nb, emb)
     demb, dvs, dnegs = torch.empty_like(emb), torch.empty_like(vspk), torch.empty_like(negs)
-    check(lib.ams_l41_loss_ns_bwd(_p(emb), _p(y), _p(vspk), _p(negs), _p(upstream), _p(demb), _p(dvs), _p(dnegs), B, TF, E, S, NSEL, K,
+    am = torch.empty(1, dtype=torch.float32, device=emb.device) if F16X3 else None
+    check(lib.ams_l41_loss_ns_bwd(_p(emb), _p(y), _p(vspk), _p(negs), _p(upstream), _p(demb), _p(dvs), _p(dnegs), _p(am), B, TF, E, S, NSEL, K,
                                   float(ns_rate), int(from_u), _p(ws), nb, _s()), 'ams_l41_loss_ns_bwd')
+    tag_amax(demb, am)
     return demb, dvs, dnegs
 
 

@@ -36,12 +36,13 @@ template <int E_, bool BWD, bool NEG, bool FROM_U, bool VEC>
 __global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb, const float* __restrict__ y,
                                                   const float* __restrict__ vs, const float* __restrict__ upstream,
                                                   float* __restrict__ part, float* __restrict__ demb, float* __restrict__ dvs_part,
-                                                  long TF, int S, int nblk, float scale, NegArgs na) {
+                                                  float* __restrict__ amax_part, long TF, int S, int nblk, float scale, NegArgs na) {
     constexpr int LD = VEC ? E_ + 4 : E_ + 1;
     constexpr int V4 = E_ / 4;
     __shared__ __attribute__((aligned(16))) float tile[256 * LD];
     __shared__ float svs[MAXS * E_];
     __shared__ float red[4][MAXS * E_ + 1];
+    __shared__ float sdzs[BWD ? 256 * MAXS : 1];              // d cost / d <Vs_s, emb> of every point (backward: the dVs sums read them)
     __shared__ float sneg[NEG ? MAXN * E_ : 1];
     __shared__ float sdz[NEG && BWD ? 256 * MAXK : 1];          // d cost / d <neg_k, emb> of every point
     __shared__ int ssel[NEG && BWD ? 256 : 1];
@@ -79,7 +80,7 @@ __global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb,
             inv_u = 1.0f / sqrtf(fmaxf(ss, 1e-12f));                          // tf.nn.l2_normalize epsilon (utils/ops.py:323)
 #pragma unroll
             for (int e = 0; e < E_; ++e) v[e] *= inv_u;
-            if (NEG && BWD) {                                                // the negatives' gradient below reads the points from LDS
+            if (BWD) {                                                       // the dVs sums (and the negatives' gradient) read the points from LDS
 #pragma unroll
                 for (int e = 0; e < E_; ++e) tile[tid * LD + e] = v[e];
             }
@@ -132,8 +133,9 @@ __global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb,
         }
         __syncthreads();
     }
+    float dv[E_];
+    float amx = 0.f;
     if (tid < npts) {
-        float dv[E_];
 #pragma unroll
         for (int e = 0; e < E_; ++e) {
             float d = 0.f;
@@ -150,14 +152,43 @@ __global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb,
             for (int e = 0; e < E_; ++e) dv[e] = (dv[e] - v[e] * dot) * inv_u;
         }
 #pragma unroll
+        for (int e = 0; e < E_; ++e) amx = fmaxf(amx, fabsf(dv[e]));
+    }
+    // dVs_s[e] of the block = sum over its points of dz_s * v_e.  Round 5 ran S * E wave-wide halving trees per block (120 at S = 3:
+    // ~10 instructions each with their nops -- the longest phase of the kernel, 0.34 of HBM at cfg5); now the points' dz lie in LDS beside
+    // the points themselves and thread (o = (s, e), half) adds its half of the block's points in point order: 128 steps of two LDS reads
+    // and one FMA, fixed order (deterministic).
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) sdzs[tid * MAXS + s] = (tid < npts && s < S) ? dz[s] : 0.f;
+    __syncthreads();
+    {
+        const int o = tid & 127, half = tid >> 7, SE = S * E_;
+        if (o < SE) {
+            const int so = o / E_, eo = o - so * E_;
+            float acc = 0.f;
+            const int p1 = min(npts, 128 * (half + 1));
+            for (int p = 128 * half; p < p1; ++p) acc += sdzs[p * MAXS + so] * tile[p * LD + eo];
+            red[half][o] = acc;
+        }
+        if (SE > 128) {                                                          // (S = 4, E = 40: outputs 128 .. 159)
+            const int o2 = 128 + o;
+            if (o2 < SE) {
+                const int so = o2 / E_, eo = o2 - so * E_;
+                float acc = 0.f;
+                const int p1 = min(npts, 128 * (half + 1));
+                for (int p = 128 * half; p < p1; ++p) acc += sdzs[p * MAXS + so] * tile[p * LD + eo];
+                red[half][o2] = acc;
+            }
+        }
+    }
+    __syncthreads();                                                             // the points have been read: the tile takes the gradients
+    if (tid < npts) {
+#pragma unroll
         for (int e = 0; e < E_; ++e) tile[tid * LD + e] = dv[e];
     }
-    for (int s = 0; s < S; ++s) {
-#pragma unroll
-        for (int e = 0; e < E_; ++e) {
-            const float c = wave_sum_lane0((tid < npts) ? dz[s] * v[e] : 0.f);       // S * E of these per block: VALU tree, not bpermutes
-            if ((tid & 63) == 0) red[tid >> 6][s * E_ + e] = c;
-        }
+    if (amax_part != nullptr) {                                                  // max |d emb| of the block (the launch's final kernel folds them)
+        amx = wave_max(amx);
+        if ((tid & 63) == 0) red[2][tid >> 6] = amx;
     }
     __syncthreads();
     float* db = demb + ((long)b * TF + p0) * E_;
@@ -172,7 +203,9 @@ __global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb,
         for (int i = tid; i < npts * E_; i += 256) db[i] = tile[(i / E_) * LD + (i % E_)];
     }
     for (int i = tid; i < S * E_; i += 256)
-        dvs_part[((long)b * nblk + blockIdx.x) * (S * E_) + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+        dvs_part[((long)b * nblk + blockIdx.x) * (S * E_) + i] = red[0][i] + red[1][i];
+    if (amax_part != nullptr && tid == 0)
+        amax_part[(long)b * nblk + blockIdx.x] = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
 }
 
 __global__ void l41_cost_final_kernel(const float* __restrict__ part, float* __restrict__ out, long n, float scale) {
@@ -185,7 +218,18 @@ __global__ void l41_cost_final_kernel(const float* __restrict__ part, float* __r
     if (threadIdx.x == 0) out[0] = (sm[0] + sm[1] + sm[2] + sm[3]) * scale;
 }
 
-__global__ void l41_dvs_final_kernel(const float* __restrict__ part, float* __restrict__ dvs, int nblk, int SE, int B) {
+// (block 0 also folds the blocks' max |d emb| into amax_out[0]: the operand bound of the two products that read d emb -- no pass over it)
+__global__ void l41_dvs_final_kernel(const float* __restrict__ part, float* __restrict__ dvs, int nblk, int SE, int B,
+                                     const float* __restrict__ amax_part, float* __restrict__ amax_out) {
+    if (amax_out != nullptr && blockIdx.x == 0) {
+        __shared__ float sm[4];
+        float m = 0.f;
+        for (long i = threadIdx.x; i < (long)B * nblk; i += blockDim.x) m = fmaxf(m, amax_part[i]);
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) amax_out[0] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    }
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * SE) return;
     const int b = i / SE, k = i - b * SE;
@@ -200,7 +244,7 @@ extern "C" {
 
 size_t ams_l41_workspace_bytes(int B, long TF, int E, int S) {
     const int nblk = ceil_div(TF, 256);
-    return sizeof(float) * (size_t)B * nblk * (S * E > 1 ? S * E : 1);
+    return sizeof(float) * (size_t)B * nblk * ((S * E > 1 ? S * E : 1) + 1);          // + one maximum per block (backward: amax_out)
 }
 
 #define AMS_L41_CASE(EE, BWD, NEG, U, V, ...) hipLaunchKernelGGL((l41_kernel<EE, BWD, NEG, U, V>), grid, dim3(256), 0, st, __VA_ARGS__)
@@ -232,14 +276,15 @@ ams_status ams_l41_loss_fwd(const float* emb, const float* y, const float* vspk,
     dim3 grid(nblk, B);
     const float scale = 1.0f / ((float)B * (float)TF * S);
     const bool from_u = emb_is_u != 0, vec = l41_vec(emb, emb);
-    AMS_L41_DISPATCH(false, false, emb, y, vspk, (const float*)nullptr, (float*)ws, (float*)nullptr, (float*)nullptr, TF, S, nblk, scale, NegArgs{})
+    AMS_L41_DISPATCH(false, false, emb, y, vspk, (const float*)nullptr, (float*)ws, (float*)nullptr, (float*)nullptr, (float*)nullptr, TF, S, nblk, scale, NegArgs{})
     hipLaunchKernelGGL(l41_cost_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, cost, (long)B * nblk, scale);
     return ams_check_launch();
 }
 
 // demb [B,TF,E], dvspk [B,S,E]; upstream = device scalar d loss / d cost
+// amax_out (optional, both backward entry points): one float that receives max |demb| of this launch
 ams_status ams_l41_loss_bwd(const float* emb, const float* y, const float* vspk, const float* upstream, float* demb, float* dvspk,
-                            int B, long TF, int E, int S, int emb_is_u, void* ws, size_t ws_bytes, void* stream) {
+                            float* amax_out, int B, long TF, int E, int S, int emb_is_u, void* ws, size_t ws_bytes, void* stream) {
     AMS_REQUIRE(emb && y && vspk && upstream && demb && dvspk && ws && B > 0 && TF > 0 && S > 0 && S <= MAXS);
     if (ws_bytes < ams_l41_workspace_bytes(B, TF, E, S)) return AMS_E_WORKSPACE_TOO_SMALL;
     hipStream_t st = (hipStream_t)stream;
@@ -247,15 +292,17 @@ ams_status ams_l41_loss_bwd(const float* emb, const float* y, const float* vspk,
     dim3 grid(nblk, B);
     const float scale = 1.0f / ((float)B * (float)TF * S);
     const bool from_u = emb_is_u != 0, vec = l41_vec(emb, demb);
-    AMS_L41_DISPATCH(true, false, emb, y, vspk, upstream, (float*)nullptr, demb, (float*)ws, TF, S, nblk, scale, NegArgs{})
-    hipLaunchKernelGGL(l41_dvs_final_kernel, dim3(ceil_div(B * S * E, 256)), dim3(256), 0, st, (const float*)ws, dvspk, nblk, S * E, B);
+    float* const amax_part = amax_out ? (float*)ws + (size_t)B * nblk * S * E : nullptr;
+    AMS_L41_DISPATCH(true, false, emb, y, vspk, upstream, (float*)nullptr, demb, (float*)ws, amax_part, TF, S, nblk, scale, NegArgs{})
+    hipLaunchKernelGGL(l41_dvs_final_kernel, dim3(ceil_div(B * S * E, 256)), dim3(256), 0, st, (const float*)ws, dvspk, nblk, S * E, B,
+                       (const float*)amax_part, amax_out);
     return ams_check_launch();
 }
 
 // ---- the same loss with negative sampling (models/L41.py:69-147,165-166).  negs [B,NSEL,K,E]: NSEL = 1 or S, NSEL * K <= 32, K <= 16.
 size_t ams_l41_ns_workspace_bytes(int B, long TF, int E, int S, int NSEL, int K) {
     const int nblk = ceil_div(TF, 256);
-    return sizeof(float) * (size_t)B * nblk * ((size_t)S * E + (size_t)NSEL * K * E);
+    return sizeof(float) * (size_t)B * nblk * ((size_t)S * E + (size_t)NSEL * K * E + 1);
 }
 
 ams_status ams_l41_loss_ns_fwd(const float* emb, const float* y, const float* vspk, const float* negs, float* cost, int B, long TF, int E,
@@ -269,15 +316,15 @@ ams_status ams_l41_loss_ns_fwd(const float* emb, const float* y, const float* vs
     const float scale = 1.0f / ((float)B * (float)TF * S);
     NegArgs na{negs, nullptr, NSEL, K, ns_rate * (float)S / (float)K};
     const bool from_u = emb_is_u != 0, vec = l41_vec(emb, emb);
-    AMS_L41_DISPATCH(false, true, emb, y, vspk, (const float*)nullptr, (float*)ws, (float*)nullptr, (float*)nullptr, TF, S, nblk, scale, na)
+    AMS_L41_DISPATCH(false, true, emb, y, vspk, (const float*)nullptr, (float*)ws, (float*)nullptr, (float*)nullptr, (float*)nullptr, TF, S, nblk, scale, na)
     hipLaunchKernelGGL(l41_cost_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, cost, (long)B * nblk, scale);
     return ams_check_launch();
 }
 
 // demb [B,TF,E], dvspk [B,S,E], dnegs [B,NSEL,K,E]
 ams_status ams_l41_loss_ns_bwd(const float* emb, const float* y, const float* vspk, const float* negs, const float* upstream, float* demb,
-                               float* dvspk, float* dnegs, int B, long TF, int E, int S, int NSEL, int K, float ns_rate, int emb_is_u,
-                               void* ws, size_t ws_bytes, void* stream) {
+                               float* dvspk, float* dnegs, float* amax_out, int B, long TF, int E, int S, int NSEL, int K, float ns_rate,
+                               int emb_is_u, void* ws, size_t ws_bytes, void* stream) {
     AMS_REQUIRE(emb && y && vspk && negs && upstream && demb && dvspk && dnegs && ws && B > 0 && TF > 0 && S > 0 && S <= MAXS);
     AMS_REQUIRE((NSEL == 1 || NSEL == S) && K > 0 && K <= MAXK && NSEL * K <= MAXN);
     if (ws_bytes < ams_l41_ns_workspace_bytes(B, TF, E, S, NSEL, K)) return AMS_E_WORKSPACE_TOO_SMALL;
@@ -289,10 +336,13 @@ ams_status ams_l41_loss_ns_bwd(const float* emb, const float* y, const float* vs
     float* dneg_part = dvs_part + (size_t)B * nblk * S * E;
     NegArgs na{negs, dneg_part, NSEL, K, ns_rate * (float)S / (float)K};
     const bool from_u = emb_is_u != 0, vec = l41_vec(emb, demb);
-    AMS_L41_DISPATCH(true, true, emb, y, vspk, upstream, (float*)nullptr, demb, dvs_part, TF, S, nblk, scale, na)
-    hipLaunchKernelGGL(l41_dvs_final_kernel, dim3(ceil_div(B * S * E, 256)), dim3(256), 0, st, (const float*)dvs_part, dvspk, nblk, S * E, B);
+    float* const amax_part = amax_out ? dneg_part + (size_t)B * nblk * NSEL * K * E : nullptr;
+    AMS_L41_DISPATCH(true, true, emb, y, vspk, upstream, (float*)nullptr, demb, dvs_part, amax_part, TF, S, nblk, scale, na)
+    hipLaunchKernelGGL(l41_dvs_final_kernel, dim3(ceil_div(B * S * E, 256)), dim3(256), 0, st, (const float*)dvs_part, dvspk, nblk, S * E, B,
+                       (const float*)amax_part, amax_out);
     const int NE = NSEL * K * E;
-    hipLaunchKernelGGL(l41_dvs_final_kernel, dim3(ceil_div(B * NE, 256)), dim3(256), 0, st, (const float*)dneg_part, dnegs, nblk, NE, B);
+    hipLaunchKernelGGL(l41_dvs_final_kernel, dim3(ceil_div(B * NE, 256)), dim3(256), 0, st, (const float*)dneg_part, dnegs, nblk, NE, B,
+                       (const float*)nullptr, (float*)nullptr);
     return ams_check_launch();
 }
 

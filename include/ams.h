@@ -415,8 +415,11 @@ ams_status ams_cplx_apply_bwd(const float* dz, const float* phasor, float* dsep,
 size_t ams_l41_workspace_bytes(int B, long TF, int E, int S);
 ams_status ams_l41_loss_fwd(const float* emb, const float* y, const float* vspk, float* cost, int B, long TF, int E, int S, int emb_is_u,
                             void* ws, size_t ws_bytes, void* stream);
+/* amax_out (ABI 4; optional, both backward entry points): ONE float that receives max |demb| of the launch -- the operand bound of the
+ * two dense-layer products that read demb, without a pass over it (839 MB at cfg5); folded from per-block maxima by the launch's own
+ * finishing kernel: nothing to clear, deterministic. */
 ams_status ams_l41_loss_bwd(const float* emb, const float* y, const float* vspk, const float* upstream, float* demb, float* dvspk,
-                            int B, long TF, int E, int S, int emb_is_u, void* ws, size_t ws_bytes, void* stream);
+                            float* amax_out, int B, long TF, int E, int S, int emb_is_u, void* ws, size_t ws_bytes, void* stream);
 /* ... with negative sampling (--sampling K)   models/L41.py:69-147,165-166:
  *   cost[b,t,f] += ns_rate * mean_k -log(sigmoid(-<negs[b, sel, k, :], emb[b,t,f,:]>))
  * negs [B,NSEL,K,E] = rows of the (normalised) speaker table the caller gathered: NSEL = 1 -- one set per utterance, ns_method
@@ -426,8 +429,8 @@ size_t ams_l41_ns_workspace_bytes(int B, long TF, int E, int S, int NSEL, int K)
 ams_status ams_l41_loss_ns_fwd(const float* emb, const float* y, const float* vspk, const float* negs, float* cost, int B, long TF, int E,
                                int S, int NSEL, int K, float ns_rate, int emb_is_u, void* ws, size_t ws_bytes, void* stream);
 ams_status ams_l41_loss_ns_bwd(const float* emb, const float* y, const float* vspk, const float* negs, const float* upstream, float* demb,
-                               float* dvspk, float* dnegs, int B, long TF, int E, int S, int NSEL, int K, float ns_rate, int emb_is_u,
-                               void* ws, size_t ws_bytes, void* stream);
+                               float* dvspk, float* dnegs, float* amax_out, int B, long TF, int E, int S, int NSEL, int K, float ns_rate,
+                               int emb_is_u, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- K16-K19 batched k-means   models/Kmeans_2.py:40-188 ----
  * xn [b,L,E] normalised input (ams_kmeans_normalize); rows r = b_idx*tries + try; centroids [b*tries, C, E];
