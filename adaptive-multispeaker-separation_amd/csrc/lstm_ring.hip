@@ -845,21 +845,29 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
 #endif
                 constexpr int PA[3] = {1, 0, 0};                // U plane: mid.hi, hi.mid, hi.hi
                 constexpr int PB[3] = {0, 1, 0};                // da plane
-                // the K = 16 chain first, then the K = 32 chain, apart: an accumulator handed DIRECTLY from one MFMA shape to the other
-                // came back wrong (the two opcodes differ in passes; back-to-back forwarding of SrcC is a same-opcode affair)
+                // Per tile TWO chains that never meet in the matrix pipe: the k-slots 8..11 on v_mfma_f32_16x16x16_f16, the k-slots 0..7 on
+                // v_mfma_f32_16x16x32_f16, each starting from the constant 0 and feeding only MFMAs of its OWN opcode; one VALU add
+                // joins them.  (An accumulator handed from one MFMA shape to the other came back wrong -- back-to-back forwarding of
+                // SrcC is a same-opcode affair -- and round 5 kept ONE chain per tile apart with a hand-counted `s_nop 15; s_nop 7`;
+                // a second accumulator SET, or a VALU pass between the chains, cost 24 / 6 registers and with them the workgroup's
+                // place beside two capped product workgroups: 2.63 -> 3.11 / 2.81 -> 3.28 ms per step, measured in round 6.)  Tile by
+                // tile the two partial sums are the only extra live registers, the chains of a tile alternate (a dependent MFMA is two
+                // issues behind its producer), and a finished tile leaves while the next one is in the pipe.
+                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                const unsigned pbase16 = (unsigned)((size_t)par * NW * NW * tile_f * 4u);
 #pragma unroll
-                for (int pp = 0; pp < 3; ++pp)
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(wr[i][PA[pp]], br[PB[pp]], acc[i], 0, 0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                asm volatile("s_nop 15\n\ts_nop 7" ::: "memory");
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int pp = 0; pp < 3; ++pp)
-#pragma unroll
-                    for (int i = 0; i < NI; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[i][PA[pp]], bq[PB[pp]], acc[i], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < NI; ++i) acc[i] = acc[i] * sc_inv;
+                for (int i = 0; i < NI; ++i) {                  // (two tiles at a time: 24 accumulator registers, 180 in all -- over the 176 the place beside the products allows)
+                    f32x4 r16 = __builtin_amdgcn_mfma_f32_16x16x16f16(wr[i][PA[0]], br[PB[0]], zero4, 0, 0, 0);
+                    f32x4 r32 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[i][PA[0]], bq[PB[0]], zero4, 0, 0, 0);
+                    r16 = __builtin_amdgcn_mfma_f32_16x16x16f16(wr[i][PA[1]], br[PB[1]], r16, 0, 0, 0);
+                    r32 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[i][PA[1]], bq[PB[1]], r32, 0, 0, 0);
+                    r16 = __builtin_amdgcn_mfma_f32_16x16x16f16(wr[i][PA[2]], br[PB[2]], r16, 0, 0, 0);
+                    r32 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wq[i][PA[2]], bq[PB[2]], r32, 0, 0, 0);
+                    acc[i] = (r16 + r32) * sc_inv;
+#ifndef AMS_RING_DBG_FINE
+                    if (toff[i] >= 0) st16(rs, pb, pbase16 + (unsigned)toff[i], ring_tag4(make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]), ring_phase(s)), fast);
+#endif
+                }
 #ifdef AMS_RING_DBG_FINE
 #pragma unroll
                 for (int i = 0; i < NI; ++i) asm volatile("" : "+v"(acc[i]));
@@ -879,6 +887,9 @@ __global__ __launch_bounds__(256) void lstm_ring_bwd_kernel(RingArgs a) {
             }
             // f32: tile column n16 of output tile tl = unit tl*16 + n16 -> consumer unit / 12, slot unit % 12; rows 4q..4q+3 contiguous
             const unsigned pbase = (unsigned)((size_t)par * NW * NW * tile_f * 4u);
+#ifndef AMS_RING_DBG_FINE
+            if constexpr (!F16)                                 // (the fp16x3 form stores every tile as it leaves the pipe, above)
+#endif
 #pragma unroll
             for (int i = 0; i < NI; ++i)
                 if (toff[i] >= 0) st16(rs, pb, pbase + (unsigned)toff[i], ring_tag4(make_float4(acc[i][0], acc[i][1], acc[i][2], acc[i][3]), ring_phase(s)), fast);
