@@ -91,6 +91,50 @@ def build(args, tmp):
     return trainer, tfds, dist
 
 
+def comm_record(dist, log_path):
+    """Who took part in the gradient exchange, as the process group and the collective library report it: backend, world size, every
+    rank's host / process / device (gathered over the process group itself), the library version, and -- RCCL -- rank 0's excerpt of
+    NCCL_DEBUG=INFO: the communicator's `Init COMPLETE` line (rank, nranks, device, bus id), the rings / trees it built, and the first
+    AllReduce line of the gradient buffer's size with the algorithm and protocol chosen for it."""
+    import socket
+    import torch
+    import torch.distributed as td
+    me = {'rank': dist.rank, 'host': socket.gethostname(), 'pid': os.getpid(), 'device': torch.cuda.current_device()}
+    try:
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+        me['device_name'] = pr.name
+        for k in ('uuid', 'pci_bus_id', 'pci_device_id', 'pci_domain_id'):
+            if hasattr(pr, k):
+                me[k] = str(getattr(pr, k))
+    except Exception:
+        pass
+    ranks = [None] * dist.world_size
+    td.all_gather_object(ranks, me)
+    rec = {'backend': td.get_backend(), 'world_size': td.get_world_size(), 'ranks': ranks,
+           'distinct_devices': len(set((r['host'], r.get('uuid') or r.get('pci_bus_id') or r['device']) for r in ranks))}
+    if rec['backend'] == 'nccl':
+        try:
+            rec['rccl_version'] = '.'.join(str(v) for v in torch.cuda.nccl.version())
+        except Exception:
+            pass
+    else:
+        rec['note'] = 'backend %s: not RCCL (several ranks sharing one GPU on a test box; AMS_DIST_BACKEND)' % rec['backend']
+    if dist.rank == 0 and log_path:
+        path = log_path.replace('%h', socket.gethostname()).replace('%p', str(os.getpid()))
+        try:
+            lines = open(path, errors='replace').read().splitlines()
+            pick = [ln for ln in lines if 'Init COMPLETE' in ln or 'nranks' in ln and 'Init START' in ln]
+            pick += [ln for ln in lines if ' Ring ' in ln or ' Trees ' in ln or 'Connected all' in ln][:6]
+            ar = [ln for ln in lines if 'AllReduce' in ln]
+            big = [ln for ln in ar if 'count %d' % 0 not in ln]
+            pick += big[-2:]
+            rec['rccl_debug_excerpt'] = [ln[-300:] for ln in pick[:14]]
+            rec['rccl_allreduce_lines'] = len(ar)
+        except Exception as e:
+            rec['rccl_debug_excerpt'] = 'unavailable (%s: %s)' % (type(e).__name__, e)
+    return rec
+
+
 def _newest_profile(suffix):
     """(parsed JSON, repo-relative path) of the newest profiles/rNN_<letter><suffix> (highest round, then highest letter), or (None, None)."""
     import glob
@@ -204,6 +248,15 @@ def main():
     import torch
     from ams_hip import ops
     tmp = tempfile.mkdtemp(prefix='ams_bench_')
+    nccl_log = None
+    if int(os.environ.get('WORLD_SIZE', '1')) > 1 and os.environ.get('AMS_DIST_BACKEND', 'nccl') == 'nccl':
+        # RCCL's own account of the communicator (ranks, devices, rings) and of the algorithm / protocol it picks for the gradient
+        # all-reduce goes to a file per rank; rank 0's excerpt is part of the JSON line (`comm`) -- the record that N ranks on N
+        # devices took part does not rest on this script's word alone.  (One log line per collective: nothing next to a 2.8 ms step.)
+        nccl_log = os.path.join(tmp, 'rccl_rank%s.log' % os.environ.get('RANK', '0'))
+        os.environ.setdefault('NCCL_DEBUG', 'INFO')
+        os.environ.setdefault('NCCL_DEBUG_SUBSYS', 'INIT,COLL,TUNING')
+        os.environ.setdefault('NCCL_DEBUG_FILE', nccl_log)
     import contextlib
     with contextlib.redirect_stdout(sys.stderr):        # the trainer echoes its config like the reference; stdout carries ONE JSON line
         trainer, tfds, dist = build(args, tmp)
@@ -457,6 +510,7 @@ def main():
         out['rank_ms_per_step'] = [round(float(v), 3) for v in per_rank.cpu().numpy()]
         out['exposed_allreduce_ms'] = round(float(exch.item()), 4)
         out['allreduce_bytes'] = int(model.optimize._gbuf.numel() * 4)
+        out['comm'] = comm_record(dist, nccl_log if os.environ.get('NCCL_DEBUG_FILE') == nccl_log else os.environ.get('NCCL_DEBUG_FILE'))
     if rank == 0:
         if world == 1 and not args.no_secondary and (B, L, N) == (64, 20480, 256):
             # BASELINE configs[2] names the fine-tuning flavour of the same model; SURVEY 8(d) makes cfg3(i) the headline and

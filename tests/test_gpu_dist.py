@@ -125,6 +125,21 @@ def test_bench_spawns_the_ranks_it_is_asked_for():
     assert j['n_gpus'] == 2 and j['steps'] == 3 and j['warmup'] == 1
     assert j['config']['global_batch'] == 8 and j['config']['parallelism'] == 'dp2'
     assert j['value'] > 0 and np.isfinite(j['final_cost'])
+    # the exchange's own record: backend, world size and one entry per rank as gathered over the process group (RCCL runs add its
+    # NCCL_DEBUG=INFO excerpt: `Init COMPLETE ... nranks N`, rings, the all-reduce's algorithm and protocol)
+    comm = j['comm']
+    assert comm['backend'] == 'gloo' and comm['world_size'] == 2 and sorted(r['rank'] for r in comm['ranks']) == [0, 1]
+    assert len(set(r['pid'] for r in comm['ranks'])) == 2 and 'not RCCL' in comm['note']
+    assert len(j['rank_ms_per_step']) == 2 and j['allreduce_bytes'] > 0
+    # strong scaling: the global batch is fixed and split over the ranks; `value` counts the global batch once per step
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1', '--batch', '8',
+                        '--scaling', 'strong', '--chunk', '4096', '--no-cpu-baseline', '--no-secondary', '--no-native-f32',
+                        '--roofline-steps', '0', '--quiet'], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    js = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][0])
+    assert js['scaling'] == 'strong' and js['n_gpus'] == 2
+    assert js['config']['global_batch'] == 8 and js['config']['batch_per_gpu'] == 4
+    assert abs(js['value'] - 8 * js['steps'] / (js['ms_per_step'] * 1e-3 * js['steps'])) <= 1e-3 * js['value']
     # a launcher that started a different number of ranks than --gpus is an error, not a silently wrong n_gpus
     env1 = dict(env, WORLD_SIZE='1', RANK='0', LOCAL_RANK='0')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0', '--batch', '4',
