@@ -410,6 +410,209 @@ __global__ __launch_bounds__(256) void dpcl_gram_u_kernel(const float* __restric
     dpcl_finish_batch(fin.per_utt, fin.out, fin.ticket, fin.clear, fin.B, &last_sh, red, PTS * ZP);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// The fused forward pass with its Gram on the 16-bit matrix pipe (round 6; E = 40, S <= 4, 16-byte aligned U).
+// dpcl_gram_u_kernel above spends 29 of its 74 us in v_mfma_f32_16x16x4_f32 (four points per instruction, MfmaUtil 0.32) and the
+// memory side another 45: neither saturated, and the phases of a slab -- stage, norm, MFMA -- add.  Here the augmented points
+//   z'_p = sqrt(D_p) [v_p | y_p]      (Z^T D Z = Z'^T Z': ONE operand, |z'| <= 1: a constant scale 2^13, no bound to measure)
+// are cut ONCE per element into two fp16 terms (fp16x3: hi.hi + hi.lo + lo.hi, f32 accumulation, as csrc/gemm.hip) and laid down
+// TRANSPOSED -- per plane [feature][point], 2 points per dword -- so that an operand of v_mfma_f32_16x16x32_f16 (lane: feature
+// lane & 15, eight consecutive points) is one ds_read_b128 and 32 points cost a wave 18 MFMAs of 4 passes instead of 48 of 8.
+// Two threads per point do norm and cut together: each sums 20 features, the pair meets by DPP, and pairs of neighbouring points swap
+// what the other one writes (DPP again), so every thread writes ten dwords per plane.  128 points per slab, one 32-point group per
+// wave; everything around it (label counts, chunk partials in chunk order, the in-launch finish) is dpcl_gram_u_kernel's.
+typedef _Float16 dp_f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 dp_f16x2 __attribute__((ext_vector_type(2)));
+typedef float dp_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned dp_pk_f16(float a, float b) {
+    const dp_f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, dp_f16x2));
+}
+__device__ __forceinline__ void dp_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = dp_pk_f16(a, b);
+    const dp_f16x2 h = __builtin_bit_cast(dp_f16x2, hi);
+    lo = dp_pk_f16(a - (float)h[0], b - (float)h[1]);
+}
+__device__ __forceinline__ float dp_lane_xor1(float v) {      // quad_perm [1,0,3,2]
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float dp_lane_xor2(float v) {      // quad_perm [2,3,0,1]
+    return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, true));
+}
+
+template <int EC, int SC>
+__global__ __launch_bounds__(256) void dpcl_gram_u16_kernel(const float* __restrict__ U, const float* __restrict__ Y,
+                                                            const float* __restrict__ cntp, float* __restrict__ inv_out,
+                                                            float* __restrict__ V_out, float* __restrict__ part, long TF, int nchunk,
+                                                            GramFinish fin) {
+    constexpr int E = EC, S = SC, NT = 3, Z = NT * 16, ZP = Z + 4;
+    constexpr int PTS = 128;                        // points per slab: one 32-point group per wave
+    constexpr int NV = PTS * E / 4 / 256;           // 16-byte loads per thread and slab
+    constexpr int HP = PTS * 2 + 16;                // bytes per feature row of a plane: + 16 -> the 16 rows of a ds_read_b128 group are 16 different slots
+    constexpr int HF = E / 2, QF = HF / 2;          // features per thread of a point's pair; features a thread WRITES (for two points)
+    static_assert(E % 8 == 0 && (PTS * E / 4) % 256 == 0 && E + S <= Z && S <= 4, "dpcl_gram_u16_kernel: E = 40-like shapes only");
+    static_assert(Z * Z <= PTS * ZP, "the final reduce reuses the raw slab");
+    __shared__ __attribute__((aligned(16))) float zt[PTS * ZP];                 // raw points [u | y | 0]; reused for the final reduce
+    __shared__ __attribute__((aligned(16))) unsigned char zh[2 * Z * HP];       // planes hi | lo of z' * 2^13, [feature][point]
+    __shared__ float dsh[PTS], ivs[PTS];
+    const int b = blockIdx.y, c = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int e_lo = lane & 15, slot = lane >> 4;
+    for (int i = tid; i < PTS * ZP; i += 256) zt[i] = 0.f;                     // padding columns stay zero
+    for (int i = tid; i < 2 * Z * HP / 4; i += 256) reinterpret_cast<unsigned*>(zh)[i] = 0u;     // padding features stay zero
+
+    float cn[8];
+    load_counts(cntp, b, S, cn);
+
+    f32x4 acc[NT][NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const long p_begin = (long)c * UCHUNK, p_end = min(TF, p_begin + UCHUNK);
+    const float* Ub = U + (long)b * TF * E;
+    const float* Yb = Y + (long)b * TF * S;
+
+    float4 pre[NV];
+    float yv[S];
+    auto fetch = [&](long p0) {                     // unconditional loads on clamped indices (see dpcl_gram_u_kernel)
+        const int npts = (int)min((long)PTS, p_end - p0);
+        const float4* src = reinterpret_cast<const float4*>(Ub + p0 * E);
+        const int last = npts * E / 4 - 1;
+#pragma unroll
+        for (int j = 0; j < NV; ++j) pre[j] = src[min(tid + 256 * j, last)];
+        if (tid < PTS) {
+            const float* yr = Yb + (p0 + min(tid, npts - 1)) * S;
+#pragma unroll
+            for (int s = 0; s < S; ++s) yv[s] = yr[s];
+        }
+    };
+
+    const int pnt2 = tid >> 1, half = tid & 1, odd = pnt2 & 1;
+    if (p_begin < p_end) fetch(p_begin);
+    for (long p0 = p_begin; p0 < p_end; p0 += PTS) {
+        const int npts = (int)min((long)PTS, p_end - p0);
+        __syncthreads();                            // MFMA phase of the previous slab is done with zh, the cut with zt
+#pragma unroll
+        for (int j = 0; j < NV; ++j) {
+            const int i4 = tid + 256 * j;
+            const int pnt = (i4 * 4) / E, e = i4 * 4 - pnt * E;
+            *reinterpret_cast<float4*>(&zt[pnt * ZP + e]) = (i4 * 4 < npts * E) ? pre[j] : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (tid < PTS) {
+            float diag = 0.f;
+#pragma unroll
+            for (int s = 0; s < S; ++s) { const float y = tid < npts ? yv[s] : 0.f; zt[tid * ZP + E + s] = y; diag += y * cn[s]; }
+            dsh[tid] = (tid < npts && diag > 0.f) ? 1.0f / sqrtf(diag) : 0.f;    // all-zero Y row: reference has D = inf
+        }
+        __syncthreads();
+        if (p0 + PTS < p_end) fetch(p0 + PTS);      // in flight during everything below
+        {
+            // norm + cut: thread (point pnt2, half): features HF half .. HF half + HF - 1 of its point
+            float v[HF];
+            const float4* row = reinterpret_cast<const float4*>(&zt[pnt2 * ZP + half * HF]);
+#pragma unroll
+            for (int q = 0; q < HF / 4; ++q) { const float4 t = row[q]; v[4 * q] = t.x; v[4 * q + 1] = t.y; v[4 * q + 2] = t.z; v[4 * q + 3] = t.w; }
+            float ss = 0.f;
+#pragma unroll
+            for (int k = 0; k < HF; ++k) ss += v[k] * v[k];
+            ss += dp_lane_xor1(ss);
+            const float iv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));   // tf.nn.l2_normalize epsilon (utils/ops.py:323)
+            if (half == 0) {
+                ivs[pnt2] = iv;
+                if (inv_out && pnt2 < npts) inv_out[(long)b * TF + p0 + pnt2] = iv;
+            }
+            const float sd = sqrtf(dsh[pnt2]) * 8192.0f;        // sqrt(D_p) * 2^13 (0 for points past the end and all-zero label rows)
+            const float sc = iv * sd;
+#pragma unroll
+            for (int k = 0; k < HF; ++k) v[k] *= sc;
+            unsigned char* const wbase = zh + (half * HF + odd * QF) * HP + (pnt2 >> 1) * 4;
+#pragma unroll
+            for (int k = 0; k < QF; ++k) {
+                const float own = odd ? v[QF + k] : v[k];       // what this thread writes: its point's feature ...
+                const float give = odd ? v[k] : v[QF + k];      // ... and what the neighbouring point's thread writes
+                const float got = dp_lane_xor2(give);
+                unsigned hi, lo;
+                dp_split2(odd ? got : own, odd ? own : got, hi, lo);           // (even point, odd point)
+                *reinterpret_cast<unsigned*>(wbase + k * HP) = hi;
+                *reinterpret_cast<unsigned*>(wbase + k * HP + Z * HP) = lo;
+            }
+            if (half == 1) {                                    // the label columns: S features, written by the even point's thread
+#pragma unroll
+                for (int s = 0; s < S; ++s) {
+                    const float own = zt[pnt2 * ZP + E + s] * sd;
+                    const float got = dp_lane_xor2(own);
+                    unsigned hi, lo;
+                    dp_split2(own, got, hi, lo);
+                    if (!odd) {
+                        *reinterpret_cast<unsigned*>(zh + (E + s) * HP + (pnt2 >> 1) * 4) = hi;
+                        *reinterpret_cast<unsigned*>(zh + (E + s) * HP + (pnt2 >> 1) * 4 + Z * HP) = lo;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (V_out) {
+            float* dst = V_out + ((long)b * TF + p0) * E;
+            for (int i = tid; i < npts * E; i += 256) {
+                const int pnt = i / E, e = i - pnt * E;
+                dst[i] = zt[pnt * ZP + e] * ivs[pnt];
+            }
+        }
+        {
+            // wave w: points 32 w .. 32 w + 31; lane (feature e_lo of a tile, points 8 slot .. 8 slot + 7)
+            const unsigned char* const rb = zh + e_lo * HP + (32 * wave + 8 * slot) * 2;
+            dp_f16x8 a[NT][2];
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int p = 0; p < 2; ++p) a[ti][p] = *reinterpret_cast<const dp_f16x8*>(rb + ti * 16 * HP + p * Z * HP);
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = ti; tj < NT; ++tj) {
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ti][1], a[tj][0], acc[ti][tj], 0, 0, 0);
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ti][0], a[tj][1], acc[ti][tj], 0, 0, 0);
+                    acc[ti][tj] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[ti][0], a[tj][0], acc[ti][tj], 0, 0, 0);
+                }
+        }
+    }
+    __syncthreads();
+    float* red = zt;                                // Z*Z <= PTS*ZP
+    for (int i = tid; i < Z * Z; i += 256) red[i] = 0.f;
+    __syncthreads();
+    constexpr float UNSCALE = 1.0f / (8192.0f * 8192.0f);
+    for (int w = 0; w < 4; ++w) {                   // fixed order: waves add one after another, mirrored tiles
+        if (wave == w) {
+#pragma unroll
+            for (int ti = 0; ti < NT; ++ti)
+#pragma unroll
+                for (int tj = ti; tj < NT; ++tj)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int row = ti * 16 + slot * 4 + r, col = tj * 16 + e_lo;
+                        const float g = acc[ti][tj][r] * UNSCALE;
+                        red[row * Z + col] += g;
+                        if (tj != ti) red[col * Z + row] += g;
+                    }
+        }
+        __syncthreads();
+    }
+    float* out = part + ((long)b * nchunk + c) * (Z * Z);
+    for (int i = tid; i < Z * Z; i += 256) __hip_atomic_store(out + i, red[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+
+    __shared__ float sm[3][16];
+    __shared__ int last_sh;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (tid == 0) last_sh = (atomicAdd(fin.ticket + 1 + b, 1u) == (unsigned)nchunk - 1u) ? 1 : 0;
+    __syncthreads();
+    if (!last_sh) return;                           // uniform over the workgroup
+    dpcl_finish_utterance<true>(part, fin.per_utt, fin.mats, E, S, Z, nchunk, fin.B, b, red, sm);
+    dpcl_finish_batch(fin.per_utt, fin.out, fin.ticket, fin.clear, fin.B, &last_sh, red, PTS * ZP);
+}
+
 // Per utterance: reduce chunk partials (fixed order), Frobenius norms, cost_b, normalised matrices for bwd.  Called by all
 // threads of a workgroup (any size that is a multiple of 64, <= 1024); gram = Z*Z floats of LDS, sm = 3 x 16 floats of LDS.
 // IN_LAUNCH: the partials were stored by other workgroups of the SAME launch (agent-scope stores): read them with agent-scope loads.
@@ -1021,6 +1224,12 @@ __global__ __launch_bounds__(256) void dpcl_bwd_u2_kernel(const float* __restric
     }
 }
 
+// AMS_DPCL_GRAM_F16=0 (read once): the fused forward keeps its Gram on v_mfma_f32_16x16x4_f32 (A/B runs; the tests hold both)
+inline bool dpcl_gram_f16() {
+    static const bool v = !(getenv("AMS_DPCL_GRAM_F16") && atoi(getenv("AMS_DPCL_GRAM_F16")) == 0);
+    return v;
+}
+
 // AMS_DPCL_LDS=1 (read once): the LDS-staged passes of round 2 also where the direct ones apply (A/B runs, tests hold both)
 inline bool dpcl_direct() {
     static const bool v = !(getenv("AMS_DPCL_LDS") && atoi(getenv("AMS_DPCL_LDS")) != 0);
@@ -1144,7 +1353,9 @@ ams_status ams_dpcl_loss_fwd_u(const float* U, const float* Y, float* inv, float
         case 2: hipLaunchKernelGGL((dpcl_gram_u_kernel<2, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk, fin); break;
         case 3: {
             const bool al = (((uintptr_t)U & 15) == 0);
-            if (E == 40 && S == 2 && al) hipLaunchKernelGGL((dpcl_gram_u_kernel<3, 40, 2>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk, fin);
+            if (E == 40 && S == 2 && al && dpcl_gram_f16()) hipLaunchKernelGGL((dpcl_gram_u16_kernel<40, 2>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, nchunk, fin);
+            else if (E == 40 && S == 3 && al && dpcl_gram_f16()) hipLaunchKernelGGL((dpcl_gram_u16_kernel<40, 3>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, nchunk, fin);
+            else if (E == 40 && S == 2 && al) hipLaunchKernelGGL((dpcl_gram_u_kernel<3, 40, 2>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk, fin);
             else if (E == 40 && S == 3 && al) hipLaunchKernelGGL((dpcl_gram_u_kernel<3, 40, 3>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk, fin);
             else hipLaunchKernelGGL((dpcl_gram_u_kernel<3, 0, 0>), grid, dim3(256), 0, st, U, Y, cntp, inv, V_out, part, TF, E, S, nchunk, fin);
             break;

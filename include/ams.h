@@ -27,7 +27,7 @@
  *   recurrence (lstm*.hip)     AMS_LSTM_RING_X6, AMS_LSTM_RING_F16, AMS_LSTM_RING_BWD_F16 (arithmetic of the rings' recurrent products),
  *                              AMS_LSTM_RING_SAFE (write-through hand-off), AMS_LSTM_RING_CUS (pretend a smaller device: fallback tests),
  *                              AMS_LSTM_XCD, AMS_LSTM_FWD_PIPE (per-step fallback kernels: grid order, fetch pipelining)
- *   losses / k-means           AMS_DPCL_LDS (1 = LDS-staged DPCL passes),
+ *   losses / k-means           AMS_DPCL_LDS (1 = LDS-staged DPCL passes), AMS_DPCL_GRAM_F16 (0 = the fused forward's Gram on the f32 MFMA),
  *                              AMS_KM_TRIES (0 = one workgroup per try), AMS_KM_SOFT (0 = soft accumulation inside kmeans_pass_kernel)
  */
 #ifndef AMS_H
