@@ -708,19 +708,24 @@ def _ps_weight_image(W2, amax_w, owner):
     return img
 
 
+def forward_product_presplit(M, N, K, out, bias, amax, label, ldc):
+    """Does out[M, N] = x . W (+ bias) run from pre-split operand images?  Both operand bounds at hand, fp16x3 not denied for this
+    product class, no audit in progress, no residency cap, 16-byte addressable output; K may be anything (the images pad it)."""
+    key = ('gemm', label, M, N, K, False, False)
+    return (PRESPLIT and amax is not None and amax[0] is not None and amax[1] is not None and key not in F16_AUDIT.denied
+            and not F16_AUDIT.active and LDS_PAD[0] == 0 and N % 4 == 0 and ldc % 4 == 0 and out.data_ptr() % 16 == 0
+            and (bias is None or bias.data_ptr() % 16 == 0) and max(M, N) * ((K + 31) // 32 * 128) < 2 ** 31
+            and load().ams_gemm_get_arith() != 0)
+
+
 def forward_product(x2, W2, bias, out, amax, label, owner, ldc=None):
-    """out[M, N] = x2 [M, K] . W2 [K, N] + bias: the forward products of the path (BLSTM input projection, Conv1D).  With both operand
-    bounds at hand and fp16x3 not denied for this product class: from pre-split operand images (csrc/gemm_ps.hip) -- x2's image is the
-    one its producer attached (tag_ps_image) or is cut here, W2's is cut once per pass; otherwise ams_gemm_f32."""
+    """out[M, N] = x2 [M, K] . W2 [K, N] + bias: the forward products of the path (BLSTM input projection, Conv1D).  From pre-split
+    operand images (csrc/gemm_ps.hip) where forward_product_presplit() says so -- x2's image is the one its producer attached
+    (tag_ps_image) or is cut here, W2's is cut once per pass; otherwise ams_gemm_f32."""
     M, K = x2.shape
     N = W2.shape[1]
     ldc = (out.stride(0) if out.dim() == 2 else N) if ldc is None else ldc
-    key = ('gemm', label, M, N, K, False, False)
-    use = (PRESPLIT and amax is not None and amax[0] is not None and amax[1] is not None and key not in F16_AUDIT.denied
-           and not F16_AUDIT.active and LDS_PAD[0] == 0 and N % 4 == 0 and ldc % 4 == 0 and out.data_ptr() % 16 == 0
-           and (bias is None or bias.data_ptr() % 16 == 0) and x2.stride(1) == 1 and W2.stride(1) == 1
-           and max(M, N) * ((K + 31) // 32 * 128) < 2 ** 31 and load().ams_gemm_get_arith() != 0)
-    if not use:
+    if not (forward_product_presplit(M, N, K, out, bias, amax, label, ldc) and x2.stride(1) == 1 and W2.stride(1) == 1):
         return gemm(x2, W2, bias=bias, out=out, M=M, N=N, K=K, lda=x2.stride(0), ldb=W2.stride(0), ldc=ldc, label=label, amax=amax)
     a_img = _ps_rows_image(x2, amax[0])
     b_img = _ps_weight_image(W2, amax[1], owner)
@@ -932,7 +937,7 @@ def blstm_fwd(x, Kf, bf, Kb, bb, amax=None):
     # ring recurrence: plane 0 = c_t (what every backward reads as `cst`), plane 1 = tanh(c_t) for the backward ring
     cst = torch.empty(((2, B, T, 2, H) if nring else (B, T, 2, H)), dtype=torch.float32, device=x.device)
     Dp = (D + 3) // 4 * 4
-    if Dp != D and x.is_cuda:
+    if Dp != D and x.is_cuda and not forward_product_presplit(B * T, 8 * H, D, G, bias, amax, 'blstm_input_gemm', 8 * H):
         # rows of D floats are not 16-byte addressable: project zero-padded copies (x: +3 zero columns, kernels: +3 zero rows)
         Wp = torch.zeros((Dp, 8 * H), dtype=Wcat.dtype, device=Wcat.device)
         Wp[:D].copy_(Wcat)
