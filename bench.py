@@ -379,9 +379,11 @@ def main():
         if not x6:
             kdesc = 'gemm_f32_kernel (v_mfma_f32_32x32x2_f32)'
         elif fl16 > 0.5 * prof['flops']:
-            kdesc = ('gemm_x6_kernel<.., F16=true> (fp16x3: 3 x v_mfma_f32_32x32x16_f16 per f32 product -- both operands scaled by a power of '
-                     'two from a per-tensor bound and split exactly into two fp16 terms, f32 accumulate; %.1f %% of the family\'s flops, the '
-                     'rest bf16x6)' % (100.0 * fl16 / prof['flops']))
+            kdesc = ('gemm_x6_kernel<.., F16=true> + gemm_ps_kernel (fp16x3: 3 x v_mfma_f32_32x32x16_f16 per f32 product -- both operands scaled '
+                     'by a power of two from a per-tensor bound and split exactly into two fp16 terms, f32 accumulate; the forward products '
+                     'from operand images cut once per step, csrc/gemm_ps.hip: %.1f %% of the family\'s flops; fp16x3 in all %.1f %%, the rest '
+                     'bf16x6)' % (100.0 * sum(ops.PROFILE.summary(t)['flops'] for t in ops.PROFILE.tags() if t.startswith('gemm16ps')) / prof['flops'],
+                                  100.0 * fl16 / prof['flops']))
         else:
             kdesc = kname + ' (6 x v_mfma_f32_32x32x16_bf16 per f32 product: exact 3-way bf16 operand split, f32 accumulate)'
         roof = {'bound': 'mfma', 'kernel': kdesc, 'achieved': round(achieved, 2),
@@ -405,7 +407,7 @@ def main():
         # counters were collected at.  null for any other shape or when no summary is committed.
         tj, tfile = _newest_profile('_hbm_traffic.json')
         if tj is not None and (B, L, N) == (64, 20480, 256):
-            gk = [v for k, v in tj.items() if k.startswith(kname) and isinstance(v, dict)]
+            gk = [v for k, v in tj.items() if (k.startswith(kname) or k.startswith('gemm_ps_kernel')) and isinstance(v, dict)]
             calls = sum(v['calls'] for v in gk)
             if calls:
                 mb = sum(v['calls'] * (v['read_MB_per_launch'] + v['write_MB_per_launch']) for v in gk) / calls
@@ -482,7 +484,8 @@ def main():
     if pi['launches']:
         t = pi['ms'] * 1e-3
         targets['blstm_input_gemm'] = {
-            'kernel': kname + '<A_ROW,B_ROW>, both directions in one [B*T, D] x [D, 8H] product',
+            'kernel': ('gemm_ps_kernel (pre-split fp16 operand images, LDS-DMA main loop)' if any(t.startswith('gemm16ps') for t in ops.PROFILE.tags())
+                       else kname + '<A_ROW,B_ROW>') + ', both directions in one [B*T, D] x [D, 8H] product',
             'avg_launch_us': round(pi['ms'] / pi['launches'] * 1e3, 2), 'TFLOP/s': round(pi['flops'] / t / 1e12, 2),
             'mfma_frac': round(pi['flops'] / t / 1e12 / ((MFMA_BF16_PEAK_TFLOPS / (3.0 if fl16 > 0 else 6.0)) if x6 else MFMA_F32_PEAK_TFLOPS), 4),
             'arithmetic': ('fp16x3 (3 MFMA products per f32 product)' if fl16 > 0 else 'bf16x6') if x6 else 'native f32 MFMA',

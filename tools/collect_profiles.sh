@@ -12,5 +12,6 @@ done
 cp $G/cfg_STFT_L41_enhance_hbm_traffic.txt $P/${T}_cfg_STFT_L41_enhance_hbm_traffic.txt
 cp $G/cfg_front_L41_S3_N512_B128_hbm_traffic.txt $P/${T}_cfg_front_L41_S3_N512_B128_hbm_traffic.txt
 cp $G/${T}_other_configs.jsonl $P/${T}_other_configs.jsonl
+cp $G/${T}_other_configs_reference_seeding.jsonl $P/${T}_other_configs_reference_seeding.jsonl 2>/dev/null
 cp $G/${T}_gpu_suite.txt $P/${T}_gpu_suite.txt
 ls $P | grep ${T}

@@ -33,12 +33,12 @@ def main():
     pos = None
     for d, name, gx, wx, cn, v in sorted(rows, key=lambda r: r[0]):
         if d not in disp:
-            m = re.search(r'gemm_(f32|x6|x3)_kernel<[^>]*>', name)
+            m = re.search(r'gemm_(f32|x6|x3)_kernel<[^>]*>|gemm_ps_kernel', name)
             if m is None:
                 key = name.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:60]
             else:
                 # a product launch is named by its position in the step's product sequence (tools/pmc_summary.py: STEP_SEQUENCE)
-                what, pos = step_label(m.group(0).split('kernel')[1], pos)
+                what, pos = step_label(m.group(0).split('kernel')[1] or '<ps>', pos)
                 key = '%s grid=%d%s' % (m.group(0), int(gx) // max(1, int(wx)), (' [' + what + ']') if what else '')
             disp[d] = {'key': key}
         e = disp[d]

@@ -24,7 +24,8 @@ STEP_SEQUENCE = ['front conv 15360x256x1024 (stream-K)', 'projection L0 5120x240
                  'LSTM dWx L0 256x2400x5120']
 # the variant each position is launched as (A loader, B loader, ..., two accumulator sets): a step whose sequence differs (the first
 # pass of a model, bench.py's side-stream-off 'alone' step) is left unlabelled instead of mislabelled
-STEP_VARIANT = ['<2, 0', '<0, 0', '<0, 0', '<0, 0', '<0, 0', '<0, 1', '<1, 0, 3, 0, false', '<0, 1', '<1, 0, 3, 0, false', '<1, 0, 3, 0, false',
+# (round 6: the four forward products run from pre-split operand images, csrc/gemm_ps.hip: variant '<ps>')
+STEP_VARIANT = ['<2, 0', '<ps>', '<ps>', '<ps>', '<ps>', '<0, 1', '<1, 0, 3, 0, false', '<0, 1', '<1, 0, 3, 0, false', '<1, 0, 3, 0, false',
                 '<1, 0, 3, 0, false', '<0, 1', '<1, 0, 3, 0, false', '<1, 0, 3, 0, false', '<1, 0, 3, 0, false', '<1, 0, 3, 0, true', '<1, 0, 3, 0, true']
 
 
@@ -48,12 +49,12 @@ def per_kernel(path, counter):
     pos = None
     for name, gx, wx, v, _ in rows:
         # the product family runs many shapes under one name: keep them apart by their position in the step (see STEP_SEQUENCE)
-        m = re.search(r'gemm_(f32|x6|x3)_kernel<[^>]*>', name)
+        m = re.search(r'gemm_(f32|x6|x3)_kernel<[^>]*>|gemm_ps_kernel', name)
         if m is None:
             key = name
         else:
             nwg = int(gx) // max(1, int(wx))
-            what, pos = step_label(m.group(0).split('kernel')[1], pos)
+            what, pos = step_label(m.group(0).split('kernel')[1] or '<ps>', pos)
             key = '%s grid=%d%s' % (m.group(0), nwg, (' [' + what + ']') if what else '')
         out.setdefault(key, []).append(float(v))
     return out
