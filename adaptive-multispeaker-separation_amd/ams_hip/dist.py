@@ -94,6 +94,14 @@ class Dist(object):
             return box[0]
         return obj
 
+    def all_gather_object(self, obj):
+        """[obj of rank 0, ..., obj of rank world - 1] (small picklable host objects)."""
+        if not self.enabled:
+            return [obj]
+        out = [None] * self.world_size
+        td.all_gather_object(out, obj)
+        return out
+
     def barrier(self):
         if self.enabled:
             td.barrier()

@@ -159,8 +159,17 @@ class KMeans(object):
         if self.seeding == 'keyed':
             d = self.dist
             world = d.world_size if (d is not None and getattr(d, 'enabled', False)) else 1
-            rank = d.rank if world > 1 else 0
-            out = keyed_seeds(self._draws, rank * R, R, L, C)           # rank r holds the global rows [r R, (r + 1) R)
+            row0 = 0
+            if world > 1:
+                # GLOBAL row of this rank's first row = rows held by the ranks before it IN THIS DRAW (a ragged last batch gives the
+                # ranks different R: rank * R would overlap or skip rows), and every rank must be at the same draw number -- both
+                # from one small host gather per draw (hard k-means under data parallelism only)
+                mine = (int(R), int(self._draws))
+                every = d.all_gather_object(mine)
+                if any(e[1] != mine[1] for e in every):
+                    raise RuntimeError('keyed k-means seeds: ranks are at different draw numbers %r -- a rank skipped a draw' % (every,))
+                row0 = sum(e[0] for e in every[:d.rank])
+            out = keyed_seeds(self._draws, row0, R, L, C)
             self._draws += 1
             return torch.from_numpy(out)
         if self.seeding == 'reference':

@@ -310,8 +310,24 @@ class Network(object):
             am = K.stage_inputs(torch.as_strided(ins[0], (n,), (1,)), torch.as_strided(static[0], (n,), (1,)), src2, dst2)
             static[0]._ams_x_amax = am              # models/adapt.py::Adapt._x tags the concatenated view with it
             pairs = rest
+            for dst, src in pairs:
+                dst.copy_(src)
+            return
         for dst, src in pairs:
             dst.copy_(src)
+        am = getattr(static[0], '_ams_x_amax', None)
+        if am is not None and static[0].is_cuda:
+            # an earlier batch went through the fused launch and the captured step holds the address of its bound: this batch came by
+            # plain copies (not back to back / not aligned), so the bound is measured over what was just copied -- never left stale
+            # (a louder batch under a stale max |x| overflows fp16 in the front product: ADVICE r05)
+            flat = static[0]
+            if self._back_to_back(static[0], static[1]):
+                flat = torch.as_strided(static[0], (static[0].numel() + static[1].numel(),), (1,))
+                K.absmax(flat, out=am)
+            else:
+                K.absmax(static[0].reshape(-1), out=am)
+                K.absmax(static[1].reshape(-1), out=(tmp := torch.empty_like(am)))
+                torch.maximum(am, tmp, out=am)
 
     def _train_graphed(self, feed_dict, step):
         """Capture zero_grad + forward + backward once (after 2 eager steps) and replay it; inputs are copied into
@@ -323,6 +339,12 @@ class Network(object):
         ins = self._fetch_inputs(feed_dict)
         opt = self.optimize
         side = st['stream']
+        epoch = getattr(get_default_graph(), 'weights_epoch', 0)
+        if st['graph'] is not None and st.get('epoch') != epoch:
+            # somebody other than the optimizer kernel wrote weights since the capture (restore_model): what the captured step took as
+            # constants -- a frozen front's filter and its bound (models/adapt.py) -- is stale.  Capture again behind two eager
+            # steps, which re-derive them.
+            st['graph'], st['n'] = None, 0
         if st['graph'] is None:
             st['n'] += 1
             if st['n'] <= 2:
@@ -353,7 +375,7 @@ class Network(object):
                 cost = self.cost_model.value(run)
                 self._backward(cost)
                 F.OVERLAP.join()
-            st['graph'], st['cost'], st['run'] = g, cost, run
+            st['graph'], st['cost'], st['run'], st['epoch'] = g, cost, run, epoch
         self._stage(st['static'], ins)
         for hook in get_default_graph().pre_replay_hooks:      # host-drawn inputs of captured kernels (k-means seeds)
             hook()

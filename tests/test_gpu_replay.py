@@ -137,3 +137,57 @@ def test_front_l41_three_speakers_replay_matches_eager():
         dist, tfds = tr.prepare()
         return tr, tfds, L
     _compare(make)
+
+
+def test_a_replayed_step_sees_weights_written_behind_the_optimizer():
+    """a captured front_DPCL step takes the FROZEN front's filter |w| * bases and its bound as constants of the capture.  When
+    something other than the optimizer kernel writes weights (restore_model -> Network._weights_written), the next call must not replay
+    the old filter: the step is captured again behind two eager steps.  Two models, same seeds: one trains eagerly, one replays; after
+    three steps the front window of both is rewritten (x 1.5) through the same hook, and the costs of the following steps still agree."""
+    from tests.smoke_step import build_front_dpcl
+    import utils.ops
+    cfg = dict(B=4, L=2048, W=64, N=16, hop=16, layer_size=16, nb_layers=2, E=8, no_summaries=True)
+    costs = []
+    for graph in (False, True):
+        utils.ops.rng.seed(42)
+        torch.manual_seed(0)
+        np.random.seed(3)
+        tmp = tempfile.mkdtemp(prefix='ams_rewrite_')
+        trainer, tfds = build_front_dpcl(tmp, hip_graph=graph, **cfg)
+        g, model = trainer.graph, trainer.model
+        c = []
+        with g.as_default():
+            feed = {tfds.handle: tfds.get_handle(tfds.TRAIN), tfds.chunk_size: cfg['L']}
+            tfds.initialize(tfds.TRAIN)
+            for i in range(4):
+                c.append(float(model.train(feed, i)))
+            g.variables['front/window/w'].data.mul_(1.5)
+            model._weights_written()
+            for i in range(4, 9):
+                c.append(float(model.train(feed, i)))
+        torch.cuda.synchronize()
+        costs.append(c)
+    assert np.allclose(costs[0], costs[1], rtol=2e-5, atol=0), costs
+    assert abs(costs[0][4] - costs[0][3]) > 1e-6 * abs(costs[0][3])        # the rewrite changed the cost: the check above is not vacuous
+
+
+def test_staging_by_plain_copies_refreshes_the_waveform_bound():
+    """Network._stage leaves max |waveform| for the front product (fp16x3 scales by it) when the fused staging launch
+    applies; a later batch that has to come by plain copies (its tensors are not back to back) must not leave the OLD bound in place --
+    a louder batch under a stale bound overflows fp16."""
+    from models.network import Network
+    B, S, L = 3, 2, 512
+    flat = torch.zeros(B * L + B * S * L, device='cuda')
+    static = [flat[:B * L].view(B, L), flat[B * L:].view(B, S, L)]
+    g = torch.Generator(device='cuda').manual_seed(1)
+    quiet = torch.rand(B * L + B * S * L, device='cuda', generator=g) * 0.01
+    net = Network.__new__(Network)
+    net._stage(static, [quiet[:B * L].view(B, L), quiet[B * L:].view(B, S, L)])          # back to back: the fused launch
+    am = static[0]._ams_x_amax
+    assert abs(float(am) - float(quiet.abs().max())) < 1e-9
+    loud_m = torch.rand(B, L, device='cuda', generator=g) * 7.0                            # two separate tensors: plain copies
+    loud_n = torch.rand(B, S, L, device='cuda', generator=g) * 9.0
+    net._stage(static, [loud_m, loud_n])
+    assert static[0]._ams_x_amax is am                                                    # same address: a captured step reads it
+    assert abs(float(am) - float(max(loud_m.abs().max(), loud_n.abs().max()))) < 1e-6
+    assert torch.equal(static[0], loud_m) and torch.equal(static[1], loud_n)

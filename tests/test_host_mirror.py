@@ -301,9 +301,16 @@ def test_keyed_kmeans_seeds_do_not_depend_on_the_number_of_ranks():
 
     class _D(object):
         enabled, world_size = True, 2
+        rows = (320, 320)                     # what the two ranks hold in the current draw
 
         def __init__(self, rank):
             self.rank = rank
+            self.draws = 0
+
+        def all_gather_object(self, obj):     # stands in for the process group: every rank reports (rows, draw number)
+            assert obj == (self.rows[self.rank], self.draws)
+            self.draws += 1
+            return [(r, obj[1]) for r in self.rows]
     with Graph().as_default():
         kms = [KMeans(2, nb_tries=10, dist=_D(r)) for r in (0, 1)]
         one = KMeans(2, nb_tries=10, seeding='keyed')
@@ -311,3 +318,7 @@ def test_keyed_kmeans_seeds_do_not_depend_on_the_number_of_ranks():
     for step in range(2):
         parts = [km._draw(320, 20480).numpy() for km in kms]
         assert np.array_equal(np.concatenate(parts), one._draw(640, 20480).numpy())
+    # a ragged last batch: the ranks hold 320 and 170 rows -- the second rank's rows follow the first's, none shared, none skipped
+    _D.rows = (320, 170)
+    parts = [km._draw(r, 20480).numpy() for km, r in zip(kms, _D.rows)]
+    assert np.array_equal(np.concatenate(parts), one._draw(490, 20480).numpy())
