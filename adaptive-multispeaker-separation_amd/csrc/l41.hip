@@ -41,8 +41,8 @@ __global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb,
     constexpr int V4 = E_ / 4;
     __shared__ __attribute__((aligned(16))) float tile[256 * LD];
     __shared__ float svs[MAXS * E_];
-    __shared__ float red[4][MAXS * E_ + 1];
-    __shared__ float sdzs[BWD ? 256 * MAXS : 1];              // d cost / d <Vs_s, emb> of every point (backward: the dVs sums read them)
+    __shared__ float red[BWD ? ((256 / E_) * MAXS * E_ > 4 * (MAXS * E_ + 1) ? (256 / E_) * MAXS * E_ : 4 * (MAXS * E_ + 1)) : 4];     // forward: 4 wave sums; backward: the parts' partial dVs sums
+    __shared__ __attribute__((aligned(16))) float sdzs[BWD ? 256 * MAXS : 1];   // d cost / d <Vs_s, emb> of every point (backward: the dVs sums read them)
     __shared__ float sneg[NEG ? MAXN * E_ : 1];
     __shared__ float sdz[NEG && BWD ? 256 * MAXK : 1];          // d cost / d <neg_k, emb> of every point
     __shared__ int ssel[NEG && BWD ? 256 : 1];
@@ -113,9 +113,9 @@ __global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb,
     }
     if (!BWD) {
         cost = wave_sum(cost);
-        if ((tid & 63) == 0) red[tid >> 6][0] = cost;
+        if ((tid & 63) == 0) red[tid >> 6] = cost;
         __syncthreads();
-        if (tid == 0) part[(long)b * nblk + blockIdx.x] = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        if (tid == 0) part[(long)b * nblk + blockIdx.x] = red[0] + red[1] + red[2] + red[3];
         return;
     }
     // backward: demb = sum_s dz_s * Vs_s ; dVs_s += dz_s * emb (block partial)
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb,
         __syncthreads();
     }
     float dv[E_];
-    float amx = 0.f;
+    float amx = 0.f, dvs_tot = 0.f;
     if (tid < npts) {
 #pragma unroll
         for (int e = 0; e < E_; ++e) {
@@ -162,23 +162,26 @@ __global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb,
     for (int s = 0; s < MAXS; ++s) sdzs[tid * MAXS + s] = (tid < npts && s < S) ? dz[s] : 0.f;
     __syncthreads();
     {
-        const int o = tid & 127, half = tid >> 7, SE = S * E_;
-        if (o < SE) {
-            const int so = o / E_, eo = o - so * E_;
-            float acc = 0.f;
-            const int p1 = min(npts, 128 * (half + 1));
-            for (int p = 128 * half; p < p1; ++p) acc += sdzs[p * MAXS + so] * tile[p * LD + eo];
-            red[half][o] = acc;
-        }
-        if (SE > 128) {                                                          // (S = 4, E = 40: outputs 128 .. 159)
-            const int o2 = 128 + o;
-            if (o2 < SE) {
-                const int so = o2 / E_, eo = o2 - so * E_;
-                float acc = 0.f;
-                const int p1 = min(npts, 128 * (half + 1));
-                for (int p = 128 * half; p < p1; ++p) acc += sdzs[p * MAXS + so] * tile[p * LD + eo];
-                red[half][o2] = acc;
+        // thread (feature e, part): the part's points one after another, ONE read of the point's feature and one 16-byte read of its
+        // dz serve all S sums (S * E threads with one sum each read 3 x as much); the parts meet below in part order
+        constexpr int NPART = 256 / E_;                                          // 6 parts at E = 40 (240 threads busy)
+        const int eo = tid % E_, part = tid / E_;
+        if (part < NPART) {
+            const int per = (256 + NPART - 1) / NPART;
+            const int pa = part * per, pb = min(npts, pa + per);
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int p = pa; p < pb; ++p) {
+                const float vv = tile[p * LD + eo];
+                const float4 dz4 = *reinterpret_cast<const float4*>(&sdzs[p * MAXS]);
+                a0 += dz4.x * vv; a1 += dz4.y * vv; a2 += dz4.z * vv; a3 += dz4.w * vv;
             }
+            float* const r = &red[part * (MAXS * E_)];
+            r[eo] = a0; r[E_ + eo] = a1; r[2 * E_ + eo] = a2; r[3 * E_ + eo] = a3;
+        }
+        __syncthreads();
+        if (tid < S * E_) {                                                      // (S * E <= 160: one output per thread, kept in a register)
+#pragma unroll
+            for (int q = 0; q < NPART; ++q) dvs_tot += red[q * (MAXS * E_) + tid];
         }
     }
     __syncthreads();                                                             // the points have been read: the tile takes the gradients
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb,
     }
     if (amax_part != nullptr) {                                                  // max |d emb| of the block (the launch's final kernel folds them)
         amx = wave_max(amx);
-        if ((tid & 63) == 0) red[2][tid >> 6] = amx;
+        if ((tid & 63) == 0) sdzs[tid >> 6] = amx;                               // (the points' dz are dead by now)
     }
     __syncthreads();
     float* db = demb + ((long)b * TF + p0) * E_;
@@ -202,20 +205,23 @@ __global__ __launch_bounds__(256) void l41_kernel(const float* __restrict__ emb,
     } else {
         for (int i = tid; i < npts * E_; i += 256) db[i] = tile[(i / E_) * LD + (i % E_)];
     }
-    for (int i = tid; i < S * E_; i += 256)
-        dvs_part[((long)b * nblk + blockIdx.x) * (S * E_) + i] = red[0][i] + red[1][i];
+    if (tid < S * E_) dvs_part[((long)b * nblk + blockIdx.x) * (S * E_) + tid] = dvs_tot;
     if (amax_part != nullptr && tid == 0)
-        amax_part[(long)b * nblk + blockIdx.x] = fmaxf(fmaxf(red[2][0], red[2][1]), fmaxf(red[2][2], red[2][3]));
+        amax_part[(long)b * nblk + blockIdx.x] = fmaxf(fmaxf(sdzs[0], sdzs[1]), fmaxf(sdzs[2], sdzs[3]));
 }
 
-__global__ void l41_cost_final_kernel(const float* __restrict__ part, float* __restrict__ out, long n, float scale) {
-    __shared__ float sm[4];
+__global__ __launch_bounds__(1024) void l41_cost_final_kernel(const float* __restrict__ part, float* __restrict__ out, long n, float scale) {
+    __shared__ float sm[16];                            // one workgroup of 16 waves: 20480 partials at cfg5 took 256 threads 27 us
     float s = 0.f;
     for (long i = threadIdx.x; i < n; i += blockDim.x) s += part[i];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) out[0] = (sm[0] + sm[1] + sm[2] + sm[3]) * scale;
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int w = 0; w < (int)(blockDim.x >> 6); ++w) t += sm[w];
+        out[0] = t * scale;
+    }
 }
 
 // (block 0 also folds the blocks' max |d emb| into amax_out[0]: the operand bound of the two products that read d emb -- no pass over it)
@@ -230,12 +236,15 @@ __global__ void l41_dvs_final_kernel(const float* __restrict__ part, float* __re
         __syncthreads();
         if (threadIdx.x == 0) amax_out[0] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
     }
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    // one WAVE per output (b, k): its lanes take the blocks c = lane, lane + 64, ... and meet in a fixed tree -- a thread per output
+    // walked 160 blocks one load at a time (94 us at cfg5: 2.4 M floats, 15 K threads)
+    const int i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= B * SE) return;
     const int b = i / SE, k = i - b * SE;
     float s = 0.f;
-    for (int c = 0; c < nblk; ++c) s += part[((long)b * nblk + c) * SE + k];
-    dvs[i] = s;
+    for (int c = lane; c < nblk; c += 64) s += part[((long)b * nblk + c) * SE + k];
+    s = wave_sum(s);
+    if (lane == 0) dvs[i] = s;
 }
 
 }  // namespace
@@ -277,7 +286,7 @@ ams_status ams_l41_loss_fwd(const float* emb, const float* y, const float* vspk,
     const float scale = 1.0f / ((float)B * (float)TF * S);
     const bool from_u = emb_is_u != 0, vec = l41_vec(emb, emb);
     AMS_L41_DISPATCH(false, false, emb, y, vspk, (const float*)nullptr, (float*)ws, (float*)nullptr, (float*)nullptr, (float*)nullptr, TF, S, nblk, scale, NegArgs{})
-    hipLaunchKernelGGL(l41_cost_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, cost, (long)B * nblk, scale);
+    hipLaunchKernelGGL(l41_cost_final_kernel, dim3(1), dim3(1024), 0, st, (const float*)ws, cost, (long)B * nblk, scale);
     return ams_check_launch();
 }
 
@@ -294,7 +303,7 @@ ams_status ams_l41_loss_bwd(const float* emb, const float* y, const float* vspk,
     const bool from_u = emb_is_u != 0, vec = l41_vec(emb, demb);
     float* const amax_part = amax_out ? (float*)ws + (size_t)B * nblk * S * E : nullptr;
     AMS_L41_DISPATCH(true, false, emb, y, vspk, upstream, (float*)nullptr, demb, (float*)ws, amax_part, TF, S, nblk, scale, NegArgs{})
-    hipLaunchKernelGGL(l41_dvs_final_kernel, dim3(ceil_div(B * S * E, 256)), dim3(256), 0, st, (const float*)ws, dvspk, nblk, S * E, B,
+    hipLaunchKernelGGL(l41_dvs_final_kernel, dim3(ceil_div(B * S * E, 4)), dim3(256), 0, st, (const float*)ws, dvspk, nblk, S * E, B,
                        (const float*)amax_part, amax_out);
     return ams_check_launch();
 }
@@ -317,7 +326,7 @@ ams_status ams_l41_loss_ns_fwd(const float* emb, const float* y, const float* vs
     NegArgs na{negs, nullptr, NSEL, K, ns_rate * (float)S / (float)K};
     const bool from_u = emb_is_u != 0, vec = l41_vec(emb, emb);
     AMS_L41_DISPATCH(false, true, emb, y, vspk, (const float*)nullptr, (float*)ws, (float*)nullptr, (float*)nullptr, (float*)nullptr, TF, S, nblk, scale, na)
-    hipLaunchKernelGGL(l41_cost_final_kernel, dim3(1), dim3(256), 0, st, (const float*)ws, cost, (long)B * nblk, scale);
+    hipLaunchKernelGGL(l41_cost_final_kernel, dim3(1), dim3(1024), 0, st, (const float*)ws, cost, (long)B * nblk, scale);
     return ams_check_launch();
 }
 
@@ -338,10 +347,10 @@ ams_status ams_l41_loss_ns_bwd(const float* emb, const float* y, const float* vs
     const bool from_u = emb_is_u != 0, vec = l41_vec(emb, demb);
     float* const amax_part = amax_out ? dneg_part + (size_t)B * nblk * NSEL * K * E : nullptr;
     AMS_L41_DISPATCH(true, true, emb, y, vspk, upstream, (float*)nullptr, demb, dvs_part, amax_part, TF, S, nblk, scale, na)
-    hipLaunchKernelGGL(l41_dvs_final_kernel, dim3(ceil_div(B * S * E, 256)), dim3(256), 0, st, (const float*)dvs_part, dvspk, nblk, S * E, B,
+    hipLaunchKernelGGL(l41_dvs_final_kernel, dim3(ceil_div(B * S * E, 4)), dim3(256), 0, st, (const float*)dvs_part, dvspk, nblk, S * E, B,
                        (const float*)amax_part, amax_out);
     const int NE = NSEL * K * E;
-    hipLaunchKernelGGL(l41_dvs_final_kernel, dim3(ceil_div(B * NE, 256)), dim3(256), 0, st, (const float*)dneg_part, dnegs, nblk, NE, B,
+    hipLaunchKernelGGL(l41_dvs_final_kernel, dim3(ceil_div(B * NE, 4)), dim3(256), 0, st, (const float*)dneg_part, dnegs, nblk, NE, B,
                        (const float*)nullptr, (float*)nullptr);
     return ams_check_launch();
 }
