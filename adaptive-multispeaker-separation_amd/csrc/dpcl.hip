@@ -1123,9 +1123,12 @@ __global__ __launch_bounds__(256) void dpcl_bwd_u2_kernel(const float* __restric
 #pragma unroll
             for (int i = 0; i < 4; ++i) z[NJ - 1][i] = g.y[i];
         }
+        float dd[NT][4];
+#if !AMS_DPCL_BWD_F16
         f32x4 acc[NT];
 #pragma unroll
         for (int ft = 0; ft < NT; ++ft) acc[ft] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#endif
 #if AMS_DPCL_BWD_F16
         {
             dh8 z8[2];
@@ -1142,21 +1145,22 @@ __global__ __launch_bounds__(256) void dpcl_bwd_u2_kernel(const float* __restric
                 const _Float16 h = (_Float16)v;
                 z4[0][e] = h; z4[1][e] = (_Float16)(v - (float)h);
             }
-            // the K = 16 chain in accumulators of its own (an accumulator handed from one MFMA shape to the other needs wait states:
-            // csrc/lstm_ring.hip); smallest terms first: lo.hi, hi.lo, hi.hi
-            f32x4 acc16[NT];
-#pragma unroll
-            for (int ft = 0; ft < NT; ++ft) acc16[ft] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            // per feature tile two chains from 0, one per MFMA shape, alternating, joined by one add (an accumulator must not pass from one
+            // shape to the other: csrc/lstm_ring.hip); smallest terms first: lo.hi, hi.lo, hi.hi.  Tile by tile only two partial sums
+            // are live: 160 registers instead of 176 -- three waves per SIMD again (round 6)
             constexpr int PA[3] = {1, 0, 0}, PB[3] = {0, 1, 0};
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int pp = 0; pp < 3; ++pp)
-#pragma unroll
-                for (int ft = 0; ft < NT; ++ft) {
-                    acc[ft] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8[ft][PA[pp]], z8[PB[pp]], acc[ft], 0, 0, 0);
-                    acc16[ft] = __builtin_amdgcn_mfma_f32_16x16x16f16(a4[ft][PA[pp]], z4[PB[pp]], acc16[ft], 0, 0, 0);
-                }
-#pragma unroll
-            for (int ft = 0; ft < NT; ++ft) acc[ft] = (acc[ft] + acc16[ft]) * m_inv;
+            for (int ft = 0; ft < NT; ++ft) {
+                f32x4 r32 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8[ft][PA[0]], z8[PB[0]], zero4, 0, 0, 0);
+                f32x4 r16 = __builtin_amdgcn_mfma_f32_16x16x16f16(a4[ft][PA[0]], z4[PB[0]], zero4, 0, 0, 0);
+                r32 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8[ft][PA[1]], z8[PB[1]], r32, 0, 0, 0);
+                r16 = __builtin_amdgcn_mfma_f32_16x16x16f16(a4[ft][PA[1]], z4[PB[1]], r16, 0, 0, 0);
+                r32 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a8[ft][PA[2]], z8[PB[2]], r32, 0, 0, 0);
+                r16 = __builtin_amdgcn_mfma_f32_16x16x16f16(a4[ft][PA[2]], z4[PB[2]], r16, 0, 0, 0);
+                const f32x4 t = (r32 + r16) * (m_inv * d);
+                dd[ft][0] = t[0]; dd[ft][1] = t[1]; dd[ft][2] = t[2]; dd[ft][3] = t[3];
+            }
         }
 #else
 #pragma unroll
@@ -1170,12 +1174,14 @@ __global__ __launch_bounds__(256) void dpcl_bwd_u2_kernel(const float* __restric
                 }
 #endif
         // acc[ft][r]: feature 16 ft + 4 slot + r of point e_lo -- the positions of the lane's own float4 number ft
-        float dd[NT][4], dot = 0.f;
+        float dot = 0.f;
 #pragma unroll
         for (int ft = 0; ft < NT; ++ft)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
+#if !AMS_DPCL_BWD_F16
                 dd[ft][r] = acc[ft][r] * d;
+#endif
                 if (uval[ft]) dot += z[ft][r] * dd[ft][r];
             }
         dot += __shfl_xor(dot, 16);
