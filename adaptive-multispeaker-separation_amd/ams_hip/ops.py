@@ -633,6 +633,27 @@ def gemm(A, B, transA=False, transB=False, bias=None, out=None, accumulate=False
 
 # ------------------------------------------------------------------ products from pre-split fp16 operand images (csrc/gemm_ps.hip)
 PRESPLIT = _os.environ.get('AMS_GEMM_PRESPLIT', '1') != '0' and F16X3
+# A captured training step is replayed both ways for a few steps and keeps the faster form (models/network.py::_train_graphed): the
+# pre-split products run the matrix pipe at twice the duty of the in-product form, and on some boards that makes the clock governor
+# settle ~8 % lower for the WHOLE step (2160 instead of 2350 MHz, tools/probes/step_power_probe.sh) -- more than the products save.
+PS_AUTOTUNE = _os.environ.get('AMS_PS_AUTOTUNE', '1') != '0'
+PS_LAUNCHES = [0]                                                # ams_gemm_ps launches issued (or captured) so far
+PS_TUNED = {}                                                    # the last decision: {'presplit': bool, 'ms_presplit': .., 'ms_in_product': ..}
+
+
+class presplit(object):
+    """with ops.presplit(False): ...  -- the forward products inside take (or avoid) the pre-split form."""
+
+    def __init__(self, on):
+        self.on = bool(on) and F16X3
+
+    def __enter__(self):
+        global PRESPLIT
+        self.old, PRESPLIT = PRESPLIT, self.on
+
+    def __exit__(self, *exc):
+        global PRESPLIT
+        PRESPLIT = self.old
 
 
 def ps_pack_rows(x2, amax, img=None):
@@ -675,6 +696,7 @@ def gemm_ps(a_img, b_img, K, amax, bias=None, out=None, ldc=None, label=''):
     amax[0].record_stream(cur)
     amax[1].record_stream(cur)
     check(lib.ams_gemm_ps(M, N, K, _p(a_img), _p(b_img), _p(out), ldc, _p(bias), _p(amax[0]), _p(amax[1]), _s()), 'ams_gemm_ps')
+    PS_LAUNCHES[0] += 1
     if ev is not None:
         PROFILE.end(ev, 2.0 * M * N * K, 4.0 * (M * K + K * N + M * N), 'gemm16ps<0,1>', label)
     return out

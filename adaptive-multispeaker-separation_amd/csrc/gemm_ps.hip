@@ -136,6 +136,9 @@ __device__ __forceinline__ void ps_locate(const PsArgs& g, int item, int& tile_m
     tile_m = band * gm + (within - tile_n * band_rows);
 }
 
+#ifndef AMS_PS_SLEEP
+#define AMS_PS_SLEEP 0
+#endif
 #ifndef AMS_PS_STAMP
 #define AMS_PS_STAMP 0
 #endif
@@ -251,6 +254,9 @@ __global__ __launch_bounds__(PS_NT, 1) void gemm_ps_kernel(const PsArgs g) {
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) c[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][pa], b[j][pb], c[i][j], 0, 0, 0);
+#if AMS_PS_SLEEP
+        __builtin_amdgcn_s_sleep(AMS_PS_SLEEP);
+#endif
     };
     auto mfma_tile = [&](int stage, auto PRE, int kt2, int stage2) {
         constexpr bool pre = decltype(PRE)::value;

@@ -364,25 +364,71 @@ class Network(object):
                 return cost.detach().reshape(-1)[0]
             st['static'] = self._static_like(ins)
             self._stage(st['static'], ins)          # (also attaches the waveforms' bound to the static buffer before the capture reads it)
-            run = self._feeds(feed_dict, True)
-            for node, t in zip((self.x_mix, self.x_non_mix, self.I), st['static']):
-                run.cache[id(node)] = t
-            g = torch.cuda.CUDAGraph()
-            torch.cuda.synchronize()
-            # thread_local: a collective library's watchdog thread (RCCL at N > 1) must not be able to invalidate this capture
-            with torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
-                opt.zero_grad(defer=True)
-                cost = self.cost_model.value(run)
-                self._backward(cost)
-                F.OVERLAP.join()
-            st['graph'], st['cost'], st['run'], st['epoch'] = g, cost, run, epoch
+
+            def capture(presplit):
+                run = self._feeds(feed_dict, True)
+                for node, t in zip((self.x_mix, self.x_non_mix, self.I), st['static']):
+                    run.cache[id(node)] = t
+                g = torch.cuda.CUDAGraph()
+                torch.cuda.synchronize()
+                # thread_local: a collective library's watchdog thread (RCCL at N > 1) must not be able to invalidate this capture
+                with K.presplit(presplit), torch.cuda.graph(g, stream=side, capture_error_mode='thread_local'):
+                    opt.zero_grad(defer=True)
+                    cost = self.cost_model.value(run)
+                    self._backward(cost)
+                    F.OVERLAP.join()
+                return g, cost, run
+            # Which form of the forward products this step replays (K.PS_AUTOTUNE): decided once per model by measurement, see below
+            choice = self.__dict__.get('_ps_choice')
+            n0 = K.PS_LAUNCHES[0]
+            first = K.PRESPLIT if choice is None else (choice and K.PRESPLIT)
+            st['graph'], st['cost'], st['run'] = capture(first)
+            st['epoch'], st['tune'] = epoch, None
+            if choice is None and K.PS_AUTOTUNE and first and K.PS_LAUNCHES[0] > n0:
+                # the captured step holds pre-split products: capture its twin without them and let the next steps decide.  Both are
+                # the same arithmetic to the last bits (tests/test_gpu_gemm_ps.py); every tuning step is a real training step.
+                st['tune'] = {'variants': [(st['graph'], st['cost'], st['run']), capture(False)], 'k': 0, 'ev': ([], [])}
+        tune = st.get('tune')
+        if tune is not None:
+            v = (tune['k'] // self._PS_TUNE_BLOCK) % 2
+            st['graph'], st['cost'], st['run'] = tune['variants'][v]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         self._stage(st['static'], ins)
         for hook in get_default_graph().pre_replay_hooks:      # host-drawn inputs of captured kernels (k-means seeds)
             hook()
         st['graph'].replay()
         opt.step()
         self.last_run = st['run']
-        return st['cost'].detach().reshape(-1)[0]
+        cost = st['cost'].detach().reshape(-1)[0]
+        if tune is not None:
+            e1.record()
+            tune['ev'][v].append((tune['k'] % self._PS_TUNE_BLOCK, e0, e1))
+            tune['k'] += 1
+            if tune['k'] >= 4 * self._PS_TUNE_BLOCK:
+                self._ps_finish_tuning(st)
+        return cost
+
+    # steps per block; blocks alternate pre-split / in-product twice; only the last third of a block is counted: the clock governor takes
+    # tens of milliseconds to settle after the form changes (blocks of 8 steps measured both forms at the slower form's clock)
+    _PS_TUNE_BLOCK = int(os.environ.get('AMS_PS_TUNE_BLOCK', '48'))
+
+    def _ps_finish_tuning(self, st):
+        """Median step time (replay + optimizer, device events) of the two captured forms over the counted tuning steps; the faster
+        form stays, the other graph is dropped.  The decision is kept on the model (a re-capture -- an audit, a restore -- reuses it)
+        and published in K.PS_TUNED for reports."""
+        tune = st['tune']
+        torch.cuda.synchronize()
+        med = []
+        for v in (0, 1):
+            t = sorted(a.elapsed_time(b) for i, a, b in tune['ev'][v] if i >= 2 * self._PS_TUNE_BLOCK // 3)
+            med.append(t[len(t) // 2])
+        keep = 0 if med[0] <= med[1] else 1
+        st['graph'], st['cost'], st['run'] = tune['variants'][keep]
+        st['tune'] = None
+        self._ps_choice = (keep == 0)
+        K.PS_TUNED.update(presplit=self._ps_choice, ms_presplit=round(med[0], 4), ms_in_product=round(med[1], 4),
+                          steps_counted=len([1 for i, a, b in tune['ev'][0] if i >= 2 * self._PS_TUNE_BLOCK // 3]))
 
     def _backward(self, cost):
         """d cost[0]: a 1-element cost is seeded with a cached ones tensor (no select / fill launches on the way back)."""

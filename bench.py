@@ -275,6 +275,14 @@ def main():
         # untimed set-up, independent of --warmup: two eager steps + the hipGraph capture happen in the first three calls
         for i in range(3 if args.graph else 1):
             one_step(0)
+        # the captured step measures its two forms (forward products from pre-split operand images or split in the product) over its
+        # next 192 replays (about half a second) and keeps the faster one on THIS board (ops.PS_AUTOTUNE): untimed, like the capture itself
+        for i in range(400):
+            if (getattr(model, '_cg_state', None) or {}).get('tune') is None:
+                break
+            one_step(0)
+        if ops.PS_TUNED and not ops.PS_TUNED.get('presplit', True):
+            ops.PRESPLIT = False                         # the eager / stamped passes below measure the form the timed graph runs
         for i in range(args.warmup):
             c = one_step(i)
         torch.cuda.synchronize()
@@ -509,6 +517,8 @@ def main():
                    'parallelism': 'dp%d' % world, 'hip_graph': bool(args.graph)},
         'roofline': roof, 'roofline_hbm': roof_hbm, 'north_star_targets': targets, 'final_cost': last_cost,
     }
+    if ops.PS_TUNED:
+        out['forward_products'] = dict(ops.PS_TUNED, note='the captured step was replayed both ways before the timed region and kept the faster form on this board: pre-split operand images (csrc/gemm_ps.hip) raise the matrix-pipe duty, and some boards then settle at a lower clock for the whole step (DESIGN.md 4.1b)')
     if world > 1:
         out['rank_ms_per_step'] = [round(float(v), 3) for v in per_rank.cpu().numpy()]
         out['exposed_allreduce_ms'] = round(float(exch.item()), 4)
