@@ -191,3 +191,41 @@ def test_staging_by_plain_copies_refreshes_the_waveform_bound():
     assert static[0]._ams_x_amax is am                                                    # same address: a captured step reads it
     assert abs(float(am) - float(max(loud_m.abs().max(), loud_n.abs().max()))) < 1e-6
     assert torch.equal(static[0], loud_m) and torch.equal(static[1], loud_n)
+
+
+def test_a_captured_step_measures_both_forms_of_its_forward_products_and_keeps_one(monkeypatch):
+    """models/network.py::_train_graphed with ops.PS_AUTOTUNE: the step is captured twice -- forward products from pre-split operand
+    images (csrc/gemm_ps.hip) and split inside the product (csrc/gemm.hip) --, the two graphs are replayed in alternating blocks (every
+    replay a real training step) and the faster one stays.  Whatever the choice on this board, the cost trajectory is the eager one:
+    the two forms differ in summation order only."""
+    from tests.smoke_step import build_front_dpcl
+    from models.network import Network
+    from ams_hip import ops
+    import utils.ops
+    monkeypatch.setattr(Network, '_PS_TUNE_BLOCK', 3)
+    monkeypatch.setattr(ops, 'PS_AUTOTUNE', True)
+    ops.PS_TUNED.clear()
+    cfg = dict(B=4, L=2048, W=64, N=16, hop=16, layer_size=16, nb_layers=2, E=8, no_summaries=True)
+    costs, models = [], []
+    for graph in (False, True):
+        utils.ops.rng.seed(42)
+        torch.manual_seed(0)
+        np.random.seed(3)
+        trainer, tfds = build_front_dpcl(tempfile.mkdtemp(prefix='ams_tune_'), hip_graph=graph, **cfg)
+        g, model = trainer.graph, trainer.model
+        c = []
+        with g.as_default():
+            feed = {tfds.handle: tfds.get_handle(tfds.TRAIN), tfds.chunk_size: cfg['L']}
+            tfds.initialize(tfds.TRAIN)
+            for i in range(2 + 12 + 4):                       # two eager steps, four blocks of three tuning replays, four more
+                c.append(float(model.train(feed, i)))
+                if graph and i == 6:
+                    assert model._cg_state['tune'] is not None and len(model._cg_state['tune']['variants']) == 2
+        torch.cuda.synchronize()
+        costs.append(c)
+        models.append(model)
+    assert np.allclose(costs[0], costs[1], rtol=2e-5, atol=0), costs
+    m = models[1]
+    assert m._cg_state['tune'] is None and isinstance(m._ps_choice, bool)
+    assert ops.PS_TUNED['presplit'] == m._ps_choice and ops.PS_TUNED['ms_presplit'] > 0 and ops.PS_TUNED['ms_in_product'] > 0
+    assert ops.PRESPLIT                                          # the process-wide default is untouched by a model's choice
