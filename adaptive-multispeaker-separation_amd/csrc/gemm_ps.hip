@@ -21,6 +21,12 @@
 // Tile 128 x 256, 8 waves of 64 x 64 (2 x 2 MFMA tiles, two accumulator sets: hi.hi | cross terms, as gemm.hip's uncapped variants),
 // persistent walk over the tiles in the XCD-aware band order of gemm.hip; the next tile's first k-tile is in flight before the finished
 // tile's stores.  Replaces: the same tf.matmul / conv1d call sites as ams_gemm_f32 (utils/ops.py:366-383, :501-503).
+//
+// Measured: 0.65-0.7 x the time of the in-product form, matrix-pipe utilisation 0.39 (K = 600 projection) / 0.54 (dense
+// forward) by counter.  On some boards that duty makes the clock governor settle ~8 % lower for every kernel of the step, which costs more
+// than these products save; the host side therefore lets a captured training step measure both forms and keep the faster one
+// (models/network.py::_train_graphed).  -DAMS_PS_SLEEP=N (s_sleep N behind every group of four MFMAs) is the probe that showed the clock
+// coming back as the duty goes down (profiles/r06_f_step_clock_and_forward_product_form.txt); it is not a tuning knob.
 #include "common.h"
 #include <type_traits>
 
