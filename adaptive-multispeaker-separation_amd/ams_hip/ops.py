@@ -702,23 +702,6 @@ def gemm_ps(a_img, b_img, K, amax, bias=None, out=None, ldc=None, label=''):
     return out
 
 
-def tag_ps_image(t, img):
-    """A producer that wrote the PS32 image of `t` (cut with the bound it tagged `t` with) attaches it; forward_product() finds it."""
-    if PRESPLIT and img is not None:
-        t._ams_ps = (img, t._version)
-    return t
-
-
-def _ps_rows_image(x2, amax_x):
-    b = x2
-    while b is not None:                                         # a view that keeps rows and columns of a tagged tensor shares its image
-        tag = getattr(b, '_ams_ps', None)
-        if tag is not None and tag[1] == b._version and b.numel() == x2.numel() and b.data_ptr() == x2.data_ptr():
-            return tag[0]
-        b = b._base
-    return ps_pack_rows(x2, amax_x)
-
-
 def _ps_weight_image(W2, amax_w, owner):
     """PS32 image of W2^T, cut once per evaluation pass (inside a captured step: by every replay) and kept across passes for frozen
     weights (Network.freeze_weights; dropped with the other derived tensors by drop_frozen_derivatives): cached on `owner`."""
@@ -742,14 +725,14 @@ def forward_product_presplit(M, N, K, out, bias, amax, label, ldc):
 
 def forward_product(x2, W2, bias, out, amax, label, owner, ldc=None):
     """out[M, N] = x2 [M, K] . W2 [K, N] + bias: the forward products of the path (BLSTM input projection, Conv1D).  From pre-split
-    operand images (csrc/gemm_ps.hip) where forward_product_presplit() says so -- x2's image is the one its producer attached
-    (tag_ps_image) or is cut here, W2's is cut once per pass; otherwise ams_gemm_f32."""
+    operand images (csrc/gemm_ps.hip) where forward_product_presplit() says so -- x2's image is cut here, W2's once per pass (kept across
+    passes for frozen weights); otherwise ams_gemm_f32."""
     M, K = x2.shape
     N = W2.shape[1]
     ldc = (out.stride(0) if out.dim() == 2 else N) if ldc is None else ldc
     if not (forward_product_presplit(M, N, K, out, bias, amax, label, ldc) and x2.stride(1) == 1 and W2.stride(1) == 1):
         return gemm(x2, W2, bias=bias, out=out, M=M, N=N, K=K, lda=x2.stride(0), ldb=W2.stride(0), ldc=ldc, label=label, amax=amax)
-    a_img = _ps_rows_image(x2, amax[0])
+    a_img = ps_pack_rows(x2, amax[0])
     b_img = _ps_weight_image(W2, amax[1], owner)
     return gemm_ps(a_img, b_img, K, amax, bias=bias, out=out, ldc=ldc, label=label)
 
