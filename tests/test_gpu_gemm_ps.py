@@ -111,3 +111,37 @@ def test_launches_back_to_back_are_deterministic():
     first = ops.gemm_ps(ai, bi, K, am).clone()
     for _ in range(20):
         assert torch.equal(ops.gemm_ps(ai, bi, K, am), first)
+
+
+def test_the_dma_pipeline_is_race_free_under_memory_pressure():
+    """The main loop's correctness rests on hand-counted waits (`vmcnt(6)`: this wave's pieces of tile t have landed, tile t + 1 stays in
+    flight) and one barrier per k-tile; a miscount shows up as RARE wrong tiles whenever a DMA happens to land late.  So: many launches of
+    several shapes (whole rounds, a tail round, one k-tile, K with a padded tail) while another stream thrashes HBM and the L2 -- every
+    output must equal the first one bit for bit, and the first one the float64 product."""
+    from ams_hip import ops
+    rng = np.random.RandomState(12)
+    shapes = [(5120, 2400, 600), (1024, 1024, 2048), (640, 512, 32), (384, 768, 100), (128, 256, 3000)]
+    cases = []
+    for M, N, K in shapes:
+        A, W = rng.randn(M, K).astype(np.float32), (rng.randn(K, N) * 0.2).astype(np.float32)
+        Ad, Wd = dev(A), dev(W)
+        am = (ops.absmax(Ad), ops.absmax(Wd))
+        ai, bi = ops.ps_pack_rows(Ad, am[0]), ops.ps_pack_cols(Wd, am[1])
+        first = ops.gemm_ps(ai, bi, K, am).clone()
+        torch.cuda.synchronize()
+        rows = np.linspace(0, M - 1, 64).astype(int)
+        ref = A[rows].astype(np.float64) @ W.astype(np.float64)
+        assert np.abs(first.cpu().numpy()[rows] - ref).max() <= 2e-5 * np.abs(ref).max() + 1e-6
+        cases.append((ai, bi, K, am, first, torch.empty_like(first)))
+    noise_stream = torch.cuda.Stream()
+    big = torch.empty(64 * 1024 * 1024, device='cuda')                 # 256 MB: does not fit the Infinity Cache either
+    bad = 0
+    for rep in range(40):
+        with torch.cuda.stream(noise_stream):
+            big.add_(1.0)
+            big.mul_(0.5)
+        for ai, bi, K, am, first, out in cases:
+            ops.gemm_ps(ai, bi, K, am, out=out)
+            bad += int(not torch.equal(out, first))
+    torch.cuda.synchronize()
+    assert bad == 0, '%d of %d launches differed from the first launch of their shape' % (bad, 40 * len(cases))
