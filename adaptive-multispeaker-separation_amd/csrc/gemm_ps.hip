@@ -90,33 +90,46 @@ __global__ __launch_bounds__(256) void ps_pack_rows_kernel(const float* __restri
     *reinterpret_cast<uint4*>(p + 64) = lo;
 }
 
-// w [K, N] row-major (row pitch ldw floats) -> image of w^T: image row n holds w[:, n] along k.  A workgroup turns a 32 (k) x 64 (n)
-// block round in LDS: coalesced reads along n, each thread then owns (n, group of 8 k).
+// w [K, N] row-major (row pitch ldw floats) -> image of w^T: image row n holds w[:, n] along k.  A workgroup turns 32 (k) x 64 (n) blocks
+// round in LDS, PS_PC_KT k-tiles one after another (3040 workgroups of one block each took 18 us for the 600 x 10240 dense kernel):
+// coalesced reads along n -- the next block's values are in flight while this one is cut --, then thread (n, group of 8 k) writes 16 bytes
+// of hi and of lo: a wave writes 16 image rows x 64 contiguous bytes per plane.
+constexpr int PS_PC_KT = 4;
 __global__ __launch_bounds__(256) void ps_pack_cols_kernel(const float* __restrict__ w, long ldw, unsigned char* __restrict__ img,
                                                            unsigned pitch, int K, int N, const float* __restrict__ amax) {
     __shared__ float t[32][65];
-    const int n0 = blockIdx.x * 64, k0 = blockIdx.y * 32;
+    const int n0 = blockIdx.x * 64;
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        const int k = k0 + ty * 8 + i, n = n0 + tx;
-        t[ty * 8 + i][tx] = (k < K && n < N) ? w[(long)k * ldw + n] : 0.f;
-    }
-    __syncthreads();
-    // a wave writes 16 image rows x (4 groups of 8 k): 64 contiguous bytes of hi and of lo per row (as (n, group) = (tid & 63, tid >> 6)
-    // a wave wrote 64 rows x 16 bytes: 21.6 us for the 600 x 10240 dense kernel, 2.3 TB/s)
-    const float s = ps_scale(amax[0]);
     const int nl = threadIdx.x >> 2, kg = threadIdx.x & 3;
-    const int n = n0 + nl;
-    if (n >= N) return;
-    uint4 hi, lo;
-    ps_split2(t[kg * 8 + 0][nl] * s, t[kg * 8 + 1][nl] * s, hi.x, lo.x);
-    ps_split2(t[kg * 8 + 2][nl] * s, t[kg * 8 + 3][nl] * s, hi.y, lo.y);
-    ps_split2(t[kg * 8 + 4][nl] * s, t[kg * 8 + 5][nl] * s, hi.z, lo.z);
-    ps_split2(t[kg * 8 + 6][nl] * s, t[kg * 8 + 7][nl] * s, hi.w, lo.w);
-    unsigned char* p = img + (long)n * pitch + (k0 >> 5) * 128 + kg * 16;
-    *reinterpret_cast<uint4*>(p) = hi;
-    *reinterpret_cast<uint4*>(p + 64) = lo;
+    const float s = ps_scale(amax[0]);
+    const int kt_end = min((int)((K + 31) / 32), (int)(blockIdx.y + 1) * PS_PC_KT);
+    float v[8];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int k = kt * 32 + ty * 8 + i, n = n0 + tx;
+            v[i] = (k < K && n < N) ? w[(long)k * ldw + n] : 0.f;
+        }
+    };
+    int kt = blockIdx.y * PS_PC_KT;
+    if (kt < kt_end) fetch(kt);
+    for (; kt < kt_end; ++kt) {
+        __syncthreads();                            // the previous block has been read
+#pragma unroll
+        for (int i = 0; i < 8; ++i) t[ty * 8 + i][tx] = v[i];
+        __syncthreads();
+        if (kt + 1 < kt_end) fetch(kt + 1);
+        if (n0 + nl < N) {
+            uint4 hi, lo;
+            ps_split2(t[kg * 8 + 0][nl] * s, t[kg * 8 + 1][nl] * s, hi.x, lo.x);
+            ps_split2(t[kg * 8 + 2][nl] * s, t[kg * 8 + 3][nl] * s, hi.y, lo.y);
+            ps_split2(t[kg * 8 + 4][nl] * s, t[kg * 8 + 5][nl] * s, hi.z, lo.z);
+            ps_split2(t[kg * 8 + 6][nl] * s, t[kg * 8 + 7][nl] * s, hi.w, lo.w);
+            unsigned char* p = img + (long)(n0 + nl) * pitch + kt * 128 + kg * 16;
+            *reinterpret_cast<uint4*>(p) = hi;
+            *reinterpret_cast<uint4*>(p + 64) = lo;
+        }
+    }
 }
 
 // ---- the product --------------------------------------------------------------------------------------------------------------------
@@ -396,7 +409,7 @@ ams_status ams_ps_pack_rows(const float* x, long ldx, void* img, int R, int K, c
 ams_status ams_ps_pack_cols(const float* w, long ldw, void* img, int K, int N, const float* amax, void* stream) {
     AMS_REQUIRE(w && img && amax && K > 0 && N > 0 && ldw >= N && (((uintptr_t)img) & 15) == 0);
     const unsigned pitch = (unsigned)ams_ps_image_pitch(K);
-    hipLaunchKernelGGL(ps_pack_cols_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)((K + 31) / 32)), dim3(256), 0, (hipStream_t)stream, w, ldw,
+    hipLaunchKernelGGL(ps_pack_cols_kernel, dim3((unsigned)((N + 63) / 64), (unsigned)(((K + 31) / 32 + PS_PC_KT - 1) / PS_PC_KT)), dim3(256), 0, (hipStream_t)stream, w, ldw,
                        (unsigned char*)img, pitch, K, N, amax);
     return ams_check_launch();
 }
