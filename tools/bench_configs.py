@@ -40,6 +40,12 @@ def _time_train(trainer, tfds, L, steps, warmup):
         feed = {tfds.handle: tfds.get_handle(tfds.TRAIN), tfds.chunk_size: L}
         for i in range(warmup):
             c = model.train(feed, i)
+        # a replayed step first measures its two forms (forward products pre-split or split in the product, models/network.py::
+        # _train_graphed) over 192 replays and keeps the faster: untimed, like the capture
+        for i in range(400):
+            if (getattr(model, '_cg_state', None) or {}).get('tune') is None:
+                break
+            c = model.train(feed, warmup)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
