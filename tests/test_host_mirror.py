@@ -322,3 +322,34 @@ def test_keyed_kmeans_seeds_do_not_depend_on_the_number_of_ranks():
     _D.rows = (320, 170)
     parts = [km._draw(r, 20480).numpy() for km, r in zip(kms, _D.rows)]
     assert np.array_equal(np.concatenate(parts), one._draw(490, 20480).numpy())
+
+
+def test_the_forward_product_form_is_decided_by_the_settled_part_of_each_tuning_block(monkeypatch):
+    """models/network.py::_ps_finish_tuning: a captured step replays its two forms in alternating blocks; only the LAST THIRD of a block
+    counts (the clock governor needs tens of milliseconds after the form changes: blocks of 8 steps measured both forms at the slower
+    form's clock and chose wrongly), the medians decide, the other graph is dropped and the decision stays on the model."""
+    import torch
+    from models.network import Network
+    from ams_hip import ops
+
+    class Ev(object):
+        def __init__(self, t):
+            self.t = t
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+    monkeypatch.setattr(torch.cuda, 'synchronize', lambda *a, **k: None)
+    monkeypatch.setattr(Network, '_PS_TUNE_BLOCK', 12)
+    net = Network.__new__(Network)
+
+    def events(settled, unsettled):
+        # steps 0..7 of a block run at the previous form's clock (`unsettled`), steps 8..11 at this form's own
+        return [(i, Ev(0.0), Ev(unsettled if i < 8 else settled)) for i in range(12)] * 2
+    st = {'tune': {'variants': [('gA', 'cA', 'rA'), ('gB', 'cB', 'rB')], 'k': 48, 'ev': (events(2.63, 2.80), events(2.76, 2.60))}}
+    ops.PS_TUNED.clear()
+    net._ps_finish_tuning(st)
+    assert st['graph'] == 'gA' and st['tune'] is None and net._ps_choice is True          # pre-split wins on its settled steps
+    assert ops.PS_TUNED['presplit'] is True and abs(ops.PS_TUNED['ms_presplit'] - 2.63) < 1e-9 and ops.PS_TUNED['steps_counted'] == 8
+    st = {'tune': {'variants': [('gA', 'cA', 'rA'), ('gB', 'cB', 'rB')], 'k': 48, 'ev': (events(2.81, 2.70), events(2.77, 2.90))}}
+    net._ps_finish_tuning(st)
+    assert st['graph'] == 'gB' and net._ps_choice is False and ops.PS_TUNED['presplit'] is False
