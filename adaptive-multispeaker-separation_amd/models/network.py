@@ -384,11 +384,20 @@ class Network(object):
             first = K.PRESPLIT if choice is None else (choice and K.PRESPLIT)
             st['graph'], st['cost'], st['run'] = capture(first)
             st['epoch'], st['tune'] = epoch, None
+            st['twin'] = capture if (K.PS_AUTOTUNE and (K.PS_LAUNCHES[0] > n0 or choice is not None)) else None      # (closes over this capture's static buffers)
             if choice is None and K.PS_AUTOTUNE and first and K.PS_LAUNCHES[0] > n0:
                 # the captured step holds pre-split products: capture its twin without them and let the next steps decide.  Both are
                 # the same arithmetic to the last bits (tests/test_gpu_gemm_ps.py); every tuning step is a real training step.
                 st['tune'] = {'variants': [(st['graph'], st['cost'], st['run']), capture(False)], 'k': 0, 'ev': ([], [])}
         tune = st.get('tune')
+        if (tune is None and self._PS_RETUNE_EVERY > 0 and K.PS_AUTOTUNE and self.__dict__.get('_ps_choice') is not None
+                and st.get('since_tune', 0) >= self._PS_RETUNE_EVERY and st.get('twin') is not None):
+            # a long run asks the question again (what a board's governor allows moves with its temperature): the form that lost is
+            # captured anew and the two are measured as at the start
+            keep = (st['graph'], st['cost'], st['run'])
+            other = st['twin'](not self._ps_choice)
+            st['tune'] = tune = {'variants': [keep, other] if self._ps_choice else [other, keep], 'k': 0, 'ev': ([], [])}
+        st['since_tune'] = 0 if tune is not None else st.get('since_tune', 0) + 1
         if tune is not None:
             v = (tune['k'] // self._PS_TUNE_BLOCK) % 2
             st['graph'], st['cost'], st['run'] = tune['variants'][v]
@@ -412,6 +421,7 @@ class Network(object):
     # steps per block; blocks alternate pre-split / in-product twice; only the last third of a block is counted: the clock governor takes
     # tens of milliseconds to settle after the form changes (blocks of 8 steps measured both forms at the slower form's clock)
     _PS_TUNE_BLOCK = int(os.environ.get('AMS_PS_TUNE_BLOCK', '48'))
+    _PS_RETUNE_EVERY = int(os.environ.get('AMS_PS_RETUNE_EVERY', '50000'))       # replays between two measurements (0 = decide once)
 
     def _ps_finish_tuning(self, st):
         """Median step time (replay + optimizer, device events) of the two captured forms over the counted tuning steps; the faster
@@ -427,7 +437,7 @@ class Network(object):
         st['graph'], st['cost'], st['run'] = tune['variants'][keep]
         st['tune'] = None
         self._ps_choice = (keep == 0)
-        K.PS_TUNED.update(presplit=self._ps_choice, ms_presplit=round(med[0], 4), ms_in_product=round(med[1], 4),
+        K.PS_TUNED.update(presplit=self._ps_choice, ms_presplit=round(med[0], 4), ms_in_product=round(med[1], 4), decisions=K.PS_TUNED.get('decisions', 0) + 1,
                           steps_counted=len([1 for i, a, b in tune['ev'][0] if i >= 2 * self._PS_TUNE_BLOCK // 3]))
 
     def _backward(self, cost):

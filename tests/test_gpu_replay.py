@@ -203,6 +203,7 @@ def test_a_captured_step_measures_both_forms_of_its_forward_products_and_keeps_o
     from ams_hip import ops
     import utils.ops
     monkeypatch.setattr(Network, '_PS_TUNE_BLOCK', 3)
+    monkeypatch.setattr(Network, '_PS_RETUNE_EVERY', 5)         # a long run asks again: here after five replays
     monkeypatch.setattr(ops, 'PS_AUTOTUNE', True)
     ops.PS_TUNED.clear()
     cfg = dict(B=4, L=2048, W=64, N=16, hop=16, layer_size=16, nb_layers=2, E=8, no_summaries=True)
@@ -217,7 +218,7 @@ def test_a_captured_step_measures_both_forms_of_its_forward_products_and_keeps_o
         with g.as_default():
             feed = {tfds.handle: tfds.get_handle(tfds.TRAIN), tfds.chunk_size: cfg['L']}
             tfds.initialize(tfds.TRAIN)
-            for i in range(2 + 12 + 4):                       # two eager steps, four blocks of three tuning replays, four more
+            for i in range(2 + 12 + 5 + 12 + 2):              # two eager steps, 4 x 3 tuning replays, five replays, a second tuning, two more
                 c.append(float(model.train(feed, i)))
                 if graph and i == 6:
                     assert model._cg_state['tune'] is not None and len(model._cg_state['tune']['variants']) == 2
@@ -228,4 +229,5 @@ def test_a_captured_step_measures_both_forms_of_its_forward_products_and_keeps_o
     m = models[1]
     assert m._cg_state['tune'] is None and isinstance(m._ps_choice, bool)
     assert ops.PS_TUNED['presplit'] == m._ps_choice and ops.PS_TUNED['ms_presplit'] > 0 and ops.PS_TUNED['ms_in_product'] > 0
+    assert ops.PS_TUNED['decisions'] == 2                        # decided at the start and once more after _PS_RETUNE_EVERY replays
     assert ops.PRESPLIT                                          # the process-wide default is untouched by a model's choice
