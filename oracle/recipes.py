@@ -93,14 +93,21 @@ def front_finetune_cost(x_mix, x_non_mix, P, hop, nb_layers, E, init_idx, nb_tri
     return loss, out
 
 
-def _enhance_loss_core(X, X_nm, P, nb_layers, E, nb_layers_enh, init_idx, nb_tries, nb_steps, nonlinearity, end_assign, want_grads):
+def _enhance_loss_core(X, X_nm, P, nb_layers, E, nb_layers_enh, init_idx, nb_tries, nb_steps, nonlinearity, end_assign, want_grads,
+                       labels=None, info=None):
     """Shared tail of the *_enhance trainers: DPCL embeddings -> hard k-means masks -> enhance BLSTM stack (network.py:610-660) ->
-    PIT squared error against the non-mix representation (network.py:662-693).  Gradients for the 'enhance/*' variables only."""
+    PIT squared error against the non-mix representation (network.py:662-693).  Gradients for the 'enhance/*' variables only.
+    `info` (a dict) receives the k-means labels; `labels` [B, TF] replaces them (tests/test_gpu_fullstep.py: at 1.3 M points a few
+    float32 embeddings lie within rounding of a cluster boundary; the test counts them, then compares the rest of the step on
+    equal labels)."""
     from . import blstm, dense
     B, T, Fq = X.shape
     S = X_nm.shape[-1]
-    V, _ = step.prediction_fwd(X, P, nb_layers, E)
-    cent, labels, best = kmeans.kmeans(V.reshape(B, T * Fq, E), init_idx, S, nb_tries, nb_steps, assign_at_end=end_assign)
+    if labels is None:
+        V, _ = step.prediction_fwd(X, P, nb_layers, E)
+        cent, labels, best = kmeans.kmeans(V.reshape(B, T * Fq, E), init_idx, S, nb_tries, nb_steps, assign_at_end=end_assign)
+    if info is not None:
+        info['labels'] = labels
     masks = kmeans.masks_from_labels(labels, S, None).astype(X.dtype)
     sep = separate.apply_masks(X, masks)                                    # [B*S, T, F]
     z = separate.enhance_input(sep, X, S, False)                            # [B*S, T, 2F]
@@ -146,11 +153,12 @@ def front_enhance_loss(x_mix, x_non_mix, P, hop, nb_layers, E, nb_layers_enh, in
 
 
 def stft_enhance_loss(x_mix, x_non_mix, P, W, hop, nb_layers, E, nb_layers_enh, init_idx, nb_tries, nb_steps, nonlinearity='softmax',
-                      end_assign=True, want_grads=True):
+                      end_assign=True, want_grads=True, labels=None, info=None):
     """STFT_Separator_enhance_Trainer objective (trainer.py:497-509 -> network.py:505-693): |STFT| -> DPCL -> hard k-means
     masks -> enhance stack -> PIT squared error against the non-mix magnitudes."""
     X, X_nm, _ = stft.stft_preprocessing(x_mix, x_non_mix, W, hop)
-    return _enhance_loss_core(X, X_nm, P, nb_layers, E, nb_layers_enh, init_idx, nb_tries, nb_steps, nonlinearity, end_assign, want_grads)
+    return _enhance_loss_core(X, X_nm, P, nb_layers, E, nb_layers_enh, init_idx, nb_tries, nb_steps, nonlinearity, end_assign, want_grads,
+                              labels=labels, info=info)
 
 
 def _enhance_forward(X, sep, P, S, nb_layers_enh, nonlinearity):

@@ -68,11 +68,13 @@ def front_dpcl_loss(x_mix, x_non_mix, P, hop, nb_layers, E, want_grads=True):
     return cost, prediction_bwd(dV, cache, P, nb_layers), V, Y
 
 
-def stft_dpcl_loss(x_mix, x_non_mix, P, W, hop, nb_layers, E, want_grads=True):
-    """cfg1 STFT_DPCL step."""
+def stft_dpcl_loss(x_mix, x_non_mix, P, W, hop, nb_layers, E, want_grads=True, mask_spectra=None):
+    """cfg1 STFT_DPCL step.  `mask_spectra` [B,T,F,S]: take the arg-max of THESE per-speaker magnitudes for the ideal
+    masks instead of the float64 ones (tests/test_gpu_fullstep.py: at 1.3 M points a few bins hold two speakers within 1e-9 of the
+    largest magnitude, and one label that falls the other way in float32 moves an untrained net's gradient by 1e-3)."""
     B, S, L = x_non_mix.shape
     X, X_nm, _ = stft.stft_preprocessing(x_mix, x_non_mix, W, hop)
-    Y, _ = separate.make_masks(X_nm, 1.0, 0.0)
+    Y, _ = separate.make_masks(X_nm if mask_spectra is None else mask_spectra, 1.0, 0.0)
     V, cache = prediction_fwd(X, P, nb_layers, E)
     T, F = V.shape[1:3]
     Vf, Yf = V.reshape(B, T * F, E), Y.reshape(B, T * F, S)
@@ -101,12 +103,14 @@ def front_l41_loss(x_mix, x_non_mix, I, P, hop, nb_layers, E, normalize=True, wa
     return cost, grads, V, Y
 
 
-def stft_l41_loss(x_mix, x_non_mix, I, P, W, hop, nb_layers, E, normalize=True, want_grads=True, sampling=None, ns_rate=0.1):
+def stft_l41_loss(x_mix, x_non_mix, I, P, W, hop, nb_layers, E, normalize=True, want_grads=True, sampling=None, ns_rate=0.1,
+                  mask_spectra=None):
     """cfg4 STFT_L41 step (trainer.py:468-486 with L41Model): |STFT| magnitudes (network.py:480-502), masks
-    y = one_hot(argmax_s |STFT(x_s)|) with (on, off) = (1, -1) (L41.py:9-10), 3xBLSTM -> Conv1D -> [l2norm], cost L41.py:47-186."""
+    y = one_hot(argmax_s |STFT(x_s)|) with (on, off) = (1, -1) (L41.py:9-10), 3xBLSTM -> Conv1D -> [l2norm], cost L41.py:47-186.
+    `mask_spectra`: as in stft_dpcl_loss."""
     B, S, L = x_non_mix.shape
     X, X_nm, _ = stft.stft_preprocessing(x_mix, x_non_mix, W, hop)
-    Y, _ = separate.make_masks(X_nm, 1.0, -1.0)
+    Y, _ = separate.make_masks(X_nm if mask_spectra is None else mask_spectra, 1.0, -1.0)
     V, cache = prediction_fwd(X, P, nb_layers, E, normalize)
     # --sampling K --ns_method k-nearest (L41.py:91-116): the neighbour sets follow from the speaker table itself
     neg = l41.knearest_indices(P['speaker_centroids'], I, sampling, normalize) if sampling is not None else None
