@@ -53,16 +53,19 @@ def pretrain_loss(x_mix, x_non_mix, P, hop, loss_kind, separation, overlap_coef=
 
 
 def front_separate_infer(x_mix, x_non_mix, P, hop, nb_layers, E, init_idx, nb_tries, nb_steps, beta=None, with_silence=False,
-                         threshold=2.0, end_assign=True):
-    """Front_Separator_Inference (trainer.py:420-434): front -> DPCL embeddings -> k-means masks -> back."""
+                         threshold=2.0, end_assign=True, labels=None):
+    """Front_Separator_Inference (trainer.py:420-434): front -> DPCL embeddings -> k-means masks -> back.  `labels` [B, TF]: use these
+    instead of running k-means (tests/test_gpu_fullstep.py compares the synthesis on equal labels after counting the unequal ones)."""
     B, S, L = x_non_mix.shape
     y = step.front_rep(x_mix, x_non_mix, P, hop)
     X, _ = separate.split_front(y, B, S)
-    V, _ = step.prediction_fwd(X, P, nb_layers, E)
     T, Fq = X.shape[1:]
-    emb = V.reshape(B, T * Fq, E)
-    w = separate.kmeans_silence_weights(np.abs(X), threshold) if with_silence else None
-    cent, labels, best = kmeans.kmeans(emb, init_idx, S, nb_tries, nb_steps, beta=beta, notsilent=w, assign_at_end=end_assign)
+    V = None
+    if labels is None:
+        V, _ = step.prediction_fwd(X, P, nb_layers, E)
+        emb = V.reshape(B, T * Fq, E)
+        w = separate.kmeans_silence_weights(np.abs(X), threshold) if with_silence else None
+        cent, labels, best = kmeans.kmeans(emb, init_idx, S, nb_tries, nb_steps, beta=beta, notsilent=w, assign_at_end=end_assign)
     masks = kmeans.masks_from_labels(labels, S, beta).astype(X.dtype)
     sep = separate.apply_masks(X, masks)
     f2 = front.front_filter(P['back/window/value'], P['back/bases/value'])
