@@ -26,6 +26,14 @@ static inline ams_status ams_check_launch() {
 
 static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// csrc/gemm_ps.hip, used by csrc/gemm.hip (ams_front_maxpool_fwd): the stride-1 conv + max-pool partial on pre-split images
+namespace ams_detail {
+size_t conv_maxpool_ps_bytes(int Bt, int L, int W, int N);
+bool conv_maxpool_ps_applies(int Bt, int L, int W, int N);
+ams_status conv_maxpool_ps(const float* x, const float* f, float* pmax, int32_t* pidx, int Bt, int L, int W, int N, int pl,
+                           const float* amax_x, const float* amax_f, void* img, hipStream_t st);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

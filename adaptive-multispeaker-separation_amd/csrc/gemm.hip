@@ -2145,6 +2145,13 @@ __global__ void pad_rows_kernel(const float* __restrict__ x, float* __restrict__
 
 inline int maxpool_padded_len(int L, int W) { return (L + W + 3 + 3) / 4 * 4; }
 
+// AMS_MAXPOOL_PS=0 (read once): path B's product cuts its operands inside the kernel (gemm_x6_kernel<A_FRAMES, .., EPI_MAXPOOL>) also where
+// the pre-split form applies (A/B runs; tests hold both)
+inline bool maxpool_ps() {
+    static const bool v = !(getenv("AMS_MAXPOOL_PS") && atoi(getenv("AMS_MAXPOOL_PS")) == 0);
+    return v;
+}
+
 }  // namespace
 
 extern "C" {
@@ -2155,7 +2162,10 @@ size_t ams_front_maxpool_workspace_bytes(int Bt, int L, int N) {
 // with room for the zero-padded copy of the signals (enables the branch-free 16-byte operand fetch of the stride-1 product)
 size_t ams_front_maxpool_workspace_bytes_w(int Bt, int L, int N, int W) {
     const size_t base = (ams_front_maxpool_workspace_bytes(Bt, L, N) + 15) / 16 * 16;
-    return base + (size_t)Bt * maxpool_padded_len(L, W) * sizeof(float);
+    size_t n = base + (size_t)Bt * maxpool_padded_len(L, W) * sizeof(float);
+    // the operand images of the pre-split form (csrc/gemm_ps.hip: eight shifted copies of the signals, the filter's image)
+    if (maxpool_ps() && ams_detail::conv_maxpool_ps_applies(Bt, L, W, N)) n = (n + 255) / 256 * 256 + ams_detail::conv_maxpool_ps_bytes(Bt, L, W, N);
+    return n;
 }
 
 // Path B front: y [Bt,T,N], argmax int64 [Bt,T,N], T = (L-P)/hop + 1   (reference models/adapt.py:115-117)
@@ -2185,6 +2195,14 @@ ams_status ams_front_maxpool_fwd(const float* x, const float* f, float* y, long 
         g.group_m = 1;
         const size_t base = (ams_front_maxpool_workspace_bytes(Bt, L, N) + 15) / 16 * 16;
         const int Lp = maxpool_padded_len(L, W);
+        const size_t ps_off = (base + (size_t)Bt * Lp * sizeof(float) + 255) / 256 * 256;
+        if (use_x6() && mp_aa && mp_ab && tuning().f16x3 && maxpool_ps() && aligned16(f) && ((uintptr_t)ws & 255) == 0 &&
+            ams_detail::conv_maxpool_ps_applies(Bt, L, W, N) && ws_bytes >= ps_off + ams_detail::conv_maxpool_ps_bytes(Bt, L, W, N)) {
+            // fp16x3 from operand images cut once per launch: the signals as eight shifted copies (consecutive stride-1 frames are the same
+            // samples moved by one: csrc/gemm_ps.hip), the filter as a PS32 image; LDS-DMA main loop, the same fused max-pool partial
+            const ams_status r = ams_detail::conv_maxpool_ps(x, f, g.C, g.pidx, Bt, L, W, N, pl, mp_aa, mp_ab, (char*)ws + ps_off, st);
+            if (r != AMS_OK) return r;
+        } else
         if (g.b_vec && W % 4 == 0 && ws_bytes >= base + (size_t)Bt * Lp * sizeof(float) && !tuning().novec) {
             // stride-1 frames are not 16-byte aligned and would straddle the zero padding: run the product on a padded copy,
             // where every 4-tap fetch is one unconditional (dword-aligned) 16-byte load

@@ -132,6 +132,38 @@ __global__ __launch_bounds__(256) void ps_pack_cols_kernel(const float* __restri
     }
 }
 
+// Stride-1 frames (path B of the front end, models/adapt.py:115-117): row (s, p) of the product's A operand is the window
+// xp[p .. p + W) of the zero-padded signal xp[i] = x[s, i - pl].  Consecutive rows are the same samples moved by ONE, so no image with
+// 16-byte pieces serves them all -- but EIGHT do: copy c holds the pieces  piece t = xp[c + 8 t .. c + 8 t + 8)  (a plane of fp16 hi, a
+// piece of fp16 lo beside it), and row p is pieces (p >> 3) + 0, 1, 2, ... of copy p & 7: 16-byte aligned, contiguous along k.  A k-tile of a
+// row is then 4 consecutive (hi, lo) piece pairs -- the eight pieces of a PS32 line in another order, so the product
+// kernel's LDS image, fragment reads and MFMA stream are those of gemm_ps_kernel; only the source address of a piece differs.
+// Layout: img [8 copies][R signals][lpp pieces][hi | lo] of 16 bytes (a row's k-tile: 128 contiguous bytes h0 l0 h1 l1 h2 l2 h3 l3); 8 x the signals' bytes (132 MB at 192 x 20480): L2 / MALL traffic
+// only, the samples a tile needs from all copies are 9 KB.  One thread per piece pair.
+__global__ __launch_bounds__(256) void ps_pack_conv_kernel(const float* __restrict__ x, unsigned char* __restrict__ img, int R, int L, int pl,
+                                                           unsigned lpp, const float* __restrict__ amax) {
+    const long id = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per_copy = (long)R * lpp;
+    if (id >= 8 * per_copy) return;
+    const int c = (int)(id / per_copy);
+    const long rem = id - (long)c * per_copy;
+    const int sgn = (int)(rem / lpp), t = (int)(rem - (long)sgn * lpp);
+    const float s = ps_scale(amax[0]);
+    const float* row = x + (long)sgn * L;
+    const int i0 = c + 8 * t - pl;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const int i = i0 + j; v[j] = (i >= 0 && i < L) ? row[i] : 0.f; }
+    uint4 hi, lo;
+    ps_split2(v[0] * s, v[1] * s, hi.x, lo.x);
+    ps_split2(v[2] * s, v[3] * s, hi.y, lo.y);
+    ps_split2(v[4] * s, v[5] * s, hi.z, lo.z);
+    ps_split2(v[6] * s, v[7] * s, hi.w, lo.w);
+    unsigned char* p = img + (((long)c * R + sgn) * lpp + t) * 32;
+    *reinterpret_cast<uint4*>(p) = hi;
+    *reinterpret_cast<uint4*>(p + 16) = lo;
+}
+
 // ---- the product --------------------------------------------------------------------------------------------------------------------
 struct PsArgs {
     const unsigned char* A; const unsigned char* B; float* C; const float* bias;
@@ -140,6 +172,10 @@ struct PsArgs {
     long ldc;
     unsigned pitch_a, pitch_b;
     int tiles_m, tiles_n, group_m;
+    // CONV (stride-1 frames of R signals of L positions, csrc/gemm.hip: ams_front_maxpool_fwd): row m = (signal m / L, position m % L) of
+    // the operand is the window xp[p .. p + K) of the zero-padded signal; A is the "shifted-copies" image of ps_pack_conv_kernel
+    int conv_L, conv_R; unsigned conv_lpp; long a_bytes;
+    int32_t* pidx;             // CONV: per (row tile, column) arg-max row, beside the maxima in C (the fused max-pool partial)
 };
 
 // position `item` of the flat order -> tile: XCD x (workgroups x, x + 8, ...) owns a contiguous run of the band order (bands of
@@ -168,6 +204,7 @@ __device__ long long g_ps_stamp[1024 * 8 * 8];
 #define PS_STAMP(ph) do { } while (0)
 #endif
 
+template <bool CONV>
 __global__ __launch_bounds__(PS_NT, 1) void gemm_ps_kernel(const PsArgs g) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char ps_smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -188,7 +225,7 @@ __global__ __launch_bounds__(PS_NT, 1) void gemm_ps_kernel(const PsArgs g) {
         r.z = __builtin_amdgcn_readfirstlane(r.z); r.w = __builtin_amdgcn_readfirstlane(r.w);
         return r;
     };
-    const i32x4_t rsA = rsrc(g.A, (long)g.M * g.pitch_a), rsB = rsrc(g.B, (long)g.N * g.pitch_b);
+    const i32x4_t rsA = rsrc(g.A, CONV ? g.a_bytes : (long)g.M * g.pitch_a), rsB = rsrc(g.B, (long)g.N * g.pitch_b);
     const i32x4_t rsBias = rsrc(reinterpret_cast<const unsigned char*>(g.bias), g.bias ? (long)g.N * 4 : 0);       // no bias: every load out of range = 0
 
     // DMA roles: one wave-wide 16-byte piece load = 8 rows x 128 B.  Wave w moves A rows 16 w .. 16 w + 15 (2 loads) and B rows
@@ -212,8 +249,21 @@ __global__ __launch_bounds__(PS_NT, 1) void gemm_ps_kernel(const PsArgs g) {
     auto setup = [&](int i) {
         ps_locate(g, (int)blockIdx.x + i * G, tile_m, tile_n);
         m0 = tile_m * PS_BM; n0 = tile_n * PS_BN;
+        if constexpr (CONV) {
+            // row m = (signal m / L, position p): piece (dslot ^ f(row)) of its k-tile 0 = piece (p >> 3) + (that & 3) of plane (that >> 2)
+            // of copy p & 7.  L % 128 == 0: a tile's rows are one signal's; rows past M: out of range -> zeros
+            const int sgn = m0 / g.conv_L, pb = m0 - sgn * g.conv_L;
 #pragma unroll
-        for (int q = 0; q < 2; ++q) voffA[q] = (unsigned)(m0 + (2 * wave + q) * 8 + drow) * g.pitch_a + (q ? pa_odd : pa_even);
+            for (int q = 0; q < 2; ++q) {
+                const int p = pb + (2 * wave + q) * 8 + drow;
+                const unsigned pc = (q ? pa_odd : pa_even) >> 4;
+                const unsigned off = ((((unsigned)(p & 7) * (unsigned)g.conv_R + (unsigned)sgn) * g.conv_lpp + (unsigned)(p >> 3) + (pc & 3u)) * 2u + (pc >> 2)) * 16u;
+                voffA[q] = (m0 + (2 * wave + q) * 8 + drow < g.M) ? off : 0xfffffff0u;
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) voffA[q] = (unsigned)(m0 + (2 * wave + q) * 8 + drow) * g.pitch_a + (q ? pa_odd : pa_even);
+        }
 #pragma unroll
         for (int q = 0; q < 4; ++q) voffB[q] = (unsigned)(n0 + (4 * wave + q) * 8 + drow) * g.pitch_b + ((q & 1) ? pa_odd : pa_even);
     };
@@ -226,7 +276,7 @@ __global__ __launch_bounds__(PS_NT, 1) void gemm_ps_kernel(const PsArgs g) {
         const bool isA = q < 2;
         const unsigned ld = lds0 + (unsigned)(stage * PS_STAGE + (isA ? (2 * wave + q) * 1024 : PS_A_BYTES + (4 * wave + q - 2) * 1024));
         const unsigned vo = isA ? voffA[q] : voffB[q - 2];
-        const int ko = kt * 128;
+        const int ko = kt * 128;                                    // (CONV: a k-tile of a row is 4 (hi, lo) piece pairs: 128 bytes as well)
         unsigned keep;
         if (isA)
             asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
@@ -348,6 +398,45 @@ __global__ __launch_bounds__(PS_NT, 1) void gemm_ps_kernel(const PsArgs g) {
             issue(0, 0);                                // the next tile's first k-tile is in flight before this tile's stores
             issue_bias((wi + 1) & 1);
         }
+        if constexpr (CONV) {
+            // Fused max-pool partial (csrc/gemm.hip: maxpool_epilogue): the [R, L, N] conv output is never written; the tile emits, per
+            // column, its maximum over the 128 rows and the row that holds it (first maximum wins ties)
+            float* const sred = reinterpret_cast<float*>(ps_smem + PS_STAGE);          // [4 wn][2 j][32] values, then rows
+            int* const srow = reinterpret_cast<int*>(sred + 256);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float best = -3.4e38f;
+                int brow = 0x7fffffff;
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const f32x16 c = (acc[i][j] + accs[i][j]) * sc_inv;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = em0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lk;
+                        const float v = c[r];
+                        if (row < g.M && (v > best || (v == best && row < brow))) { best = v; brow = row; }
+                    }
+                }
+                const float ob = __shfl_xor(best, 32, 64);
+                const int orow = __shfl_xor(brow, 32, 64);
+                if (ob > best || (ob == best && orow < brow)) { best = ob; brow = orow; }
+                if (wm == 1 && lk == 0) { sred[(wn * 2 + j) * 32 + l31] = best; srow[(wn * 2 + j) * 32 + l31] = brow; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (wm == 0 && lk == 0) {
+                    const float ob2 = sred[(wn * 2 + j) * 32 + l31];
+                    const int or2 = srow[(wn * 2 + j) * 32 + l31];
+                    if (ob2 > best || (ob2 == best && or2 < brow)) { best = ob2; brow = or2; }
+                    const int col = en0 + wn * 64 + j * 32 + l31;
+                    if (col < g.N) { g.C[(long)(em0 / PS_BM) * g.N + col] = best; g.pidx[(long)(em0 / PS_BM) * g.N + col] = brow; }
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            PS_STAMP(2);
+            if (more && nk > 1) issue(1, 1);            // (the last __syncthreads: the scratch has been read)
+            continue;
+        }
         // Epilogue (C/D layout of a 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)): each wave turns its
         // 64-column band round in a private 8 KB patch of stages 1..2, 32 rows at a time, and stores float4 rows (csrc/gemm.hip)
         float* const wl = reinterpret_cast<float*>(ps_smem + PS_STAGE) + wave * 2048;
@@ -426,13 +515,59 @@ ams_status ams_gemm_ps(int M, int N, int K, const void* A_img, const void* B_img
     g.tiles_m = (M + PS_BM - 1) / PS_BM; g.tiles_n = (N + PS_BN - 1) / PS_BN;
     g.group_m = ps_group_m(g.tiles_m, g.tiles_n);
     static const int cus = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; return n; }();
-    static const bool raised = [] { return hipFuncSetAttribute((const void*)gemm_ps_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS) == hipSuccess; }();
+    static const bool raised = [] { return hipFuncSetAttribute((const void*)gemm_ps_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS) == hipSuccess; }();
     if (!raised) return AMS_E_LAUNCH_FAILED;
     const int items = g.tiles_m * g.tiles_n;
     int grid = items < cus ? items : cus;
     if (grid >= 8) grid -= grid % 8;                    // a workgroup's items stay on one XCD (ps_locate)
-    hipLaunchKernelGGL(gemm_ps_kernel, dim3((unsigned)grid), dim3(PS_NT), PS_LDS, (hipStream_t)stream, g);
+    hipLaunchKernelGGL(gemm_ps_kernel<false>, dim3((unsigned)grid), dim3(PS_NT), PS_LDS, (hipStream_t)stream, g);
     return ams_check_launch();
 }
 
 }  // extern "C"
+
+// ---- path B of the front end on pre-split images (called by csrc/gemm.hip: ams_front_maxpool_fwd; not an entry point of its own) -----------
+namespace ams_detail {
+
+// pieces of 16 bytes per signal and plane of the shifted-copies image: the last row's last k-tile ends at piece (L - 1) / 8 + 4 nk - 1
+static inline unsigned conv_lpp(int L, int W) { return (unsigned)((L - 1) / 8 + 4 * ((W + 31) / 32) + 1); }
+
+__attribute__((visibility("hidden"))) size_t conv_maxpool_ps_bytes(int Bt, int L, int W, int N) {
+    const size_t a = (size_t)8 * 2 * Bt * conv_lpp(L, W) * 16, b = ams_ps_image_bytes(N, W);
+    return (a + 255) / 256 * 256 + (b + 255) / 256 * 256;
+}
+// the shapes the kernel takes: whole 128-row tiles inside one signal, 32-bit offsets into the images
+__attribute__((visibility("hidden"))) bool conv_maxpool_ps_applies(int Bt, int L, int W, int N) {
+    return L % PS_BM == 0 && N % 4 == 0 && (size_t)8 * 2 * Bt * conv_lpp(L, W) * 16 < ((size_t)1 << 31) - 64 && ams_ps_image_bytes(N, W) < ((size_t)1 << 31);
+}
+
+// tile maxima / rows of  x (*) f  (stride 1, SAME) into pmax / pidx [Bt L / 128, N]; img: conv_maxpool_ps_bytes of scratch, 256-byte aligned
+__attribute__((visibility("hidden"))) ams_status conv_maxpool_ps(const float* x, const float* f, float* pmax, int32_t* pidx, int Bt, int L, int W,
+                                                                 int N, int pl, const float* amax_x, const float* amax_f, void* img,
+                                                                 hipStream_t st) {
+    const unsigned lpp = conv_lpp(L, W);
+    const size_t a_bytes = (size_t)8 * 2 * Bt * lpp * 16;
+    unsigned char* const ia = (unsigned char*)img;
+    unsigned char* const ib = ia + (a_bytes + 255) / 256 * 256;
+    const long pieces = (long)8 * Bt * lpp;
+    hipLaunchKernelGGL(ps_pack_conv_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, x, ia, Bt, L, pl, lpp, amax_x);
+    ams_status r = ams_ps_pack_cols(f, N, ib, W, N, amax_f, st);
+    if (r != AMS_OK) return r;
+    PsArgs g{};
+    g.A = ia; g.B = ib; g.C = pmax; g.pidx = pidx; g.bias = nullptr; g.amax_a = amax_x; g.amax_b = amax_f;
+    g.M = Bt * L; g.N = N; g.K = W; g.ldc = N;
+    g.pitch_a = 0; g.pitch_b = (unsigned)ams_ps_image_pitch(W);
+    g.conv_L = L; g.conv_R = Bt; g.conv_lpp = lpp; g.a_bytes = (long)a_bytes;
+    g.tiles_m = g.M / PS_BM; g.tiles_n = (N + PS_BN - 1) / PS_BN;
+    g.group_m = ps_group_m(g.tiles_m, g.tiles_n);
+    static const int cus = [] { int dev = 0, n = 0; if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256; return n; }();
+    static const bool raised = [] { return hipFuncSetAttribute((const void*)gemm_ps_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, PS_LDS) == hipSuccess; }();
+    if (!raised) return AMS_E_LAUNCH_FAILED;
+    const int items = g.tiles_m * g.tiles_n;
+    int grid = items < cus ? items : cus;
+    if (grid >= 8) grid -= grid % 8;
+    hipLaunchKernelGGL(gemm_ps_kernel<true>, dim3((unsigned)grid), dim3(PS_NT), PS_LDS, st, g);
+    return ams_check_launch();
+}
+
+}  // namespace ams_detail

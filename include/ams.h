@@ -23,7 +23,8 @@
  *                              AMS_GEMM_X6RULE, AMS_GEMM_X6WASTE (tile choice), AMS_X6_PERSIST (0 = one tile per workgroup),
  *                              AMS_GEMM_SPLITS, AMS_GEMM_GROUP_M (split-K / band height overrides), AMS_GEMM_NOVEC (force the dword-fetch
  *                              f32 kernel), AMS_GEMM_NOPRIO, AMS_MAXPOOL_CFG (0 = 128x128 tile for the fused conv + max-pool),
- *                              AMS_GATHER_LDS (0 = register form of ams_gather_filter_grad)
+ *                              AMS_GATHER_LDS (0 = register form of ams_gather_filter_grad), AMS_MAXPOOL_PS (0 = path B's product cuts its operands
+ *                              in the kernel also where the pre-split form applies)
  *   recurrence (lstm*.hip)     AMS_LSTM_RING_X6, AMS_LSTM_RING_F16, AMS_LSTM_RING_BWD_F16 (arithmetic of the rings' recurrent products),
  *                              AMS_LSTM_RING_SAFE (write-through hand-off), AMS_LSTM_RING_CUS (pretend a smaller device: fallback tests),
  *                              AMS_LSTM_XCD, AMS_LSTM_FWD_PIPE (per-step fallback kernels: grid order, fetch pipelining)

@@ -1,5 +1,7 @@
 """GPU: products from pre-split fp16 operand images (csrc/gemm_ps.hip, include/ams.h "PS32") against float64 and against the in-product
 fp16x3 form of ams_gemm_f32 -- same terms, same three products, f32 accumulation: the two differ only in summation order."""
+import os
+
 import numpy as np
 import pytest
 
@@ -145,3 +147,52 @@ def test_the_dma_pipeline_is_race_free_under_memory_pressure():
             bad += int(not torch.equal(out, first))
     torch.cuda.synchronize()
     assert bad == 0, '%d of %d launches differed from the first launch of their shape' % (bad, 40 * len(cases))
+
+
+_MAXPOOL_SCRIPT = r'''
+import os, sys, numpy as np, torch
+sys.path[:0] = [os.environ['AMS_ROOT'], os.path.join(os.environ['AMS_ROOT'], 'adaptive-multispeaker-separation_amd')]
+from ams_hip import pooling
+out = {}
+for Bt, L, W, N, P, hop in ((3, 1024, 64, 16, 128, 128), (2, 2048, 1024, 256, 256, 256), (5, 1280, 100, 40, 128, 128), (1, 4096, 512, 300, 256, 128)):
+    rng = np.random.RandomState(Bt * 1000 + W)
+    x = torch.from_numpy(rng.randn(Bt, L).astype(np.float32)).cuda()
+    x[0, : L // 3] = 0.0                                        # digital silence at the head of a signal (the zero padding continues it)
+    f = torch.from_numpy((rng.randn(W, N) / np.sqrt(W)).astype(np.float32)).cuda()
+    y, am = pooling.front_maxpool_fwd(x, f, P, hop)
+    torch.cuda.synchronize()
+    out['y_%d_%d' % (L, W)] = y.cpu().numpy()
+    out['a_%d_%d' % (L, W)] = am.cpu().numpy()
+    out['w_%d_%d' % (L, W)] = np.array([pooling.load().ams_front_maxpool_workspace_bytes_w(Bt, L, N, W)])
+np.savez(sys.argv[1], **out)
+'''
+
+
+def test_path_b_from_shifted_copy_images_equals_the_in_product_cut(tmp_path):
+    """The stride-1 conv + max-pool partial of path B (models/adapt.py:115-117) on pre-split images (csrc/gemm_ps.hip: the signals as
+    eight shifted copies, LDS-DMA main loop) against the form that cuts its operands inside the product (AMS_MAXPOOL_PS=0; the switch is
+    read once per process, hence two processes): the same three fp16 products of the same terms, every output element accumulated in the
+    same order (measured: identical bits; asserted: pooled values to 2e-6 of the largest, arg-max positions equal but for ties at that
+    level); W = 64 ... 1024, N below / at / above one 256-column tile, W not a multiple of 32, silence at the head
+    of a signal."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / 'maxpool_forms.py'
+    script.write_text(_MAXPOOL_SCRIPT)
+    res = {}
+    for form in ('1', '0'):
+        env = dict(os.environ, AMS_MAXPOOL_PS=form, AMS_ROOT=root)
+        out = tmp_path / ('form%s.npz' % form)
+        subprocess.run([sys.executable, str(script), str(out)], check=True, env=env, timeout=600)
+        res[form] = np.load(out)
+    assert sorted(res['1'].files) == sorted(res['0'].files) and len(res['1'].files) == 12
+    for k in [k for k in res['1'].files if k.startswith('y_')]:
+        y1, y0, a1, a0 = res['1'][k], res['0'][k], res['1']['a' + k[1:]], res['0']['a' + k[1:]]
+        # (the pre-split form asks for room for its images: the process that was to use it did)
+        assert int(res['1']['w' + k[1:]][0]) > int(res['0']['w' + k[1:]][0])
+        top = np.abs(y0).max()
+        assert np.abs(y1 - y0).max() <= 2e-6 * top, (k, np.abs(y1 - y0).max() / top)
+        same = float((a1 == a0).mean())
+        print('path B forms', k, 'max |dy| / max |y| %.2g' % (np.abs(y1 - y0).max() / top), 'arg-max equal %.6f' % same)
+        assert same > 0.999, (k, same)
