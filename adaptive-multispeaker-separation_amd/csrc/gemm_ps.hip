@@ -239,7 +239,12 @@ __global__ __launch_bounds__(PS_NT, 1) void gemm_ps_kernel(const PsArgs g) {
     const int ff = (l31 >> 1) & 7;
     unsigned fa[2], fb[2];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) fa[i] = (unsigned)(((wm * 2 + i) * 32 + l31) * 128 + ((lk ^ ff) * 16));
+    for (int i = 0; i < 2; ++i) {
+        if constexpr (CONV)                         // tile row 64 wm + 32 i + l31 lives in LDS row 64 wm + 8 (l31 & 7) + 4 i + (l31 >> 3), pieces XOR-ed with l31 & 7 (setup)
+            fa[i] = (unsigned)((wm * 64 + 8 * (l31 & 7) + 4 * i + (l31 >> 3)) * 128 + ((lk ^ (l31 & 7)) * 16));
+        else
+            fa[i] = (unsigned)(((wm * 2 + i) * 32 + l31) * 128 + ((lk ^ ff) * 16));
+    }
 #pragma unroll
     for (int j = 0; j < 2; ++j) fb[j] = (unsigned)(PS_A_BYTES + ((wn * 2 + j) * 32 + l31) * 128 + ((lk ^ ff) * 16));
 
@@ -250,15 +255,18 @@ __global__ __launch_bounds__(PS_NT, 1) void gemm_ps_kernel(const PsArgs g) {
         ps_locate(g, (int)blockIdx.x + i * G, tile_m, tile_n);
         m0 = tile_m * PS_BM; n0 = tile_n * PS_BN;
         if constexpr (CONV) {
-            // row m = (signal m / L, position p): piece (dslot ^ f(row)) of its k-tile 0 = piece (p >> 3) + (that & 3) of plane (that >> 2)
-            // of copy p & 7.  L % 128 == 0: a tile's rows are one signal's; rows past M: out of range -> zeros
+            // The eight LDS rows 8 A + d (d = 0 .. 7) one piece load fills hold the tile rows 64 h + 8 d + a (A = 8 h + a): positions
+            // 8 apart, i.e. CONSECUTIVE pieces (p >> 3) of ONE copy (p & 7 = a; L % 128 == 0: a tile's rows are one signal's) -- the load
+            // reads ~350 contiguous bytes instead of eight 128-byte runs in eight copies.  LDS piece slot ^ (A & 7) of the row's k-tile
+            // (mfma fragments: fa) = pair (that & 3), half (that >> 2) of the copy.  Rows past M: out of range -> zeros
             const int sgn = m0 / g.conv_L, pb = m0 - sgn * g.conv_L;
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
-                const int p = pb + (2 * wave + q) * 8 + drow;
-                const unsigned pc = (q ? pa_odd : pa_even) >> 4;
-                const unsigned off = ((((unsigned)(p & 7) * (unsigned)g.conv_R + (unsigned)sgn) * g.conv_lpp + (unsigned)(p >> 3) + (pc & 3u)) * 2u + (pc >> 2)) * 16u;
-                voffA[q] = (m0 + (2 * wave + q) * 8 + drow < g.M) ? off : 0xfffffff0u;
+                const int A_ = 2 * wave + q, a = A_ & 7, row = (A_ >> 3) * 64 + 8 * drow + a;
+                const int p = pb + row;
+                const unsigned pc = (unsigned)(dslot ^ a);
+                const unsigned off = ((((unsigned)a * (unsigned)g.conv_R + (unsigned)sgn) * g.conv_lpp + (unsigned)(p >> 3) + (pc & 3u)) * 2u + (pc >> 2)) * 16u;
+                voffA[q] = (m0 + row < g.M) ? off : 0xfffffff0u;
             }
         } else {
 #pragma unroll
@@ -308,11 +316,19 @@ __global__ __launch_bounds__(PS_NT, 1) void gemm_ps_kernel(const PsArgs g) {
     // piece loads of k-tile kt + 2 (`pre`) go out BETWEEN the groups of four MFMAs, and the fragments of k-step 1 are read behind the
     // first group: issued in one block behind the barrier they kept the matrix pipe idle for ~800 of a k-tile's ~1500 cycles
     // (all eight waves leave the barrier together, so nobody's MFMAs covered anybody's issue slots).
+    // CONV: rows r + 32 of k-tile j ARE rows r of k-tile j + 1 (the same samples), so the fragments of a wave's second row tile become
+    // those of its first row tile one k-tile later: carried in registers, only the second row tile is read from LDS (a quarter of the
+    // kernel's LDS reads)
+    f16x8_t carry[2][2];
+    bool prime = true;
     auto frags = [&](const unsigned char* sb, int ks, f16x8_t (&a)[2][2], f16x8_t (&b)[2][2]) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int p = 0; p < 2; ++p) a[i][p] = *reinterpret_cast<const f16x8_t*>(sb + (fa[i] ^ (unsigned)(ks * 32 + p * 64)));
+            for (int p = 0; p < 2; ++p) {
+                if (CONV && i == 0) a[i][p] = carry[ks][p];
+                else a[i][p] = *reinterpret_cast<const f16x8_t*>(sb + (fa[i] ^ (unsigned)(ks * 32 + p * 64)));
+            }
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -331,6 +347,15 @@ __global__ __launch_bounds__(PS_NT, 1) void gemm_ps_kernel(const PsArgs g) {
         constexpr bool pre = decltype(PRE)::value;
         const unsigned char* const sb = ps_smem + stage * PS_STAGE;
         f16x8_t a0[2][2], b0[2][2], a1[2][2], b1[2][2];
+        if constexpr (CONV) {
+            if (prime) {                                // first k-tile of a tile: the first row tile's fragments come from LDS too
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) carry[ks][p] = *reinterpret_cast<const f16x8_t*>(sb + (fa[0] ^ (unsigned)(ks * 32 + p * 64)));
+                prime = false;
+            }
+        }
         frags(sb, 0, a0, b0);
         __builtin_amdgcn_sched_barrier(0);
         four(accs, a0, b0, 1, 0);
@@ -355,6 +380,10 @@ __global__ __launch_bounds__(PS_NT, 1) void gemm_ps_kernel(const PsArgs g) {
         if constexpr (pre) { issue1(kt2, stage2, 4); issue1(kt2, stage2, 5); }
         __builtin_amdgcn_sched_barrier(0);
         four(acc, a1, b1, 0, 0);
+        if constexpr (CONV) {
+#pragma unroll
+            for (int p = 0; p < 2; ++p) { carry[0][p] = a0[1][p]; carry[1][p] = a1[1][p]; }
+        }
     };
 
     setup(0);
@@ -369,6 +398,7 @@ __global__ __launch_bounds__(PS_NT, 1) void gemm_ps_kernel(const PsArgs g) {
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { acc[i][j][r] = 0.f; accs[i][j][r] = 0.f; }
+        prime = true;
         int st = 0;
         for (int kt = 0; kt < nk - 2; ++kt) {
             // this wave's six loads of tile kt are older than the six of tile kt + 1: vmcnt(6) retires them (and everything older: the
