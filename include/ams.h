@@ -76,8 +76,11 @@ ams_status ams_front_conv_bwd_filter(const float* x, const float* dy, float* df,
  * argmax int64 = l*N + n (no batch term).  Sparse (unpool-free) synthesis and gather-form filter
  * gradients (models/adapt.py:210-243, utils/ops.py:94-120). ---- */
 size_t ams_front_maxpool_workspace_bytes(int Bt, int L, int N);
-size_t ams_front_maxpool_workspace_bytes_w(int Bt, int L, int N, int W);   /* + room for the zero-padded signal copy (faster product) */
-/* amax_x / amax_f (optional, both or neither): device pointers to upper bounds of max |x|, max |f| -> the product runs as fp16x3 */
+size_t ams_front_maxpool_workspace_bytes_w(int Bt, int L, int N, int W);   /* + room for the zero-padded signal copy (faster product) and, where
+ * the pre-split form applies (L % 128 == 0, N % 4 == 0), for its operand images: eight shifted fp16 hi | lo copies of the signals = 8 x their
+ * bytes (csrc/gemm_ps.hip).  ws must then be 256-byte aligned, else the launch cuts its operands inside the product as before */
+/* amax_x / amax_f (optional, both or neither): device pointers to upper bounds of max |x|, max |f| -> the product runs as fp16x3 (with the
+ * larger workspace: from images cut once per launch; both forms give the same bits) */
 ams_status ams_front_maxpool_fwd(const float* x, const float* f, float* y, long long* argmax, int Bt, int L, int W, int N, int P, int hop,
                                  const float* amax_x, const float* amax_f, void* ws, size_t ws_bytes, void* stream);
 /* the sparse kernels take int32 sample positions (argmax / N, converted once) and the synthesis filter TRANSPOSED, f2t [N, W] */
