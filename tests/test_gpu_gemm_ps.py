@@ -154,7 +154,8 @@ import os, sys, numpy as np, torch
 sys.path[:0] = [os.environ['AMS_ROOT'], os.path.join(os.environ['AMS_ROOT'], 'adaptive-multispeaker-separation_amd')]
 from ams_hip import pooling
 out = {}
-for Bt, L, W, N, P, hop in ((3, 1024, 64, 16, 128, 128), (2, 2048, 1024, 256, 256, 256), (5, 1280, 100, 40, 128, 128), (1, 4096, 512, 300, 256, 128)):
+for Bt, L, W, N, P, hop in ((3, 1024, 64, 16, 128, 128), (2, 2048, 1024, 256, 256, 256), (5, 1280, 100, 40, 128, 128), (1, 4096, 512, 300, 256, 128),
+                            (1, 128, 16, 4, 128, 128), (2, 256, 33, 8, 128, 128), (7, 384, 96, 260, 128, 128)):
     rng = np.random.RandomState(Bt * 1000 + W)
     x = torch.from_numpy(rng.randn(Bt, L).astype(np.float32)).cuda()
     x[0, : L // 3] = 0.0                                        # digital silence at the head of a signal (the zero padding continues it)
@@ -173,8 +174,8 @@ def test_path_b_from_shifted_copy_images_equals_the_in_product_cut(tmp_path):
     eight shifted copies, LDS-DMA main loop) against the form that cuts its operands inside the product (AMS_MAXPOOL_PS=0; the switch is
     read once per process, hence two processes): the same three fp16 products of the same terms, every output element accumulated in the
     same order (measured: identical bits; asserted: pooled values to 2e-6 of the largest, arg-max positions equal but for ties at that
-    level); W = 64 ... 1024, N below / at / above one 256-column tile, W not a multiple of 32, silence at the head
-    of a signal."""
+    level); W = 16 ... 1024 (one k-tile, two, W not a multiple of 32), N = 4 ... 300 (below / at / above one 256-column tile), one tile per
+    signal, silence at the head of a signal."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -186,7 +187,7 @@ def test_path_b_from_shifted_copy_images_equals_the_in_product_cut(tmp_path):
         out = tmp_path / ('form%s.npz' % form)
         subprocess.run([sys.executable, str(script), str(out)], check=True, env=env, timeout=600)
         res[form] = np.load(out)
-    assert sorted(res['1'].files) == sorted(res['0'].files) and len(res['1'].files) == 12
+    assert sorted(res['1'].files) == sorted(res['0'].files) and len(res['1'].files) == 21
     for k in [k for k in res['1'].files if k.startswith('y_')]:
         y1, y0, a1, a0 = res['1'][k], res['0'][k], res['1']['a' + k[1:]], res['0']['a' + k[1:]]
         # (the pre-split form asks for room for its images: the process that was to use it did)
