@@ -179,6 +179,7 @@ WORKLOADS = {
     'pretraining_A': lambda s, w: wl_pretraining(s, w, False),
     'pretraining_A_graph': lambda s, w: wl_pretraining(s, max(w, 4), False, graph=True),
     'pretraining_B_maxpool': lambda s, w: wl_pretraining(s, w, True),
+    'pretraining_B_maxpool_graph': lambda s, w: wl_pretraining(s, max(w, 4), True, graph=True),
     'front_DPCL_finetuning': wl_front_dpcl_finetuning,
     'front_DPCL_finetuning_graph': lambda s, w: wl_front_dpcl_finetuning(s, max(w, 4), graph=True),
     'front_DPCL_inference': wl_front_dpcl_inference,
