@@ -197,3 +197,35 @@ def test_path_b_from_shifted_copy_images_equals_the_in_product_cut(tmp_path):
         same = float((a1 == a0).mean())
         print('path B forms', k, 'max |dy| / max |y| %.2g' % (np.abs(y1 - y0).max() / top), 'arg-max equal %.6f' % same)
         assert same > 0.999, (k, same)
+
+
+def test_path_b_pipeline_is_race_free_under_memory_pressure():
+    """The same screen for the conv variant of the kernel (shifted-copy images, fragments carried in registers from one k-tile to the
+    next, piece loads that fill LDS rows 8 tile rows apart): launches of three shapes while another stream thrashes HBM and the L2 --
+    pooled values and arg-max of every launch equal the first launch's bit for bit, and the first launch the float64 conv."""
+    from ams_hip import pooling
+    from oracle import front as ofront
+    rng = np.random.RandomState(21)
+    cases = []
+    for Bt, L, W, N, P, hop in ((8, 4096, 1024, 256, 256, 256), (3, 2048, 96, 40, 128, 128), (16, 1024, 512, 260, 128, 128)):
+        x = rng.randn(Bt, L).astype(np.float32)
+        f = (rng.randn(W, N) / np.sqrt(W)).astype(np.float32)
+        xd, fd = dev(x), dev(f)
+        y0, a0 = pooling.front_maxpool_fwd(xd, fd, P, hop)
+        torch.cuda.synchronize()
+        y_ref, a_ref = ofront.front_maxpool(x[:1].astype(np.float64), f.astype(np.float64), P, hop)
+        assert np.abs(y0[:1].cpu().numpy() - y_ref).max() <= 2e-5 * np.abs(y_ref).max()
+        assert float((a0[:1].cpu().numpy() == a_ref).mean()) > 0.999
+        cases.append((xd, fd, P, hop, y0.clone(), a0.clone()))
+    noise_stream = torch.cuda.Stream()
+    big = torch.empty(64 * 1024 * 1024, device='cuda')
+    bad = 0
+    for rep in range(25):
+        with torch.cuda.stream(noise_stream):
+            big.add_(1.0)
+            big.mul_(0.5)
+        for xd, fd, P, hop, y0, a0 in cases:
+            y, a = pooling.front_maxpool_fwd(xd, fd, P, hop)
+            bad += int(not (torch.equal(y, y0) and torch.equal(a, a0)))
+    torch.cuda.synchronize()
+    assert bad == 0, '%d of %d launches differed from the first launch of their shape' % (bad, 25 * len(cases))
