@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get('AMS_HIP_LIB') or os.path.join(_HERE, 'libams_hip.so')   # env: kernel-variant A/B runs
 HEADER_PATH = os.path.normpath(os.path.join(_HERE, '..', '..', 'include', 'ams.h'))
 
-ABI_VERSION = 4            # include/ams.h: AMS_ABI_VERSION
+ABI_VERSION = 5            # include/ams.h: AMS_ABI_VERSION
 
 _CT = {
     'int': ctypes.c_int, 'long': ctypes.c_long, 'float': ctypes.c_float, 'size_t': ctypes.c_size_t,

@@ -47,4 +47,6 @@ def soft_bwd(xn, inv, init_idx, best, w, trace, dsel, dout, C, tries, iterations
     idx_sel = (init_idx if index is None else init_idx[index]).to(torch.int32).contiguous()      # [b, C]
     check(lib.ams_kmeans_soft_bwd(p(xn), p(wsel), p(w_final), p(cst), p(dst), p(dsel_c), p(dout_c), p(inv), p(inv0), p(idx_sel), p(dxn), p(g),
                                   b, L, E, C, float(beta), iterations, p(ws), nb, s()), 'ams_kmeans_soft_bwd')
-    return dxn
+    # the pass that wrote dx left max |dx| in the workspace (ABI 5): the bound of the dense layer's two gradient products
+    off = lib.ams_kmeans_soft_bwd_amax_offset(b, L, E, C, iterations) // 4
+    return ops.tag_amax(dxn, ws[off:off + 1])

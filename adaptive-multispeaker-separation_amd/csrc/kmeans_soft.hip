@@ -55,6 +55,7 @@ struct KsArgs {
     float* rec;         // [b, n_it + 1, N]
     float* G;           // [n_it + 1, b, C*E]
     unsigned* ticket;   // [b]
+    unsigned* amax;     // max |dx| as float bits (ams_kmeans_soft_bwd_amax_offset): cleared by ks_init_kernel, folded by ks_dx_kernel / ks_seed_kernel
     long L; int b, n_it, nG, spw; float beta;      // nG chunks per utterance, spw slabs of 256 points per workgroup
 };
 
@@ -72,6 +73,7 @@ __global__ void ks_init_kernel(KsArgs a) {
     }
     for (int i = tid; i < R::CE; i += blockDim.x) a.G[((long)a.n_it * a.b + r) * R::CE + i] = a.dsel ? a.dsel[(long)r * R::CE + i] : 0.f;
     if (tid == 0) a.ticket[r] = 0u;
+    if (tid == 0 && r == 0) *a.amax = 0u;
 }
 
 // softmax labels and d/d(d2) of one point for one constants record.  FINAL: dlab comes from dout, no dnum / dden.
@@ -268,6 +270,7 @@ __global__ __launch_bounds__(256) void ks_dx_kernel(KsArgs a, int chunks_per_wg)
     const float* wb = a.w ? a.w + (long)r * a.L : nullptr;
     const float* wf = a.w_final ? a.w_final + (long)r * a.L : nullptr;
     ks_cfloat* rec0 = ks_const(a.rec + (long)r * (a.n_it + 1) * R::N);
+    float amax_l = 0.f;                                         // max |dx| of the rows this thread wrote (the bound of the products that read dx)
     for (int s = 0; s < chunks_per_wg; ++s) {
         const long p0 = ((long)blockIdx.x * chunks_per_wg + s) * 256;
         if (p0 >= a.L) break;
@@ -370,6 +373,8 @@ __global__ __launch_bounds__(256) void ks_dx_kernel(KsArgs a, int chunks_per_wg)
 #pragma unroll
             for (int q = 0; q < V4; ++q)
                 *reinterpret_cast<float4*>(&buf[tid * LD + q * 4]) = make_float4(dxl[2 * q][0], dxl[2 * q][1], dxl[2 * q + 1][0], dxl[2 * q + 1][1]);
+#pragma unroll
+            for (int q = 0; q < E_ / 2; ++q) amax_l = fmaxf(amax_l, fmaxf(fabsf(dxl[q][0]), fabsf(dxl[q][1])));
         }
         __syncthreads();
         {
@@ -384,6 +389,10 @@ __global__ __launch_bounds__(256) void ks_dx_kernel(KsArgs a, int chunks_per_wg)
             }
         }
     }
+    // one atomic per wave (a NaN in dx is dropped by fmaxf here and reaches the products through dx itself)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amax_l = fmaxf(amax_l, __shfl_xor(amax_l, o, 64));
+    if ((tid & 63) == 0) atomicMax(a.amax, __float_as_uint(amax_l));
 }
 
 // c_0 = xn[seed]: the remaining centroid gradient g0 goes onto the rows it was picked from (the C picks of an utterance are distinct --
@@ -407,7 +416,12 @@ __global__ void ks_seed_kernel(KsArgs a) {
             gv = (gv - vv * wave_sum(vv * gv)) * a.inv0[(long)r * a.L + row];
         }
     }
-    if (lane < E_) d[lane] += gv;
+    float nv = 0.f;
+    if (lane < E_) { nv = d[lane] + gv; d[lane] = nv; }
+    nv = fabsf(nv);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nv = fmaxf(nv, __shfl_xor(nv, o, 64));
+    if (lane == 0) atomicMax(a.amax, __float_as_uint(nv));
 }
 
 template <int E_, int C_>
@@ -441,7 +455,12 @@ size_t ams_kmeans_soft_bwd_workspace_bytes(int b, long L, int E, int C, int n_it
     if (b <= 0 || L <= 0 || E <= 0 || C <= 0 || n_it < 0) return 0;
     const size_t nG = (size_t)ks_chunks(b, L), CE = (size_t)C * E;
     return ks_align((size_t)b * nG * (CE + C) * 4) + ks_align((size_t)b * (n_it + 1) * (2 * CE + 8) * 4) + ks_align((size_t)(n_it + 1) * b * CE * 4) +
-           ks_align((size_t)b * 4);
+           ks_align((size_t)b * 4) + 256;
+}
+// byte offset, inside that workspace, of max |dx| (a float): valid after ams_kmeans_soft_bwd -- the operand bound of the products that read dx
+size_t ams_kmeans_soft_bwd_amax_offset(int b, long L, int E, int C, int n_it) {
+    const size_t n = ams_kmeans_soft_bwd_workspace_bytes(b, L, E, C, n_it);
+    return n ? n - 256 : 0;
 }
 
 // Gradient of the selected try of the unrolled soft k-means w.r.t. the normalised embeddings (Kmeans_2.py:145-188).
@@ -466,7 +485,8 @@ ams_status ams_kmeans_soft_bwd(const float* xn, const float* w, const float* w_f
     a.part = (float*)p; p += ks_align((size_t)b * a.nG * (CE + C) * 4);
     a.rec = (float*)p; p += ks_align((size_t)b * (n_it + 1) * (2 * CE + 8) * 4);
     a.G = (float*)p; p += ks_align((size_t)(n_it + 1) * b * CE * 4);
-    a.ticket = (unsigned*)p;
+    a.ticket = (unsigned*)p; p += ks_align((size_t)b * 4);
+    a.amax = (unsigned*)p;
     hipStream_t st = (hipStream_t)stream;
     if (E == 40 && C == 2) return ks_run<40, 2>(a, st);
     if (E == 40 && C == 3) return ks_run<40, 3>(a, st);

@@ -40,7 +40,7 @@
 extern "C" {
 #endif
 
-#define AMS_ABI_VERSION 4
+#define AMS_ABI_VERSION 5
 
 typedef int32_t ams_status;
 #define AMS_OK 0
@@ -464,8 +464,10 @@ ams_status ams_kmeans_iterate(const float* xn, const float* w, const float* cent
  *   leaves as the gradient w.r.t. u, the Jacobian applied in the pass that holds the point in registers instead of in a pass of its
  *   own; inv0 [b,L] (may be NULL; needs inv): that u was itself normalise(u0) with inv0 = 1/|u0| (ams_l2norm2_fwd: the embedding
  *   network's Normalize layer, models/dpcl.py:32, followed by the k-means' own) -- dx leaves as the gradient w.r.t. u0.
- *   ws: ams_kmeans_soft_bwd_workspace_bytes. */
+ *   ws: ams_kmeans_soft_bwd_workspace_bytes.  ABI 5: the call also leaves max |dx| (a float, at byte ams_kmeans_soft_bwd_amax_offset of
+ *   ws): the operand bound of the dense layer's gradient products, folded by the pass that writes dx instead of a pass over dx. */
 size_t ams_kmeans_soft_bwd_workspace_bytes(int b, long L, int E, int C, int n_it);
+size_t ams_kmeans_soft_bwd_amax_offset(int b, long L, int E, int C, int n_it);
 ams_status ams_kmeans_soft_bwd(const float* xn, const float* w, const float* w_final, const float* cents, const float* dens, const float* dsel,
                                const float* dout, const float* inv, const float* inv0, const int32_t* seed, float* dx, float* g0, int b, long L,
                                int E, int C, float beta, int n_it, void* ws, size_t ws_bytes, void* stream);
