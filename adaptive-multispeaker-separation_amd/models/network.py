@@ -230,6 +230,16 @@ class Network(object):
         F.OVERLAP.enabled = (bool(self.args.get('overlap_weight_grads', True)) and torch.cuda.is_available()
                              and os.environ.get('AMS_OVERLAP', '1') != '0')
         F.OVERLAP.on_ready = opt.bucket_ready if getattr(opt, 'overlap', False) else None
+        # Variables this recipe does NOT train (a restored separator under an enhance stack, a restored front end) are written by nobody
+        # between passes -- the optimizer owns only the trainable ones, and restore_model() / _weights_written() drop what was derived:
+        # what a pass derives from them alone (operand bounds, pre-split images, gathered kernels) is kept across passes as in the
+        # inference recipes (freeze_weights): 13 absmax + fill pairs and 4 image cuts per STFT_L41_enhance step otherwise
+        if os.environ.get('AMS_FREEZE_UNTRAINED', '1') != '0':
+            trained = set(id(v) for v in self.trainable_variables)
+            for v in g.variables.values():
+                if id(v) not in trained:
+                    K.drop_frozen_derivatives(v)
+                    v._ams_frozen = True
         self.optimizer = opt
         self.increment_epoch = opt.increment_epoch
         g.summaries['optimize/learning_rate'] = Node('learning_rate', lambda run: opt.learning_rate())
