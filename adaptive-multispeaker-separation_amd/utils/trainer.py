@@ -187,6 +187,10 @@ class Trainer(object):
         if dist.enabled:
             for v in self.graph.global_variables():
                 dist.broadcast(v.data)
+            # the variables were written behind the model's back: whatever a pass derived from them and kept (bounds, images, gathered
+            # kernels of variables nobody trains; a captured step's constants) is stale
+            from models.network import Network
+            Network._weights_written()
 
     def prepare(self):
         """Everything Trainer.train does before its loop: graph, input pipeline, build(), replica sync."""
