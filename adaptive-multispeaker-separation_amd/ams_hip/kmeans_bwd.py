@@ -36,8 +36,15 @@ def soft_bwd(xn, inv, init_idx, best, w, trace, dsel, dout, C, tries, iterations
     ws = ops._ws(nb, xn)
     p, s = ops._p, ops._s
     w_final = None if assign_at_end else wsel
-    cst = torch.stack(cents).contiguous()                                   # [n_it + 1, b, C, E]
-    dst = torch.stack(dens).contiguous() if iterations else None            # [n_it, b, C]
+    # ops.kmeans_run keeps the trace as slices of two stacked buffers: with one try per utterance they ARE what the call wants
+    def stacked(ts):
+        base = ts[0]._base
+        if (index is None and base is not None and base.is_contiguous() and base.shape[0] == len(ts) and base.shape[1:] == ts[0].shape
+                and all(t._base is base and t.data_ptr() == base[i].data_ptr() for i, t in enumerate(ts))):
+            return base
+        return torch.stack(ts).contiguous()
+    cst = stacked(cents)                                                    # [n_it + 1, b, C, E]
+    dst = stacked(dens) if iterations else None                             # [n_it, b, C]
     dxn = torch.empty_like(xn)
     g = torch.empty((b, C, E), dtype=torch.float32, device=dev)
     dsel_c = dsel.contiguous() if dsel is not None else None

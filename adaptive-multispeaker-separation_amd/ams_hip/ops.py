@@ -1773,13 +1773,17 @@ def kmeans_run(xn, init_idx, C, tries, iterations, beta=None, w=None, assign_at_
     tk = _KM_TICKETS.get((dev.index, torch.cuda.current_stream().cuda_stream))
     if tk is None or tk.numel() < R:
         tk = _KM_TICKETS[(dev.index, torch.cuda.current_stream().cuda_stream)] = torch.zeros(max(R, 1024), dtype=torch.int32, device=dev)
-    cent = torch.empty((R, C, E), dtype=torch.float32, device=dev)
+    # soft: the centroids and denominators of all iterations are slices of TWO stacked buffers -- what the backward pass wants in one
+    # piece (kmeans_bwd.soft_bwd: no torch.stack of 21 small tensors in front of its first launch)
+    cstack = torch.empty((iterations + 1, R, C, E), dtype=torch.float32, device=dev) if not hard else None
+    dstack = torch.empty((max(iterations, 1), R, C), dtype=torch.float32, device=dev) if not hard else None
+    cent = cstack[0] if cstack is not None else torch.empty((R, C, E), dtype=torch.float32, device=dev)
     check(lib.ams_kmeans_init(_p(xn), _p(init_idx), _p(cent), b, tries, L, E, C, _s()), 'ams_kmeans_init')
     trace = [cent]
     wm = 1 if faithful_tile else 0
-    for _ in range(iterations):
-        nxt = torch.empty_like(cent)
-        den = torch.empty((R, C), dtype=torch.float32, device=dev) if not hard else None
+    for it in range(iterations):
+        nxt = cstack[it + 1] if cstack is not None else torch.empty_like(cent)
+        den = dstack[it] if dstack is not None else None
         check(lib.ams_kmeans_iterate(_p(xn), _p(w), _p(cent), _p(nxt), _p(den), b, tries, L, E, C, bval, wm, _p(ws), nb, _p(tk), _s()),
               'ams_kmeans_iterate')
         cent = nxt
