@@ -485,8 +485,10 @@ ams_status ams_kmeans_soft_bwd(const float* xn, const float* w, const float* w_f
     a.part = (float*)p; p += ks_align((size_t)b * a.nG * (CE + C) * 4);
     a.rec = (float*)p; p += ks_align((size_t)b * (n_it + 1) * (2 * CE + 8) * 4);
     a.G = (float*)p; p += ks_align((size_t)(n_it + 1) * b * CE * 4);
-    a.ticket = (unsigned*)p; p += ks_align((size_t)b * 4);
-    a.amax = (unsigned*)p;
+    a.ticket = (unsigned*)p;
+    // (the partial sums above are laid out for the chunk count this launch uses, which may be below the one the size query assumed: the
+    // bound's word is addressed from the END of the workspace, where ams_kmeans_soft_bwd_amax_offset says it is)
+    a.amax = (unsigned*)((char*)ws + ams_kmeans_soft_bwd_amax_offset(b, L, E, C, n_it));
     hipStream_t st = (hipStream_t)stream;
     if (E == 40 && C == 2) return ks_run<40, 2>(a, st);
     if (E == 40 && C == 3) return ks_run<40, 3>(a, st);

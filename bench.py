@@ -306,6 +306,8 @@ def main():
         opt_.exchange_events = None
         ops.raise_on_ring_errors()                       # a ring launch that gave up a bounded wait would make this number meaningless
         last_cost = float(c)
+        if last_cost != last_cost or last_cost in (float('inf'), float('-inf')):
+            raise SystemExit('bench.py: the timed steps ended with cost %r -- a diverged step is not a measurement' % last_cost)
         prof_steps = args.steps
         if args.graph and args.roofline_steps:
             # HIP events recorded during capture cannot be read back after a replay (hipErrorInvalidHandle), so the launches of the

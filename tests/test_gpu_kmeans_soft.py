@@ -43,7 +43,7 @@ def torch_soft_kmeans(X, idx, C, tries, iters, beta, w, end, faithful=True):
 
 
 @pytest.mark.parametrize('b,L,E,C,tries,iters,with_w,end', [(2, 3000, 40, 2, 2, 3, True, True), (2, 2500, 8, 3, 1, 4, True, False),
-                                                              (1, 4200, 40, 2, 1, 2, False, True)])
+                                                              (1, 4200, 40, 2, 1, 2, False, True), (8, 20480, 40, 2, 1, 3, True, True)])
 def test_soft_kmeans_backward(b, L, E, C, tries, iters, with_w, end, monkeypatch):
     from ams_hip import functional as F, ops
     tagged = []
@@ -78,13 +78,18 @@ def test_soft_kmeans_backward(b, L, E, C, tries, iters, with_w, end, monkeypatch
 
 
 @pytest.mark.parametrize('b,L,E,C,tries,iters,with_w,end', [(2, 3000, 40, 2, 1, 3, True, True), (2, 2500, 8, 3, 2, 4, True, False),
-                                                              (1, 4200, 40, 2, 1, 2, False, True), (2, 1111, 20, 2, 1, 2, False, True)])
-def test_soft_kmeans_from_the_unnormalised_embeddings(b, L, E, C, tries, iters, with_w, end):
+                                                              (1, 4200, 40, 2, 1, 2, False, True), (2, 1111, 20, 2, 1, 2, False, True),
+                                                              (8, 20480, 40, 2, 1, 4, True, True)])
+def test_soft_kmeans_from_the_unnormalised_embeddings(b, L, E, C, tries, iters, with_w, end, monkeypatch):
     """A fine-tuning step hands the k-means the embedding network's output BEFORE its Normalize layer (F.kmeans(pre_norm=...)): both
     normalisations in one pass (ams_l2norm2_fwd), both Jacobians in the pass that writes the gradient (ams_kmeans_soft_bwd inv / inv0).
     Forward: the bits of Normalize -> k-means(normalize_input).  Backward: against float64 autograd of the same composition, and close
-    to the two-pass HIP form."""
-    from ams_hip import functional as F
+    to the two-pass HIP form.  The last shape is a fine-tuning step's (8 utterances x 20480 points: the launch uses fewer chunks per
+    utterance than the workspace query assumes -- the word that receives max |dx| must still be where the query says)."""
+    from ams_hip import functional as F, ops
+    tagged = []
+    real_tag = ops.tag_amax
+    monkeypatch.setattr(ops, 'tag_amax', lambda t, a: (tagged.append((t, a)), real_tag(t, a))[1])
     rng = np.random.RandomState(L + C + 1)
     centers = rng.randn(C, E) * 1.5
     U = (centers[rng.randint(0, C, (b, L))] + rng.randn(b, L, E) * 0.8) * np.exp(rng.randn(b, L, 1))      # rows of very different length
@@ -119,3 +124,8 @@ def test_soft_kmeans_from_the_unnormalised_embeddings(b, L, E, C, tries, iters, 
         err = np.abs(g - g_ref).max() / np.abs(g_ref).max()
         assert err < 1e-3, (name, err)
     assert np.abs(f[3] - t[3]).max() / np.abs(t[3]).max() < 1e-5
+    if ops.F16X3:                                       # ABI 5: every soft backward left the bound of the gradient it wrote
+        dxs = [(t_, a_) for t_, a_ in tagged if tuple(t_.shape) == (b, L, E)]
+        assert len(dxs) == 2
+        for t_, a_ in dxs:
+            assert float(a_) == float(t_.abs().max())
