@@ -231,3 +231,31 @@ def test_a_captured_step_measures_both_forms_of_its_forward_products_and_keeps_o
     assert ops.PS_TUNED['presplit'] == m._ps_choice and ops.PS_TUNED['ms_presplit'] > 0 and ops.PS_TUNED['ms_in_product'] > 0
     assert ops.PS_TUNED['decisions'] == 2                        # decided at the start and once more after _PS_RETUNE_EVERY replays
     assert ops.PRESPLIT                                          # the process-wide default is untouched by a model's choice
+
+
+def test_front_dpcl_finetuning_replay_matches_eager():
+    """cfg3(ii) at the model's real size and a SMALL batch (8 utterances x 20480 points: the soft k-means backward then launches fewer
+    chunks per utterance than its workspace query assumes -- the shape at which the word holding max |dx| was once read from the wrong
+    place and the replayed step diverged while every test at 2-3 k points or at B = 64 passed): replayed = eager, all costs finite."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'tools'))
+    import bench_configs as bc
+    from models.dpcl import DPCL
+    from utils.trainer import Front_Separator_Finetuning_Trainer
+    B, L, S, N = 8, 20480, 2, 256
+    tmp = tempfile.mkdtemp(prefix='ams_ft_replay_')
+    tr0, tfds0, a0 = bc._front_dpcl_checkpoint(tmp, DPCL, 'front_DPCL', B, S, L, N)
+    with tr0.graph.as_default():
+        tr0.model.create_saver()
+        tr0.model.save(0)
+        folder = tr0.model._dir()
+    del tr0
+
+    def make(graph):
+        a = dict(a0)
+        a.update(model_folder=folder, nb_tries=1, nb_steps=10, beta_kmeans=10.0, with_silence=True, threshold=2.0, end_assign=True,
+                 loss='sdr+l2', optimizer='RMSProp', learning_rate=1e-4, hip_graph=graph)
+        tr = Front_Separator_Finetuning_Trainer(DPCL, 'front_L41_finetuning', **a)
+        dist, tfds = tr.prepare()
+        return tr, tfds, L
+    _compare(make)
